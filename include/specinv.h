@@ -1,0 +1,155 @@
+/*
+ * specinv.h - C ABI of libspecinv.so, the MI355X (gfx950) spectrogram-inversion engine.
+ *
+ * The reference (yoyololicon/spectrogram-inversion, package torch_specinv) has no FFI of
+ * its own: its hot path is a set of plain Python functions exported at
+ * torch_specinv/__init__.py:6.  This header is the boundary a binding for that path would
+ * use; every entry point names the reference code it replaces (paths relative to the
+ * reference checkout).  The Python host layer in spectrogram_inversion_amd/ binds it with
+ * ctypes and mirrors the reference's function signatures on top.
+ *
+ * Conventions
+ *   - plain C: opaque plan handle, raw pointers, ints/doubles; no exceptions cross the ABI.
+ *   - every function returns 0 on success or a negative SPECINV_E* code; the message for the
+ *     calling thread's last failure is available from specinv_last_error().
+ *   - all data pointers are DEVICE pointers (HIP, the plan's device) unless the parameter
+ *     name ends in _host.  The caller owns them; the plan owns its internal state buffers.
+ *   - spectrogram arguments use the reference's layout: row-major (batch, n_freq, n_frames),
+ *     real (float/double) or complex interleaved (re, im).  Waveforms are (batch, length).
+ *   - work is enqueued on the plan's stream (specinv_plan_set_stream; default: the null
+ *     stream).  Functions that return scalars to the host synchronise that stream.
+ *   - a plan is not thread-safe; different plans may be used from different threads.
+ */
+#ifndef SPECINV_H
+#define SPECINV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPECINV_ABI_VERSION 1
+
+enum {
+  SPECINV_OK = 0,
+  SPECINV_EINVAL = -1,       /* bad argument (the host layer raises AssertionError / ValueError) */
+  SPECINV_EHIP = -2,         /* a HIP runtime call failed */
+  SPECINV_EUNSUPPORTED = -3, /* configuration not implemented on the device path */
+  SPECINV_ENOMEM = -4,
+  SPECINV_ESTATE = -5        /* call sequence error (e.g. iterate before init) */
+};
+
+enum { SPECINV_F32 = 0, SPECINV_F64 = 1 };
+enum { SPECINV_PAD_REFLECT = 0, SPECINV_PAD_CONSTANT = 1, SPECINV_PAD_REPLICATE = 2, SPECINV_PAD_CIRCULAR = 3 };
+enum { SPECINV_METRIC_SC = 0, SPECINV_METRIC_SNR = 1, SPECINV_METRIC_SER = 2 };
+
+/* Normalised STFT arguments: what torch_specinv/methods.py:21-91 (_args_helper) returns,
+ * plus the problem shape.  `window_host` has n_fft elements of `dtype` and is already
+ * centre-padded (methods.py:80-83). */
+typedef struct specinv_stft_cfg {
+  int32_t n_fft;
+  int32_t hop_length;
+  int32_t n_frames;      /* T */
+  int32_t batch;         /* B */
+  int32_t center;        /* bool */
+  int32_t pad_mode;      /* SPECINV_PAD_* ; only read by the forward STFT when center != 0 */
+  int32_t normalized;    /* bool: 'ortho' scaling both ways (methods.py:142-146) */
+  int32_t onesided;      /* bool */
+  int32_t dtype;         /* SPECINV_F32 / SPECINV_F64 */
+  int32_t device;        /* HIP device ordinal */
+  const void* window_host;
+} specinv_stft_cfg;
+
+typedef struct specinv_plan specinv_plan;
+
+/* One evaluation of _training_loop (methods.py:180-184): metric value and F.mse_loss. */
+typedef struct specinv_eval {
+  int32_t iteration;     /* 0-based index of the iteration that was evaluated */
+  double metric;
+  double loss;
+} specinv_eval;
+
+/* Progress callback, called on the host after each evaluation; return non-zero to abort. */
+typedef int (*specinv_eval_cb)(const specinv_eval* ev, void* user);
+
+/* Whole-tensor sums behind metrics.py:14,28-29,43 and F.mse_loss:
+ * sums[0] = sum((a-b)^2), sums[1] = sum(a^2), sums[2] = sum(b^2), sums[3] = element count. */
+
+const char* specinv_last_error(void);
+int specinv_abi_version(void);
+
+/* ---- plan ---------------------------------------------------------------------------- */
+int specinv_plan_create(const specinv_stft_cfg* cfg, specinv_plan** out);
+int specinv_plan_destroy(specinv_plan* plan);
+int specinv_plan_set_stream(specinv_plan* plan, void* hip_stream);
+/* n_freq (F), signal length L = (T-1)*hop + n_fft - 2*pad (methods.py:127), and whether the
+ * fused gfx950 fast path (one wave per frame, LDS-resident FFT, register overlap-add) is used. */
+int specinv_plan_n_freq(const specinv_plan* plan);
+int64_t specinv_plan_length(const specinv_plan* plan);
+int specinv_plan_fast_path(const specinv_plan* plan);
+/* 0: allow the fast path when the configuration supports it (default); 1: force the generic kernels. */
+int specinv_plan_force_generic(specinv_plan* plan, int on);
+
+/* ---- building blocks ------------------------------------------------------------------ */
+/* torch.stft(x, n_fft, **processed_args) as called at methods.py:241.  x (B, L_in) -> spec
+ * (B, F, T) complex.  L_in must give exactly the plan's T frames. */
+int specinv_stft(specinv_plan* plan, const void* x, int64_t length, void* spec_out);
+/* _istft + _ola, methods.py:114-150: spec (B, F, T) complex -> x (B, L) = OLA / envelope. */
+int specinv_istft(specinv_plan* plan, const void* spec, void* x_out);
+/* window-square envelope of methods.py:129-131, (L,) */
+int specinv_envelope(specinv_plan* plan, void* env_out);
+/* phase_init, methods.py:572-615: mag (B, F, T) real -> (B, F, T) complex */
+int specinv_phase_init(specinv_plan* plan, const void* mag, void* spec_out);
+/* metrics.py sums over n elements of two real device arrays of the plan's dtype */
+int specinv_metric_sums(specinv_plan* plan, const void* a, const void* b, int64_t n, double sums_host[4]);
+
+/* ---- griffin_lim (methods.py:193-270) -------------------------------------------------- */
+/* Setup :223-235.  `init_spec` (B,F,T) complex is the starting spectrogram (cmplx_spec);
+ * `mag` (B,F,T) real is target_spec.  If init_spec is NULL the plan runs phase_init(mag). */
+int specinv_gla_init(specinv_plan* plan, const void* init_spec, const void* mag, double alpha);
+/* n_iter closure calls (:237-250).  If eval_last != 0 the |STFT| of the last call is reduced
+ * against the target into sums_host[4] (this synchronises the stream). */
+int specinv_gla_iterate(specinv_plan* plan, int n_iter, int eval_last, double sums_host[4]);
+/* The whole _training_loop (:153-190) on the device side: evaluation every eva_iter, early
+ * stop rule :186-190.  evals_out (may be NULL) receives up to max_iter/eva_iter entries. */
+int specinv_gla_run(specinv_plan* plan, int max_iter, int eva_iter, double tol, int metric,
+                    specinv_eval* evals_out, int* n_evals_out, int* iters_done_out,
+                    specinv_eval_cb cb, void* user);
+
+/* ---- ADMM (methods.py:415-506) --------------------------------------------------------- */
+int specinv_admm_init(specinv_plan* plan, const void* init_spec, const void* mag, double rho);
+int specinv_admm_iterate(specinv_plan* plan, int n_iter, int eval_last, double sums_host[4]);
+int specinv_admm_run(specinv_plan* plan, int max_iter, int eva_iter, double tol, int metric,
+                     specinv_eval* evals_out, int* n_evals_out, int* iters_done_out,
+                     specinv_eval_cb cb, void* user);
+
+/* current waveform estimate status_dict['x'] (B, L) of the running GLA / ADMM state */
+int specinv_get_wave(specinv_plan* plan, void* x_out);
+/* current pre_spec (GLA) or X (ADMM) as (B, F, T) complex - for state-parity tests */
+int specinv_get_state_spec(specinv_plan* plan, int which, void* spec_out);
+
+/* ---- RTISI-LA (methods.py:273-412) ------------------------------------------------------ */
+int specinv_rtisi_run(specinv_plan* plan, const void* mag, int look_ahead, int asymmetric_window,
+                      int max_iter, double alpha, void* x_out);
+
+/* ---- L_BFGS building blocks (methods.py:509-569 + torch.optim.LBFGS) -------------------- */
+/* transform kinds for the fused forward/backward: V = |STFT(x)| or V = log1p(M |STFT(x)|) */
+enum { SPECINV_TF_MAG = 0, SPECINV_TF_LOGMEL = 1 };
+/* mel_fb: (n_mels, F) device array or NULL for SPECINV_TF_MAG */
+int specinv_transform_setup(specinv_plan* plan, int kind, const void* mel_fb, int n_mels);
+/* V = transform(x): x (B, L_x) -> (B, n_out, T) with n_out = F or n_mels */
+int specinv_transform_forward(specinv_plan* plan, const void* x, int64_t length, void* v_out);
+/* loss = mean((transform(x) - target)^2) and d loss / d x (methods.py:545-550) */
+int specinv_transform_loss_grad(specinv_plan* plan, const void* x, int64_t length, const void* target,
+                                double* loss_host, void* grad_out);
+/* flat-vector kernels of the two-loop recursion (n elements of the plan dtype) */
+int specinv_vec_dot(specinv_plan* plan, const void* a, const void* b, int64_t n, double* out_host);
+int specinv_vec_axpy(specinv_plan* plan, double alpha, const void* x, void* y, int64_t n);
+int specinv_vec_scale(specinv_plan* plan, double alpha, const void* x, void* y, int64_t n);
+int specinv_vec_absmax_abssum(specinv_plan* plan, const void* x, int64_t n, double out_host[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECINV_H */

@@ -1,0 +1,390 @@
+// Generic (any n_fft / hop / pad mode / sidedness / f32+f64) kernels of libspecinv.
+//
+// One workgroup owns one frame: the frame's n_fft samples are staged in LDS, transformed by
+// a Stockham autosort FFT whose radix list is a factorisation of n_fft (any prime factor is
+// handled by a direct small DFT), updated in the frequency domain, transformed back and
+// written out windowed; a second kernel overlap-adds the frames (gather form, so the sum
+// order is fixed and the result is bitwise reproducible) and divides by the envelope.
+// This is the coverage path; the measured path for the headline shapes is kernels_fast.h.
+#pragma once
+#include "common.h"
+
+namespace specinv {
+
+template <typename T>
+struct FrameCfg {
+  int n_fft, n_freq, n_frames, hop, pad, pad_mode, onesided;
+  int64_t length;  // samples per batch row of the signal being read / written
+  T fwd_scale;     // 1 or n_fft^-1/2 (torch.stft normalized=True)
+  T inv_scale;     // 1/n_fft or n_fft^-1/2 (irfft norm backward / ortho)
+  int n_stages;
+  int radix[kMaxStages];
+  const cplx<T>* tw;  // tw[n] = exp(-2 pi i n / n_fft)
+  const T* window;    // n_fft
+};
+
+// ---- signal access with torch.stft's centre padding (methods.py:241 -> F.pad) -----------
+template <typename T>
+__device__ inline T load_padded(const T* __restrict__ x, int64_t L, int64_t n, int pad_mode) {
+  if (n >= 0 && n < L) return x[n];
+  switch (pad_mode) {
+    case SPECINV_PAD_REFLECT:
+      n = n < 0 ? -n : 2 * (L - 1) - n;
+      n = n < 0 ? 0 : (n >= L ? L - 1 : n);
+      return x[n];
+    case SPECINV_PAD_REPLICATE:
+      return x[n < 0 ? 0 : L - 1];
+    case SPECINV_PAD_CIRCULAR:
+      n %= L;
+      if (n < 0) n += L;
+      return x[n];
+    default:
+      return T(0);
+  }
+}
+
+// ---- Stockham FFT of n_fft complex points held in LDS ------------------------------------
+// On entry `a` holds the input (all threads synchronised); on exit `a` points at the result
+// (natural order, unscaled) and all threads are synchronised.
+template <typename T>
+__device__ inline void lds_fft(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, bool inverse) {
+  const int N = c.n_fft;
+  int ns = 1;
+  for (int s = 0; s < c.n_stages; ++s) {
+    const int R = c.radix[s];
+    const int m = ns * R;
+    const int stride = N / R;
+    const int twstep = N / m;
+    for (int o = threadIdx.x; o < N; o += blockDim.x) {
+      const int block = o / m;
+      const int within = o - block * m;
+      const int r = within / ns;
+      const int k = within - r * ns;
+      const int j = block * ns + k;
+      const int e1 = k + r * ns;  // < m
+      T accx = 0, accy = 0;
+      int e = 0;
+      for (int q = 0; q < R; ++q) {
+        cplx<T> v = a[j + q * stride];
+        cplx<T> w = c.tw[e * twstep];
+        if (inverse) w.y = -w.y;
+        accx += v.x * w.x - v.y * w.y;
+        accy += v.x * w.y + v.y * w.x;
+        e += e1;
+        if (e >= m) e -= m;
+      }
+      b[o] = mk<T>(accx, accy);
+    }
+    __syncthreads();
+    cplx<T>* tmp = a;
+    a = b;
+    b = tmp;
+    ns = m;
+  }
+}
+
+// windowed frame t of row `x` -> LDS (imaginary part zero); ends synchronised
+template <typename T>
+__device__ inline void load_frame(const FrameCfg<T>& c, const T* __restrict__ x, int t, cplx<T>* a,
+                                  const T* __restrict__ window) {
+  const int64_t start = (int64_t)t * c.hop - c.pad;
+  for (int n = threadIdx.x; n < c.n_fft; n += blockDim.x) {
+    T v = load_padded(x, c.length, start + n, c.pad_mode);
+    a[n] = mk<T>(v * window[n], T(0));
+  }
+  __syncthreads();
+}
+
+// LDS bins [0, n_freq) -> real frame (inverse FFT, scale, synthesis window) -> out[n_fft]
+template <typename T>
+__device__ inline void spectrum_to_frame(const FrameCfg<T>& c, cplx<T>* a, cplx<T>* b, T* __restrict__ out,
+                                         const T* __restrict__ window) {
+  const int N = c.n_fft;
+  if (c.onesided) {
+    // irfft semantics: Hermitian extension, imaginary parts of DC / Nyquist ignored
+    for (int f = threadIdx.x; f <= N / 2; f += blockDim.x) {
+      cplx<T> v = a[f];
+      if (f == 0 || 2 * f == N) {
+        a[f] = mk<T>(v.x, T(0));
+      } else {
+        a[N - f] = conj(v);
+      }
+    }
+    __syncthreads();
+  }
+  lds_fft(a, b, c, true);
+  for (int n = threadIdx.x; n < N; n += blockDim.x) out[n] = (a[n].x * c.inv_scale) * window[n];
+}
+
+// sum over the workgroup; result valid on thread 0
+__device__ inline double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double tot = 0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) tot += red[w];
+  }
+  return tot;
+}
+
+// ---- forward STFT: x (B, length) -> spec (B, T, F) [frame-major internal layout] -----------
+template <typename T>
+__global__ void k_stft(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ spec) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* b = a + c.n_fft;
+  const int t = blockIdx.x, bi = blockIdx.y;
+  load_frame(c, x + (int64_t)bi * c.length, t, a, c.window);
+  lds_fft(a, b, c, false);
+  cplx<T>* out = spec + ((int64_t)bi * c.n_frames + t) * c.n_freq;
+  for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) out[f] = mk<T>(a[f].x * c.fwd_scale, a[f].y * c.fwd_scale);
+}
+
+// ---- inverse frames: spec (B, T, F) -> windowed frames (B, T, N) ---------------------------
+template <typename T>
+__global__ void k_istft_frames(FrameCfg<T> c, const cplx<T>* __restrict__ spec, T* __restrict__ frames) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* b = a + c.n_fft;
+  const int t = blockIdx.x, bi = blockIdx.y;
+  const cplx<T>* in = spec + ((int64_t)bi * c.n_frames + t) * c.n_freq;
+  for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) a[f] = in[f];
+  __syncthreads();
+  spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
+}
+
+// ---- overlap-add + envelope division (methods.py:127,132) ---------------------------------
+// x[b, n] = (sum_t frames[b, t, n + pad - t*hop]) / env[n], t ascending.
+template <typename T>
+__global__ void k_ola(const T* __restrict__ frames, const T* __restrict__ env, T* __restrict__ x, int n_fft,
+                      int hop, int pad, int n_frames, int64_t length, int64_t total, int use_env) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t bi = i / length;
+  const int64_t n = i - bi * length;
+  const int64_t np = n + pad;
+  int64_t t_hi = np / hop;
+  if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+  int64_t t_lo = np - n_fft + 1 <= 0 ? 0 : (np - n_fft + hop) / hop;
+  const T* fr = frames + bi * n_frames * n_fft;
+  T acc = 0;
+  for (int64_t t = t_lo; t <= t_hi; ++t) acc += fr[t * n_fft + (np - t * hop)];
+  x[i] = use_env ? acc / env[n] : acc;
+}
+
+// ---- Griffin-Lim iteration, frame part (methods.py:237-248) ---------------------------------
+// R = STFT(x)_t ; out = |R| ; S = R - lr*P ; P <- S ; S' = S * m / (|S| + 1e-16) ; frame = w * irfft(S')
+template <typename T, bool EVAL>
+__global__ void k_gla_frame(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ P,
+                            const T* __restrict__ mag, T lr, T* __restrict__ frames, double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[16];
+  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* b = a + c.n_fft;
+  const int t = blockIdx.x, bi = blockIdx.y;
+  load_frame(c, x + (int64_t)bi * c.length, t, a, c.window);
+  lds_fft(a, b, c, false);
+  const int64_t base = ((int64_t)bi * c.n_frames + t) * c.n_freq;
+  double s_d = 0, s_o = 0;
+  for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) {
+    const cplx<T> r = mk<T>(a[f].x * c.fwd_scale, a[f].y * c.fwd_scale);
+    const cplx<T> p = P[base + f];
+    const T m = mag[base + f];
+    if (EVAL) {
+      const T o = si_hypot(r.x, r.y);
+      const double d = (double)o - (double)m;
+      s_d += d * d;
+      s_o += (double)o * (double)o;
+    }
+    const cplx<T> s = mk<T>(r.x - p.x * lr, r.y - p.y * lr);
+    P[base + f] = s;
+    const T inv = T(1) / (si_hypot(s.x, s.y) + eps16<T>::value);
+    a[f] = mk<T>((s.x * m) * inv, (s.y * m) * inv);
+  }
+  __syncthreads();
+  spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
+  if (EVAL) {
+    const double d = block_sum(s_d, red);
+    const double o = block_sum(s_o, red);
+    if (threadIdx.x == 0) {
+      const int64_t pi = (int64_t)bi * c.n_frames + t;
+      partials[2 * pi] = d;
+      partials[2 * pi + 1] = o;
+    }
+  }
+}
+
+// ---- ADMM iteration, frame part (methods.py:458-477) ---------------------------------------
+// R = STFT(x)_t ; Y = X + U ; Z = (rho*Y + R)/(1+rho) ; U <- U + X - Z ; X <- Z - U ;
+// X <- X*m/(|X|+1e-16) ; Y' = X + U ; frame = w * irfft(Y').  Only X and U are stored:
+// Y is recomputed as fl(X + U), which is the value the reference stores (:475).
+template <typename T, bool EVAL>
+__global__ void k_admm_frame(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ X,
+                             cplx<T>* __restrict__ U, const T* __restrict__ mag, T rho, T inv1p,
+                             T* __restrict__ frames, double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[16];
+  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* b = a + c.n_fft;
+  const int t = blockIdx.x, bi = blockIdx.y;
+  load_frame(c, x + (int64_t)bi * c.length, t, a, c.window);
+  lds_fft(a, b, c, false);
+  const int64_t base = ((int64_t)bi * c.n_frames + t) * c.n_freq;
+  double s_d = 0, s_o = 0;
+  for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) {
+    const cplx<T> r = mk<T>(a[f].x * c.fwd_scale, a[f].y * c.fwd_scale);
+    const cplx<T> xo = X[base + f];
+    const cplx<T> uo = U[base + f];
+    const T m = mag[base + f];
+    if (EVAL) {
+      const T o = si_hypot(r.x, r.y);
+      const double d = (double)o - (double)m;
+      s_d += d * d;
+      s_o += (double)o * (double)o;
+    }
+    const cplx<T> y = xo + uo;
+    const cplx<T> z = mk<T>((rho * y.x + r.x) * inv1p, (rho * y.y + r.y) * inv1p);
+    const cplx<T> un = (uo + xo) - z;
+    cplx<T> xn = z - un;
+    const T inv = T(1) / (si_hypot(xn.x, xn.y) + eps16<T>::value);
+    xn = mk<T>((xn.x * m) * inv, (xn.y * m) * inv);
+    X[base + f] = xn;
+    U[base + f] = un;
+    a[f] = xn + un;
+  }
+  __syncthreads();
+  spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
+  if (EVAL) {
+    const double d = block_sum(s_d, red);
+    const double o = block_sum(s_o, red);
+    if (threadIdx.x == 0) {
+      const int64_t pi = (int64_t)bi * c.n_frames + t;
+      partials[2 * pi] = d;
+      partials[2 * pi + 1] = o;
+    }
+  }
+}
+
+// ---- deterministic reductions ----------------------------------------------------------------
+// sums[k] = sum_i partials[n_comp*i + k] for k < n_comp; single workgroup, fixed order.
+__global__ void k_finish_partials(const double* __restrict__ partials, int64_t n, int n_comp,
+                                  double* __restrict__ sums) {
+  __shared__ double red[16];
+  for (int k = 0; k < n_comp; ++k) {
+    double v = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) v += partials[n_comp * i + k];
+    const double tot = block_sum(v, red);
+    if (threadIdx.x == 0) sums[k] = tot;
+  }
+}
+
+// per-block partial sums of (a-b)^2, a^2, b^2 (b may be null: only a^2 is meaningful)
+template <typename T>
+__global__ void k_metric_partials(const T* __restrict__ a, const T* __restrict__ b, int64_t n,
+                                  double* __restrict__ partials) {
+  __shared__ double red[16];
+  double sd = 0, sa = 0, sb = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double av = (double)a[i];
+    const double bv = b ? (double)b[i] : 0.0;
+    sd += (av - bv) * (av - bv);
+    sa += av * av;
+    sb += bv * bv;
+  }
+  const double d = block_sum(sd, red), aa = block_sum(sa, red), bb = block_sum(sb, red);
+  if (threadIdx.x == 0) {
+    partials[3 * blockIdx.x] = d;
+    partials[3 * blockIdx.x + 1] = aa;
+    partials[3 * blockIdx.x + 2] = bb;
+  }
+}
+
+// ---- batched 2-D transpose (B, R, C) -> (B, C, R), any element type ---------------------------
+template <typename E>
+__global__ void k_transpose(const E* __restrict__ in, E* __restrict__ out, int R, int C) {
+  __shared__ E tile[32][33];
+  const int64_t boff = (int64_t)blockIdx.z * R * C;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, cc = c0 + threadIdx.x;
+    if (r < R && cc < C) tile[i][threadIdx.x] = in[boff + (int64_t)r * C + cc];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int cc = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && cc < C) out[boff + (int64_t)cc * R + r] = tile[threadIdx.x][i];
+  }
+}
+
+// ---- phase_init (methods.py:572-615) -----------------------------------------------------------
+// One wave per (b, f) row of the (B, F, T) magnitude: peak test / omega in the input dtype in
+// the reference's operation order, float64 running sum over time with each partial sum
+// rounded to the input dtype (ATen's CPU cumsum), cos/sin evaluated in float64 of the rounded
+// phase and rounded once.
+template <typename T>
+__device__ inline bool peak_omega(const T* __restrict__ col, int64_t fstride, int g, int F, T two_pi, T n_fft,
+                                  T hop, T& w) {
+#pragma clang fp contract(off)
+  if (g < 1 || g > F - 2) return false;
+  const T a = col[(int64_t)(g - 1) * fstride];
+  const T bb = col[(int64_t)g * fstride];
+  const T r = col[(int64_t)(g + 1) * fstride];
+  if (!(bb > r && bb > a)) return false;                // :597
+  const T p = T(0.5) * (a - r) / (a - T(2) * bb + r);   // :604
+  w = two_pi * (T(g) + p) / n_fft * hop;                // :605
+  return true;
+}
+
+template <typename T>
+__global__ void k_phase_init(const T* __restrict__ mag, cplx<T>* __restrict__ out, int B, int F, int Tn,
+                             int n_fft, int hop) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B * F) return;
+  const int bi = row / F, f = row - bi * F;
+  const T* base = mag + (int64_t)bi * F * Tn;
+  cplx<T>* orow = out + ((int64_t)bi * F + f) * Tn;
+  const T two_pi = T(6.283185307179586476925286766559);
+  double carry = 0;
+  for (int t0 = 0; t0 < Tn; t0 += 64) {
+    const int t = t0 + lane;
+    T om = 0, m0 = 0;
+    if (t < Tn) {
+      const T* col = base + t;
+      m0 = col[(int64_t)f * Tn];
+      T w;
+      // scatter order :607-609: own bin, else the k+1 write of a peak below, else the k-1
+      // write of a peak above (later statements overwrite earlier ones)
+      if (peak_omega<T>(col, Tn, f, F, two_pi, T(n_fft), T(hop), w)) om = w;
+      else if (peak_omega<T>(col, Tn, f - 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
+      else if (peak_omega<T>(col, Tn, f + 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
+    }
+    double v = (double)om;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    v += carry;
+    carry = __shfl(v, 63, 64);
+    if (t < Tn) {
+      const T phi = (T)v;                                  // :611
+      double s, cs;
+      sincos((double)phi, &s, &cs);                        // :612
+      orow[t] = mk<T>(m0 * (T)cs, m0 * (T)s);              // :614
+    }
+  }
+}
+
+// |z| of a complex array (target_spec = spec.abs(), methods.py:110)
+template <typename T>
+__global__ void k_cabs(const cplx<T>* __restrict__ in, T* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = si_hypot(in[i].x, in[i].y);
+}
+
+}  // namespace specinv

@@ -1,0 +1,62 @@
+// Plan object behind the C ABI (include/specinv.h).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "common.h"
+
+namespace specinv {
+
+enum class Method { None, Gla, Admm };
+
+// Type-erased interface; PlanT<float> / PlanT<double> implement it (plan_impl.h).
+struct PlanBase {
+  specinv_stft_cfg cfg{};
+  int n_freq = 0;
+  int pad = 0;
+  int64_t length = 0;  // (T-1)*hop + n_fft - 2*pad
+  hipStream_t stream = nullptr;
+  Method method = Method::None;
+  bool force_generic = false;
+
+  virtual ~PlanBase() = default;
+  virtual int setup() = 0;
+  virtual bool fast_path() const = 0;
+
+  virtual int stft(const void* x, int64_t len, void* spec_out) = 0;
+  virtual int istft(const void* spec, void* x_out) = 0;
+  virtual int envelope(void* env_out) = 0;
+  virtual int phase_init(const void* mag, void* spec_out) = 0;
+  virtual int metric_sums(const void* a, const void* b, int64_t n, double sums[4]) = 0;
+
+  virtual int gla_init(const void* init_spec, const void* mag, double alpha) = 0;
+  virtual int admm_init(const void* init_spec, const void* mag, double rho) = 0;
+  virtual int iterate(int n_iter, bool eval_last, double sums[4]) = 0;
+  virtual int get_wave(void* x_out) = 0;
+  virtual int get_state_spec(int which, void* spec_out) = 0;
+
+  virtual int rtisi_run(const void* mag, int look_ahead, int asym, int max_iter, double alpha, void* x_out) = 0;
+
+  virtual int transform_setup(int kind, const void* mel_fb, int n_mels) = 0;
+  virtual int transform_forward(const void* x, int64_t len, void* v_out) = 0;
+  virtual int transform_loss_grad(const void* x, int64_t len, const void* target, double* loss, void* grad) = 0;
+  virtual int vec_dot(const void* a, const void* b, int64_t n, double* out) = 0;
+  virtual int vec_axpy(double alpha, const void* x, void* y, int64_t n) = 0;
+  virtual int vec_scale(double alpha, const void* x, void* y, int64_t n) = 0;
+  virtual int vec_absmax_abssum(const void* x, int64_t n, double out[2]) = 0;
+
+  // _training_loop (methods.py:153-190) driving `iterate`
+  int run_loop(int max_iter, int eva_iter, double tol, int metric, specinv_eval* evals, int* n_evals,
+               int* iters_done, specinv_eval_cb cb, void* user);
+};
+
+std::unique_ptr<PlanBase> make_plan_f32();
+std::unique_ptr<PlanBase> make_plan_f64();
+
+double metric_from_sums(int metric, const double sums[4]);
+
+}  // namespace specinv
+
+struct specinv_plan {
+  std::unique_ptr<specinv::PlanBase> impl;
+};

@@ -1,0 +1,401 @@
+// PlanT<T>: owns the device state of one (device, shape, stft-args) problem and launches the
+// kernels.  T = float or double.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "kernels_fast.h"
+#include "kernels_generic.h"
+#include "kernels_lbfgs.h"
+#include "kernels_rtisi.h"
+#include "plan.h"
+
+namespace specinv {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  // grow-only allocation
+  int reserve(size_t n) {
+    if (n <= bytes && p) return SPECINV_OK;
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(SPECINV_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    return SPECINV_OK;
+  }
+  template <typename U>
+  U* as() const { return static_cast<U*>(p); }
+};
+
+inline std::vector<int> factorize(int n) {
+  std::vector<int> f;
+  const int small[] = {4, 2, 3, 5, 7, 11, 13};
+  for (int p : small)
+    while (n % p == 0) {
+      f.push_back(p);
+      n /= p;
+    }
+  for (int d = 17; n > 1; d += 2)
+    while (n % d == 0) {
+      f.push_back(d);
+      n /= d;
+    }
+  return f;
+}
+
+template <typename T>
+struct PlanT final : PlanBase {
+  using C = cplx<T>;
+  DevBuf window, tw, env;
+  DevBuf x, frames, specA, specB, mag, partials, sums, tmp_spec, tmp_real;
+  DevBuf rt_state;                      // RTISI per-item state
+  DevBuf tf_mel, tf_spec, tf_v, tf_dv;  // transform (L_BFGS) scratch
+  std::vector<T> h_window;
+  FrameCfg<T> fc{};
+  size_t lds_bytes = 0;
+  double sum_m2 = 0, count = 0;
+  T coef = 0;  // lr (GLA) or rho (ADMM)
+  FastState<T> fast;
+  int tf_kind = -1, tf_mels = 0;
+
+  int B() const { return cfg.batch; }
+  int Tn() const { return cfg.n_frames; }
+  int N() const { return cfg.n_fft; }
+  int64_t nspec() const { return (int64_t)B() * Tn() * n_freq; }
+
+  // ------------------------------------------------------------------------------------
+  int setup() override {
+    SI_CHECK(cfg.n_fft >= 2 && cfg.hop_length >= 1 && cfg.n_frames >= 1 && cfg.batch >= 1, SPECINV_EINVAL,
+             "bad shape: n_fft=%d hop=%d frames=%d batch=%d", cfg.n_fft, cfg.hop_length, cfg.n_frames, cfg.batch);
+    SI_CHECK(cfg.window_host != nullptr, SPECINV_EINVAL, "window_host is NULL");
+    SI_CHECK(cfg.pad_mode >= 0 && cfg.pad_mode <= 3, SPECINV_EINVAL, "bad pad_mode %d", cfg.pad_mode);
+    SI_CHECK(!cfg.onesided || cfg.n_fft % 2 == 0, SPECINV_EINVAL, "onesided needs an even n_fft");
+    SI_HIP(hipSetDevice(cfg.device));
+    n_freq = cfg.onesided ? cfg.n_fft / 2 + 1 : cfg.n_fft;
+    pad = cfg.center ? cfg.n_fft / 2 : 0;
+    length = (int64_t)(cfg.n_frames - 1) * cfg.hop_length + cfg.n_fft - 2 * pad;
+    SI_CHECK(length >= 1, SPECINV_EINVAL, "empty signal (length %lld)", (long long)length);
+    SI_CHECK(cfg.batch <= 65535, SPECINV_EUNSUPPORTED, "batch > 65535");
+
+    const int n = cfg.n_fft;
+    h_window.assign(static_cast<const T*>(cfg.window_host), static_cast<const T*>(cfg.window_host) + n);
+    cfg.window_host = nullptr;
+    SI_TRY(window.reserve(n * sizeof(T)));
+    SI_HIP(hipMemcpy(window.p, h_window.data(), n * sizeof(T), hipMemcpyHostToDevice));
+
+    std::vector<C> h_tw(n);
+    for (int i = 0; i < n; ++i) {
+      const long double a = -2.0L * 3.141592653589793238462643383279502884L * i / n;
+      h_tw[i] = mk<T>((T)cosl(a), (T)sinl(a));
+    }
+    SI_TRY(tw.reserve(n * sizeof(C)));
+    SI_HIP(hipMemcpy(tw.p, h_tw.data(), n * sizeof(C), hipMemcpyHostToDevice));
+
+    // window-square envelope (methods.py:129-131); products in T like the reference's
+    // `weight * weight`, the <= ceil(N/hop) term sums in double, rounded once
+    std::vector<double> e(length, 0.0);
+    for (int t = 0; t < cfg.n_frames; ++t)
+      for (int k = 0; k < n; ++k) {
+        const int64_t pos = (int64_t)t * cfg.hop_length + k - pad;
+        if (pos >= 0 && pos < length) e[pos] += (double)(T)(h_window[k] * h_window[k]);
+      }
+    std::vector<T> h_env(length);
+    for (int64_t i = 0; i < length; ++i) h_env[i] = (T)e[i];
+    SI_TRY(env.reserve(length * sizeof(T)));
+    SI_HIP(hipMemcpy(env.p, h_env.data(), length * sizeof(T), hipMemcpyHostToDevice));
+
+    std::vector<int> rad = factorize(n);
+    SI_CHECK((int)rad.size() <= kMaxStages, SPECINV_EUNSUPPORTED, "n_fft=%d has too many prime factors", n);
+    fc.n_fft = n;
+    fc.n_freq = n_freq;
+    fc.n_frames = cfg.n_frames;
+    fc.hop = cfg.hop_length;
+    fc.pad = pad;
+    fc.pad_mode = cfg.pad_mode;
+    fc.onesided = cfg.onesided;
+    fc.length = length;
+    fc.fwd_scale = cfg.normalized ? (T)(1.0 / std::sqrt((double)n)) : T(1);
+    fc.inv_scale = cfg.normalized ? (T)(1.0 / std::sqrt((double)n)) : (T)(1.0 / n);
+    fc.n_stages = (int)rad.size();
+    for (size_t i = 0; i < rad.size(); ++i) fc.radix[i] = rad[i];
+    fc.tw = tw.as<C>();
+    fc.window = window.as<T>();
+    lds_bytes = 2 * (size_t)n * sizeof(C);
+    SI_CHECK(lds_bytes <= 160 * 1024 - 256, SPECINV_EUNSUPPORTED,
+             "n_fft=%d needs %zu bytes of LDS per frame (limit 160 KiB)", n, lds_bytes);
+    if (lds_bytes > 48 * 1024) {
+      const int lim = (int)lds_bytes;
+      SI_HIP(hipFuncSetAttribute((const void*)k_stft<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_istft_frames<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_gla_frame<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_gla_frame<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_admm_frame<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_admm_frame<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    }
+    SI_TRY(sums.reserve(8 * sizeof(double)));
+    SI_TRY(fast.setup(cfg, h_window, length, pad));
+    return SPECINV_OK;
+  }
+
+  bool fast_path() const override { return fast.supported && !force_generic; }
+
+  // ------------------------------------------------------------------------------------
+  // layout helpers: user (B, F, T) <-> internal (B, T, F)
+  template <typename E>
+  int transpose(const E* in, E* out, int R, int Cc) {
+    dim3 grid((Cc + 31) / 32, (R + 31) / 32, B());
+    SI_CHECK(grid.y <= 65535, SPECINV_EUNSUPPORTED, "dimension too large for transpose");
+    hipLaunchKernelGGL((k_transpose<E>), grid, dim3(32, 8), 0, stream, in, out, R, Cc);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  FrameCfg<T> frame_cfg(int64_t len) const {
+    FrameCfg<T> c = fc;
+    c.length = len;
+    return c;
+  }
+
+  int launch_ola(const T* fr, T* out, bool use_env) {
+    const int64_t total = (int64_t)B() * length;
+    hipLaunchKernelGGL((k_ola<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, fr, env.as<T>(), out,
+                       N(), cfg.hop_length, pad, Tn(), length, total, use_env ? 1 : 0);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  int frames_needed() { return frames.reserve((size_t)B() * Tn() * N() * sizeof(T)); }
+
+  // internal-layout spectrum -> x
+  int istft_internal(const C* spec_btf, T* out) {
+    SI_TRY(frames_needed());
+    hipLaunchKernelGGL((k_istft_frames<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, frame_cfg(length), spec_btf,
+                       frames.as<T>());
+    SI_HIP(hipGetLastError());
+    return launch_ola(frames.as<T>(), out, true);
+  }
+
+  int stft_internal(const T* xin, int64_t len, C* spec_btf) {
+    const int64_t tcheck = 1 + (len + 2 * pad - N()) / cfg.hop_length;
+    SI_CHECK(len + 2 * pad >= N() && tcheck == Tn(), SPECINV_EINVAL,
+             "signal length %lld gives %lld frames, plan has %d", (long long)len, (long long)tcheck, Tn());
+    if (cfg.center && cfg.pad_mode == SPECINV_PAD_REFLECT)
+      SI_CHECK(pad < len, SPECINV_EINVAL, "reflect padding needs n_fft/2 < length");
+    hipLaunchKernelGGL((k_stft<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, frame_cfg(len), xin, spec_btf);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  int stft(const void* xin, int64_t len, void* spec_out) override {
+    SI_CHECK(xin && spec_out, SPECINV_EINVAL, "null pointer");
+    SI_TRY(tmp_spec.reserve(nspec() * sizeof(C)));
+    SI_TRY(stft_internal(static_cast<const T*>(xin), len, tmp_spec.as<C>()));
+    return transpose<C>(tmp_spec.as<C>(), static_cast<C*>(spec_out), Tn(), n_freq);
+  }
+
+  int istft(const void* spec, void* x_out) override {
+    SI_CHECK(spec && x_out, SPECINV_EINVAL, "null pointer");
+    SI_TRY(tmp_spec.reserve(nspec() * sizeof(C)));
+    SI_TRY(transpose<C>(static_cast<const C*>(spec), tmp_spec.as<C>(), n_freq, Tn()));
+    return istft_internal(tmp_spec.as<C>(), static_cast<T*>(x_out));
+  }
+
+  int envelope(void* env_out) override {
+    SI_CHECK(env_out, SPECINV_EINVAL, "null pointer");
+    SI_HIP(hipMemcpyAsync(env_out, env.p, length * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    return SPECINV_OK;
+  }
+
+  int phase_init(const void* magp, void* spec_out) override {
+    SI_CHECK(magp && spec_out, SPECINV_EINVAL, "null pointer");
+    const int rows = B() * n_freq;
+    hipLaunchKernelGGL((k_phase_init<T>), dim3((rows + 3) / 4), dim3(256), 0, stream, static_cast<const T*>(magp),
+                       static_cast<C*>(spec_out), B(), n_freq, Tn(), N(), cfg.hop_length);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  int reduce3(const T* a, const T* b, int64_t n, double out3[3]) {
+    const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
+    SI_TRY(partials.reserve(std::max<size_t>((size_t)nb * 3, (size_t)B() * Tn() * 2) * sizeof(double)));
+    hipLaunchKernelGGL((k_metric_partials<T>), dim3(nb), dim3(256), 0, stream, a, b, n, partials.as<double>());
+    SI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, stream, partials.as<double>(), (int64_t)nb, 3,
+                       sums.as<double>());
+    SI_HIP(hipGetLastError());
+    SI_HIP(hipMemcpyAsync(out3, sums.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+    SI_HIP(hipStreamSynchronize(stream));
+    return SPECINV_OK;
+  }
+
+  int metric_sums(const void* a, const void* b, int64_t n, double s[4]) override {
+    SI_CHECK(a && b && n > 0, SPECINV_EINVAL, "bad arguments");
+    double r[3];
+    SI_TRY(reduce3(static_cast<const T*>(a), static_cast<const T*>(b), n, r));
+    s[0] = r[0];
+    s[1] = r[1];
+    s[2] = r[2];
+    s[3] = (double)n;
+    return SPECINV_OK;
+  }
+
+  // ------------------------------------------------------------------------------------
+  // shared part of gla_init / admm_init: target + starting spectrum into internal layout,
+  // x = ISTFT(start) (methods.py:233 / :453)
+  int init_common(const void* init_spec, const void* magp) {
+    SI_CHECK(init_spec || magp, SPECINV_EINVAL, "need init_spec and/or mag");
+    const int64_t ns = nspec();
+    SI_TRY(specA.reserve(ns * sizeof(C)));
+    SI_TRY(mag.reserve(ns * sizeof(T)));
+    SI_TRY(x.reserve((size_t)B() * length * sizeof(T)));
+    SI_TRY(partials.reserve(std::max<size_t>((size_t)B() * Tn() * 2, 3 * 1024) * sizeof(double)));
+    const C* start_user = static_cast<const C*>(init_spec);
+    if (!init_spec) {
+      SI_TRY(tmp_spec.reserve(ns * sizeof(C)));
+      SI_TRY(phase_init(magp, tmp_spec.p));                       // methods.py:106
+      start_user = tmp_spec.as<C>();
+    }
+    SI_TRY(transpose<C>(start_user, specA.as<C>(), n_freq, Tn()));
+    if (magp) {
+      SI_TRY(transpose<T>(static_cast<const T*>(magp), mag.as<T>(), n_freq, Tn()));
+    } else {                                                        // methods.py:110
+      hipLaunchKernelGGL((k_cabs<T>), dim3((unsigned)ceil_div(ns, 256)), dim3(256), 0, stream, specA.as<C>(),
+                         mag.as<T>(), ns);
+      SI_HIP(hipGetLastError());
+    }
+    double r[3];
+    SI_TRY(reduce3(mag.as<T>(), nullptr, ns, r));
+    sum_m2 = r[1];
+    count = (double)ns;
+    return istft_internal(specA.as<C>(), x.as<T>());
+  }
+
+  int gla_init(const void* init_spec, const void* magp, double alpha) override {
+    SI_CHECK(alpha >= 0, SPECINV_EINVAL, "alpha must be >= 0");
+    method = Method::None;
+    SI_TRY(init_common(init_spec, magp));
+    coef = (T)(alpha / (1.0 + alpha));                              // methods.py:235
+    if (fast_path()) SI_TRY(fast.gla_begin(*this));
+    method = Method::Gla;
+    return SPECINV_OK;
+  }
+
+  int admm_init(const void* init_spec, const void* magp, double rho) override {
+    method = Method::None;
+    SI_TRY(init_common(init_spec, magp));
+    SI_TRY(specB.reserve(nspec() * sizeof(C)));
+    SI_HIP(hipMemsetAsync(specB.p, 0, nspec() * sizeof(C), stream));  // U = 0, methods.py:456
+    coef = (T)rho;
+    if (fast_path()) SI_TRY(fast.admm_begin(*this));
+    method = Method::Admm;
+    return SPECINV_OK;
+  }
+
+  int iterate(int n_iter, bool eval_last, double s[4]) override {
+    SI_CHECK(method != Method::None, SPECINV_ESTATE, "iterate called before gla_init/admm_init");
+    SI_CHECK(n_iter >= 0, SPECINV_EINVAL, "n_iter < 0");
+    if (n_iter == 0) return SPECINV_OK;
+    if (fast_path()) {
+      SI_TRY(fast.iterate(*this, n_iter, eval_last));
+    } else {
+      SI_TRY(frames_needed());
+      const T inv1p = T(1) / (T)(1.0 + (double)coef);
+      for (int i = 0; i < n_iter; ++i) {
+        const bool ev = eval_last && i == n_iter - 1;
+        const dim3 grid(Tn(), B()), blk(256);
+        if (method == Method::Gla) {
+          if (ev)
+            hipLaunchKernelGGL((k_gla_frame<T, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
+                               mag.as<T>(), coef, frames.as<T>(), partials.as<double>());
+          else
+            hipLaunchKernelGGL((k_gla_frame<T, false>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
+                               mag.as<T>(), coef, frames.as<T>(), partials.as<double>());
+        } else {
+          if (ev)
+            hipLaunchKernelGGL((k_admm_frame<T, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
+                               specB.as<C>(), mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
+          else
+            hipLaunchKernelGGL((k_admm_frame<T, false>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
+                               specB.as<C>(), mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
+        }
+        SI_HIP(hipGetLastError());
+        SI_TRY(launch_ola(frames.as<T>(), x.as<T>(), true));
+      }
+    }
+    if (eval_last) {
+      SI_CHECK(s != nullptr, SPECINV_EINVAL, "sums_host is NULL");
+      hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, stream, partials.as<double>(),
+                         (int64_t)B() * Tn(), 2, sums.as<double>());
+      SI_HIP(hipGetLastError());
+      double r[2];
+      SI_HIP(hipMemcpyAsync(r, sums.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
+      SI_HIP(hipStreamSynchronize(stream));
+      s[0] = r[0];
+      s[1] = r[1];
+      s[2] = sum_m2;
+      s[3] = count;
+    }
+    return SPECINV_OK;
+  }
+
+  int get_wave(void* x_out) override {
+    SI_CHECK(method != Method::None, SPECINV_ESTATE, "no running state");
+    SI_CHECK(x_out, SPECINV_EINVAL, "null pointer");
+    if (fast_path()) return fast.get_wave(*this, static_cast<T*>(x_out));
+    SI_HIP(hipMemcpyAsync(x_out, x.p, (size_t)B() * length * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    return SPECINV_OK;
+  }
+
+  int get_state_spec(int which, void* spec_out) override {
+    SI_CHECK(method != Method::None, SPECINV_ESTATE, "no running state");
+    SI_CHECK(spec_out && (which == 0 || (which == 1 && method == Method::Admm)), SPECINV_EINVAL, "bad arguments");
+    if (fast_path()) return fast.get_state_spec(*this, which, static_cast<C*>(spec_out));
+    return transpose<C>(which == 0 ? specA.as<C>() : specB.as<C>(), static_cast<C*>(spec_out), Tn(), n_freq);
+  }
+
+  // ------------------------------------------------------------------------------------
+  int rtisi_run(const void* magp, int look_ahead, int asym, int max_iter, double alpha, void* x_out) override {
+    return rtisi_launch(*this, static_cast<const T*>(magp), look_ahead, asym, max_iter, alpha, static_cast<T*>(x_out));
+  }
+
+  // ------------------------------------------------------------------------------------
+  int transform_setup(int kind, const void* mel_fb, int n_mels) override {
+    return tf_setup(*this, kind, static_cast<const T*>(mel_fb), n_mels);
+  }
+  int transform_forward(const void* xin, int64_t len, void* v_out) override {
+    return tf_forward(*this, static_cast<const T*>(xin), len, static_cast<T*>(v_out));
+  }
+  int transform_loss_grad(const void* xin, int64_t len, const void* target, double* loss, void* grad) override {
+    return tf_loss_grad(*this, static_cast<const T*>(xin), len, static_cast<const T*>(target), loss,
+                        static_cast<T*>(grad));
+  }
+  int vec_dot(const void* a, const void* b, int64_t n, double* out) override {
+    return lb_dot(*this, static_cast<const T*>(a), static_cast<const T*>(b), n, out);
+  }
+  int vec_axpy(double alpha, const void* xin, void* y, int64_t n) override {
+    return lb_axpy(*this, (T)alpha, static_cast<const T*>(xin), static_cast<T*>(y), n);
+  }
+  int vec_scale(double alpha, const void* xin, void* y, int64_t n) override {
+    return lb_scale(*this, (T)alpha, static_cast<const T*>(xin), static_cast<T*>(y), n);
+  }
+  int vec_absmax_abssum(const void* xin, int64_t n, double out[2]) override {
+    return lb_absmax_abssum(*this, static_cast<const T*>(xin), n, out);
+  }
+};
+
+}  // namespace specinv

@@ -1,0 +1,236 @@
+// libspecinv.so - C ABI entry points (include/specinv.h).  gfx950 only.
+#include <cstdarg>
+#include <cstdio>
+#include <new>
+
+#include "plan_impl.h"
+
+namespace specinv {
+
+std::string& last_error() {
+  static thread_local std::string msg;
+  return msg;
+}
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+std::unique_ptr<PlanBase> make_plan_f32() { return std::unique_ptr<PlanBase>(new PlanT<float>()); }
+std::unique_ptr<PlanBase> make_plan_f64() { return std::unique_ptr<PlanBase>(new PlanT<double>()); }
+
+// metrics.py:14 (sc, dB), :28-29 (snr), :43 (ser) from the whole-tensor sums
+// sums = { sum((out-target)^2), sum(out^2), sum(target^2), count }
+double metric_from_sums(int metric, const double s[4]) {
+  switch (metric) {
+    case SPECINV_METRIC_SC:
+      return 20.0 * (std::log10(std::sqrt(s[0])) - std::log10(std::sqrt(s[2])));
+    case SPECINV_METRIC_SNR:
+      return -10.0 * std::log10(s[0] / s[2]);
+    default:
+      return 10.0 * (std::log10(s[1]) - std::log10(s[0]));
+  }
+}
+
+// _training_loop, methods.py:153-190.  Iterations between evaluations are enqueued back to
+// back; the host only synchronises at an evaluation.
+int PlanBase::run_loop(int max_iter, int eva_iter, double tol, int metric, specinv_eval* evals, int* n_evals,
+                       int* iters_done, specinv_eval_cb cb, void* user) {
+  SI_CHECK(eva_iter > 0, SPECINV_EINVAL, "eva_iter must be > 0");    // :163
+  SI_CHECK(max_iter > 0, SPECINV_EINVAL, "max_iter must be > 0");    // :164
+  SI_CHECK(tol >= 0, SPECINV_EINVAL, "tol must be >= 0");            // :165
+  SI_CHECK(metric >= 0 && metric <= 2, SPECINV_EINVAL, "unknown metric");  // :168
+  double init_loss = 0, prev = 0;
+  bool have_init = false;
+  int done = 0, ne = 0;
+  while (done < max_iter) {
+    const int until_eval = eva_iter - (done % eva_iter);             // next i with i % eva == eva-1
+    if (done + until_eval > max_iter) {
+      SI_TRY(iterate(max_iter - done, false, nullptr));
+      done = max_iter;
+      break;
+    }
+    double s[4];
+    SI_TRY(iterate(until_eval, true, s));
+    done += until_eval;
+    specinv_eval ev;
+    ev.iteration = done - 1;
+    ev.metric = metric_from_sums(metric, s);
+    ev.loss = s[0] / s[3];                                            // F.mse_loss, :182
+    if (evals) evals[ne] = ev;
+    ++ne;
+    if (cb && cb(&ev, user) != 0) break;
+    if (!have_init || init_loss == 0.0) {                             // `if not init_loss`, :186
+      init_loss = ev.loss;
+      have_init = true;
+    } else if ((prev - ev.loss) / init_loss < tol && prev > ev.loss) {  // :188
+      break;
+    }
+    prev = ev.loss;
+  }
+  if (n_evals) *n_evals = ne;
+  if (iters_done) *iters_done = done;
+  return SPECINV_OK;
+}
+
+}  // namespace specinv
+
+using namespace specinv;
+
+#define PLAN_OR_FAIL(p) SI_CHECK((p) != nullptr && (p)->impl, SPECINV_EINVAL, "plan is NULL")
+
+extern "C" {
+
+const char* specinv_last_error(void) { return last_error().c_str(); }
+int specinv_abi_version(void) { return SPECINV_ABI_VERSION; }
+
+int specinv_plan_create(const specinv_stft_cfg* cfg, specinv_plan** out) {
+  SI_CHECK(cfg && out, SPECINV_EINVAL, "null argument");
+  SI_CHECK(cfg->dtype == SPECINV_F32 || cfg->dtype == SPECINV_F64, SPECINV_EINVAL, "bad dtype %d", cfg->dtype);
+  specinv_plan* p = new (std::nothrow) specinv_plan();
+  SI_CHECK(p, SPECINV_ENOMEM, "out of host memory");
+  p->impl = cfg->dtype == SPECINV_F32 ? make_plan_f32() : make_plan_f64();
+  p->impl->cfg = *cfg;
+  const int rc = p->impl->setup();
+  if (rc != SPECINV_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SPECINV_OK;
+}
+
+int specinv_plan_destroy(specinv_plan* plan) {
+  if (plan) {
+    if (plan->impl) (void)hipSetDevice(plan->impl->cfg.device);
+    delete plan;
+  }
+  return SPECINV_OK;
+}
+
+int specinv_plan_set_stream(specinv_plan* plan, void* hip_stream) {
+  PLAN_OR_FAIL(plan);
+  plan->impl->stream = static_cast<hipStream_t>(hip_stream);
+  return SPECINV_OK;
+}
+
+int specinv_plan_n_freq(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->n_freq : SPECINV_EINVAL; }
+int64_t specinv_plan_length(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->length : SPECINV_EINVAL; }
+int specinv_plan_fast_path(const specinv_plan* plan) { return plan && plan->impl ? (plan->impl->fast_path() ? 1 : 0) : SPECINV_EINVAL; }
+int specinv_plan_force_generic(specinv_plan* plan, int on) {
+  PLAN_OR_FAIL(plan);
+  SI_CHECK(plan->impl->method == Method::None, SPECINV_ESTATE, "cannot switch paths while a method is running");
+  plan->impl->force_generic = on != 0;
+  return SPECINV_OK;
+}
+
+#define ENTER(plan)                                 \
+  PLAN_OR_FAIL(plan);                               \
+  SI_HIP(hipSetDevice((plan)->impl->cfg.device))
+
+int specinv_stft(specinv_plan* plan, const void* x, int64_t length, void* spec_out) {
+  ENTER(plan);
+  return plan->impl->stft(x, length, spec_out);
+}
+int specinv_istft(specinv_plan* plan, const void* spec, void* x_out) {
+  ENTER(plan);
+  return plan->impl->istft(spec, x_out);
+}
+int specinv_envelope(specinv_plan* plan, void* env_out) {
+  ENTER(plan);
+  return plan->impl->envelope(env_out);
+}
+int specinv_phase_init(specinv_plan* plan, const void* mag, void* spec_out) {
+  ENTER(plan);
+  return plan->impl->phase_init(mag, spec_out);
+}
+int specinv_metric_sums(specinv_plan* plan, const void* a, const void* b, int64_t n, double sums_host[4]) {
+  ENTER(plan);
+  SI_CHECK(sums_host, SPECINV_EINVAL, "sums_host is NULL");
+  return plan->impl->metric_sums(a, b, n, sums_host);
+}
+
+int specinv_gla_init(specinv_plan* plan, const void* init_spec, const void* mag, double alpha) {
+  ENTER(plan);
+  return plan->impl->gla_init(init_spec, mag, alpha);
+}
+int specinv_gla_iterate(specinv_plan* plan, int n_iter, int eval_last, double sums_host[4]) {
+  ENTER(plan);
+  SI_CHECK(plan->impl->method == Method::Gla, SPECINV_ESTATE, "specinv_gla_init has not been called");
+  return plan->impl->iterate(n_iter, eval_last != 0, sums_host);
+}
+int specinv_gla_run(specinv_plan* plan, int max_iter, int eva_iter, double tol, int metric, specinv_eval* evals_out,
+                    int* n_evals_out, int* iters_done_out, specinv_eval_cb cb, void* user) {
+  ENTER(plan);
+  SI_CHECK(plan->impl->method == Method::Gla, SPECINV_ESTATE, "specinv_gla_init has not been called");
+  return plan->impl->run_loop(max_iter, eva_iter, tol, metric, evals_out, n_evals_out, iters_done_out, cb, user);
+}
+
+int specinv_admm_init(specinv_plan* plan, const void* init_spec, const void* mag, double rho) {
+  ENTER(plan);
+  return plan->impl->admm_init(init_spec, mag, rho);
+}
+int specinv_admm_iterate(specinv_plan* plan, int n_iter, int eval_last, double sums_host[4]) {
+  ENTER(plan);
+  SI_CHECK(plan->impl->method == Method::Admm, SPECINV_ESTATE, "specinv_admm_init has not been called");
+  return plan->impl->iterate(n_iter, eval_last != 0, sums_host);
+}
+int specinv_admm_run(specinv_plan* plan, int max_iter, int eva_iter, double tol, int metric, specinv_eval* evals_out,
+                     int* n_evals_out, int* iters_done_out, specinv_eval_cb cb, void* user) {
+  ENTER(plan);
+  SI_CHECK(plan->impl->method == Method::Admm, SPECINV_ESTATE, "specinv_admm_init has not been called");
+  return plan->impl->run_loop(max_iter, eva_iter, tol, metric, evals_out, n_evals_out, iters_done_out, cb, user);
+}
+
+int specinv_get_wave(specinv_plan* plan, void* x_out) {
+  ENTER(plan);
+  return plan->impl->get_wave(x_out);
+}
+int specinv_get_state_spec(specinv_plan* plan, int which, void* spec_out) {
+  ENTER(plan);
+  return plan->impl->get_state_spec(which, spec_out);
+}
+
+int specinv_rtisi_run(specinv_plan* plan, const void* mag, int look_ahead, int asymmetric_window, int max_iter,
+                      double alpha, void* x_out) {
+  ENTER(plan);
+  return plan->impl->rtisi_run(mag, look_ahead, asymmetric_window, max_iter, alpha, x_out);
+}
+
+int specinv_transform_setup(specinv_plan* plan, int kind, const void* mel_fb, int n_mels) {
+  ENTER(plan);
+  return plan->impl->transform_setup(kind, mel_fb, n_mels);
+}
+int specinv_transform_forward(specinv_plan* plan, const void* x, int64_t length, void* v_out) {
+  ENTER(plan);
+  return plan->impl->transform_forward(x, length, v_out);
+}
+int specinv_transform_loss_grad(specinv_plan* plan, const void* x, int64_t length, const void* target,
+                                double* loss_host, void* grad_out) {
+  ENTER(plan);
+  return plan->impl->transform_loss_grad(x, length, target, loss_host, grad_out);
+}
+int specinv_vec_dot(specinv_plan* plan, const void* a, const void* b, int64_t n, double* out_host) {
+  ENTER(plan);
+  return plan->impl->vec_dot(a, b, n, out_host);
+}
+int specinv_vec_axpy(specinv_plan* plan, double alpha, const void* x, void* y, int64_t n) {
+  ENTER(plan);
+  return plan->impl->vec_axpy(alpha, x, y, n);
+}
+int specinv_vec_scale(specinv_plan* plan, double alpha, const void* x, void* y, int64_t n) {
+  ENTER(plan);
+  return plan->impl->vec_scale(alpha, x, y, n);
+}
+int specinv_vec_absmax_abssum(specinv_plan* plan, const void* x, int64_t n, double out_host[2]) {
+  ENTER(plan);
+  return plan->impl->vec_absmax_abssum(x, n, out_host);
+}
+
+}  // extern "C"

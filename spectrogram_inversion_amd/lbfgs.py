@@ -1,0 +1,226 @@
+"""L-BFGS optimiser used by `L_BFGS` (reference: torch_specinv/methods.py:543,553 hand the
+problem to the third-party `torch.optim.LBFGS`).
+
+This is an independent implementation of that optimiser's published algorithm with its
+option names and defaults (lr, max_iter, max_eval, tolerance_grad, tolerance_change,
+history_size, line_search_fn): limited-memory BFGS two-loop recursion, first step length
+min(1, 1/|g|_1)*lr, curvature guard y.s > 1e-10, initial Hessian scale y.s/y.y, optional
+strong-Wolfe line search by cubic interpolation.  The host only runs the control flow;
+all vector arithmetic (dot, axpy, scale, |.|max / |.|1) is done by libspecinv's HIP
+reduction kernels through a `VecOps` backend, with dot products accumulated in float64.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .plan import StftArgs, get_plan
+
+
+class HipVecOps:
+    """Vector primitives on the HIP device (libspecinv vec_* entry points)."""
+
+    def __init__(self, dtype, device):
+        args = StftArgs(2, 2, 1, torch.ones(2, dtype=dtype), False, "reflect", False, True)
+        self.plan = get_plan(args, 1, 1, dtype, device)
+
+    def dot(self, a, b):
+        return self.plan.vec_dot(a, b)
+
+    def axpy(self, alpha, x, y):
+        self.plan.vec_axpy(alpha, x, y)
+
+    def scaled(self, alpha, x):
+        out = torch.empty_like(x)
+        self.plan.vec_scale(alpha, x, out)
+        return out
+
+    def absmax_abssum(self, x):
+        return self.plan.vec_absmax_abssum(x)
+
+
+def _cubic_step(xa, fa, ga, xb, fb, gb, bounds=None):
+    """Minimiser of the cubic interpolating (xa, fa, ga) and (xb, fb, gb), clipped to bounds."""
+    lo, hi = bounds if bounds is not None else ((xa, xb) if xa <= xb else (xb, xa))
+    d1 = ga + gb - 3.0 * (fa - fb) / (xa - xb)
+    disc = d1 * d1 - ga * gb
+    if disc < 0:
+        return 0.5 * (lo + hi)
+    d2 = math.sqrt(disc)
+    if xa <= xb:
+        pos = xb - (xb - xa) * ((gb + d2 - d1) / (gb - ga + 2.0 * d2))
+    else:
+        pos = xa - (xa - xb) * ((ga + d2 - d1) / (ga - gb + 2.0 * d2))
+    return min(max(pos, lo), hi)
+
+
+class LBFGS:
+    """Optimises the flat tensor `x` in place.  `step(fg)` performs one `optimizer.step`:
+    `fg(x)` must return (loss: float, grad: tensor like x)."""
+
+    def __init__(self, x, device=None, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7,
+                 tolerance_change=1e-9, history_size=100, line_search_fn=None, vec_ops=None):
+        if not 0.0 <= lr:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        if line_search_fn not in (None, "strong_wolfe"):
+            raise RuntimeError("only 'strong_wolfe' is supported")
+        self.x = x
+        self.lr, self.max_iter = float(lr), int(max_iter)
+        self.max_eval = int(max_eval) if max_eval is not None else self.max_iter * 5 // 4
+        self.tol_grad, self.tol_change = tolerance_grad, tolerance_change
+        self.history_size, self.line_search = int(history_size), line_search_fn
+        self.ops = vec_ops if vec_ops is not None else HipVecOps(x.dtype, x.device if device is None else device)
+        self.total_iters = 0
+        self.func_evals = 0
+        self.d = None
+        self.t = None
+        self.ys, self.ss, self.rho = [], [], []
+        self.h_diag = 1.0
+        self.prev_grad = None
+        self.prev_loss = None
+
+    # ---- pieces -----------------------------------------------------------------------------
+    def _direction(self, g):
+        """Two-loop recursion: returns -H g for the current memory."""
+        ops = self.ops
+        m = len(self.ys)
+        q = ops.scaled(-1.0, g)
+        al = [0.0] * m
+        for i in range(m - 1, -1, -1):
+            al[i] = ops.dot(self.ss[i], q) * self.rho[i]
+            ops.axpy(-al[i], self.ys[i], q)
+        r = ops.scaled(self.h_diag, q)
+        for i in range(m):
+            be = ops.dot(self.ys[i], r) * self.rho[i]
+            ops.axpy(al[i] - be, self.ss[i], r)
+        return r
+
+    def _wolfe(self, fg, x0, t, d, f0, g0, gtd0, max_ls, c1=1e-4, c2=0.9):
+        ops = self.ops
+
+        def phi(step):
+            trial = x0.clone()
+            ops.axpy(step, d, trial)
+            f, g = fg(trial)
+            return f, g, ops.dot(g, d)
+
+        d_norm = ops.absmax_abssum(d)[0]
+        f_new, g_new, gtd_new = phi(t)
+        evals, it = 1, 0
+        t_prev, f_prev, g_prev, gtd_prev = 0.0, f0, g0, gtd0
+        done, br = False, None
+        while it < max_ls:
+            if f_new > f0 + c1 * t * gtd0 or (it > 1 and f_new >= f_prev):
+                br = [[t_prev, f_prev, g_prev, gtd_prev], [t, f_new, g_new, gtd_new]]
+                break
+            if abs(gtd_new) <= -c2 * gtd0:
+                br, done = [[t, f_new, g_new, gtd_new]], True
+                break
+            if gtd_new >= 0:
+                br = [[t_prev, f_prev, g_prev, gtd_prev], [t, f_new, g_new, gtd_new]]
+                break
+            nxt = _cubic_step(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, (t + 0.01 * (t - t_prev), t * 10))
+            t_prev, f_prev, g_prev, gtd_prev = t, f_new, g_new, gtd_new
+            t = nxt
+            f_new, g_new, gtd_new = phi(t)
+            evals += 1
+            it += 1
+        if it == max_ls:
+            br = [[0.0, f0, g0, gtd0], [t, f_new, g_new, gtd_new]]
+
+        stalled = False
+        lo, hi = (0, 1) if br[0][1] <= br[-1][1] else (1, 0)
+        while not done and it < max_ls:
+            if abs(br[1][0] - br[0][0]) * d_norm < self.tol_change:
+                break
+            t = _cubic_step(br[0][0], br[0][1], br[0][3], br[1][0], br[1][1], br[1][3])
+            bmax, bmin = max(br[0][0], br[1][0]), min(br[0][0], br[1][0])
+            margin = 0.1 * (bmax - bmin)
+            if min(bmax - t, t - bmin) < margin:
+                if stalled or t >= bmax or t <= bmin:
+                    t = bmax - margin if abs(t - bmax) < abs(t - bmin) else bmin + margin
+                    stalled = False
+                else:
+                    stalled = True
+            else:
+                stalled = False
+            f_new, g_new, gtd_new = phi(t)
+            evals += 1
+            it += 1
+            if f_new > f0 + c1 * t * gtd0 or f_new >= br[lo][1]:
+                br[hi] = [t, f_new, g_new, gtd_new]
+                lo, hi = (0, 1) if br[0][1] <= br[1][1] else (1, 0)
+            else:
+                if abs(gtd_new) <= -c2 * gtd0:
+                    done = True
+                elif gtd_new * (br[hi][0] - br[lo][0]) >= 0:
+                    br[hi] = list(br[lo])
+                br[lo] = [t, f_new, g_new, gtd_new]
+        if len(br) == 1:
+            lo = 0
+        return br[lo][1], br[lo][2], br[lo][0], evals
+
+    # ---- one optimizer.step ------------------------------------------------------------------
+    def step(self, fg):
+        ops, x = self.ops, self.x
+        loss, g = fg(x)
+        first_loss = loss
+        evals = 1
+        self.func_evals += 1
+        if ops.absmax_abssum(g)[0] <= self.tol_grad:
+            return first_loss
+        d, t = self.d, self.t
+        n_iter = 0
+        while n_iter < self.max_iter:
+            n_iter += 1
+            self.total_iters += 1
+            if self.total_iters == 1:
+                d = ops.scaled(-1.0, g)
+                self.ys, self.ss, self.rho, self.h_diag = [], [], [], 1.0
+            else:
+                y = g.clone()
+                ops.axpy(-1.0, self.prev_grad, y)
+                s = ops.scaled(t, d)
+                ys = ops.dot(y, s)
+                if ys > 1e-10:
+                    if len(self.ys) == self.history_size:
+                        self.ys.pop(0)
+                        self.ss.pop(0)
+                        self.rho.pop(0)
+                    self.ys.append(y)
+                    self.ss.append(s)
+                    self.rho.append(1.0 / ys)
+                    self.h_diag = ys / ops.dot(y, y)
+                d = self._direction(g)
+            self.prev_grad = g.clone()
+            self.prev_loss = loss
+            if self.total_iters == 1:
+                t = min(1.0, 1.0 / ops.absmax_abssum(g)[1]) * self.lr
+            else:
+                t = self.lr
+            gtd = ops.dot(g, d)
+            if gtd > -self.tol_change:
+                break
+            ls_evals = 0
+            if self.line_search is not None:
+                loss, g, t, ls_evals = self._wolfe(fg, x.clone(), t, d, loss, g, gtd, self.max_eval - evals)
+                ops.axpy(t, d, x)
+                opt = ops.absmax_abssum(g)[0] <= self.tol_grad
+            else:
+                ops.axpy(t, d, x)
+                opt = False
+                if n_iter != self.max_iter:
+                    loss, g = fg(x)
+                    opt = ops.absmax_abssum(g)[0] <= self.tol_grad
+                    ls_evals = 1
+            evals += ls_evals
+            self.func_evals += ls_evals
+            if n_iter == self.max_iter or evals >= self.max_eval or opt:
+                break
+            if abs(t) * ops.absmax_abssum(d)[0] <= self.tol_change:
+                break
+            if abs(loss - self.prev_loss) < self.tol_change:
+                break
+        self.d, self.t = d, t
+        return first_loss

@@ -1,0 +1,174 @@
+"""Drop-in host layer: the public functions of the reference's
+`torch_specinv/methods.py` (exported at torch_specinv/__init__.py:6) with the same
+names, argument meaning, defaults and error behaviour, running on libspecinv's
+HIP kernels.
+
+Differences that are deliberate:
+  * compute always happens on the HIP device.  Tensors that live on the CPU are
+    staged to the current HIP device and the result is returned on the input's
+    device; without a GPU the functions raise (there is no CPU fallback).
+  * results are not differentiable w.r.t. `spec`.
+"""
+from __future__ import annotations
+
+import torch
+from tqdm import tqdm
+
+from . import _lib
+from .lbfgs import LBFGS as _LBFGS
+from .plan import args_helper, get_plan, require_gpu
+from .transforms import DeviceTransform
+
+__all__ = ["griffin_lim", "RTISI_LA", "ADMM", "L_BFGS", "phase_init"]
+
+
+def _format_spec(spec):
+    """methods.py:99-111 shape rules (2-D -> (1, F, T); rank must be 2 or 3)."""
+    assert 4 > spec.dim() > 1
+    return spec.unsqueeze(0) if spec.dim() == 2 else spec
+
+
+def _finish(x, spec, out_device):
+    """methods.py:267-270: squeeze unless the input was exactly (1, F, T)."""
+    if not (spec.shape[0] == 1 and spec.dim() == 3):
+        x = x.squeeze(0)
+    return x.to(out_device)
+
+
+def _run_loop(plan, max_iter, tol, verbose, eva_iter, metric):
+    """Drives the library's `_training_loop` (methods.py:153-190) and mirrors its tqdm bar."""
+    assert eva_iter > 0
+    assert max_iter > 0
+    assert tol >= 0
+    assert isinstance(metric, str) and metric.upper() in _lib.METRICS
+    name = metric.upper()
+    with tqdm(total=max_iter, disable=not verbose) as pbar:
+        def on_eval(_it, m, loss):
+            pbar.set_postfix(**{name: m}, loss=loss)
+            pbar.update(eva_iter)
+            return 0
+        return plan.run(max_iter, eva_iter, tol, metric, callback=on_eval if verbose else None)
+
+
+def _iterative(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, stft_kwargs):
+    spec3 = _format_spec(spec)
+    real_in = not spec3.is_complex()
+    args = args_helper(spec3, **stft_kwargs)
+    device = require_gpu(spec3.device)
+    rdtype = spec3.real.dtype if spec3.is_complex() else spec3.dtype
+    plan = get_plan(args, spec3.shape[0], spec3.shape[2], rdtype, device)
+    init = getattr(plan, which + "_init")
+    if real_in:
+        init(None, spec3, coef)        # phase_init on the device (methods.py:106)
+    else:
+        init(spec3, None, coef)        # target = |spec| (methods.py:110)
+    _run_loop(plan, max_iter, tol, verbose, eva_iter, metric)
+    return _finish(plan.wave(), spec, spec.device)
+
+
+def griffin_lim(spec, max_iter=200, tol=1e-6, alpha=0.99, verbose=True, eva_iter=10, metric="sc", **stft_kwargs):
+    r"""Griffin-Lim / Fast Griffin-Lim phase reconstruction (reference: methods.py:193-270).
+
+    Args and return value are those of `torch_specinv.methods.griffin_lim`: `spec` is a
+    magnitude (F, T) / (B, F, T) tensor, or a complex one to warm-start from; `alpha` is the
+    Fast-Griffin-Lim momentum (default 0.99, methods.py:196); `**stft_kwargs` are the
+    `torch.stft` arguments the spectrogram was computed with.  Returns (L,) / (B, L).
+    """
+    assert alpha >= 0
+    return _iterative("gla", spec, alpha, max_iter, tol, verbose, eva_iter, metric, stft_kwargs)
+
+
+def ADMM(spec, max_iter=1000, tol=1e-6, rho=0.1, verbose=1, eva_iter=10, metric="sc", **stft_kwargs):
+    r"""Griffin-Lim-like phase recovery via ADMM (reference: methods.py:415-506)."""
+    assert eva_iter > 0
+    assert max_iter > 0
+    assert tol >= 0
+    assert isinstance(metric, str) and metric.upper() in _lib.METRICS
+    return _iterative("admm", spec, rho, max_iter, tol, verbose, eva_iter, metric, stft_kwargs)
+
+
+def RTISI_LA(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, alpha=0.99, verbose=1, **stft_kwargs):
+    r"""Real-Time Iterative Spectrogram Inversion with Look-Ahead (reference: methods.py:273-412).
+
+    The whole frame-serial recursion runs inside one kernel launch per batch (one workgroup
+    per batch item), so `verbose` has no per-frame progress to show.
+    """
+    assert max_iter > 0
+    assert alpha >= 0
+    assert not spec.is_complex()
+    spec3 = _format_spec(spec)
+    args = args_helper(spec3, **stft_kwargs)
+    device = require_gpu(spec3.device)
+    plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
+    x = plan.rtisi(spec3, look_ahead, asymmetric_window, max_iter, alpha)
+    return _finish(x, spec, spec.device)
+
+
+def phase_init(spec, **stft_kwargs):
+    r"""Single-pass phase initialisation (reference: methods.py:572-615).  Returns a complex
+    tensor of the input's shape."""
+    assert not spec.is_complex()
+    shape = spec.shape
+    spec3 = spec.unsqueeze(0) if spec.dim() == 2 else spec
+    assert spec3.dim() == 3
+    args = args_helper(spec3, **stft_kwargs)
+    device = require_gpu(spec3.device)
+    plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
+    return plan.phase_init(spec3).view(shape).to(spec.device)
+
+
+def L_BFGS(spec, transform_fn, samples=None, init_x0=None, outer_max_iter=1000, tol=1e-6, verbose=1, eva_iter=10,
+           metric="sc", **kwargs):
+    r"""Waveform optimisation with L-BFGS (reference: methods.py:509-569).
+
+    `transform_fn` is either a `spectrogram_inversion_amd.transforms.DeviceTransform`
+    (`MagSTFT`, `LogMelSTFT`: fused HIP forward + analytic backward) or any differentiable
+    callable like in the reference (then torch autograd evaluates it and only the optimiser's
+    vector arithmetic runs on libspecinv's kernels).  `**kwargs` go to the optimiser with
+    `torch.optim.LBFGS`'s names and defaults.
+    """
+    assert eva_iter > 0
+    assert outer_max_iter > 0
+    assert tol >= 0
+    assert isinstance(metric, str) and metric.upper() in _lib.METRICS
+    device = require_gpu(spec.device)
+    if init_x0 is None:
+        init_x0 = spec.new_empty(*samples).normal_(std=1e-6)             # methods.py:538
+    out_device = init_x0.device
+    x = init_x0.detach().to(device=device).clone().contiguous()
+    target = spec.detach().to(device)
+
+    if isinstance(transform_fn, DeviceTransform):
+        fwd, fg = transform_fn.bind(x, target)
+    else:
+        def fwd(v):
+            with torch.no_grad():
+                return transform_fn(v)
+
+        def fg(v):
+            p = v.detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                loss = torch.nn.functional.mse_loss(transform_fn(p), target)   # methods.py:547-549
+            (g,) = torch.autograd.grad(loss, p)
+            return float(loss), g.contiguous()
+
+    opt = _LBFGS(x, device=device, **kwargs)
+    name = metric.upper()
+    from .metrics import _sums, _from_sums
+    init_loss = None
+    previous_loss = None
+    with tqdm(total=outer_max_iter, disable=not verbose) as pbar:
+        for i in range(outer_max_iter):                                   # _training_loop, :178
+            opt.step(fg)                                                  # :553
+            if i % eva_iter == eva_iter - 1:
+                v = fwd(x)                                                # :554-556
+                s = _sums(v, target.reshape(v.shape))
+                m, l2 = _from_sums(name, s), s[0] / s[3]
+                pbar.set_postfix(**{name: m}, loss=l2)
+                pbar.update(eva_iter)
+                if not init_loss:
+                    init_loss = l2
+                elif (previous_loss - l2) / init_loss < tol and previous_loss > l2:
+                    break
+                previous_loss = l2
+    return x.to(out_device)

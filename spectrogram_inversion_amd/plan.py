@@ -1,0 +1,322 @@
+"""Python handle on a libspecinv plan: argument normalisation (the reference's
+`_args_helper`, torch_specinv/methods.py:21-91) and thin typed wrappers over the
+C ABI.  torch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+_REAL = {torch.complex64: torch.float32, torch.complex128: torch.float64, torch.complex32: torch.float16}
+_CPLX = {torch.float32: torch.complex64, torch.float64: torch.complex128}
+_RECOGNISED = ("win_length", "window", "hop_length", "center", "pad_mode", "normalized", "onesided",
+               "return_complex")
+
+
+@dataclass
+class StftArgs:
+    """What `_args_helper` returns (methods.py:85-91), window already centre-padded."""
+    n_fft: int
+    win_length: int
+    hop_length: int
+    window: torch.Tensor
+    center: bool
+    pad_mode: str
+    normalized: bool
+    onesided: bool
+
+    @property
+    def n_freq(self):
+        return self.n_fft // 2 + 1 if self.onesided else self.n_fft
+
+    @property
+    def padding(self):
+        return self.n_fft // 2 if self.center else 0
+
+    def signal_length(self, n_frames):
+        return (n_frames - 1) * self.hop_length + self.n_fft - 2 * self.padding
+
+    def frame_count(self, length):
+        return 1 + (length + 2 * self.padding - self.n_fft) // self.hop_length
+
+
+def args_helper(spec: torch.Tensor, **stft_kwargs) -> StftArgs:
+    """methods.py:21-91.  Unknown kwargs are silently ignored (:42-46)."""
+    kw = {k: stft_kwargs[k] for k in _RECOGNISED if k in stft_kwargs}
+    win_length = kw.get("win_length", None)
+    window = kw.get("window", None)
+    hop_length = kw.get("hop_length", None)
+    center = kw.get("center", True)
+    pad_mode = kw.get("pad_mode", "reflect")
+    normalized = kw.get("normalized", False)
+    onesided = kw.get("onesided", None)
+
+    dtype = _REAL.get(spec.dtype, spec.dtype)                         # :49-57
+    if onesided is None:                                              # :59-63
+        onesided = not (window is not None and window.is_complex())
+    n_fft = (spec.shape[-2] - 1) * 2 if onesided else spec.shape[-2]  # :65-68
+    if not win_length:                                                # :70-71
+        win_length = n_fft
+    if not hop_length:                                                # :73-74
+        hop_length = n_fft // 4
+    if window is None:                                                # :76-77
+        window = torch.ones(win_length, dtype=dtype)
+    assert n_fft >= win_length                                        # :79
+    if window.is_complex():
+        raise NotImplementedError("complex windows are not supported on the device path")
+    window = window.detach().to(device="cpu", dtype=dtype).reshape(-1)
+    assert window.numel() == win_length
+    if n_fft > win_length:                                            # :80-83
+        left = (n_fft - win_length) // 2
+        right = (n_fft - win_length + 1) // 2
+        window = torch.nn.functional.pad(window, [left, right])
+        win_length = n_fft
+    return StftArgs(int(n_fft), int(win_length), int(hop_length), window.contiguous(), bool(center),
+                    str(pad_mode), bool(normalized), bool(onesided))
+
+
+def require_gpu(device: torch.device | None = None) -> torch.device:
+    """The engine only runs on the HIP device; there is no CPU path."""
+    if device is not None and device.type == "cuda":
+        return device
+    if not torch.cuda.is_available():
+        raise RuntimeError("spectrogram_inversion_amd needs an MI355X (HIP) device; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Plan:
+    """One (device, dtype, batch, frames, stft-args) problem."""
+
+    def __init__(self, args: StftArgs, batch: int, n_frames: int, dtype: torch.dtype, device: torch.device):
+        if dtype not in _CPLX:
+            raise NotImplementedError(f"dtype {dtype} is not supported on the device path (float32/float64 only)")
+        if args.pad_mode not in _lib.PAD_MODES:
+            raise AssertionError(f"unknown pad_mode {args.pad_mode!r}")
+        self.lib = _lib.load()
+        self.args = args
+        self.batch, self.n_frames = int(batch), int(n_frames)
+        self.dtype, self.cdtype = dtype, _CPLX[dtype]
+        self.device = device
+        win = args.window.to(dtype=dtype, device="cpu").contiguous()
+        cfg = _lib.StftCfg(args.n_fft, args.hop_length, self.n_frames, self.batch, int(args.center),
+                           _lib.PAD_MODES[args.pad_mode], int(args.normalized), int(args.onesided),
+                           _lib.F32 if dtype == torch.float32 else _lib.F64,
+                           device.index if device.index is not None else torch.cuda.current_device(),
+                           win.data_ptr())
+        handle = C.c_void_p()
+        _lib.check(self.lib.specinv_plan_create(C.byref(cfg), C.byref(handle)))
+        self._h = handle
+        self.n_freq = self.lib.specinv_plan_n_freq(self._h)
+        self.length = int(self.lib.specinv_plan_length(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self.lib.specinv_plan_destroy(h)
+            except Exception:
+                pass
+
+    # -- helpers ------------------------------------------------------------------------
+    def _sync_stream(self):
+        s = torch.cuda.current_stream(self.device)
+        _lib.check(self.lib.specinv_plan_set_stream(self._h, C.c_void_p(s.cuda_stream)))
+
+    def _in(self, t: torch.Tensor, dtype, shape=None):
+        t = t.detach().to(device=self.device, dtype=dtype).contiguous()
+        if shape is not None:
+            assert tuple(t.shape) == tuple(shape), f"expected shape {tuple(shape)}, got {tuple(t.shape)}"
+        return t
+
+    def _spec_shape(self):
+        return (self.batch, self.n_freq, self.n_frames)
+
+    @property
+    def fast_path(self) -> bool:
+        return bool(self.lib.specinv_plan_fast_path(self._h))
+
+    def force_generic(self, on=True):
+        _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))
+
+    # -- building blocks ------------------------------------------------------------------
+    def stft(self, x: torch.Tensor) -> torch.Tensor:
+        self._sync_stream()
+        x = self._in(x, self.dtype)
+        assert x.dim() == 2 and x.shape[0] == self.batch
+        out = torch.empty(self._spec_shape(), dtype=self.cdtype, device=self.device)
+        _lib.check(self.lib.specinv_stft(self._h, x.data_ptr(), x.shape[1], out.data_ptr()))
+        return out
+
+    def istft(self, spec: torch.Tensor) -> torch.Tensor:
+        self._sync_stream()
+        spec = self._in(spec, self.cdtype, self._spec_shape())
+        out = torch.empty((self.batch, self.length), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.specinv_istft(self._h, spec.data_ptr(), out.data_ptr()))
+        return out
+
+    def envelope(self) -> torch.Tensor:
+        self._sync_stream()
+        out = torch.empty((self.length,), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.specinv_envelope(self._h, out.data_ptr()))
+        return out
+
+    def phase_init(self, mag: torch.Tensor) -> torch.Tensor:
+        self._sync_stream()
+        mag = self._in(mag, self.dtype, self._spec_shape())
+        out = torch.empty(self._spec_shape(), dtype=self.cdtype, device=self.device)
+        _lib.check(self.lib.specinv_phase_init(self._h, mag.data_ptr(), out.data_ptr()))
+        return out
+
+    def metric_sums(self, a: torch.Tensor, b: torch.Tensor):
+        self._sync_stream()
+        a = self._in(a, self.dtype)
+        b = self._in(b, self.dtype, a.shape)
+        sums = (C.c_double * 4)()
+        _lib.check(self.lib.specinv_metric_sums(self._h, a.data_ptr(), b.data_ptr(), a.numel(), sums))
+        return list(sums)
+
+    # -- iterative methods ----------------------------------------------------------------
+    def _init(self, fn, init_spec, mag, coef):
+        self._sync_stream()
+        keep = []
+        ip = mp = None
+        if init_spec is not None:
+            keep.append(self._in(init_spec, self.cdtype, self._spec_shape()))
+            ip = keep[-1].data_ptr()
+        if mag is not None:
+            keep.append(self._in(mag, self.dtype, self._spec_shape()))
+            mp = keep[-1].data_ptr()
+        _lib.check(fn(self._h, ip, mp, float(coef)))
+
+    def gla_init(self, init_spec, mag, alpha):
+        self._init(self.lib.specinv_gla_init, init_spec, mag, alpha)
+        self._method = "gla"
+
+    def admm_init(self, init_spec, mag, rho):
+        self._init(self.lib.specinv_admm_init, init_spec, mag, rho)
+        self._method = "admm"
+
+    def iterate(self, n_iter: int, eval_last: bool = False):
+        self._sync_stream()
+        fn = self.lib.specinv_gla_iterate if self._method == "gla" else self.lib.specinv_admm_iterate
+        sums = (C.c_double * 4)()
+        _lib.check(fn(self._h, int(n_iter), int(eval_last), sums))
+        return list(sums) if eval_last else None
+
+    def run(self, max_iter, eva_iter=10, tol=0.0, metric="sc", callback=None):
+        """The reference's `_training_loop` (methods.py:153-190) executed by the library.
+        Returns (iterations_done, [(iteration, metric, loss), ...])."""
+        self._sync_stream()
+        assert isinstance(metric, str) and metric.upper() in _lib.METRICS          # :167-168
+        fn = self.lib.specinv_gla_run if self._method == "gla" else self.lib.specinv_admm_run
+        cap = max(1, int(max_iter) // max(1, int(eva_iter)) + 1)
+        evals = (_lib.Eval * cap)()
+        n_ev, done = C.c_int(0), C.c_int(0)
+        if callback is not None:
+            def _cb(evp, _user):
+                e = evp.contents
+                return int(bool(callback(e.iteration, e.metric, e.loss)))
+            cb = _lib.EVAL_CB(_cb)
+        else:
+            cb = _lib.EVAL_CB()
+        _lib.check(fn(self._h, int(max_iter), int(eva_iter), float(tol), _lib.METRICS[metric.upper()],
+                      evals, C.byref(n_ev), C.byref(done), cb, None))
+        return done.value, [(evals[i].iteration, evals[i].metric, evals[i].loss) for i in range(n_ev.value)]
+
+    def wave(self) -> torch.Tensor:
+        self._sync_stream()
+        out = torch.empty((self.batch, self.length), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.specinv_get_wave(self._h, out.data_ptr()))
+        return out
+
+    def state_spec(self, which=0) -> torch.Tensor:
+        self._sync_stream()
+        out = torch.empty(self._spec_shape(), dtype=self.cdtype, device=self.device)
+        _lib.check(self.lib.specinv_get_state_spec(self._h, int(which), out.data_ptr()))
+        return out
+
+    def rtisi(self, mag, look_ahead, asymmetric_window, max_iter, alpha) -> torch.Tensor:
+        self._sync_stream()
+        mag = self._in(mag, self.dtype, self._spec_shape())
+        out = torch.empty((self.batch, self.length), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.specinv_rtisi_run(self._h, mag.data_ptr(), int(look_ahead), int(bool(asymmetric_window)),
+                                              int(max_iter), float(alpha), out.data_ptr()))
+        return out
+
+    # -- L_BFGS building blocks -------------------------------------------------------------
+    def transform_setup(self, kind: int, mel_fb: torch.Tensor | None = None):
+        self._sync_stream()
+        if mel_fb is not None:
+            self._mel = self._in(mel_fb, self.dtype)
+            assert self._mel.dim() == 2 and self._mel.shape[1] == self.n_freq
+            _lib.check(self.lib.specinv_transform_setup(self._h, kind, self._mel.data_ptr(), self._mel.shape[0]))
+            self.n_out = self._mel.shape[0]
+        else:
+            _lib.check(self.lib.specinv_transform_setup(self._h, kind, None, 0))
+            self.n_out = self.n_freq
+
+    def transform_forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._sync_stream()
+        x = self._in(x, self.dtype)
+        out = torch.empty((self.batch, self.n_out, self.n_frames), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.specinv_transform_forward(self._h, x.data_ptr(), x.shape[-1], out.data_ptr()))
+        return out
+
+    def transform_loss_grad(self, x: torch.Tensor, target: torch.Tensor):
+        self._sync_stream()
+        x = self._in(x, self.dtype)
+        target = self._in(target, self.dtype, (self.batch, self.n_out, self.n_frames))
+        grad = torch.empty_like(x)
+        loss = C.c_double(0)
+        _lib.check(self.lib.specinv_transform_loss_grad(self._h, x.data_ptr(), x.shape[-1], target.data_ptr(),
+                                                        C.byref(loss), grad.data_ptr()))
+        return loss.value, grad
+
+    def vec_dot(self, a, b) -> float:
+        self._sync_stream()
+        out = C.c_double(0)
+        _lib.check(self.lib.specinv_vec_dot(self._h, a.data_ptr(), b.data_ptr(), a.numel(), C.byref(out)))
+        return out.value
+
+    def vec_axpy(self, alpha, x, y):
+        """y += alpha * x (in place)."""
+        self._sync_stream()
+        _lib.check(self.lib.specinv_vec_axpy(self._h, float(alpha), x.data_ptr(), y.data_ptr(), x.numel()))
+
+    def vec_scale(self, alpha, x, y):
+        """y = alpha * x."""
+        self._sync_stream()
+        _lib.check(self.lib.specinv_vec_scale(self._h, float(alpha), x.data_ptr(), y.data_ptr(), x.numel()))
+
+    def vec_absmax_abssum(self, x):
+        self._sync_stream()
+        out = (C.c_double * 2)()
+        _lib.check(self.lib.specinv_vec_absmax_abssum(self._h, x.data_ptr(), x.numel(), out))
+        return out[0], out[1]
+
+
+# small LRU of plans so that repeated calls with one configuration reuse device state
+_CACHE: "OrderedDict[tuple, Plan]" = OrderedDict()
+_CACHE_MAX = 4
+
+
+def get_plan(args: StftArgs, batch: int, n_frames: int, dtype: torch.dtype, device: torch.device) -> Plan:
+    key = (str(device), dtype, batch, n_frames, args.n_fft, args.hop_length, args.center, args.pad_mode,
+           args.normalized, args.onesided, args.window.to(torch.float64).numpy().tobytes())
+    plan = _CACHE.get(key)
+    if plan is None:
+        plan = Plan(args, batch, n_frames, dtype, device)
+        _CACHE[key] = plan
+        while len(_CACHE) > _CACHE_MAX:
+            _CACHE.popitem(last=False)
+    else:
+        _CACHE.move_to_end(key)
+    return plan
+
+
+def clear_plan_cache():
+    _CACHE.clear()

@@ -1,0 +1,86 @@
+"""Device transforms for `L_BFGS`: callables `x -> representation` whose forward pass and
+analytic loss gradient run as fused HIP kernels (|STFT| and log1p(mel @ |STFT|)).
+
+They stand in for the `transform_fn` closures of the reference's examples
+(README.md:55-73, test/test_lbfgs.py:17-18, main.py:21-43) on the fast path; any other
+differentiable callable is still accepted by `L_BFGS` and evaluated through autograd.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .plan import StftArgs, get_plan, require_gpu
+
+
+class DeviceTransform:
+    kind = None
+
+    def __init__(self, n_fft, hop_length=None, win_length=None, window=None, center=True, pad_mode="reflect",
+                 normalized=False, onesided=True):
+        if not win_length:
+            win_length = n_fft
+        if not hop_length:
+            hop_length = n_fft // 4
+        self.n_fft, self.hop_length, self.win_length = int(n_fft), int(hop_length), int(win_length)
+        self.window = window
+        self.center, self.pad_mode, self.normalized, self.onesided = bool(center), pad_mode, bool(normalized), bool(onesided)
+
+    def _args(self, dtype) -> StftArgs:
+        w = self.window
+        if w is None:
+            w = torch.ones(self.win_length, dtype=dtype)
+        w = w.detach().to("cpu", dtype).reshape(-1)
+        assert w.numel() == self.win_length and self.n_fft >= self.win_length
+        if self.n_fft > self.win_length:
+            left = (self.n_fft - self.win_length) // 2
+            w = torch.nn.functional.pad(w, [left, self.n_fft - self.win_length - left])
+        return StftArgs(self.n_fft, self.n_fft, self.hop_length, w.contiguous(), self.center, self.pad_mode,
+                        self.normalized, self.onesided)
+
+    def _mel(self):
+        return None
+
+    def _plan(self, x2):
+        args = self._args(x2.dtype)
+        device = require_gpu(x2.device)
+        plan = get_plan(args, x2.shape[0], args.frame_count(x2.shape[1]), x2.dtype, device)
+        plan.transform_setup(self.kind, self._mel())
+        return plan
+
+    def __call__(self, x):
+        x2 = x.reshape(1, -1) if x.dim() == 1 else x
+        v = self._plan(x2.to(require_gpu(x.device))).transform_forward(x2)
+        return (v[0] if x.dim() == 1 else v).to(x.device)
+
+    def bind(self, x, target):
+        """Returns (forward(x), loss_and_grad(x)) closures for the optimiser."""
+        x2 = x.reshape(1, -1) if x.dim() == 1 else x
+        plan = self._plan(x2)
+        tgt = target.reshape(plan.batch, plan.n_out, plan.n_frames)
+
+        def fwd(v):
+            return plan.transform_forward(v.reshape(x2.shape))
+
+        def fg(v):
+            loss, g = plan.transform_loss_grad(v.reshape(x2.shape), tgt)
+            return loss, g.reshape(v.shape)
+
+        return fwd, fg
+
+
+class MagSTFT(DeviceTransform):
+    """x -> |torch.stft(x, n_fft, ...)|  (B, F, T)."""
+    kind = _lib.TF_MAG
+
+
+class LogMelSTFT(DeviceTransform):
+    """x -> log1p(mel_fb @ |torch.stft(x, n_fft, ...)|)  (B, n_mels, T)."""
+    kind = _lib.TF_LOGMEL
+
+    def __init__(self, mel_fb, n_fft, **kw):
+        super().__init__(n_fft, **kw)
+        self.mel_fb = mel_fb
+
+    def _mel(self):
+        return self.mel_fb

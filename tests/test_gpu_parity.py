@@ -1,0 +1,239 @@
+"""Parity of the HIP path (through the C ABI) against the golden fixtures captured from the
+reference and against the CPU oracle on seeded inputs.  Needs an MI355X: `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _util import (G0_CASES, finite_close, g0_kwargs, hann, load_golden, rel_l2, sc_linear,
+                   sweep_kwargs)
+
+pytestmark = pytest.mark.gpu
+
+import spectrogram_inversion_amd as si                      # noqa: E402
+from spectrogram_inversion_amd.plan import args_helper, get_plan   # noqa: E402
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dev()) if dtype is None else t.to(dev(), dtype)
+
+
+def tkw(kw):
+    """numpy stft kwargs -> torch kwargs (window as tensor)."""
+    out = dict(kw)
+    if out.get("window") is not None:
+        out["window"] = torch.from_numpy(np.asarray(out["window"]))
+    return out
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def plan_for(spec_shape, dtype, **kw):
+    b, f, t = spec_shape
+    probe = torch.empty((1, f, 1), dtype=dtype)
+    a = args_helper(probe, **tkw(kw))
+    return get_plan(a, b, t, dtype, dev())
+
+
+# ---- library really is the HIP one ----------------------------------------------------------
+def test_native_library_loaded():
+    from spectrogram_inversion_amd import _lib
+    lib = _lib.load()
+    assert lib.specinv_abi_version() == 1
+    with open("/proc/self/maps") as fh:
+        assert "libspecinv.so" in fh.read()
+
+
+# ---- G0: stft / istft / envelope --------------------------------------------------------------
+@pytest.mark.parametrize("i", range(len(G0_CASES)))
+def test_stft_istft(i):
+    g = load_golden("g0_stft")
+    kw = g0_kwargs(G0_CASES[i])
+    spec_ref = g[f"spec{i}"]
+    plan = plan_for(spec_ref.shape, torch.float32, **kw)
+    s = N(plan.stft(T(g["x"])))
+    assert s.shape == spec_ref.shape
+    assert rel_l2(s, spec_ref) < 3e-6
+    env = N(plan.envelope())
+    assert finite_close(env, g[f"env{i}"], 1e-6)
+    y = N(plan.istft(T(spec_ref)))
+    e = g[f"env{i}"]
+    assert y.shape == g[f"istft{i}"].shape
+    assert finite_close(y * e, g[f"istft{i}"] * e, 2e-5)
+
+
+# ---- G1: phase_init -------------------------------------------------------------------------------
+@pytest.mark.parametrize("i", range(4))
+def test_phase_init(i):
+    g = load_golden("g1_phase_init")
+    mag = g[f"mag{i}"]
+    hop = int(g[f"hop{i}"])
+    kw = {"hop_length": hop} if hop else {}
+    out = N(si.phase_init(T(mag), **kw))
+    ref = g[f"out{i}"]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    # bit-exact up to the last-place rounding of cos/sin (<= 2 ulp of the magnitude)
+    err = np.abs(out - ref).max()
+    assert err <= 4 * np.finfo(np.float32).eps * np.abs(ref).max(), err
+    out64 = N(si.phase_init(T(mag.astype(np.float64)), **kw))
+    assert np.abs(out64 - g[f"out64_{i}"]).max() < 1e-9
+
+
+# ---- G2: griffin_lim ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
+@pytest.mark.parametrize("it", [1, 10, 100])
+def test_gla_waveforms(alpha, it):
+    g = load_golden("g2_gla")
+    kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
+    key = f"a{alpha}_it{it}"
+    y = N(si.griffin_lim(T(g["init"]), max_iter=it, alpha=alpha, tol=0, verbose=False, eva_iter=10, **kw))
+    ref, ref64 = g["wave_" + key], g["wave64_" + key]
+    noise = rel_l2(ref, ref64)
+    assert y.shape == ref.shape
+    # gate: waveform rel-L2 <= 1e-4 (north-star bar), and within a small multiple of the reference's own
+    # float32-vs-float64 noise
+    assert rel_l2(y, ref) < min(1e-4, max(6 * noise, 3e-6)), (rel_l2(y, ref), noise)
+
+
+def test_gla_trace_and_spectral_convergence():
+    g = load_golden("g2_gla")
+    kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
+    for alpha in (0.0, 0.3, 0.99):
+        spec = T(g["init"])
+        a = args_helper(spec, **kw)
+        plan = get_plan(a, spec.shape[0], spec.shape[2], torch.float32, dev())
+        plan.gla_init(spec, None, alpha)
+        done, evals = plan.run(100, 10, 0.0, "sc")
+        assert done == 100 and len(evals) == 10
+        tr = g[f"trace_a{alpha}_it100"]
+        got = np.array([[m, l] for _, m, l in evals])
+        assert np.abs(sc_linear(got[:, 0]) - sc_linear(tr[:, 0])).max() < 1e-5      # |dSC_lin| <= 1e-5
+        np.testing.assert_allclose(got[:, 1], tr[:, 1], rtol=2e-4)
+
+
+@pytest.mark.parametrize("metric", ["snr", "ser"])
+def test_gla_from_magnitude(metric):
+    g = load_golden("g2_gla")
+    kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
+    y = N(si.griffin_lim(T(g["mag"]), max_iter=20, alpha=0.3, tol=0, eva_iter=5, metric=metric, verbose=False, **kw))
+    assert rel_l2(y, g["wave_mag_" + metric]) < 1e-4
+
+
+def test_gla_early_stop_and_shapes():
+    g = load_golden("g2_gla")
+    kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
+    spec = T(g["init"])
+    a = args_helper(spec, **kw)
+    plan = get_plan(a, spec.shape[0], spec.shape[2], torch.float32, dev())
+    plan.gla_init(spec, None, 0.99)
+    done, _ = plan.run(2000, 10, 1e-6, "sc")
+    assert abs(done - int(g["iters_tol"])) <= 10, (done, int(g["iters_tol"]))
+    y2 = N(si.griffin_lim(T(g["mag"][0]), max_iter=3, alpha=0.3, tol=0, verbose=False, **kw))
+    assert y2.shape == g["wave_2d"].shape and rel_l2(y2, g["wave_2d"]) < 1e-5
+    y3 = N(si.griffin_lim(T(g["mag"][:1]), max_iter=3, alpha=0.3, tol=0, verbose=False, **kw))
+    assert y3.shape == g["wave_1ft"].shape and rel_l2(y3, g["wave_1ft"]) < 1e-5
+
+
+def test_cpu_tensor_roundtrip_device():
+    g = load_golden("g2_gla")
+    kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
+    y = si.griffin_lim(torch.from_numpy(g["mag"]), max_iter=2, alpha=0.3, tol=0, verbose=False, **kw)
+    assert y.device.type == "cpu" and y.shape == (2, 4992)
+
+
+# ---- G3: stft-kwarg sweep --------------------------------------------------------------------------------
+def _sweep_ids():
+    return list(range(len(load_golden("g3_sweep")["meta"])))
+
+
+@pytest.mark.parametrize("i", _sweep_ids())
+def test_kwarg_sweep(i):
+    g = load_golden("g3_sweep")
+    kw = tkw(sweep_kwargs(g["meta"][i]))
+    spec = T(g[f"spec{i}"])
+    y = N(si.griffin_lim(spec, max_iter=2, alpha=0.5, verbose=False, **kw))
+    assert y.shape == g[f"gla{i}"].shape
+    assert finite_close(y, g[f"gla{i}"], 5e-5), g["meta"][i]
+    z = N(si.ADMM(spec, max_iter=2, rho=0.5, verbose=False, **kw))
+    assert finite_close(z, g[f"admm{i}"], 5e-5), g["meta"][i]
+
+
+# ---- G4: ADMM ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rho", [0.1, 1.0])
+@pytest.mark.parametrize("it", [1, 2, 5])
+def test_admm_waveforms(rho, it):
+    g = load_golden("g4_admm")
+    kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
+    key = f"r{rho}_it{it}"
+    y = N(si.ADMM(T(g["init"]), max_iter=it, rho=rho, tol=0, verbose=False, **kw))
+    tol = {1: 5e-6, 2: 5e-5, 5: 5e-4}[it]      # rho=0.1 amplifies rounding ~10x per iteration
+    assert rel_l2(y, g["wave_" + key]) < tol
+
+
+@pytest.mark.parametrize("rho", [0.1, 1.0])
+def test_admm_200_sc(rho):
+    g = load_golden("g4_admm")
+    kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
+    spec = T(g["init"])
+    a = args_helper(spec, **kw)
+    plan = get_plan(a, spec.shape[0], spec.shape[2], torch.float32, dev())
+    plan.admm_init(spec, None, rho)
+    _, evals = plan.run(200, 10, 0.0, "sc")
+    tr, tr64 = g[f"trace_r{rho}_it200"], g[f"trace64_r{rho}_it200"]
+    got = sc_linear(np.array([m for _, m, _ in evals]))
+    spread = np.abs(sc_linear(tr[:, 0]) - sc_linear(tr64[:, 0])).max()
+    assert np.abs(got - sc_linear(tr[:, 0])).max() < max(3 * spread, 3e-3 if rho == 0.1 else 1e-5)
+
+
+# ---- G7 / G8 -----------------------------------------------------------------------------------------------------
+def test_metrics():
+    g = load_golden("g7_metrics")
+    a, b = T(g["a"]), T(g["b"])
+    got = np.array([si.sc(a, b).item(), si.snr(a, b).item(), si.ser(a, b).item()])
+    np.testing.assert_allclose(got, g["vals64"][:3], rtol=2e-6)
+    np.testing.assert_allclose(got, g["vals"][:3], rtol=1e-4, atol=1e-4)
+
+
+def test_float64():
+    g = load_golden("g8_f64")
+    kw = dict(hop_length=64, window=torch.from_numpy(g["window"]))
+    init = T(g["init"])
+    assert np.abs(N(si.phase_init(T(g["mag"]), **kw)) - g["init"]).max() < 1e-9
+    f = dict(tol=0, verbose=False)
+    assert rel_l2(N(si.griffin_lim(init, max_iter=1, alpha=0.3, **f, **kw)), g["gla1"]) < 1e-11
+    assert rel_l2(N(si.griffin_lim(init, max_iter=5, alpha=0.3, **f, **kw)), g["gla5"]) < 1e-10
+    assert rel_l2(N(si.ADMM(init, max_iter=1, rho=0.1, **f, **kw)), g["admm1"]) < 1e-11
+    assert rel_l2(N(si.ADMM(init, max_iter=5, rho=0.1, **f, **kw)), g["admm5"]) < 1e-9
+
+
+# ---- seeded oracle comparisons at sizes the oracle handles in seconds ---------------------------------------------------
+@pytest.mark.parametrize("n_fft,hop,frames,batch", [(1024, 256, 64, 2), (2048, 512, 48, 3), (512, 128, 33, 1),
+                                                   (300, 75, 20, 2)])
+def test_gla_vs_oracle(n_fft, hop, frames, batch):
+    rng = np.random.default_rng(7 + n_fft)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    w = hann(n_fft)
+    ref = oracle.griffin_lim(mag, max_iter=12, alpha=0.3, tol=0, hop_length=hop, window=w)
+    y = N(si.griffin_lim(T(mag), max_iter=12, alpha=0.3, tol=0, verbose=False, hop_length=hop,
+                         window=torch.from_numpy(w)))
+    assert rel_l2(y, ref) < 1e-4, rel_l2(y, ref)
+
+
+def test_state_spec_parity():
+    rng = np.random.default_rng(11)
+    mag = rng.random((2, 129, 30), dtype=np.float32)
+    w = hann(256)
+    init = oracle.phase_init(mag, hop_length=64, window=w)
+    _, st = oracle.griffin_lim(init, max_iter=3, alpha=0.5, tol=0, hop_length=64, window=w, return_state=True)
+    spec = T(init)
+    plan = get_plan(args_helper(spec, hop_length=64, window=torch.from_numpy(w)), 2, 30, torch.float32, dev())
+    plan.gla_init(spec, None, 0.5)
+    plan.iterate(3)
+    assert rel_l2(N(plan.state_spec(0)), st["pre_spec"]) < 1e-5
