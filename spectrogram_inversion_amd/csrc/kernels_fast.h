@@ -1,28 +1,758 @@
-// Fused gfx950 fast path (placeholder until the wave-per-frame kernels land).
+// Fused gfx950 fast path: one Griffin-Lim / ADMM iteration = ONE kernel launch.
+//
+// Mapping (n_fft = N = 128*R, hop = N/4, float32, onesided, center + reflect):
+//   * one 64-lane wave owns one frame at a time and walks a chunk of consecutive frames of one
+//     batch item; nothing is shared between waves except read-only tables, so the frame loop
+//     has no workgroup barrier.
+//   * the N real samples are packed as M = N/2 = 64*R complex points, R per lane
+//     (lane l, register u  <->  z[64u + l] = x[128u + 2l] + i x[128u + 2l + 1], a coalesced
+//     512-byte row per load instruction).  The M-point FFT runs as
+//         in-register radix-R  ->  cross-lane radix-(64/R) butterflies  ->  RxR transpose
+//         through wave-private LDS  ->  in-register radix-R,
+//     which leaves bin k in lane k mod 64, register k div 64.
+//   * real-FFT split: lane r trades its upper R/2 registers with lane 64-r (ds_bpermute), after
+//     which every lane holds R/2 conjugate pairs (k, M-k).  The spectral state (pre_spec / X, U /
+//     target magnitude) lives in HBM in exactly that pair order, so each lane reads and writes
+//     16-byte pieces of contiguous 1-KiB rows.  Bin M/2 is the one odd bin; lane 0 carries it.
+//   * the momentum / ADMM update and the magnitude projection are applied to the pairs in
+//     registers, the pairs are folded back, and the mirrored inverse FFT returns the frame in
+//     the input register layout.
+//   * overlap-add is done in registers: with hop = N/4 a lane's R registers split into 4
+//     quarters that land on 4 consecutive hop-blocks; three quarter-accumulators are carried
+//     from frame to frame and one finished hop-block is normalised by the envelope and stored
+//     per frame.  A chunk starts by recomputing the 3 frames before it (read-only halo).
+//   Algorithmic HBM traffic per frame-iteration: 8*hop + 20*F bytes (GLA), 8*hop + 36*F (ADMM).
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
 
 namespace specinv {
+namespace fast {
+
+using v2f = float __attribute__((ext_vector_type(2)));
+using v4f = float __attribute__((ext_vector_type(4)));
+
+enum { MODE_GLA = 0, MODE_ADMM = 1 };
+
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// a * conj(b)
+__device__ __forceinline__ v2f cmulc(v2f a, v2f b) { return v2f{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+__device__ __forceinline__ v2f cconj(v2f a) { return v2f{a.x, -a.y}; }
+__device__ __forceinline__ v2f mul_i(v2f a) { return v2f{-a.y, a.x}; }    // a * (+i)
+__device__ __forceinline__ v2f mul_mi(v2f a) { return v2f{a.y, -a.x}; }   // a * (-i)
+template <bool INV>
+__device__ __forceinline__ v2f rot(v2f a) { return INV ? mul_i(a) : mul_mi(a); }
+// exp(-+ i*theta) from (cos, sin): forward uses (c, -s), inverse (c, +s)
+template <bool INV>
+__device__ __forceinline__ v2f twc(float c, float s) { return v2f{c, INV ? s : -s}; }
+template <bool INV>
+__device__ __forceinline__ v2f dirmul(v2f a, v2f w) { return INV ? cmulc(a, w) : cmul(a, w); }
+
+__device__ __forceinline__ v2f shfl_xor2(v2f a, int mask) {
+  return v2f{__shfl_xor(a.x, mask, 64), __shfl_xor(a.y, mask, 64)};
+}
+__device__ __forceinline__ v2f shfl2(v2f a, int src) { return v2f{__shfl(a.x, src, 64), __shfl(a.y, src, 64)}; }
+
+// ---- small in-register DFTs (natural order in, natural order out) ------------------------------
+template <bool INV>
+__device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+  const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<INV>(a1 - a3);
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = t1 + t3;
+  a3 = t1 - t3;
+}
+
+template <int R, bool INV>
+struct Dft;
+
+template <bool INV>
+struct Dft<4, INV> {
+  static __device__ __forceinline__ void run(v2f (&a)[4]) { dft4<INV>(a[0], a[1], a[2], a[3]); }
+};
+
+template <bool INV>
+struct Dft<8, INV> {
+  static __device__ __forceinline__ void run(v2f (&a)[8]) {
+    constexpr float h = 0.70710678118654752440f;
+    // n = 4*n1 + n0: radix-2 over n1, twiddle W8^(n0*k1), radix-4 over n0
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) {
+      const v2f s = a[n0] + a[n0 + 4], d = a[n0] - a[n0 + 4];
+      a[n0] = s;
+      a[n0 + 4] = d;
+    }
+    a[5] = dirmul<INV>(a[5], v2f{h, -h});
+    a[6] = rot<INV>(a[6]);
+    a[7] = dirmul<INV>(a[7], v2f{-h, -h});
+    dft4<INV>(a[0], a[1], a[2], a[3]);
+    dft4<INV>(a[4], a[5], a[6], a[7]);
+    // a[k0 + 4*k1] = X[k1 + 2*k0]
+    v2f o[8];
+#pragma unroll
+    for (int k0 = 0; k0 < 4; ++k0) {
+      o[2 * k0] = a[k0];
+      o[2 * k0 + 1] = a[k0 + 4];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = o[i];
+  }
+};
+
+template <bool INV>
+struct Dft<16, INV> {
+  static __device__ __forceinline__ void run(v2f (&a)[16]) {
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    // n = 4*n1 + n0: radix-4 over n1 (in place -> slot n0 + 4*k1), twiddle W16^(n0*k1), radix-4 over n0
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) dft4<INV>(a[n0], a[n0 + 4], a[n0 + 8], a[n0 + 12]);
+    a[5] = dirmul<INV>(a[5], v2f{c1, -s1});    // W16^1
+    a[6] = dirmul<INV>(a[6], v2f{h, -h});      // W16^2
+    a[7] = dirmul<INV>(a[7], v2f{s1, -c1});    // W16^3
+    a[9] = dirmul<INV>(a[9], v2f{h, -h});      // W16^2
+    a[10] = rot<INV>(a[10]);                   // W16^4
+    a[11] = dirmul<INV>(a[11], v2f{-h, -h});   // W16^6
+    a[13] = dirmul<INV>(a[13], v2f{s1, -c1});  // W16^3
+    a[14] = dirmul<INV>(a[14], v2f{-h, -h});   // W16^6
+    a[15] = dirmul<INV>(a[15], v2f{-c1, s1});  // W16^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+    // a[k0 + 4*k1] = X[k1 + 4*k0]
+    v2f o[16];
+#pragma unroll
+    for (int k0 = 0; k0 < 4; ++k0)
+#pragma unroll
+      for (int k1 = 0; k1 < 4; ++k1) o[k1 + 4 * k0] = a[k0 + 4 * k1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = o[i];
+  }
+};
+
+template <int R>
+struct Geo {
+  static constexpr int C = 64 / R;       // cross-lane radix
+  static constexpr int LOGC = C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : 4;
+  static constexpr int M = 64 * R;       // complex points per frame
+  static constexpr int N = 2 * M;        // n_fft
+  static constexpr int H = R / 2;        // conjugate pairs per lane
+  static constexpr int QU = R / 4;       // registers per hop-block quarter
+  static constexpr int HOP = N / 4;
+  static constexpr int TR = 64 * (R + 1);  // transpose scratch per wave (complex elements)
+  static constexpr size_t lds_bytes(int waves) { return sizeof(v2f) * (size_t)(M + (R - 1) * 64 + waves * TR); }
+};
+
+// per-lane constants
+template <int R>
+struct LaneConst {
+  int lane, n2, v, kv, partner;
+  v2f post;                // W_64^(n2*kv)
+  v2f stage[3];            // stage twiddles of the cross-lane radix-2 network (index s)
+  v2f wn;                  // W_N^lane
+  int tr_a;                // transpose address for layout A: (kv*R + reg)*(R+1) + n2  -> base + reg*(R+1)
+  int tr_b;                // layout B: lane*(R+1) + reg
+};
+
+__device__ __forceinline__ v2f unit(float turns_times_2) {  // exp(-i*pi*x)
+  float s, c;
+  sincospif(turns_times_2, &s, &c);
+  return v2f{c, -s};
+}
+
+template <int R>
+__device__ __forceinline__ LaneConst<R> lane_consts() {
+  using G = Geo<R>;
+  LaneConst<R> k;
+  k.lane = threadIdx.x & 63;
+  k.n2 = k.lane % R;
+  k.v = k.lane / R;
+  int rev = 0;
+#pragma unroll
+  for (int bit = 0; bit < G::LOGC; ++bit) rev |= ((k.v >> bit) & 1) << (G::LOGC - 1 - bit);
+  k.kv = rev;
+  k.partner = (64 - k.lane) & 63;
+  k.post = unit(2.0f * (float)(k.n2 * k.kv) / 64.0f);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int hs = 1 << s;
+    const bool upper = (k.v >> s) & 1;
+    // radix-2 DIF stage with half size hs (in units of v): upper outputs times W_{2hs}^(v mod hs)
+    k.stage[s] = upper ? unit(2.0f * (float)(k.v & (hs - 1)) / (float)(2 * hs)) : v2f{1.0f, 0.0f};
+  }
+  k.wn = unit(2.0f * (float)k.lane / (float)G::N);
+  k.tr_a = (k.kv * R) * (R + 1) + k.n2;
+  k.tr_b = k.lane * (R + 1);
+  return k;
+}
+
+// ---- M-point FFT across the wave ------------------------------------------------------------------
+// forward: in z[u] = time sample 64u + lane; out z[j] = bin lane + 64j
+template <int R>
+__device__ __forceinline__ void fft_forward(v2f (&z)[R], const LaneConst<R>& k, const v2f* __restrict__ tw1,
+                                            v2f* __restrict__ tr) {
+  using G = Geo<R>;
+  Dft<R, false>::run(z);
+#pragma unroll
+  for (int k1 = 1; k1 < R; ++k1) z[k1] = cmul(z[k1], tw1[(k1 - 1) * 64 + k.lane]);
+  // cross-lane radix-C, decimation in frequency; result for kv = bitrev(v) at position v
+#pragma unroll
+  for (int s = G::LOGC - 1; s >= 0; --s) {
+    const bool upper = (k.v >> s) & 1;
+    const float sg = upper ? -1.0f : 1.0f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const v2f p = shfl_xor2(z[i], R << s);
+      z[i] = v2f{fmaf(z[i].x, sg, p.x), fmaf(z[i].y, sg, p.y)};   // lower: a + p ; upper: p - a
+      if (s > 0) z[i] = cmul(z[i], k.stage[s]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) z[i] = cmul(z[i], k.post);
+  // transpose n2 <-> k1 inside each group of R lanes (wave-private LDS, no barrier)
+#pragma unroll
+  for (int i = 0; i < R; ++i) tr[k.tr_a + i * (R + 1)] = z[i];
+#pragma unroll
+  for (int i = 0; i < R; ++i) z[i] = tr[k.tr_b + i];
+  Dft<R, false>::run(z);
+}
+
+// inverse (unnormalised): in z[j] = bin lane + 64j; out z[u] = time sample 64u + lane
+template <int R>
+__device__ __forceinline__ void fft_inverse(v2f (&z)[R], const LaneConst<R>& k, const v2f* __restrict__ tw1,
+                                            v2f* __restrict__ tr) {
+  using G = Geo<R>;
+  Dft<R, true>::run(z);
+#pragma unroll
+  for (int i = 0; i < R; ++i) tr[k.tr_b + i] = z[i];
+#pragma unroll
+  for (int i = 0; i < R; ++i) z[i] = cmulc(tr[k.tr_a + i * (R + 1)], k.post);
+#pragma unroll
+  for (int s = 0; s < G::LOGC; ++s) {
+    const bool upper = (k.v >> s) & 1;
+    const float sg = upper ? -1.0f : 1.0f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (s > 0) z[i] = cmulc(z[i], k.stage[s]);
+      const v2f p = shfl_xor2(z[i], R << s);
+      z[i] = v2f{fmaf(z[i].x, sg, p.x), fmaf(z[i].y, sg, p.y)};
+    }
+  }
+#pragma unroll
+  for (int k1 = 1; k1 < R; ++k1) z[k1] = cmulc(z[k1], tw1[(k1 - 1) * 64 + k.lane]);
+  Dft<R, true>::run(z);
+}
+
+// W_64^j = exp(-2 pi i j / 64), j < 16: the per-pair step of the real-FFT twiddle W_N^(lane + 64 j)
+__device__ __forceinline__ v2f w64(int j) {
+  constexpr float tab[16][2] = {{1.000000000e+00f, -0.000000000e+00f}, {9.951847267e-01f, -9.801714033e-02f}, {9.807852804e-01f, -1.950903220e-01f}, {9.569403357e-01f, -2.902846773e-01f}, {9.238795325e-01f, -3.826834324e-01f}, {8.819212643e-01f, -4.713967368e-01f}, {8.314696123e-01f, -5.555702330e-01f}, {7.730104534e-01f, -6.343932842e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {6.343932842e-01f, -7.730104534e-01f}, {5.555702330e-01f, -8.314696123e-01f}, {4.713967368e-01f, -8.819212643e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {2.902846773e-01f, -9.569403357e-01f}, {1.950903220e-01f, -9.807852804e-01f}, {9.801714033e-02f, -9.951847267e-01f}};
+  return v2f{tab[j][0], tab[j][1]};
+}
+
+struct FastArgs {
+  const float* x_in;
+  float* x_out;
+  const v4f* P_in;     // GLA: pre_spec pairs ; ADMM: X pairs      [B*T][H][64] x (Re k, Im k, Re M-k, Im M-k)
+  v4f* P_out;
+  const v2f* Pmid_in;  // bin M/2                                   [B*T]
+  v2f* Pmid_out;
+  const v4f* U_in;     // ADMM only
+  v4f* U_out;
+  const v2f* Umid_in;
+  v2f* Umid_out;
+  const v4f* m_pairs;  // target magnitude                          [B*T][H/2][64] x (k_2c, M-k_2c, k_2c+1, M-k_2c+1)
+  const float* m_mid;  //                                           [B*T]
+  const float* window;   // N
+  const float* inv_env;  // L, 1 / envelope
+  double* partials;      // [n_waves][2]
+  int T, chunk, nchunks, n_waves;
+  long long L;
+  float coef;       // lr (GLA) or rho (ADMM)
+  float inv1p;      // 1/(1+rho)
+  float fwd_scale;  // 1 or N^-1/2
+  float inv_scale;  // 1/N or N^-1/2
+};
+
+__device__ __forceinline__ float fast_abs(v2f s) { return __builtin_amdgcn_sqrtf(fmaf(s.x, s.x, s.y * s.y)); }
+
+// Frequency-domain update of one bin.  `r` is the STFT bin, `p`/`u` the stored state, `m` the target.
+// Returns the bin to synthesise from (already multiplied by isc); writes the new state.
+template <int MODE, bool EVAL>
+__device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const FastArgs& a, bool live, double& sd,
+                                          double& so) {
+  if (EVAL) {
+    const float o = fast_abs(r);
+    if (live) {
+      const double d = (double)o - (double)m;
+      sd += d * d;
+      so += (double)o * (double)o;
+    }
+  }
+  if (MODE == MODE_GLA) {
+    // methods.py:243-247: S = R - lr*P ; P <- S ; S * m / (|S| + 1e-16)
+    const v2f s = v2f{fmaf(-a.coef, p.x, r.x), fmaf(-a.coef, p.y, r.y)};
+    p = s;
+    const float inv = __builtin_amdgcn_rcpf(fast_abs(s) + 1e-16f) * a.inv_scale;
+    return v2f{(s.x * m) * inv, (s.y * m) * inv};
+  } else {
+    // methods.py:467-475
+    const v2f y = p + u;
+    const v2f z = v2f{fmaf(a.coef, y.x, r.x) * a.inv1p, fmaf(a.coef, y.y, r.y) * a.inv1p};
+    const v2f un = (u + p) - z;
+    v2f xn = z - un;
+    const float inv = __builtin_amdgcn_rcpf(fast_abs(xn) + 1e-16f);
+    xn = v2f{(xn.x * m) * inv, (xn.y * m) * inv};
+    p = xn;
+    u = un;
+    return (xn + un) * a.inv_scale;
+  }
+}
+
+template <int R, int MODE, bool EVAL>
+__global__ __launch_bounds__(256) void k_fused(FastArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = threadIdx.x >> 6;
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);   // W_M^(l*k1)
+  }
+  __syncthreads();
+
+  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  if (w >= a.n_waves) return;
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  const int t_begin = c * a.chunk;
+  const int t_end = min(a.T, t_begin + a.chunk);
+  const int t_start = max(0, t_begin - 3);
+  const float* xrow = a.x_in + (long long)b * a.L;
+  float* orow = a.x_out + (long long)b * a.L;
+  const float half_scale = 0.5f * a.fwd_scale;
+
+  v2f acc[3 * QU];
+#pragma unroll
+  for (int i = 0; i < 3 * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
+  double sd = 0.0, so = 0.0;
+
+  for (int t = t_start; t < t_end; ++t) {
+    const bool live = t >= t_begin;
+    const long long fi = (long long)b * a.T + t;
+
+    // ---- issue the state loads early; they are consumed after the forward FFT
+    v4f pp[H], uu[H], mm[H / 2];
+#pragma unroll
+    for (int j = 0; j < H; ++j) pp[j] = a.P_in[(fi * H + j) * 64 + lane];
+    if (MODE == MODE_ADMM) {
+#pragma unroll
+      for (int j = 0; j < H; ++j) uu[j] = a.U_in[(fi * H + j) * 64 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < H / 2; ++j) mm[j] = a.m_pairs[(fi * (H / 2) + j) * 64 + lane];
+    v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
+    float mmid = 0.0f;
+    if (lane == 0) {
+      pmid = a.Pmid_in[fi];
+      mmid = a.m_mid[fi];
+      if (MODE == MODE_ADMM) umid = a.Umid_in[fi];
+    }
+
+    // ---- analysis: windowed frame -> registers
+    v2f z[R];
+    const long long s0 = (long long)(t - 2) * HOP;   // signal index of the frame's first sample
+    if (t >= 2 && t <= a.T - 3) {
+      const v2f* src = reinterpret_cast<const v2f*>(xrow + s0);
+#pragma unroll
+      for (int u = 0; u < R; ++u) z[u] = src[64 * u + lane];
+    } else {
+      // frames that reach into torch.stft's reflect padding
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        long long n0 = s0 + 128 * u + 2 * lane, n1 = n0 + 1;
+        n0 = n0 < 0 ? -n0 : (n0 >= a.L ? 2 * (a.L - 1) - n0 : n0);
+        n1 = n1 < 0 ? -n1 : (n1 >= a.L ? 2 * (a.L - 1) - n1 : n1);
+        z[u] = v2f{xrow[n0], xrow[n1]};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+
+    fft_forward<R>(z, k, lds_tw1, tr);
+
+    // ---- conjugate partners: upper half of lane (64 - r)
+    v2f rc[H];   // rc[i] pairs with own register H-1-i ... see below: rc[m-H] = Z[M - (lane + 64*(R-1-m))]
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f alt = z[(m + 1) % R];              // lane 0 is its own partner, shifted by one register
+      const v2f snd = lane == 0 ? alt : z[m];
+      rc[m - H] = shfl2(snd, k.partner);
+    }
+
+    // ---- per pair: split -> update -> fold back
+    v2f back[H];   // back[j] = Z''[M - k_j], to be returned to the partner lane
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      // W_N^(lane + 64 j) = W_N^lane * W_{2R}^j
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f zk = z[j], zm = rc[R - 1 - j - H];
+      const v2f e2 = zk + cconj(zm);
+      const v2f o2 = mul_mi(zk - cconj(zm));
+      const v2f tw = cmul(wk, o2);
+      v2f xk = (e2 + tw) * half_scale;
+      v2f xm = cconj(e2 - tw) * half_scale;
+      v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
+      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
+      if (MODE == MODE_ADMM) {
+        uk = v2f{uu[j].x, uu[j].y};
+        um = v2f{uu[j].z, uu[j].w};
+      }
+      const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+      const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+      v2f ak = update_bin<MODE, EVAL>(xk, pk, uk, mk, a, live, sd, so);
+      v2f am = update_bin<MODE, EVAL>(xm, pm, um, mq, a, live, sd, so);
+      if (live) {
+        a.P_out[(fi * H + j) * 64 + lane] = v4f{pk.x, pk.y, pm.x, pm.y};
+        if (MODE == MODE_ADMM) a.U_out[(fi * H + j) * 64 + lane] = v4f{uk.x, uk.y, um.x, um.y};
+      }
+      if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = ak + cconj(am);
+      const v2f o2i = cmulc(ak - cconj(am), wk);
+      z[j] = e2i + mul_i(o2i);
+      back[j] = cconj(e2i - mul_i(o2i));
+    }
+    // ---- bin M/2 (lane 0): X = conj(Z), Z'' = 2 conj(X')
+    v2f zmid;
+    {
+      v2f xmid = cconj(z[H]) * a.fwd_scale;
+      const bool live0 = live && lane == 0;
+      const v2f am = update_bin<MODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
+      if (live0) {
+        a.Pmid_out[fi] = pmid;
+        if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
+      }
+      zmid = cconj(am) * 2.0f;
+    }
+    // ---- return the mirrored halves
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f gen = back[R - 1 - m];
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      const v2f snd = lane == 0 ? l0 : gen;
+      z[m] = shfl2(snd, k.partner);
+    }
+
+    fft_inverse<R>(z, k, lds_tw1, tr);
+
+    // ---- synthesis window, register overlap-add, one finished hop-block out
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    if (live && t >= 2) {
+      const long long o0 = (long long)(t - 2) * HOP;
+#pragma unroll
+      for (int i = 0; i < QU; ++i) {
+        const v2f ie = *reinterpret_cast<const v2f*>(a.inv_env + o0 + 128 * i + 2 * lane);
+        *reinterpret_cast<v2f*>(orow + o0 + 128 * i + 2 * lane) = (acc[i] + z[i]) * ie;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+      acc[i] = acc[QU + i] + z[QU + i];
+      acc[QU + i] = acc[2 * QU + i] + z[2 * QU + i];
+      acc[2 * QU + i] = z[3 * QU + i];
+    }
+  }
+  // the chunk that holds the last frame also finishes hop-block T (frames T-3 .. T-1)
+  if (t_end == a.T) {
+    const long long o0 = (long long)(a.T - 2) * HOP;
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+      const v2f ie = *reinterpret_cast<const v2f*>(a.inv_env + o0 + 128 * i + 2 * lane);
+      *reinterpret_cast<v2f*>(orow + o0 + 128 * i + 2 * lane) = acc[i] * ie;
+    }
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0) {
+      a.partials[2 * (long long)w] = d;
+      a.partials[2 * (long long)w + 1] = o;
+    }
+  }
+}
+
+// ---- layout conversion between the frame-major (B*T, F) spectra and the pair layout ---------------
+template <int R>
+__global__ void k_spec_to_pairs(const v2f* __restrict__ spec, v4f* __restrict__ pairs, v2f* __restrict__ mid,
+                                long long n_frames) {
+  using G = Geo<R>;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (frame, j, lane)
+  if (i >= n_frames * G::H * 64) return;
+  const int lane = i & 63;
+  const int j = (i >> 6) % G::H;
+  const long long f = i / (64 * G::H);
+  const v2f* s = spec + f * (G::M + 1);
+  const int kk = lane + 64 * j;
+  const v2f a = s[kk], bb = s[G::M - kk];
+  pairs[i] = v4f{a.x, a.y, bb.x, bb.y};
+  if (lane == 0 && j == 0) mid[f] = s[G::M / 2];
+}
+
+template <int R>
+__global__ void k_pairs_to_spec(const v4f* __restrict__ pairs, const v2f* __restrict__ mid, v2f* __restrict__ spec,
+                                long long n_frames) {
+  using G = Geo<R>;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_frames * G::H * 64) return;
+  const int lane = i & 63;
+  const int j = (i >> 6) % G::H;
+  const long long f = i / (64 * G::H);
+  v2f* s = spec + f * (G::M + 1);
+  const int kk = lane + 64 * j;
+  const v4f p = pairs[i];
+  s[kk] = v2f{p.x, p.y};
+  s[G::M - kk] = v2f{p.z, p.w};
+  if (lane == 0 && j == 0) s[G::M / 2] = mid[f];
+}
+
+template <int R>
+__global__ void k_mag_to_pairs(const float* __restrict__ mag, v4f* __restrict__ pairs, float* __restrict__ mid,
+                               long long n_frames) {
+  using G = Geo<R>;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (frame, c, lane)
+  if (i >= n_frames * (G::H / 2) * 64) return;
+  const int lane = i & 63;
+  const int c = (i >> 6) % (G::H / 2);
+  const long long f = i / (64 * (G::H / 2));
+  const float* s = mag + f * (G::M + 1);
+  const int k0 = lane + 64 * (2 * c), k1 = lane + 64 * (2 * c + 1);
+  pairs[i] = v4f{s[k0], s[G::M - k0], s[k1], s[G::M - k1]};
+  if (lane == 0 && c == 0) mid[f] = s[G::M / 2];
+}
+
+__global__ void k_reciprocal(const float* __restrict__ in, float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.0f / in[i];
+}
+
+}  // namespace fast
+
+// ---- host side ---------------------------------------------------------------------------------------
+struct FastBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~FastBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int reserve(size_t n) {
+    if (p && n <= bytes) return SPECINV_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, n ? n : 16);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(SPECINV_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    return SPECINV_OK;
+  }
+  template <typename U>
+  U* as() const { return static_cast<U*>(p); }
+};
 
 template <typename T>
 struct FastState {
   bool supported = false;
-  int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) {
+  int n_partials = 0;
+  int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
+  template <typename P>
+  int gla_begin(P&) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
+  template <typename P>
+  int admm_begin(P&) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
+  template <typename P>
+  int iterate(P&, int, bool) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
+  template <typename P>
+  int get_wave(P&, T*) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
+  template <typename P>
+  int get_state_spec(P&, int, cplx<T>*) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
+};
+
+template <>
+struct FastState<float> {
+  using v2f = fast::v2f;
+  using v4f = fast::v4f;
+  bool supported = false;
+  int R = 0;
+  int chunk = 32, nchunks = 0, n_waves = 0, n_partials = 0;
+  int cur = 0;   // index of the buffers holding the current state
+  int mode = fast::MODE_GLA;
+  FastBuf xb[2], Pb[2], Pmid[2], Ub[2], Umid[2], mpairs, mmid, inv_env, scratch;
+
+  int setup(const specinv_stft_cfg& cfg, const std::vector<float>&, int64_t length, int pad) {
     supported = false;
+    if (cfg.dtype != SPECINV_F32 || !cfg.onesided || !cfg.center || cfg.pad_mode != SPECINV_PAD_REFLECT) return SPECINV_OK;
+    if (cfg.hop_length * 4 != cfg.n_fft) return SPECINV_OK;
+    if (cfg.n_fft == 2048) R = 16;
+    else if (cfg.n_fft == 1024) R = 8;
+    else return SPECINV_OK;
+    if (cfg.n_frames < 6 || pad >= length) return SPECINV_OK;
+    if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
+      if (e[0] == '1') return SPECINV_OK;
+    }
+    // frames per wave: enough waves to fill 256 CUs x 12 wave slots once, halo overhead 3/chunk
+    const long long frames = (long long)cfg.batch * cfg.n_frames;
+    int ch = 32;
+    while (ch > 8 && frames / ch < 2048) ch /= 2;
+    if (const char* e = getenv("SPECINV_FAST_CHUNK")) {
+      const int v = atoi(e);
+      if (v >= 4) ch = v;
+    }
+    chunk = std::min(ch, cfg.n_frames);
+    nchunks = (cfg.n_frames + chunk - 1) / chunk;
+    n_waves = cfg.batch * nchunks;
+    supported = true;
     return SPECINV_OK;
   }
+
+  template <int RR, typename P>
+  int begin_t(P& pl, int md) {
+    using G = fast::Geo<RR>;
+    mode = md;
+    const long long nf = (long long)pl.B() * pl.Tn();
+    const size_t pbytes = (size_t)nf * G::H * 64 * sizeof(v4f);
+    for (int i = 0; i < 2; ++i) {
+      SI_TRY(xb[i].reserve((size_t)pl.B() * pl.length * sizeof(float)));
+      SI_TRY(Pb[i].reserve(pbytes));
+      SI_TRY(Pmid[i].reserve(nf * sizeof(v2f)));
+      if (md == fast::MODE_ADMM) {
+        SI_TRY(Ub[i].reserve(pbytes));
+        SI_TRY(Umid[i].reserve(nf * sizeof(v2f)));
+      }
+    }
+    SI_TRY(mpairs.reserve((size_t)nf * (G::H / 2) * 64 * sizeof(v4f)));
+    SI_TRY(mmid.reserve(nf * sizeof(float)));
+    SI_TRY(inv_env.reserve(pl.length * sizeof(float)));
+    cur = 0;
+    const long long np = nf * G::H * 64;
+    hipLaunchKernelGGL((fast::k_spec_to_pairs<RR>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
+                       reinterpret_cast<const v2f*>(pl.specA.p), Pb[0].template as<v4f>(), Pmid[0].template as<v2f>(), nf);
+    SI_HIP(hipGetLastError());
+    if (md == fast::MODE_ADMM) {
+      SI_HIP(hipMemsetAsync(Ub[0].p, 0, pbytes, pl.stream));
+      SI_HIP(hipMemsetAsync(Umid[0].p, 0, nf * sizeof(v2f), pl.stream));
+    }
+    const long long nm = nf * (G::H / 2) * 64;
+    hipLaunchKernelGGL((fast::k_mag_to_pairs<RR>), dim3((unsigned)ceil_div(nm, 256)), dim3(256), 0, pl.stream,
+                       pl.mag.template as<float>(), mpairs.template as<v4f>(), mmid.template as<float>(), nf);
+    SI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fast::k_reciprocal, dim3((unsigned)ceil_div(pl.length, 256)), dim3(256), 0, pl.stream,
+                       pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length);
+    SI_HIP(hipGetLastError());
+    SI_HIP(hipMemcpyAsync(xb[0].p, pl.x.p, (size_t)pl.B() * pl.length * sizeof(float), hipMemcpyDeviceToDevice,
+                          pl.stream));
+    return SPECINV_OK;
+  }
+
   template <typename P>
-  int gla_begin(P&) { return fail(SPECINV_EUNSUPPORTED, "fast path not built"); }
+  int gla_begin(P& pl) { return R == 16 ? begin_t<16>(pl, fast::MODE_GLA) : begin_t<8>(pl, fast::MODE_GLA); }
   template <typename P>
-  int admm_begin(P&) { return fail(SPECINV_EUNSUPPORTED, "fast path not built"); }
+  int admm_begin(P& pl) { return R == 16 ? begin_t<16>(pl, fast::MODE_ADMM) : begin_t<8>(pl, fast::MODE_ADMM); }
+
+  template <int RR, int MODE, bool EVAL, typename P>
+  int launch(P& pl, const fast::FastArgs& a) {
+    using G = fast::Geo<RR>;
+    const size_t lds = G::lds_bytes(4);
+    static bool attr_done = false;
+    if (!attr_done) {
+      SI_HIP(hipFuncSetAttribute((const void*)fast::k_fused<RR, MODE, EVAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((fast::k_fused<RR, MODE, EVAL>), dim3((n_waves + 3) / 4), dim3(256), lds, pl.stream, a);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
   template <typename P>
-  int iterate(P&, int, bool) { return fail(SPECINV_EUNSUPPORTED, "fast path not built"); }
+  int iterate(P& pl, int n_iter, bool eval_last) {
+    SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2, 3 * 1024) * sizeof(double)));
+    for (int i = 0; i < n_iter; ++i) {
+      const bool ev = eval_last && i == n_iter - 1;
+      const int nx = cur ^ 1;
+      fast::FastArgs a{};
+      a.x_in = xb[cur].template as<float>();
+      a.x_out = xb[nx].template as<float>();
+      a.P_in = Pb[cur].template as<v4f>();
+      a.P_out = Pb[nx].template as<v4f>();
+      a.Pmid_in = Pmid[cur].template as<v2f>();
+      a.Pmid_out = Pmid[nx].template as<v2f>();
+      a.U_in = Ub[cur].template as<v4f>();
+      a.U_out = Ub[nx].template as<v4f>();
+      a.Umid_in = Umid[cur].template as<v2f>();
+      a.Umid_out = Umid[nx].template as<v2f>();
+      a.m_pairs = mpairs.template as<v4f>();
+      a.m_mid = mmid.template as<float>();
+      a.window = pl.window.template as<float>();
+      a.inv_env = inv_env.template as<float>();
+      a.partials = pl.partials.template as<double>();
+      a.T = pl.Tn();
+      a.chunk = chunk;
+      a.nchunks = nchunks;
+      a.n_waves = n_waves;
+      a.L = pl.length;
+      a.coef = pl.coef;
+      a.inv1p = 1.0f / (float)(1.0 + (double)pl.coef);
+      a.fwd_scale = pl.fc.fwd_scale;
+      a.inv_scale = pl.fc.inv_scale;
+      int rc;
+      if (R == 16) {
+        if (mode == fast::MODE_GLA) rc = ev ? launch<16, fast::MODE_GLA, true>(pl, a) : launch<16, fast::MODE_GLA, false>(pl, a);
+        else rc = ev ? launch<16, fast::MODE_ADMM, true>(pl, a) : launch<16, fast::MODE_ADMM, false>(pl, a);
+      } else {
+        if (mode == fast::MODE_GLA) rc = ev ? launch<8, fast::MODE_GLA, true>(pl, a) : launch<8, fast::MODE_GLA, false>(pl, a);
+        else rc = ev ? launch<8, fast::MODE_ADMM, true>(pl, a) : launch<8, fast::MODE_ADMM, false>(pl, a);
+      }
+      SI_TRY(rc);
+      cur = nx;
+    }
+    n_partials = n_waves;
+    return SPECINV_OK;
+  }
+
   template <typename P>
-  int get_wave(P&, T*) { return fail(SPECINV_EUNSUPPORTED, "fast path not built"); }
+  int get_wave(P& pl, float* out) {
+    SI_HIP(hipMemcpyAsync(out, xb[cur].p, (size_t)pl.B() * pl.length * sizeof(float), hipMemcpyDeviceToDevice, pl.stream));
+    return SPECINV_OK;
+  }
+
   template <typename P>
-  int get_state_spec(P&, int, cplx<T>*) { return fail(SPECINV_EUNSUPPORTED, "fast path not built"); }
+  int get_state_spec(P& pl, int which, cplx<float>* out) {
+    const long long nf = (long long)pl.B() * pl.Tn();
+    SI_TRY(scratch.reserve((size_t)nf * pl.n_freq * sizeof(v2f)));
+    const FastBuf& src = which == 0 ? Pb[cur] : Ub[cur];
+    const FastBuf& mid = which == 0 ? Pmid[cur] : Umid[cur];
+    if (R == 16) {
+      const long long np = nf * fast::Geo<16>::H * 64;
+      hipLaunchKernelGGL((fast::k_pairs_to_spec<16>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
+                         src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf);
+    } else {
+      const long long np = nf * fast::Geo<8>::H * 64;
+      hipLaunchKernelGGL((fast::k_pairs_to_spec<8>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
+                         src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf);
+    }
+    SI_HIP(hipGetLastError());
+    return pl.template transpose<cplx<float>>(scratch.template as<cplx<float>>(), out, pl.Tn(), pl.n_freq);
+  }
 };
 
 }  // namespace specinv

@@ -339,8 +339,9 @@ struct PlanT final : PlanBase {
     }
     if (eval_last) {
       SI_CHECK(s != nullptr, SPECINV_EINVAL, "sums_host is NULL");
-      hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, stream, partials.as<double>(),
-                         (int64_t)B() * Tn(), 2, sums.as<double>());
+      const int64_t n_part = fast_path() ? (int64_t)fast.n_partials : (int64_t)B() * Tn();
+      hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, stream, partials.as<double>(), n_part, 2,
+                         sums.as<double>());
       SI_HIP(hipGetLastError());
       double r[2];
       SI_HIP(hipMemcpyAsync(r, sums.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));

@@ -1,0 +1,161 @@
+"""The fused wave-per-frame kernels (kernels_fast.h) against the oracle and against the generic
+kernels, through the C ABI.  Needs an MI355X: `-m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _util import hann, rel_l2, sc_linear
+
+pytestmark = pytest.mark.gpu
+
+from spectrogram_inversion_amd.plan import Plan, args_helper   # noqa: E402
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_plan(n_fft, hop, frames, batch, window=None, normalized=False, chunk=None):
+    w = torch.from_numpy(hann(n_fft) if window is None else window)
+    probe = torch.empty((1, n_fft // 2 + 1, 1))
+    a = args_helper(probe, hop_length=hop, window=w, normalized=normalized)
+    if chunk is not None:
+        os.environ["SPECINV_FAST_CHUNK"] = str(chunk)
+    try:
+        return Plan(a, batch, frames, torch.float32, dev())
+    finally:
+        os.environ.pop("SPECINV_FAST_CHUNK", None)
+
+
+SHAPES = [(2048, 512, 40, 2), (1024, 256, 37, 3), (2048, 512, 6, 1), (1024, 256, 130, 2)]
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch", SHAPES)
+@pytest.mark.parametrize("chunk", [None, 4, 7])
+def test_fast_path_selected_and_matches_oracle(n_fft, hop, frames, batch, chunk):
+    rng = np.random.default_rng(n_fft + frames)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    w = hann(n_fft)
+    init = oracle.phase_init(mag, hop_length=hop, window=w)
+    trace = []
+    ref, st = oracle.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, eva_iter=5, hop_length=hop, window=w,
+                                 trace=trace, return_state=True)
+    plan = make_plan(n_fft, hop, frames, batch, chunk=chunk)
+    assert plan.fast_path
+    plan.gla_init(T(init), None, 0.3)
+    done, evals = plan.run(10, 5, 0.0, "sc")
+    assert done == 10 and len(evals) == 2
+    y = N(plan.wave())
+    assert rel_l2(y, ref.reshape(y.shape)) < 2e-5, rel_l2(y, ref.reshape(y.shape))
+    got = sc_linear(np.array([m for _, m, _ in evals]))
+    want = sc_linear(np.array([m for _, m, _ in trace]))
+    assert np.abs(got - want).max() < 1e-5
+    assert rel_l2(N(plan.state_spec(0)), st["pre_spec"]) < 1e-4
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch", SHAPES[:2])
+def test_fast_equals_generic(n_fft, hop, frames, batch):
+    rng = np.random.default_rng(5)
+    mag = T(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32))
+    fast = make_plan(n_fft, hop, frames, batch)
+    gen = make_plan(n_fft, hop, frames, batch)
+    gen.force_generic(True)
+    assert fast.fast_path and not gen.fast_path
+    out = []
+    for p in (fast, gen):
+        p.gla_init(None, mag, 0.99)
+        p.iterate(7)
+        s = p.iterate(1, eval_last=True)
+        out.append((N(p.wave()), s))
+    assert rel_l2(out[0][0], out[1][0]) < 2e-5
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-5)
+
+
+def test_fast_alpha_zero_and_normalized():
+    rng = np.random.default_rng(6)
+    n_fft, hop, frames, batch = 1024, 256, 24, 2
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    w = hann(n_fft)
+    for normalized in (False, True):
+        ref = oracle.griffin_lim(mag, max_iter=6, alpha=0.0, tol=0, hop_length=hop, window=w, normalized=normalized)
+        plan = make_plan(n_fft, hop, frames, batch, normalized=normalized)
+        assert plan.fast_path
+        plan.gla_init(None, T(mag), 0.0)
+        plan.iterate(6)
+        assert rel_l2(N(plan.wave()), ref) < 2e-5
+
+
+def test_fast_rectangular_window():
+    """win_length < n_fft: zero-padded window, envelope never zero with hop = n_fft/4."""
+    rng = np.random.default_rng(8)
+    n_fft, hop, frames, batch = 2048, 512, 16, 1
+    w = np.zeros(n_fft, dtype=np.float32)
+    w[200:1848] = 1.0
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    ref = oracle.griffin_lim(mag, max_iter=4, alpha=0.5, tol=0, hop_length=hop, window=w)
+    plan = make_plan(n_fft, hop, frames, batch, window=w)
+    plan.gla_init(None, T(mag), 0.5)
+    plan.iterate(4)
+    assert rel_l2(N(plan.wave()), ref.reshape(batch, -1)) < 2e-5
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch", SHAPES[:2])
+@pytest.mark.parametrize("rho", [0.1, 1.0])
+def test_fast_admm(n_fft, hop, frames, batch, rho):
+    rng = np.random.default_rng(9)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    w = hann(n_fft)
+    init = oracle.phase_init(mag, hop_length=hop, window=w)
+    ref, st = oracle.admm(init, max_iter=3, rho=rho, tol=0, hop_length=hop, window=w, return_state=True)
+    plan = make_plan(n_fft, hop, frames, batch)
+    assert plan.fast_path
+    plan.admm_init(T(init), None, rho)
+    plan.iterate(3)
+    tol = 2e-4 if rho == 0.1 else 2e-5          # rho=0.1 amplifies rounding ~10x per iteration
+    assert rel_l2(N(plan.wave()), ref.reshape(batch, -1)) < tol
+    assert rel_l2(N(plan.state_spec(0)), st["X"]) < tol
+    assert rel_l2(N(plan.state_spec(1)), st["U"]) < 20 * tol
+
+
+def test_full_size_properties():
+    """BASELINE config 2 at full size (n_fft 2048, hop 512, 1024 frames): no oracle run needed - the
+    fused float32 kernels are compared with the generic kernels in float64 (same algorithm, different
+    code, 2^29 times finer rounding) and must be as close to them as the generic float32 kernels are."""
+    n_fft, hop, frames, batch = 2048, 512, 1024, 4
+    rng = np.random.default_rng(1234)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    fast = make_plan(n_fft, hop, frames, batch)
+    assert fast.fast_path
+    fast.gla_init(None, T(mag), 0.3)
+    _, evals = fast.run(30, 10, 0.0, "sc")
+    losses = [l for _, _, l in evals]
+    assert losses[0] > losses[1] > losses[2]
+    yf = fast.wave()
+    assert bool(torch.isfinite(yf).all())
+    init = fast.phase_init(T(mag))                      # identical starting point for all three runs
+
+    gen = make_plan(n_fft, hop, frames, batch)
+    gen.force_generic(True)
+    w64 = torch.from_numpy(hann(n_fft, np.float64))
+    a64 = args_helper(torch.empty((1, n_fft // 2 + 1, 1), dtype=torch.float64), hop_length=hop, window=w64)
+    ref = Plan(a64, batch, frames, torch.float64, dev())
+    res = {}
+    for name, p, x0 in (("fast", fast, init), ("gen", gen, init), ("f64", ref, init.to(torch.complex128))):
+        p.gla_init(x0, None, 0.3)
+        _, ev = p.run(30, 10, 0.0, "sc")
+        res[name] = (N(p.wave()).astype(np.float64), sc_linear([m for _, m, _ in ev]))
+    err_fast = rel_l2(res["fast"][0], res["f64"][0])
+    err_gen = rel_l2(res["gen"][0], res["f64"][0])
+    assert err_fast < max(2.0 * err_gen, 1e-4), (err_fast, err_gen)
+    assert np.abs(res["fast"][1] - res["f64"][1]).max() < 1e-5      # |dSC_lin| <= 1e-5 (north-star bar)
