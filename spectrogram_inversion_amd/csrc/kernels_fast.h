@@ -389,11 +389,13 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
 
     // ---- conjugate partners: upper half of lane (64 - r)
     v2f rc[H];   // rc[i] pairs with own register H-1-i ... see below: rc[m-H] = Z[M - (lane + 64*(R-1-m))]
+    // (the lane-0 special case is patched AFTER the shuffle: selecting between two elements of
+    // one register array before it makes the compiler index the array dynamically)
 #pragma unroll
     for (int m = H; m < R; ++m) {
-      const v2f alt = z[(m + 1) % R];              // lane 0 is its own partner, shifted by one register
-      const v2f snd = lane == 0 ? alt : z[m];
-      rc[m - H] = shfl2(snd, k.partner);
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];              // lane 0 is its own partner, shifted by one register
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
     }
 
     // ---- per pair: split -> update -> fold back
@@ -446,10 +448,9 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
     // ---- return the mirrored halves
 #pragma unroll
     for (int m = H; m < R; ++m) {
-      const v2f gen = back[R - 1 - m];
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
       const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
-      const v2f snd = lane == 0 ? l0 : gen;
-      z[m] = shfl2(snd, k.partner);
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
     }
 
     fft_inverse<R>(z, k, lds_tw1, tr);
