@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libspecinv.so")
+# SPECINV_LIB selects a tuning variant built by tools/sweep_variants.sh (development only)
+LIB_PATH = os.environ.get("SPECINV_LIB") or os.path.join(_PKG, "libspecinv.so")
 
 OK, EINVAL, EHIP, EUNSUPPORTED, ENOMEM, ESTATE = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1

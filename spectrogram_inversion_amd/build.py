@@ -40,19 +40,22 @@ def is_stale() -> bool:
     return any(os.path.getmtime(p) > t for p in srcs + hdrs)
 
 
-def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    """Compile if missing or older than any source.  Returns the library path."""
-    if not force and not is_stale():
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """Compile if missing or older than any source.  Returns the library path.
+    `extra_flags` / `out` build tuning variants next to the default library."""
+    global_out = out or LIB_PATH
+    if out is None and not force and not is_stale():
         return LIB_PATH
     srcs, _ = sources()
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("SPECINV_EXTRA_FLAGS", "").split())
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-           *extra_flags, *srcs, "-o", LIB_PATH + ".tmp"]
+           *extra_flags, *srcs, "-o", global_out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(global_out + ".tmp", global_out)
+    return global_out
 
 
 if __name__ == "__main__":

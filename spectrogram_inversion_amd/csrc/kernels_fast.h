@@ -29,6 +29,17 @@
 
 #include "common.h"
 
+// build-time tunables of the fused kernel (see tools/sweep_variants.sh)
+#ifndef SPECINV_XPREF      // 0: load the frame when it starts; 1: carry the samples in registers and prefetch one
+#define SPECINV_XPREF 2    //    hop-block ahead; 2: fetch the whole next frame after the spectral update (into the
+#endif                     //    registers the consumed state frees) so that it flies during the inverse FFT
+#ifndef SPECINV_PLATE      // 0: issue the state loads at the start of the frame; 1: after the forward FFT
+#define SPECINV_PLATE 0
+#endif
+#ifndef SPECINV_MINWAVES   // __launch_bounds__ waves per SIMD (caps the register allocation)
+#define SPECINV_MINWAVES 2
+#endif
+
 namespace specinv {
 namespace fast {
 
@@ -149,7 +160,7 @@ template <int R>
 struct LaneConst {
   int lane, n2, v, kv, partner;
   v2f post;                // W_64^(n2*kv)
-  v2f stage[3];            // stage twiddles of the cross-lane radix-2 network (index s)
+  v2f stage[1];            // twiddle between the cross-lane radix-4 and radix-2 steps (C == 8)
   v2f wn;                  // W_N^lane
   int tr_a;                // transpose address for layout A: (kv*R + reg)*(R+1) + n2  -> base + reg*(R+1)
   int tr_b;                // layout B: lane*(R+1) + reg
@@ -168,23 +179,54 @@ __device__ __forceinline__ LaneConst<R> lane_consts() {
   k.lane = threadIdx.x & 63;
   k.n2 = k.lane % R;
   k.v = k.lane / R;
-  int rev = 0;
-#pragma unroll
-  for (int bit = 0; bit < G::LOGC; ++bit) rev |= ((k.v >> bit) & 1) << (G::LOGC - 1 - bit);
-  k.kv = rev;
+  // frequency digit held at lane position v after the cross-lane transform, and the one twiddle of the
+  // radix-4 x radix-2 split (C == 8 only): W8^(vl * kh) with v = 2*vh + vl, kv = kh + 4*kl, kh = vh, kl = vl
+  if (G::C == 4) {
+    k.kv = k.v;
+    k.stage[0] = v2f{1.0f, 0.0f};
+  } else {
+    const int vh = k.v >> 1, vl = k.v & 1;
+    k.kv = vh + 4 * vl;
+    k.stage[0] = unit(2.0f * (float)(vl * vh) / 8.0f);
+  }
   k.partner = (64 - k.lane) & 63;
   k.post = unit(2.0f * (float)(k.n2 * k.kv) / 64.0f);
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int hs = 1 << s;
-    const bool upper = (k.v >> s) & 1;
-    // radix-2 DIF stage with half size hs (in units of v): upper outputs times W_{2hs}^(v mod hs)
-    k.stage[s] = upper ? unit(2.0f * (float)(k.v & (hs - 1)) / (float)(2 * hs)) : v2f{1.0f, 0.0f};
-  }
   k.wn = unit(2.0f * (float)k.lane / (float)G::N);
   k.tr_a = (k.kv * R) * (R + 1) + k.n2;
   k.tr_b = k.lane * (R + 1);
   return k;
+}
+
+// ---- cross-lane butterflies with the gfx950 lane-swap instructions ---------------------------------
+// v_permlane32_swap a, b : swaps a[32..63] with b[0..31];  v_permlane16_swap a, b : swaps the odd 16-lane
+// rows of a with the even rows of b.  Two levels of swaps bring the four values that sit in lanes
+// l, l+16, l+32, l+48 of ONE register into four registers of one lane (each 16-lane row ends up
+// owning one of the four registers), a plain in-register radix-4 runs at full lane efficiency, and the
+// same swaps in reverse order put result kv back into lane row kv.  No LDS round trip, no twiddles.
+__device__ __forceinline__ void swap32(v2f& a, v2f& b) {
+  const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a = v2f{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+  b = v2f{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+__device__ __forceinline__ void swap16(v2f& a, v2f& b) {
+  const auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  const auto ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a = v2f{__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+  b = v2f{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+// DFT over lane bits 5,4 (lane = 16*q + r, q = 0..3) of four registers at once
+template <bool INV>
+__device__ __forceinline__ void xlane_dft4(v2f& A, v2f& B, v2f& C, v2f& D) {
+  swap32(A, B);
+  swap32(C, D);
+  swap16(A, C);
+  swap16(B, D);
+  dft4<INV>(A, C, B, D);   // this lane's four values, q = 0..3, sit in (A, C, B, D)
+  swap16(A, C);
+  swap16(B, D);
+  swap32(A, B);
+  swap32(C, D);
 }
 
 // ---- M-point FFT across the wave ------------------------------------------------------------------
@@ -196,16 +238,21 @@ __device__ __forceinline__ void fft_forward(v2f (&z)[R], const LaneConst<R>& k, 
   Dft<R, false>::run(z);
 #pragma unroll
   for (int k1 = 1; k1 < R; ++k1) z[k1] = cmul(z[k1], tw1[(k1 - 1) * 64 + k.lane]);
-  // cross-lane radix-C, decimation in frequency; result for kv = bitrev(v) at position v
+  // cross-lane radix-C over v = lane / R; afterwards lane position v holds frequency digit k.kv
+  if (G::C == 4) {
 #pragma unroll
-  for (int s = G::LOGC - 1; s >= 0; --s) {
-    const bool upper = (k.v >> s) & 1;
+    for (int g = 0; g < R; g += 4) xlane_dft4<false>(z[g], z[g + 1], z[g + 2], z[g + 3]);
+  } else {
+    // C == 8, v = 2*vh + vl: radix-4 over vh (lane bits 5,4), twiddle W8^(vl*kh), radix-2 over vl (lane bit 3)
+#pragma unroll
+    for (int g = 0; g < R; g += 4) xlane_dft4<false>(z[g], z[g + 1], z[g + 2], z[g + 3]);
+    const bool upper = k.v & 1;
     const float sg = upper ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const v2f p = shfl_xor2(z[i], R << s);
+      z[i] = cmul(z[i], k.stage[0]);
+      const v2f p = shfl_xor2(z[i], R);
       z[i] = v2f{fmaf(z[i].x, sg, p.x), fmaf(z[i].y, sg, p.y)};   // lower: a + p ; upper: p - a
-      if (s > 0) z[i] = cmul(z[i], k.stage[s]);
     }
   }
 #pragma unroll
@@ -228,16 +275,20 @@ __device__ __forceinline__ void fft_inverse(v2f (&z)[R], const LaneConst<R>& k, 
   for (int i = 0; i < R; ++i) tr[k.tr_b + i] = z[i];
 #pragma unroll
   for (int i = 0; i < R; ++i) z[i] = cmulc(tr[k.tr_a + i * (R + 1)], k.post);
+  if (G::C == 4) {
 #pragma unroll
-  for (int s = 0; s < G::LOGC; ++s) {
-    const bool upper = (k.v >> s) & 1;
+    for (int g = 0; g < R; g += 4) xlane_dft4<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
+  } else {
+    const bool upper = k.v & 1;
     const float sg = upper ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      if (s > 0) z[i] = cmulc(z[i], k.stage[s]);
-      const v2f p = shfl_xor2(z[i], R << s);
+      const v2f p = shfl_xor2(z[i], R);
       z[i] = v2f{fmaf(z[i].x, sg, p.x), fmaf(z[i].y, sg, p.y)};
+      z[i] = cmulc(z[i], k.stage[0]);
     }
+#pragma unroll
+    for (int g = 0; g < R; g += 4) xlane_dft4<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
   }
 #pragma unroll
   for (int k1 = 1; k1 < R; ++k1) z[k1] = cmulc(z[k1], tw1[(k1 - 1) * 64 + k.lane]);
@@ -309,14 +360,42 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const 
   }
 }
 
+// One hop-block (N/4 samples, padded-signal block index j) of row `xrow` in the register layout
+// (lane l, register i <-> samples 128 i + 2 l, +1).  Blocks 2..T lie inside the signal; the two
+// blocks on either side are torch.stft's reflect padding.
+template <int R>
+__device__ __forceinline__ void load_block(const float* __restrict__ xrow, long long L, int T, int j, int lane,
+                                           v2f (&q)[R / 4]) {
+  constexpr int HOP = Geo<R>::HOP;
+  const long long s0 = (long long)(j - 2) * HOP;
+  if (j >= 2 && j <= T) {
+    const v2f* src = reinterpret_cast<const v2f*>(xrow + s0);   // uniform
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) q[i] = src[64u * i + (unsigned)lane];
+  } else {
+#pragma unroll
+    for (int i = 0; i < R / 4; ++i) {
+      long long n0 = s0 + 128 * i + 2 * lane, n1 = n0 + 1;
+      n0 = n0 < 0 ? -n0 : (n0 >= L ? 2 * (L - 1) - n0 : n0);
+      n1 = n1 < 0 ? -n1 : (n1 >= L ? 2 * (L - 1) - n1 : n1);
+      q[i] = v2f{xrow[(unsigned)n0], xrow[(unsigned)n1]};
+    }
+  }
+}
+
+__device__ __forceinline__ v4f ld_stream(const v4f* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(v4f* p, v4f v) { __builtin_nontemporal_store(v, p); }
+
 template <int R, int MODE, bool EVAL>
-__global__ __launch_bounds__(256) void k_fused(FastArgs a) {
+__global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
   using G = Geo<R>;
   constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* lds_win = reinterpret_cast<v2f*>(smem);
   v2f* lds_tw1 = lds_win + M;
-  const int wib = threadIdx.x >> 6;
+  // wave-uniform values are forced into SGPRs: every global address below is then
+  // "scalar base + 32-bit lane offset" instead of one 64-bit VGPR pointer per access
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
 
   for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
@@ -330,6 +409,7 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
   if (w >= a.n_waves) return;
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
   const int b = w / a.nchunks, c = w - b * a.nchunks;
   const int t_begin = c * a.chunk;
   const int t_end = min(a.T, t_begin + a.chunk);
@@ -343,49 +423,96 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
   for (int i = 0; i < 3 * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
   double sd = 0.0, so = 0.0;
 
+  // raw samples of the current frame: three hop-blocks carried from frame to frame plus the
+  // new one, which is fetched one frame ahead so that its latency hides behind a whole frame
+#if SPECINV_XPREF == 2
+  v2f znext[R];
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    v2f q[QU];
+    load_block<R>(xrow, a.L, a.T, t_start + qq, lane, q);
+#pragma unroll
+    for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
+  }
+#elif SPECINV_XPREF == 1
+  v2f xq[3][QU], xn[QU];
+  load_block<R>(xrow, a.L, a.T, t_start, lane, xq[0]);
+  load_block<R>(xrow, a.L, a.T, t_start + 1, lane, xq[1]);
+  load_block<R>(xrow, a.L, a.T, t_start + 2, lane, xq[2]);
+  load_block<R>(xrow, a.L, a.T, t_start + 3, lane, xn);
+#endif
+
   for (int t = t_start; t < t_end; ++t) {
+    // Keep the loop-invariant table reads (window, twiddles) and products inside the loop: hoisted out
+    // of it they pin ~80 VGPRs for the whole kernel and cost a wave of occupancy.
+    asm volatile("" ::: "memory");
+    v2f wn = k.wn;
+    asm volatile("" : "+v"(wn));
     const bool live = t >= t_begin;
     const long long fi = (long long)b * a.T + t;
 
-    // ---- issue the state loads early; they are consumed after the forward FFT
     v4f pp[H], uu[H], mm[H / 2];
-#pragma unroll
-    for (int j = 0; j < H; ++j) pp[j] = a.P_in[(fi * H + j) * 64 + lane];
-    if (MODE == MODE_ADMM) {
-#pragma unroll
-      for (int j = 0; j < H; ++j) uu[j] = a.U_in[(fi * H + j) * 64 + lane];
-    }
-#pragma unroll
-    for (int j = 0; j < H / 2; ++j) mm[j] = a.m_pairs[(fi * (H / 2) + j) * 64 + lane];
     v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
     float mmid = 0.0f;
-    if (lane == 0) {
-      pmid = a.Pmid_in[fi];
-      mmid = a.m_mid[fi];
-      if (MODE == MODE_ADMM) umid = a.Umid_in[fi];
-    }
+    // per-frame uniform bases (SGPR) + unsigned 32-bit lane offsets -> "saddr + voffset" addressing
+    const v4f* pin = a.P_in + fi * (H * 64);
+    const v4f* uin = MODE == MODE_ADMM ? a.U_in + fi * (H * 64) : nullptr;
+    const v4f* min_ = a.m_pairs + fi * (H / 2 * 64);
+    v4f* pout = a.P_out + fi * (H * 64);
+    v4f* uout = MODE == MODE_ADMM ? a.U_out + fi * (H * 64) : nullptr;
+#define SPECINV_STATE_LOADS()                                                              \
+  do {                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin[j * 64u + ulane]); \
+    if (MODE == MODE_ADMM) {                                                               \
+      _Pragma("unroll") for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin[j * 64u + ulane]); \
+    }                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]); \
+    if (lane == 0) {                                                                       \
+      pmid = a.Pmid_in[fi];                                                                \
+      mmid = a.m_mid[fi];                                                                  \
+      if (MODE == MODE_ADMM) umid = a.Umid_in[fi];                                         \
+    }                                                                                      \
+  } while (0)
+#if !SPECINV_PLATE
+    SPECINV_STATE_LOADS();   // early: the loads fly during the forward FFT
+#endif
 
     // ---- analysis: windowed frame -> registers
     v2f z[R];
-    const long long s0 = (long long)(t - 2) * HOP;   // signal index of the frame's first sample
-    if (t >= 2 && t <= a.T - 3) {
-      const v2f* src = reinterpret_cast<const v2f*>(xrow + s0);
+#if SPECINV_XPREF == 2
 #pragma unroll
-      for (int u = 0; u < R; ++u) z[u] = src[64 * u + lane];
-    } else {
-      // frames that reach into torch.stft's reflect padding
+    for (int u = 0; u < R; ++u) z[u] = znext[u] * lds_win[64 * u + lane];
+#elif SPECINV_XPREF == 1
+    // slide the sample window and prefetch the next hop-block
 #pragma unroll
-      for (int u = 0; u < R; ++u) {
-        long long n0 = s0 + 128 * u + 2 * lane, n1 = n0 + 1;
-        n0 = n0 < 0 ? -n0 : (n0 >= a.L ? 2 * (a.L - 1) - n0 : n0);
-        n1 = n1 < 0 ? -n1 : (n1 >= a.L ? 2 * (a.L - 1) - n1 : n1);
-        z[u] = v2f{xrow[n0], xrow[n1]};
-      }
+    for (int i = 0; i < QU; ++i) {
+      z[i] = xq[0][i] * lds_win[64 * i + lane];
+      z[QU + i] = xq[1][i] * lds_win[64 * (QU + i) + lane];
+      z[2 * QU + i] = xq[2][i] * lds_win[64 * (2 * QU + i) + lane];
+      z[3 * QU + i] = xn[i] * lds_win[64 * (3 * QU + i) + lane];
+      xq[0][i] = xq[1][i];
+      xq[1][i] = xq[2][i];
+      xq[2][i] = xn[i];
     }
+    if (t + 1 < t_end) load_block<R>(xrow, a.L, a.T, t + 4, lane, xn);
+#else
+    {
+      v2f q[QU];
 #pragma unroll
-    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+      for (int qq = 0; qq < 4; ++qq) {
+        load_block<R>(xrow, a.L, a.T, t + qq, lane, q);
+#pragma unroll
+        for (int i = 0; i < QU; ++i) z[qq * QU + i] = q[i];
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    }
+#endif
 
     fft_forward<R>(z, k, lds_tw1, tr);
+#if SPECINV_PLATE
+    SPECINV_STATE_LOADS();
+#endif
 
     // ---- conjugate partners: upper half of lane (64 - r)
     v2f rc[H];   // rc[i] pairs with own register H-1-i ... see below: rc[m-H] = Z[M - (lane + 64*(R-1-m))]
@@ -403,7 +530,7 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       // W_N^(lane + 64 j) = W_N^lane * W_{2R}^j
-      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = zk + cconj(zm);
       const v2f o2 = mul_mi(zk - cconj(zm));
@@ -421,8 +548,8 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
       v2f ak = update_bin<MODE, EVAL>(xk, pk, uk, mk, a, live, sd, so);
       v2f am = update_bin<MODE, EVAL>(xm, pm, um, mq, a, live, sd, so);
       if (live) {
-        a.P_out[(fi * H + j) * 64 + lane] = v4f{pk.x, pk.y, pm.x, pm.y};
-        if (MODE == MODE_ADMM) a.U_out[(fi * H + j) * 64 + lane] = v4f{uk.x, uk.y, um.x, um.y};
+        st_stream(&pout[j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
+        if (MODE == MODE_ADMM) st_stream(&uout[j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
       }
       if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
         ak.y = 0.0f;
@@ -453,6 +580,19 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
       z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
     }
 
+#if SPECINV_XPREF == 2
+    if (t + 1 < t_end) {
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        v2f q[QU];
+        load_block<R>(xrow, a.L, a.T, t + 1 + qq, lane, q);
+#pragma unroll
+        for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
+      }
+    }
+#endif
+
+    asm volatile("" ::: "memory");   // re-read the twiddles instead of keeping them live since the forward FFT
     fft_inverse<R>(z, k, lds_tw1, tr);
 
     // ---- synthesis window, register overlap-add, one finished hop-block out
@@ -460,11 +600,10 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
     for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
     if (live && t >= 2) {
       const long long o0 = (long long)(t - 2) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
+      v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) {
-        const v2f ie = *reinterpret_cast<const v2f*>(a.inv_env + o0 + 128 * i + 2 * lane);
-        *reinterpret_cast<v2f*>(orow + o0 + 128 * i + 2 * lane) = (acc[i] + z[i]) * ie;
-      }
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = (acc[i] + z[i]) * envp[64u * i + ulane];
     }
 #pragma unroll
     for (int i = 0; i < QU; ++i) {
@@ -476,11 +615,10 @@ __global__ __launch_bounds__(256) void k_fused(FastArgs a) {
   // the chunk that holds the last frame also finishes hop-block T (frames T-3 .. T-1)
   if (t_end == a.T) {
     const long long o0 = (long long)(a.T - 2) * HOP;
+    const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
+    v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-    for (int i = 0; i < QU; ++i) {
-      const v2f ie = *reinterpret_cast<const v2f*>(a.inv_env + o0 + 128 * i + 2 * lane);
-      *reinterpret_cast<v2f*>(orow + o0 + 128 * i + 2 * lane) = acc[i] * ie;
-    }
+    for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[i] * envp[64u * i + ulane];
   }
   if (EVAL) {
     const double d = wave_sum(sd), o = wave_sum(so);
