@@ -1,25 +1,508 @@
-// L_BFGS building blocks (methods.py:509-569): fused transform forward / loss+gradient and the
-// flat-vector kernels of the two-loop recursion.
+// L_BFGS building blocks (reference: torch_specinv/methods.py:509-569 + torch.optim.LBFGS).
+//
+//   * transform forward  V = |STFT(x)|  or  V = log1p(Mel @ |STFT(x)|)
+//   * loss = mean((V - target)^2) and its analytic gradient w.r.t. x (verified against
+//     autograd): dV = 2(V-T)/numel ; dMel = dV/(1 + Mel|S|) ; dA = Mel^T dMel ; G = dA * S/|S|
+//     (0 where |S| = 0) ; frame gradient = Re sum_k G[k] e^{+2 pi i k n/N} (onesided: interior bins
+//     halved, then Hermitian inverse) * window ; overlap-add without envelope ; padded margins folded
+//     back according to the pad mode.
+//   * the two mel contractions are dense GEMMs and run on the matrix cores with the exact-float32 MFMA
+//     (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) - the only MFMA use in the library.
+//   * flat-vector reductions / updates of the two-loop recursion, accumulated in float64.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
+#include "kernels_generic.h"
 
 namespace specinv {
 
-template <typename P, typename T>
-int tf_setup(P&, int, const T*, int) { return fail(SPECINV_EUNSUPPORTED, "transform path not built yet"); }
-template <typename P, typename T>
-int tf_forward(P&, const T*, int64_t, T*) { return fail(SPECINV_EUNSUPPORTED, "transform path not built yet"); }
-template <typename P, typename T>
-int tf_loss_grad(P&, const T*, int64_t, const T*, double*, T*) {
-  return fail(SPECINV_EUNSUPPORTED, "transform path not built yet");
+// ---- flat vector kernels ------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_dot_partials(const T* __restrict__ a, const T* __restrict__ b, int64_t n, double* __restrict__ part) {
+  __shared__ double red[16];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    s += (double)a[i] * (double)b[i];
+  const double t = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
+
+template <typename T>
+__global__ void k_abs_partials(const T* __restrict__ a, int64_t n, double* __restrict__ part) {
+  __shared__ double red[16];
+  double s = 0, m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = fabs((double)a[i]);
+    s += v;
+    m = v > m ? v : m;
+  }
+  // max over the block
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(m, off, 64);
+    m = o > m ? o : m;
+  }
+  __shared__ double mx[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) mx[wave] = m;
+  const double t = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    double mm = 0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) mm = mx[w] > mm ? mx[w] : mm;
+    part[2 * blockIdx.x] = mm;
+    part[2 * blockIdx.x + 1] = t;
+  }
+}
+
+// out[0] = max_i part[2i], out[1] = sum_i part[2i+1]
+__global__ void k_finish_absmax(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0, m = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    m = part[2 * i] > m ? part[2 * i] : m;
+    s += part[2 * i + 1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(m, off, 64);
+    m = o > m ? o : m;
+  }
+  __shared__ double mx[16];
+  if ((threadIdx.x & 63) == 0) mx[threadIdx.x >> 6] = m;
+  const double t = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    double mm = 0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) mm = mx[w] > mm ? mx[w] : mm;
+    out[0] = mm;
+    out[1] = t;
+  }
+}
+
+template <typename T>
+__global__ void k_axpy(T alpha, const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = y[i] + alpha * x[i];
+}
+
+template <typename T>
+__global__ void k_scale(T alpha, const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = alpha * x[i];
+}
+
 template <typename P, typename T>
-int lb_dot(P&, const T*, const T*, int64_t, double*) { return fail(SPECINV_EUNSUPPORTED, "not built yet"); }
+int lb_reduce_blocks(P& pl, int64_t n, int comps) {
+  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * comps, 3 * 1024) * sizeof(double)));
+  return nb;
+}
+
 template <typename P, typename T>
-int lb_axpy(P&, T, const T*, T*, int64_t) { return fail(SPECINV_EUNSUPPORTED, "not built yet"); }
+int lb_dot(P& pl, const T* a, const T* b, int64_t n, double* out) {
+  SI_CHECK(a && b && out && n > 0, SPECINV_EINVAL, "bad arguments");
+  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb, 3 * 1024) * sizeof(double)));
+  hipLaunchKernelGGL((k_dot_partials<T>), dim3(nb), dim3(256), 0, pl.stream, a, b, n, pl.partials.template as<double>());
+  SI_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), (int64_t)nb, 1,
+                     pl.sums.template as<double>());
+  SI_HIP(hipGetLastError());
+  SI_HIP(hipMemcpyAsync(out, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(hipStreamSynchronize(pl.stream));
+  return SPECINV_OK;
+}
+
 template <typename P, typename T>
-int lb_scale(P&, T, const T*, T*, int64_t) { return fail(SPECINV_EUNSUPPORTED, "not built yet"); }
+int lb_axpy(P& pl, T alpha, const T* x, T* y, int64_t n) {
+  SI_CHECK(x && y && n > 0, SPECINV_EINVAL, "bad arguments");
+  hipLaunchKernelGGL((k_axpy<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, pl.stream, alpha, x, y, n);
+  SI_HIP(hipGetLastError());
+  return SPECINV_OK;
+}
+
 template <typename P, typename T>
-int lb_absmax_abssum(P&, const T*, int64_t, double*) { return fail(SPECINV_EUNSUPPORTED, "not built yet"); }
+int lb_scale(P& pl, T alpha, const T* x, T* y, int64_t n) {
+  SI_CHECK(x && y && n > 0, SPECINV_EINVAL, "bad arguments");
+  hipLaunchKernelGGL((k_scale<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, pl.stream, alpha, x, y, n);
+  SI_HIP(hipGetLastError());
+  return SPECINV_OK;
+}
+
+template <typename P, typename T>
+int lb_absmax_abssum(P& pl, const T* x, int64_t n, double* out) {
+  SI_CHECK(x && out && n > 0, SPECINV_EINVAL, "bad arguments");
+  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * 2, 3 * 1024) * sizeof(double)));
+  hipLaunchKernelGGL((k_abs_partials<T>), dim3(nb), dim3(256), 0, pl.stream, x, n, pl.partials.template as<double>());
+  SI_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_finish_absmax, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), nb,
+                     pl.sums.template as<double>());
+  SI_HIP(hipGetLastError());
+  SI_HIP(hipMemcpyAsync(out, pl.sums.p, 2 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(hipStreamSynchronize(pl.stream));
+  return SPECINV_OK;
+}
+
+// ---- mel contractions on the matrix cores ----------------------------------------------------------------
+// One wave owns a 32 x 32 output tile and feeds v_mfma_f32_32x32x2_f32 (A: lane l holds A[l&31][l>>5],
+// B: lane l holds B[l>>5][l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)).  Operands are staged
+// through LDS in 32 x 32 tiles with a one-dword row pad (conflict-free column reads).
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+__device__ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// mm[bt, m] = sum_f Mel[m, f] * |S[bt, f]|  ->  V = log1p(mm).   S: (BT, F) complex, Mel: (n_mels, F).
+// grid (ceil(BT/32), ceil(n_mels/32)), one wave per block.  Float32 only.
+__global__ __launch_bounds__(64) void k_mel_forward_mfma(const cplx<float>* __restrict__ spec, const float* __restrict__ mel,
+                                                         float* __restrict__ mm_out, int64_t BT, int F, int n_mels) {
+  __shared__ float sa[32][33];   // Mel tile  [m][k]
+  __shared__ float sb[32][33];   // |S| tile  [bt][k]
+  const int lane = threadIdx.x;
+  const int64_t bt0 = (int64_t)blockIdx.x * 32;
+  const int m0 = blockIdx.y * 32;
+  f32x16 acc = {0};
+  for (int k0 = 0; k0 < F; k0 += 32) {
+    // 32 x 32 tiles, 16 elements per lane, rows contiguous in k (coalesced 128-byte rows)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = i * 2 + (lane >> 5), c = lane & 31;
+      const int k = k0 + c;
+      float va = 0.f, vb = 0.f;
+      if (k < F) {
+        if (m0 + r < n_mels) va = mel[(int64_t)(m0 + r) * F + k];
+        if (bt0 + r < BT) {
+          const cplx<float> s = spec[(bt0 + r) * F + k];
+          vb = hypotf(s.x, s.y);
+        }
+      }
+      sa[r][c] = va;
+      sb[r][c] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float a = sa[lane & 31][kk + (lane >> 5)];
+      const float b = sb[lane & 31][kk + (lane >> 5)];
+      acc = mfma_32x32x2(a, b, acc);
+    }
+    __syncthreads();
+  }
+  // D[row = m][col = bt]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int col = lane & 31;
+    if (m0 + row < n_mels && bt0 + col < BT) mm_out[(bt0 + col) * n_mels + m0 + row] = acc[r];
+  }
+}
+
+// dA[bt, f] = sum_m dM[bt, m] * Mel[m, f] ; G[bt, f] = dA * S/|S| * (interior ? 1/2 : 1)   (in place over S)
+// grid (ceil(BT/32), ceil(F/32)), one wave per block.
+__global__ __launch_bounds__(64) void k_mel_backward_mfma(cplx<float>* __restrict__ spec, const float* __restrict__ mel,
+                                                          const float* __restrict__ dM, int64_t BT, int F, int n_mels,
+                                                          int n_fft, int onesided) {
+  __shared__ float sa[32][33];   // dM tile  [bt][m]
+  __shared__ float sb[32][33];   // Mel tile [m][f]
+  const int lane = threadIdx.x;
+  const int64_t bt0 = (int64_t)blockIdx.x * 32;
+  const int f0 = blockIdx.y * 32;
+  f32x16 acc = {0};
+  for (int k0 = 0; k0 < n_mels; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = i * 2 + (lane >> 5), c = lane & 31;
+      float va = 0.f, vb = 0.f;
+      if (bt0 + r < BT && k0 + c < n_mels) va = dM[(bt0 + r) * n_mels + k0 + c];
+      if (k0 + r < n_mels && f0 + c < F) vb = mel[(int64_t)(k0 + r) * F + f0 + c];
+      sa[r][c] = va;
+      sb[r][c] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float a = sa[lane & 31][kk + (lane >> 5)];   // A[i = bt][k = m]
+      const float b = sb[kk + (lane >> 5)][lane & 31];   // B[k = m][j = f]
+      acc = mfma_32x32x2(a, b, acc);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // bt
+    const int f = f0 + (lane & 31);
+    if (bt0 + row < BT && f < F) {
+      const int64_t idx = (bt0 + row) * F + f;
+      const cplx<float> s = spec[idx];
+      const float mag = hypotf(s.x, s.y);
+      float g = mag > 0.f ? acc[r] / mag : 0.f;
+      if (onesided && f != 0 && 2 * f != n_fft) g *= 0.5f;
+      spec[idx] = mk<float>(s.x * g, s.y * g);
+    }
+  }
+}
+
+// ---- elementwise pieces -----------------------------------------------------------------------------------------
+// V = |S| in user layout (B, F, T) from S (B, T, F)
+template <typename T>
+__global__ void k_mag_to_user(const cplx<T>* __restrict__ spec, T* __restrict__ v, int Bn, int Tn, int F) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, f, t)
+  if (i >= (int64_t)Bn * F * Tn) return;
+  const int t = i % Tn;
+  const int f = (i / Tn) % F;
+  const int64_t b = i / ((int64_t)Tn * F);
+  const cplx<T> s = spec[(b * Tn + t) * F + f];
+  v[i] = si_hypot(s.x, s.y);
+}
+
+// V = log1p(mm) in user layout (B, n_mels, T) from mm (B*T, n_mels)
+template <typename T>
+__global__ void k_log1p_to_user(const T* __restrict__ mm, T* __restrict__ v, int Bn, int Tn, int n_mels) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, m, t)
+  if (i >= (int64_t)Bn * n_mels * Tn) return;
+  const int t = i % Tn;
+  const int m = (i / Tn) % n_mels;
+  const int64_t b = i / ((int64_t)Tn * n_mels);
+  v[i] = log1p(mm[(b * Tn + t) * n_mels + m]);
+}
+
+// MAG transform: loss partials and G = (2/numel) (|S| - T) S/|S| * (interior ? 1/2 : 1) in place over S
+template <typename T>
+__global__ void k_mag_loss_grad(cplx<T>* __restrict__ spec, const T* __restrict__ target, int Bn, int Tn, int F, int n_fft,
+                                int onesided, double inv_numel, double* __restrict__ part) {
+  __shared__ double red[16];
+  double s2 = 0;
+  const int64_t total = (int64_t)Bn * Tn * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = i % F;
+    const int t = (i / F) % Tn;
+    const int64_t b = i / ((int64_t)F * Tn);
+    const cplx<T> s = spec[i];
+    const T mag = si_hypot(s.x, s.y);
+    const T d = mag - target[(b * F + f) * Tn + t];
+    s2 += (double)d * (double)d;
+    T g = mag > T(0) ? (T)(2.0 * inv_numel) * d / mag : T(0);
+    if (onesided && f != 0 && 2 * f != n_fft) g *= T(0.5);
+    spec[i] = mk<T>(s.x * g, s.y * g);
+  }
+  const double t = block_sum(s2, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// LOGMEL: loss partials and dM = (2/numel) (log1p(mm) - T) / (1 + mm), in place over mm (BT, n_mels)
+template <typename T>
+__global__ void k_logmel_loss_dm(T* __restrict__ mm, const T* __restrict__ target, int Bn, int Tn, int n_mels,
+                                 double inv_numel, double* __restrict__ part) {
+  __shared__ double red[16];
+  double s2 = 0;
+  const int64_t total = (int64_t)Bn * Tn * n_mels;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = i % n_mels;
+    const int t = (i / n_mels) % Tn;
+    const int64_t b = i / ((int64_t)n_mels * Tn);
+    const T v = mm[i];
+    const T d = log1p(v) - target[(b * n_mels + m) * Tn + t];
+    s2 += (double)d * (double)d;
+    mm[i] = (T)(2.0 * inv_numel) * d / (T(1) + v);
+  }
+  const double t = block_sum(s2, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// float64 / generic mel contractions (VALU): thread per output
+template <typename T>
+__global__ void k_mel_forward_valu(const cplx<T>* __restrict__ spec, const T* __restrict__ mel, T* __restrict__ mm,
+                                   int64_t BT, int F, int n_mels) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BT * n_mels) return;
+  const int m = i % n_mels;
+  const int64_t bt = i / n_mels;
+  T acc = 0;
+  for (int f = 0; f < F; ++f) {
+    const cplx<T> s = spec[bt * F + f];
+    acc += mel[(int64_t)m * F + f] * si_hypot(s.x, s.y);
+  }
+  mm[i] = acc;
+}
+
+template <typename T>
+__global__ void k_mel_backward_valu(cplx<T>* __restrict__ spec, const T* __restrict__ mel, const T* __restrict__ dM,
+                                    int64_t BT, int F, int n_mels, int n_fft, int onesided) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BT * F) return;
+  const int f = i % F;
+  const int64_t bt = i / F;
+  T acc = 0;
+  for (int m = 0; m < n_mels; ++m) acc += dM[bt * n_mels + m] * mel[(int64_t)m * F + f];
+  const cplx<T> s = spec[i];
+  const T mag = si_hypot(s.x, s.y);
+  T g = mag > T(0) ? acc / mag : T(0);
+  if (onesided && f != 0 && 2 * f != n_fft) g *= T(0.5);
+  spec[i] = mk<T>(s.x * g, s.y * g);
+}
+
+// gradient frames: inverse transform of G with the forward scale and the analysis window
+template <typename T>
+__global__ void k_grad_frames(FrameCfg<T> c, const cplx<T>* __restrict__ g, T* __restrict__ frames) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* b = a + c.n_fft;
+  const int t = blockIdx.x, bi = blockIdx.y;
+  const cplx<T>* in = g + ((int64_t)bi * c.n_frames + t) * c.n_freq;
+  for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) a[f] = in[f];
+  __syncthreads();
+  spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
+}
+
+// overlap-add of the gradient frames over the padded signal and fold of the padded margins
+template <typename T>
+__global__ void k_grad_fold(const T* __restrict__ frames, T* __restrict__ grad, int n_fft, int hop, int pad, int pad_mode,
+                            int n_frames, int64_t len, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t bi = i / len;
+  const int64_t n = i - bi * len;
+  const T* fr = frames + bi * n_frames * n_fft;
+  const int64_t covered = (int64_t)(n_frames - 1) * hop + n_fft;   // padded positions that receive any frame
+  auto at = [&](int64_t np) -> T {                                 // gradient w.r.t. padded sample np
+    if (np < 0 || np >= covered) return T(0);
+    int64_t t_hi = np / hop;
+    if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+    const int64_t t_lo = np - n_fft + 1 <= 0 ? 0 : (np - n_fft + hop) / hop;
+    T acc = 0;
+    for (int64_t t = t_lo; t <= t_hi; ++t) acc += fr[t * n_fft + (np - t * hop)];
+    return acc;
+  };
+  T g = at(n + pad);
+  if (pad > 0) {
+    switch (pad_mode) {
+      case SPECINV_PAD_REFLECT:
+        if (n >= 1 && n <= pad) g += at(pad - n);                               // left margin i = pad - n
+        if (n <= len - 2 && n >= len - 1 - pad) g += at(pad + len + (len - 2 - n));
+        break;
+      case SPECINV_PAD_REPLICATE:
+        if (n == 0)
+          for (int64_t j = 0; j < pad; ++j) g += at(j);
+        if (n == len - 1)
+          for (int64_t j = 0; j < pad; ++j) g += at(pad + len + j);
+        break;
+      case SPECINV_PAD_CIRCULAR:
+        if (n >= len - pad) g += at(n - (len - pad));
+        if (n < pad) g += at(pad + len + n);
+        break;
+      default:
+        break;
+    }
+  }
+  grad[i] = g;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+template <typename P, typename T>
+int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
+  SI_CHECK(kind == SPECINV_TF_MAG || kind == SPECINV_TF_LOGMEL, SPECINV_EINVAL, "unknown transform kind %d", kind);
+  if (kind == SPECINV_TF_LOGMEL) {
+    SI_CHECK(mel_fb && n_mels > 0, SPECINV_EINVAL, "log-mel transform needs a filterbank");
+    SI_TRY(pl.tf_mel.reserve((size_t)n_mels * pl.n_freq * sizeof(T)));
+    SI_HIP(hipMemcpyAsync(pl.tf_mel.p, mel_fb, (size_t)n_mels * pl.n_freq * sizeof(T), hipMemcpyDeviceToDevice, pl.stream));
+    pl.tf_mels = n_mels;
+  } else {
+    pl.tf_mels = 0;
+  }
+  pl.tf_kind = kind;
+  return SPECINV_OK;
+}
+
+template <typename P, typename T>
+int tf_mel_forward(P& pl) {
+  const int64_t BT = (int64_t)pl.B() * pl.Tn();
+  SI_TRY(pl.tf_v.reserve((size_t)BT * pl.tf_mels * sizeof(T)));
+  if constexpr (std::is_same<T, float>::value) {
+    hipLaunchKernelGGL(k_mel_forward_mfma, dim3((unsigned)ceil_div(BT, 32), (unsigned)ceil_div(pl.tf_mels, 32)), dim3(64), 0,
+                       pl.stream, pl.tf_spec.template as<cplx<float>>(), pl.tf_mel.template as<float>(),
+                       pl.tf_v.template as<float>(), BT, pl.n_freq, pl.tf_mels);
+  } else {
+    hipLaunchKernelGGL((k_mel_forward_valu<T>), dim3((unsigned)ceil_div(BT * pl.tf_mels, 256)), dim3(256), 0, pl.stream,
+                       pl.tf_spec.template as<cplx<T>>(), pl.tf_mel.template as<T>(), pl.tf_v.template as<T>(), BT, pl.n_freq,
+                       pl.tf_mels);
+  }
+  SI_HIP(hipGetLastError());
+  return SPECINV_OK;
+}
+
+template <typename P, typename T>
+int tf_forward(P& pl, const T* x, int64_t len, T* v_out) {
+  SI_CHECK(pl.tf_kind >= 0, SPECINV_ESTATE, "specinv_transform_setup has not been called");
+  SI_CHECK(x && v_out, SPECINV_EINVAL, "null pointer");
+  using C = cplx<T>;
+  SI_TRY(pl.tf_spec.reserve(pl.nspec() * sizeof(C)));
+  SI_TRY(pl.stft_internal(x, len, pl.tf_spec.template as<C>()));
+  if (pl.tf_kind == SPECINV_TF_MAG) {
+    const int64_t n = pl.nspec();
+    hipLaunchKernelGGL((k_mag_to_user<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, pl.stream,
+                       pl.tf_spec.template as<C>(), v_out, pl.B(), pl.Tn(), pl.n_freq);
+  } else {
+    SI_TRY((tf_mel_forward<P, T>(pl)));
+    const int64_t n = (int64_t)pl.B() * pl.Tn() * pl.tf_mels;
+    hipLaunchKernelGGL((k_log1p_to_user<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, pl.stream,
+                       pl.tf_v.template as<T>(), v_out, pl.B(), pl.Tn(), pl.tf_mels);
+  }
+  SI_HIP(hipGetLastError());
+  return SPECINV_OK;
+}
+
+template <typename P, typename T>
+int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, T* grad) {
+  SI_CHECK(pl.tf_kind >= 0, SPECINV_ESTATE, "specinv_transform_setup has not been called");
+  SI_CHECK(x && target && loss && grad, SPECINV_EINVAL, "null pointer");
+  using C = cplx<T>;
+  const int64_t BT = (int64_t)pl.B() * pl.Tn();
+  SI_TRY(pl.tf_spec.reserve(pl.nspec() * sizeof(C)));
+  SI_TRY(pl.stft_internal(x, len, pl.tf_spec.template as<C>()));
+  const int nb = 1024;
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb, 3 * 1024) * sizeof(double)));
+  double numel;
+  if (pl.tf_kind == SPECINV_TF_MAG) {
+    numel = (double)pl.nspec();
+    hipLaunchKernelGGL((k_mag_loss_grad<T>), dim3(nb), dim3(256), 0, pl.stream, pl.tf_spec.template as<C>(), target, pl.B(),
+                       pl.Tn(), pl.n_freq, pl.N(), pl.cfg.onesided, 1.0 / numel, pl.partials.template as<double>());
+    SI_HIP(hipGetLastError());
+  } else {
+    numel = (double)BT * pl.tf_mels;
+    SI_TRY((tf_mel_forward<P, T>(pl)));
+    hipLaunchKernelGGL((k_logmel_loss_dm<T>), dim3(nb), dim3(256), 0, pl.stream, pl.tf_v.template as<T>(), target, pl.B(),
+                       pl.Tn(), pl.tf_mels, 1.0 / numel, pl.partials.template as<double>());
+    SI_HIP(hipGetLastError());
+    if constexpr (std::is_same<T, float>::value) {
+      hipLaunchKernelGGL(k_mel_backward_mfma, dim3((unsigned)ceil_div(BT, 32), (unsigned)ceil_div(pl.n_freq, 32)), dim3(64), 0,
+                         pl.stream, pl.tf_spec.template as<cplx<float>>(), pl.tf_mel.template as<float>(),
+                         pl.tf_v.template as<float>(), BT, pl.n_freq, pl.tf_mels, pl.N(), pl.cfg.onesided);
+    } else {
+      hipLaunchKernelGGL((k_mel_backward_valu<T>), dim3((unsigned)ceil_div(BT * pl.n_freq, 256)), dim3(256), 0, pl.stream,
+                         pl.tf_spec.template as<C>(), pl.tf_mel.template as<T>(), pl.tf_v.template as<T>(), BT, pl.n_freq,
+                         pl.tf_mels, pl.N(), pl.cfg.onesided);
+    }
+    SI_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), (int64_t)nb, 1,
+                     pl.sums.template as<double>());
+  SI_HIP(hipGetLastError());
+  // frames of the gradient: irfft-style inverse with the forward scale
+  SI_TRY(pl.frames_needed());
+  FrameCfg<T> c = pl.frame_cfg(len);
+  c.inv_scale = pl.fc.fwd_scale;
+  hipLaunchKernelGGL((k_grad_frames<T>), dim3(pl.Tn(), pl.B()), dim3(256), pl.lds_bytes, pl.stream, c,
+                     pl.tf_spec.template as<C>(), pl.frames.template as<T>());
+  SI_HIP(hipGetLastError());
+  const int64_t total = (int64_t)pl.B() * len;
+  hipLaunchKernelGGL((k_grad_fold<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, pl.frames.template as<T>(),
+                     grad, pl.N(), pl.cfg.hop_length, pl.pad, pl.cfg.pad_mode, pl.Tn(), len, total);
+  SI_HIP(hipGetLastError());
+  double s;
+  SI_HIP(hipMemcpyAsync(&s, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(hipStreamSynchronize(pl.stream));
+  *loss = s / numel;
+  return SPECINV_OK;
+}
 
 }  // namespace specinv

@@ -146,6 +146,7 @@ struct PlanT final : PlanBase {
       SI_HIP(hipFuncSetAttribute((const void*)k_gla_frame<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       SI_HIP(hipFuncSetAttribute((const void*)k_admm_frame<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       SI_HIP(hipFuncSetAttribute((const void*)k_admm_frame<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_grad_frames<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     }
     SI_TRY(sums.reserve(8 * sizeof(double)));
     SI_TRY(fast.setup(cfg, h_window, length, pad));

@@ -150,7 +150,7 @@ def L_BFGS(spec, transform_fn, samples=None, init_x0=None, outer_max_iter=1000, 
             with torch.enable_grad():
                 loss = torch.nn.functional.mse_loss(transform_fn(p), target)   # methods.py:547-549
             (g,) = torch.autograd.grad(loss, p)
-            return float(loss), g.contiguous()
+            return float(loss.detach()), g.contiguous()
 
     opt = _LBFGS(x, device=device, **kwargs)
     name = metric.upper()
