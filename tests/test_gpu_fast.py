@@ -57,7 +57,9 @@ def test_fast_path_selected_and_matches_oracle(n_fft, hop, frames, batch, chunk)
     done, evals = plan.run(10, 5, 0.0, "sc")
     assert done == 10 and len(evals) == 2
     y = N(plan.wave())
-    assert rel_l2(y, ref.reshape(y.shape)) < 5e-5, rel_l2(y, ref.reshape(y.shape))
+    # gate = the north-star bar (waveform rel-L2 <= 1e-4); typical value 1e-6..2e-5, the 6-frame case
+    # amplifies float32 rounding noise ~200x in 10 iterations for any kernel (tools/acc_small.py)
+    assert rel_l2(y, ref.reshape(y.shape)) < 1e-4, rel_l2(y, ref.reshape(y.shape))
     got = sc_linear(np.array([m for _, m, _ in evals]))
     want = sc_linear(np.array([m for _, m, _ in trace]))
     assert np.abs(got - want).max() < 1e-5
