@@ -1,0 +1,163 @@
+"""Host-side logic that needs no GPU: argument normalisation, shape rules, error behaviour, metric
+formulas, the L-BFGS control flow (with a torch-CPU vector backend supplied by the test), mel filterbank."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import spectrogram_inversion_amd as si
+from _util import hann, load_golden, sweep_kwargs
+from spectrogram_inversion_amd.lbfgs import LBFGS
+from spectrogram_inversion_amd.metrics import _from_sums
+from spectrogram_inversion_amd.plan import args_helper, require_gpu
+
+
+def _tk(kw):
+    out = dict(kw)
+    if out.get("window") is not None:
+        out["window"] = torch.from_numpy(np.asarray(out["window"]))
+    return out
+
+
+def test_args_helper_matches_oracle_over_sweep():
+    g = load_golden("g3_sweep")
+    for row in g["meta"]:
+        kw = sweep_kwargs(row)
+        n_freq = 257 if kw["onesided"] else 512
+        a = args_helper(torch.empty(1, n_freq, 3), **_tk(kw))
+        o = oracle.args_helper(n_freq, np.float32, **kw)
+        assert (a.n_fft, a.win_length, a.hop_length, a.center, a.pad_mode, a.normalized, a.onesided) == \
+               (o.n_fft, o.win_length, o.hop_length, o.center, o.pad_mode, o.normalized, o.onesided)
+        np.testing.assert_array_equal(a.window.numpy(), o.window)
+        for frames in (1, 7, 40):
+            assert a.signal_length(frames) == oracle.signal_length(frames, o)
+        assert a.frame_count(4410) == oracle.frame_count(4410, o)
+
+
+def test_args_helper_rules():
+    spec = torch.empty(2, 257, 9)
+    a = args_helper(spec)                                   # defaults: methods.py:34-41,70-77
+    assert (a.n_fft, a.hop_length, a.win_length, a.onesided, a.center, a.pad_mode) == (512, 128, 512, True, True, "reflect")
+    assert torch.equal(a.window, torch.ones(512))
+    a = args_helper(spec, win_length=300, maxiter=7, foo="ignored")    # unknown kwargs dropped, :42-46
+    assert a.window.numel() == 512 and a.window[:106].sum() == 0 and a.window[106:406].sum() == 300
+    a = args_helper(torch.empty(2, 512, 9), onesided=False)
+    assert a.n_fft == 512 and a.n_freq == 512
+    a = args_helper(torch.empty(2, 257, 9, dtype=torch.complex64))
+    assert a.window.dtype == torch.float32                  # complex -> real dtype, :50-57
+    with pytest.raises(AssertionError):
+        args_helper(spec, win_length=600)                   # n_fft >= win_length, :79
+
+
+def test_argument_errors_precede_device_use():
+    mag = torch.rand(2, 65, 8)
+    with pytest.raises(AssertionError):
+        si.griffin_lim(mag, alpha=-1)                       # methods.py:223
+    with pytest.raises(AssertionError):
+        si.griffin_lim(torch.rand(65))                      # rank check, :101
+    with pytest.raises(AssertionError):
+        si.ADMM(mag, metric="psnr")                         # :443
+    with pytest.raises(AssertionError):
+        si.ADMM(mag, eva_iter=0)                            # :440
+    with pytest.raises(AssertionError):
+        si.RTISI_LA(mag.to(torch.complex64))                # :297
+    with pytest.raises(AssertionError):
+        si.RTISI_LA(mag, max_iter=0)                        # :295
+    with pytest.raises(AssertionError):
+        si.phase_init(mag.to(torch.complex64))              # :586
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        require_gpu(torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        si.griffin_lim(torch.rand(2, 65, 8), max_iter=1, verbose=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        si.sc(torch.rand(4), torch.rand(4))
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    import re
+    root = os.path.dirname(os.path.abspath(si.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_metric_formulas():
+    rng = np.random.default_rng(0)
+    a, b = rng.random(1000), rng.random(1000)
+    s = [float(((a - b) ** 2).sum()), float((a ** 2).sum()), float((b ** 2).sum()), 1000.0]
+    assert math.isclose(_from_sums("SC", s), oracle.sc(a, b), rel_tol=1e-12)
+    assert math.isclose(_from_sums("SNR", s), oracle.snr(a, b), rel_tol=1e-12)
+    assert math.isclose(_from_sums("SER", s), oracle.ser(a, b), rel_tol=1e-12)
+
+
+class TorchVecOps:
+    """Vector backend used ONLY here, to exercise the optimiser's host control flow without a GPU."""
+
+    def dot(self, a, b):
+        return float(torch.dot(a.reshape(-1), b.reshape(-1)))
+
+    def axpy(self, alpha, x, y):
+        y.add_(x, alpha=alpha)
+
+    def scaled(self, alpha, x):
+        return x * alpha
+
+    def absmax_abssum(self, x):
+        return float(x.abs().max()), float(x.abs().sum())
+
+
+@pytest.mark.parametrize("tag,kw", [("wolfe", dict(max_iter=40, history_size=5, line_search_fn="strong_wolfe")),
+                                    ("wolfe_h100", dict(max_iter=25, line_search_fn="strong_wolfe")),
+                                    ("fixed", dict(max_iter=30, lr=1e-3, history_size=4))])
+def test_lbfgs_control_flow_retraces_torch(tag, kw):
+    g = load_golden("g9_lbfgs_rosen")
+    x = torch.from_numpy(g["x0"].copy())
+    losses = []
+
+    def fg(v):
+        a, b = v[1:] - v[:-1] ** 2, 1.0 - v[:-1]
+        f = float((100.0 * a * a + b * b).sum())
+        gr = torch.zeros_like(v)
+        gr[1:] += 200.0 * a
+        gr[:-1] += -400.0 * a * v[:-1] - 2.0 * b
+        losses.append(f)
+        return f, gr
+
+    opt = LBFGS(x, vec_ops=TorchVecOps(), **kw)
+    for _ in range(2):
+        opt.step(fg)
+    ref = g[f"losses_{tag}"]
+    assert len(losses) == len(ref)
+    np.testing.assert_allclose(losses, ref, rtol=5e-4, atol=1e-7)
+    np.testing.assert_allclose(x.numpy(), g[f"x_{tag}"], rtol=1e-4, atol=1e-6)
+
+
+def test_lbfgs_option_validation():
+    x = torch.zeros(3)
+    with pytest.raises(ValueError):
+        LBFGS(x, lr=-1.0, vec_ops=TorchVecOps())
+    with pytest.raises(RuntimeError):
+        LBFGS(x, line_search_fn="armijo", vec_ops=TorchVecOps())
+    assert LBFGS(x, max_iter=20, vec_ops=TorchVecOps()).max_eval == 25       # max_iter * 5 // 4
+
+
+def test_mel_filterbank():
+    fb = si.mel_filterbank(22050, 2048, 80)
+    assert fb.shape == (80, 1025) and fb.dtype == np.float32 and (fb >= 0).all()
+    assert 0.02 < (fb > 0).mean() < 0.03                     # ~2.4 % non-zeros
+    peaks = fb.argmax(1)
+    assert (np.diff(peaks) > 0).all()                        # centre frequencies increase
+    # Slaney area normalisation: every filter integrates to ~1 over frequency (bin width sr/n_fft)
+    area = fb.sum(1) * (22050 / 2048)
+    assert np.allclose(area[5:], 1.0, atol=0.08)
+    g = load_golden("g6_lbfgs")
+    np.testing.assert_array_equal(fb[:, ::64], g["mel_fb_check"])
