@@ -130,7 +130,7 @@ def main():
         done, _ = plan.run(iters, 10, 0.0, "sc")        # 100 iterations, evaluation every 10
         x = plan.wave()
         if world > 1:
-            x = gather_waveforms(x, dst=0)
+            x = gather_waveforms(x, dst=0, sizes=[batch] * world)      # weak scaling: equal shards
         return done, x
 
     def fence():

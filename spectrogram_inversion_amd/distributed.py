@@ -29,19 +29,26 @@ def shard_bounds(n_items: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None):
+def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None):
     """Gather (B_r, L) blocks of possibly different B_r to `dst`.  Returns the concatenated
-    (sum B_r, L) tensor on `dst`, None elsewhere."""
+    (sum B_r, L) tensor on `dst`, None elsewhere.  `sizes` (the per-rank batch sizes) may be
+    passed when known, e.g. equal shards, to skip the size exchange."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
         return x_local
-    sizes = [None] * world
-    dist.all_gather_object(sizes, int(x_local.shape[0]), group=group)
+    if sizes is None:
+        # batch sizes of all ranks: one small tensor all-gather on the data's own device / backend
+        mine = torch.tensor([x_local.shape[0]], dtype=torch.int64, device=x_local.device)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine, group=group)
+        sizes = [int(t.item()) for t in every]
     if len(set(sizes)) == 1:
-        out = [torch.empty_like(x_local) for _ in range(world)] if rank == dst else None
+        # receive straight into the slices of the final (world*B_r, L) tensor: no concatenation pass
+        big = x_local.new_empty((world * sizes[0],) + tuple(x_local.shape[1:])) if rank == dst else None
+        out = list(big.split(sizes[0], 0)) if rank == dst else None
         dist.gather(x_local.contiguous(), out, dst=dst, group=group)
-        return torch.cat(out, 0) if rank == dst else None
+        return big
     # ragged batch: point-to-point to the root
     if rank == dst:
         parts = []
