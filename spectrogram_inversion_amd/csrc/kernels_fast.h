@@ -304,6 +304,8 @@ __device__ __forceinline__ v2f w64(int j) {
 struct FastArgs {
   const float* x_in;
   float* x_out;
+  const float* xtail_in;   // [B][nchunks][3*HOP]: what chunk c's last three frames add to the first three
+  float* xtail_out;        //                       hop-blocks of chunk c+1 (already times 1/envelope)
   const v4f* P_in;     // GLA: pre_spec pairs ; ADMM: X pairs      [B*T][H][64] x (Re k, Im k, Re M-k, Im M-k)
   v4f* P_out;
   const v2f* Pmid_in;  // bin M/2                                   [B*T]
@@ -360,18 +362,35 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const 
   }
 }
 
+// Frames [chunk_begin(c), chunk_begin(c+1)) belong to wave-chunk c; sizes differ by at most one frame.
+__device__ __forceinline__ int chunk_begin(int c, int T, int nchunks) { return (int)(((long long)c * T) / nchunks); }
+
 // One hop-block (N/4 samples, padded-signal block index j) of row `xrow` in the register layout
 // (lane l, register i <-> samples 128 i + 2 l, +1).  Blocks 2..T lie inside the signal; the two
-// blocks on either side are torch.stft's reflect padding.
+// blocks on either side are torch.stft's reflect padding.  The first three hop-blocks of every chunk but
+// the first were stored as two partial sums (the chunk's own frames in x, the previous chunk's last three
+// frames in `xtail`); they are added here.  Edge (reflected) blocks never touch such blocks because the
+// first and the last chunk are at least 6 frames long.
 template <int R>
-__device__ __forceinline__ void load_block(const float* __restrict__ xrow, long long L, int T, int j, int lane,
-                                           v2f (&q)[R / 4]) {
+__device__ __forceinline__ void load_block(const float* __restrict__ xrow, const float* __restrict__ tailrow,
+                                           long long L, int T, int nchunks, int j, int lane, v2f (&q)[R / 4]) {
   constexpr int HOP = Geo<R>::HOP;
   const long long s0 = (long long)(j - 2) * HOP;
   if (j >= 2 && j <= T) {
     const v2f* src = reinterpret_cast<const v2f*>(xrow + s0);   // uniform
 #pragma unroll
     for (int i = 0; i < R / 4; ++i) q[i] = src[64u * i + (unsigned)lane];
+    if (j < T) {
+      int c = (int)(((long long)j * nchunks) / T);
+      if (chunk_begin(c + 1, T, nchunks) <= j) ++c;
+      if (chunk_begin(c, T, nchunks) > j) --c;
+      const int off = j - chunk_begin(c, T, nchunks);
+      if (c >= 1 && off < 3) {
+        const v2f* tl = reinterpret_cast<const v2f*>(tailrow + ((long long)(c - 1) * 3 + off) * HOP);
+#pragma unroll
+        for (int i = 0; i < R / 4; ++i) q[i] = q[i] + tl[64u * i + (unsigned)lane];
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < R / 4; ++i) {
@@ -411,10 +430,11 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
   const int b = w / a.nchunks, c = w - b * a.nchunks;
-  const int t_begin = c * a.chunk;
-  const int t_end = min(a.T, t_begin + a.chunk);
-  const int t_start = max(0, t_begin - 3);
+  const int t_begin = chunk_begin(c, a.T, a.nchunks);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  const int t_start = t_begin;   // no halo: the previous chunk's share of the first three hop-blocks comes via xtail
   const float* xrow = a.x_in + (long long)b * a.L;
+  const float* tailrow = a.xtail_in + (long long)b * a.nchunks * 3 * HOP;
   float* orow = a.x_out + (long long)b * a.L;
   const float half_scale = 0.5f * a.fwd_scale;
 
@@ -430,16 +450,16 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     v2f q[QU];
-    load_block<R>(xrow, a.L, a.T, t_start + qq, lane, q);
+    load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start + qq, lane, q);
 #pragma unroll
     for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
   }
 #elif SPECINV_XPREF == 1
   v2f xq[3][QU], xn[QU];
-  load_block<R>(xrow, a.L, a.T, t_start, lane, xq[0]);
-  load_block<R>(xrow, a.L, a.T, t_start + 1, lane, xq[1]);
-  load_block<R>(xrow, a.L, a.T, t_start + 2, lane, xq[2]);
-  load_block<R>(xrow, a.L, a.T, t_start + 3, lane, xn);
+  load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start, lane, xq[0]);
+  load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start + 1, lane, xq[1]);
+  load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start + 2, lane, xq[2]);
+  load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start + 3, lane, xn);
 #endif
 
   for (int t = t_start; t < t_end; ++t) {
@@ -448,7 +468,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
     asm volatile("" ::: "memory");
     v2f wn = k.wn;
     asm volatile("" : "+v"(wn));
-    const bool live = t >= t_begin;
+    constexpr bool live = true;
     const long long fi = (long long)b * a.T + t;
 
     v4f pp[H], uu[H], mm[H / 2];
@@ -494,13 +514,13 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
       xq[1][i] = xq[2][i];
       xq[2][i] = xn[i];
     }
-    if (t + 1 < t_end) load_block<R>(xrow, a.L, a.T, t + 4, lane, xn);
+    if (t + 1 < t_end) load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t + 4, lane, xn);
 #else
     {
       v2f q[QU];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        load_block<R>(xrow, a.L, a.T, t + qq, lane, q);
+        load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t + qq, lane, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) z[qq * QU + i] = q[i];
       }
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         v2f q[QU];
-        load_block<R>(xrow, a.L, a.T, t + 1 + qq, lane, q);
+        load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t + 1 + qq, lane, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
       }
@@ -612,13 +632,22 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
       acc[2 * QU + i] = z[3 * QU + i];
     }
   }
-  // the chunk that holds the last frame also finishes hop-block T (frames T-3 .. T-1)
   if (t_end == a.T) {
+    // the chunk that holds the last frame also finishes hop-block T (frames T-3 .. T-1)
     const long long o0 = (long long)(a.T - 2) * HOP;
     const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
     v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
     for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[i] * envp[64u * i + ulane];
+  } else {
+    // what this chunk's last three frames contribute to the next chunk's first three hop-blocks
+    v2f* tl = reinterpret_cast<v2f*>(a.xtail_out + ((long long)b * a.nchunks + c) * 3 * HOP);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + (long long)(t_end + q - 2) * HOP);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = acc[q * QU + i] * envp[64u * i + ulane];
+    }
   }
   if (EVAL) {
     const double d = wave_sum(sd), o = wave_sum(so);
@@ -627,6 +656,113 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
       a.partials[2 * (long long)w + 1] = o;
     }
   }
+}
+
+// ISTFT of a spectrum held in pair layout: x = overlap-add(w * irfft(S)) / envelope  (methods.py:233: the
+// initial signal of griffin_lim / ADMM).  Same wave-per-chunk walk as k_fused, without the analysis half.
+template <int R>
+__global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused_istft(FastArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
+  }
+  __syncthreads();
+  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  if (w >= a.n_waves) return;
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  const int t_begin = chunk_begin(c, a.T, a.nchunks);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  const int t_start = max(0, t_begin - 3);       // one-off kernel: recompute the 3-frame halo, write whole blocks
+  float* orow = a.x_out + (long long)b * a.L;
+  v2f acc[3 * QU];
+#pragma unroll
+  for (int i = 0; i < 3 * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
+  for (int t = t_start; t < t_end; ++t) {
+    asm volatile("" ::: "memory");
+    v2f wn = k.wn;
+    asm volatile("" : "+v"(wn));
+    const bool live = t >= t_begin;
+    const long long fi = (long long)b * a.T + t;
+    const v4f* pin = a.P_in + fi * (H * 64);
+    v4f pp[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) pp[j] = pin[j * 64u + ulane];
+    v2f pmid = v2f{0.0f, 0.0f};
+    if (lane == 0) pmid = a.Pmid_in[fi];
+    v2f z[R], back[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+      v2f ak = v2f{pp[j].x, pp[j].y} * a.inv_scale, am = v2f{pp[j].z, pp[j].w} * a.inv_scale;
+      if (j == 0 && lane == 0) {
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = ak + cconj(am);
+      const v2f o2i = cmulc(ak - cconj(am), wk);
+      z[j] = e2i + mul_i(o2i);
+      back[j] = cconj(e2i - mul_i(o2i));
+    }
+    const v2f zmid = cconj(pmid * a.inv_scale) * 2.0f;
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+    fft_inverse<R>(z, k, lds_tw1, tr);
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    if (live && t >= 2) {
+      const long long o0 = (long long)(t - 2) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
+      v2f* outp = reinterpret_cast<v2f*>(orow + o0);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = (acc[i] + z[i]) * envp[64u * i + ulane];
+    }
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+      acc[i] = acc[QU + i] + z[QU + i];
+      acc[QU + i] = acc[2 * QU + i] + z[2 * QU + i];
+      acc[2 * QU + i] = z[3 * QU + i];
+    }
+  }
+  if (t_end == a.T) {
+    const long long o0 = (long long)(a.T - 2) * HOP;
+    const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
+    v2f* outp = reinterpret_cast<v2f*>(orow + o0);
+#pragma unroll
+    for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[i] * envp[64u * i + ulane];
+  }
+}
+
+// x += the tail partial sums (final waveform for get_wave)
+template <int R>
+__global__ void k_add_tails(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, long long L,
+                            long long total) {
+  constexpr int HOP = Geo<R>::HOP;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c, q, sample) over tails
+  if (i >= total) return;
+  const int smp = i % HOP;
+  const int q = (i / HOP) % 3;
+  const int c = (i / (3 * HOP)) % nchunks;
+  const long long b = i / ((long long)3 * HOP * nchunks);
+  if (c >= nchunks - 1) return;                       // the last chunk has no successor
+  const int blk = chunk_begin(c + 1, T, nchunks) + q; // padded-signal hop-block
+  // register layout of a block: element (reg i2, lane l, comp e) <-> sample 128*i2 + 2*l + e
+  const int i2 = smp / 128, rem = smp % 128;
+  x[b * L + (long long)(blk - 2) * HOP + smp] += xtail[((b * nchunks + c) * 3 + q) * HOP + (i2 * 64 + rem / 2) * 2 + (rem & 1)];
 }
 
 // ---- layout conversion between the frame-major (B*T, F) spectra and the pair layout ---------------
@@ -735,7 +871,7 @@ struct FastState<float> {
   int chunk = 32, nchunks = 0, n_waves = 0, n_partials = 0;
   int cur = 0;   // index of the buffers holding the current state
   int mode = fast::MODE_GLA;
-  FastBuf xb[2], Pb[2], Pmid[2], Ub[2], Umid[2], mpairs, mmid, inv_env, scratch;
+  FastBuf xb[2], xtail[2], Pb[2], Pmid[2], Ub[2], Umid[2], mpairs, mmid, inv_env, scratch;
 
   int setup(const specinv_stft_cfg& cfg, const std::vector<float>&, int64_t length, int pad) {
     supported = false;
@@ -757,7 +893,7 @@ struct FastState<float> {
       if (v >= 4) ch = v;
     }
     chunk = std::min(ch, cfg.n_frames);
-    nchunks = (cfg.n_frames + chunk - 1) / chunk;
+    nchunks = std::max(1, cfg.n_frames / chunk);   // frames split as evenly as possible, every chunk >= 8 (or all) frames
     n_waves = cfg.batch * nchunks;
     supported = true;
     return SPECINV_OK;
@@ -769,7 +905,9 @@ struct FastState<float> {
     mode = md;
     const long long nf = (long long)pl.B() * pl.Tn();
     const size_t pbytes = (size_t)nf * G::H * 64 * sizeof(v4f);
+    const size_t tail_bytes = (size_t)pl.B() * nchunks * 3 * G::HOP * sizeof(float);
     for (int i = 0; i < 2; ++i) {
+      SI_TRY(xtail[i].reserve(tail_bytes));
       SI_TRY(xb[i].reserve((size_t)pl.B() * pl.length * sizeof(float)));
       SI_TRY(Pb[i].reserve(pbytes));
       SI_TRY(Pmid[i].reserve(nf * sizeof(v2f)));
@@ -797,8 +935,25 @@ struct FastState<float> {
     hipLaunchKernelGGL(fast::k_reciprocal, dim3((unsigned)ceil_div(pl.length, 256)), dim3(256), 0, pl.stream,
                        pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length);
     SI_HIP(hipGetLastError());
-    SI_HIP(hipMemcpyAsync(xb[0].p, pl.x.p, (size_t)pl.B() * pl.length * sizeof(float), hipMemcpyDeviceToDevice,
-                          pl.stream));
+    SI_HIP(hipMemsetAsync(xtail[0].p, 0, tail_bytes, pl.stream));   // x0 below is written whole
+    // x0 = ISTFT(start spectrum) (methods.py:233 / :453) straight from the pair layout
+    fast::FastArgs a{};
+    a.x_out = xb[0].template as<float>();
+    a.P_in = Pb[0].template as<v4f>();
+    a.Pmid_in = Pmid[0].template as<v2f>();
+    a.window = pl.window.template as<float>();
+    a.inv_env = inv_env.template as<float>();
+    a.T = pl.Tn();
+    a.chunk = chunk;
+    a.nchunks = nchunks;
+    a.n_waves = n_waves;
+    a.L = pl.length;
+    a.fwd_scale = pl.fc.fwd_scale;
+    a.inv_scale = pl.fc.inv_scale;
+    const size_t lds = G::lds_bytes(4);
+    SI_HIP(hipFuncSetAttribute((const void*)fast::k_fused_istft<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((fast::k_fused_istft<RR>), dim3((n_waves + 3) / 4), dim3(256), lds, pl.stream, a);
+    SI_HIP(hipGetLastError());
     return SPECINV_OK;
   }
 
@@ -831,6 +986,8 @@ struct FastState<float> {
       fast::FastArgs a{};
       a.x_in = xb[cur].template as<float>();
       a.x_out = xb[nx].template as<float>();
+      a.xtail_in = xtail[cur].template as<float>();
+      a.xtail_out = xtail[nx].template as<float>();
       a.P_in = Pb[cur].template as<v4f>();
       a.P_out = Pb[nx].template as<v4f>();
       a.Pmid_in = Pmid[cur].template as<v2f>();
@@ -871,6 +1028,17 @@ struct FastState<float> {
   template <typename P>
   int get_wave(P& pl, float* out) {
     SI_HIP(hipMemcpyAsync(out, xb[cur].p, (size_t)pl.B() * pl.length * sizeof(float), hipMemcpyDeviceToDevice, pl.stream));
+    if (nchunks > 1) {
+      const int hop = pl.cfg.hop_length;
+      const long long total = (long long)pl.B() * nchunks * 3 * hop;
+      if (R == 16)
+        hipLaunchKernelGGL((fast::k_add_tails<16>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, out,
+                           xtail[cur].template as<float>(), pl.Tn(), nchunks, (long long)pl.length, total);
+      else
+        hipLaunchKernelGGL((fast::k_add_tails<8>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, out,
+                           xtail[cur].template as<float>(), pl.Tn(), nchunks, (long long)pl.length, total);
+      SI_HIP(hipGetLastError());
+    }
     return SPECINV_OK;
   }
 

@@ -283,6 +283,7 @@ struct PlanT final : PlanBase {
     SI_TRY(reduce3(mag.as<T>(), nullptr, ns, r));
     sum_m2 = r[1];
     count = (double)ns;
+    if (fast_path()) return SPECINV_OK;          // the fused path computes x0 itself from its own layout
     return istft_internal(specA.as<C>(), x.as<T>());
   }
 
