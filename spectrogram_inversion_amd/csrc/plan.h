@@ -32,6 +32,11 @@ struct PlanBase {
   virtual int gla_init(const void* init_spec, const void* mag, double alpha) = 0;
   virtual int admm_init(const void* init_spec, const void* mag, double rho) = 0;
   virtual int iterate(int n_iter, bool eval_last, double sums[4]) = 0;
+  // evaluations whose result cannot influence the run (tol == 0, no callback) stay on the device and are
+  // read back once at the end: deferred_slot >= 0 makes iterate() park its sums in that slot
+  int deferred_slot = -1;
+  virtual int begin_deferred(int n_slots) = 0;
+  virtual int read_deferred(int n_slots, double* out) = 0;
   virtual int get_wave(void* x_out) = 0;
   virtual int get_state_spec(int which, void* spec_out) = 0;
 

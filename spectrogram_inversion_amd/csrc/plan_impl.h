@@ -64,6 +64,7 @@ struct PlanT final : PlanBase {
   DevBuf window, tw, env;
   DevBuf x, frames, specA, specB, mag, partials, sums, tmp_spec, tmp_real;
   DevBuf rt_state;                      // RTISI per-item state
+  DevBuf eval_log;                      // per-evaluation sums of a run with deferred read-back
   DevBuf tf_mel, tf_spec, tf_v, tf_dv;  // transform (L_BFGS) scratch
   std::vector<T> h_window;
   FrameCfg<T> fc{};
@@ -340,8 +341,16 @@ struct PlanT final : PlanBase {
       }
     }
     if (eval_last) {
-      SI_CHECK(s != nullptr, SPECINV_EINVAL, "sums_host is NULL");
       const int64_t n_part = fast_path() ? (int64_t)fast.n_partials : (int64_t)B() * Tn();
+      if (deferred_slot >= 0) {
+        // deferred evaluation (run_loop with tol == 0 and no callback): keep the sums on the device
+        SI_TRY(eval_log.reserve((size_t)(deferred_slot + 1) * 2 * sizeof(double)));
+        hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, stream, partials.as<double>(), n_part, 2,
+                           eval_log.as<double>() + 2 * deferred_slot);
+        SI_HIP(hipGetLastError());
+        return SPECINV_OK;
+      }
+      SI_CHECK(s != nullptr, SPECINV_EINVAL, "sums_host is NULL");
       hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, stream, partials.as<double>(), n_part, 2,
                          sums.as<double>());
       SI_HIP(hipGetLastError());
@@ -352,6 +361,26 @@ struct PlanT final : PlanBase {
       s[1] = r[1];
       s[2] = sum_m2;
       s[3] = count;
+    }
+    return SPECINV_OK;
+  }
+
+  int begin_deferred(int n_slots) override {
+    SI_TRY(eval_log.reserve((size_t)std::max(1, n_slots) * 2 * sizeof(double)));
+    return SPECINV_OK;
+  }
+
+  int read_deferred(int n_slots, double* out /* n_slots x 4 */) override {
+    std::vector<double> h((size_t)n_slots * 2);
+    if (n_slots > 0) {
+      SI_HIP(hipMemcpyAsync(h.data(), eval_log.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    }
+    SI_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < n_slots; ++i) {
+      out[4 * i] = h[2 * i];
+      out[4 * i + 1] = h[2 * i + 1];
+      out[4 * i + 2] = sum_m2;
+      out[4 * i + 3] = count;
     }
     return SPECINV_OK;
   }

@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <new>
+#include <vector>
 
 #include "plan_impl.h"
 
@@ -49,6 +50,38 @@ int PlanBase::run_loop(int max_iter, int eva_iter, double tol, int metric, speci
   double init_loss = 0, prev = 0;
   bool have_init = false;
   int done = 0, ne = 0;
+  if (tol == 0.0 && cb == nullptr) {
+    // The stop rule `(prev - loss)/init < 0 and prev > loss` (:188) can never fire with tol == 0, and
+    // nobody watches the evaluations: enqueue everything, read all sums back once.
+    const int n_slots = max_iter / eva_iter;
+    SI_TRY(begin_deferred(n_slots));
+    int rc = SPECINV_OK;
+    while (done < max_iter && rc == SPECINV_OK) {
+      const int until_eval = eva_iter - (done % eva_iter);
+      if (done + until_eval > max_iter) {
+        rc = iterate(max_iter - done, false, nullptr);
+        done = max_iter;
+        break;
+      }
+      deferred_slot = ne;
+      rc = iterate(until_eval, true, nullptr);
+      deferred_slot = -1;
+      done += until_eval;
+      ++ne;
+    }
+    deferred_slot = -1;
+    SI_TRY(rc);
+    std::vector<double> all((size_t)std::max(1, ne) * 4);
+    SI_TRY(read_deferred(ne, all.data()));
+    for (int i = 0; i < ne && evals; ++i) {
+      evals[i].iteration = (i + 1) * eva_iter - 1;
+      evals[i].metric = metric_from_sums(metric, &all[4 * i]);
+      evals[i].loss = all[4 * i] / all[4 * i + 3];
+    }
+    if (n_evals) *n_evals = ne;
+    if (iters_done) *iters_done = done;
+    return SPECINV_OK;
+  }
   while (done < max_iter) {
     const int until_eval = eva_iter - (done % eva_iter);             // next i with i % eva == eva-1
     if (done + until_eval > max_iter) {
