@@ -363,7 +363,9 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const 
 }
 
 // Frames [chunk_begin(c), chunk_begin(c+1)) belong to wave-chunk c; sizes differ by at most one frame.
-__device__ __forceinline__ int chunk_begin(int c, int T, int nchunks) { return (int)(((long long)c * T) / nchunks); }
+__device__ __host__ __forceinline__ int chunk_begin(int c, int T, int nchunks) {
+  return (int)(((unsigned)c * (unsigned)T) / (unsigned)nchunks);   // c * T < 2^32 for any plan that fits in memory
+}
 
 // One hop-block (N/4 samples, padded-signal block index j) of row `xrow` in the register layout
 // (lane l, register i <-> samples 128 i + 2 l, +1).  Blocks 2..T lie inside the signal; the two
@@ -373,23 +375,28 @@ __device__ __forceinline__ int chunk_begin(int c, int T, int nchunks) { return (
 // first and the last chunk are at least 6 frames long.
 template <int R>
 __device__ __forceinline__ void load_block(const float* __restrict__ xrow, const float* __restrict__ tailrow,
-                                           long long L, int T, int nchunks, int j, int lane, v2f (&q)[R / 4]) {
+                                           long long L, int T, int c, int t_begin, int t_end, int j, int lane,
+                                           v2f (&q)[R / 4]) {
   constexpr int HOP = Geo<R>::HOP;
   const long long s0 = (long long)(j - 2) * HOP;
   if (j >= 2 && j <= T) {
     const v2f* src = reinterpret_cast<const v2f*>(xrow + s0);   // uniform
 #pragma unroll
     for (int i = 0; i < R / 4; ++i) q[i] = src[64u * i + (unsigned)lane];
-    if (j < T) {
-      int c = (int)(((long long)j * nchunks) / T);
-      if (chunk_begin(c + 1, T, nchunks) <= j) ++c;
-      if (chunk_begin(c, T, nchunks) > j) --c;
-      const int off = j - chunk_begin(c, T, nchunks);
-      if (c >= 1 && off < 3) {
-        const v2f* tl = reinterpret_cast<const v2f*>(tailrow + ((long long)(c - 1) * 3 + off) * HOP);
+    // a wave only ever reads blocks t_begin .. t_end + 2 of its own chunk c: split blocks are the chunk's
+    // own first three (other half from chunk c-1) and the next chunk's first three (other half: this chunk's)
+    int tc = -1, off = 0;
+    if (c >= 1 && j - t_begin < 3) {
+      tc = c - 1;
+      off = j - t_begin;
+    } else if (j >= t_end && j < T) {
+      tc = c;
+      off = j - t_end;
+    }
+    if (tc >= 0) {
+      const v2f* tl = reinterpret_cast<const v2f*>(tailrow + ((long long)tc * 3 + off) * HOP);
 #pragma unroll
-        for (int i = 0; i < R / 4; ++i) q[i] = q[i] + tl[64u * i + (unsigned)lane];
-      }
+      for (int i = 0; i < R / 4; ++i) q[i] = q[i] + tl[64u * i + (unsigned)lane];
     }
   } else {
 #pragma unroll
@@ -450,16 +457,16 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     v2f q[QU];
-    load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start + qq, lane, q);
+    load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + qq, lane, q);
 #pragma unroll
     for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
   }
 #elif SPECINV_XPREF == 1
   v2f xq[3][QU], xn[QU];
-  load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start, lane, xq[0]);
-  load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start + 1, lane, xq[1]);
-  load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start + 2, lane, xq[2]);
-  load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t_start + 3, lane, xn);
+  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start, lane, xq[0]);
+  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 1, lane, xq[1]);
+  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 2, lane, xq[2]);
+  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 3, lane, xn);
 #endif
 
   for (int t = t_start; t < t_end; ++t) {
@@ -514,13 +521,13 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
       xq[1][i] = xq[2][i];
       xq[2][i] = xn[i];
     }
-    if (t + 1 < t_end) load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t + 4, lane, xn);
+    if (t + 1 < t_end) load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 4, lane, xn);
 #else
     {
       v2f q[QU];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t + qq, lane, q);
+        load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) z[qq * QU + i] = q[i];
       }
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         v2f q[QU];
-        load_block<R>(xrow, tailrow, a.L, a.T, a.nchunks, t + 1 + qq, lane, q);
+        load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 1 + qq, lane, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
       }
