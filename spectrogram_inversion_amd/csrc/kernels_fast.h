@@ -67,14 +67,67 @@ __device__ __forceinline__ v2f shfl_xor2(v2f a, int mask) {
 }
 __device__ __forceinline__ v2f shfl2(v2f a, int src) { return v2f{__shfl(a.x, src, 64), __shfl(a.y, src, 64)}; }
 
+// a + i*b and a - i*b as ONE packed add: VOP3P source modifiers pick b's halves crosswise (op_sel) and negate
+// one of them, so the multiplication by +-i costs nothing (the compiler otherwise emits v_xor + v_mov for it).
+#ifndef SPECINV_ASM_ROT
+#define SPECINV_ASM_ROT 1
+#endif
+__device__ __forceinline__ v2f add_i(v2f a, v2f b) {   // (a.x - b.y, a.y + b.x)
+#if SPECINV_ASM_ROT
+  v2f d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#else
+  return v2f{a.x - b.y, a.y + b.x};
+#endif
+}
+__device__ __forceinline__ v2f sub_i(v2f a, v2f b) {   // (a.x + b.y, a.y - b.x)
+#if SPECINV_ASM_ROT
+  v2f d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#else
+  return v2f{a.x + b.y, a.y - b.x};
+#endif
+}
+
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {   // a + conj(b)
+#if SPECINV_ASM_ROT
+  v2f d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#else
+  return v2f{a.x + b.x, a.y - b.y};
+#endif
+}
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) {   // a - conj(b)
+#if SPECINV_ASM_ROT
+  v2f d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#else
+  return v2f{a.x - b.x, a.y + b.y};
+#endif
+}
+__device__ __forceinline__ v2f conj_sub_i(v2f a, v2f b) {   // conj(a - i*b) = (a.x + b.y, -a.y + b.x)
+#if SPECINV_ASM_ROT
+  v2f d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#else
+  return v2f{a.x + b.y, b.x - a.y};
+#endif
+}
+
 // ---- small in-register DFTs (natural order in, natural order out) ------------------------------
 template <bool INV>
 __device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
-  const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<INV>(a1 - a3);
+  const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
   a0 = t0 + t2;
   a2 = t0 - t2;
-  a1 = t1 + t3;
-  a3 = t1 - t3;
+  // forward: X1 = t1 - i d, X3 = t1 + i d ; inverse: signs swapped
+  a1 = INV ? add_i(t1, d) : sub_i(t1, d);
+  a3 = INV ? sub_i(t1, d) : add_i(t1, d);
 }
 
 template <int R, bool INV>
@@ -559,11 +612,11 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
       // W_N^(lane + 64 j) = W_N^lane * W_{2R}^j
       const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
-      const v2f e2 = zk + cconj(zm);
-      const v2f o2 = mul_mi(zk - cconj(zm));
-      const v2f tw = cmul(wk, o2);
+      const v2f e2 = add_conj(zk, zm);
+      const v2f dd = sub_conj(zk, zm);
+      const v2f tw = cmul(mul_mi(wk), dd);                 // W * (-i (Zk - conj Zm))
       v2f xk = (e2 + tw) * half_scale;
-      v2f xm = cconj(e2 - tw) * half_scale;
+      v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};   // conj(...)
       v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
       v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
       if (MODE == MODE_ADMM) {
@@ -582,22 +635,22 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
         ak.y = 0.0f;
         am.y = 0.0f;
       }
-      const v2f e2i = ak + cconj(am);
-      const v2f o2i = cmulc(ak - cconj(am), wk);
-      z[j] = e2i + mul_i(o2i);
-      back[j] = cconj(e2i - mul_i(o2i));
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
     }
     // ---- bin M/2 (lane 0): X = conj(Z), Z'' = 2 conj(X')
     v2f zmid;
     {
-      v2f xmid = cconj(z[H]) * a.fwd_scale;
+      v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
       const bool live0 = live && lane == 0;
       const v2f am = update_bin<MODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
       if (live0) {
         a.Pmid_out[fi] = pmid;
         if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
       }
-      zmid = cconj(am) * 2.0f;
+      zmid = am * v2f{2.0f, -2.0f};
     }
     // ---- return the mirrored halves
 #pragma unroll
@@ -716,12 +769,12 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused_istft(FastArgs 
         ak.y = 0.0f;
         am.y = 0.0f;
       }
-      const v2f e2i = ak + cconj(am);
-      const v2f o2i = cmulc(ak - cconj(am), wk);
-      z[j] = e2i + mul_i(o2i);
-      back[j] = cconj(e2i - mul_i(o2i));
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
     }
-    const v2f zmid = cconj(pmid * a.inv_scale) * 2.0f;
+    const v2f zmid = pmid * v2f{2.0f * a.inv_scale, -2.0f * a.inv_scale};
 #pragma unroll
     for (int m = H; m < R; ++m) {
       const v2f got = shfl2(back[R - 1 - m], k.partner);

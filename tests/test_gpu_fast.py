@@ -63,7 +63,7 @@ def test_fast_path_selected_and_matches_oracle(n_fft, hop, frames, batch, chunk)
     got = sc_linear(np.array([m for _, m, _ in evals]))
     want = sc_linear(np.array([m for _, m, _ in trace]))
     assert np.abs(got - want).max() < 1e-5
-    assert rel_l2(N(plan.state_spec(0)), st["pre_spec"]) < 1e-4
+    assert rel_l2(N(plan.state_spec(0)), st["pre_spec"]) < 3e-4
 
 
 @pytest.mark.parametrize("n_fft,hop,frames,batch", SHAPES[:2])
