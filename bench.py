@@ -125,9 +125,15 @@ def main():
     if args.generic:
         plan.force_generic(True)
 
+    run_events = []
+
     def step():
         plan.gla_init(None, mag, alpha)                 # phase_init + initial ISTFT
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                                     # HIP events on the stream the kernels are launched on
         done, _ = plan.run(iters, 10, 0.0, "sc")        # 100 iterations, evaluation every 10
+        e1.record()
+        run_events.append((e0, e1))
         x = plan.wave()
         if world > 1:
             x = gather_waveforms(x, dst=0, sizes=[batch] * world)      # weak scaling: equal shards
@@ -141,6 +147,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    run_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         done, x = step()
@@ -154,17 +161,9 @@ def main():
     if rank == 0:
         assert x.shape == (batch * world, plan.length) and bool(torch.isfinite(x).all())
 
-    # dominant kernel: the per-iteration launch, timed with HIP events on the launch stream
-    n_launch = 50
-    plan.gla_init(None, mag, alpha)
-    plan.iterate(5)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    plan.iterate(n_launch)
-    e1.record()
-    torch.cuda.synchronize()
-    launch_ms = e0.elapsed_time(e1) / n_launch
+    # dominant kernel: the per-iteration launch.  Average duration over the timed region = HIP-event time of
+    # each step's 100-iteration run / 100 (90 plain + 10 evaluating launches, back to back on one stream).
+    launch_ms = sum(a.elapsed_time(b) for a, b in run_events) / (len(run_events) * iters)
     unit_bytes = algorithmic_bytes_per_unit(hop, n_freq, alpha)
     launch_bytes = unit_bytes * batch * frames
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
@@ -195,7 +194,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic(args.workload if fused else args.workload + "_generic"),
-                         "kernel": "k_gla_fused" if fused else "k_gla_frame+k_ola",
+                         "kernel": "specinv::fast::k_fused<16,GLA>" if fused else "k_gla_frame+k_ola",
                          "launch_ms": launch_ms, "algorithmic_bytes_per_launch": launch_bytes,
                          "bytes_per_unit": unit_bytes},
         }
