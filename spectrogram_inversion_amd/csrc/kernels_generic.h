@@ -46,8 +46,15 @@ __device__ inline T load_padded(const T* __restrict__ x, int64_t L, int64_t n, i
 // ---- Stockham FFT of n_fft complex points held in LDS ------------------------------------
 // On entry `a` holds the input (all threads synchronised); on exit `a` points at the result
 // (natural order, unscaled) and all threads are synchronised.
+// `tid` / `nthr`: the calling thread's rank inside, and the size of, the thread group that owns the
+// transform (default: the whole workgroup).  Every thread of the WORKGROUP must still reach the barriers.
 template <typename T>
-__device__ inline void lds_fft(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, bool inverse) {
+__device__ inline void lds_fft(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, bool inverse, int tid = -1,
+                               int nthr = 0) {
+  if (tid < 0) {
+    tid = threadIdx.x;
+    nthr = blockDim.x;
+  }
   const int N = c.n_fft;
   int ns = 1;
   for (int s = 0; s < c.n_stages; ++s) {
@@ -55,7 +62,7 @@ __device__ inline void lds_fft(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, b
     const int m = ns * R;
     const int stride = N / R;
     const int twstep = N / m;
-    for (int o = threadIdx.x; o < N; o += blockDim.x) {
+    for (int o = tid; o < N; o += nthr) {
       const int block = o / m;
       const int within = o - block * m;
       const int r = within / ns;
