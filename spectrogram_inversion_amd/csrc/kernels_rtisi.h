@@ -10,8 +10,11 @@
 #pragma once
 #include <vector>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels_generic.h"
+#include "kernels_rtisi_fast.h"
 
 namespace specinv {
 
@@ -204,6 +207,12 @@ int rtisi_launch(P& pl, const T* mag_user, int look_ahead, int asym, int max_ite
   SI_HIP(hipMemcpyAsync(d_a1, a1.data(), N * sizeof(T), hipMemcpyHostToDevice, pl.stream));
   SI_HIP(hipMemcpyAsync(d_a2, a2.data(), N * sizeof(T), hipMemcpyHostToDevice, pl.stream));
   SI_HIP(hipStreamSynchronize(pl.stream));    // the host vectors go out of scope
+
+  if constexpr (std::is_same<T, float>::value) {
+    bool used = false;
+    SI_TRY(rtisi_fast_launch(pl, mag_user, la, asym, max_iter, alpha, x_out, d_wsyn, d_a1, d_a2, &used));
+    if (used) return SPECINV_OK;
+  }
 
   SI_TRY(pl.mag.reserve(pl.nspec() * sizeof(T)));
   SI_TRY((pl.template transpose<T>(mag_user, pl.mag.template as<T>(), F, Tn)));

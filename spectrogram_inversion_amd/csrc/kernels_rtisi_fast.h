@@ -1,0 +1,332 @@
+// RTISI-LA on the wave-level FFT of kernels_fast.h (float32, onesided, hop = n_fft/4, n_fft in {1024, 2048}).
+//
+// The recursion (reference: torch_specinv/methods.py:363-404) is serial per batch item, so what matters is
+// the latency of ONE inner step.  One workgroup owns one item; wave q owns look-ahead frame q for the whole
+// run.  Everything an inner step touches stays on the CU:
+//   * the frame ring (K kept + LA+1 look-ahead frames) lives in LDS;
+//   * each wave keeps its frame's previous spectrum (pre_spec, conjugate-pair order), its target magnitudes,
+//     its analysis window and the synthesis window in REGISTERS (one wave per SIMD: 512 VGPRs available);
+//   * per step a wave overlap-adds the <= 4 ring frames that cover its frame straight into registers, runs the
+//     packed real FFT (in-register radix-R, lane-swap radix-4, one LDS transpose), applies momentum and the
+//     magnitude projection to the pairs, transforms back and writes the frame to the ring: 2 workgroup
+//     barriers per step, no global memory traffic except the once-per-frame target load and commit.
+// Step latency drops from ~115 us (generic k_rtisi) to a few us.
+#pragma once
+#include "kernels_fast.h"
+
+namespace specinv {
+namespace fast {
+
+struct RtisiFastArgs {
+  const v4f* m_pairs;   // [B*T][H/2][64] target magnitude, pair order
+  const float* m_mid;   // [B*T]
+  float* frames_out;    // (B, T, N) committed frames times the synthesis window
+  const float* window;  // N   analysis/synthesis window w
+  const float* wsyn;    // N   w * hop / (w.w)
+  const float* asym1;   // N
+  const float* asym2;   // N
+  int T, la, max_iter, asym;
+  float lr, fwd_scale, inv_scale;
+};
+
+template <int R>
+struct RtisiGeo {
+  using G = Geo<R>;
+  static constexpr int K = 3;   // kept frames: (n_fft - 1) / hop with hop = n_fft / 4
+  // LDS (v2f units): ring | tw1 | per-wave transpose scratch | per-wave pre_spec exchange (pairs as 2 x v2f + mid)
+  static constexpr size_t lds_bytes(int la) {
+    const size_t waves = la + 1, nslots = K + la + 1;
+    return sizeof(v2f) * (nslots * G::M + (R - 1) * 64 + waves * G::TR + waves * (G::H * 2 * 64 + 64));
+  }
+};
+
+// MAXT: 256 (look_ahead <= 3: one wave per SIMD, the full 512-register file per lane) or 512
+template <int R, int MAXT>
+__global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, QU = G::QU, M = G::M, K = RtisiGeo<R>::K;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int la = a.la, nslots = K + la + 1, nw = la + 1;
+  v2f* ring = reinterpret_cast<v2f*>(smem);                 // [nslots][M]
+  v2f* lds_tw1 = ring + (size_t)nslots * M;                 // [(R-1)*64]
+  const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's look-ahead slot
+  v2f* tr = lds_tw1 + (R - 1) * 64 + q * G::TR;
+  v2f* xch = lds_tw1 + (R - 1) * 64 + nw * G::TR;           // [nw][H*2*64 + 64] pre_spec exchange
+  const int bi = blockIdx.x;
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
+  }
+  for (int i = threadIdx.x; i < (nslots - 1) * M; i += blockDim.x) ring[i] = v2f{0.0f, 0.0f};
+
+  // per-wave register tables (sample 128u + 2 lane, +1  <->  register u)
+  v2f wsyn[R], win0[R], win1[R], wout[QU];
+  {
+    const v2f* ws = reinterpret_cast<const v2f*>(a.wsyn);
+    const v2f* w = reinterpret_cast<const v2f*>(a.window);
+    const bool newest = a.asym && q == la;                  // methods.py:371-383
+    const v2f* w0 = newest ? reinterpret_cast<const v2f*>(a.asym1) : w;   // first inner iteration
+    const v2f* w1 = newest ? reinterpret_cast<const v2f*>(a.asym2) : w;   // later iterations
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      wsyn[u] = ws[64u * u + ulane];
+      win0[u] = w0[64u * u + ulane];
+      win1[u] = w1[64u * u + ulane];
+    }
+  }
+  (void)wout;
+
+  // ---- first frame (methods.py:353-358): irfft of the zero-phase first target frame into the newest slot
+  const long long f0 = (long long)bi * a.T;
+  __syncthreads();
+  if (q == 0) {
+    v2f z[R], back[H];
+    const v4f* mp = a.m_pairs + f0 * (H / 2 * 64);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v4f mm = mp[(j / 2) * 64u + ulane];
+      const float mk = (j & 1) ? mm.z : mm.x, mq = (j & 1) ? mm.w : mm.y;
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f ak = v2f{mk * a.inv_scale, 0.0f}, am = v2f{mq * a.inv_scale, 0.0f};
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    float mmid = 0.0f;
+    if (lane == 0) mmid = a.m_mid[f0];
+    const v2f zmid = v2f{2.0f * mmid * a.inv_scale, 0.0f};
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+    fft_inverse<R>(z, k, lds_tw1, tr);
+    v2f* dst = ring + (size_t)(nslots - 1) * M;
+#pragma unroll
+    for (int u = 0; u < R; ++u) dst[64 * u + lane] = z[u];
+  }
+  __syncthreads();
+
+  v4f pre[H];            // this frame's pre_spec pairs (Re k, Im k, Re M-k, Im M-k)
+  v2f premid = v2f{0.0f, 0.0f};
+  v4f shifted[H];        // pre_spec of frame q+1 at the end of the previous outer step (methods.py:391)
+  v2f shiftedmid = v2f{0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    pre[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    shifted[j] = pre[j];
+  }
+  int base = 0;          // ring slot of frame 0 (oldest kept frame)
+  const float half_scale = 0.5f * a.fwd_scale;
+
+  for (int i = 0; i < a.T + la; ++i) {
+    // target of this wave's frame for the whole outer step (zero outside the spectrogram: methods.py:339)
+    const int tt = i + q - la;
+    v4f mm[H / 2];
+    float mmid = 0.0f;
+#pragma unroll
+    for (int j = 0; j < H / 2; ++j) mm[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    if (tt >= 0 && tt < a.T) {
+      const v4f* mp = a.m_pairs + (f0 + tt) * (H / 2 * 64);
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) mm[j] = mp[j * 64u + ulane];
+      if (lane == 0) mmid = a.m_mid[f0 + tt];
+    }
+
+    for (int it = 0; it < a.max_iter; ++it) {
+      // ---- this frame's samples = overlap-add of the ring frames that cover it (methods.py:365-370)
+      v2f z[R];
+#pragma unroll
+      for (int qi = 0; qi < 4; ++qi) {
+        const int blk = K + q + qi;                  // hop-block index counted from ring frame 0
+#pragma unroll
+        for (int i2 = 0; i2 < QU; ++i2) z[qi * QU + i2] = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int d = 3; d >= 0; --d) {               // frame f = blk - d contributes its quarter d (f ascending)
+          const int f = blk - d;
+          if (f >= 0 && f < nslots) {
+            int slot = base + f;
+            if (slot >= nslots) slot -= nslots;
+            const v2f* fr = ring + (size_t)slot * M + d * QU * 64;
+#pragma unroll
+            for (int i2 = 0; i2 < QU; ++i2) z[qi * QU + i2] += fr[64 * i2 + lane] * wsyn[d * QU + i2];
+          }
+        }
+      }
+      __syncthreads();                               // every wave has read the ring; slots may be rewritten
+#pragma unroll
+      for (int u = 0; u < R; ++u) z[u] = z[u] * (it ? win1[u] : win0[u]);
+
+      fft_forward<R>(z, k, lds_tw1, tr);
+
+      v2f rc[H];
+#pragma unroll
+      for (int m = H; m < R; ++m) {
+        const v2f got = shfl2(z[m], k.partner);
+        const v2f own = z[(m + 1) % R];
+        rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+      }
+      const bool use_own = it > 0;                   // methods.py:387-388
+      const bool use_shift = it == 0 && i > 0 && q < la;   // :389-391
+      const float lr = (use_own || use_shift) ? a.lr : 0.0f;
+      v2f back[H];
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+        const v2f zk = z[j], zm = rc[R - 1 - j - H];
+        const v2f e2 = add_conj(zk, zm);
+        const v2f dd = sub_conj(zk, zm);
+        const v2f tw = cmul(mul_mi(wk), dd);
+        const v2f xk = (e2 + tw) * half_scale;
+        const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
+        const v4f p = use_own ? pre[j] : shifted[j];
+        const v2f sk = v2f{fmaf(-lr, p.x, xk.x), fmaf(-lr, p.y, xk.y)};
+        const v2f sm = v2f{fmaf(-lr, p.z, xm.x), fmaf(-lr, p.w, xm.y)};
+        pre[j] = v4f{sk.x, sk.y, sm.x, sm.y};        // :392
+        const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+        const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+        const float ik = __builtin_amdgcn_rcpf(fast_abs(sk) + 1e-16f) * a.inv_scale;   // :394-396
+        const float im = __builtin_amdgcn_rcpf(fast_abs(sm) + 1e-16f) * a.inv_scale;
+        v2f ak = v2f{(sk.x * mk) * ik, (sk.y * mk) * ik};
+        v2f am = v2f{(sm.x * mq) * im, (sm.y * mq) * im};
+        if (j == 0 && lane == 0) {
+          ak.y = 0.0f;
+          am.y = 0.0f;
+        }
+        const v2f e2i = add_conj(ak, am);
+        const v2f o2i = cmulc(sub_conj(ak, am), wk);
+        z[j] = add_i(e2i, o2i);
+        back[j] = conj_sub_i(e2i, o2i);
+      }
+      v2f zmid;
+      {
+        const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
+        const v2f p = use_own ? premid : shiftedmid;
+        const v2f s = v2f{fmaf(-lr, p.x, xmid.x), fmaf(-lr, p.y, xmid.y)};
+        premid = s;
+        const float inv = __builtin_amdgcn_rcpf(fast_abs(s) + 1e-16f) * a.inv_scale;
+        zmid = v2f{(s.x * mmid) * inv, (s.y * mmid) * inv} * v2f{2.0f, -2.0f};
+      }
+#pragma unroll
+      for (int m = H; m < R; ++m) {
+        const v2f got = shfl2(back[R - 1 - m], k.partner);
+        const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+        z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+      }
+      fft_inverse<R>(z, k, lds_tw1, tr);
+
+      int slot = base + K + q;
+      if (slot >= nslots) slot -= nslots;
+      v2f* dst = ring + (size_t)slot * M;
+#pragma unroll
+      for (int u = 0; u < R; ++u) dst[64 * u + lane] = z[u];                 // :398
+      __syncthreads();                               // new frames visible before the next overlap-add
+    }
+
+    // ---- commit look-ahead slot 0 (methods.py:401-404), publish pre_spec for the frame-shifted momentum
+    int s0 = base + K;
+    if (s0 >= nslots) s0 -= nslots;
+    if (q == 0 && i >= la) {
+      const v2f* src = ring + (size_t)s0 * M;
+      const v2f* w = reinterpret_cast<const v2f*>(a.window);
+      v2f* dst = reinterpret_cast<v2f*>(a.frames_out + ((long long)bi * a.T + (i - la)) * (2 * M));
+#pragma unroll
+      for (int u = 0; u < R; ++u) dst[64u * u + ulane] = src[64 * u + lane] * w[64u * u + ulane];
+    }
+    {
+      v2f* mine = xch + (size_t)q * (H * 2 * 64 + 64);
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        mine[(2 * j) * 64 + lane] = v2f{pre[j].x, pre[j].y};
+        mine[(2 * j + 1) * 64 + lane] = v2f{pre[j].z, pre[j].w};
+      }
+      if (lane == 0) mine[H * 2 * 64] = premid;
+    }
+    __syncthreads();
+    if (q < la) {
+      const v2f* nxt = xch + (size_t)(q + 1) * (H * 2 * 64 + 64);
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const v2f a0 = nxt[(2 * j) * 64 + lane], a1 = nxt[(2 * j + 1) * 64 + lane];
+        shifted[j] = v4f{a0.x, a0.y, a1.x, a1.y};
+      }
+      shiftedmid = nxt[H * 2 * 64];
+    }
+    if (q == la) {   // the oldest frame's slot becomes the new (zero) newest frame
+      v2f* fresh = ring + (size_t)base * M;
+#pragma unroll
+      for (int u = 0; u < R; ++u) fresh[64 * u + lane] = v2f{0.0f, 0.0f};
+    }
+    base = base + 1 == nslots ? 0 : base + 1;
+    __syncthreads();
+  }
+}
+
+}  // namespace fast
+
+// returns SPECINV_EUNSUPPORTED (without setting an error) when the configuration is not covered
+template <typename P>
+int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_iter, double alpha, float* x_out,
+                      const float* d_wsyn, const float* d_a1, const float* d_a2, bool* used) {
+  *used = false;
+  const auto& cfg = pl.cfg;
+  if (cfg.dtype != SPECINV_F32 || !cfg.onesided || cfg.hop_length * 4 != cfg.n_fft) return SPECINV_OK;
+  if (cfg.n_fft != 2048 && cfg.n_fft != 1024) return SPECINV_OK;
+  if (la > 7 || pl.force_generic) return SPECINV_OK;
+  const int R = cfg.n_fft / 128;
+  const size_t lds = R == 16 ? fast::RtisiGeo<16>::lds_bytes(la) : fast::RtisiGeo<8>::lds_bytes(la);
+  if (lds > 160 * 1024 - 1024) return SPECINV_OK;
+  if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
+    if (e[0] == '1') return SPECINV_OK;
+  }
+  using v4f = fast::v4f;
+  const long long nf = (long long)pl.B() * pl.Tn();
+  const int H = R / 2;
+  SI_TRY(pl.mag.reserve(pl.nspec() * sizeof(float)));
+  SI_TRY((pl.template transpose<float>(mag_user, pl.mag.template as<float>(), pl.n_freq, pl.Tn())));
+  SI_TRY(pl.fast.mpairs.reserve((size_t)nf * (H / 2) * 64 * sizeof(v4f)));
+  SI_TRY(pl.fast.mmid.reserve(nf * sizeof(float)));
+  const long long nm = nf * (H / 2) * 64;
+  if (R == 16)
+    hipLaunchKernelGGL((fast::k_mag_to_pairs<16>), dim3((unsigned)ceil_div(nm, 256)), dim3(256), 0, pl.stream,
+                       pl.mag.template as<float>(), pl.fast.mpairs.template as<v4f>(), pl.fast.mmid.template as<float>(), nf);
+  else
+    hipLaunchKernelGGL((fast::k_mag_to_pairs<8>), dim3((unsigned)ceil_div(nm, 256)), dim3(256), 0, pl.stream,
+                       pl.mag.template as<float>(), pl.fast.mpairs.template as<v4f>(), pl.fast.mmid.template as<float>(), nf);
+  SI_HIP(hipGetLastError());
+  SI_TRY(pl.frames_needed());
+  fast::RtisiFastArgs a{};
+  a.m_pairs = pl.fast.mpairs.template as<v4f>();
+  a.m_mid = pl.fast.mmid.template as<float>();
+  a.frames_out = pl.frames.template as<float>();
+  a.window = pl.window.template as<float>();
+  a.wsyn = d_wsyn;
+  a.asym1 = d_a1;
+  a.asym2 = d_a2;
+  a.T = pl.Tn();
+  a.la = la;
+  a.max_iter = max_iter;
+  a.asym = asym ? 1 : 0;
+  a.lr = (float)(alpha / (1.0 + alpha));
+  a.fwd_scale = pl.fc.fwd_scale;
+  a.inv_scale = pl.fc.inv_scale;
+  const int threads = 64 * (la + 1);
+  const void* fn;
+  if (R == 16) fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<16, 256> : (const void*)fast::k_rtisi_fast<16, 512>;
+  else fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<8, 256> : (const void*)fast::k_rtisi_fast<8, 512>;
+  SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  void* kargs[] = {&a};
+  SI_HIP(hipLaunchKernel(fn, dim3(pl.B()), dim3(threads), kargs, lds, pl.stream));
+  SI_HIP(hipGetLastError());
+  SI_TRY(pl.launch_ola(pl.frames.template as<float>(), x_out, true));
+  *used = true;
+  return SPECINV_OK;
+}
+
+}  // namespace specinv

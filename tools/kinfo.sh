@@ -1,13 +1,8 @@
-# print register/scratch usage of the fused kernels inside a built library (dev tool)
-f=$1
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --list --type=o --input=$f 2>/dev/null | head -3
+f=$1; pat=$2
 tmp=$(mktemp -d)
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$f --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$tmp/dev.co 2>/dev/null || \
 python3 - "$f" "$tmp/dev.co" <<'PY'
 import sys
 b=open(sys.argv[1],'rb').read()
-i=b.find(b'\x7fELF', b.find(b'__CLANG_OFFLOAD_BUNDLE__'))
-# find ELF with machine AMDGPU (0xE0)
 pos=0; found=None
 while True:
     i=b.find(b'\x7fELF',pos)
@@ -16,5 +11,5 @@ while True:
     pos=i+4
 open(sys.argv[2],'wb').write(b[found:])
 PY
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes $tmp/dev.co | grep -E "\.name:|vgpr_count|vgpr_spill|private_segment_fixed" | grep -A3 "k_fused" | grep -vE "^--" | paste - - - - | sed 's/  */ /g' | cut -c1-200
+/opt/rocm/lib/llvm/bin/llvm-readelf --notes $tmp/dev.co | grep -E "\.name:|vgpr_count|vgpr_spill|private_segment_fixed|agpr_count|group_segment_fixed" | grep -A5 "$pat" | grep -vE "^--" | tr '\n' ' ' | sed 's/\.name:/\n.name:/g' | sed 's/  */ /g' | cut -c1-260
 rm -rf $tmp
