@@ -1,0 +1,116 @@
+"""Drop-in API behaviour on the device: shapes, devices, dtypes, progress reporting, early stop, path selection
+for configurations around the edges of the fused kernels.  Needs an MI355X: `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _util import hann, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+import spectrogram_inversion_amd as si                              # noqa: E402
+from spectrogram_inversion_amd.plan import Plan, args_helper         # noqa: E402
+
+DEV = "cuda:0"
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("x_sizes", [(4410,), (2, 4410), (1, 4410)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("nfft", [128, 256, 512])
+def test_reference_shape_contract(x_sizes, dtype, nfft):
+    """The reference's own test (test/test_griffin.py:9-21, test_admm.py, test_rtisila.py): output rank, batch and
+    length rules for every method with default stft arguments."""
+    torch.manual_seed(0)
+    x = torch.randn(*x_sizes, dtype=dtype, device=DEV)
+    spec = torch.stft(x, nfft, return_complex=True).abs()
+    for fn, kw in ((si.griffin_lim, dict(max_iter=4)), (si.ADMM, dict(max_iter=4)), (si.RTISI_LA, dict(max_iter=4))):
+        y = fn(spec, verbose=False, **kw)
+        assert y.dtype == dtype and y.device == spec.device
+        assert y.dim() == x.dim()
+        if y.dim() > 1:
+            assert y.shape[0] == x.shape[0] and y.shape[1] <= x.shape[1]
+        assert bool(torch.isfinite(y).all())
+
+
+def test_path_selection_at_the_edges():
+    w = torch.from_numpy(hann(2048))
+    probe = torch.empty(1, 1025, 1)
+    assert Plan(args_helper(probe, hop_length=512, window=w), 1, 6, torch.float32, torch.device(DEV)).fast_path
+    assert not Plan(args_helper(probe, hop_length=512, window=w), 1, 5, torch.float32, torch.device(DEV)).fast_path   # too short
+    assert not Plan(args_helper(probe, hop_length=500, window=w), 1, 40, torch.float32, torch.device(DEV)).fast_path  # hop != n_fft/4
+    assert not Plan(args_helper(probe, hop_length=512, window=w, center=False), 1, 40, torch.float32,
+                    torch.device(DEV)).fast_path
+    assert not Plan(args_helper(probe, hop_length=512, window=w, pad_mode="constant"), 1, 40, torch.float32,
+                    torch.device(DEV)).fast_path
+    w64 = torch.from_numpy(hann(2048, np.float64))
+    assert not Plan(args_helper(probe.double(), hop_length=512, window=w64), 1, 40, torch.float64,
+                    torch.device(DEV)).fast_path
+
+
+@pytest.mark.parametrize("frames", [3, 5])
+def test_short_signals_use_generic_kernels(frames):
+    rng = np.random.default_rng(frames)
+    mag = rng.random((2, 1025, frames), dtype=np.float32)
+    w = hann(2048)
+    ref = oracle.griffin_lim(mag, max_iter=5, alpha=0.3, tol=0, hop_length=512, window=w)
+    y = N(si.griffin_lim(torch.from_numpy(mag).to(DEV), max_iter=5, alpha=0.3, tol=0, verbose=False, hop_length=512,
+                         window=torch.from_numpy(w)))
+    assert rel_l2(y, ref) < 1e-4
+
+
+def test_warm_start_from_complex_spectrogram_on_fused_path():
+    rng = np.random.default_rng(12)
+    mag = rng.random((2, 513, 20), dtype=np.float32)
+    w = hann(1024)
+    init = oracle.phase_init(mag, hop_length=256, window=w) * np.exp(1j * 0.3).astype(np.complex64)
+    ref = oracle.griffin_lim(init, max_iter=6, tol=0, hop_length=256, window=w)          # default alpha = 0.99
+    y = N(si.griffin_lim(torch.from_numpy(init).to(DEV), max_iter=6, tol=0, verbose=False, hop_length=256,
+                         window=torch.from_numpy(w)))
+    assert rel_l2(y, ref) < 1e-4
+
+
+def test_progress_and_early_stop_on_fused_path(capsys):
+    rng = np.random.default_rng(13)
+    mag = rng.random((1, 513, 24), dtype=np.float32)
+    w = hann(1024)
+    tr = []
+    _, st = oracle.griffin_lim(mag, max_iter=400, tol=1e-4, eva_iter=5, hop_length=256, window=w, trace=tr,
+                               return_state=True)
+    plan = Plan(args_helper(torch.empty(1, 513, 1), hop_length=256, window=torch.from_numpy(w)), 1, 24, torch.float32,
+                torch.device(DEV))
+    assert plan.fast_path
+    plan.gla_init(None, torch.from_numpy(mag).to(DEV), 0.99)
+    seen = []
+    done, evals = plan.run(400, 5, 1e-4, "sc", callback=lambda it, m, l: seen.append(it) or 0)
+    assert abs(done - st["iters"]) <= 5 and done < 400          # the stop rule of methods.py:186-190 fired
+    assert seen == [e[0] for e in evals]
+    y = si.griffin_lim(torch.from_numpy(mag).to(DEV), max_iter=20, eva_iter=5, verbose=True, hop_length=256,
+                       window=torch.from_numpy(w))            # tqdm bar like the reference
+    assert "SC=" in capsys.readouterr().err
+    assert y.shape == (1, 23 * 256)
+
+
+def test_callback_abort():
+    rng = np.random.default_rng(14)
+    mag = torch.from_numpy(rng.random((1, 513, 24), dtype=np.float32)).to(DEV)
+    plan = Plan(args_helper(mag, hop_length=256, window=torch.from_numpy(hann(1024))), 1, 24, torch.float32,
+                torch.device(DEV))
+    plan.gla_init(None, mag, 0.5)
+    done, evals = plan.run(100, 10, 0.0, "snr", callback=lambda it, m, l: it >= 29)
+    assert done == 30 and len(evals) == 3
+
+
+def test_state_errors():
+    from spectrogram_inversion_amd import _lib
+    plan = Plan(args_helper(torch.empty(1, 513, 1), hop_length=256, window=torch.from_numpy(hann(1024))), 1, 24,
+                torch.float32, torch.device(DEV))
+    plan._method = "gla"
+    with pytest.raises(_lib.SpecinvError):
+        plan.iterate(1)                                      # iterate before init: SPECINV_ESTATE
+    with pytest.raises(AssertionError):
+        plan.stft(torch.zeros(1, 100, device=DEV))           # wrong length for the plan's frame count
