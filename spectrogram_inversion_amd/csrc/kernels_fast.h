@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "common.h"
+#include "kernels_generic.h"
 
 // build-time tunables of the fused kernel (see tools/sweep_variants.sh)
 #ifndef SPECINV_XPREF      // 0: load the frame when it starts; 1: carry the samples in registers and prefetch one
@@ -807,6 +808,78 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused_istft(FastArgs 
   }
 }
 
+// User layout (B, F, T) -> pair layout in one pass (32 x 32 tile transposed through LDS): reads are contiguous in
+// time, writes are 8-byte (spectrum) / 4-byte (magnitude) pieces of the 16-byte pair records, contiguous in k.
+// Bin f goes to pair k = f (first half) for f < M/2, to pair k = M - f (second half) for f > M/2, to `mid` for M/2.
+template <int R>
+__global__ void k_user_spec_to_pairs(const v2f* __restrict__ in, v2f* __restrict__ pairs /* v4f records as 2 x v2f */,
+                                     v2f* __restrict__ mid, int T) {
+  using G = Geo<R>;
+  constexpr int F = G::M + 1;
+  __shared__ v2f tile[32][33];
+  const int b = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int f = f0 + i, t = t0 + threadIdx.x;
+    if (f < F && t < T) tile[i][threadIdx.x] = in[((long long)b * F + f) * T + t];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int t = t0 + i, f = f0 + threadIdx.x;
+    if (f >= F || t >= T) continue;
+    const long long fr = (long long)b * T + t;
+    const v2f v = tile[threadIdx.x][i];
+    if (2 * f == G::M) {
+      mid[fr] = v;
+    } else {
+      const int kk = f < G::M / 2 ? f : G::M - f, half = f < G::M / 2 ? 0 : 1;
+      pairs[(((fr * G::H) + (kk >> 6)) * 64 + (kk & 63)) * 2 + half] = v;
+    }
+  }
+}
+
+// same for the target magnitude; also per-block partial sums of m^2 (for the metrics)
+template <int R>
+__global__ void k_user_mag_to_pairs(const float* __restrict__ in, float* __restrict__ pairs /* v4f records */,
+                                    float* __restrict__ mid, int T, double* __restrict__ partials) {
+  using G = Geo<R>;
+  constexpr int F = G::M + 1;
+  __shared__ float tile[32][33];
+  __shared__ double red[4];
+  const int b = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  double s2 = 0.0;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int f = f0 + i, t = t0 + threadIdx.x;
+    if (f < F && t < T) {
+      const float v = in[((long long)b * F + f) * T + t];
+      tile[i][threadIdx.x] = v;
+      s2 += (double)v * (double)v;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int t = t0 + i, f = f0 + threadIdx.x;
+    if (f >= F || t >= T) continue;
+    const long long fr = (long long)b * T + t;
+    const float v = tile[threadIdx.x][i];
+    if (2 * f == G::M) {
+      mid[fr] = v;
+    } else {
+      const int kk = f < G::M / 2 ? f : G::M - f, second = f < G::M / 2 ? 0 : 1;
+      const int j = kk >> 6;
+      pairs[(((fr * (G::H / 2)) + (j >> 1)) * 64 + (kk & 63)) * 4 + (j & 1) * 2 + second] = v;
+    }
+  }
+  s2 = wave_sum(s2);
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if ((tid & 63) == 0) red[tid >> 6] = s2;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < (int)((blockDim.x * blockDim.y + 63) >> 6); ++w) tot += red[w];
+    partials[((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
 // x += the tail partial sums (final waveform for get_wave)
 template <int R>
 __global__ void k_add_tails(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, long long L,
@@ -911,9 +984,7 @@ struct FastState {
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
   template <typename P>
-  int gla_begin(P&) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
-  template <typename P>
-  int admm_begin(P&) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
+  int begin(P&, int, const void*, const void*, double*) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
   template <typename P>
   int iterate(P&, int, bool) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
   template <typename P>
@@ -959,8 +1030,9 @@ struct FastState<float> {
     return SPECINV_OK;
   }
 
+  // `spec_user` (B, F, T) complex and `mag_user` (B, F, T) are the caller's / phase_init's arrays
   template <int RR, typename P>
-  int begin_t(P& pl, int md) {
+  int begin_t(P& pl, int md, const v2f* spec_user, const float* mag_user, double* sum_m2_out) {
     using G = fast::Geo<RR>;
     mode = md;
     const long long nf = (long long)pl.B() * pl.Tn();
@@ -980,18 +1052,25 @@ struct FastState<float> {
     SI_TRY(mmid.reserve(nf * sizeof(float)));
     SI_TRY(inv_env.reserve(pl.length * sizeof(float)));
     cur = 0;
-    const long long np = nf * G::H * 64;
-    hipLaunchKernelGGL((fast::k_spec_to_pairs<RR>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
-                       reinterpret_cast<const v2f*>(pl.specA.p), Pb[0].template as<v4f>(), Pmid[0].template as<v2f>(), nf);
-    SI_HIP(hipGetLastError());
+    {
+      const dim3 grid((pl.Tn() + 31) / 32, (pl.n_freq + 31) / 32, pl.B()), blk(32, 8);
+      hipLaunchKernelGGL((fast::k_user_spec_to_pairs<RR>), grid, blk, 0, pl.stream, spec_user, Pb[0].template as<v2f>(),
+                         Pmid[0].template as<v2f>(), pl.Tn());
+      SI_HIP(hipGetLastError());
+      const long long nblk = (long long)grid.x * grid.y * grid.z;
+      SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nblk, 3 * 1024) * sizeof(double)));
+      hipLaunchKernelGGL((fast::k_user_mag_to_pairs<RR>), grid, blk, 0, pl.stream, mag_user, mpairs.template as<float>(),
+                         mmid.template as<float>(), pl.Tn(), pl.partials.template as<double>());
+      SI_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), nblk, 1,
+                         pl.sums.template as<double>() + 4);
+      SI_HIP(hipGetLastError());
+      SI_HIP(hipMemcpyAsync(sum_m2_out, pl.sums.template as<double>() + 4, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+    }
     if (md == fast::MODE_ADMM) {
       SI_HIP(hipMemsetAsync(Ub[0].p, 0, pbytes, pl.stream));
       SI_HIP(hipMemsetAsync(Umid[0].p, 0, nf * sizeof(v2f), pl.stream));
     }
-    const long long nm = nf * (G::H / 2) * 64;
-    hipLaunchKernelGGL((fast::k_mag_to_pairs<RR>), dim3((unsigned)ceil_div(nm, 256)), dim3(256), 0, pl.stream,
-                       pl.mag.template as<float>(), mpairs.template as<v4f>(), mmid.template as<float>(), nf);
-    SI_HIP(hipGetLastError());
     hipLaunchKernelGGL(fast::k_reciprocal, dim3((unsigned)ceil_div(pl.length, 256)), dim3(256), 0, pl.stream,
                        pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length);
     SI_HIP(hipGetLastError());
@@ -1014,13 +1093,16 @@ struct FastState<float> {
     SI_HIP(hipFuncSetAttribute((const void*)fast::k_fused_istft<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((fast::k_fused_istft<RR>), dim3((n_waves + 3) / 4), dim3(256), lds, pl.stream, a);
     SI_HIP(hipGetLastError());
+    SI_HIP(hipStreamSynchronize(pl.stream));   // *sum_m2_out is valid from here on
     return SPECINV_OK;
   }
 
   template <typename P>
-  int gla_begin(P& pl) { return R == 16 ? begin_t<16>(pl, fast::MODE_GLA) : begin_t<8>(pl, fast::MODE_GLA); }
-  template <typename P>
-  int admm_begin(P& pl) { return R == 16 ? begin_t<16>(pl, fast::MODE_ADMM) : begin_t<8>(pl, fast::MODE_ADMM); }
+  int begin(P& pl, int md, const void* spec_user, const void* mag_user, double* sum_m2_out) {
+    const v2f* s = static_cast<const v2f*>(spec_user);
+    const float* m = static_cast<const float*>(mag_user);
+    return R == 16 ? begin_t<16>(pl, md, s, m, sum_m2_out) : begin_t<8>(pl, md, s, m, sum_m2_out);
+  }
 
   template <int RR, int MODE, bool EVAL, typename P>
   int launch(P& pl, const fast::FastArgs& a) {

@@ -149,7 +149,7 @@ struct PlanT final : PlanBase {
       SI_HIP(hipFuncSetAttribute((const void*)k_admm_frame<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       SI_HIP(hipFuncSetAttribute((const void*)k_grad_frames<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     }
-    SI_TRY(sums.reserve(8 * sizeof(double)));
+    SI_TRY(sums.reserve(16 * sizeof(double)));
     SI_TRY(fast.setup(cfg, h_window, length, pad));
     return SPECINV_OK;
   }
@@ -259,19 +259,32 @@ struct PlanT final : PlanBase {
   // ------------------------------------------------------------------------------------
   // shared part of gla_init / admm_init: target + starting spectrum into internal layout,
   // x = ISTFT(start) (methods.py:233 / :453)
-  int init_common(const void* init_spec, const void* magp) {
+  int init_common(const void* init_spec, const void* magp, int fast_mode) {
     SI_CHECK(init_spec || magp, SPECINV_EINVAL, "need init_spec and/or mag");
     const int64_t ns = nspec();
-    SI_TRY(specA.reserve(ns * sizeof(C)));
-    SI_TRY(mag.reserve(ns * sizeof(T)));
-    SI_TRY(x.reserve((size_t)B() * length * sizeof(T)));
-    SI_TRY(partials.reserve(std::max<size_t>((size_t)B() * Tn() * 2, 3 * 1024) * sizeof(double)));
+    count = (double)ns;
     const C* start_user = static_cast<const C*>(init_spec);
     if (!init_spec) {
       SI_TRY(tmp_spec.reserve(ns * sizeof(C)));
       SI_TRY(phase_init(magp, tmp_spec.p));                       // methods.py:106
       start_user = tmp_spec.as<C>();
     }
+    if (fast_path()) {
+      // fused path: user layout -> pair layout directly, x0 from its own ISTFT kernel
+      const T* mag_user = static_cast<const T*>(magp);
+      if (!magp) {                                                  // methods.py:110
+        SI_TRY(tmp_real.reserve(ns * sizeof(T)));
+        hipLaunchKernelGGL((k_cabs<T>), dim3((unsigned)ceil_div(ns, 256)), dim3(256), 0, stream, start_user,
+                           tmp_real.as<T>(), ns);
+        SI_HIP(hipGetLastError());
+        mag_user = tmp_real.as<T>();
+      }
+      return fast.begin(*this, fast_mode, start_user, mag_user, &sum_m2);
+    }
+    SI_TRY(specA.reserve(ns * sizeof(C)));
+    SI_TRY(mag.reserve(ns * sizeof(T)));
+    SI_TRY(x.reserve((size_t)B() * length * sizeof(T)));
+    SI_TRY(partials.reserve(std::max<size_t>((size_t)B() * Tn() * 2, 3 * 1024) * sizeof(double)));
     SI_TRY(transpose<C>(start_user, specA.as<C>(), n_freq, Tn()));
     if (magp) {
       SI_TRY(transpose<T>(static_cast<const T*>(magp), mag.as<T>(), n_freq, Tn()));
@@ -283,28 +296,26 @@ struct PlanT final : PlanBase {
     double r[3];
     SI_TRY(reduce3(mag.as<T>(), nullptr, ns, r));
     sum_m2 = r[1];
-    count = (double)ns;
-    if (fast_path()) return SPECINV_OK;          // the fused path computes x0 itself from its own layout
     return istft_internal(specA.as<C>(), x.as<T>());
   }
 
   int gla_init(const void* init_spec, const void* magp, double alpha) override {
     SI_CHECK(alpha >= 0, SPECINV_EINVAL, "alpha must be >= 0");
     method = Method::None;
-    SI_TRY(init_common(init_spec, magp));
     coef = (T)(alpha / (1.0 + alpha));                              // methods.py:235
-    if (fast_path()) SI_TRY(fast.gla_begin(*this));
+    SI_TRY(init_common(init_spec, magp, fast::MODE_GLA));
     method = Method::Gla;
     return SPECINV_OK;
   }
 
   int admm_init(const void* init_spec, const void* magp, double rho) override {
     method = Method::None;
-    SI_TRY(init_common(init_spec, magp));
-    SI_TRY(specB.reserve(nspec() * sizeof(C)));
-    SI_HIP(hipMemsetAsync(specB.p, 0, nspec() * sizeof(C), stream));  // U = 0, methods.py:456
     coef = (T)rho;
-    if (fast_path()) SI_TRY(fast.admm_begin(*this));
+    SI_TRY(init_common(init_spec, magp, fast::MODE_ADMM));
+    if (!fast_path()) {
+      SI_TRY(specB.reserve(nspec() * sizeof(C)));
+      SI_HIP(hipMemsetAsync(specB.p, 0, nspec() * sizeof(C), stream));  // U = 0, methods.py:456
+    }
     method = Method::Admm;
     return SPECINV_OK;
   }
