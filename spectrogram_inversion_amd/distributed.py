@@ -29,14 +29,30 @@ def shard_bounds(n_items: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None):
+class PendingGather:
+    """Handle of a gather that was started without waiting (`gather_waveforms(..., async_op=True)`): the
+    collective runs on RCCL's own stream while the caller enqueues the next inversion; `result()` waits."""
+
+    def __init__(self, work, out, keep):
+        self._work, self._out, self._keep = work, out, keep
+
+    def result(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        return self._out
+
+
+def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None, async_op: bool = False):
     """Gather (B_r, L) blocks of possibly different B_r to `dst`.  Returns the concatenated
     (sum B_r, L) tensor on `dst`, None elsewhere.  `sizes` (the per-rank batch sizes) may be
-    passed when known, e.g. equal shards, to skip the size exchange."""
+    passed when known, e.g. equal shards, to skip the size exchange.  With `async_op=True` (equal
+    shards only) a `PendingGather` is returned instead and the transfer overlaps later work."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
-        return x_local
+        return PendingGather(None, x_local, None) if async_op else x_local
     if sizes is None:
         # batch sizes of all ranks: one small tensor all-gather on the data's own device / backend
         mine = torch.tensor([x_local.shape[0]], dtype=torch.int64, device=x_local.device)
@@ -47,8 +63,12 @@ def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None
         # receive straight into the slices of the final (world*B_r, L) tensor: no concatenation pass
         big = x_local.new_empty((world * sizes[0],) + tuple(x_local.shape[1:])) if rank == dst else None
         out = list(big.split(sizes[0], 0)) if rank == dst else None
-        dist.gather(x_local.contiguous(), out, dst=dst, group=group)
+        src = x_local.contiguous()
+        if async_op:
+            return PendingGather(dist.gather(src, out, dst=dst, group=group, async_op=True), big, src)
+        dist.gather(src, out, dst=dst, group=group)
         return big
+    assert not async_op, "async gather needs equal shards"
     # ragged batch: point-to-point to the root
     if rank == dst:
         parts = []

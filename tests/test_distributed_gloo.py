@@ -98,3 +98,27 @@ def test_two_rank_sharded_inversion_matches_single_process(tmp_path):
     # whole-batch metric / loss (methods.py:181-182) from all-reduced per-rank sums
     want = np.array([[i, m, l] for i, m, l in trace])
     np.testing.assert_allclose(got["evals"], want, rtol=1e-6)
+
+
+def _async_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spectrogram_inversion_amd.distributed import gather_waveforms
+    handles = [gather_waveforms(torch.full((3, 5), float(10 * k + rank)), dst=0, sizes=[3] * world, async_op=True)
+               for k in range(3)]                       # several gathers in flight, completed later in order
+    for k, h in enumerate(handles):
+        y = h.result()
+        if rank == 0:
+            assert y.shape == (6, 5) and y[:3].eq(10 * k).all() and y[3:].eq(10 * k + 1).all()
+        else:
+            assert y is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_async_gather_overlaps_and_completes():
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_async_worker, args=(2, port), nprocs=2, join=True)
