@@ -148,6 +148,13 @@ int specinv_vec_dot(specinv_plan* plan, const void* a, const void* b, int64_t n,
 int specinv_vec_axpy(specinv_plan* plan, double alpha, const void* x, void* y, int64_t n);
 int specinv_vec_scale(specinv_plan* plan, double alpha, const void* x, void* y, int64_t n);
 int specinv_vec_absmax_abssum(specinv_plan* plan, const void* x, int64_t n, double out_host[2]);
+/* The whole L-BFGS two-loop recursion d = -H g on the device (torch.optim.LBFGS.step's "compute the approximate
+ * inverse Hessian multiplied by the gradient"): s_list_host / y_list_host are HOST arrays of m device pointers
+ * (old_stps / old_dirs, oldest first), rho_host[m] = 1 / (y_i . s_i).  All 2m dot products stay on the device
+ * (no host synchronisation); d_out receives the direction. */
+int specinv_lbfgs_direction(specinv_plan* plan, const void* g, const void* const* s_list_host,
+                            const void* const* y_list_host, const double* rho_host, int m, double h_diag,
+                            void* d_out, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,56 @@ int lb_absmax_abssum(P& pl, const T* x, int64_t n, double* out) {
   return SPECINV_OK;
 }
 
+// ---- two-loop recursion with device-resident scalars -----------------------------------------------------
+// slot = scale * sum(partials)      (al_i = rho_i * (s_i . q))
+__global__ void k_finish_scaled(const double* __restrict__ part, int n, double scale, double* __restrict__ slot) {
+  __shared__ double red[16];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+  const double t = block_sum(s, red);
+  if (threadIdx.x == 0) *slot = scale * t;
+}
+
+// y += (sa * a[0] + sb * (b ? b[0] : 0)) * x    with the coefficient read from device memory
+template <typename T>
+__global__ void k_axpy_dev(const double* __restrict__ a, double sa, const double* __restrict__ b, double sb,
+                           const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+  const T c = (T)(sa * a[0] + (b ? sb * b[0] : 0.0));
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = y[i] + c * x[i];
+}
+
+template <typename P, typename T>
+int lb_direction(P& pl, const T* g, const void* const* s_list, const void* const* y_list, const double* rho, int m,
+                 double h_diag, T* d, int64_t n) {
+  SI_CHECK(g && d && n > 0 && m >= 0, SPECINV_EINVAL, "bad arguments");
+  SI_CHECK(m == 0 || (s_list && y_list && rho), SPECINV_EINVAL, "history arrays are NULL");
+  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb, 3 * 1024) * sizeof(double)));
+  SI_TRY(pl.lb_scal.reserve((size_t)(m + 2) * sizeof(double)));
+  double* al = pl.lb_scal.template as<double>();      // al[0..m-1], be at al[m]
+  double* part = pl.partials.template as<double>();
+  const dim3 ge((unsigned)ceil_div(n, 256)), blk(256);
+  hipLaunchKernelGGL((k_scale<T>), ge, blk, 0, pl.stream, T(-1), g, d, n);                       // q = -g
+  for (int i = m - 1; i >= 0; --i) {
+    const T* si = static_cast<const T*>(s_list[i]);
+    const T* yi = static_cast<const T*>(y_list[i]);
+    hipLaunchKernelGGL((k_dot_partials<T>), dim3(nb), blk, 0, pl.stream, si, static_cast<const T*>(d), n, part);
+    hipLaunchKernelGGL(k_finish_scaled, dim3(1), blk, 0, pl.stream, part, nb, rho[i], al + i);   // al_i
+    hipLaunchKernelGGL((k_axpy_dev<T>), ge, blk, 0, pl.stream, al + i, -1.0, (const double*)nullptr, 0.0, yi, d, n);
+  }
+  hipLaunchKernelGGL((k_scale<T>), ge, blk, 0, pl.stream, (T)h_diag, static_cast<const T*>(d), d, n);   // r = H0 q
+  for (int i = 0; i < m; ++i) {
+    const T* si = static_cast<const T*>(s_list[i]);
+    const T* yi = static_cast<const T*>(y_list[i]);
+    hipLaunchKernelGGL((k_dot_partials<T>), dim3(nb), blk, 0, pl.stream, yi, static_cast<const T*>(d), n, part);
+    hipLaunchKernelGGL(k_finish_scaled, dim3(1), blk, 0, pl.stream, part, nb, rho[i], al + m);   // be_i
+    hipLaunchKernelGGL((k_axpy_dev<T>), ge, blk, 0, pl.stream, al + i, 1.0, al + m, -1.0, si, d, n);
+  }
+  SI_HIP(hipGetLastError());
+  return SPECINV_OK;
+}
+
 // ---- mel contractions on the matrix cores ----------------------------------------------------------------
 // One wave owns a 32 x 32 output tile and feeds v_mfma_f32_32x32x2_f32 (A: lane l holds A[l&31][l>>5],
 // B: lane l holds B[l>>5][l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)).  Operands are staged

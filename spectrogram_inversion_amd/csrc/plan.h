@@ -49,6 +49,8 @@ struct PlanBase {
   virtual int vec_axpy(double alpha, const void* x, void* y, int64_t n) = 0;
   virtual int vec_scale(double alpha, const void* x, void* y, int64_t n) = 0;
   virtual int vec_absmax_abssum(const void* x, int64_t n, double out[2]) = 0;
+  virtual int lbfgs_direction(const void* g, const void* const* s_list, const void* const* y_list, const double* rho,
+                              int m, double h_diag, void* d_out, int64_t n) = 0;
 
   // _training_loop (methods.py:153-190) driving `iterate`
   int run_loop(int max_iter, int eva_iter, double tol, int metric, specinv_eval* evals, int* n_evals,

@@ -64,6 +64,7 @@ struct PlanT final : PlanBase {
   DevBuf window, tw, env;
   DevBuf x, frames, specA, specB, mag, partials, sums, tmp_spec, tmp_real;
   DevBuf rt_state;                      // RTISI per-item state
+  DevBuf lb_scal;                       // device scalars of the L-BFGS two-loop recursion
   DevBuf eval_log;                      // per-evaluation sums of a run with deferred read-back
   DevBuf tf_mel, tf_spec, tf_v, tf_dv;  // transform (L_BFGS) scratch
   std::vector<T> h_window;
@@ -438,6 +439,10 @@ struct PlanT final : PlanBase {
   }
   int vec_absmax_abssum(const void* xin, int64_t n, double out[2]) override {
     return lb_absmax_abssum(*this, static_cast<const T*>(xin), n, out);
+  }
+  int lbfgs_direction(const void* g, const void* const* s_list, const void* const* y_list, const double* rho, int m,
+                      double h_diag, void* d_out, int64_t n) override {
+    return lb_direction(*this, static_cast<const T*>(g), s_list, y_list, rho, m, h_diag, static_cast<T*>(d_out), n);
   }
 };
 

@@ -266,4 +266,11 @@ int specinv_vec_absmax_abssum(specinv_plan* plan, const void* x, int64_t n, doub
   return plan->impl->vec_absmax_abssum(x, n, out_host);
 }
 
+int specinv_lbfgs_direction(specinv_plan* plan, const void* g, const void* const* s_list_host,
+                            const void* const* y_list_host, const double* rho_host, int m, double h_diag, void* d_out,
+                            int64_t n) {
+  ENTER(plan);
+  return plan->impl->lbfgs_direction(g, s_list_host, y_list_host, rho_host, m, h_diag, d_out, n);
+}
+
 }  // extern "C"

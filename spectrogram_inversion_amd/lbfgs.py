@@ -39,6 +39,9 @@ class HipVecOps:
     def absmax_abssum(self, x):
         return self.plan.vec_absmax_abssum(x)
 
+    def direction(self, g, ss, ys, rho, h_diag):
+        return self.plan.lbfgs_direction(g, ss, ys, rho, h_diag)
+
 
 def _cubic_step(xa, fa, ga, xb, fb, gb, bounds=None):
     """Minimiser of the cubic interpolating (xa, fa, ga) and (xb, fb, gb), clipped to bounds."""
@@ -84,6 +87,8 @@ class LBFGS:
     def _direction(self, g):
         """Two-loop recursion: returns -H g for the current memory."""
         ops = self.ops
+        if hasattr(ops, "direction"):          # device-resident scalars: no host sync inside the recursion
+            return ops.direction(g, self.ss, self.ys, self.rho, self.h_diag)
         m = len(self.ys)
         q = ops.scaled(-1.0, g)
         al = [0.0] * m

@@ -292,6 +292,18 @@ class Plan:
         self._sync_stream()
         _lib.check(self.lib.specinv_vec_scale(self._h, float(alpha), x.data_ptr(), y.data_ptr(), x.numel()))
 
+    def lbfgs_direction(self, g, s_list, y_list, rho, h_diag):
+        """d = -H g by the two-loop recursion, all dot products kept on the device."""
+        self._sync_stream()
+        m = len(s_list)
+        d = torch.empty_like(g)
+        sp = (C.c_void_p * max(1, m))(*[t.data_ptr() for t in s_list])
+        yp = (C.c_void_p * max(1, m))(*[t.data_ptr() for t in y_list])
+        rh = (C.c_double * max(1, m))(*[float(r) for r in rho])
+        _lib.check(self.lib.specinv_lbfgs_direction(self._h, g.data_ptr(), sp, yp, rh, m, float(h_diag), d.data_ptr(),
+                                                    g.numel()))
+        return d
+
     def vec_absmax_abssum(self, x):
         self._sync_stream()
         out = (C.c_double * 2)()
