@@ -880,6 +880,140 @@ __global__ void k_user_mag_to_pairs(const float* __restrict__ in, float* __restr
   }
 }
 
+// ---- stand-alone transforms on the wave-level FFT (any hop; used by specinv_stft and the L_BFGS objective) ----
+// windowed frame starting at signal index `start` (may reach into the reflect padding) -> registers
+template <int R>
+__device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, long long len, long long start, int lane,
+                                                const v2f* __restrict__ lds_win, v2f (&z)[R]) {
+  constexpr int N = Geo<R>::N;
+  if (start >= 0 && start + N <= len && (start & 1) == 0) {
+    const v2f* src = reinterpret_cast<const v2f*>(xrow + start);
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = src[64u * u + (unsigned)lane];
+  } else {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      long long n0 = start + 128 * u + 2 * lane, n1 = n0 + 1;
+      n0 = n0 < 0 ? -n0 : (n0 >= len ? 2 * (len - 1) - n0 : n0);
+      n1 = n1 < 0 ? -n1 : (n1 >= len ? 2 * (len - 1) - n1 : n1);
+      z[u] = v2f{xrow[n0], xrow[n1]};
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+}
+
+struct FastXformArgs {
+  const float* x;        // (B, len)
+  v2f* spec;             // (B*T, F) frame-major, natural bin order
+  float* frames;         // (B*T, N)
+  const float* window;
+  long long len, n_frames_total;
+  int T, hop, pad;
+  float scale;
+};
+
+template <int R>
+__device__ __forceinline__ void xform_tables(const float* __restrict__ window, v2f* lds_win, v2f* lds_tw1) {
+  constexpr int M = Geo<R>::M;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{window[2 * i], window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
+  }
+  __syncthreads();
+}
+
+// torch.stft (center, reflect, onesided): one wave per frame, spectrum written in natural bin order
+// (register j of lane l is bin l + 64 j: every store instruction covers 64 consecutive bins)
+template <int R>
+__global__ __launch_bounds__(256) void k_fast_stft(FastXformArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, M = G::M;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  for (long long fi = (long long)blockIdx.x * 4 + wib; fi < a.n_frames_total; fi += (long long)gridDim.x * 4) {
+    const long long b = fi / a.T;
+    const int t = (int)(fi - b * a.T);
+    v2f z[R];
+    load_frame_regs<R>(a.x + b * a.len, a.len, (long long)t * a.hop - a.pad, lane, lds_win, z);
+    fft_forward<R>(z, k, lds_tw1, tr);
+    v2f rc[H];
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+    v2f* out = a.spec + fi * (M + 1);
+    const float hs = 0.5f * a.scale;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f zk = z[j], zm = rc[R - 1 - j - H];
+      const v2f e2 = add_conj(zk, zm);
+      const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
+      const int kk = lane + 64 * j;
+      out[kk] = (e2 + tw) * hs;
+      out[M - kk] = (e2 - tw) * v2f{hs, -hs};
+    }
+    if (lane == 0) out[M / 2] = z[H] * v2f{a.scale, -a.scale};
+  }
+}
+
+// frames[n] = window[n] * scale * Re sum_k Xfull[k] e^{+2 pi i k n / N} for the Hermitian extension Xfull of the
+// stored onesided spectrum (imaginary parts of DC / Nyquist ignored): the synthesis half of an ISTFT and the
+// adjoint of the STFT (L_BFGS gradient).  Natural bin order in, one wave per frame.
+template <int R>
+__global__ __launch_bounds__(256) void k_fast_inverse_frames(FastXformArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, M = G::M;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  for (long long fi = (long long)blockIdx.x * 4 + wib; fi < a.n_frames_total; fi += (long long)gridDim.x * 4) {
+    const v2f* in = a.spec + fi * (M + 1);
+    v2f z[R], back[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const int kk = lane + 64 * j;
+      v2f ak = in[kk] * a.scale, am = in[M - kk] * a.scale;
+      if (j == 0 && lane == 0) {
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    v2f zmid = v2f{0.0f, 0.0f};
+    if (lane == 0) zmid = in[M / 2] * v2f{2.0f * a.scale, -2.0f * a.scale};
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+    fft_inverse<R>(z, k, lds_tw1, tr);
+    v2f* out = reinterpret_cast<v2f*>(a.frames + fi * (2 * M));
+#pragma unroll
+    for (int u = 0; u < R; ++u) out[64u * u + (unsigned)lane] = z[u] * lds_win[64 * u + lane];
+  }
+}
+
 // x += the tail partial sums (final waveform for get_wave)
 template <int R>
 __global__ void k_add_tails(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, long long L,
@@ -981,8 +1115,11 @@ struct FastBuf {
 template <typename T>
 struct FastState {
   bool supported = false;
+  bool xform_ok = false;
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
+  template <typename P>
+  int launch_xform(P&, bool, const T*, long long, void*, T*, T) { return fail(SPECINV_EUNSUPPORTED, "no fused path"); }
   template <typename P>
   int begin(P&, int, const void*, const void*, double*) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
   template <typename P>
@@ -1006,7 +1143,15 @@ struct FastState<float> {
 
   int setup(const specinv_stft_cfg& cfg, const std::vector<float>&, int64_t length, int pad) {
     supported = false;
+    xform_ok = false;
     if (cfg.dtype != SPECINV_F32 || !cfg.onesided || !cfg.center || cfg.pad_mode != SPECINV_PAD_REFLECT) return SPECINV_OK;
+    if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
+      if (e[0] == '1') return SPECINV_OK;
+    }
+    if (cfg.n_fft == 2048 || cfg.n_fft == 1024) {
+      xform_ok = true;
+      xform_R = cfg.n_fft / 128;
+    }
     if (cfg.hop_length * 4 != cfg.n_fft) return SPECINV_OK;
     if (cfg.n_fft == 2048) R = 16;
     else if (cfg.n_fft == 1024) R = 8;
@@ -1102,6 +1247,34 @@ struct FastState<float> {
     const v2f* s = static_cast<const v2f*>(spec_user);
     const float* m = static_cast<const float*>(mag_user);
     return R == 16 ? begin_t<16>(pl, md, s, m, sum_m2_out) : begin_t<8>(pl, md, s, m, sum_m2_out);
+  }
+
+  // wave-level FFT usable for stand-alone transforms of this plan (any hop / frame count)
+  bool xform_ok = false;
+  int xform_R = 0;
+
+  template <typename P>
+  int launch_xform(P& pl, bool forward, const float* x, long long len, fast::v2f* spec, float* frames, float scale) {
+    fast::FastXformArgs a{};
+    a.x = x;
+    a.spec = spec;
+    a.frames = frames;
+    a.window = pl.window.template as<float>();
+    a.len = len;
+    a.n_frames_total = (long long)pl.B() * pl.Tn();
+    a.T = pl.Tn();
+    a.hop = pl.cfg.hop_length;
+    a.pad = pl.pad;
+    a.scale = scale;
+    const size_t lds = xform_R == 16 ? fast::Geo<16>::lds_bytes(4) : fast::Geo<8>::lds_bytes(4);
+    const unsigned grid = (unsigned)std::min<long long>((a.n_frames_total + 3) / 4, 256 * 12);
+    const void* fn;
+    if (xform_R == 16) fn = forward ? (const void*)fast::k_fast_stft<16> : (const void*)fast::k_fast_inverse_frames<16>;
+    else fn = forward ? (const void*)fast::k_fast_stft<8> : (const void*)fast::k_fast_inverse_frames<8>;
+    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* kargs[] = {&a};
+    SI_HIP(hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, pl.stream));
+    return SPECINV_OK;
   }
 
   template <int RR, int MODE, bool EVAL, typename P>

@@ -539,11 +539,7 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
   SI_HIP(hipGetLastError());
   // frames of the gradient: irfft-style inverse with the forward scale
   SI_TRY(pl.frames_needed());
-  FrameCfg<T> c = pl.frame_cfg(len);
-  c.inv_scale = pl.fc.fwd_scale;
-  hipLaunchKernelGGL((k_grad_frames<T>), dim3(pl.Tn(), pl.B()), dim3(256), pl.lds_bytes, pl.stream, c,
-                     pl.tf_spec.template as<C>(), pl.frames.template as<T>());
-  SI_HIP(hipGetLastError());
+  SI_TRY(pl.inverse_frames(pl.tf_spec.template as<C>(), pl.frames.template as<T>(), pl.fc.fwd_scale, len));
   const int64_t total = (int64_t)pl.B() * len;
   hipLaunchKernelGGL((k_grad_fold<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, pl.frames.template as<T>(),
                      grad, pl.N(), pl.cfg.hop_length, pl.pad, pl.cfg.pad_mode, pl.Tn(), len, total);

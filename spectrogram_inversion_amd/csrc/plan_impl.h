@@ -3,6 +3,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "kernels_fast.h"
@@ -187,9 +188,7 @@ struct PlanT final : PlanBase {
   // internal-layout spectrum -> x
   int istft_internal(const C* spec_btf, T* out) {
     SI_TRY(frames_needed());
-    hipLaunchKernelGGL((k_istft_frames<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, frame_cfg(length), spec_btf,
-                       frames.as<T>());
-    SI_HIP(hipGetLastError());
+    SI_TRY(inverse_frames(spec_btf, frames.as<T>(), fc.inv_scale, length));
     return launch_ola(frames.as<T>(), out, true);
   }
 
@@ -199,7 +198,26 @@ struct PlanT final : PlanBase {
              "signal length %lld gives %lld frames, plan has %d", (long long)len, (long long)tcheck, Tn());
     if (cfg.center && cfg.pad_mode == SPECINV_PAD_REFLECT)
       SI_CHECK(pad < len, SPECINV_EINVAL, "reflect padding needs n_fft/2 < length");
+    if constexpr (std::is_same<T, float>::value) {
+      if (fast.xform_ok && !force_generic)
+        return fast.launch_xform(*this, true, xin, (long long)len, reinterpret_cast<fast::v2f*>(spec_btf), nullptr,
+                                 fc.fwd_scale);
+    }
     hipLaunchKernelGGL((k_stft<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, frame_cfg(len), xin, spec_btf);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  // frames[b,t,:] = window * scale * (Hermitian inverse DFT sum of spec[b,t,:]); scale = 1/N gives _istft's frames
+  int inverse_frames(const C* spec_btf, T* fr, T scale, int64_t len) {
+    if constexpr (std::is_same<T, float>::value) {
+      if (fast.xform_ok && !force_generic)
+        return fast.launch_xform(*this, false, nullptr, (long long)len,
+                                 const_cast<fast::v2f*>(reinterpret_cast<const fast::v2f*>(spec_btf)), fr, scale);
+    }
+    FrameCfg<T> c = frame_cfg(len);
+    c.inv_scale = scale;
+    hipLaunchKernelGGL((k_grad_frames<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, c, spec_btf, fr);
     SI_HIP(hipGetLastError());
     return SPECINV_OK;
   }

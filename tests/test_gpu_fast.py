@@ -166,3 +166,46 @@ def test_full_size_properties():
     err_gen = rel_l2(res["gen"][0], res["f64"][0])
     assert err_fast < max(2.0 * err_gen, 1e-5), (err_fast, err_gen)
     assert np.abs(res["fast"][1] - res["f64"][1]).max() < 1e-5      # |dSC_lin| <= 1e-5 (north-star bar)
+
+
+@pytest.mark.parametrize("n_fft,hop,length", [(1024, 300, 9000), (2048, 512, 7 * 512), (2048, 333, 12000), (1024, 256, 2560)])
+def test_fast_standalone_transforms(n_fft, hop, length):
+    """specinv_stft / specinv_istft on the wave-level FFT (any hop) against the oracle and the generic kernels."""
+    rng = np.random.default_rng(n_fft + hop)
+    x = rng.standard_normal((3, length)).astype(np.float32)
+    w = hann(n_fft)
+    a = oracle.args_helper(n_fft // 2 + 1, np.float32, hop_length=hop, window=w)
+    frames = oracle.frame_count(length, a)
+    ta = args_helper(torch.empty(1, n_fft // 2 + 1, 1), hop_length=hop, window=torch.from_numpy(w))
+    fast = Plan(ta, 3, frames, torch.float32, dev())
+    gen = Plan(ta, 3, frames, torch.float32, dev())
+    gen.force_generic(True)
+    ref = oracle.stft(x, a)
+    s_fast, s_gen = N(fast.stft(T(x))), N(gen.stft(T(x)))
+    assert rel_l2(s_fast, ref) < 2e-6 and rel_l2(s_gen, ref) < 2e-6
+    spec = (rng.standard_normal(ref.shape) + 1j * rng.standard_normal(ref.shape)).astype(np.complex64)
+    y_ref, env = oracle.istft(spec, a)
+    for p in (fast, gen):
+        y = N(p.istft(T(spec)))
+        assert rel_l2(y * env, y_ref * env) < 3e-6
+
+
+def test_fast_logmel_gradient_vs_autograd_f32():
+    import spectrogram_inversion_amd as si
+    torch.manual_seed(5)
+    x = 0.1 * torch.randn(2, 20 * 512, device=dev())
+    fb = torch.from_numpy(si.mel_filterbank(22050, 2048, 80)).to(dev())
+    win = torch.hann_window(2048, device=dev())
+
+    def fn(v):
+        return torch.log1p(torch.matmul(fb, torch.stft(v, 2048, hop_length=512, window=win, return_complex=True).abs()))
+
+    target = fn(x + 0.05 * torch.randn_like(x))
+    xt = x.clone().requires_grad_(True)
+    loss_ref = torch.nn.functional.mse_loss(fn(xt), target)
+    (g_ref,) = torch.autograd.grad(loss_ref, xt)
+    tr = si.LogMelSTFT(fb, 2048, hop_length=512, window=win)
+    _, fg = tr.bind(x, target)
+    loss, grad = fg(x)
+    assert abs(loss - loss_ref.item()) < 2e-5 * loss_ref.item()
+    assert rel_l2(N(grad), N(g_ref)) < 2e-5
