@@ -280,6 +280,9 @@ struct PlanT final : PlanBase {
   // x = ISTFT(start) (methods.py:233 / :453)
   int init_common(const void* init_spec, const void* magp, int fast_mode) {
     SI_CHECK(init_spec || magp, SPECINV_EINVAL, "need init_spec and/or mag");
+    // torch.stft refuses reflect padding that is not smaller than the signal (methods.py:241 would raise)
+    SI_CHECK(!(cfg.center && cfg.pad_mode == SPECINV_PAD_REFLECT && pad >= length), SPECINV_EINVAL,
+             "reflect padding (%d) must be smaller than the signal length (%lld): too few frames", pad, (long long)length);
     const int64_t ns = nspec();
     count = (double)ns;
     const C* start_user = static_cast<const C*>(init_spec);

@@ -114,3 +114,13 @@ def test_state_errors():
         plan.iterate(1)                                      # iterate before init: SPECINV_ESTATE
     with pytest.raises(AssertionError):
         plan.stft(torch.zeros(1, 100, device=DEV))           # wrong length for the plan's frame count
+
+
+def test_too_short_for_reflect_padding_is_rejected():
+    """2 frames of n_fft 512 / hop 128 give a 128-sample signal: torch.stft refuses to reflect-pad it by 256
+    (the reference raises inside its first closure call); the plan refuses it up front."""
+    mag = torch.rand(1, 257, 2, device=DEV)
+    with pytest.raises(AssertionError, match="reflect padding"):
+        si.griffin_lim(mag, max_iter=2, verbose=False, hop_length=128)
+    y = si.griffin_lim(mag, max_iter=2, verbose=False, hop_length=128, pad_mode="constant")   # other pad modes are fine
+    assert y.shape == (1, 128)
