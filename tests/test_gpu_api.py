@@ -52,7 +52,7 @@ def test_path_selection_at_the_edges():
                     torch.device(DEV)).fast_path
 
 
-@pytest.mark.parametrize("frames", [3, 5])
+@pytest.mark.parametrize("frames", [4, 5])
 def test_short_signals_use_generic_kernels(frames):
     rng = np.random.default_rng(frames)
     mag = rng.random((2, 1025, frames), dtype=np.float32)
