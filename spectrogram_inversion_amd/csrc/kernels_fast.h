@@ -34,11 +34,14 @@
 #ifndef SPECINV_XPREF      // 0: load the frame when it starts; 1: carry the samples in registers and prefetch one
 #define SPECINV_XPREF 1    //    hop-block ahead (measured best: 0.336 vs 0.352 ms on C2); 2: fetch the whole next
 #endif                     //    frame after the spectral update so that it flies during the inverse FFT
-#ifndef SPECINV_PLATE      // 0: issue the state loads at the start of the frame; 1: after the forward FFT
-#define SPECINV_PLATE 0
+#ifndef SPECINV_PLATE      // 0: issue the state loads at the start of the frame; 1: after the forward FFT;
+#define SPECINV_PLATE 0    // 2: one frame ahead, right after the previous frame's spectral update freed the registers
 #endif
 #ifndef SPECINV_TW_REGS    // 1: keep the pass-1 twiddles of the FFT in registers instead of re-reading the LDS table
 #define SPECINV_TW_REGS 1   // measured on C2: 0.313 vs 0.318 ms
+#endif
+#ifndef SPECINV_ABLATE     // timing experiments (WRONG RESULTS): 1 no state stores, 2 no state loads, 4 no FFTs
+#define SPECINV_ABLATE 0
 #endif
 #ifndef SPECINV_MINWAVES   // __launch_bounds__ waves per SIMD (caps the register allocation)
 #define SPECINV_MINWAVES 2
@@ -492,8 +495,20 @@ __device__ __forceinline__ void load_block(const float* __restrict__ xrow, const
   }
 }
 
-__device__ __forceinline__ v4f ld_stream(const v4f* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void st_stream(v4f* p, v4f v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ v4f ld_stream(const v4f* p) {
+#if SPECINV_ABLATE & 2
+  return v4f{1.0f, 0.5f, 0.25f, 2.0f} * (float)(((unsigned long long)p >> 4) & 7);
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ void st_stream(v4f* p, v4f v) {
+#if SPECINV_ABLATE & 1
+  if (v.x == 1.2345e30f) __builtin_nontemporal_store(v, p);   // keeps the value alive, (almost) never stores
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
 
 template <int R, int MODE, bool EVAL>
 __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
@@ -557,6 +572,31 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
   load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 3, lane, xn);
 #endif
 
+  // state of frame `FI`: uniform bases (SGPR) + unsigned 32-bit lane offsets -> "saddr + voffset" addressing
+#define SPECINV_STATE_LOADS(FI)                                                            \
+  do {                                                                                     \
+    const long long fl_ = (FI);                                                            \
+    const v4f* pin_ = a.P_in + fl_ * (H * 64);                                             \
+    const v4f* min_ = a.m_pairs + fl_ * (H / 2 * 64);                                      \
+    _Pragma("unroll") for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin_[j * 64u + ulane]); \
+    if (MODE == MODE_ADMM) {                                                               \
+      const v4f* uin_ = a.U_in + fl_ * (H * 64);                                           \
+      _Pragma("unroll") for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin_[j * 64u + ulane]); \
+    }                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]); \
+    if (lane == 0) {                                                                       \
+      pmid = a.Pmid_in[fl_];                                                               \
+      mmid = a.m_mid[fl_];                                                                 \
+      if (MODE == MODE_ADMM) umid = a.Umid_in[fl_];                                        \
+    }                                                                                      \
+  } while (0)
+#if SPECINV_PLATE == 2
+  v4f pp[H], uu[H], mm[H / 2];
+  v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
+  float mmid = 0.0f;
+  SPECINV_STATE_LOADS((long long)b * a.T + t_start);
+#endif
+
   for (int t = t_start; t < t_end; ++t) {
     // Keep the loop-invariant table reads (window, twiddles) and products inside the loop: hoisted out
     // of it they pin ~80 VGPRs for the whole kernel and cost a wave of occupancy.
@@ -565,31 +605,15 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
     asm volatile("" : "+v"(wn));
     constexpr bool live = true;
     const long long fi = (long long)b * a.T + t;
-
+    v4f* pout = a.P_out + fi * (H * 64);
+    v4f* uout = MODE == MODE_ADMM ? a.U_out + fi * (H * 64) : nullptr;
+#if SPECINV_PLATE != 2
     v4f pp[H], uu[H], mm[H / 2];
     v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
     float mmid = 0.0f;
-    // per-frame uniform bases (SGPR) + unsigned 32-bit lane offsets -> "saddr + voffset" addressing
-    const v4f* pin = a.P_in + fi * (H * 64);
-    const v4f* uin = MODE == MODE_ADMM ? a.U_in + fi * (H * 64) : nullptr;
-    const v4f* min_ = a.m_pairs + fi * (H / 2 * 64);
-    v4f* pout = a.P_out + fi * (H * 64);
-    v4f* uout = MODE == MODE_ADMM ? a.U_out + fi * (H * 64) : nullptr;
-#define SPECINV_STATE_LOADS()                                                              \
-  do {                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin[j * 64u + ulane]); \
-    if (MODE == MODE_ADMM) {                                                               \
-      _Pragma("unroll") for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin[j * 64u + ulane]); \
-    }                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]); \
-    if (lane == 0) {                                                                       \
-      pmid = a.Pmid_in[fi];                                                                \
-      mmid = a.m_mid[fi];                                                                  \
-      if (MODE == MODE_ADMM) umid = a.Umid_in[fi];                                         \
-    }                                                                                      \
-  } while (0)
-#if !SPECINV_PLATE
-    SPECINV_STATE_LOADS();   // early: the loads fly during the forward FFT
+#endif
+#if SPECINV_PLATE == 0
+    SPECINV_STATE_LOADS(fi);   // early: the loads fly during the forward FFT
 #endif
 
     // ---- analysis: windowed frame -> registers
@@ -624,13 +648,14 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
     }
 #endif
 
-#if SPECINV_TW_REGS
+#if SPECINV_ABLATE & 4
+#elif SPECINV_TW_REGS
     fft_forward_t<R>(z, k, twr, tr);
 #else
     fft_forward<R>(z, k, lds_tw1, tr);
 #endif
-#if SPECINV_PLATE
-    SPECINV_STATE_LOADS();
+#if SPECINV_PLATE == 1
+    SPECINV_STATE_LOADS(fi);
 #endif
 
     // ---- conjugate partners: upper half of lane (64 - r)
@@ -698,6 +723,11 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
       const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
       z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
     }
+#if SPECINV_PLATE == 2
+    // the state registers are free again: fetch the next frame's state now, it flies through the inverse FFT,
+    // the overlap-add and the next forward FFT
+    if (t + 1 < t_end) SPECINV_STATE_LOADS(fi + 1);
+#endif
 
 #if SPECINV_XPREF == 2
     if (t + 1 < t_end) {
@@ -711,7 +741,8 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
     }
 #endif
 
-#if SPECINV_TW_REGS
+#if SPECINV_ABLATE & 4
+#elif SPECINV_TW_REGS
     fft_inverse_t<R>(z, k, twr, tr);
 #else
     asm volatile("" ::: "memory");   // re-read the twiddles instead of keeping them live since the forward FFT
