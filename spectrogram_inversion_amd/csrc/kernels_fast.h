@@ -405,7 +405,7 @@ struct FastArgs {
   const float* window;   // N
   const float* inv_env;  // L, 1 / envelope
   double* partials;      // [n_waves][2]
-  int T, chunk, nchunks, n_waves;
+  int T, chunk, nchunks, n_waves, pad_mode;
   long long L;
   float coef;       // lr (GLA) or rho (ADMM)
   float inv1p;      // 1/(1+rho)
@@ -448,6 +448,21 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const 
   }
 }
 
+// signal index of padded position n (n < 0 or n >= L) for torch.stft's pad modes; -1 = zero (constant padding)
+__device__ __forceinline__ long long pad_index(long long n, long long L, int pad_mode) {
+  if (n >= 0 && n < L) return n;
+  switch (pad_mode) {
+    case SPECINV_PAD_REFLECT:
+      return n < 0 ? -n : 2 * (L - 1) - n;
+    case SPECINV_PAD_REPLICATE:
+      return n < 0 ? 0 : L - 1;
+    case SPECINV_PAD_CIRCULAR:
+      return n < 0 ? n + L : n - L;
+    default:
+      return -1;
+  }
+}
+
 // Frames [chunk_begin(c), chunk_begin(c+1)) belong to wave-chunk c; sizes differ by at most one frame.
 __device__ __host__ __forceinline__ int chunk_begin(int c, int T, int nchunks) {
   return (int)(((unsigned)c * (unsigned)T) / (unsigned)nchunks);   // c * T < 2^32 for any plan that fits in memory
@@ -462,7 +477,7 @@ __device__ __host__ __forceinline__ int chunk_begin(int c, int T, int nchunks) {
 template <int R>
 __device__ __forceinline__ void load_block(const float* __restrict__ xrow, const float* __restrict__ tailrow,
                                            long long L, int T, int c, int t_begin, int t_end, int j, int lane,
-                                           v2f (&q)[R / 4]) {
+                                           int pad_mode, v2f (&q)[R / 4]) {
   constexpr int HOP = Geo<R>::HOP;
   const long long s0 = (long long)(j - 2) * HOP;
   if (j >= 2 && j <= T) {
@@ -487,10 +502,9 @@ __device__ __forceinline__ void load_block(const float* __restrict__ xrow, const
   } else {
 #pragma unroll
     for (int i = 0; i < R / 4; ++i) {
-      long long n0 = s0 + 128 * i + 2 * lane, n1 = n0 + 1;
-      n0 = n0 < 0 ? -n0 : (n0 >= L ? 2 * (L - 1) - n0 : n0);
-      n1 = n1 < 0 ? -n1 : (n1 >= L ? 2 * (L - 1) - n1 : n1);
-      q[i] = v2f{xrow[(unsigned)n0], xrow[(unsigned)n1]};
+      const long long n0 = pad_index(s0 + 128 * i + 2 * lane, L, pad_mode);
+      const long long n1 = pad_index(s0 + 128 * i + 2 * lane + 1, L, pad_mode);
+      q[i] = v2f{n0 < 0 ? 0.0f : xrow[(unsigned)n0], n1 < 0 ? 0.0f : xrow[(unsigned)n1]};
     }
   }
 }
@@ -560,16 +574,16 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     v2f q[QU];
-    load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + qq, lane, q);
+    load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + qq, lane, a.pad_mode, q);
 #pragma unroll
     for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
   }
 #elif SPECINV_XPREF == 1
   v2f xq[3][QU], xn[QU];
-  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start, lane, xq[0]);
-  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 1, lane, xq[1]);
-  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 2, lane, xq[2]);
-  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 3, lane, xn);
+  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start, lane, a.pad_mode, xq[0]);
+  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 1, lane, a.pad_mode, xq[1]);
+  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 2, lane, a.pad_mode, xq[2]);
+  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 3, lane, a.pad_mode, xn);
 #endif
 
   // state of frame `FI`: uniform bases (SGPR) + unsigned 32-bit lane offsets -> "saddr + voffset" addressing
@@ -633,13 +647,13 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
       xq[1][i] = xq[2][i];
       xq[2][i] = xn[i];
     }
-    if (t + 1 < t_end) load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 4, lane, xn);
+    if (t + 1 < t_end) load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 4, lane, a.pad_mode, xn);
 #else
     {
       v2f q[QU];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, q);
+        load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, a.pad_mode, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) z[qq * QU + i] = q[i];
       }
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         v2f q[QU];
-        load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 1 + qq, lane, q);
+        load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 1 + qq, lane, a.pad_mode, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
       }
@@ -957,7 +971,7 @@ __global__ void k_user_mag_to_pairs(const float* __restrict__ in, float* __restr
 // windowed frame starting at signal index `start` (may reach into the reflect padding) -> registers
 template <int R>
 __device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, long long len, long long start, int lane,
-                                                const v2f* __restrict__ lds_win, v2f (&z)[R]) {
+                                                int pad_mode, const v2f* __restrict__ lds_win, v2f (&z)[R]) {
   constexpr int N = Geo<R>::N;
   if (start >= 0 && start + N <= len && (start & 1) == 0) {
     const v2f* src = reinterpret_cast<const v2f*>(xrow + start);
@@ -966,10 +980,9 @@ __device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, 
   } else {
 #pragma unroll
     for (int u = 0; u < R; ++u) {
-      long long n0 = start + 128 * u + 2 * lane, n1 = n0 + 1;
-      n0 = n0 < 0 ? -n0 : (n0 >= len ? 2 * (len - 1) - n0 : n0);
-      n1 = n1 < 0 ? -n1 : (n1 >= len ? 2 * (len - 1) - n1 : n1);
-      z[u] = v2f{xrow[n0], xrow[n1]};
+      const long long n0 = pad_index(start + 128 * u + 2 * lane, len, pad_mode);
+      const long long n1 = pad_index(start + 128 * u + 2 * lane + 1, len, pad_mode);
+      z[u] = v2f{n0 < 0 ? 0.0f : xrow[n0], n1 < 0 ? 0.0f : xrow[n1]};
     }
   }
 #pragma unroll
@@ -982,7 +995,7 @@ struct FastXformArgs {
   float* frames;         // (B*T, N)
   const float* window;
   long long len, n_frames_total;
-  int T, hop, pad;
+  int T, hop, pad, pad_mode;
   float scale;
 };
 
@@ -1015,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_fast_stft(FastXformArgs a) {
     const long long b = fi / a.T;
     const int t = (int)(fi - b * a.T);
     v2f z[R];
-    load_frame_regs<R>(a.x + b * a.len, a.len, (long long)t * a.hop - a.pad, lane, lds_win, z);
+    load_frame_regs<R>(a.x + b * a.len, a.len, (long long)t * a.hop - a.pad, lane, a.pad_mode, lds_win, z);
     fft_forward<R>(z, k, lds_tw1, tr);
     v2f rc[H];
 #pragma unroll
@@ -1217,19 +1230,19 @@ struct FastState<float> {
   int setup(const specinv_stft_cfg& cfg, const std::vector<float>&, int64_t length, int pad) {
     supported = false;
     xform_ok = false;
-    if (cfg.dtype != SPECINV_F32 || !cfg.onesided || !cfg.center || cfg.pad_mode != SPECINV_PAD_REFLECT) return SPECINV_OK;
+    if (cfg.dtype != SPECINV_F32 || !cfg.onesided) return SPECINV_OK;
     if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
       if (e[0] == '1') return SPECINV_OK;
     }
     if (cfg.n_fft == 2048 || cfg.n_fft == 1024) {
-      xform_ok = true;
+      xform_ok = true;              // any hop, any pad mode, centred or not
       xform_R = cfg.n_fft / 128;
     }
-    if (cfg.hop_length * 4 != cfg.n_fft) return SPECINV_OK;
+    if (!cfg.center || cfg.hop_length * 4 != cfg.n_fft) return SPECINV_OK;
     if (cfg.n_fft == 2048) R = 16;
     else if (cfg.n_fft == 1024) R = 8;
     else return SPECINV_OK;
-    if (cfg.n_frames < 6 || pad >= length) return SPECINV_OK;
+    if (cfg.n_frames < 6 || pad >= length) return SPECINV_OK;   // (pad >= length is refused later for reflect)
     if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
       if (e[0] == '1') return SPECINV_OK;
     }
@@ -1338,6 +1351,7 @@ struct FastState<float> {
     a.T = pl.Tn();
     a.hop = pl.cfg.hop_length;
     a.pad = pl.pad;
+    a.pad_mode = pl.cfg.pad_mode;
     a.scale = scale;
     const size_t lds = xform_R == 16 ? fast::Geo<16>::lds_bytes(4) : fast::Geo<8>::lds_bytes(4);
     const unsigned grid = (unsigned)std::min<long long>((a.n_frames_total + 3) / 4, 256 * 12);
@@ -1393,6 +1407,7 @@ struct FastState<float> {
       a.chunk = chunk;
       a.nchunks = nchunks;
       a.n_waves = n_waves;
+      a.pad_mode = pl.cfg.pad_mode;
       a.L = pl.length;
       a.coef = pl.coef;
       a.inv1p = 1.0f / (float)(1.0 + (double)pl.coef);

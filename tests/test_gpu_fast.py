@@ -209,3 +209,35 @@ def test_fast_logmel_gradient_vs_autograd_f32():
     loss, grad = fg(x)
     assert abs(loss - loss_ref.item()) < 2e-5 * loss_ref.item()
     assert rel_l2(N(grad), N(g_ref)) < 2e-5
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "replicate", "circular"])
+@pytest.mark.parametrize("n_fft,hop,frames", [(1024, 256, 21), (2048, 512, 9)])
+def test_fused_path_other_pad_modes(pad_mode, n_fft, hop, frames):
+    rng = np.random.default_rng(frames)
+    mag = rng.random((2, n_fft // 2 + 1, frames), dtype=np.float32)
+    w = hann(n_fft)
+    ref = oracle.griffin_lim(mag, max_iter=6, alpha=0.3, tol=0, hop_length=hop, window=w, pad_mode=pad_mode)
+    a = args_helper(torch.empty(1, n_fft // 2 + 1, 1), hop_length=hop, window=torch.from_numpy(w), pad_mode=pad_mode)
+    plan = Plan(a, 2, frames, torch.float32, dev())
+    assert plan.fast_path
+    plan.gla_init(None, T(mag), 0.3)
+    plan.iterate(6)
+    assert rel_l2(N(plan.wave()), ref) < 1e-4
+    # the stand-alone STFT on the wave-level FFT honours the pad mode too
+    x = rng.standard_normal((2, plan.length)).astype(np.float32)
+    oa = oracle.args_helper(n_fft // 2 + 1, np.float32, hop_length=hop, window=w, pad_mode=pad_mode)
+    assert rel_l2(N(plan.stft(T(x))), oracle.stft(x, oa)) < 2e-6
+
+
+def test_fast_transform_without_centering():
+    rng = np.random.default_rng(77)
+    n_fft, hop = 1024, 200
+    x = rng.standard_normal((2, 6000)).astype(np.float32)
+    w = hann(n_fft)
+    oa = oracle.args_helper(n_fft // 2 + 1, np.float32, hop_length=hop, window=w, center=False)
+    frames = oracle.frame_count(6000, oa)
+    a = args_helper(torch.empty(1, n_fft // 2 + 1, 1), hop_length=hop, window=torch.from_numpy(w), center=False)
+    plan = Plan(a, 2, frames, torch.float32, dev())
+    assert not plan.fast_path                      # fused iteration needs centring; the transform does not
+    assert rel_l2(N(plan.stft(T(x))), oracle.stft(x, oa)) < 2e-6
