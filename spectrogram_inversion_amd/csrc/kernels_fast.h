@@ -1,14 +1,15 @@
 // Fused gfx950 fast path: one Griffin-Lim / ADMM iteration = ONE kernel launch.
 //
-// Mapping (n_fft = N = 128*R, hop = N/4, float32, onesided, center + reflect):
+// Mapping (n_fft = N = 128*R with R in {8, 16}, hop = N/4, float32, onesided, centred, any pad mode):
 //   * one 64-lane wave owns one frame at a time and walks a chunk of consecutive frames of one
 //     batch item; nothing is shared between waves except read-only tables, so the frame loop
 //     has no workgroup barrier.
 //   * the N real samples are packed as M = N/2 = 64*R complex points, R per lane
 //     (lane l, register u  <->  z[64u + l] = x[128u + 2l] + i x[128u + 2l + 1], a coalesced
 //     512-byte row per load instruction).  The M-point FFT runs as
-//         in-register radix-R  ->  cross-lane radix-(64/R) butterflies  ->  RxR transpose
-//         through wave-private LDS  ->  in-register radix-R,
+//         in-register radix-R  ->  cross-lane radix-(64/R) butterflies on the gfx950 lane-swap
+//         instructions (v_permlane32_swap / v_permlane16_swap)  ->  RxR transpose through
+//         wave-private LDS  ->  in-register radix-R,
 //     which leaves bin k in lane k mod 64, register k div 64.
 //   * real-FFT split: lane r trades its upper R/2 registers with lane 64-r (ds_bpermute), after
 //     which every lane holds R/2 conjugate pairs (k, M-k).  The spectral state (pre_spec / X, U /
@@ -20,7 +21,9 @@
 //   * overlap-add is done in registers: with hop = N/4 a lane's R registers split into 4
 //     quarters that land on 4 consecutive hop-blocks; three quarter-accumulators are carried
 //     from frame to frame and one finished hop-block is normalised by the envelope and stored
-//     per frame.  A chunk starts by recomputing the 3 frames before it (read-only halo).
+//     per frame.  No halo: the first three hop-blocks of a chunk are stored as two partial sums
+//     (own frames in x, the previous chunk's last three frames in xtail) that the next
+//     iteration's loader adds.
 //   Algorithmic HBM traffic per frame-iteration: 8*hop + 20*F bytes (GLA), 8*hop + 36*F (ADMM).
 #pragma once
 #include <algorithm>
@@ -30,7 +33,7 @@
 #include "common.h"
 #include "kernels_generic.h"
 
-// build-time tunables of the fused kernel (see tools/sweep_variants.sh)
+// build-time tunables of the fused kernel (tools/sweep_variants.py builds variants, tools/run_variants.sh times them)
 #ifndef SPECINV_XPREF      // 0: load the frame when it starts; 1: carry the samples in registers and prefetch one
 #define SPECINV_XPREF 1    //    hop-block ahead (measured best: 0.336 vs 0.352 ms on C2); 2: fetch the whole next
 #endif                     //    frame after the spectral update so that it flies during the inverse FFT
@@ -405,7 +408,7 @@ struct FastArgs {
   const float* window;   // N
   const float* inv_env;  // L, 1 / envelope
   double* partials;      // [n_waves][2]
-  int T, chunk, nchunks, n_waves, pad_mode;
+  int T, nchunks, n_waves, pad_mode;
   long long L;
   float coef;       // lr (GLA) or rho (ADMM)
   float inv1p;      // 1/(1+rho)
@@ -1314,7 +1317,6 @@ struct FastState<float> {
     a.window = pl.window.template as<float>();
     a.inv_env = inv_env.template as<float>();
     a.T = pl.Tn();
-    a.chunk = chunk;
     a.nchunks = nchunks;
     a.n_waves = n_waves;
     a.L = pl.length;
@@ -1404,8 +1406,7 @@ struct FastState<float> {
       a.inv_env = inv_env.template as<float>();
       a.partials = pl.partials.template as<double>();
       a.T = pl.Tn();
-      a.chunk = chunk;
-      a.nchunks = nchunks;
+        a.nchunks = nchunks;
       a.n_waves = n_waves;
       a.pad_mode = pl.cfg.pad_mode;
       a.L = pl.length;

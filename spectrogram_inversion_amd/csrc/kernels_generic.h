@@ -151,19 +151,6 @@ __global__ void k_stft(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restri
   for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) out[f] = mk<T>(a[f].x * c.fwd_scale, a[f].y * c.fwd_scale);
 }
 
-// ---- inverse frames: spec (B, T, F) -> windowed frames (B, T, N) ---------------------------
-template <typename T>
-__global__ void k_istft_frames(FrameCfg<T> c, const cplx<T>* __restrict__ spec, T* __restrict__ frames) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* b = a + c.n_fft;
-  const int t = blockIdx.x, bi = blockIdx.y;
-  const cplx<T>* in = spec + ((int64_t)bi * c.n_frames + t) * c.n_freq;
-  for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) a[f] = in[f];
-  __syncthreads();
-  spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
-}
-
 // ---- overlap-add + envelope division (methods.py:127,132) ---------------------------------
 // x[b, n] = (sum_t frames[b, t, n + pad - t*hop]) / env[n], t ascending.
 template <typename T>

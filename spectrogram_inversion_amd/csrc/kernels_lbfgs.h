@@ -92,13 +92,6 @@ __global__ void k_scale(T alpha, const T* __restrict__ x, T* __restrict__ y, int
 }
 
 template <typename P, typename T>
-int lb_reduce_blocks(P& pl, int64_t n, int comps) {
-  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
-  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * comps, 3 * 1024) * sizeof(double)));
-  return nb;
-}
-
-template <typename P, typename T>
 int lb_dot(P& pl, const T* a, const T* b, int64_t n, double* out) {
   SI_CHECK(a && b && out && n > 0, SPECINV_EINVAL, "bad arguments");
   const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
@@ -391,7 +384,8 @@ __global__ void k_mel_backward_valu(cplx<T>* __restrict__ spec, const T* __restr
   spec[i] = mk<T>(s.x * g, s.y * g);
 }
 
-// gradient frames: inverse transform of G with the forward scale and the analysis window
+// inverse frames (generic): windowed Hermitian inverse transform of a (B, T, F) spectrum, scale = c.inv_scale.
+// Used by _istft (scale 1/N) and by the STFT adjoint of the L_BFGS gradient (scale = forward scale).
 template <typename T>
 __global__ void k_grad_frames(FrameCfg<T> c, const cplx<T>* __restrict__ g, T* __restrict__ frames) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
   for (int i = threadIdx.x; i < (nslots - 1) * M; i += blockDim.x) ring[i] = v2f{0.0f, 0.0f};
 
   // per-wave register tables (sample 128u + 2 lane, +1  <->  register u)
-  v2f wsyn[R], win0[R], win1[R], wout[QU];
+  v2f wsyn[R], win0[R], win1[R];
   {
     const v2f* ws = reinterpret_cast<const v2f*>(a.wsyn);
     const v2f* w = reinterpret_cast<const v2f*>(a.window);
@@ -78,7 +78,6 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
       win1[u] = w1[64u * u + ulane];
     }
   }
-  (void)wout;
 
   // ---- first frame (methods.py:353-358): irfft of the zero-phase first target frame into the newest slot
   const long long f0 = (long long)bi * a.T;

@@ -67,7 +67,7 @@ struct PlanT final : PlanBase {
   DevBuf rt_state;                      // RTISI per-item state
   DevBuf lb_scal;                       // device scalars of the L-BFGS two-loop recursion
   DevBuf eval_log;                      // per-evaluation sums of a run with deferred read-back
-  DevBuf tf_mel, tf_spec, tf_v, tf_dv;  // transform (L_BFGS) scratch
+  DevBuf tf_mel, tf_spec, tf_v;         // transform (L_BFGS) scratch
   std::vector<T> h_window;
   FrameCfg<T> fc{};
   size_t lds_bytes = 0;
@@ -144,7 +144,6 @@ struct PlanT final : PlanBase {
     if (lds_bytes > 48 * 1024) {
       const int lim = (int)lds_bytes;
       SI_HIP(hipFuncSetAttribute((const void*)k_stft<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_istft_frames<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       SI_HIP(hipFuncSetAttribute((const void*)k_gla_frame<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       SI_HIP(hipFuncSetAttribute((const void*)k_gla_frame<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       SI_HIP(hipFuncSetAttribute((const void*)k_admm_frame<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
