@@ -129,6 +129,21 @@ int specinv_get_wave(specinv_plan* plan, void* x_out);
 /* current pre_spec (GLA) or X (ADMM) as (B, F, T) complex - for state-parity tests */
 int specinv_get_state_spec(specinv_plan* plan, int which, void* spec_out);
 
+/* ---- differentiating griffin_lim w.r.t. the spectrogram (the reference's outputs are autograd-differentiable:
+ * test/test_griffin.py:54,65-66).  Element-wise pieces work on (B, F, T) arrays; "g*" are cotangents. ---------- */
+/* one closure call without the transforms, methods.py:243-247: S = R - lr*P ; Q = S*mag/(|S| + 1e-16) */
+int specinv_gla_update(specinv_plan* plan, const void* R, const void* P, const void* mag, double lr, void* S_out,
+                       void* Q_out);
+/* its adjoint: gR = gS, gP = -lr*gS, gmag += d/dmag, with gS = proj^T(gQ) + gP_next (gP_next may be NULL) */
+int specinv_gla_update_adjoint(specinv_plan* plan, const void* gQ, const void* gP_next, const void* S, const void* mag,
+                               double lr, void* gR_out, void* gP_out, void* gmag_accum);
+/* adjoint of specinv_istft: cotangent of x (B, L) -> cotangent of the spectrogram (B, F, T) complex */
+int specinv_istft_adjoint(specinv_plan* plan, const void* g_x, void* g_spec_out);
+/* adjoint of specinv_stft: cotangent of the spectrogram -> cotangent of x (B, length) */
+int specinv_stft_adjoint(specinv_plan* plan, const void* g_spec, int64_t length, void* g_x_out);
+/* adjoint of specinv_phase_init: gmag += d/dmag of <g_spec, phase_init(mag)> */
+int specinv_phase_init_adjoint(specinv_plan* plan, const void* mag, const void* g_spec, void* gmag_accum);
+
 /* ---- RTISI-LA (methods.py:273-412) ------------------------------------------------------ */
 int specinv_rtisi_run(specinv_plan* plan, const void* mag, int look_ahead, int asymmetric_window,
                       int max_iter, double alpha, void* x_out);

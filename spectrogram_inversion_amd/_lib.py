@@ -62,6 +62,11 @@ SIGNATURES = {
     "specinv_admm_run": (C.c_int, [_P, C.c_int, C.c_int, _D, C.c_int, C.POINTER(Eval), _IP, _IP, EVAL_CB, _P]),
     "specinv_get_wave": (C.c_int, [_P, _P]),
     "specinv_get_state_spec": (C.c_int, [_P, C.c_int, _P]),
+    "specinv_gla_update": (C.c_int, [_P, _P, _P, _P, _D, _P, _P]),
+    "specinv_gla_update_adjoint": (C.c_int, [_P, _P, _P, _P, _P, _D, _P, _P, _P]),
+    "specinv_istft_adjoint": (C.c_int, [_P, _P, _P]),
+    "specinv_stft_adjoint": (C.c_int, [_P, _P, _I64, _P]),
+    "specinv_phase_init_adjoint": (C.c_int, [_P, _P, _P, _P]),
     "specinv_rtisi_run": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _D, _P]),
     "specinv_transform_setup": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "specinv_transform_forward": (C.c_int, [_P, _P, _I64, _P]),

@@ -1208,7 +1208,7 @@ struct FastState {
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
   template <typename P>
-  int launch_xform(P&, bool, const T*, long long, void*, T*, T) { return fail(SPECINV_EUNSUPPORTED, "no fused path"); }
+  int launch_xform(P&, bool, const T*, long long, void*, T*, T, int = -1) { return fail(SPECINV_EUNSUPPORTED, "no fused path"); }
   template <typename P>
   int begin(P&, int, const void*, const void*, double*) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
   template <typename P>
@@ -1342,7 +1342,8 @@ struct FastState<float> {
   int xform_R = 0;
 
   template <typename P>
-  int launch_xform(P& pl, bool forward, const float* x, long long len, fast::v2f* spec, float* frames, float scale) {
+  int launch_xform(P& pl, bool forward, const float* x, long long len, fast::v2f* spec, float* frames, float scale,
+                   int pad_mode = -1) {
     fast::FastXformArgs a{};
     a.x = x;
     a.spec = spec;
@@ -1353,7 +1354,7 @@ struct FastState<float> {
     a.T = pl.Tn();
     a.hop = pl.cfg.hop_length;
     a.pad = pl.pad;
-    a.pad_mode = pl.cfg.pad_mode;
+    a.pad_mode = pad_mode >= 0 ? pad_mode : pl.cfg.pad_mode;
     a.scale = scale;
     const size_t lds = xform_R == 16 ? fast::Geo<16>::lds_bytes(4) : fast::Geo<8>::lds_bytes(4);
     const unsigned grid = (unsigned)std::min<long long>((a.n_frames_total + 3) / 4, 256 * 12);

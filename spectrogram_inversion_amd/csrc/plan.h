@@ -40,6 +40,13 @@ struct PlanBase {
   virtual int get_wave(void* x_out) = 0;
   virtual int get_state_spec(int which, void* spec_out) = 0;
 
+  virtual int gla_update(const void* R, const void* P, const void* mag, double lr, void* S_out, void* Q_out) = 0;
+  virtual int gla_update_adjoint(const void* gQ, const void* gPn, const void* S, const void* mag, double lr, void* gR,
+                                 void* gP, void* gmag) = 0;
+  virtual int istft_adjoint(const void* g_x, void* g_spec_out) = 0;
+  virtual int stft_adjoint(const void* g_spec, int64_t len, void* g_x_out) = 0;
+  virtual int phase_init_adjoint(const void* mag, const void* g_spec, void* gmag) = 0;
+
   virtual int rtisi_run(const void* mag, int look_ahead, int asym, int max_iter, double alpha, void* x_out) = 0;
 
   virtual int transform_setup(int kind, const void* mel_fb, int n_mels) = 0;

@@ -6,6 +6,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "kernels_adjoint.h"
 #include "kernels_fast.h"
 #include "kernels_generic.h"
 #include "kernels_lbfgs.h"
@@ -191,18 +192,24 @@ struct PlanT final : PlanBase {
     return launch_ola(frames.as<T>(), out, true);
   }
 
-  int stft_internal(const T* xin, int64_t len, C* spec_btf) {
+  // pad_mode_override >= 0 / scale_override > 0 replace the plan's pad mode / forward scale (used by the adjoints)
+  int stft_internal(const T* xin, int64_t len, C* spec_btf, int pad_mode_override = -1, T scale_override = T(0)) {
+    const int pm = pad_mode_override >= 0 ? pad_mode_override : cfg.pad_mode;
+    const T sc = scale_override > T(0) ? scale_override : fc.fwd_scale;
     const int64_t tcheck = 1 + (len + 2 * pad - N()) / cfg.hop_length;
     SI_CHECK(len + 2 * pad >= N() && tcheck == Tn(), SPECINV_EINVAL,
              "signal length %lld gives %lld frames, plan has %d", (long long)len, (long long)tcheck, Tn());
-    if (cfg.center && cfg.pad_mode == SPECINV_PAD_REFLECT)
+    if (cfg.center && pm == SPECINV_PAD_REFLECT)
       SI_CHECK(pad < len, SPECINV_EINVAL, "reflect padding needs n_fft/2 < length");
     if constexpr (std::is_same<T, float>::value) {
       if (fast.xform_ok && !force_generic)
-        return fast.launch_xform(*this, true, xin, (long long)len, reinterpret_cast<fast::v2f*>(spec_btf), nullptr,
-                                 fc.fwd_scale);
+        return fast.launch_xform(*this, true, xin, (long long)len, reinterpret_cast<fast::v2f*>(spec_btf), nullptr, sc,
+                                 pm);
     }
-    hipLaunchKernelGGL((k_stft<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, frame_cfg(len), xin, spec_btf);
+    FrameCfg<T> c = frame_cfg(len);
+    c.pad_mode = pm;
+    c.fwd_scale = sc;
+    hipLaunchKernelGGL((k_stft<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, c, xin, spec_btf);
     SI_HIP(hipGetLastError());
     return SPECINV_OK;
   }
@@ -433,6 +440,85 @@ struct PlanT final : PlanBase {
   }
 
   // ------------------------------------------------------------------------------------
+  // ------------------------------------------------------------------------------------
+  // differentiation building blocks (kernels_adjoint.h)
+  int gla_update(const void* R, const void* P, const void* m, double lr, void* S_out, void* Q_out) override {
+    SI_CHECK(R && P && m && S_out && Q_out, SPECINV_EINVAL, "null pointer");
+    const int64_t n = nspec();
+    hipLaunchKernelGGL((k_gla_update<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, static_cast<const C*>(R),
+                       static_cast<const C*>(P), static_cast<const T*>(m), (T)lr, static_cast<C*>(S_out),
+                       static_cast<C*>(Q_out), n);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  int gla_update_adjoint(const void* gQ, const void* gPn, const void* S, const void* m, double lr, void* gR, void* gP,
+                         void* gmag) override {
+    SI_CHECK(gQ && S && m && gR && gP && gmag, SPECINV_EINVAL, "null pointer");
+    const int64_t n = nspec();
+    hipLaunchKernelGGL((k_gla_update_adjoint<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream,
+                       static_cast<const C*>(gQ), static_cast<const C*>(gPn), static_cast<const C*>(S),
+                       static_cast<const T*>(m), (T)lr, static_cast<C*>(gR), static_cast<C*>(gP), static_cast<T*>(gmag), n);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  // x = overlap_add(w * inv_scale * IDFT_H(Q)) / env   =>   gQ = scale_k * DFT(w * zero-padded frames of g/env)
+  int istft_adjoint(const void* g_x, void* g_spec_out) override {
+    SI_CHECK(g_x && g_spec_out, SPECINV_EINVAL, "null pointer");
+    const int64_t total = (int64_t)B() * length;
+    SI_TRY(tmp_real.reserve(total * sizeof(T)));
+    hipLaunchKernelGGL((k_div_env<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
+                       static_cast<const T*>(g_x), env.as<T>(), tmp_real.as<T>(), length, total);
+    SI_HIP(hipGetLastError());
+    SI_TRY(tmp_spec.reserve(nspec() * sizeof(C)));
+    SI_TRY(stft_internal(tmp_real.as<T>(), length, tmp_spec.as<C>(), SPECINV_PAD_CONSTANT, T(1)));
+    const int64_t ns = nspec();
+    hipLaunchKernelGGL((k_istft_adjoint_scale<T>), dim3((unsigned)ceil_div(ns, 256)), dim3(256), 0, stream,
+                       tmp_spec.as<C>(), n_freq, N(), cfg.onesided, fc.inv_scale, ns);
+    SI_HIP(hipGetLastError());
+    return transpose<C>(tmp_spec.as<C>(), static_cast<C*>(g_spec_out), Tn(), n_freq);
+  }
+
+  // R = fwd_scale * DFT(w * padded frames of x)   =>   gx = fold(overlap_add(w * fwd_scale * sum_k gR_k e^{+})))
+  int stft_adjoint(const void* g_spec, int64_t len, void* g_x_out) override {
+    SI_CHECK(g_spec && g_x_out, SPECINV_EINVAL, "null pointer");
+    const int64_t tcheck = 1 + (len + 2 * pad - N()) / cfg.hop_length;
+    SI_CHECK(len + 2 * pad >= N() && tcheck == Tn(), SPECINV_EINVAL, "signal length %lld does not match the plan",
+             (long long)len);
+    const int64_t ns = nspec();
+    SI_TRY(tmp_spec.reserve(ns * sizeof(C)));
+    SI_TRY(transpose<C>(static_cast<const C*>(g_spec), tmp_spec.as<C>(), n_freq, Tn()));
+    if (cfg.onesided) {
+      hipLaunchKernelGGL((k_halve_interior<T>), dim3((unsigned)ceil_div(ns, 256)), dim3(256), 0, stream, tmp_spec.as<C>(),
+                         n_freq, N(), ns);
+      SI_HIP(hipGetLastError());
+    }
+    SI_TRY(frames_needed());
+    SI_TRY(inverse_frames(tmp_spec.as<C>(), frames.as<T>(), fc.fwd_scale, len));
+    const int64_t total = (int64_t)B() * len;
+    hipLaunchKernelGGL((k_grad_fold<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, frames.as<T>(),
+                       static_cast<T*>(g_x_out), N(), cfg.hop_length, pad, cfg.pad_mode, Tn(), len, total);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  int phase_init_adjoint(const void* magp, const void* g_spec, void* gmag) override {
+    SI_CHECK(magp && g_spec && gmag, SPECINV_EINVAL, "null pointer");
+    const int64_t ns = nspec();
+    SI_TRY(tmp_real.reserve(ns * sizeof(T)));
+    const int rows = B() * n_freq;
+    hipLaunchKernelGGL((k_phase_init_adjoint_rows<T>), dim3((rows + 3) / 4), dim3(256), 0, stream,
+                       static_cast<const T*>(magp), static_cast<const C*>(g_spec), static_cast<T*>(gmag),
+                       tmp_real.as<T>(), B(), n_freq, Tn(), N(), cfg.hop_length);
+    SI_HIP(hipGetLastError());
+    hipLaunchKernelGGL((k_phase_init_adjoint_peaks<T>), dim3((unsigned)ceil_div(ns, 256)), dim3(256), 0, stream,
+                       static_cast<const T*>(magp), tmp_real.as<T>(), static_cast<T*>(gmag), B(), n_freq, Tn(), N(),
+                       cfg.hop_length);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
   int rtisi_run(const void* magp, int look_ahead, int asym, int max_iter, double alpha, void* x_out) override {
     return rtisi_launch(*this, static_cast<const T*>(magp), look_ahead, asym, max_iter, alpha, static_cast<T*>(x_out));
   }

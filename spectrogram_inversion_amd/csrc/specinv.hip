@@ -230,6 +230,29 @@ int specinv_get_state_spec(specinv_plan* plan, int which, void* spec_out) {
   return plan->impl->get_state_spec(which, spec_out);
 }
 
+int specinv_gla_update(specinv_plan* plan, const void* R, const void* P, const void* mag, double lr, void* S_out,
+                       void* Q_out) {
+  ENTER(plan);
+  return plan->impl->gla_update(R, P, mag, lr, S_out, Q_out);
+}
+int specinv_gla_update_adjoint(specinv_plan* plan, const void* gQ, const void* gP_next, const void* S, const void* mag,
+                               double lr, void* gR_out, void* gP_out, void* gmag_accum) {
+  ENTER(plan);
+  return plan->impl->gla_update_adjoint(gQ, gP_next, S, mag, lr, gR_out, gP_out, gmag_accum);
+}
+int specinv_istft_adjoint(specinv_plan* plan, const void* g_x, void* g_spec_out) {
+  ENTER(plan);
+  return plan->impl->istft_adjoint(g_x, g_spec_out);
+}
+int specinv_stft_adjoint(specinv_plan* plan, const void* g_spec, int64_t length, void* g_x_out) {
+  ENTER(plan);
+  return plan->impl->stft_adjoint(g_spec, length, g_x_out);
+}
+int specinv_phase_init_adjoint(specinv_plan* plan, const void* mag, const void* g_spec, void* gmag_accum) {
+  ENTER(plan);
+  return plan->impl->phase_init_adjoint(mag, g_spec, gmag_accum);
+}
+
 int specinv_rtisi_run(specinv_plan* plan, const void* mag, int look_ahead, int asymmetric_window, int max_iter,
                       double alpha, void* x_out) {
   ENTER(plan);

@@ -239,6 +239,43 @@ class Plan:
         _lib.check(self.lib.specinv_get_state_spec(self._h, int(which), out.data_ptr()))
         return out
 
+    # -- differentiation building blocks ------------------------------------------------------------
+    def gla_update(self, R, P, mag, lr):
+        """S = R - lr*P ; Q = S*mag/(|S| + 1e-16)  (methods.py:243-247).  Returns (S, Q)."""
+        self._sync_stream()
+        S, Q = torch.empty_like(R), torch.empty_like(R)
+        _lib.check(self.lib.specinv_gla_update(self._h, R.data_ptr(), P.data_ptr(), mag.data_ptr(), float(lr),
+                                               S.data_ptr(), Q.data_ptr()))
+        return S, Q
+
+    def gla_update_adjoint(self, gQ, gP_next, S, mag, lr, gmag):
+        """Adjoint of `gla_update`; accumulates d/dmag into `gmag`, returns (gR, gP)."""
+        self._sync_stream()
+        gR, gP = torch.empty_like(gQ), torch.empty_like(gQ)
+        _lib.check(self.lib.specinv_gla_update_adjoint(
+            self._h, gQ.data_ptr(), None if gP_next is None else gP_next.data_ptr(), S.data_ptr(), mag.data_ptr(),
+            float(lr), gR.data_ptr(), gP.data_ptr(), gmag.data_ptr()))
+        return gR, gP
+
+    def istft_adjoint(self, g_x: torch.Tensor) -> torch.Tensor:
+        self._sync_stream()
+        g_x = self._in(g_x, self.dtype, (self.batch, self.length))
+        out = torch.empty(self._spec_shape(), dtype=self.cdtype, device=self.device)
+        _lib.check(self.lib.specinv_istft_adjoint(self._h, g_x.data_ptr(), out.data_ptr()))
+        return out
+
+    def stft_adjoint(self, g_spec: torch.Tensor, length: int) -> torch.Tensor:
+        self._sync_stream()
+        g_spec = self._in(g_spec, self.cdtype, self._spec_shape())
+        out = torch.empty((self.batch, int(length)), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.specinv_stft_adjoint(self._h, g_spec.data_ptr(), int(length), out.data_ptr()))
+        return out
+
+    def phase_init_adjoint(self, mag, g_spec, gmag):
+        """gmag += d/dmag <g_spec, phase_init(mag)>."""
+        self._sync_stream()
+        _lib.check(self.lib.specinv_phase_init_adjoint(self._h, mag.data_ptr(), g_spec.data_ptr(), gmag.data_ptr()))
+
     def rtisi(self, mag, look_ahead, asymmetric_window, max_iter, alpha) -> torch.Tensor:
         self._sync_stream()
         mag = self._in(mag, self.dtype, self._spec_shape())

@@ -414,9 +414,49 @@ def g9_lbfgs_rosen():
     save("g9_lbfgs_rosen", **out)
 
 
+def g10_autograd():
+    """Gradients of the reference's griffin_lim w.r.t. the input spectrogram (torch autograd)."""
+    out = {}
+    rng = np.random.default_rng(110)
+    cases = [("f32_hann", np.float32, 128, 32, True, dict()), ("f64_hann", np.float64, 128, 32, True, dict()),
+             ("f64_rect_default", np.float64, 128, None, False, dict()),
+             ("f64_const_pad", np.float64, 64, 16, True, dict(pad_mode="constant")),
+             ("f64_normalized", np.float64, 64, 16, True, dict(normalized=True))]
+    for tag, dt, n_fft, hop, use_hann, extra in cases:
+        mag = (rng.random((2, n_fft // 2 + 1, 12)) + 0.05).astype(dt)
+        kw = dict(extra)
+        if hop:
+            kw["hop_length"] = hop
+        if use_hann:
+            kw["window"] = t(hann(n_fft, dt))
+        spec = t(mag).requires_grad_(True)
+        y = M.griffin_lim(spec, max_iter=3, alpha=0.5, tol=0, verbose=False, **kw)
+        wv = rng.standard_normal(tuple(y.shape)).astype(dt)
+        (y * t(wv)).sum().backward()
+        out[f"mag_{tag}"] = mag
+        out[f"w_{tag}"] = wv
+        out[f"y_{tag}"] = y.detach().numpy()
+        out[f"grad_{tag}"] = spec.grad.numpy()
+    # complex (warm-start) input: gradient w.r.t. the complex spectrogram
+    mag = (rng.random((1, 65, 10)) + 0.05)
+    c = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(np.complex128)
+    spec = t(c).requires_grad_(True)
+    y = M.griffin_lim(spec, max_iter=2, alpha=0.3, tol=0, verbose=False, hop_length=32, window=t(hann(128, np.float64)))
+    wv = rng.standard_normal(tuple(y.shape))
+    (y * t(wv)).sum().backward()
+    out["c_complex"], out["w_complex"], out["grad_complex"] = c, wv, spec.grad.numpy()
+    # the reference's own test pattern (test/test_griffin.py:53-66): mse against the original signal
+    x = rng.standard_normal(2000).astype(np.float32)
+    sp = torch.stft(t(x), 256, return_complex=True).abs().requires_grad_(True)
+    y = M.griffin_lim(sp, max_iter=2, verbose=False)
+    torch.nn.functional.mse_loss(t(x)[:y.shape[0]], y).backward()
+    out["x_ref_test"], out["grad_ref_test"] = x, sp.grad.numpy()
+    save("g10_autograd", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     table = dict(g0=g0_stft, g1=g1_phase_init, g2=g2_gla, g3=g3_sweep, g4=g4_admm, g5=g5_rtisi,
-                 g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen)
+                 g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd)
     for w in which:
         table[w]()

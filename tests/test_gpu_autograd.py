@@ -1,0 +1,108 @@
+"""Gradients of griffin_lim w.r.t. the input spectrogram: hand-written adjoints against the gradients torch
+autograd gives for the reference (tests/golden/g10_autograd.npz), plus adjoint identities.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from _util import hann, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+import spectrogram_inversion_amd as si                               # noqa: E402
+from spectrogram_inversion_amd.plan import Plan, args_helper          # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+CASES = [("f32_hann", 128, 32, True, {}, 2e-4), ("f64_hann", 128, 32, True, {}, 1e-9),
+         ("f64_rect_default", 128, None, False, {}, 1e-9), ("f64_const_pad", 64, 16, True, dict(pad_mode="constant"), 1e-9),
+         ("f64_normalized", 64, 16, True, dict(normalized=True), 1e-9)]
+
+
+@pytest.mark.parametrize("tag,n_fft,hop,use_hann,extra,tol", CASES)
+def test_gradient_matches_reference_autograd(tag, n_fft, hop, use_hann, extra, tol):
+    g = load_golden("g10_autograd")
+    mag = g[f"mag_{tag}"]
+    kw = dict(extra)
+    if hop:
+        kw["hop_length"] = hop
+    if use_hann:
+        kw["window"] = torch.from_numpy(hann(n_fft, mag.dtype.type))
+    spec = T(mag).requires_grad_(True)
+    y = si.griffin_lim(spec, max_iter=3, alpha=0.5, tol=0, verbose=False, **kw)
+    assert y.requires_grad
+    assert rel_l2(N(y), g[f"y_{tag}"]) < max(tol, 1e-5 if mag.dtype == np.float32 else 1e-11)
+    (y * T(g[f"w_{tag}"])).sum().backward()
+    assert spec.grad is not None and spec.grad.shape == spec.shape
+    assert rel_l2(N(spec.grad), g[f"grad_{tag}"]) < tol, rel_l2(N(spec.grad), g[f"grad_{tag}"])
+
+
+def test_gradient_complex_warm_start():
+    g = load_golden("g10_autograd")
+    spec = T(g["c_complex"]).requires_grad_(True)
+    y = si.griffin_lim(spec, max_iter=2, alpha=0.3, tol=0, verbose=False, hop_length=32,
+                       window=torch.from_numpy(hann(128, np.float64)))
+    (y * T(g["w_complex"])).sum().backward()
+    assert rel_l2(N(spec.grad), g["grad_complex"]) < 1e-9
+
+
+def test_reference_test_pattern_backward():
+    """test/test_griffin.py:53-66: spec.requires_grad, mse against the original signal, backward()."""
+    g = load_golden("g10_autograd")
+    x = T(g["x_ref_test"])
+    sp = torch.stft(x, 256, return_complex=True).abs().requires_grad_(True)
+    y = si.griffin_lim(sp, max_iter=2, verbose=False)
+    torch.nn.functional.mse_loss(x[:y.shape[0]], y).backward()
+    assert hasattr(sp, "grad") and rel_l2(N(sp.grad), g["grad_ref_test"]) < 5e-4
+
+
+def test_no_grad_requested_keeps_the_fused_path():
+    mag = torch.rand(1, 513, 16, device=DEV)
+    y = si.griffin_lim(mag, max_iter=2, verbose=False, hop_length=256, window=torch.hann_window(1024))
+    assert not y.requires_grad
+    with torch.no_grad():
+        y2 = si.griffin_lim(mag.clone().requires_grad_(True), max_iter=2, verbose=False, hop_length=256,
+                            window=torch.hann_window(1024))
+    assert not y2.requires_grad and torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,dtype,kw", [(128, 32, 9, torch.float64, {}), (1024, 256, 12, torch.float32, {}),
+                                                       (64, 20, 11, torch.float64, dict(pad_mode="circular")),
+                                                       (64, 16, 9, torch.float64, dict(center=False)),
+                                                       (64, 16, 9, torch.float64, dict(onesided=False, normalized=True))])
+def test_adjoint_identities(n_fft, hop, frames, dtype, kw):
+    """<A x, Y> = <x, A^T Y> for the STFT and <B Q, g> = <Q, B^T g> for the ISTFT (real inner products)."""
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    w = torch.from_numpy(hann(n_fft, npdt))
+    n_freq = n_fft // 2 + 1 if kw.get("onesided", True) else n_fft
+    a = args_helper(torch.empty(1, n_freq, 1, dtype=dtype), hop_length=hop, window=w, **kw)
+    plan = Plan(a, 2, frames, dtype, DEV)
+    torch.manual_seed(0)
+    cd = torch.complex64 if dtype == torch.float32 else torch.complex128
+    x = torch.randn(2, plan.length, dtype=dtype, device=DEV)
+    Y = torch.randn(2, n_freq, frames, dtype=cd, device=DEV)
+    tol = 2e-5 if dtype == torch.float32 else 1e-12
+
+    def rdot(u, v):
+        return float((u.conj() * v).real.sum()) if u.is_complex() else float((u * v).sum())
+
+    lhs, rhs = rdot(plan.stft(x), Y), rdot(x, plan.stft_adjoint(Y, plan.length))
+    assert abs(lhs - rhs) < tol * max(1.0, abs(lhs)), (lhs, rhs)
+    if kw.get("center", True):                          # with center=False the Hann envelope has zeros (1/0)
+        gq = torch.randn(2, plan.length, dtype=dtype, device=DEV)
+        lhs, rhs = rdot(plan.istft(Y), gq), rdot(Y, plan.istft_adjoint(gq))
+        if kw.get("onesided", True):
+            # irfft ignores the imaginary parts of DC / Nyquist: compare against Y with those removed
+            Y0 = Y.clone()
+            Y0[:, 0].imag.zero_()
+            Y0[:, -1].imag.zero_()
+            rhs = rdot(Y0, plan.istft_adjoint(gq))
+        assert abs(lhs - rhs) < tol * max(1.0, abs(lhs)), (lhs, rhs)
