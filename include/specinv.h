@@ -137,6 +137,12 @@ int specinv_gla_update(specinv_plan* plan, const void* R, const void* P, const v
 /* its adjoint: gR = gS, gP = -lr*gS, gmag += d/dmag, with gS = proj^T(gQ) + gP_next (gP_next may be NULL) */
 int specinv_gla_update_adjoint(specinv_plan* plan, const void* gQ, const void* gP_next, const void* S, const void* mag,
                                double lr, void* gR_out, void* gP_out, void* gmag_accum);
+/* one ADMM closure call without the transforms, methods.py:467-475 (V is the pre-projection value Z - U', kept for
+ * the adjoint; Yn = X' + U' feeds the ISTFT) and its adjoint (gXn / gUn may be NULL) */
+int specinv_admm_update(specinv_plan* plan, const void* R, const void* X, const void* U, const void* mag, double rho,
+                        void* Xn_out, void* Un_out, void* V_out, void* Yn_out);
+int specinv_admm_update_adjoint(specinv_plan* plan, const void* gYn, const void* gXn, const void* gUn, const void* V,
+                                const void* mag, double rho, void* gR_out, void* gX_out, void* gU_out, void* gmag_accum);
 /* adjoint of specinv_istft: cotangent of x (B, L) -> cotangent of the spectrogram (B, F, T) complex */
 int specinv_istft_adjoint(specinv_plan* plan, const void* g_x, void* g_spec_out);
 /* adjoint of specinv_stft: cotangent of the spectrogram -> cotangent of x (B, length) */

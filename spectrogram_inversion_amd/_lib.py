@@ -64,6 +64,8 @@ SIGNATURES = {
     "specinv_get_state_spec": (C.c_int, [_P, C.c_int, _P]),
     "specinv_gla_update": (C.c_int, [_P, _P, _P, _P, _D, _P, _P]),
     "specinv_gla_update_adjoint": (C.c_int, [_P, _P, _P, _P, _P, _D, _P, _P, _P]),
+    "specinv_admm_update": (C.c_int, [_P, _P, _P, _P, _P, _D, _P, _P, _P, _P]),
+    "specinv_admm_update_adjoint": (C.c_int, [_P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P]),
     "specinv_istft_adjoint": (C.c_int, [_P, _P, _P]),
     "specinv_stft_adjoint": (C.c_int, [_P, _P, _I64, _P]),
     "specinv_phase_init_adjoint": (C.c_int, [_P, _P, _P, _P]),

@@ -48,6 +48,55 @@ __global__ void k_gla_update_adjoint(const cplx<T>* __restrict__ gQ, const cplx<
   gm[i] += dot / d;
 }
 
+// ADMM closure without the transforms (methods.py:467-475) and its adjoint.
+//   Y = X + U ; Z = (rho Y + R)/(1+rho) ; U' = U + X - Z ; V = Z - U' ; X' = V m/(|V| + 1e-16) ; Y' = X' + U'
+template <typename T>
+__global__ void k_admm_update(const cplx<T>* __restrict__ R, const cplx<T>* __restrict__ X, const cplx<T>* __restrict__ U,
+                              const T* __restrict__ m, T rho, T inv1p, cplx<T>* __restrict__ Xn, cplx<T>* __restrict__ Un,
+                              cplx<T>* __restrict__ V_out, cplx<T>* __restrict__ Yn, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const cplx<T> r = R[i], xo = X[i], uo = U[i];
+  const cplx<T> y = xo + uo;
+  const cplx<T> z = mk<T>((rho * y.x + r.x) * inv1p, (rho * y.y + r.y) * inv1p);
+  const cplx<T> un = (uo + xo) - z;
+  const cplx<T> v = z - un;
+  const T inv = T(1) / (si_hypot(v.x, v.y) + eps16<T>::value);
+  const cplx<T> xn = mk<T>((v.x * m[i]) * inv, (v.y * m[i]) * inv);
+  Xn[i] = xn;
+  Un[i] = un;
+  V_out[i] = v;
+  Yn[i] = xn + un;
+}
+
+// cotangents of (Y' via the ISTFT, X', U') -> cotangents of (R, X, U), gm += d/dm.  gXn / gUn may be NULL.
+template <typename T>
+__global__ void k_admm_update_adjoint(const cplx<T>* __restrict__ gYn, const cplx<T>* __restrict__ gXn,
+                                      const cplx<T>* __restrict__ gUn, const cplx<T>* __restrict__ V,
+                                      const T* __restrict__ m, T rho, T inv1p, cplx<T>* __restrict__ gR,
+                                      cplx<T>* __restrict__ gX, cplx<T>* __restrict__ gU, T* __restrict__ gm, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  cplx<T> gx = gYn[i], gu = gYn[i];                       // Y' = X' + U'
+  if (gXn) gx = gx + gXn[i];
+  if (gUn) gu = gu + gUn[i];
+  // X' = proj(V, m)
+  const cplx<T> v = V[i];
+  const T mag = si_hypot(v.x, v.y);
+  const T d = mag + eps16<T>::value;
+  const T dot = gx.x * v.x + gx.y * v.y;
+  const T c1 = m[i] / d;
+  const T c2 = mag > T(0) ? dot * m[i] / (d * d * mag) : T(0);
+  const cplx<T> gv = mk<T>(gx.x * c1 - v.x * c2, gx.y * c1 - v.y * c2);
+  gm[i] += dot / d;
+  gu = gu - gv;                                           // V = Z - U'
+  cplx<T> gz = gv - gu;                                   // ... and U' = U + X - Z
+  const cplx<T> gy = mk<T>(gz.x * (rho * inv1p), gz.y * (rho * inv1p));   // Z = (rho Y + R)/(1+rho)
+  gR[i] = mk<T>(gz.x * inv1p, gz.y * inv1p);
+  gX[i] = gu + gy;                                        // U' = U + X - Z ; Y = X + U
+  gU[i] = gu + gy;
+}
+
 template <typename T>
 __global__ void k_div_env(const T* __restrict__ g, const T* __restrict__ env, T* __restrict__ u, int64_t L, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

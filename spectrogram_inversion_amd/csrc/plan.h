@@ -43,6 +43,10 @@ struct PlanBase {
   virtual int gla_update(const void* R, const void* P, const void* mag, double lr, void* S_out, void* Q_out) = 0;
   virtual int gla_update_adjoint(const void* gQ, const void* gPn, const void* S, const void* mag, double lr, void* gR,
                                  void* gP, void* gmag) = 0;
+  virtual int admm_update(const void* R, const void* X, const void* U, const void* mag, double rho, void* Xn, void* Un,
+                          void* V, void* Yn) = 0;
+  virtual int admm_update_adjoint(const void* gYn, const void* gXn, const void* gUn, const void* V, const void* mag,
+                                  double rho, void* gR, void* gX, void* gU, void* gmag) = 0;
   virtual int istft_adjoint(const void* g_x, void* g_spec_out) = 0;
   virtual int stft_adjoint(const void* g_spec, int64_t len, void* g_x_out) = 0;
   virtual int phase_init_adjoint(const void* mag, const void* g_spec, void* gmag) = 0;

@@ -463,6 +463,31 @@ struct PlanT final : PlanBase {
     return SPECINV_OK;
   }
 
+  int admm_update(const void* R, const void* X, const void* U, const void* m, double rho, void* Xn, void* Un, void* V,
+                  void* Yn) override {
+    SI_CHECK(R && X && U && m && Xn && Un && V && Yn, SPECINV_EINVAL, "null pointer");
+    const int64_t n = nspec();
+    const T r = (T)rho, inv1p = T(1) / (T)(1.0 + (double)r);
+    hipLaunchKernelGGL((k_admm_update<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, static_cast<const C*>(R),
+                       static_cast<const C*>(X), static_cast<const C*>(U), static_cast<const T*>(m), r, inv1p,
+                       static_cast<C*>(Xn), static_cast<C*>(Un), static_cast<C*>(V), static_cast<C*>(Yn), n);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  int admm_update_adjoint(const void* gYn, const void* gXn, const void* gUn, const void* V, const void* m, double rho,
+                          void* gR, void* gX, void* gU, void* gmag) override {
+    SI_CHECK(gYn && V && m && gR && gX && gU && gmag, SPECINV_EINVAL, "null pointer");
+    const int64_t n = nspec();
+    const T r = (T)rho, inv1p = T(1) / (T)(1.0 + (double)r);
+    hipLaunchKernelGGL((k_admm_update_adjoint<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream,
+                       static_cast<const C*>(gYn), static_cast<const C*>(gXn), static_cast<const C*>(gUn),
+                       static_cast<const C*>(V), static_cast<const T*>(m), r, inv1p, static_cast<C*>(gR),
+                       static_cast<C*>(gX), static_cast<C*>(gU), static_cast<T*>(gmag), n);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
   // x = overlap_add(w * inv_scale * IDFT_H(Q)) / env   =>   gQ = scale_k * DFT(w * zero-padded frames of g/env)
   int istft_adjoint(const void* g_x, void* g_spec_out) override {
     SI_CHECK(g_x && g_spec_out, SPECINV_EINVAL, "null pointer");

@@ -240,6 +240,16 @@ int specinv_gla_update_adjoint(specinv_plan* plan, const void* gQ, const void* g
   ENTER(plan);
   return plan->impl->gla_update_adjoint(gQ, gP_next, S, mag, lr, gR_out, gP_out, gmag_accum);
 }
+int specinv_admm_update(specinv_plan* plan, const void* R, const void* X, const void* U, const void* mag, double rho,
+                        void* Xn_out, void* Un_out, void* V_out, void* Yn_out) {
+  ENTER(plan);
+  return plan->impl->admm_update(R, X, U, mag, rho, Xn_out, Un_out, V_out, Yn_out);
+}
+int specinv_admm_update_adjoint(specinv_plan* plan, const void* gYn, const void* gXn, const void* gUn, const void* V,
+                                const void* mag, double rho, void* gR_out, void* gX_out, void* gU_out, void* gmag_accum) {
+  ENTER(plan);
+  return plan->impl->admm_update_adjoint(gYn, gXn, gUn, V, mag, rho, gR_out, gX_out, gU_out, gmag_accum);
+}
 int specinv_istft_adjoint(specinv_plan* plan, const void* g_x, void* g_spec_out) {
   ENTER(plan);
   return plan->impl->istft_adjoint(g_x, g_spec_out);

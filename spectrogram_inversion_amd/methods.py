@@ -7,8 +7,8 @@ Differences that are deliberate:
   * compute always happens on the HIP device.  Tensors that live on the CPU are
     staged to the current HIP device and the result is returned on the input's
     device; without a GPU the functions raise (there is no CPU fallback).
-  * `griffin_lim` is differentiable w.r.t. `spec` (recorded forward + hand-written adjoints, see
-    autograd.py); `ADMM` / `RTISI_LA` results are not (not built yet).
+  * `griffin_lim` and `ADMM` are differentiable w.r.t. `spec` (recorded forward + hand-written adjoints,
+    see autograd.py); `RTISI_LA` results are not.
 """
 from __future__ import annotations
 
@@ -58,17 +58,17 @@ def _iterative(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, stft
     device = require_gpu(spec3.device)
     rdtype = spec3.real.dtype if spec3.is_complex() else spec3.dtype
     plan = get_plan(args, spec3.shape[0], spec3.shape[2], rdtype, device)
-    if which == "gla" and torch.is_grad_enabled() and spec.requires_grad:
+    if torch.is_grad_enabled() and spec.requires_grad:
         # a gradient w.r.t. the spectrogram is wanted: recorded forward + hand-written adjoints (autograd.py)
-        from .autograd import griffin_lim_differentiable
+        from .autograd import admm_differentiable, griffin_lim_differentiable
+        run = griffin_lim_differentiable if which == "gla" else admm_differentiable
         assert eva_iter > 0 and max_iter > 0 and tol >= 0
         name = metric.upper()
         with tqdm(total=max_iter, disable=not verbose) as pbar:
             def on_eval(_it, m, loss):
                 pbar.set_postfix(**{name: m}, loss=loss)
                 pbar.update(eva_iter)
-            x = griffin_lim_differentiable(spec3.to(device), plan, coef, max_iter, tol, eva_iter, metric,
-                                           on_eval if verbose else None)
+            x = run(spec3.to(device), plan, coef, max_iter, tol, eva_iter, metric, on_eval if verbose else None)
         return _finish(x, spec, spec.device)
     init = getattr(plan, which + "_init")
     if real_in:

@@ -257,6 +257,22 @@ class Plan:
             float(lr), gR.data_ptr(), gP.data_ptr(), gmag.data_ptr()))
         return gR, gP
 
+    def admm_update(self, R, X, U, mag, rho):
+        """methods.py:467-475 without the transforms.  Returns (X', U', V, Y') with V = Z - U' (pre-projection)."""
+        self._sync_stream()
+        Xn, Un, V, Yn = (torch.empty_like(R) for _ in range(4))
+        _lib.check(self.lib.specinv_admm_update(self._h, R.data_ptr(), X.data_ptr(), U.data_ptr(), mag.data_ptr(), float(rho),
+                                                Xn.data_ptr(), Un.data_ptr(), V.data_ptr(), Yn.data_ptr()))
+        return Xn, Un, V, Yn
+
+    def admm_update_adjoint(self, gYn, gXn, gUn, V, mag, rho, gmag):
+        self._sync_stream()
+        gR, gX, gU = (torch.empty_like(gYn) for _ in range(3))
+        _lib.check(self.lib.specinv_admm_update_adjoint(
+            self._h, gYn.data_ptr(), None if gXn is None else gXn.data_ptr(), None if gUn is None else gUn.data_ptr(),
+            V.data_ptr(), mag.data_ptr(), float(rho), gR.data_ptr(), gX.data_ptr(), gU.data_ptr(), gmag.data_ptr()))
+        return gR, gX, gU
+
     def istft_adjoint(self, g_x: torch.Tensor) -> torch.Tensor:
         self._sync_stream()
         g_x = self._in(g_x, self.dtype, (self.batch, self.length))

@@ -454,9 +454,40 @@ def g10_autograd():
     save("g10_autograd", **out)
 
 
+def g11_autograd_admm():
+    """Gradients of the reference's ADMM w.r.t. the input spectrogram (torch autograd; test/test_admm.py:54-66)."""
+    out = {}
+    rng = np.random.default_rng(111)
+    cases = [("f32_hann", np.float32, 128, 32, True, 0.1, dict()), ("f64_hann", np.float64, 128, 32, True, 0.1, dict()),
+             ("f64_rect_default", np.float64, 64, None, False, 0.5, dict()),
+             ("f64_twosided", np.float64, 64, 16, True, 0.2, dict(onesided=False, pad_mode="constant"))]
+    for tag, dt, n_fft, hop, use_hann, rho, extra in cases:
+        F_ = n_fft if extra.get("onesided") is False else n_fft // 2 + 1
+        mag = (rng.random((2, F_, 12)) + 0.05).astype(dt)
+        kw = dict(extra)
+        if hop:
+            kw["hop_length"] = hop
+        if use_hann:
+            kw["window"] = t(hann(n_fft, dt))
+        spec = t(mag).requires_grad_(True)
+        y = M.ADMM(spec, max_iter=3, rho=rho, tol=0, verbose=False, **kw)
+        wv = rng.standard_normal(tuple(y.shape)).astype(dt)
+        (y * t(wv)).sum().backward()
+        out[f"mag_{tag}"], out[f"w_{tag}"] = mag, wv
+        out[f"y_{tag}"], out[f"grad_{tag}"] = y.detach().numpy(), spec.grad.numpy()
+    mag = (rng.random((1, 65, 10)) + 0.05)
+    c = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(np.complex128)
+    spec = t(c).requires_grad_(True)
+    y = M.ADMM(spec, max_iter=2, rho=0.3, tol=0, verbose=False, hop_length=32, window=t(hann(128, np.float64)))
+    wv = rng.standard_normal(tuple(y.shape))
+    (y * t(wv)).sum().backward()
+    out["c_complex"], out["w_complex"], out["grad_complex"] = c, wv, spec.grad.numpy()
+    save("g11_autograd_admm", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     table = dict(g0=g0_stft, g1=g1_phase_init, g2=g2_gla, g3=g3_sweep, g4=g4_admm, g5=g5_rtisi,
-                 g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd)
+                 g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd, g11=g11_autograd_admm)
     for w in which:
         table[w]()

@@ -106,3 +106,42 @@ def test_adjoint_identities(n_fft, hop, frames, dtype, kw):
             Y0[:, -1].imag.zero_()
             rhs = rdot(Y0, plan.istft_adjoint(gq))
         assert abs(lhs - rhs) < tol * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+ADMM_CASES = [("f32_hann", 128, 32, True, 0.1, {}, 3e-4), ("f64_hann", 128, 32, True, 0.1, {}, 1e-9),
+              ("f64_rect_default", 64, None, False, 0.5, {}, 1e-9),
+              ("f64_twosided", 64, 16, True, 0.2, dict(onesided=False, pad_mode="constant"), 1e-9)]
+
+
+@pytest.mark.parametrize("tag,n_fft,hop,use_hann,rho,extra,tol", ADMM_CASES)
+def test_admm_gradient_matches_reference_autograd(tag, n_fft, hop, use_hann, rho, extra, tol):
+    g = load_golden("g11_autograd_admm")
+    mag = g[f"mag_{tag}"]
+    kw = dict(extra)
+    if hop:
+        kw["hop_length"] = hop
+    if use_hann:
+        kw["window"] = torch.from_numpy(hann(n_fft, mag.dtype.type))
+    spec = T(mag).requires_grad_(True)
+    y = si.ADMM(spec, max_iter=3, rho=rho, tol=0, verbose=False, **kw)
+    assert y.requires_grad
+    assert rel_l2(N(y), g[f"y_{tag}"]) < max(tol, 1e-5 if mag.dtype == np.float32 else 1e-11)
+    (y * T(g[f"w_{tag}"])).sum().backward()
+    assert rel_l2(N(spec.grad), g[f"grad_{tag}"]) < tol, rel_l2(N(spec.grad), g[f"grad_{tag}"])
+
+
+def test_admm_gradient_complex_warm_start():
+    g = load_golden("g11_autograd_admm")
+    spec = T(g["c_complex"]).requires_grad_(True)
+    y = si.ADMM(spec, max_iter=2, rho=0.3, tol=0, verbose=False, hop_length=32,
+                window=torch.from_numpy(hann(128, np.float64)))
+    (y * T(g["w_complex"])).sum().backward()
+    assert rel_l2(N(spec.grad), g["grad_complex"]) < 1e-9
+
+
+def test_admm_differentiable_forward_equals_fused_forward():
+    mag = torch.rand(2, 513, 24, device=DEV, dtype=torch.float64) + 0.05
+    kw = dict(hop_length=256, window=torch.hann_window(1024, dtype=torch.float64))
+    y0 = si.ADMM(mag, max_iter=5, tol=0, verbose=False, **kw)
+    y1 = si.ADMM(mag.clone().requires_grad_(True), max_iter=5, tol=0, verbose=False, **kw)
+    assert rel_l2(N(y1), N(y0)) < 1e-10
