@@ -154,6 +154,17 @@ int specinv_phase_init_adjoint(specinv_plan* plan, const void* mag, const void* 
 int specinv_rtisi_run(specinv_plan* plan, const void* mag, int look_ahead, int asymmetric_window,
                       int max_iter, double alpha, void* x_out);
 
+/* Streaming RTISI-LA: the recursion of methods.py:363-404 fed a few frames at a time (what "real-time" in its name
+ * is about, :275-278).  The plan's n_frames is the largest number of frames one push may carry; the stream length
+ * is open-ended.  `push` takes (B, F, k) magnitudes and appends the samples that became final to x_out (row b at
+ * x_out + b*out_stride; at most k*hop of them, *n_out per row, the first pushes give fewer: a sample is final once
+ * look_ahead more frames are known).  `flush` ends the signal and returns the rest (at most look_ahead*hop + n_fft).
+ * Concatenated, the pieces are the (B, L) result of specinv_rtisi_run on the whole spectrogram. */
+int specinv_rtisi_stream_begin(specinv_plan* plan, int look_ahead, int asymmetric_window, int max_iter, double alpha);
+int specinv_rtisi_stream_push(specinv_plan* plan, const void* mag, int k, void* x_out, int64_t out_stride,
+                              int64_t* n_out);
+int specinv_rtisi_stream_flush(specinv_plan* plan, void* x_out, int64_t out_stride, int64_t* n_out);
+
 /* ---- L_BFGS building blocks (methods.py:509-569 + torch.optim.LBFGS) -------------------- */
 /* transform kinds for the fused forward/backward: V = |STFT(x)| or V = log1p(M |STFT(x)|) */
 enum { SPECINV_TF_MAG = 0, SPECINV_TF_LOGMEL = 1 };

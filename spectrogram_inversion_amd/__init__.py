@@ -16,4 +16,5 @@ from .methods import L_BFGS, RTISI_LA, griffin_lim, ADMM, phase_init   # noqa: E
 from . import metrics                                                   # noqa: E402,F401
 from .metrics import sc, snr, ser                                       # noqa: E402,F401
 from .transforms import MagSTFT, LogMelSTFT                             # noqa: E402,F401
+from .streaming import RTISIStream                                      # noqa: E402,F401
 from .mel import mel_filterbank                                         # noqa: E402,F401

@@ -70,6 +70,9 @@ SIGNATURES = {
     "specinv_stft_adjoint": (C.c_int, [_P, _P, _I64, _P]),
     "specinv_phase_init_adjoint": (C.c_int, [_P, _P, _P, _P]),
     "specinv_rtisi_run": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _D, _P]),
+    "specinv_rtisi_stream_begin": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),
+    "specinv_rtisi_stream_push": (C.c_int, [_P, _P, C.c_int, _P, _I64, C.POINTER(C.c_int64)]),
+    "specinv_rtisi_stream_flush": (C.c_int, [_P, _P, _I64, C.POINTER(C.c_int64)]),
     "specinv_transform_setup": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "specinv_transform_forward": (C.c_int, [_P, _P, _I64, _P]),
     "specinv_transform_loss_grad": (C.c_int, [_P, _P, _I64, _P, _DP, _P]),

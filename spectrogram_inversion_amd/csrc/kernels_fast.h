@@ -49,6 +49,9 @@
 #ifndef SPECINV_MINWAVES   // __launch_bounds__ waves per SIMD (caps the register allocation)
 #define SPECINV_MINWAVES 2
 #endif
+#ifndef SPECINV_NT
+#define SPECINV_NT 1         // nontemporal state streams (keeps the re-used samples in L2)
+#endif
 
 namespace specinv {
 namespace fast {
@@ -516,14 +519,20 @@ __device__ __forceinline__ v4f ld_stream(const v4f* p) {
 #if SPECINV_ABLATE & 2
   return v4f{1.0f, 0.5f, 0.25f, 2.0f} * (float)(((unsigned long long)p >> 4) & 7);
 #else
+#if SPECINV_NT
   return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
 #endif
 }
 __device__ __forceinline__ void st_stream(v4f* p, v4f v) {
 #if SPECINV_ABLATE & 1
   if (v.x == 1.2345e30f) __builtin_nontemporal_store(v, p);   // keeps the value alive, (almost) never stores
-#else
+#elif SPECINV_NT
   __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
 #endif
 }
 

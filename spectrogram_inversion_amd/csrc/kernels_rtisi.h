@@ -31,6 +31,12 @@ struct RtisiArgs {
   int keep, la, steps, max_iter, asym;
   int groups;        // look-ahead frames transformed concurrently (each thread group owns LDS FFT buffers)
   T lr;
+  // step range of this launch.  A whole-signal run is [0, steps + la) from scratch; a stream resumes from the
+  // state the previous launch left in `ring` / `pre` and addresses `mag` / `frames_out` as rings of frames.
+  int i_begin, i_end, resume;
+  int n_valid;       // target frames that exist so far (look-ahead slots beyond them see a zero target, methods.py:339)
+  int mag_ring;      // 0: mag is (B, steps, F); else (B, mag_ring, F) indexed by frame % mag_ring
+  int out_ring;      // 0: frames_out is (B, steps, N); else (B, out_ring, N) indexed by frame % out_ring
 };
 
 template <typename T>
@@ -48,13 +54,13 @@ __global__ void k_rtisi(RtisiArgs<T> r) {
   const int nslots = r.keep + r.la + 1;
   T* ring = r.ring + (int64_t)bi * nslots * N;
   cplx<T>* pre_base = r.pre + (int64_t)bi * 2 * (r.la + 1) * F;
-  const T* mag = r.mag + (int64_t)bi * r.steps * F;
-  T* fout = r.frames_out + (int64_t)bi * r.steps * N;
+  const T* mag = r.mag + (int64_t)bi * (r.mag_ring ? r.mag_ring : r.steps) * F;
+  T* fout = r.frames_out + (int64_t)bi * (r.out_ring ? r.out_ring : r.steps) * N;
   const int xlen = r.la * hop + N;
 
   // ---- initial state (methods.py:353-358): zero frames, newest slot = irfft(first target frame, zero phase)
-  for (int i = threadIdx.x; i < (nslots - 1) * N; i += blockDim.x) ring[i] = T(0);
-  {
+  if (!r.resume) {
+    for (int i = threadIdx.x; i < (nslots - 1) * N; i += blockDim.x) ring[i] = T(0);
     cplx<T>* pa = a;
     cplx<T>* pb = b;
     if (g == 0)
@@ -77,9 +83,9 @@ __global__ void k_rtisi(RtisiArgs<T> r) {
     __syncthreads();
   }
 
-  int base = 0;   // ring slot of frame 0 (oldest kept frame)
-  int pcur = 0;   // pre_spec buffer read in this inner step (the other one is written)
-  for (int i = 0; i < r.steps + r.la; ++i) {
+  int base = r.i_begin % nslots;                                  // ring slot of the oldest kept frame
+  int pcur = (int)(((int64_t)r.i_begin * r.max_iter) & 1);        // pre_spec buffer read in this inner step
+  for (int i = r.i_begin; i < r.i_end; ++i) {
     for (int j = 0; j < r.max_iter; ++j) {
       // ---- overlap-add of all K+LA+1 frames with the synthesis window, samples [K*hop, (K+LA)*hop + N)
       for (int np = threadIdx.x; np < xlen; np += blockDim.x) {
@@ -112,7 +118,8 @@ __global__ void k_rtisi(RtisiArgs<T> r) {
         lds_fft(pa, pb, c, false, gt, gsz);
         if (active) {
           const int tt = i + q - r.la;          // target frame of look-ahead slot q (methods.py:339, :395)
-          const bool valid = tt >= 0 && tt < r.steps;
+          const bool valid = tt >= 0 && tt < r.n_valid;
+          const int mrow = r.mag_ring ? tt % r.mag_ring : tt;
           for (int f = gt; f < F; f += gsz) {
             cplx<T> s = mk<T>(pa[f].x * c.fwd_scale, pa[f].y * c.fwd_scale);
             if (j) {                            // methods.py:387-388
@@ -123,7 +130,7 @@ __global__ void k_rtisi(RtisiArgs<T> r) {
               s = mk<T>(s.x - r.lr * p.x, s.y - r.lr * p.y);
             }
             pre_out[(int64_t)q * F + f] = s;    // :392
-            const T m = valid ? mag[(int64_t)tt * F + f] : T(0);
+            const T m = valid ? mag[(int64_t)mrow * F + f] : T(0);
             const T inv = T(1) / (si_hypot(s.x, s.y) + eps16<T>::value);     // :394
             pa[f] = mk<T>((s.x * m) * inv, (s.y * m) * inv);                  // :395-396
           }
@@ -154,7 +161,8 @@ __global__ void k_rtisi(RtisiArgs<T> r) {
     if (s0 >= nslots) s0 -= nslots;
     if (i >= r.la) {
       const T* src = ring + (int64_t)s0 * N;
-      T* dst = fout + (int64_t)(i - r.la) * N;
+      const int cf = i - r.la;
+      T* dst = fout + (int64_t)(r.out_ring ? cf % r.out_ring : cf) * N;
       for (int k = threadIdx.x; k < N; k += blockDim.x) dst[k] = src[k] * c.window[k];
     }
     __syncthreads();
@@ -165,17 +173,21 @@ __global__ void k_rtisi(RtisiArgs<T> r) {
   }
 }
 
-template <typename P, typename T>
-int rtisi_launch(P& pl, const T* mag_user, int look_ahead, int asym, int max_iter, double alpha, T* x_out) {
-  SI_CHECK(mag_user && x_out, SPECINV_EINVAL, "null pointer");
-  SI_CHECK(max_iter > 0, SPECINV_EINVAL, "max_iter must be > 0");     // methods.py:295
-  SI_CHECK(alpha >= 0, SPECINV_EINVAL, "alpha must be >= 0");        // methods.py:296
-  const int N = pl.N(), hop = pl.cfg.hop_length, F = pl.n_freq, Tn = pl.Tn(), Bn = pl.B();
+// windows (methods.py:318-336, evaluated in T like the reference does) and the per-item state of one recursion
+template <typename T>
+struct RtisiLayout {
+  int keep = 0, la = 0, nslots = 0;
+  cplx<T>* pre = nullptr;
+  T *ring = nullptr, *wsyn = nullptr, *asym1 = nullptr, *asym2 = nullptr;
+  char* extra = nullptr;   // `extra_bytes` more, 16-byte aligned
+};
+
+template <typename P, typename T, typename Buf>
+int rtisi_prepare(P& pl, int look_ahead, Buf& buf, size_t extra_bytes, RtisiLayout<T>& lay) {
+  const int N = pl.N(), hop = pl.cfg.hop_length, F = pl.n_freq, Bn = pl.B();
   const int keep = (N - 1) / hop;                                     // methods.py:322
   const int la = look_ahead < 0 ? keep : look_ahead;                  // :323-324
   const int nslots = keep + la + 1;
-
-  // windows (methods.py:318-336), evaluated in T like the reference does
   const std::vector<T>& w = pl.h_window;
   T dot = 0;
   for (int k = 0; k < N; ++k) dot += w[k] * w[k];
@@ -196,45 +208,32 @@ int rtisi_launch(P& pl, const T* mag_user, int look_ahead, int asym, int max_ite
   }
   const size_t ring_elems = (size_t)Bn * nslots * N;
   const size_t pre_elems = (size_t)Bn * 2 * (la + 1) * F;
-  SI_TRY(pl.rt_state.reserve(ring_elems * sizeof(T) + pre_elems * sizeof(cplx<T>) + 3 * (size_t)N * sizeof(T) + 64));
-  char* basep = static_cast<char*>(pl.rt_state.p);
-  cplx<T>* d_pre = reinterpret_cast<cplx<T>*>(basep);
-  T* d_ring = reinterpret_cast<T*>(basep + pre_elems * sizeof(cplx<T>));
-  T* d_wsyn = d_ring + ring_elems;
-  T* d_a1 = d_wsyn + N;
-  T* d_a2 = d_a1 + N;
-  SI_HIP(hipMemcpyAsync(d_wsyn, wsyn.data(), N * sizeof(T), hipMemcpyHostToDevice, pl.stream));
-  SI_HIP(hipMemcpyAsync(d_a1, a1.data(), N * sizeof(T), hipMemcpyHostToDevice, pl.stream));
-  SI_HIP(hipMemcpyAsync(d_a2, a2.data(), N * sizeof(T), hipMemcpyHostToDevice, pl.stream));
+  const size_t fixed = ring_elems * sizeof(T) + pre_elems * sizeof(cplx<T>) + 3 * (size_t)N * sizeof(T);
+  const size_t fixed_al = (fixed + 63) & ~(size_t)63;
+  SI_TRY(buf.reserve(fixed_al + extra_bytes + 64));
+  char* basep = static_cast<char*>(buf.p);
+  lay.keep = keep;
+  lay.la = la;
+  lay.nslots = nslots;
+  lay.pre = reinterpret_cast<cplx<T>*>(basep);
+  lay.ring = reinterpret_cast<T*>(basep + pre_elems * sizeof(cplx<T>));
+  lay.wsyn = lay.ring + ring_elems;
+  lay.asym1 = lay.wsyn + N;
+  lay.asym2 = lay.asym1 + N;
+  lay.extra = basep + fixed_al;
+  SI_HIP(hipMemcpyAsync(lay.wsyn, wsyn.data(), N * sizeof(T), hipMemcpyHostToDevice, pl.stream));
+  SI_HIP(hipMemcpyAsync(lay.asym1, a1.data(), N * sizeof(T), hipMemcpyHostToDevice, pl.stream));
+  SI_HIP(hipMemcpyAsync(lay.asym2, a2.data(), N * sizeof(T), hipMemcpyHostToDevice, pl.stream));
   SI_HIP(hipStreamSynchronize(pl.stream));    // the host vectors go out of scope
+  return SPECINV_OK;
+}
 
-  if constexpr (std::is_same<T, float>::value) {
-    bool used = false;
-    SI_TRY(rtisi_fast_launch(pl, mag_user, la, asym, max_iter, alpha, x_out, d_wsyn, d_a1, d_a2, &used));
-    if (used) return SPECINV_OK;
-  }
-
-  SI_TRY(pl.mag.reserve(pl.nspec() * sizeof(T)));
-  SI_TRY((pl.template transpose<T>(mag_user, pl.mag.template as<T>(), F, Tn)));
-  SI_TRY(pl.frames_needed());
-
-  RtisiArgs<T> r;
-  r.c = pl.fc;
-  r.mag = pl.mag.template as<T>();
-  r.ring = d_ring;
-  r.pre = d_pre;
-  r.frames_out = pl.frames.template as<T>();
-  r.wsyn = d_wsyn;
-  r.asym1 = d_a1;
-  r.asym2 = d_a2;
-  r.keep = keep;
-  r.la = la;
-  r.steps = Tn;
-  r.max_iter = max_iter;
-  r.asym = asym ? 1 : 0;
-  r.lr = (T)(alpha / (1.0 + alpha));                                  // methods.py:360
+// launch geometry of k_rtisi: as many look-ahead frames in flight as LDS (2 FFT buffers per group) and threads
+// (>= 128 per group) allow
+template <typename P, typename T>
+int rtisi_generic_launch(P& pl, RtisiArgs<T>& r) {
+  const int N = pl.N(), hop = pl.cfg.hop_length, la = r.la;
   const int threads = N >= 2048 ? 1024 : (N >= 1024 ? 512 : 256);
-  // as many look-ahead frames in flight as LDS (2 FFT buffers per group) and threads (>= 128 per group) allow
   const size_t xbytes = ((size_t)la * hop + N) * sizeof(T);
   int groups = 1;
   while (groups * 2 <= la + 1 && threads / (groups * 2) >= 128 &&
@@ -245,9 +244,219 @@ int rtisi_launch(P& pl, const T* mag_user, int look_ahead, int asym, int max_ite
   SI_CHECK(lds <= 160 * 1024 - 512, SPECINV_EUNSUPPORTED, "RTISI_LA: n_fft=%d look_ahead=%d needs %zu bytes of LDS", N, la,
            lds);
   SI_HIP(hipFuncSetAttribute((const void*)k_rtisi<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_rtisi<T>), dim3(Bn), dim3(threads), lds, pl.stream, r);
+  hipLaunchKernelGGL((k_rtisi<T>), dim3(pl.B()), dim3(threads), lds, pl.stream, r);
   SI_HIP(hipGetLastError());
+  return SPECINV_OK;
+}
+
+template <typename P, typename T>
+int rtisi_launch(P& pl, const T* mag_user, int look_ahead, int asym, int max_iter, double alpha, T* x_out) {
+  SI_CHECK(mag_user && x_out, SPECINV_EINVAL, "null pointer");
+  SI_CHECK(max_iter > 0, SPECINV_EINVAL, "max_iter must be > 0");     // methods.py:295
+  SI_CHECK(alpha >= 0, SPECINV_EINVAL, "alpha must be >= 0");        // methods.py:296
+  const int F = pl.n_freq, Tn = pl.Tn();
+  RtisiLayout<T> lay;
+  SI_TRY(rtisi_prepare(pl, look_ahead, pl.rt_state, 0, lay));
+  const int la = lay.la;
+
+  if constexpr (std::is_same<T, float>::value) {
+    bool used = false;
+    SI_TRY(rtisi_fast_launch(pl, mag_user, la, asym, max_iter, alpha, x_out, lay.wsyn, lay.asym1, lay.asym2, &used));
+    if (used) return SPECINV_OK;
+  }
+
+  SI_TRY(pl.mag.reserve(pl.nspec() * sizeof(T)));
+  SI_TRY((pl.template transpose<T>(mag_user, pl.mag.template as<T>(), F, Tn)));
+  SI_TRY(pl.frames_needed());
+
+  RtisiArgs<T> r{};
+  r.c = pl.fc;
+  r.mag = pl.mag.template as<T>();
+  r.ring = lay.ring;
+  r.pre = lay.pre;
+  r.frames_out = pl.frames.template as<T>();
+  r.wsyn = lay.wsyn;
+  r.asym1 = lay.asym1;
+  r.asym2 = lay.asym2;
+  r.keep = lay.keep;
+  r.la = la;
+  r.steps = Tn;
+  r.max_iter = max_iter;
+  r.asym = asym ? 1 : 0;
+  r.lr = (T)(alpha / (1.0 + alpha));                                  // methods.py:360
+  r.i_begin = 0;
+  r.i_end = Tn + la;
+  r.resume = 0;
+  r.n_valid = Tn;
+  SI_TRY(rtisi_generic_launch(pl, r));
   return pl.launch_ola(pl.frames.template as<T>(), x_out, true);     // methods.py:406-408
+}
+
+// ---- streaming: the same recursion fed a few frames at a time -------------------------------------------
+// Frame c is committed at step c + la; once it is, the padded samples [c*hop, (c+1)*hop) are final (frame c+1
+// starts at (c+1)*hop).  `commits` holds the last keep+1+cap committed frames (times the window).  The sums run
+// in the order of k_ola and the envelope like PlanT::setup (products in T, sum in double), so the concatenated
+// output equals the whole-signal run of the same kernel bit for bit.
+template <typename T>
+__global__ void k_rtisi_emit(const T* __restrict__ commits, int out_ring, const T* __restrict__ window, int n_fft,
+                             int hop, int64_t np0, int64_t np1, int64_t c_last, T* __restrict__ out, int64_t out_stride) {
+#pragma clang fp contract(off)   // the envelope sums rounded products, like the host loop of PlanT::setup
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np1 - np0) return;
+  const int bi = blockIdx.y;
+  const int64_t np = np0 + i;
+  int64_t t_hi = np / hop;
+  if (t_hi > c_last) t_hi = c_last;
+  const int64_t t_lo = np - n_fft + 1 <= 0 ? 0 : (np - n_fft + hop) / hop;
+  const T* fr = commits + (int64_t)bi * out_ring * n_fft;
+  T acc = 0;
+  double env = 0;
+  for (int64_t t = t_lo; t <= t_hi; ++t) {
+    const int k = (int)(np - t * hop);
+    acc += fr[(t % out_ring) * n_fft + k];
+    const T w2 = window[k] * window[k];
+    env += (double)w2;
+  }
+  out[(int64_t)bi * out_stride + i] = acc / (T)env;
+}
+
+// scatter (B, F, k) user frames into the (B, mag_ring, F) ring at frames t0 .. t0+k-1
+template <typename T>
+__global__ void k_rtisi_store_mag(const T* __restrict__ user, int F, int k, T* __restrict__ ring, int mag_ring, int64_t t0) {
+  __shared__ T tile[32][33];
+  const int bi = blockIdx.z;
+  const int f0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int f = f0 + r, j = j0 + threadIdx.x;
+    if (f < F && j < k) tile[r][threadIdx.x] = user[((int64_t)bi * F + f) * k + j];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int j = j0 + r, f = f0 + threadIdx.x;
+    if (f < F && j < k) ring[((int64_t)bi * mag_ring + (t0 + j) % mag_ring) * F + f] = tile[threadIdx.x][r];
+  }
+}
+
+template <typename T>
+struct RtisiStream {
+  bool active = false, flushed = false;
+  RtisiLayout<T> lay;
+  int asym = 0, max_iter = 0, mag_ring = 0, out_ring = 0;
+  T lr = 0;
+  int64_t steps_done = 0, n_pushed = 0, emitted = 0;   // emitted: next padded sample to hand out
+  T *mags = nullptr, *commits = nullptr;
+};
+
+template <typename P, typename T>
+int rtisi_stream_begin(P& pl, RtisiStream<T>& st, int look_ahead, int asym, int max_iter, double alpha) {
+  SI_CHECK(max_iter > 0, SPECINV_EINVAL, "max_iter must be > 0");
+  SI_CHECK(alpha >= 0, SPECINV_EINVAL, "alpha must be >= 0");
+  const int N = pl.N(), hop = pl.cfg.hop_length, F = pl.n_freq, cap = pl.Tn(), Bn = pl.B();
+  const int keep = (N - 1) / hop;
+  const int la = look_ahead < 0 ? keep : look_ahead;
+  st.mag_ring = la + 1 + cap;
+  st.out_ring = keep + 1 + cap;
+  const size_t mag_bytes = ((size_t)Bn * st.mag_ring * F * sizeof(T) + 63) & ~(size_t)63;
+  const size_t out_bytes = (size_t)Bn * st.out_ring * N * sizeof(T);
+  SI_TRY(rtisi_prepare(pl, look_ahead, pl.rs_state, mag_bytes + out_bytes, st.lay));
+  st.mags = reinterpret_cast<T*>(st.lay.extra);
+  st.commits = reinterpret_cast<T*>(st.lay.extra + mag_bytes);
+  st.asym = asym ? 1 : 0;
+  st.max_iter = max_iter;
+  st.lr = (T)(alpha / (1.0 + alpha));
+  st.steps_done = st.n_pushed = 0;
+  st.emitted = pl.pad;                          // centre trimming: the first pad samples are never handed out
+  st.active = true;
+  st.flushed = false;
+  return SPECINV_OK;
+}
+
+template <typename P, typename T>
+int rtisi_stream_steps(P& pl, RtisiStream<T>& st, int n_steps) {
+  RtisiArgs<T> r{};
+  r.c = pl.fc;
+  r.mag = st.mags;
+  r.ring = st.lay.ring;
+  r.pre = st.lay.pre;
+  r.frames_out = st.commits;
+  r.wsyn = st.lay.wsyn;
+  r.asym1 = st.lay.asym1;
+  r.asym2 = st.lay.asym2;
+  r.keep = st.lay.keep;
+  r.la = st.lay.la;
+  r.steps = 0;
+  r.max_iter = st.max_iter;
+  r.asym = st.asym;
+  r.lr = st.lr;
+  r.i_begin = (int)st.steps_done;
+  r.i_end = (int)st.steps_done + n_steps;
+  r.resume = st.steps_done > 0;
+  r.n_valid = (int)st.n_pushed;
+  r.mag_ring = st.mag_ring;
+  r.out_ring = st.out_ring;
+  SI_TRY(rtisi_generic_launch(pl, r));
+  st.steps_done += n_steps;
+  return SPECINV_OK;
+}
+
+// hand out every padded sample in [st.emitted, upto), appended at column *n_out of x_out
+template <typename P, typename T>
+int rtisi_stream_emit(P& pl, RtisiStream<T>& st, int64_t upto, T* x_out, int64_t out_stride, int64_t* n_out) {
+  const int64_t c_last = st.steps_done - st.lay.la - 1;      // newest committed frame
+  const int64_t n = upto - st.emitted;
+  if (n <= 0) return SPECINV_OK;
+  SI_CHECK(out_stride >= *n_out + n, SPECINV_EINVAL, "out_stride %lld < %lld samples of this call", (long long)out_stride,
+           (long long)(*n_out + n));
+  hipLaunchKernelGGL((k_rtisi_emit<T>), dim3((unsigned)ceil_div(n, 256), pl.B()), dim3(256), 0, pl.stream, st.commits,
+                     st.out_ring, pl.window.template as<T>(), pl.N(), pl.cfg.hop_length, st.emitted, upto, c_last,
+                     x_out + *n_out, out_stride);
+  SI_HIP(hipGetLastError());
+  st.emitted = upto;
+  *n_out += n;
+  return SPECINV_OK;
+}
+
+// samples that are final once `commits` frames are committed and `n_pushed` frames are known to exist
+template <typename P, typename T>
+int64_t rtisi_stream_final(const P& pl, const RtisiStream<T>& st) {
+  const int64_t commits = st.steps_done - st.lay.la;                                 // frames 0 .. commits-1
+  if (commits <= 0) return 0;
+  const int64_t end = (st.n_pushed - 1) * pl.cfg.hop_length + pl.N() - pl.pad;       // right trim if the signal ended here
+  return std::min<int64_t>(commits * pl.cfg.hop_length, end);
+}
+
+template <typename P, typename T>
+int rtisi_stream_push(P& pl, RtisiStream<T>& st, const T* mag_user, int k, T* x_out, int64_t out_stride, int64_t* n_out) {
+  SI_CHECK(st.active && !st.flushed, SPECINV_ESTATE, "rtisi_stream_push without rtisi_stream_begin (or after flush)");
+  SI_CHECK(mag_user && x_out && n_out, SPECINV_EINVAL, "null pointer");
+  SI_CHECK(k >= 1 && k <= pl.Tn(), SPECINV_EINVAL, "push of %d frames, the plan was made for at most %d", k, pl.Tn());
+  SI_CHECK(st.steps_done + k < (int64_t)1 << 30, SPECINV_EUNSUPPORTED, "stream too long");
+  *n_out = 0;
+  const int F = pl.n_freq;
+  hipLaunchKernelGGL((k_rtisi_store_mag<T>), dim3((k + 31) / 32, (F + 31) / 32, pl.B()), dim3(32, 8), 0, pl.stream, mag_user,
+                     F, k, st.mags, st.mag_ring, st.n_pushed);
+  SI_HIP(hipGetLastError());
+  st.n_pushed += k;
+  SI_TRY(rtisi_stream_steps(pl, st, k));
+  return rtisi_stream_emit(pl, st, rtisi_stream_final(pl, st), x_out, out_stride, n_out);
+}
+
+// end of the signal: la more steps (their new look-ahead slots see zero targets) and the tail of the last frames
+template <typename P, typename T>
+int rtisi_stream_flush(P& pl, RtisiStream<T>& st, T* x_out, int64_t out_stride, int64_t* n_out) {
+  SI_CHECK(st.active && !st.flushed, SPECINV_ESTATE, "rtisi_stream_flush without rtisi_stream_begin (or twice)");
+  SI_CHECK(x_out && n_out, SPECINV_EINVAL, "null pointer");
+  SI_CHECK(st.n_pushed >= 1, SPECINV_ESTATE, "rtisi_stream_flush before any frame was pushed");
+  *n_out = 0;
+  for (int left = st.lay.la; left > 0;) {       // the ring of committed frames takes Tn() new frames per launch
+    const int n = std::min(left, pl.Tn());
+    SI_TRY(rtisi_stream_steps(pl, st, n));
+    SI_TRY(rtisi_stream_emit(pl, st, rtisi_stream_final(pl, st), x_out, out_stride, n_out));
+    left -= n;
+  }
+  st.flushed = true;
+  const int64_t total = (st.n_pushed - 1) * pl.cfg.hop_length + pl.N() - pl.pad;
+  return rtisi_stream_emit(pl, st, total, x_out, out_stride, n_out);
 }
 
 }  // namespace specinv

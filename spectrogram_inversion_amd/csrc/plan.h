@@ -52,6 +52,9 @@ struct PlanBase {
   virtual int phase_init_adjoint(const void* mag, const void* g_spec, void* gmag) = 0;
 
   virtual int rtisi_run(const void* mag, int look_ahead, int asym, int max_iter, double alpha, void* x_out) = 0;
+  virtual int rtisi_stream_begin(int look_ahead, int asym, int max_iter, double alpha) = 0;
+  virtual int rtisi_stream_push(const void* mag, int k, void* x_out, int64_t out_stride, int64_t* n_out) = 0;
+  virtual int rtisi_stream_flush(void* x_out, int64_t out_stride, int64_t* n_out) = 0;
 
   virtual int transform_setup(int kind, const void* mel_fb, int n_mels) = 0;
   virtual int transform_forward(const void* x, int64_t len, void* v_out) = 0;

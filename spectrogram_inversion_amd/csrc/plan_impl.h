@@ -66,6 +66,8 @@ struct PlanT final : PlanBase {
   DevBuf window, tw, env;
   DevBuf x, frames, specA, specB, mag, partials, sums, tmp_spec, tmp_real;
   DevBuf rt_state;                      // RTISI per-item state
+  DevBuf rs_state;                      // ... of the streaming recursion (survives between pushes)
+  RtisiStream<T> rstream;
   DevBuf lb_scal;                       // device scalars of the L-BFGS two-loop recursion
   DevBuf eval_log;                      // per-evaluation sums of a run with deferred read-back
   DevBuf tf_mel, tf_spec, tf_v;         // transform (L_BFGS) scratch
@@ -546,6 +548,16 @@ struct PlanT final : PlanBase {
 
   int rtisi_run(const void* magp, int look_ahead, int asym, int max_iter, double alpha, void* x_out) override {
     return rtisi_launch(*this, static_cast<const T*>(magp), look_ahead, asym, max_iter, alpha, static_cast<T*>(x_out));
+  }
+
+  int rtisi_stream_begin(int look_ahead, int asym, int max_iter, double alpha) override {
+    return specinv::rtisi_stream_begin(*this, rstream, look_ahead, asym, max_iter, alpha);
+  }
+  int rtisi_stream_push(const void* magp, int k, void* x_out, int64_t out_stride, int64_t* n_out) override {
+    return specinv::rtisi_stream_push(*this, rstream, static_cast<const T*>(magp), k, static_cast<T*>(x_out), out_stride, n_out);
+  }
+  int rtisi_stream_flush(void* x_out, int64_t out_stride, int64_t* n_out) override {
+    return specinv::rtisi_stream_flush(*this, rstream, static_cast<T*>(x_out), out_stride, n_out);
   }
 
   // ------------------------------------------------------------------------------------

@@ -269,6 +269,19 @@ int specinv_rtisi_run(specinv_plan* plan, const void* mag, int look_ahead, int a
   return plan->impl->rtisi_run(mag, look_ahead, asymmetric_window, max_iter, alpha, x_out);
 }
 
+int specinv_rtisi_stream_begin(specinv_plan* plan, int look_ahead, int asymmetric_window, int max_iter, double alpha) {
+  ENTER(plan);
+  return plan->impl->rtisi_stream_begin(look_ahead, asymmetric_window, max_iter, alpha);
+}
+int specinv_rtisi_stream_push(specinv_plan* plan, const void* mag, int k, void* x_out, int64_t out_stride, int64_t* n_out) {
+  ENTER(plan);
+  return plan->impl->rtisi_stream_push(mag, k, x_out, out_stride, n_out);
+}
+int specinv_rtisi_stream_flush(specinv_plan* plan, void* x_out, int64_t out_stride, int64_t* n_out) {
+  ENTER(plan);
+  return plan->impl->rtisi_stream_flush(x_out, out_stride, n_out);
+}
+
 int specinv_transform_setup(specinv_plan* plan, int kind, const void* mel_fb, int n_mels) {
   ENTER(plan);
   return plan->impl->transform_setup(kind, mel_fb, n_mels);

@@ -300,6 +300,29 @@ class Plan:
                                               int(max_iter), float(alpha), out.data_ptr()))
         return out
 
+    # -- streaming RTISI-LA (the plan's n_frames = most frames per push) ------------------------
+    def rtisi_stream_begin(self, look_ahead, asymmetric_window, max_iter, alpha):
+        self._sync_stream()
+        _lib.check(self.lib.specinv_rtisi_stream_begin(self._h, int(look_ahead), int(bool(asymmetric_window)),
+                                                       int(max_iter), float(alpha)))
+
+    def rtisi_stream_push(self, mag: torch.Tensor) -> torch.Tensor:
+        self._sync_stream()
+        k = int(mag.shape[2])
+        mag = self._in(mag, self.dtype, (self.batch, self.n_freq, k))
+        out = torch.empty((self.batch, k * self.args.hop_length), dtype=self.dtype, device=self.device)
+        n = C.c_int64(0)
+        _lib.check(self.lib.specinv_rtisi_stream_push(self._h, mag.data_ptr(), k, out.data_ptr(), out.shape[1], C.byref(n)))
+        return out[:, :n.value]
+
+    def rtisi_stream_flush(self, look_ahead: int) -> torch.Tensor:
+        self._sync_stream()
+        cap = look_ahead * self.args.hop_length + self.args.n_fft
+        out = torch.empty((self.batch, cap), dtype=self.dtype, device=self.device)
+        n = C.c_int64(0)
+        _lib.check(self.lib.specinv_rtisi_stream_flush(self._h, out.data_ptr(), cap, C.byref(n)))
+        return out[:, :n.value]
+
     # -- L_BFGS building blocks -------------------------------------------------------------
     def transform_setup(self, kind: int, mel_fb: torch.Tensor | None = None):
         self._sync_stream()
