@@ -154,6 +154,16 @@ int specinv_phase_init_adjoint(specinv_plan* plan, const void* mag, const void* 
 int specinv_rtisi_run(specinv_plan* plan, const void* mag, int look_ahead, int asymmetric_window,
                       int max_iter, double alpha, void* x_out);
 
+/* RTISI_LA with a gradient (the reference's result is differentiable w.r.t. spec: test/test_rtisila.py:58-70).
+ * `_run_recorded` is specinv_rtisi_run on the generic kernel that also stores every pre-projection spectrum in
+ * `rec` (specinv_rtisi_record_elems() complex numbers of the plan's dtype); `_adjoint` sweeps the recursion
+ * backwards: g_x (B, L) -> gmag_out (B, F, T), overwritten. */
+int specinv_rtisi_record_elems(specinv_plan* plan, int look_ahead, int max_iter, int64_t* n_complex_out);
+int specinv_rtisi_run_recorded(specinv_plan* plan, const void* mag, int look_ahead, int asymmetric_window, int max_iter,
+                               double alpha, void* x_out, void* rec_out);
+int specinv_rtisi_adjoint(specinv_plan* plan, const void* mag, const void* rec, const void* g_x, int look_ahead,
+                          int asymmetric_window, int max_iter, double alpha, void* gmag_out);
+
 /* Streaming RTISI-LA: the recursion of methods.py:363-404 fed a few frames at a time (what "real-time" in its name
  * is about, :275-278).  The plan's n_frames is the largest number of frames one push may carry; the stream length
  * is open-ended.  `push` takes (B, F, k) magnitudes and appends the samples that became final to x_out (row b at

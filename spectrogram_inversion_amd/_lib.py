@@ -70,6 +70,9 @@ SIGNATURES = {
     "specinv_stft_adjoint": (C.c_int, [_P, _P, _I64, _P]),
     "specinv_phase_init_adjoint": (C.c_int, [_P, _P, _P, _P]),
     "specinv_rtisi_run": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _D, _P]),
+    "specinv_rtisi_record_elems": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "specinv_rtisi_run_recorded": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _D, _P, _P]),
+    "specinv_rtisi_adjoint": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _D, _P]),
     "specinv_rtisi_stream_begin": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D]),
     "specinv_rtisi_stream_push": (C.c_int, [_P, _P, C.c_int, _P, _I64, C.POINTER(C.c_int64)]),
     "specinv_rtisi_stream_flush": (C.c_int, [_P, _P, _I64, C.POINTER(C.c_int64)]),

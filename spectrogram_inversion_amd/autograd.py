@@ -1,4 +1,4 @@
-"""Differentiable Griffin-Lim / ADMM: d(waveform)/d(spectrogram) like the reference's autograd path
+"""Differentiable Griffin-Lim / ADMM / RTISI-LA: d(waveform)/d(spectrogram) like the reference's autograd path
 (`spec.requires_grad=True`, test/test_griffin.py:54,65-66; README.md:8-9 advertises use inside training).
 
 The forward pass records the per-iteration spectra and is assembled from libspecinv's building blocks
@@ -135,6 +135,28 @@ class _ADMMFn(torch.autograd.Function):
             gc = gc + gX                                               # X0 = C0 (U0 = 0 is a constant)
         ctx.saved_spectra = None
         return _input_grad(ctx, plan, mag, c0, gc, gm), None, None, None, None, None, None, None
+
+
+class _RtisiFn(torch.autograd.Function):
+    """`RTISI_LA` (methods.py:363-404): the recorded run and the backward sweep are one persistent kernel each."""
+
+    @staticmethod
+    def forward(ctx, spec3, plan, look_ahead, asym, max_iter, alpha):
+        mag = spec3.detach().contiguous()
+        x, rec = plan.rtisi_recorded(mag, look_ahead, asym, max_iter, alpha)
+        ctx.plan, ctx.cfg = plan, (look_ahead, asym, max_iter, alpha)
+        ctx.save_for_backward(mag, rec)
+        return x
+
+    @staticmethod
+    def backward(ctx, g_y):
+        mag, rec = ctx.saved_tensors
+        gm = ctx.plan.rtisi_adjoint(mag, rec, g_y.detach().contiguous(), *ctx.cfg)
+        return gm, None, None, None, None, None
+
+
+def rtisi_differentiable(spec3, plan, look_ahead, asym, max_iter, alpha):
+    return _RtisiFn.apply(spec3, plan, look_ahead, asym, max_iter, alpha)
 
 
 def admm_differentiable(spec3, plan, rho, max_iter, tol, eva_iter, metric, on_eval=None):

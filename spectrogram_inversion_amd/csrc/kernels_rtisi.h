@@ -37,6 +37,7 @@ struct RtisiArgs {
   int n_valid;       // target frames that exist so far (look-ahead slots beyond them see a zero target, methods.py:339)
   int mag_ring;      // 0: mag is (B, steps, F); else (B, mag_ring, F) indexed by frame % mag_ring
   int out_ring;      // 0: frames_out is (B, steps, N); else (B, out_ring, N) indexed by frame % out_ring
+  cplx<T>* rec;      // NULL, or (B, steps+la, max_iter, la+1, F): every pre-projection spectrum, for the adjoint
 };
 
 template <typename T>
@@ -130,6 +131,8 @@ __global__ void k_rtisi(RtisiArgs<T> r) {
               s = mk<T>(s.x - r.lr * p.x, s.y - r.lr * p.y);
             }
             pre_out[(int64_t)q * F + f] = s;    // :392
+            if (r.rec)
+              r.rec[((((int64_t)bi * (r.steps + r.la) + i) * r.max_iter + j) * (r.la + 1) + q) * F + f] = s;
             const T m = valid ? mag[(int64_t)mrow * F + f] : T(0);
             const T inv = T(1) / (si_hypot(s.x, s.y) + eps16<T>::value);     // :394
             pa[f] = mk<T>((s.x * m) * inv, (s.y * m) * inv);                  // :395-396
@@ -290,6 +293,234 @@ int rtisi_launch(P& pl, const T* mag_user, int look_ahead, int asym, int max_ite
   r.n_valid = Tn;
   SI_TRY(rtisi_generic_launch(pl, r));
   return pl.launch_ola(pl.frames.template as<T>(), x_out, true);     // methods.py:406-408
+}
+
+// ---- gradient w.r.t. the magnitudes (the reference's result is differentiable: test/test_rtisila.py:58-70) ---------
+// Reverse sweep over the recorded run: one workgroup per item walks the (steps+la)*max_iter inner steps backwards.
+// Cotangents: g_ring (every ring frame), g_pre (double-buffered like pre), gx (the overlap-added look-ahead span, LDS).
+template <typename T>
+struct RtisiAdjArgs {
+  FrameCfg<T> c;
+  const T* mag;          // (B, T, F)
+  const cplx<T>* rec;    // recorded pre-projection spectra
+  const T* g_x;          // (B, L) cotangent of the waveform
+  const T* env;          // (L,)
+  T* g_ring;             // (B, K+LA+1, N)
+  cplx<T>* g_pre;        // (B, 2, LA+1, F)
+  T* gmag;               // (B, T, F), zero on entry
+  const T *wsyn, *asym1, *asym2;
+  int keep, la, steps, max_iter, asym;
+  T lr;
+};
+
+template <typename T>
+__global__ void k_rtisi_adjoint(RtisiAdjArgs<T> r) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FrameCfg<T>& c = r.c;
+  const int N = c.n_fft, F = c.n_freq, hop = c.hop;
+  cplx<T>* pa = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* pb = pa + N;
+  T* gxb = reinterpret_cast<T*>(pb + N);            // la*hop + N
+  const int bi = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int nslots = r.keep + r.la + 1, xlen = r.la * hop + N;
+  T* g_ring = r.g_ring + (int64_t)bi * nslots * N;
+  cplx<T>* g_pre = r.g_pre + (int64_t)bi * 2 * (r.la + 1) * F;
+  const T* mag = r.mag + (int64_t)bi * r.steps * F;
+  T* gmag = r.gmag + (int64_t)bi * r.steps * F;
+  const T* g_x = r.g_x + (int64_t)bi * c.length;
+  const cplx<T>* rec = r.rec + (int64_t)bi * (r.steps + r.la) * r.max_iter * (r.la + 1) * F;
+
+  for (int i = tid; i < nslots * N; i += nt) g_ring[i] = T(0);
+  for (int i = tid; i < 2 * (r.la + 1) * F; i += nt) g_pre[i] = mk<T>(T(0), T(0));
+  __syncthreads();
+
+  for (int i = r.steps + r.la - 1; i >= 0; --i) {
+    const int base = i % nslots;
+    // the slot that became the next step's (zero) newest frame was this step's oldest kept frame: nothing flows back
+    for (int k = tid; k < N; k += nt) g_ring[(int64_t)base * N + k] = T(0);
+    if (i >= r.la) {                                 // commit: frames_out[i-la] = ring[keep] * window, then k_ola / env
+      int s0 = base + r.keep;
+      if (s0 >= nslots) s0 -= nslots;
+      const int64_t off = (int64_t)(i - r.la) * hop - c.pad;
+      for (int k = tid; k < N; k += nt) {
+        const int64_t n = off + k;
+        if (n >= 0 && n < c.length) g_ring[(int64_t)s0 * N + k] += g_x[n] / r.env[n] * c.window[k];
+      }
+    }
+    __syncthreads();
+    for (int j = r.max_iter - 1; j >= 0; --j) {
+      const int64_t sidx = (int64_t)i * r.max_iter + j;
+      const int pin = (int)(sidx & 1);
+      cplx<T>* gp_out = g_pre + (int64_t)(pin ^ 1) * (r.la + 1) * F;   // cotangent of what this inner step wrote
+      cplx<T>* gp_in = g_pre + (int64_t)pin * (r.la + 1) * F;          // ... of what it read
+      for (int n = tid; n < xlen; n += nt) gxb[n] = T(0);
+      if (j == 0)
+        for (int f = tid; f < F; f += nt) gp_in[f] = mk<T>(T(0), T(0));   // slot 0 of the shifted momentum is unused
+      __syncthreads();
+      for (int q = 0; q <= r.la; ++q) {
+        int slot = base + r.keep + q;
+        if (slot >= nslots) slot -= nslots;
+        T* gfr = g_ring + (int64_t)slot * N;
+        // ring[slot] = inv_scale * Re IDFT(Hermitian(Y))   =>   gY = inv_scale * (interior ? 2 : Re) DFT(g)
+        for (int k = tid; k < N; k += nt) {
+          pa[k] = mk<T>(gfr[k], T(0));
+          gfr[k] = T(0);                              // the frame was overwritten: its old value only fed the overlap-add
+        }
+        __syncthreads();
+        lds_fft(pa, pb, c, false);
+        const int tt = i + q - r.la;
+        const bool valid = tt >= 0 && tt < r.steps;
+        const cplx<T>* srow = rec + (sidx * (r.la + 1) + q) * F;
+        for (int f = tid; f < F; f += nt) {
+          cplx<T> gy = pa[f];
+          if (c.onesided) {
+            if (f == 0 || 2 * f == N) gy = mk<T>(gy.x * c.inv_scale, T(0));
+            else gy = mk<T>(gy.x * (2 * c.inv_scale), gy.y * (2 * c.inv_scale));
+          } else {
+            gy = mk<T>(gy.x * c.inv_scale, gy.y * c.inv_scale);
+          }
+          // Y = S m / (|S| + eps)   (methods.py:394-396)
+          const cplx<T> sv = srow[f];
+          const T m = valid ? mag[(int64_t)tt * F + f] : T(0);
+          const T ab = si_hypot(sv.x, sv.y);
+          const T d = ab + eps16<T>::value;
+          const T dot = gy.x * sv.x + gy.y * sv.y;
+          const T c1 = m / d;
+          const T c2 = ab > T(0) ? dot * m / (d * d * ab) : T(0);
+          cplx<T> gs = mk<T>(gy.x * c1 - sv.x * c2, gy.y * c1 - sv.y * c2);
+          if (valid) gmag[(int64_t)tt * F + f] += dot / d;
+          // pre_out[q] = S                                  (:392)
+          const cplx<T> gpo = gp_out[(int64_t)q * F + f];
+          gs = mk<T>(gs.x + gpo.x, gs.y + gpo.y);
+          // S = R - lr * pre_in[q] (j > 0)  |  R - lr * pre_in[q+1] (j == 0, i > 0, q < la)   (:387-391)
+          if (j) gp_in[(int64_t)q * F + f] = mk<T>(-r.lr * gs.x, -r.lr * gs.y);
+          else if (q < r.la) gp_in[(int64_t)(q + 1) * F + f] = i ? mk<T>(-r.lr * gs.x, -r.lr * gs.y) : mk<T>(T(0), T(0));
+          // R = fwd_scale * DFT(frame): stored bins only -> halve the interior ones before the Hermitian inverse
+          if (c.onesided && f != 0 && 2 * f != N) gs = mk<T>(gs.x * T(0.5), gs.y * T(0.5));
+          pa[f] = gs;
+        }
+        __syncthreads();
+        if (c.onesided) {
+          for (int f = tid; f <= N / 2; f += nt) {
+            const cplx<T> v = pa[f];
+            if (f == 0 || 2 * f == N) pa[f] = mk<T>(v.x, T(0));
+            else pa[N - f] = conj(v);
+          }
+          __syncthreads();
+        }
+        lds_fft(pa, pb, c, true);
+        const T* win = (r.asym && q == r.la) ? (j ? r.asym2 : r.asym1) : c.window;
+        for (int k = tid; k < N; k += nt) gxb[q * hop + k] += pa[k].x * c.fwd_scale * win[k];
+        __syncthreads();
+      }
+      // x[n] = sum_f ring[f][n - f*hop] * wsyn[...]  over every slot, n in [keep*hop, keep*hop + xlen)
+      for (int e = tid; e < nslots * N; e += nt) {
+        const int f = e / N, k = e - f * N;
+        const int np = f * hop + k - r.keep * hop;
+        if (np >= 0 && np < xlen) {
+          int slot = base + f;
+          if (slot >= nslots) slot -= nslots;
+          g_ring[(int64_t)slot * N + k] += gxb[np] * r.wsyn[k];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // initial state: newest slot = inv_scale * Re IDFT(Hermitian(mag[0] + 0j))   (methods.py:353-358)
+  {
+    const T* gfr = g_ring + (int64_t)(nslots - 1) * N;
+    for (int k = tid; k < N; k += nt) pa[k] = mk<T>(gfr[k], T(0));
+    __syncthreads();
+    lds_fft(pa, pb, c, false);
+    for (int f = tid; f < F; f += nt) {
+      const T sc = (c.onesided && f != 0 && 2 * f != N) ? 2 * c.inv_scale : c.inv_scale;
+      gmag[f] += pa[f].x * sc;
+    }
+  }
+}
+
+template <typename T>
+inline int64_t rtisi_record_elems(int batch, int n_frames, int n_freq, int n_fft, int hop, int look_ahead, int max_iter) {
+  const int keep = (n_fft - 1) / hop;
+  const int la = look_ahead < 0 ? keep : look_ahead;
+  return (int64_t)batch * (n_frames + la) * max_iter * (la + 1) * n_freq;
+}
+
+// whole-signal run on the generic kernel that also records what the adjoint needs
+template <typename P, typename T>
+int rtisi_launch_recorded(P& pl, const T* mag_user, int look_ahead, int asym, int max_iter, double alpha, T* x_out,
+                          cplx<T>* rec) {
+  SI_CHECK(mag_user && x_out && rec, SPECINV_EINVAL, "null pointer");
+  SI_CHECK(max_iter > 0, SPECINV_EINVAL, "max_iter must be > 0");
+  SI_CHECK(alpha >= 0, SPECINV_EINVAL, "alpha must be >= 0");
+  const int F = pl.n_freq, Tn = pl.Tn();
+  RtisiLayout<T> lay;
+  SI_TRY(rtisi_prepare(pl, look_ahead, pl.rt_state, 0, lay));
+  SI_TRY(pl.mag.reserve(pl.nspec() * sizeof(T)));
+  SI_TRY((pl.template transpose<T>(mag_user, pl.mag.template as<T>(), F, Tn)));
+  SI_TRY(pl.frames_needed());
+  RtisiArgs<T> r{};
+  r.c = pl.fc;
+  r.mag = pl.mag.template as<T>();
+  r.ring = lay.ring;
+  r.pre = lay.pre;
+  r.frames_out = pl.frames.template as<T>();
+  r.wsyn = lay.wsyn;
+  r.asym1 = lay.asym1;
+  r.asym2 = lay.asym2;
+  r.keep = lay.keep;
+  r.la = lay.la;
+  r.steps = Tn;
+  r.max_iter = max_iter;
+  r.asym = asym ? 1 : 0;
+  r.lr = (T)(alpha / (1.0 + alpha));
+  r.i_begin = 0;
+  r.i_end = Tn + lay.la;
+  r.n_valid = Tn;
+  r.rec = rec;
+  SI_TRY(rtisi_generic_launch(pl, r));
+  return pl.launch_ola(pl.frames.template as<T>(), x_out, true);
+}
+
+template <typename P, typename T>
+int rtisi_adjoint_launch(P& pl, const T* mag_user, const cplx<T>* rec, const T* g_x, int look_ahead, int asym, int max_iter,
+                         double alpha, T* gmag_user) {
+  SI_CHECK(mag_user && rec && g_x && gmag_user, SPECINV_EINVAL, "null pointer");
+  SI_CHECK(max_iter > 0 && alpha >= 0, SPECINV_EINVAL, "bad max_iter / alpha");
+  const int N = pl.N(), hop = pl.cfg.hop_length, F = pl.n_freq, Tn = pl.Tn();
+  RtisiLayout<T> lay;     // same layout as the forward: ring -> g_ring, pre -> g_pre
+  const size_t gm_bytes = (size_t)pl.nspec() * sizeof(T);
+  SI_TRY(rtisi_prepare(pl, look_ahead, pl.rt_state, gm_bytes, lay));
+  SI_TRY(pl.mag.reserve(pl.nspec() * sizeof(T)));
+  SI_TRY((pl.template transpose<T>(mag_user, pl.mag.template as<T>(), F, Tn)));
+  T* gm = reinterpret_cast<T*>(lay.extra);
+  SI_HIP(hipMemsetAsync(gm, 0, gm_bytes, pl.stream));
+  RtisiAdjArgs<T> r{};
+  r.c = pl.fc;
+  r.mag = pl.mag.template as<T>();
+  r.rec = rec;
+  r.g_x = g_x;
+  r.env = pl.env.template as<T>();
+  r.g_ring = lay.ring;
+  r.g_pre = lay.pre;
+  r.gmag = gm;
+  r.wsyn = lay.wsyn;
+  r.asym1 = lay.asym1;
+  r.asym2 = lay.asym2;
+  r.keep = lay.keep;
+  r.la = lay.la;
+  r.steps = Tn;
+  r.max_iter = max_iter;
+  r.asym = asym ? 1 : 0;
+  r.lr = (T)(alpha / (1.0 + alpha));
+  const int threads = N >= 2048 ? 1024 : (N >= 1024 ? 512 : 256);
+  const size_t lds = 2 * (size_t)N * sizeof(cplx<T>) + ((size_t)lay.la * hop + N) * sizeof(T);
+  SI_CHECK(lds <= 160 * 1024 - 512, SPECINV_EUNSUPPORTED, "RTISI_LA adjoint: n_fft=%d look_ahead=%d needs %zu bytes of LDS", N,
+           lay.la, lds);
+  SI_HIP(hipFuncSetAttribute((const void*)k_rtisi_adjoint<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_rtisi_adjoint<T>), dim3(pl.B()), dim3(threads), lds, pl.stream, r);
+  SI_HIP(hipGetLastError());
+  return pl.template transpose<T>(gm, gmag_user, Tn, F);
 }
 
 // ---- streaming: the same recursion fed a few frames at a time -------------------------------------------

@@ -52,6 +52,11 @@ struct PlanBase {
   virtual int phase_init_adjoint(const void* mag, const void* g_spec, void* gmag) = 0;
 
   virtual int rtisi_run(const void* mag, int look_ahead, int asym, int max_iter, double alpha, void* x_out) = 0;
+  virtual int rtisi_record_elems(int look_ahead, int max_iter, int64_t* out) = 0;
+  virtual int rtisi_run_recorded(const void* mag, int look_ahead, int asym, int max_iter, double alpha, void* x_out,
+                                 void* rec_out) = 0;
+  virtual int rtisi_adjoint(const void* mag, const void* rec, const void* g_x, int look_ahead, int asym, int max_iter,
+                            double alpha, void* gmag_out) = 0;
   virtual int rtisi_stream_begin(int look_ahead, int asym, int max_iter, double alpha) = 0;
   virtual int rtisi_stream_push(const void* mag, int k, void* x_out, int64_t out_stride, int64_t* n_out) = 0;
   virtual int rtisi_stream_flush(void* x_out, int64_t out_stride, int64_t* n_out) = 0;

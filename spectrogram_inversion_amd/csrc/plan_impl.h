@@ -550,6 +550,22 @@ struct PlanT final : PlanBase {
     return rtisi_launch(*this, static_cast<const T*>(magp), look_ahead, asym, max_iter, alpha, static_cast<T*>(x_out));
   }
 
+  int rtisi_record_elems(int look_ahead, int max_iter, int64_t* out) override {
+    SI_CHECK(out && max_iter > 0, SPECINV_EINVAL, "bad arguments");
+    *out = specinv::rtisi_record_elems<T>(B(), Tn(), n_freq, N(), cfg.hop_length, look_ahead, max_iter);
+    return SPECINV_OK;
+  }
+  int rtisi_run_recorded(const void* magp, int look_ahead, int asym, int max_iter, double alpha, void* x_out,
+                         void* rec_out) override {
+    return rtisi_launch_recorded(*this, static_cast<const T*>(magp), look_ahead, asym, max_iter, alpha,
+                                 static_cast<T*>(x_out), static_cast<C*>(rec_out));
+  }
+  int rtisi_adjoint(const void* magp, const void* rec, const void* g_x, int look_ahead, int asym, int max_iter, double alpha,
+                    void* gmag_out) override {
+    return rtisi_adjoint_launch(*this, static_cast<const T*>(magp), static_cast<const C*>(rec), static_cast<const T*>(g_x),
+                                look_ahead, asym, max_iter, alpha, static_cast<T*>(gmag_out));
+  }
+
   int rtisi_stream_begin(int look_ahead, int asym, int max_iter, double alpha) override {
     return specinv::rtisi_stream_begin(*this, rstream, look_ahead, asym, max_iter, alpha);
   }

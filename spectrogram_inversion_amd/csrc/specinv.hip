@@ -269,6 +269,20 @@ int specinv_rtisi_run(specinv_plan* plan, const void* mag, int look_ahead, int a
   return plan->impl->rtisi_run(mag, look_ahead, asymmetric_window, max_iter, alpha, x_out);
 }
 
+int specinv_rtisi_record_elems(specinv_plan* plan, int look_ahead, int max_iter, int64_t* n_complex_out) {
+  ENTER(plan);
+  return plan->impl->rtisi_record_elems(look_ahead, max_iter, n_complex_out);
+}
+int specinv_rtisi_run_recorded(specinv_plan* plan, const void* mag, int look_ahead, int asymmetric_window, int max_iter,
+                               double alpha, void* x_out, void* rec_out) {
+  ENTER(plan);
+  return plan->impl->rtisi_run_recorded(mag, look_ahead, asymmetric_window, max_iter, alpha, x_out, rec_out);
+}
+int specinv_rtisi_adjoint(specinv_plan* plan, const void* mag, const void* rec, const void* g_x, int look_ahead,
+                          int asymmetric_window, int max_iter, double alpha, void* gmag_out) {
+  ENTER(plan);
+  return plan->impl->rtisi_adjoint(mag, rec, g_x, look_ahead, asymmetric_window, max_iter, alpha, gmag_out);
+}
 int specinv_rtisi_stream_begin(specinv_plan* plan, int look_ahead, int asymmetric_window, int max_iter, double alpha) {
   ENTER(plan);
   return plan->impl->rtisi_stream_begin(look_ahead, asymmetric_window, max_iter, alpha);

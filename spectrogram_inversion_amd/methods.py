@@ -7,8 +7,8 @@ Differences that are deliberate:
   * compute always happens on the HIP device.  Tensors that live on the CPU are
     staged to the current HIP device and the result is returned on the input's
     device; without a GPU the functions raise (there is no CPU fallback).
-  * `griffin_lim` and `ADMM` are differentiable w.r.t. `spec` (recorded forward + hand-written adjoints,
-    see autograd.py); `RTISI_LA` results are not.
+  * `griffin_lim`, `ADMM` and `RTISI_LA` are differentiable w.r.t. `spec` (recorded forward + hand-written
+    adjoint kernels, see autograd.py).
 """
 from __future__ import annotations
 
@@ -113,7 +113,11 @@ def RTISI_LA(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, alpha=0.
     args = args_helper(spec3, **stft_kwargs)
     device = require_gpu(spec3.device)
     plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
-    x = plan.rtisi(spec3, look_ahead, asymmetric_window, max_iter, alpha)
+    if torch.is_grad_enabled() and spec.requires_grad:
+        from .autograd import rtisi_differentiable
+        x = rtisi_differentiable(spec3.to(device), plan, look_ahead, asymmetric_window, max_iter, alpha)
+    else:
+        x = plan.rtisi(spec3, look_ahead, asymmetric_window, max_iter, alpha)
     return _finish(x, spec, spec.device)
 
 

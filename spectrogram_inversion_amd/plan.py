@@ -300,6 +300,26 @@ class Plan:
                                               int(max_iter), float(alpha), out.data_ptr()))
         return out
 
+    def rtisi_recorded(self, mag, look_ahead, asymmetric_window, max_iter, alpha):
+        """RTISI_LA on the generic kernel, also returning the record the adjoint needs."""
+        self._sync_stream()
+        mag = self._in(mag, self.dtype, self._spec_shape())
+        n = C.c_int64(0)
+        _lib.check(self.lib.specinv_rtisi_record_elems(self._h, int(look_ahead), int(max_iter), C.byref(n)))
+        rec = torch.empty(n.value, dtype=self.cdtype, device=self.device)
+        out = torch.empty((self.batch, self.length), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.specinv_rtisi_run_recorded(self._h, mag.data_ptr(), int(look_ahead), int(bool(asymmetric_window)),
+                                                       int(max_iter), float(alpha), out.data_ptr(), rec.data_ptr()))
+        return out, rec
+
+    def rtisi_adjoint(self, mag, rec, g_x, look_ahead, asymmetric_window, max_iter, alpha):
+        self._sync_stream()
+        g_x = self._in(g_x, self.dtype, (self.batch, self.length))
+        gmag = torch.empty(self._spec_shape(), dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.specinv_rtisi_adjoint(self._h, mag.data_ptr(), rec.data_ptr(), g_x.data_ptr(), int(look_ahead),
+                                                  int(bool(asymmetric_window)), int(max_iter), float(alpha), gmag.data_ptr()))
+        return gmag
+
     # -- streaming RTISI-LA (the plan's n_frames = most frames per push) ------------------------
     def rtisi_stream_begin(self, look_ahead, asymmetric_window, max_iter, alpha):
         self._sync_stream()

@@ -485,9 +485,53 @@ def g11_autograd_admm():
     save("g11_autograd_admm", **out)
 
 
+def g12_autograd_rtisi():
+    """Gradients of the reference's RTISI_LA w.r.t. the magnitudes (torch autograd; test/test_rtisila.py:58-70)."""
+    out = {}
+    rng = np.random.default_rng(112)
+    cases = [("f64_la_default_asym", np.float64, 128, 32, -1, True, 0.99, 2, dict()),
+             ("f64_la_default_sym", np.float64, 128, 32, -1, False, 0.99, 2, dict()),
+             ("f64_la0", np.float64, 128, 32, 0, True, 0.5, 3, dict()),
+             ("f64_la1_hop50", np.float64, 128, 50, 1, True, 0.99, 2, dict()),
+             ("f64_la5_alpha0", np.float64, 64, 16, 5, False, 0.0, 2, dict()),
+             ("f64_twosided_norm", np.float64, 64, 16, 2, True, 0.99, 2, dict(onesided=False, normalized=True)),
+             ("f64_rect_default", np.float64, 64, None, -1, True, 0.99, 1, dict()),
+             ("f32_la2", np.float32, 128, 32, 2, True, 0.99, 2, dict())]
+    meta = []
+    for tag, dt, n_fft, hop, la, asym, alpha, iters, extra in cases:
+        F_ = n_fft if extra.get("onesided") is False else n_fft // 2 + 1
+        mag = (rng.random((2, F_, 9)) + 0.05).astype(dt)
+        kw = dict(extra)
+        if hop:
+            kw["hop_length"] = hop
+        if tag != "f64_rect_default":
+            kw["window"] = t(hann(n_fft, dt))
+        spec = t(mag).requires_grad_(True)
+        y = M.RTISI_LA(spec, look_ahead=la, asymmetric_window=asym, max_iter=iters, alpha=alpha, verbose=False, **kw)
+        wv = rng.standard_normal(tuple(y.shape)).astype(dt)
+        (y * t(wv)).sum().backward()
+        out[f"mag_{tag}"], out[f"w_{tag}"] = mag, wv
+        out[f"y_{tag}"], out[f"grad_{tag}"] = y.detach().numpy(), spec.grad.numpy()
+        meta.append(f"{tag}|{n_fft}|{hop or 0}|{la}|{int(asym)}|{alpha}|{iters}|{int(extra.get('onesided', True))}|"
+                    f"{int(extra.get('normalized', False))}")
+    out["meta"] = np.array(meta)
+    # the reference's own test pattern (test/test_rtisila.py:46-70)
+    x = rng.standard_normal(2000).astype(np.float32)
+    sp = torch.stft(t(x), 256, return_complex=True).abs().requires_grad_(True)
+    y = M.RTISI_LA(sp, max_iter=2, verbose=False)
+    torch.nn.functional.mse_loss(t(x)[:y.shape[0]], y).backward()
+    out["x_ref_test"], out["grad_ref_test"] = x, sp.grad.numpy()
+    # same pattern in float64 (in float32 the symmetric-window recursion decorrelates between implementations)
+    sp = torch.stft(t(x.astype(np.float64)), 256, return_complex=True).abs().requires_grad_(True)
+    y = M.RTISI_LA(sp, max_iter=2, verbose=False)
+    torch.nn.functional.mse_loss(t(x.astype(np.float64))[:y.shape[0]], y).backward()
+    out["grad_ref_test64"] = sp.grad.numpy()
+    save("g12_autograd_rtisi", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     table = dict(g0=g0_stft, g1=g1_phase_init, g2=g2_gla, g3=g3_sweep, g4=g4_admm, g5=g5_rtisi,
-                 g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd, g11=g11_autograd_admm)
+                 g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd, g11=g11_autograd_admm, g12=g12_autograd_rtisi)
     for w in which:
         table[w]()
