@@ -48,6 +48,167 @@ __device__ inline T load_padded(const T* __restrict__ x, int64_t L, int64_t n, i
 // (natural order, unscaled) and all threads are synchronised.
 // `tid` / `nthr`: the calling thread's rank inside, and the size of, the thread group that owns the
 // transform (default: the whole workgroup).  Every thread of the WORKGROUP must still reach the barriers.
+//
+// One thread owns one radix-R butterfly of a stage: R strided loads, R-1 twiddles W_m^(k q) from the
+// table, an in-register DFT_R, R stores.  Radices 2, 3, 4, 5, 7, 8 are unrolled; a larger prime
+// factor falls back to one output per thread (direct DFT_R from LDS).
+// times -i (forward) / +i (inverse)
+template <typename T, bool INV>
+__device__ __forceinline__ cplx<T> rot_mi(cplx<T> a) {
+  return INV ? mk<T>(-a.y, a.x) : mk<T>(a.y, -a.x);
+}
+
+template <typename T, bool INV>
+__device__ __forceinline__ void bf4(cplx<T>& v0, cplx<T>& v1, cplx<T>& v2, cplx<T>& v3) {
+  const cplx<T> s02 = v0 + v2, d02 = v0 - v2, s13 = v1 + v3, d13 = rot_mi<T, INV>(v1 - v3);
+  v0 = s02 + s13;
+  v2 = s02 - s13;
+  v1 = d02 + d13;
+  v3 = d02 - d13;
+}
+
+template <typename T, int R, bool INV>
+struct Butterfly {   // generic small prime: X_r = sum_q v_q W_R^(q r), W_R^e = tw[e * N / R]
+  static __device__ __forceinline__ void run(cplx<T> (&v)[R], const cplx<T>* __restrict__ tw, int N) {
+    cplx<T> w[R];
+#pragma unroll
+    for (int e = 0; e < R; ++e) {
+      w[e] = tw[e * (N / R)];
+      if (INV) w[e].y = -w[e].y;
+    }
+    cplx<T> o[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      cplx<T> acc = v[0];
+#pragma unroll
+      for (int q = 1; q < R; ++q) acc = acc + cmul(v[q], w[(q * r) % R]);
+      o[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = o[r];
+  }
+};
+template <typename T, bool INV>
+struct Butterfly<T, 2, INV> {
+  static __device__ __forceinline__ void run(cplx<T> (&v)[2], const cplx<T>*, int) {
+    const cplx<T> a = v[0] + v[1], b = v[0] - v[1];
+    v[0] = a;
+    v[1] = b;
+  }
+};
+template <typename T, bool INV>
+struct Butterfly<T, 3, INV> {
+  static __device__ __forceinline__ void run(cplx<T> (&v)[3], const cplx<T>*, int) {
+    const T h = T(0.86602540378443864676372317075294);   // sin(pi/3)
+    const cplx<T> t = v[1] + v[2];
+    const cplx<T> m = mk<T>(v[0].x - T(0.5) * t.x, v[0].y - T(0.5) * t.y);
+    const cplx<T> d = v[1] - v[2];
+    const cplx<T> s = rot_mi<T, INV>(mk<T>(h * d.x, h * d.y));
+    v[0] = v[0] + t;
+    v[1] = m + s;
+    v[2] = m - s;
+  }
+};
+template <typename T, bool INV>
+struct Butterfly<T, 4, INV> {
+  static __device__ __forceinline__ void run(cplx<T> (&v)[4], const cplx<T>*, int) { bf4<T, INV>(v[0], v[1], v[2], v[3]); }
+};
+template <typename T, bool INV>
+struct Butterfly<T, 8, INV> {
+  static __device__ __forceinline__ void run(cplx<T> (&v)[8], const cplx<T>*, int) {
+    const T h = T(0.70710678118654752440084436210485);
+    bf4<T, INV>(v[0], v[2], v[4], v[6]);   // even samples -> E0..E3 in v0, v2, v4, v6
+    bf4<T, INV>(v[1], v[3], v[5], v[7]);   // odd samples  -> O0..O3 in v1, v3, v5, v7
+    // O_k *= W8^k (conjugated for the inverse)
+    const cplx<T> o1 = INV ? mk<T>(h * (v[3].x - v[3].y), h * (v[3].x + v[3].y)) : mk<T>(h * (v[3].x + v[3].y), h * (v[3].y - v[3].x));
+    const cplx<T> o2 = rot_mi<T, INV>(v[5]);
+    const cplx<T> o3 = INV ? mk<T>(-h * (v[7].x + v[7].y), h * (v[7].x - v[7].y)) : mk<T>(h * (v[7].y - v[7].x), -h * (v[7].x + v[7].y));
+    const cplx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+    v[0] = e0 + o0;
+    v[4] = e0 - o0;
+    v[1] = e1 + o1;
+    v[5] = e1 - o1;
+    v[2] = e2 + o2;
+    v[6] = e2 - o2;
+    v[3] = e3 + o3;
+    v[7] = e3 - o3;
+  }
+};
+
+template <typename T, int R, bool INV>
+__device__ __forceinline__ void fft_stage(const cplx<T>* __restrict__ a, cplx<T>* __restrict__ b, const FrameCfg<T>& c,
+                                          int ns, int tid, int nthr) {
+  const int N = c.n_fft, nb = N / R, tws = N / (ns * R);
+  for (int j = tid; j < nb; j += nthr) {
+    const int blk = j / ns, k = j - blk * ns;
+    cplx<T> v[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = a[j + q * nb];
+    if (ns > 1) {
+      const int kt = k * tws;                 // W_m^(k q) = tw[k q N/m], k q < m
+#pragma unroll
+      for (int q = 1; q < R; ++q) {
+        cplx<T> w = c.tw[kt * q];
+        if (INV) w.y = -w.y;
+        v[q] = cmul(v[q], w);
+      }
+    }
+    Butterfly<T, R, INV>::run(v, c.tw, N);
+    const int base = blk * ns * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) b[base + r * ns] = v[r];
+  }
+}
+
+// any radix: one output per thread, direct DFT_R
+template <typename T>
+__device__ inline void fft_stage_any(const cplx<T>* __restrict__ a, cplx<T>* __restrict__ b, const FrameCfg<T>& c, int R,
+                                     int ns, bool inverse, int tid, int nthr) {
+  const int N = c.n_fft, m = ns * R, stride = N / R, twstep = N / m;
+  for (int o = tid; o < N; o += nthr) {
+    const int block = o / m;
+    const int within = o - block * m;
+    const int r = within / ns;
+    const int k = within - r * ns;
+    const int j = block * ns + k;
+    const int e1 = k + r * ns;  // < m
+    T accx = 0, accy = 0;
+    int e = 0;
+    for (int q = 0; q < R; ++q) {
+      const cplx<T> v = a[j + q * stride];
+      cplx<T> w = c.tw[e * twstep];
+      if (inverse) w.y = -w.y;
+      accx += v.x * w.x - v.y * w.y;
+      accy += v.x * w.y + v.y * w.x;
+      e += e1;
+      if (e >= m) e -= m;
+    }
+    b[o] = mk<T>(accx, accy);
+  }
+}
+
+template <typename T, bool INV>
+__device__ inline void lds_fft_dir(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, int tid, int nthr) {
+  int ns = 1;
+  for (int s = 0; s < c.n_stages; ++s) {
+    const int R = c.radix[s];
+    switch (R) {
+      case 2: fft_stage<T, 2, INV>(a, b, c, ns, tid, nthr); break;
+      case 3: fft_stage<T, 3, INV>(a, b, c, ns, tid, nthr); break;
+      case 4: fft_stage<T, 4, INV>(a, b, c, ns, tid, nthr); break;
+      case 5: fft_stage<T, 5, INV>(a, b, c, ns, tid, nthr); break;
+      case 7: fft_stage<T, 7, INV>(a, b, c, ns, tid, nthr); break;
+      case 8: fft_stage<T, 8, INV>(a, b, c, ns, tid, nthr); break;
+      default: fft_stage_any<T>(a, b, c, R, ns, INV, tid, nthr); break;
+    }
+    __syncthreads();
+    cplx<T>* tmp = a;
+    a = b;
+    b = tmp;
+    ns *= R;
+  }
+}
+
 template <typename T>
 __device__ inline void lds_fft(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, bool inverse, int tid = -1,
                                int nthr = 0) {
@@ -55,39 +216,8 @@ __device__ inline void lds_fft(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, b
     tid = threadIdx.x;
     nthr = blockDim.x;
   }
-  const int N = c.n_fft;
-  int ns = 1;
-  for (int s = 0; s < c.n_stages; ++s) {
-    const int R = c.radix[s];
-    const int m = ns * R;
-    const int stride = N / R;
-    const int twstep = N / m;
-    for (int o = tid; o < N; o += nthr) {
-      const int block = o / m;
-      const int within = o - block * m;
-      const int r = within / ns;
-      const int k = within - r * ns;
-      const int j = block * ns + k;
-      const int e1 = k + r * ns;  // < m
-      T accx = 0, accy = 0;
-      int e = 0;
-      for (int q = 0; q < R; ++q) {
-        cplx<T> v = a[j + q * stride];
-        cplx<T> w = c.tw[e * twstep];
-        if (inverse) w.y = -w.y;
-        accx += v.x * w.x - v.y * w.y;
-        accy += v.x * w.y + v.y * w.x;
-        e += e1;
-        if (e >= m) e -= m;
-      }
-      b[o] = mk<T>(accx, accy);
-    }
-    __syncthreads();
-    cplx<T>* tmp = a;
-    a = b;
-    b = tmp;
-    ns = m;
-  }
+  if (inverse) lds_fft_dir<T, true>(a, b, c, tid, nthr);
+  else lds_fft_dir<T, false>(a, b, c, tid, nthr);
 }
 
 // windowed frame t of row `x` -> LDS (imaginary part zero); ends synchronised

@@ -44,9 +44,25 @@ struct DevBuf {
   U* as() const { return static_cast<U*>(p); }
 };
 
+// radix schedule of the LDS Stockham FFT: powers of two as 8s and 4s (fewest stages), then 3, 5, 7, other primes
 inline std::vector<int> factorize(int n) {
   std::vector<int> f;
-  const int small[] = {4, 2, 3, 5, 7, 11, 13};
+  int e = 0;
+  while (n % 2 == 0) {
+    ++e;
+    n /= 2;
+  }
+  if (e == 1) f.push_back(2);
+  else if (e % 3 == 0) f.insert(f.end(), e / 3, 8);
+  else if (e % 3 == 2) {
+    f.push_back(4);                       // small first radix: its stores are the strided ones
+    f.insert(f.end(), e / 3, 8);
+  } else if (e >= 4) {
+    f.push_back(4);
+    f.push_back(4);
+    f.insert(f.end(), (e - 4) / 3, 8);
+  }
+  const int small[] = {3, 5, 7, 11, 13};
   for (int p : small)
     while (n % p == 0) {
       f.push_back(p);
