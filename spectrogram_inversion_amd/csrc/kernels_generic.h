@@ -300,93 +300,134 @@ __global__ void k_ola(const T* __restrict__ frames, const T* __restrict__ env, T
   x[i] = use_env ? acc / env[n] : acc;
 }
 
-// ---- Griffin-Lim iteration, frame part (methods.py:237-248) ---------------------------------
-// R = STFT(x)_t ; out = |R| ; S = R - lr*P ; P <- S ; S' = S * m / (|S| + 1e-16) ; frame = w * irfft(S')
-template <typename T, bool EVAL>
-__global__ void k_gla_frame(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ P,
-                            const T* __restrict__ mag, T lr, T* __restrict__ frames, double* __restrict__ partials) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double red[16];
-  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* b = a + c.n_fft;
-  const int t = blockIdx.x, bi = blockIdx.y;
-  load_frame(c, x + (int64_t)bi * c.length, t, a, c.window);
-  lds_fft(a, b, c, false);
-  const int64_t base = ((int64_t)bi * c.n_frames + t) * c.n_freq;
-  double s_d = 0, s_o = 0;
-  for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) {
-    const cplx<T> r = mk<T>(a[f].x * c.fwd_scale, a[f].y * c.fwd_scale);
-    const cplx<T> p = P[base + f];
-    const T m = mag[base + f];
-    if (EVAL) {
-      const T o = si_hypot(r.x, r.y);
-      const double d = (double)o - (double)m;
-      s_d += d * d;
-      s_o += (double)o * (double)o;
-    }
-    const cplx<T> s = mk<T>(r.x - p.x * lr, r.y - p.y * lr);
-    P[base + f] = s;
-    const T inv = T(1) / (si_hypot(s.x, s.y) + eps16<T>::value);
-    a[f] = mk<T>((s.x * m) * inv, (s.y * m) * inv);
+// ---- Griffin-Lim / ADMM iteration, frame part (methods.py:237-248, :458-477) -----------------
+// ---- two frames per complex FFT ---------------------------------------------------------------
+// The frames are real, so frames t and t+1 ride one complex transform: z = a + i b gives
+// A_f = (Z_f + conj Z_{N-f})/2, B_f = (Z_f - conj Z_{N-f})/(2i); on the way back the spectra that
+// irfft / ifft(.).real actually see are the Hermitian parts H(Y)_f = (Y_f + conj Y_{N-f})/2 (for a
+// one-sided spectrum: the Hermitian extension, DC / Nyquist imaginary parts ignored), and
+// Z'_f = H(Y_A)_f + i H(Y_B)_f comes back as a = Re z', b = Im z'.  Works for any n_fft and any radix.
+// One thread owns the bin pair (f, N-f) of both frames.
+template <typename T, int MODE>   // 0: Griffin-Lim (S0 = pre_spec), 1: ADMM (S0 = X, S1 = U)
+__device__ __forceinline__ cplx<T> update_one(cplx<T> r, cplx<T>* __restrict__ S0, cplx<T>* __restrict__ S1,
+                                              const T* __restrict__ mag, int64_t idx, T coef, T inv1p, bool eval,
+                                              double& s_d, double& s_o) {
+  const T m = mag[idx];
+  if (eval) {
+    const T o = si_hypot(r.x, r.y);
+    const double d = (double)o - (double)m;
+    s_d += d * d;
+    s_o += (double)o * (double)o;
   }
-  __syncthreads();
-  spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
-  if (EVAL) {
-    const double d = block_sum(s_d, red);
-    const double o = block_sum(s_o, red);
-    if (threadIdx.x == 0) {
-      const int64_t pi = (int64_t)bi * c.n_frames + t;
-      partials[2 * pi] = d;
-      partials[2 * pi + 1] = o;
-    }
-  }
-}
-
-// ---- ADMM iteration, frame part (methods.py:458-477) ---------------------------------------
-// R = STFT(x)_t ; Y = X + U ; Z = (rho*Y + R)/(1+rho) ; U <- U + X - Z ; X <- Z - U ;
-// X <- X*m/(|X|+1e-16) ; Y' = X + U ; frame = w * irfft(Y').  Only X and U are stored:
-// Y is recomputed as fl(X + U), which is the value the reference stores (:475).
-template <typename T, bool EVAL>
-__global__ void k_admm_frame(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ X,
-                             cplx<T>* __restrict__ U, const T* __restrict__ mag, T rho, T inv1p,
-                             T* __restrict__ frames, double* __restrict__ partials) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double red[16];
-  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* b = a + c.n_fft;
-  const int t = blockIdx.x, bi = blockIdx.y;
-  load_frame(c, x + (int64_t)bi * c.length, t, a, c.window);
-  lds_fft(a, b, c, false);
-  const int64_t base = ((int64_t)bi * c.n_frames + t) * c.n_freq;
-  double s_d = 0, s_o = 0;
-  for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) {
-    const cplx<T> r = mk<T>(a[f].x * c.fwd_scale, a[f].y * c.fwd_scale);
-    const cplx<T> xo = X[base + f];
-    const cplx<T> uo = U[base + f];
-    const T m = mag[base + f];
-    if (EVAL) {
-      const T o = si_hypot(r.x, r.y);
-      const double d = (double)o - (double)m;
-      s_d += d * d;
-      s_o += (double)o * (double)o;
-    }
+  if (MODE == 0) {                                             // methods.py:243-247
+    const cplx<T> p = S0[idx];
+    const cplx<T> sv = mk<T>(r.x - p.x * coef, r.y - p.y * coef);
+    S0[idx] = sv;
+    const T inv = T(1) / (si_hypot(sv.x, sv.y) + eps16<T>::value);
+    return mk<T>((sv.x * m) * inv, (sv.y * m) * inv);
+  } else {                                                     // methods.py:467-475
+    const cplx<T> xo = S0[idx], uo = S1[idx];
     const cplx<T> y = xo + uo;
-    const cplx<T> z = mk<T>((rho * y.x + r.x) * inv1p, (rho * y.y + r.y) * inv1p);
+    const cplx<T> z = mk<T>((coef * y.x + r.x) * inv1p, (coef * y.y + r.y) * inv1p);
     const cplx<T> un = (uo + xo) - z;
     cplx<T> xn = z - un;
     const T inv = T(1) / (si_hypot(xn.x, xn.y) + eps16<T>::value);
     xn = mk<T>((xn.x * m) * inv, (xn.y * m) * inv);
-    X[base + f] = xn;
-    U[base + f] = un;
-    a[f] = xn + un;
+    S0[idx] = xn;
+    S1[idx] = un;
+    return xn + un;
   }
-  __syncthreads();
-  spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
+}
+
+template <typename T, int MODE, bool EVAL>
+__global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ S0, cplx<T>* __restrict__ S1,
+                            const T* __restrict__ mag, T coef, T inv1p, T* __restrict__ frames,
+                            double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[16];
+  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* b = a + c.n_fft;
+  const int N = c.n_fft, F = c.n_freq;
+  const int t0 = 2 * blockIdx.x, bi = blockIdx.y;
+  const T* xr = x + (int64_t)bi * c.length;
+  const T hs = T(0.5) * c.fwd_scale;
+  double s_d = 0, s_o = 0;
+  // Normally one pass with (ta, tb) = (t0, t0+1).  A non-finite sample (the reference's 0/0 where the envelope
+  // vanishes, methods.py:132) must stay inside its own frame, so such a pair is done as two single-frame passes.
+  int ta = t0, tb = t0 + 1 < c.n_frames ? t0 + 1 : -1;
+  for (int pass = 0; pass < 2; ++pass) {
+    int bad = 0;
+    {
+      const int64_t sa = (int64_t)ta * c.hop - c.pad, sb = (int64_t)tb * c.hop - c.pad;
+      for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const T w = c.window[n];
+        const T va = load_padded(xr, c.length, sa + n, c.pad_mode) * w;
+        const T vb = tb >= 0 ? load_padded(xr, c.length, sb + n, c.pad_mode) * w : T(0);
+        bad |= !__builtin_isfinite(va) || !__builtin_isfinite(vb);
+        a[n] = mk<T>(va, vb);
+      }
+    }
+    const bool split = __syncthreads_or(bad) && tb >= 0;   // (also the barrier after the load)
+    if (split) {
+      tb = -1;
+      for (int n = threadIdx.x; n < N; n += blockDim.x) a[n].y = T(0);
+      __syncthreads();
+    }
+    lds_fft(a, b, c, false);
+    const int64_t base_a = ((int64_t)bi * c.n_frames + ta) * F, base_b = ((int64_t)bi * c.n_frames + tb) * F;
+    const bool has_b = tb >= 0;
+    for (int f = threadIdx.x; f <= N / 2; f += blockDim.x) {
+      const int g = f ? N - f : 0;
+      const cplx<T> zf = a[f], zg = a[g];
+      // spectra of the two frames at bin f (bin g holds their conjugates)
+      const cplx<T> ra = mk<T>((zf.x + zg.x) * hs, (zf.y - zg.y) * hs);
+      const cplx<T> rb = mk<T>((zf.y + zg.y) * hs, (zg.x - zf.x) * hs);
+      cplx<T> ha, hb;   // Hermitian parts of the updated spectra at bin f
+      if (c.onesided) {
+        ha = update_one<T, MODE>(ra, S0, S1, mag, base_a + f, coef, inv1p, EVAL, s_d, s_o);
+        hb = has_b ? update_one<T, MODE>(rb, S0, S1, mag, base_b + f, coef, inv1p, EVAL, s_d, s_o) : mk<T>(T(0), T(0));
+        if (g == f) {
+          ha.y = T(0);
+          hb.y = T(0);
+        }
+      } else {
+        const cplx<T> yaf = update_one<T, MODE>(ra, S0, S1, mag, base_a + f, coef, inv1p, EVAL, s_d, s_o);
+        const cplx<T> ybf = has_b ? update_one<T, MODE>(rb, S0, S1, mag, base_b + f, coef, inv1p, EVAL, s_d, s_o)
+                                  : mk<T>(T(0), T(0));
+        cplx<T> yag = yaf, ybg = ybf;
+        if (g != f) {
+          yag = update_one<T, MODE>(conj(ra), S0, S1, mag, base_a + g, coef, inv1p, EVAL, s_d, s_o);
+          if (has_b) ybg = update_one<T, MODE>(conj(rb), S0, S1, mag, base_b + g, coef, inv1p, EVAL, s_d, s_o);
+        }
+        ha = mk<T>(T(0.5) * (yaf.x + yag.x), T(0.5) * (yaf.y - yag.y));
+        hb = mk<T>(T(0.5) * (ybf.x + ybg.x), T(0.5) * (ybf.y - ybg.y));
+      }
+      b[f] = mk<T>(ha.x - hb.y, ha.y + hb.x);
+      if (g != f) b[g] = mk<T>(ha.x + hb.y, hb.x - ha.y);
+    }
+    __syncthreads();
+    {
+      cplx<T>* tmp = a;
+      a = b;
+      b = tmp;
+    }
+    lds_fft(a, b, c, true);
+    T* fa = frames + ((int64_t)bi * c.n_frames + ta) * N;
+    T* fb = frames + ((int64_t)bi * c.n_frames + tb) * N;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      const T w = c.window[n];
+      fa[n] = (a[n].x * c.inv_scale) * w;
+      if (has_b) fb[n] = (a[n].y * c.inv_scale) * w;
+    }
+    if (!split) break;
+    ta = t0 + 1;          // second pass: the other frame on its own
+    __syncthreads();      // everyone is done reading `a` before the next load overwrites it
+  }
   if (EVAL) {
     const double d = block_sum(s_d, red);
     const double o = block_sum(s_o, red);
     if (threadIdx.x == 0) {
-      const int64_t pi = (int64_t)bi * c.n_frames + t;
+      const int64_t pi = (int64_t)bi * gridDim.x + blockIdx.x;
       partials[2 * pi] = d;
       partials[2 * pi + 1] = o;
     }

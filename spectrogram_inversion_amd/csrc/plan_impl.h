@@ -163,10 +163,10 @@ struct PlanT final : PlanBase {
     if (lds_bytes > 48 * 1024) {
       const int lim = (int)lds_bytes;
       SI_HIP(hipFuncSetAttribute((const void*)k_stft<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_gla_frame<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_gla_frame<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_admm_frame<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_admm_frame<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_iter_pair<T, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_iter_pair<T, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_iter_pair<T, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      SI_HIP(hipFuncSetAttribute((const void*)k_iter_pair<T, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       SI_HIP(hipFuncSetAttribute((const void*)k_grad_frames<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     }
     SI_TRY(sums.reserve(16 * sizeof(double)));
@@ -377,20 +377,20 @@ struct PlanT final : PlanBase {
       const T inv1p = T(1) / (T)(1.0 + (double)coef);
       for (int i = 0; i < n_iter; ++i) {
         const bool ev = eval_last && i == n_iter - 1;
-        const dim3 grid(Tn(), B()), blk(256);
+        const dim3 grid((Tn() + 1) / 2, B()), blk(256);   // two frames per complex FFT
         if (method == Method::Gla) {
           if (ev)
-            hipLaunchKernelGGL((k_gla_frame<T, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
-                               mag.as<T>(), coef, frames.as<T>(), partials.as<double>());
+            hipLaunchKernelGGL((k_iter_pair<T, 0, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
+                               (C*)nullptr, mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
           else
-            hipLaunchKernelGGL((k_gla_frame<T, false>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
-                               mag.as<T>(), coef, frames.as<T>(), partials.as<double>());
+            hipLaunchKernelGGL((k_iter_pair<T, 0, false>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
+                               (C*)nullptr, mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
         } else {
           if (ev)
-            hipLaunchKernelGGL((k_admm_frame<T, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
+            hipLaunchKernelGGL((k_iter_pair<T, 1, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
                                specB.as<C>(), mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
           else
-            hipLaunchKernelGGL((k_admm_frame<T, false>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
+            hipLaunchKernelGGL((k_iter_pair<T, 1, false>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
                                specB.as<C>(), mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
         }
         SI_HIP(hipGetLastError());
@@ -398,7 +398,7 @@ struct PlanT final : PlanBase {
       }
     }
     if (eval_last) {
-      const int64_t n_part = fast_path() ? (int64_t)fast.n_partials : (int64_t)B() * Tn();
+      const int64_t n_part = fast_path() ? (int64_t)fast.n_partials : (int64_t)B() * ((Tn() + 1) / 2);
       if (deferred_slot >= 0) {
         // deferred evaluation (run_loop with tol == 0 and no callback): keep the sums on the device
         SI_TRY(eval_log.reserve((size_t)(deferred_slot + 1) * 2 * sizeof(double)));
