@@ -1112,6 +1112,143 @@ __global__ __launch_bounds__(256) void k_fast_inverse_frames(FastXformArgs a) {
   }
 }
 
+// ---- one iteration for any hop / centring (n_fft 1024 / 2048): frame kernel + gather overlap-add ---------------
+// Same wave-level FFT, pair-layout state and update as k_fused, but a wave takes whole frames one at a time (samples
+// straight from x, any hop, any pad mode) and writes the windowed synthesis frame to `frames`; k_ola then does the
+// overlap-add / envelope division.  Costs one frame round trip (8 N bytes per frame) more than k_fused; used when
+// hop != n_fft/4 or centre = False.  MODE_INIT synthesises the stored spectrum as it is (the initial ISTFT).
+constexpr int MODE_INIT = 2;
+struct SemiArgs {
+  FastArgs f;              // x_in, P_in (updated in place), U_in, m_pairs, ..., L, T, pad_mode, coef, scales, partials
+  float* frames;           // (B*T, N)
+  long long n_frames_total;
+  int hop, pad;
+};
+
+template <int R, int MODE, bool EVAL>
+__global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
+  using G = Geo<R>;
+  constexpr int H = G::H, M = G::M;
+  constexpr int UMODE = MODE == MODE_INIT ? MODE_GLA : MODE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const FastArgs& a = s.f;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const float half_scale = 0.5f * a.fwd_scale;
+  double sd = 0.0, so = 0.0;
+  for (long long fi = (long long)blockIdx.x * 4 + wib; fi < s.n_frames_total; fi += (long long)gridDim.x * 4) {
+    const long long b = fi / a.T;
+    const int t = (int)(fi - b * a.T);
+    v4f pp[H], uu[H], mm[H / 2];
+    v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
+    float mmid = 0.0f;
+    {
+      v4f* pin = a.P_out + fi * (H * 64);
+#pragma unroll
+      for (int j = 0; j < H; ++j) pp[j] = pin[j * 64u + ulane];
+      if (MODE == MODE_ADMM) {
+        v4f* uin = a.U_out + fi * (H * 64);
+#pragma unroll
+        for (int j = 0; j < H; ++j) uu[j] = uin[j * 64u + ulane];
+      }
+      if (MODE != MODE_INIT) {
+        const v4f* min = a.m_pairs + fi * (H / 2 * 64);
+#pragma unroll
+        for (int j = 0; j < H / 2; ++j) mm[j] = min[j * 64u + ulane];
+      }
+      if (lane == 0) {
+        pmid = a.Pmid_out[fi];
+        if (MODE != MODE_INIT) mmid = a.m_mid[fi];
+        if (MODE == MODE_ADMM) umid = a.Umid_out[fi];
+      }
+    }
+    v2f z[R], rc[H];
+    if (MODE != MODE_INIT) {
+      load_frame_regs<R>(a.x_in + b * a.L, a.L, (long long)t * s.hop - s.pad, lane, a.pad_mode, lds_win, z);
+      fft_forward<R>(z, k, lds_tw1, tr);
+#pragma unroll
+      for (int m = H; m < R; ++m) {
+        const v2f got = shfl2(z[m], k.partner);
+        const v2f own = z[(m + 1) % R];
+        rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+      }
+    }
+    v2f back[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
+      v2f ak, am;
+      if (MODE != MODE_INIT) {
+        const v2f zk = z[j], zm = rc[R - 1 - j - H];
+        const v2f e2 = add_conj(zk, zm);
+        const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
+        const v2f xk = (e2 + tw) * half_scale;
+        const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
+        v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
+        if (MODE == MODE_ADMM) {
+          uk = v2f{uu[j].x, uu[j].y};
+          um = v2f{uu[j].z, uu[j].w};
+        }
+        const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+        const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+        ak = update_bin<UMODE, EVAL>(xk, pk, uk, mk, a, true, sd, so);
+        am = update_bin<UMODE, EVAL>(xm, pm, um, mq, a, true, sd, so);
+        a.P_out[fi * (H * 64) + j * 64u + ulane] = v4f{pk.x, pk.y, pm.x, pm.y};
+        if (MODE == MODE_ADMM) a.U_out[fi * (H * 64) + j * 64u + ulane] = v4f{uk.x, uk.y, um.x, um.y};
+      } else {
+        ak = pk * a.inv_scale;
+        am = pm * a.inv_scale;
+      }
+      if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    v2f zmid;
+    if (MODE != MODE_INIT) {
+      const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
+      const bool live0 = lane == 0;
+      const v2f am = update_bin<UMODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
+      if (live0) {
+        a.Pmid_out[fi] = pmid;
+        if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
+      }
+      zmid = am * v2f{2.0f, -2.0f};
+    } else {
+      zmid = pmid * v2f{2.0f * a.inv_scale, -2.0f * a.inv_scale};
+    }
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+    fft_inverse<R>(z, k, lds_tw1, tr);
+    v2f* out = reinterpret_cast<v2f*>(s.frames + fi * (2 * M));
+#pragma unroll
+    for (int u = 0; u < R; ++u) out[64u * u + ulane] = z[u] * lds_win[64 * u + lane];
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0) {
+      const long long w = (long long)blockIdx.x * 4 + wib;
+      a.partials[2 * w] = d;
+      a.partials[2 * w + 1] = o;
+    }
+  }
+}
+
 // x += the tail partial sums (final waveform for get_wave)
 template <int R>
 __global__ void k_add_tails(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, long long L,
@@ -1213,6 +1350,7 @@ struct FastBuf {
 template <typename T>
 struct FastState {
   bool supported = false;
+  bool semi = false;
   bool xform_ok = false;
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
@@ -1233,6 +1371,8 @@ struct FastState<float> {
   using v2f = fast::v2f;
   using v4f = fast::v4f;
   bool supported = false;
+  bool semi = false;   // k_semi + k_ola instead of k_fused (hop != n_fft/4 or centre = False)
+  int semi_grid = 0;
   int R = 0;
   int chunk = 32, nchunks = 0, n_waves = 0, n_partials = 0;
   int cur = 0;   // index of the buffers holding the current state
@@ -1250,13 +1390,22 @@ struct FastState<float> {
       xform_ok = true;              // any hop, any pad mode, centred or not
       xform_R = cfg.n_fft / 128;
     }
-    if (!cfg.center || cfg.hop_length * 4 != cfg.n_fft) return SPECINV_OK;
-    if (cfg.n_fft == 2048) R = 16;
-    else if (cfg.n_fft == 1024) R = 8;
-    else return SPECINV_OK;
-    if (cfg.n_frames < 6 || pad >= length) return SPECINV_OK;   // (pad >= length is refused later for reflect)
-    if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
-      if (e[0] == '1') return SPECINV_OK;
+    if (!xform_ok) return SPECINV_OK;
+    R = xform_R;
+    semi = false;
+    if (!cfg.center || cfg.hop_length * 4 != cfg.n_fft || cfg.n_frames < 6 || pad >= length) {
+      // any other hop / centring: frame kernel on the wave-level FFT + gather overlap-add (k_semi)
+      if (const char* e = getenv("SPECINV_DISABLE_SEMI")) {
+        if (e[0] == '1') return SPECINV_OK;
+      }
+      semi = true;
+      chunk = cfg.n_frames;
+      nchunks = 1;
+      const long long nf = (long long)cfg.batch * cfg.n_frames;
+      semi_grid = (int)std::min<long long>((nf + 3) / 4, 256 * 8);
+      n_waves = semi_grid * 4;
+      supported = true;
+      return SPECINV_OK;
     }
     // frames per wave: enough waves to fill 256 CUs x 12 wave slots once, halo overhead 3/chunk
     const long long frames = (long long)cfg.batch * cfg.n_frames;
@@ -1281,8 +1430,8 @@ struct FastState<float> {
     const long long nf = (long long)pl.B() * pl.Tn();
     const size_t pbytes = (size_t)nf * G::H * 64 * sizeof(v4f);
     const size_t tail_bytes = (size_t)pl.B() * nchunks * 3 * G::HOP * sizeof(float);
-    for (int i = 0; i < 2; ++i) {
-      SI_TRY(xtail[i].reserve(tail_bytes));
+    for (int i = 0; i < (semi ? 1 : 2); ++i) {     // k_semi updates its state in place
+      if (!semi) SI_TRY(xtail[i].reserve(tail_bytes));
       SI_TRY(xb[i].reserve((size_t)pl.B() * pl.length * sizeof(float)));
       SI_TRY(Pb[i].reserve(pbytes));
       SI_TRY(Pmid[i].reserve(nf * sizeof(v2f)));
@@ -1291,6 +1440,7 @@ struct FastState<float> {
         SI_TRY(Umid[i].reserve(nf * sizeof(v2f)));
       }
     }
+    if (semi) SI_TRY(pl.frames_needed());
     SI_TRY(mpairs.reserve((size_t)nf * (G::H / 2) * 64 * sizeof(v4f)));
     SI_TRY(mmid.reserve(nf * sizeof(float)));
     SI_TRY(inv_env.reserve(pl.length * sizeof(float)));
@@ -1313,6 +1463,12 @@ struct FastState<float> {
     if (md == fast::MODE_ADMM) {
       SI_HIP(hipMemsetAsync(Ub[0].p, 0, pbytes, pl.stream));
       SI_HIP(hipMemsetAsync(Umid[0].p, 0, nf * sizeof(v2f), pl.stream));
+    }
+    if (semi) {
+      // x0 = ISTFT(start spectrum): synthesis frames from the pair layout, then the gather overlap-add
+      SI_TRY((launch_semi<RR, fast::MODE_INIT, false>(pl)));
+      SI_HIP(hipStreamSynchronize(pl.stream));   // *sum_m2_out is valid from here on
+      return SPECINV_OK;
     }
     hipLaunchKernelGGL(fast::k_reciprocal, dim3((unsigned)ceil_div(pl.length, 256)), dim3(256), 0, pl.stream,
                        pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length);
@@ -1391,8 +1547,60 @@ struct FastState<float> {
     return SPECINV_OK;
   }
 
+  template <int RR, int MODE, bool EVAL, typename P>
+  int launch_semi(P& pl) {
+    using G = fast::Geo<RR>;
+    fast::SemiArgs s{};
+    fast::FastArgs& a = s.f;
+    a.x_in = xb[0].template as<float>();
+    a.P_out = Pb[0].template as<v4f>();
+    a.Pmid_out = Pmid[0].template as<v2f>();
+    a.U_out = Ub[0].template as<v4f>();
+    a.Umid_out = Umid[0].template as<v2f>();
+    a.m_pairs = mpairs.template as<v4f>();
+    a.m_mid = mmid.template as<float>();
+    a.window = pl.window.template as<float>();
+    a.partials = pl.partials.template as<double>();
+    a.T = pl.Tn();
+    a.pad_mode = pl.cfg.pad_mode;
+    a.L = pl.length;
+    a.coef = pl.coef;
+    a.inv1p = 1.0f / (float)(1.0 + (double)pl.coef);
+    a.fwd_scale = pl.fc.fwd_scale;
+    a.inv_scale = pl.fc.inv_scale;
+    s.frames = pl.frames.template as<float>();
+    s.n_frames_total = (long long)pl.B() * pl.Tn();
+    s.hop = pl.cfg.hop_length;
+    s.pad = pl.pad;
+    const size_t lds = G::lds_bytes(4);
+    SI_HIP(hipFuncSetAttribute((const void*)fast::k_semi<RR, MODE, EVAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((fast::k_semi<RR, MODE, EVAL>), dim3(semi_grid), dim3(256), lds, pl.stream, s);
+    SI_HIP(hipGetLastError());
+    return pl.launch_ola(pl.frames.template as<float>(), xb[0].template as<float>(), true);
+  }
+
+  template <typename P>
+  int iterate_semi(P& pl, int n_iter, bool eval_last) {
+    SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2, 3 * 1024) * sizeof(double)));
+    for (int i = 0; i < n_iter; ++i) {
+      const bool ev = eval_last && i == n_iter - 1;
+      int rc;
+      if (R == 16) {
+        if (mode == fast::MODE_GLA) rc = ev ? launch_semi<16, fast::MODE_GLA, true>(pl) : launch_semi<16, fast::MODE_GLA, false>(pl);
+        else rc = ev ? launch_semi<16, fast::MODE_ADMM, true>(pl) : launch_semi<16, fast::MODE_ADMM, false>(pl);
+      } else {
+        if (mode == fast::MODE_GLA) rc = ev ? launch_semi<8, fast::MODE_GLA, true>(pl) : launch_semi<8, fast::MODE_GLA, false>(pl);
+        else rc = ev ? launch_semi<8, fast::MODE_ADMM, true>(pl) : launch_semi<8, fast::MODE_ADMM, false>(pl);
+      }
+      SI_TRY(rc);
+    }
+    n_partials = n_waves;
+    return SPECINV_OK;
+  }
+
   template <typename P>
   int iterate(P& pl, int n_iter, bool eval_last) {
+    if (semi) return iterate_semi(pl, n_iter, eval_last);
     SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2, 3 * 1024) * sizeof(double)));
     for (int i = 0; i < n_iter; ++i) {
       const bool ev = eval_last && i == n_iter - 1;

@@ -22,6 +22,7 @@ struct PlanBase {
   virtual ~PlanBase() = default;
   virtual int setup() = 0;
   virtual bool fast_path() const = 0;
+  virtual int path_kind() const = 0;   // 0 generic, 1 fused, 2 frame kernel + overlap-add
 
   virtual int stft(const void* x, int64_t len, void* spec_out) = 0;
   virtual int istft(const void* spec, void* x_out) = 0;

@@ -175,6 +175,7 @@ struct PlanT final : PlanBase {
   }
 
   bool fast_path() const override { return fast.supported && !force_generic; }
+  int path_kind() const override { return fast_path() ? (fast.semi ? 2 : 1) : 0; }
 
   // ------------------------------------------------------------------------------------
   // layout helpers: user (B, F, T) <-> internal (B, T, F)

@@ -155,7 +155,7 @@ int specinv_plan_set_stream(specinv_plan* plan, void* hip_stream) {
 
 int specinv_plan_n_freq(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->n_freq : SPECINV_EINVAL; }
 int64_t specinv_plan_length(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->length : SPECINV_EINVAL; }
-int specinv_plan_fast_path(const specinv_plan* plan) { return plan && plan->impl ? (plan->impl->fast_path() ? 1 : 0) : SPECINV_EINVAL; }
+int specinv_plan_fast_path(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->path_kind() : SPECINV_EINVAL; }
 int specinv_plan_force_generic(specinv_plan* plan, int on) {
   PLAN_OR_FAIL(plan);
   SI_CHECK(plan->impl->method == Method::None, SPECINV_ESTATE, "cannot switch paths while a method is running");

@@ -137,7 +137,13 @@ class Plan:
 
     @property
     def fast_path(self) -> bool:
-        return bool(self.lib.specinv_plan_fast_path(self._h))
+        """True when the iteration runs on the wave-level FFT kernels (`path` tells which form)."""
+        return self.lib.specinv_plan_fast_path(self._h) > 0
+
+    @property
+    def path(self) -> str:
+        """"fused" (one launch per iteration), "frame" (wave-level frame kernel + overlap-add) or "generic"."""
+        return ("generic", "fused", "frame")[self.lib.specinv_plan_fast_path(self._h)]
 
     def force_generic(self, on=True):
         _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))

@@ -40,21 +40,26 @@ def test_reference_shape_contract(x_sizes, dtype, nfft):
 def test_path_selection_at_the_edges():
     w = torch.from_numpy(hann(2048))
     probe = torch.empty(1, 1025, 1)
-    assert Plan(args_helper(probe, hop_length=512, window=w), 1, 6, torch.float32, torch.device(DEV)).fast_path
-    assert not Plan(args_helper(probe, hop_length=512, window=w), 1, 5, torch.float32, torch.device(DEV)).fast_path   # too short
-    assert not Plan(args_helper(probe, hop_length=500, window=w), 1, 40, torch.float32, torch.device(DEV)).fast_path  # hop != n_fft/4
-    assert not Plan(args_helper(probe, hop_length=512, window=w, center=False), 1, 40, torch.float32,
-                    torch.device(DEV)).fast_path
+    dev = torch.device(DEV)
+    assert Plan(args_helper(probe, hop_length=512, window=w), 1, 6, torch.float32, dev).path == "fused"
+    assert Plan(args_helper(probe, hop_length=512, window=w), 1, 5, torch.float32, dev).path == "frame"   # too short
+    assert Plan(args_helper(probe, hop_length=500, window=w), 1, 40, torch.float32, dev).path == "frame"  # hop != n_fft/4
+    assert Plan(args_helper(probe, hop_length=512, window=w, center=False), 1, 40, torch.float32, dev).path == "frame"
     for pm in ("constant", "replicate", "circular"):          # only the four edge hop-blocks differ
-        assert Plan(args_helper(probe, hop_length=512, window=w, pad_mode=pm), 1, 40, torch.float32,
-                    torch.device(DEV)).fast_path
+        assert Plan(args_helper(probe, hop_length=512, window=w, pad_mode=pm), 1, 40, torch.float32, dev).path == "fused"
     w64 = torch.from_numpy(hann(2048, np.float64))
-    assert not Plan(args_helper(probe.double(), hop_length=512, window=w64), 1, 40, torch.float64,
-                    torch.device(DEV)).fast_path
+    assert Plan(args_helper(probe.double(), hop_length=512, window=w64), 1, 40, torch.float64, dev).path == "generic"
+    assert Plan(args_helper(torch.empty(1, 2048, 1), hop_length=512, window=w, onesided=False), 1, 40, torch.float32,
+                dev).path == "generic"
+    w512 = torch.from_numpy(hann(512))
+    assert Plan(args_helper(torch.empty(1, 257, 1), hop_length=128, window=w512), 1, 40, torch.float32, dev).path == "generic"
+    p = Plan(args_helper(probe, hop_length=512, window=w), 1, 6, torch.float32, dev)
+    p.force_generic(True)
+    assert p.path == "generic" and not p.fast_path
 
 
 @pytest.mark.parametrize("frames", [4, 5])
-def test_short_signals_use_generic_kernels(frames):
+def test_short_signals_off_the_fused_kernel(frames):
     rng = np.random.default_rng(frames)
     mag = rng.random((2, 1025, frames), dtype=np.float32)
     w = hann(2048)

@@ -1,0 +1,139 @@
+"""The any-hop wave-level iteration (k_semi + k_ola: n_fft 1024 / 2048 with hop != n_fft/4 or centre = False)
+against the oracle and the generic kernels, through the C ABI.  Needs an MI355X: `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _util import finite_close, hann, rel_l2, sc_linear
+
+pytestmark = pytest.mark.gpu
+
+import spectrogram_inversion_amd as si                          # noqa: E402
+from spectrogram_inversion_amd.plan import Plan, args_helper    # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_plan(n_fft, hop, frames, batch, dtype=torch.float32, **kw):
+    w = kw.pop("window", None)
+    w = torch.from_numpy(hann(n_fft)) if w is None else torch.from_numpy(w)
+    probe = torch.empty((1, n_fft // 2 + 1, 1))
+    return Plan(args_helper(probe, hop_length=hop, window=w.to(dtype), **kw), batch, frames, dtype, DEV)
+
+
+# n_fft, hop, frames, batch, extra: the reference's demo shape (main.py:13-14: 1024 / 128), hops that do not divide
+# n_fft, odd hops (unaligned frame starts), hop = n_fft/2, too few frames for the fused kernel, no centring
+SHAPES = [(1024, 128, 40, 2, {}), (2048, 256, 21, 2, {}), (2048, 333, 17, 1, {}), (1024, 100, 33, 3, {}),
+          (2048, 1024, 9, 2, {}), (1024, 256, 5, 2, {}), (2048, 512, 2, 1, dict(pad_mode="constant")),
+          (1024, 256, 12, 2, dict(center=False, window=np.ones(1024, dtype=np.float32))),
+          (2048, 300, 10, 1, dict(pad_mode="circular")), (1024, 128, 16, 2, dict(normalized=True, pad_mode="replicate"))]
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch,extra", SHAPES)
+def test_semi_gla_matches_oracle(n_fft, hop, frames, batch, extra):
+    rng = np.random.default_rng(n_fft + hop + frames)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01
+    okw = dict(extra)
+    w = okw.pop("window", hann(n_fft))
+    init = oracle.phase_init(mag, hop_length=hop, window=w, **okw)
+    trace = []
+    ref, st = oracle.griffin_lim(init, max_iter=6, alpha=0.3, tol=0, eva_iter=3, hop_length=hop, window=w, trace=trace,
+                                 return_state=True, **okw)
+    plan = make_plan(n_fft, hop, frames, batch, **dict(extra))
+    assert plan.fast_path                      # wave-level FFT path, not the LDS Stockham kernels
+    plan.gla_init(T(init), None, 0.3)
+    done, evals = plan.run(6, 3, 0.0, "sc")
+    assert done == 6 and len(evals) == 2
+    y = N(plan.wave())
+    assert rel_l2(y, ref.reshape(y.shape)) < 1e-4, rel_l2(y, ref.reshape(y.shape))
+    got = sc_linear(np.array([m for _, m, _ in evals]))
+    want = sc_linear(np.array([m for _, m, _ in trace]))
+    assert np.abs(got - want).max() < 1e-5
+    assert rel_l2(N(plan.state_spec(0)), st["pre_spec"]) < 3e-4
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch,extra", SHAPES[:4])
+@pytest.mark.parametrize("rho", [0.1, 1.0])
+def test_semi_admm_matches_oracle(n_fft, hop, frames, batch, extra, rho):
+    rng = np.random.default_rng(11)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01
+    w = hann(n_fft)
+    init = oracle.phase_init(mag, hop_length=hop, window=w)
+    ref, st = oracle.admm(init, max_iter=3, rho=rho, tol=0, hop_length=hop, window=w, return_state=True)
+    plan = make_plan(n_fft, hop, frames, batch)
+    assert plan.fast_path
+    plan.admm_init(T(init), None, rho)
+    plan.iterate(3)
+    tol = 3e-4 if rho == 0.1 else 5e-5
+    assert rel_l2(N(plan.wave()), ref.reshape(batch, -1)) < tol
+    assert rel_l2(N(plan.state_spec(0)), st["X"]) < tol
+    assert rel_l2(N(plan.state_spec(1)), st["U"]) < 20 * tol
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch,extra", SHAPES)
+def test_semi_equals_generic(n_fft, hop, frames, batch, extra):
+    """Same plan forced onto the generic kernels: waveforms, evaluation sums and state agree to rounding."""
+    rng = np.random.default_rng(5)
+    mag = T(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01)
+    fast, gen = make_plan(n_fft, hop, frames, batch, **dict(extra)), make_plan(n_fft, hop, frames, batch, **dict(extra))
+    gen.force_generic(True)
+    assert fast.fast_path and not gen.fast_path
+    out = []
+    for p in (fast, gen):
+        p.gla_init(None, mag, 0.99)
+        p.iterate(4)
+        s = p.iterate(1, eval_last=True)
+        out.append((N(p.wave()), s, N(p.state_spec(0))))
+    assert rel_l2(out[0][0], out[1][0]) < 5e-5
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-5)
+    assert rel_l2(out[0][2], out[1][2]) < 5e-5
+
+
+def test_semi_vs_float64_at_demo_size():
+    """The reference's demo shape (main.py: n_fft 1024, hop 128) at a realistic size against the float64 kernels."""
+    n_fft, hop, frames, batch = 1024, 128, 600, 4
+    mag = torch.rand((batch, n_fft // 2 + 1, frames), generator=torch.Generator().manual_seed(2)) + 0.01
+    p32 = make_plan(n_fft, hop, frames, batch)
+    p64 = make_plan(n_fft, hop, frames, batch, dtype=torch.float64)
+    assert p32.fast_path and not p64.fast_path
+    c0 = p64.phase_init(mag.double().to(DEV))
+    p32.gla_init(c0.to(torch.complex64), None, 0.3)
+    p64.gla_init(c0, None, 0.3)
+    p32.iterate(9)
+    p64.iterate(9)
+    s32, s64 = p32.iterate(1, eval_last=True), p64.iterate(1, eval_last=True)
+    assert rel_l2(N(p32.wave()), N(p64.wave())) < 1e-4
+    sc32, sc64 = np.sqrt(s32[0] / s32[2]), np.sqrt(s64[0] / s64[2])
+    assert abs(sc32 - sc64) < 1e-5
+
+
+def test_semi_nan_stays_in_its_frame():
+    """centre = False with a Hann window: the envelope is 0 at the first sample, the reference divides 0 by 0 there
+    (methods.py:132) and the NaN spreads over the frames that cover it in the next iteration - exactly those."""
+    n_fft, hop, frames = 1024, 256, 12
+    rng = np.random.default_rng(3)
+    mag = rng.random((1, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01
+    ref = oracle.griffin_lim(mag, max_iter=2, alpha=0.5, tol=0, hop_length=hop, window=hann(n_fft), center=False)
+    y = N(si.griffin_lim(T(mag), max_iter=2, alpha=0.5, tol=0, verbose=False, hop_length=hop,
+                         window=torch.from_numpy(hann(n_fft)), center=False))
+    assert np.isnan(ref).any() and finite_close(y, ref.reshape(y.shape), 1e-4)
+
+
+def test_semi_public_api_demo_call():
+    """main.py:13-45: griffin_lim(spec, max_iter, alpha=0.3, window, win_length, hop_length=128) on a complex STFT."""
+    x = torch.randn(2, 16000, generator=torch.Generator().manual_seed(1)).to(DEV)
+    w = torch.hann_window(1024, device=DEV)
+    spec = torch.stft(x, 1024, hop_length=128, win_length=1024, window=w, return_complex=True).abs()
+    y = si.griffin_lim(spec, max_iter=30, alpha=0.3, tol=0, verbose=False, win_length=1024, window=w, hop_length=128)
+    assert y.shape == (2, 16000)
+    again = torch.stft(y, 1024, hop_length=128, win_length=1024, window=w, return_complex=True).abs()
+    assert float(si.sc(again, spec)) < -12.0         # spectral convergence in dB after 30 iterations
