@@ -300,6 +300,28 @@ __global__ void k_ola(const T* __restrict__ frames, const T* __restrict__ env, T
   x[i] = use_env ? acc / env[n] : acc;
 }
 
+// four consecutive samples per thread (float, hop / n_fft / pad / length all multiples of 4): the four samples
+// share their frame range and sit contiguously in every frame, so each term is one 16-byte load.  Same sums in
+// the same order as k_ola.
+__global__ void k_ola_f4(const float* __restrict__ frames, const float* __restrict__ env, float* __restrict__ x, int n_fft,
+                         int hop, int pad, int n_frames, int64_t length, int64_t total4, int use_env) {
+  using f4 = float __attribute__((ext_vector_type(4)));
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int64_t l4 = length / 4;
+  const int64_t bi = i / l4;
+  const int64_t n = (i - bi * l4) * 4;
+  const int64_t np = n + pad;
+  int64_t t_hi = np / hop;
+  if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+  const int64_t t_lo = np - n_fft + 1 <= 0 ? 0 : (np - n_fft + hop) / hop;
+  const float* fr = frames + bi * n_frames * n_fft;
+  f4 acc = f4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int64_t t = t_lo; t <= t_hi; ++t) acc += *reinterpret_cast<const f4*>(fr + t * n_fft + (np - t * hop));
+  if (use_env) acc = acc / *reinterpret_cast<const f4*>(env + n);
+  *reinterpret_cast<f4*>(x + bi * length + n) = acc;
+}
+
 // ---- Griffin-Lim / ADMM iteration, frame part (methods.py:237-248, :458-477) -----------------
 // ---- two frames per complex FFT ---------------------------------------------------------------
 // The frames are real, so frames t and t+1 ride one complex transform: z = a + i b gives

@@ -196,6 +196,14 @@ struct PlanT final : PlanBase {
 
   int launch_ola(const T* fr, T* out, bool use_env) {
     const int64_t total = (int64_t)B() * length;
+    if constexpr (std::is_same<T, float>::value) {
+      if (cfg.hop_length % 4 == 0 && N() % 4 == 0 && pad % 4 == 0 && length % 4 == 0) {
+        hipLaunchKernelGGL(k_ola_f4, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, stream, fr, env.as<float>(), out,
+                           N(), cfg.hop_length, pad, Tn(), length, total / 4, use_env ? 1 : 0);
+        SI_HIP(hipGetLastError());
+        return SPECINV_OK;
+      }
+    }
     hipLaunchKernelGGL((k_ola<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, fr, env.as<T>(), out,
                        N(), cfg.hop_length, pad, Tn(), length, total, use_env ? 1 : 0);
     SI_HIP(hipGetLastError());
