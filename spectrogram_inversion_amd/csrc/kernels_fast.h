@@ -221,6 +221,17 @@ struct Geo {
   static constexpr size_t lds_bytes(int waves) { return sizeof(v2f) * (size_t)(M + (R - 1) * 64 + waves * TR); }
 };
 
+// overlap geometry of the fused kernels: hop = N / OV, OV in {2, 4, 8}
+template <int R, int OV>
+struct Ovl {
+  static_assert(OV == 2 || OV == 4 || OV == 8, "hop must be n_fft / 2, / 4 or / 8");
+  static_assert(R % OV == 0, "a hop-block must be whole registers");
+  static constexpr int HOP = Geo<R>::N / OV;
+  static constexpr int QU = R / OV;      // registers per hop-block
+  static constexpr int NB = OV - 1;      // hop-blocks carried from frame to frame (accumulators, sample window, tails)
+  static constexpr int PB = OV / 2;      // hop-blocks of centre padding on either side
+};
+
 // per-lane constants
 template <int R>
 struct LaneConst {
@@ -480,8 +491,74 @@ __device__ __host__ __forceinline__ int chunk_begin(int c, int T, int nchunks) {
 // the first were stored as two partial sums (the chunk's own frames in x, the previous chunk's last three
 // frames in `xtail`); they are added here.  Edge (reflected) blocks never touch such blocks because the
 // first and the last chunk are at least 6 frames long.
-template <int R>
+template <int R, int OV>
 __device__ __forceinline__ void load_block(const float* __restrict__ xrow, const float* __restrict__ tailrow,
+                                           long long L, int T, int c, int t_begin, int t_end, int j, int lane,
+                                           int pad_mode, v2f (&q)[R / OV]) {
+  using O = Ovl<R, OV>;
+  constexpr int HOP = O::HOP, QU = O::QU, NB = O::NB, PB = O::PB;
+  const long long s0 = (long long)(j - PB) * HOP;
+  if (j >= PB && j <= T + PB - 2) {
+    const v2f* src = reinterpret_cast<const v2f*>(xrow + s0);   // uniform
+#pragma unroll
+    for (int i = 0; i < QU; ++i) q[i] = src[64u * i + (unsigned)lane];
+    // a wave only ever reads blocks t_begin .. t_end + NB - 1 of its own chunk c: split blocks are the chunk's
+    // own first NB (other half from chunk c-1) and the next chunk's first NB (other half: this chunk's)
+    int tc = -1, off = 0;
+    if (c >= 1 && j - t_begin < NB) {
+      tc = c - 1;
+      off = j - t_begin;
+    } else if (j >= t_end && j < T) {
+      tc = c;
+      off = j - t_end;
+    }
+    if (tc >= 0) {
+      const v2f* tl = reinterpret_cast<const v2f*>(tailrow + ((long long)tc * NB + off) * HOP);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) q[i] = q[i] + tl[64u * i + (unsigned)lane];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+      const long long n0 = pad_index(s0 + 128 * i + 2 * lane, L, pad_mode);
+      const long long n1 = pad_index(s0 + 128 * i + 2 * lane + 1, L, pad_mode);
+      q[i] = v2f{n0 < 0 ? 0.0f : xrow[(unsigned)n0], n1 < 0 ? 0.0f : xrow[(unsigned)n1]};
+    }
+  }
+}
+
+__device__ __forceinline__ v4f ld_stream(const v4f* p) {
+#if SPECINV_ABLATE & 2
+  return v4f{1.0f, 0.5f, 0.25f, 2.0f} * (float)(((unsigned long long)p >> 4) & 7);
+#else
+#if SPECINV_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+#endif
+}
+__device__ __forceinline__ void st_stream(v4f* p, v4f v) {
+#if SPECINV_ABLATE & 1
+  if (v.x == 1.2345e30f) __builtin_nontemporal_store(v, p);   // keeps the value alive, (almost) never stores
+#elif SPECINV_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
+// ---- hop = n_fft/4: the headline shape keeps its own hand-tuned copy of the kernel --------------------------------
+// (k_fused<R, 4, ...> below is the same algorithm; the compiler's register allocation of this text is the one that
+// was tuned and measured - 6 % faster at C2 - so it stays as it is.)
+// One hop-block (N/4 samples, padded-signal block index j) of row `xrow` in the register layout
+// (lane l, register i <-> samples 128 i + 2 l, +1).  Blocks 2..T lie inside the signal; the two
+// blocks on either side are torch.stft's reflect padding.  The first three hop-blocks of every chunk but
+// the first were stored as two partial sums (the chunk's own frames in x, the previous chunk's last three
+// frames in `xtail`); they are added here.  Edge (reflected) blocks never touch such blocks because the
+// first and the last chunk are at least 6 frames long.
+template <int R>
+__device__ __forceinline__ void load_block4(const float* __restrict__ xrow, const float* __restrict__ tailrow,
                                            long long L, int T, int c, int t_begin, int t_end, int j, int lane,
                                            int pad_mode, v2f (&q)[R / 4]) {
   constexpr int HOP = Geo<R>::HOP;
@@ -515,29 +592,8 @@ __device__ __forceinline__ void load_block(const float* __restrict__ xrow, const
   }
 }
 
-__device__ __forceinline__ v4f ld_stream(const v4f* p) {
-#if SPECINV_ABLATE & 2
-  return v4f{1.0f, 0.5f, 0.25f, 2.0f} * (float)(((unsigned long long)p >> 4) & 7);
-#else
-#if SPECINV_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-#endif
-}
-__device__ __forceinline__ void st_stream(v4f* p, v4f v) {
-#if SPECINV_ABLATE & 1
-  if (v.x == 1.2345e30f) __builtin_nontemporal_store(v, p);   // keeps the value alive, (almost) never stores
-#elif SPECINV_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-
 template <int R, int MODE, bool EVAL>
-__global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
+__global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused4(FastArgs a) {
   using G = Geo<R>;
   constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -586,20 +642,20 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     v2f q[QU];
-    load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + qq, lane, a.pad_mode, q);
+    load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + qq, lane, a.pad_mode, q);
 #pragma unroll
     for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
   }
 #elif SPECINV_XPREF == 1
   v2f xq[3][QU], xn[QU];
-  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start, lane, a.pad_mode, xq[0]);
-  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 1, lane, a.pad_mode, xq[1]);
-  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 2, lane, a.pad_mode, xq[2]);
-  load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 3, lane, a.pad_mode, xn);
+  load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start, lane, a.pad_mode, xq[0]);
+  load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 1, lane, a.pad_mode, xq[1]);
+  load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 2, lane, a.pad_mode, xq[2]);
+  load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + 3, lane, a.pad_mode, xn);
 #endif
 
   // state of frame `FI`: uniform bases (SGPR) + unsigned 32-bit lane offsets -> "saddr + voffset" addressing
-#define SPECINV_STATE_LOADS(FI)                                                            \
+#define SPECINV_STATE_LOADS4(FI)                                                            \
   do {                                                                                     \
     const long long fl_ = (FI);                                                            \
     const v4f* pin_ = a.P_in + fl_ * (H * 64);                                             \
@@ -620,7 +676,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
   v4f pp[H], uu[H], mm[H / 2];
   v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
   float mmid = 0.0f;
-  SPECINV_STATE_LOADS((long long)b * a.T + t_start);
+  SPECINV_STATE_LOADS4((long long)b * a.T + t_start);
 #endif
 
   for (int t = t_start; t < t_end; ++t) {
@@ -639,7 +695,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
     float mmid = 0.0f;
 #endif
 #if SPECINV_PLATE == 0
-    SPECINV_STATE_LOADS(fi);   // early: the loads fly during the forward FFT
+    SPECINV_STATE_LOADS4(fi);   // early: the loads fly during the forward FFT
 #endif
 
     // ---- analysis: windowed frame -> registers
@@ -659,13 +715,13 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
       xq[1][i] = xq[2][i];
       xq[2][i] = xn[i];
     }
-    if (t + 1 < t_end) load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 4, lane, a.pad_mode, xn);
+    if (t + 1 < t_end) load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 4, lane, a.pad_mode, xn);
 #else
     {
       v2f q[QU];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, a.pad_mode, q);
+        load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, a.pad_mode, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) z[qq * QU + i] = q[i];
       }
@@ -681,7 +737,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
     fft_forward<R>(z, k, lds_tw1, tr);
 #endif
 #if SPECINV_PLATE == 1
-    SPECINV_STATE_LOADS(fi);
+    SPECINV_STATE_LOADS4(fi);
 #endif
 
     // ---- conjugate partners: upper half of lane (64 - r)
@@ -752,7 +808,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #if SPECINV_PLATE == 2
     // the state registers are free again: fetch the next frame's state now, it flies through the inverse FFT,
     // the overlap-add and the next forward FFT
-    if (t + 1 < t_end) SPECINV_STATE_LOADS(fi + 1);
+    if (t + 1 < t_end) SPECINV_STATE_LOADS4(fi + 1);
 #endif
 
 #if SPECINV_XPREF == 2
@@ -760,7 +816,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         v2f q[QU];
-        load_block<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 1 + qq, lane, a.pad_mode, q);
+        load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 1 + qq, lane, a.pad_mode, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) znext[qq * QU + i] = q[i];
       }
@@ -818,12 +874,239 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
   }
 }
 
+template <int R, int OV, int MODE, bool EVAL>
+__global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
+  using G = Geo<R>;
+  using O = Ovl<R, OV>;
+  constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  // wave-uniform values are forced into SGPRs: every global address below is then
+  // "scalar base + 32-bit lane offset" instead of one 64-bit VGPR pointer per access
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);   // W_M^(l*k1)
+  }
+  __syncthreads();
+
+  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  if (w >= a.n_waves) return;
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  const int t_begin = chunk_begin(c, a.T, a.nchunks);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  const int t_start = t_begin;   // no halo: the previous chunk's share of the first NB hop-blocks comes via xtail
+  const float* xrow = a.x_in + (long long)b * a.L;
+  const float* tailrow = a.xtail_in + (long long)b * a.nchunks * NB * HOP;
+  float* orow = a.x_out + (long long)b * a.L;
+  const float half_scale = 0.5f * a.fwd_scale;
+
+  v2f acc[NB * QU];
+#pragma unroll
+  for (int i = 0; i < NB * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
+  double sd = 0.0, so = 0.0;
+#if SPECINV_TW_REGS
+  TwRegs<R> twr;
+#pragma unroll
+  for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = lds_tw1[(k1 - 1) * 64 + lane];
+#endif
+
+  // raw samples of the current frame: NB hop-blocks carried from frame to frame plus the
+  // new one, which is fetched one frame ahead so that its latency hides behind a whole frame
+  v2f xq[NB][QU], xn[QU];
+#pragma unroll
+  for (int q = 0; q < NB; ++q)
+    load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + q, lane, a.pad_mode, xq[q]);
+  load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t_start + NB, lane, a.pad_mode, xn);
+
+  // state of frame `FI`: uniform bases (SGPR) + unsigned 32-bit lane offsets -> "saddr + voffset" addressing
+#define SPECINV_STATE_LOADS(FI)                                                            \
+  do {                                                                                     \
+    const long long fl_ = (FI);                                                            \
+    const v4f* pin_ = a.P_in + fl_ * (H * 64);                                             \
+    const v4f* min_ = a.m_pairs + fl_ * (H / 2 * 64);                                      \
+    _Pragma("unroll") for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin_[j * 64u + ulane]); \
+    if (MODE == MODE_ADMM) {                                                               \
+      const v4f* uin_ = a.U_in + fl_ * (H * 64);                                           \
+      _Pragma("unroll") for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin_[j * 64u + ulane]); \
+    }                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]); \
+    if (lane == 0) {                                                                       \
+      pmid = a.Pmid_in[fl_];                                                               \
+      mmid = a.m_mid[fl_];                                                                 \
+      if (MODE == MODE_ADMM) umid = a.Umid_in[fl_];                                        \
+    }                                                                                      \
+  } while (0)
+
+  for (int t = t_start; t < t_end; ++t) {
+    // Keep the loop-invariant table reads (window, twiddles) and products inside the loop: hoisted out
+    // of it they pin ~80 VGPRs for the whole kernel and cost a wave of occupancy.
+    asm volatile("" ::: "memory");
+    v2f wn = k.wn;
+    asm volatile("" : "+v"(wn));
+    constexpr bool live = true;
+    const long long fi = (long long)b * a.T + t;
+    v4f* pout = a.P_out + fi * (H * 64);
+    v4f* uout = MODE == MODE_ADMM ? a.U_out + fi * (H * 64) : nullptr;
+    v4f pp[H], uu[H], mm[H / 2];
+    v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
+    float mmid = 0.0f;
+    SPECINV_STATE_LOADS(fi);   // early: the loads fly during the forward FFT
+
+    // ---- analysis: windowed frame -> registers; slide the sample window and prefetch the next hop-block
+    v2f z[R];
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+#pragma unroll
+      for (int q = 0; q < NB; ++q) z[q * QU + i] = xq[q][i] * lds_win[64 * (q * QU + i) + lane];
+      z[NB * QU + i] = xn[i] * lds_win[64 * (NB * QU + i) + lane];
+#pragma unroll
+      for (int q = 0; q + 1 < NB; ++q) xq[q][i] = xq[q + 1][i];
+      xq[NB - 1][i] = xn[i];
+    }
+    if (t + 1 < t_end) load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + OV, lane, a.pad_mode, xn);
+
+#if SPECINV_ABLATE & 4
+#elif SPECINV_TW_REGS
+    fft_forward_t<R>(z, k, twr, tr);
+#else
+    fft_forward<R>(z, k, lds_tw1, tr);
+#endif
+
+    // ---- conjugate partners: upper half of lane (64 - r)
+    v2f rc[H];   // rc[i] pairs with own register H-1-i ... see below: rc[m-H] = Z[M - (lane + 64*(R-1-m))]
+    // (the lane-0 special case is patched AFTER the shuffle: selecting between two elements of
+    // one register array before it makes the compiler index the array dynamically)
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];              // lane 0 is its own partner, shifted by one register
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+
+    // ---- per pair: split -> update -> fold back
+    v2f back[H];   // back[j] = Z''[M - k_j], to be returned to the partner lane
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      // W_N^(lane + 64 j) = W_N^lane * W_{2R}^j
+      const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+      const v2f zk = z[j], zm = rc[R - 1 - j - H];
+      const v2f e2 = add_conj(zk, zm);
+      const v2f dd = sub_conj(zk, zm);
+      const v2f tw = cmul(mul_mi(wk), dd);                 // W * (-i (Zk - conj Zm))
+      v2f xk = (e2 + tw) * half_scale;
+      v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};   // conj(...)
+      v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
+      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
+      if (MODE == MODE_ADMM) {
+        uk = v2f{uu[j].x, uu[j].y};
+        um = v2f{uu[j].z, uu[j].w};
+      }
+      const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+      const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+      v2f ak = update_bin<MODE, EVAL>(xk, pk, uk, mk, a, live, sd, so);
+      v2f am = update_bin<MODE, EVAL>(xm, pm, um, mq, a, live, sd, so);
+      if (live) {
+        st_stream(&pout[j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
+        if (MODE == MODE_ADMM) st_stream(&uout[j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+      }
+      if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    // ---- bin M/2 (lane 0): X = conj(Z), Z'' = 2 conj(X')
+    v2f zmid;
+    {
+      v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
+      const bool live0 = live && lane == 0;
+      const v2f am = update_bin<MODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
+      if (live0) {
+        a.Pmid_out[fi] = pmid;
+        if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
+      }
+      zmid = am * v2f{2.0f, -2.0f};
+    }
+    // ---- return the mirrored halves
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+
+#if SPECINV_ABLATE & 4
+#elif SPECINV_TW_REGS
+    fft_inverse_t<R>(z, k, twr, tr);
+#else
+    asm volatile("" ::: "memory");   // re-read the twiddles instead of keeping them live since the forward FFT
+    fft_inverse<R>(z, k, lds_tw1, tr);
+#endif
+
+    // ---- synthesis window, register overlap-add, one finished hop-block out
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    if (live && t >= PB) {
+      const long long o0 = (long long)(t - PB) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
+      v2f* outp = reinterpret_cast<v2f*>(orow + o0);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = (acc[i] + z[i]) * envp[64u * i + ulane];
+    }
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+#pragma unroll
+      for (int q = 0; q + 1 < NB; ++q) acc[q * QU + i] = acc[(q + 1) * QU + i] + z[(q + 1) * QU + i];
+      acc[(NB - 1) * QU + i] = z[NB * QU + i];
+    }
+  }
+  if (t_end == a.T) {
+    // the chunk that holds the last frame also finishes hop-blocks T .. T + PB - 2 (the frames that reach them are done)
+#pragma unroll
+    for (int q = 0; q < PB - 1; ++q) {
+      const long long o0 = (long long)(a.T + q - PB) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
+      v2f* outp = reinterpret_cast<v2f*>(orow + o0);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[q * QU + i] * envp[64u * i + ulane];
+    }
+  } else {
+    // what this chunk's last NB frames contribute to the next chunk's first NB hop-blocks
+    v2f* tl = reinterpret_cast<v2f*>(a.xtail_out + ((long long)b * a.nchunks + c) * NB * HOP);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + (long long)(t_end + q - PB) * HOP);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = acc[q * QU + i] * envp[64u * i + ulane];
+    }
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0) {
+      a.partials[2 * (long long)w] = d;
+      a.partials[2 * (long long)w + 1] = o;
+    }
+  }
+}
+
 // ISTFT of a spectrum held in pair layout: x = overlap-add(w * irfft(S)) / envelope  (methods.py:233: the
 // initial signal of griffin_lim / ADMM).  Same wave-per-chunk walk as k_fused, without the analysis half.
-template <int R>
+template <int R, int OV>
 __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused_istft(FastArgs a) {
   using G = Geo<R>;
-  constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
+  using O = Ovl<R, OV>;
+  constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* lds_win = reinterpret_cast<v2f*>(smem);
   v2f* lds_tw1 = lds_win + M;
@@ -843,11 +1126,11 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused_istft(FastArgs 
   const int b = w / a.nchunks, c = w - b * a.nchunks;
   const int t_begin = chunk_begin(c, a.T, a.nchunks);
   const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
-  const int t_start = max(0, t_begin - 3);       // one-off kernel: recompute the 3-frame halo, write whole blocks
+  const int t_start = max(0, t_begin - NB);      // one-off kernel: recompute the NB-frame halo, write whole blocks
   float* orow = a.x_out + (long long)b * a.L;
-  v2f acc[3 * QU];
+  v2f acc[NB * QU];
 #pragma unroll
-  for (int i = 0; i < 3 * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
+  for (int i = 0; i < NB * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
   for (int t = t_start; t < t_end; ++t) {
     asm volatile("" ::: "memory");
     v2f wn = k.wn;
@@ -884,8 +1167,8 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused_istft(FastArgs 
     fft_inverse<R>(z, k, lds_tw1, tr);
 #pragma unroll
     for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
-    if (live && t >= 2) {
-      const long long o0 = (long long)(t - 2) * HOP;
+    if (live && t >= PB) {
+      const long long o0 = (long long)(t - PB) * HOP;
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
@@ -893,17 +1176,20 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused_istft(FastArgs 
     }
 #pragma unroll
     for (int i = 0; i < QU; ++i) {
-      acc[i] = acc[QU + i] + z[QU + i];
-      acc[QU + i] = acc[2 * QU + i] + z[2 * QU + i];
-      acc[2 * QU + i] = z[3 * QU + i];
+#pragma unroll
+      for (int q = 0; q + 1 < NB; ++q) acc[q * QU + i] = acc[(q + 1) * QU + i] + z[(q + 1) * QU + i];
+      acc[(NB - 1) * QU + i] = z[NB * QU + i];
     }
   }
   if (t_end == a.T) {
-    const long long o0 = (long long)(a.T - 2) * HOP;
-    const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
-    v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-    for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[i] * envp[64u * i + ulane];
+    for (int q = 0; q < PB - 1; ++q) {
+      const long long o0 = (long long)(a.T + q - PB) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
+      v2f* outp = reinterpret_cast<v2f*>(orow + o0);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[q * QU + i] * envp[64u * i + ulane];
+    }
   }
 }
 
@@ -1250,21 +1536,21 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
 }
 
 // x += the tail partial sums (final waveform for get_wave)
-template <int R>
+template <int R, int OV>
 __global__ void k_add_tails(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, long long L,
                             long long total) {
-  constexpr int HOP = Geo<R>::HOP;
+  constexpr int HOP = Ovl<R, OV>::HOP, NB = Ovl<R, OV>::NB, PB = Ovl<R, OV>::PB;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c, q, sample) over tails
   if (i >= total) return;
   const int smp = i % HOP;
-  const int q = (i / HOP) % 3;
-  const int c = (i / (3 * HOP)) % nchunks;
-  const long long b = i / ((long long)3 * HOP * nchunks);
+  const int q = (i / HOP) % NB;
+  const int c = (i / (NB * HOP)) % nchunks;
+  const long long b = i / ((long long)NB * HOP * nchunks);
   if (c >= nchunks - 1) return;                       // the last chunk has no successor
   const int blk = chunk_begin(c + 1, T, nchunks) + q; // padded-signal hop-block
   // register layout of a block: element (reg i2, lane l, comp e) <-> sample 128*i2 + 2*l + e
   const int i2 = smp / 128, rem = smp % 128;
-  x[b * L + (long long)(blk - 2) * HOP + smp] += xtail[((b * nchunks + c) * 3 + q) * HOP + (i2 * 64 + rem / 2) * 2 + (rem & 1)];
+  x[b * L + (long long)(blk - PB) * HOP + smp] += xtail[((b * nchunks + c) * NB + q) * HOP + (i2 * 64 + rem / 2) * 2 + (rem & 1)];
 }
 
 // ---- layout conversion between the frame-major (B*T, F) spectra and the pair layout ---------------
@@ -1374,6 +1660,7 @@ struct FastState<float> {
   bool semi = false;   // k_semi + k_ola instead of k_fused (hop != n_fft/4 or centre = False)
   int semi_grid = 0;
   int R = 0;
+  int OV = 0;          // n_fft / hop of the fused kernel (2, 4 or 8)
   int chunk = 32, nchunks = 0, n_waves = 0, n_partials = 0;
   int cur = 0;   // index of the buffers holding the current state
   int mode = fast::MODE_GLA;
@@ -1393,12 +1680,20 @@ struct FastState<float> {
     if (!xform_ok) return SPECINV_OK;
     R = xform_R;
     semi = false;
-    if (!cfg.center || cfg.hop_length * 4 != cfg.n_fft || cfg.n_frames < 6 || pad >= length) {
+    // fused kernel: hop = n_fft / 2, / 4 or / 8 (whole registers per hop-block), centred, enough frames
+    OV = 0;
+    for (int o : {2, 4, 8})
+      if (cfg.hop_length * o == cfg.n_fft && R % o == 0) OV = o;
+    if (const char* e = getenv("SPECINV_FUSED_OV4_ONLY")) {
+      if (e[0] == '1' && OV != 4) OV = 0;
+    }
+    if (!cfg.center || OV == 0 || cfg.n_frames < OV + 2 || pad >= length) {
       // any other hop / centring: frame kernel on the wave-level FFT + gather overlap-add (k_semi)
       if (const char* e = getenv("SPECINV_DISABLE_SEMI")) {
         if (e[0] == '1') return SPECINV_OK;
       }
       semi = true;
+      OV = 0;
       chunk = cfg.n_frames;
       nchunks = 1;
       const long long nf = (long long)cfg.batch * cfg.n_frames;
@@ -1407,16 +1702,18 @@ struct FastState<float> {
       supported = true;
       return SPECINV_OK;
     }
-    // frames per wave: enough waves to fill 256 CUs x 12 wave slots once, halo overhead 3/chunk
+    // frames per wave: enough waves to fill 256 CUs x 8 wave slots once; a chunk boundary costs OV - 1 split
+    // hop-blocks, and the reflected edge samples must not fall on split blocks (first / last chunk long enough)
     const long long frames = (long long)cfg.batch * cfg.n_frames;
+    const int floor_ch = OV == 8 ? 16 : 8;
     int ch = 32;
-    while (ch > 8 && frames / ch < 2048) ch /= 2;
+    while (ch > floor_ch && frames / ch < 2048) ch /= 2;
     if (const char* e = getenv("SPECINV_FAST_CHUNK")) {
       const int v = atoi(e);
-      if (v >= 4) ch = v;
+      if (v >= 4) ch = std::max(v, OV == 8 ? 13 : 4);
     }
     chunk = std::min(ch, cfg.n_frames);
-    nchunks = std::max(1, cfg.n_frames / chunk);   // frames split as evenly as possible, every chunk >= 8 (or all) frames
+    nchunks = std::max(1, cfg.n_frames / chunk);   // frames split as evenly as possible, every chunk >= `chunk` (or all) frames
     n_waves = cfg.batch * nchunks;
     supported = true;
     return SPECINV_OK;
@@ -1426,10 +1723,11 @@ struct FastState<float> {
   template <int RR, typename P>
   int begin_t(P& pl, int md, const v2f* spec_user, const float* mag_user, double* sum_m2_out) {
     using G = fast::Geo<RR>;
+    const int hop = pl.cfg.hop_length;
     mode = md;
     const long long nf = (long long)pl.B() * pl.Tn();
     const size_t pbytes = (size_t)nf * G::H * 64 * sizeof(v4f);
-    const size_t tail_bytes = (size_t)pl.B() * nchunks * 3 * G::HOP * sizeof(float);
+    const size_t tail_bytes = (size_t)pl.B() * nchunks * (OV > 0 ? OV - 1 : 0) * hop * sizeof(float);
     for (int i = 0; i < (semi ? 1 : 2); ++i) {     // k_semi updates its state in place
       if (!semi) SI_TRY(xtail[i].reserve(tail_bytes));
       SI_TRY(xb[i].reserve((size_t)pl.B() * pl.length * sizeof(float)));
@@ -1488,9 +1786,16 @@ struct FastState<float> {
     a.fwd_scale = pl.fc.fwd_scale;
     a.inv_scale = pl.fc.inv_scale;
     const size_t lds = G::lds_bytes(4);
-    SI_HIP(hipFuncSetAttribute((const void*)fast::k_fused_istft<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((fast::k_fused_istft<RR>), dim3((n_waves + 3) / 4), dim3(256), lds, pl.stream, a);
-    SI_HIP(hipGetLastError());
+    const void* fn = nullptr;
+    if constexpr (RR % 8 == 0) {
+      if (OV == 8) fn = (const void*)fast::k_fused_istft<RR, 8>;
+    }
+    if (OV == 4) fn = (const void*)fast::k_fused_istft<RR, 4>;
+    if (OV == 2) fn = (const void*)fast::k_fused_istft<RR, 2>;
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
+    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* kargs[] = {&a};
+    SI_HIP(hipLaunchKernel(fn, dim3((n_waves + 3) / 4), dim3(256), kargs, lds, pl.stream));
     SI_HIP(hipStreamSynchronize(pl.stream));   // *sum_m2_out is valid from here on
     return SPECINV_OK;
   }
@@ -1536,14 +1841,17 @@ struct FastState<float> {
   int launch(P& pl, const fast::FastArgs& a) {
     using G = fast::Geo<RR>;
     const size_t lds = G::lds_bytes(4);
-    static bool attr_done = false;
-    if (!attr_done) {
-      SI_HIP(hipFuncSetAttribute((const void*)fast::k_fused<RR, MODE, EVAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-      attr_done = true;
+    const void* fn = nullptr;
+    if constexpr (RR % 8 == 0) {
+      if (OV == 8) fn = (const void*)fast::k_fused<RR, 8, MODE, EVAL>;
     }
-    hipLaunchKernelGGL((fast::k_fused<RR, MODE, EVAL>), dim3((n_waves + 3) / 4), dim3(256), lds, pl.stream, a);
-    SI_HIP(hipGetLastError());
+    if (OV == 4) fn = (const void*)fast::k_fused4<RR, MODE, EVAL>;
+    if (OV == 2) fn = (const void*)fast::k_fused<RR, 2, MODE, EVAL>;
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
+    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    fast::FastArgs args = a;
+    void* kargs[] = {&args};
+    SI_HIP(hipLaunchKernel(fn, dim3((n_waves + 3) / 4), dim3(256), kargs, lds, pl.stream));
     return SPECINV_OK;
   }
 
@@ -1652,14 +1960,16 @@ struct FastState<float> {
     SI_HIP(hipMemcpyAsync(out, xb[cur].p, (size_t)pl.B() * pl.length * sizeof(float), hipMemcpyDeviceToDevice, pl.stream));
     if (nchunks > 1) {
       const int hop = pl.cfg.hop_length;
-      const long long total = (long long)pl.B() * nchunks * 3 * hop;
-      if (R == 16)
-        hipLaunchKernelGGL((fast::k_add_tails<16>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, out,
-                           xtail[cur].template as<float>(), pl.Tn(), nchunks, (long long)pl.length, total);
-      else
-        hipLaunchKernelGGL((fast::k_add_tails<8>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, out,
-                           xtail[cur].template as<float>(), pl.Tn(), nchunks, (long long)pl.length, total);
-      SI_HIP(hipGetLastError());
+      const long long total = (long long)pl.B() * nchunks * (OV - 1) * hop;
+      const void* fn = nullptr;
+      if (R == 16) fn = OV == 8 ? (const void*)fast::k_add_tails<16, 8> : OV == 4 ? (const void*)fast::k_add_tails<16, 4> : (const void*)fast::k_add_tails<16, 2>;
+      else fn = OV == 8 ? (const void*)fast::k_add_tails<8, 8> : OV == 4 ? (const void*)fast::k_add_tails<8, 4> : (const void*)fast::k_add_tails<8, 2>;
+      float* xo = out;
+      const float* tl = xtail[cur].template as<float>();
+      int Tn = pl.Tn(), nc = nchunks;
+      long long Ln = (long long)pl.length, tot = total;
+      void* kargs[] = {&xo, &tl, &Tn, &nc, &Ln, &tot};
+      SI_HIP(hipLaunchKernel(fn, dim3((unsigned)ceil_div(total, 256)), dim3(256), kargs, 0, pl.stream));
     }
     return SPECINV_OK;
   }

@@ -241,3 +241,95 @@ def test_fast_transform_without_centering():
     plan = Plan(a, 2, frames, torch.float32, dev())
     assert plan.path == "frame"                   # fused iteration needs centring; the transform does not
     assert rel_l2(N(plan.stft(T(x))), oracle.stft(x, oa)) < 2e-6
+
+
+# ---- hop = n_fft/8 (the reference's demo shape, main.py:13-14) and n_fft/2 on the fused kernel -------------------
+OV_SHAPES = [(1024, 128, 60, 2), (2048, 256, 45, 2), (2048, 1024, 20, 2), (1024, 512, 33, 3), (2048, 256, 10, 1),
+             (1024, 512, 4, 2)]
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch", OV_SHAPES)
+@pytest.mark.parametrize("chunk", [None, 13, 16])
+def test_fused_other_overlaps_match_oracle(n_fft, hop, frames, batch, chunk):
+    rng = np.random.default_rng(n_fft + hop + frames)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01
+    w = hann(n_fft)
+    init = oracle.phase_init(mag, hop_length=hop, window=w)
+    trace = []
+    ref, st = oracle.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, eva_iter=5, hop_length=hop, window=w,
+                                 trace=trace, return_state=True)
+    plan = make_plan(n_fft, hop, frames, batch, chunk=chunk)
+    assert plan.path == "fused"
+    plan.gla_init(T(init), None, 0.3)
+    done, evals = plan.run(10, 5, 0.0, "sc")
+    assert done == 10 and len(evals) == 2
+    y = N(plan.wave())
+    assert rel_l2(y, ref.reshape(y.shape)) < 1e-4, rel_l2(y, ref.reshape(y.shape))
+    got = sc_linear(np.array([m for _, m, _ in evals]))
+    want = sc_linear(np.array([m for _, m, _ in trace]))
+    assert np.abs(got - want).max() < 1e-5
+    assert rel_l2(N(plan.state_spec(0)), st["pre_spec"]) < 3e-4
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch", OV_SHAPES[:4])
+def test_fused_other_overlaps_admm_and_paths_agree(n_fft, hop, frames, batch):
+    """ADMM on the fused kernel against the oracle; the same problem on the frame kernel and on the generic kernels."""
+    rng = np.random.default_rng(21)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01
+    w = hann(n_fft)
+    init = oracle.phase_init(mag, hop_length=hop, window=w)
+    ref, st = oracle.admm(init, max_iter=3, rho=1.0, tol=0, hop_length=hop, window=w, return_state=True)
+    fused = make_plan(n_fft, hop, frames, batch)
+    os.environ["SPECINV_FUSED_OV4_ONLY"] = "1"
+    try:
+        frame = make_plan(n_fft, hop, frames, batch)
+    finally:
+        os.environ.pop("SPECINV_FUSED_OV4_ONLY", None)
+    gen = make_plan(n_fft, hop, frames, batch)
+    gen.force_generic(True)
+    assert (fused.path, frame.path, gen.path) == ("fused", "frame", "generic")
+    waves = []
+    for p in (fused, frame, gen):
+        p.admm_init(T(init), None, 1.0)
+        p.iterate(2)
+        s = p.iterate(1, eval_last=True)
+        waves.append((N(p.wave()), s))
+        assert rel_l2(waves[-1][0], ref.reshape(batch, -1)) < 5e-5
+        assert rel_l2(N(p.state_spec(0)), st["X"]) < 5e-5
+        assert rel_l2(N(p.state_spec(1)), st["U"]) < 1e-3
+    for other in waves[1:]:
+        np.testing.assert_allclose(waves[0][1], other[1], rtol=2e-5)
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "replicate", "circular"])
+@pytest.mark.parametrize("n_fft,hop,frames", [(1024, 128, 40), (2048, 1024, 12)])
+def test_fused_other_overlaps_pad_modes(pad_mode, n_fft, hop, frames):
+    rng = np.random.default_rng(31)
+    mag = rng.random((2, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01
+    w = hann(n_fft)
+    ref = oracle.griffin_lim(mag, max_iter=4, alpha=0.5, tol=0, hop_length=hop, window=w, pad_mode=pad_mode)
+    probe = torch.empty((1, n_fft // 2 + 1, 1))
+    plan = Plan(args_helper(probe, hop_length=hop, window=torch.from_numpy(w), pad_mode=pad_mode), 2, frames,
+                torch.float32, dev())
+    assert plan.path == "fused"
+    plan.gla_init(None, T(mag), 0.5)
+    plan.iterate(4)
+    assert rel_l2(N(plan.wave()), ref.reshape(2, -1)) < 5e-5
+
+
+def test_fused_demo_shape_full_size_vs_float64():
+    """n_fft 1024 / hop 128 at a few thousand frames: fused float32 against the generic kernels in float64."""
+    n_fft, hop, frames, batch = 1024, 128, 3000, 4
+    mag = torch.rand((batch, n_fft // 2 + 1, frames), generator=torch.Generator().manual_seed(2)) + 0.01
+    w32 = torch.from_numpy(hann(n_fft))
+    p32 = Plan(args_helper(mag, hop_length=hop, window=w32), batch, frames, torch.float32, dev())
+    p64 = Plan(args_helper(mag.double(), hop_length=hop, window=w32.double()), batch, frames, torch.float64, dev())
+    assert p32.path == "fused" and p64.path == "generic"
+    c0 = p64.phase_init(mag.double().to(dev()))
+    p32.gla_init(c0.to(torch.complex64), None, 0.3)
+    p64.gla_init(c0, None, 0.3)
+    p32.iterate(9)
+    p64.iterate(9)
+    s32, s64 = p32.iterate(1, eval_last=True), p64.iterate(1, eval_last=True)
+    assert rel_l2(N(p32.wave()), N(p64.wave())) < 1e-4
+    assert abs(np.sqrt(s32[0] / s32[2]) - np.sqrt(s64[0] / s64[2])) < 1e-5

@@ -30,12 +30,12 @@ def make_plan(n_fft, hop, frames, batch, dtype=torch.float32, **kw):
     return Plan(args_helper(probe, hop_length=hop, window=w.to(dtype), **kw), batch, frames, dtype, DEV)
 
 
-# n_fft, hop, frames, batch, extra: the reference's demo shape (main.py:13-14: 1024 / 128), hops that do not divide
-# n_fft, odd hops (unaligned frame starts), hop = n_fft/2, too few frames for the fused kernel, no centring
-SHAPES = [(1024, 128, 40, 2, {}), (2048, 256, 21, 2, {}), (2048, 333, 17, 1, {}), (1024, 100, 33, 3, {}),
-          (2048, 1024, 9, 2, {}), (1024, 256, 5, 2, {}), (2048, 512, 2, 1, dict(pad_mode="constant")),
+# n_fft, hop, frames, batch, extra: hops that do not divide n_fft, odd hops (unaligned frame starts), hop = n_fft/16
+# and 3 n_fft/8, too few frames for the fused kernel, no centring
+SHAPES = [(1024, 64, 40, 2, {}), (2048, 768, 21, 2, {}), (2048, 333, 17, 1, {}), (1024, 100, 33, 3, {}),
+          (2048, 1024, 3, 2, {}), (1024, 256, 5, 2, {}), (2048, 512, 2, 1, dict(pad_mode="constant")),
           (1024, 256, 12, 2, dict(center=False, window=np.ones(1024, dtype=np.float32))),
-          (2048, 300, 10, 1, dict(pad_mode="circular")), (1024, 128, 16, 2, dict(normalized=True, pad_mode="replicate"))]
+          (2048, 300, 10, 1, dict(pad_mode="circular")), (1024, 192, 16, 2, dict(normalized=True, pad_mode="replicate"))]
 
 
 @pytest.mark.parametrize("n_fft,hop,frames,batch,extra", SHAPES)
@@ -49,7 +49,7 @@ def test_semi_gla_matches_oracle(n_fft, hop, frames, batch, extra):
     ref, st = oracle.griffin_lim(init, max_iter=6, alpha=0.3, tol=0, eva_iter=3, hop_length=hop, window=w, trace=trace,
                                  return_state=True, **okw)
     plan = make_plan(n_fft, hop, frames, batch, **dict(extra))
-    assert plan.fast_path                      # wave-level FFT path, not the LDS Stockham kernels
+    assert plan.path == "frame"               # wave-level FFT frame kernel, not the LDS Stockham kernels
     plan.gla_init(T(init), None, 0.3)
     done, evals = plan.run(6, 3, 0.0, "sc")
     assert done == 6 and len(evals) == 2
@@ -70,7 +70,7 @@ def test_semi_admm_matches_oracle(n_fft, hop, frames, batch, extra, rho):
     init = oracle.phase_init(mag, hop_length=hop, window=w)
     ref, st = oracle.admm(init, max_iter=3, rho=rho, tol=0, hop_length=hop, window=w, return_state=True)
     plan = make_plan(n_fft, hop, frames, batch)
-    assert plan.fast_path
+    assert plan.path == "frame"
     plan.admm_init(T(init), None, rho)
     plan.iterate(3)
     tol = 3e-4 if rho == 0.1 else 5e-5
@@ -86,25 +86,28 @@ def test_semi_equals_generic(n_fft, hop, frames, batch, extra):
     mag = T(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01)
     fast, gen = make_plan(n_fft, hop, frames, batch, **dict(extra)), make_plan(n_fft, hop, frames, batch, **dict(extra))
     gen.force_generic(True)
-    assert fast.fast_path and not gen.fast_path
+    assert fast.path == "frame" and gen.path == "generic"
     out = []
     for p in (fast, gen):
         p.gla_init(None, mag, 0.99)
         p.iterate(4)
         s = p.iterate(1, eval_last=True)
         out.append((N(p.wave()), s, N(p.state_spec(0))))
-    assert rel_l2(out[0][0], out[1][0]) < 5e-5
+    # (three frames at hop = n_fft/2 leave the edges with a tiny envelope: float32 rounding noise is amplified
+    # ~10x per iteration by any two implementations, tools/acc_small.py)
+    tol = 5e-4 if frames <= 3 else 5e-5
+    assert rel_l2(out[0][0], out[1][0]) < tol
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-5)
-    assert rel_l2(out[0][2], out[1][2]) < 5e-5
+    assert rel_l2(out[0][2], out[1][2]) < tol
 
 
-def test_semi_vs_float64_at_demo_size():
-    """The reference's demo shape (main.py: n_fft 1024, hop 128) at a realistic size against the float64 kernels."""
-    n_fft, hop, frames, batch = 1024, 128, 600, 4
+def test_semi_vs_float64_at_speech_size():
+    """A 25 ms / 10 ms style analysis (hop does not divide n_fft) at a realistic size against the float64 kernels."""
+    n_fft, hop, frames, batch = 1024, 160, 600, 4
     mag = torch.rand((batch, n_fft // 2 + 1, frames), generator=torch.Generator().manual_seed(2)) + 0.01
     p32 = make_plan(n_fft, hop, frames, batch)
     p64 = make_plan(n_fft, hop, frames, batch, dtype=torch.float64)
-    assert p32.fast_path and not p64.fast_path
+    assert p32.path == "frame" and p64.path == "generic"
     c0 = p64.phase_init(mag.double().to(DEV))
     p32.gla_init(c0.to(torch.complex64), None, 0.3)
     p64.gla_init(c0, None, 0.3)
