@@ -208,10 +208,47 @@ struct Dft<16, INV> {
   }
 };
 
+// W_32^e = exp(-2 pi i e / 32)
+__device__ __forceinline__ v2f w32(int e) {
+  constexpr float tab[32][2] = {{1.000000000e+00f, -0.000000000e+00f}, {9.807852804e-01f, -1.950903220e-01f}, {9.238795325e-01f, -3.826834324e-01f}, {8.314696123e-01f, -5.555702330e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {5.555702330e-01f, -8.314696123e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {1.950903220e-01f, -9.807852804e-01f}, {6.123233996e-17f, -1.000000000e+00f}, {-1.950903220e-01f, -9.807852804e-01f}, {-3.826834324e-01f, -9.238795325e-01f}, {-5.555702330e-01f, -8.314696123e-01f}, {-7.071067812e-01f, -7.071067812e-01f}, {-8.314696123e-01f, -5.555702330e-01f}, {-9.238795325e-01f, -3.826834324e-01f}, {-9.807852804e-01f, -1.950903220e-01f}, {-1.000000000e+00f, -1.224646799e-16f}, {-9.807852804e-01f, 1.950903220e-01f}, {-9.238795325e-01f, 3.826834324e-01f}, {-8.314696123e-01f, 5.555702330e-01f}, {-7.071067812e-01f, 7.071067812e-01f}, {-5.555702330e-01f, 8.314696123e-01f}, {-3.826834324e-01f, 9.238795325e-01f}, {-1.950903220e-01f, 9.807852804e-01f}, {-1.836970199e-16f, 1.000000000e+00f}, {1.950903220e-01f, 9.807852804e-01f}, {3.826834324e-01f, 9.238795325e-01f}, {5.555702330e-01f, 8.314696123e-01f}, {7.071067812e-01f, 7.071067812e-01f}, {8.314696123e-01f, 5.555702330e-01f}, {9.238795325e-01f, 3.826834324e-01f}, {9.807852804e-01f, 1.950903220e-01f}};
+  return v2f{tab[e][0], tab[e][1]};
+}
+
+template <bool INV>
+struct Dft<32, INV> {
+  static __device__ __forceinline__ void run(v2f (&a)[32]) {
+    // n = 8*n1 + n0: radix-4 over n1 (in place -> slot n0 + 8*k1), twiddle W32^(n0*k1), radix-8 over n0
+#pragma unroll
+    for (int n0 = 0; n0 < 8; ++n0) dft4<INV>(a[n0], a[n0 + 8], a[n0 + 16], a[n0 + 24]);
+#pragma unroll
+    for (int k1 = 1; k1 < 4; ++k1)
+#pragma unroll
+      for (int n0 = 1; n0 < 8; ++n0) {
+        const int e = n0 * k1;
+        if (e == 8) a[n0 + 8 * k1] = rot<INV>(a[n0 + 8 * k1]);
+        else a[n0 + 8 * k1] = dirmul<INV>(a[n0 + 8 * k1], w32(e));
+      }
+    v2f o[32];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+      v2f t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = a[8 * k1 + i];
+      Dft<8, INV>::run(t);
+      // t[k0] = X[k1 + 4*k0]
+#pragma unroll
+      for (int k0 = 0; k0 < 8; ++k0) o[k1 + 4 * k0] = t[k0];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a[i] = o[i];
+  }
+};
+
 template <int R>
 struct Geo {
   static constexpr int C = 64 / R;       // cross-lane radix
   static constexpr int LOGC = C == 2 ? 1 : C == 4 ? 2 : C == 8 ? 3 : 4;
+  static_assert(R == 4 || R == 8 || R == 16 || R == 32, "n_fft must be 512, 1024, 2048 or 4096");
   static constexpr int M = 64 * R;       // complex points per frame
   static constexpr int N = 2 * M;        // n_fft
   static constexpr int H = R / 2;        // conjugate pairs per lane
@@ -237,7 +274,7 @@ template <int R>
 struct LaneConst {
   int lane, n2, v, kv, partner;
   v2f post;                // W_64^(n2*kv)
-  v2f stage[1];            // twiddle between the cross-lane radix-4 and radix-2 steps (C == 8)
+  v2f stage[2];            // twiddles between the cross-lane radix-4 and radix-2 steps (C == 8: one, C == 16: two)
   v2f wn;                  // W_N^lane
   int tr_a;                // transpose address for layout A: (kv*R + reg)*(R+1) + n2  -> base + reg*(R+1)
   int tr_b;                // layout B: lane*(R+1) + reg
@@ -258,13 +295,21 @@ __device__ __forceinline__ LaneConst<R> lane_consts() {
   k.v = k.lane / R;
   // frequency digit held at lane position v after the cross-lane transform, and the one twiddle of the
   // radix-4 x radix-2 split (C == 8 only): W8^(vl * kh) with v = 2*vh + vl, kv = kh + 4*kl, kh = vh, kl = vl
-  if (G::C == 4) {
+  k.stage[1] = v2f{1.0f, 0.0f};
+  if (G::C == 4 || G::C == 2) {
     k.kv = k.v;
     k.stage[0] = v2f{1.0f, 0.0f};
-  } else {
+  } else if (G::C == 8) {
     const int vh = k.v >> 1, vl = k.v & 1;
     k.kv = vh + 4 * vl;
     k.stage[0] = unit(2.0f * (float)(vl * vh) / 8.0f);
+  } else {
+    // C == 16, v = 4*vh + vl, vl = 2*b3 + b2 (lane bits 3, 2): radix-4 over vh, twiddle W16^(vl*kh), then the radix-4
+    // over vl as two radix-2 steps (bit 3 first, twiddle W4^(b2*k3), then bit 2); digits kh = vh, kl = b3 + 2*b2
+    const int vh = k.v >> 2, vl = k.v & 3, b3 = vl >> 1, b2 = vl & 1;
+    k.kv = vh + 4 * (b3 + 2 * b2);
+    k.stage[0] = unit(2.0f * (float)(vl * vh) / 16.0f);
+    k.stage[1] = (b3 && b2) ? v2f{0.0f, -1.0f} : v2f{1.0f, 0.0f};
   }
   k.partner = (64 - k.lane) & 63;
   k.post = unit(2.0f * (float)(k.n2 * k.kv) / 64.0f);
@@ -306,6 +351,21 @@ __device__ __forceinline__ void xlane_dft4(v2f& A, v2f& B, v2f& C, v2f& D) {
   swap32(C, D);
 }
 
+// DFT over lane bit 5 of two registers at once: after the first swap the low half of the wave holds both halves
+// of A (in A, B) and the high half both halves of B
+__device__ __forceinline__ void xlane_dft2(v2f& A, v2f& B) {
+  swap32(A, B);
+  const v2f sum = A + B, dif = A - B;
+  A = sum;
+  B = dif;
+  swap32(A, B);
+}
+// radix-2 over one lane bit (lower lane: a + partner, upper lane: partner - a)
+__device__ __forceinline__ v2f xlane_bf2(v2f z, int mask, float sg) {
+  const v2f p = shfl_xor2(z, mask);
+  return v2f{fmaf(z.x, sg, p.x), fmaf(z.y, sg, p.y)};
+}
+
 // ---- M-point FFT across the wave ------------------------------------------------------------------
 // forward: in z[u] = time sample 64u + lane; out z[j] = bin lane + 64j
 // pass-1 twiddles W_M^(lane*k1): read from the LDS table (default) or from a per-lane register copy
@@ -343,9 +403,22 @@ __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k
 #pragma unroll
   for (int k1 = 1; k1 < R; ++k1) z[k1] = cmul(z[k1], tw(k1));
   // cross-lane radix-C over v = lane / R; afterwards lane position v holds frequency digit k.kv
-  if (G::C == 4) {
+  if (G::C == 2) {
+#pragma unroll
+    for (int g = 0; g < R; g += 2) xlane_dft2(z[g], z[g + 1]);
+  } else if (G::C == 4) {
 #pragma unroll
     for (int g = 0; g < R; g += 4) xlane_dft4<false>(z[g], z[g + 1], z[g + 2], z[g + 3]);
+  } else if (G::C == 16) {
+#pragma unroll
+    for (int g = 0; g < R; g += 4) xlane_dft4<false>(z[g], z[g + 1], z[g + 2], z[g + 3]);
+    const float s3 = (k.lane & 8) ? -1.0f : 1.0f, s2 = (k.lane & 4) ? -1.0f : 1.0f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      z[i] = cmul(z[i], k.stage[0]);
+      z[i] = cmul(xlane_bf2(z[i], 8, s3), k.stage[1]);
+      z[i] = xlane_bf2(z[i], 4, s2);
+    }
   } else {
     // C == 8, v = 2*vh + vl: radix-4 over vh (lane bits 5,4), twiddle W8^(vl*kh), radix-2 over vl (lane bit 3)
 #pragma unroll
@@ -378,7 +451,19 @@ __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k
   for (int i = 0; i < R; ++i) tr[k.tr_b + i] = z[i];
 #pragma unroll
   for (int i = 0; i < R; ++i) z[i] = cmulc(tr[k.tr_a + i * (R + 1)], k.post);
-  if (G::C == 4) {
+  if (G::C == 2) {
+#pragma unroll
+    for (int g = 0; g < R; g += 2) xlane_dft2(z[g], z[g + 1]);
+  } else if (G::C == 4) {
+#pragma unroll
+    for (int g = 0; g < R; g += 4) xlane_dft4<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
+  } else if (G::C == 16) {
+    const float s3 = (k.lane & 8) ? -1.0f : 1.0f, s2 = (k.lane & 4) ? -1.0f : 1.0f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      z[i] = cmulc(xlane_bf2(z[i], 4, s2), k.stage[1]);
+      z[i] = cmulc(xlane_bf2(z[i], 8, s3), k.stage[0]);
+    }
 #pragma unroll
     for (int g = 0; g < R; g += 4) xlane_dft4<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
   } else {
@@ -875,7 +960,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused4(FastArgs a) {
 }
 
 template <int R, int OV, int MODE, bool EVAL>
-__global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
+__global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(FastArgs a) {
   using G = Geo<R>;
   using O = Ovl<R, OV>;
   constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
@@ -1103,7 +1188,7 @@ __global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused(FastArgs a) {
 // ISTFT of a spectrum held in pair layout: x = overlap-add(w * irfft(S)) / envelope  (methods.py:233: the
 // initial signal of griffin_lim / ADMM).  Same wave-per-chunk walk as k_fused, without the analysis half.
 template <int R, int OV>
-__global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused_istft(FastArgs a) {
+__global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_istft(FastArgs a) {
   using G = Geo<R>;
   using O = Ovl<R, OV>;
   constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
@@ -1652,6 +1737,15 @@ struct FastState {
   int get_state_spec(P&, int, cplx<T>*) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
 };
 
+// run STMT with `RR` bound to the compile-time registers-per-lane count R = n_fft / 128
+#define SPECINV_R_SWITCH(RV, ...)                      \
+  switch (RV) {                                        \
+    case 4: { constexpr int RR = 4; __VA_ARGS__; } break;   \
+    case 8: { constexpr int RR = 8; __VA_ARGS__; } break;   \
+    case 16: { constexpr int RR = 16; __VA_ARGS__; } break; \
+    default: { constexpr int RR = 32; __VA_ARGS__; } break; \
+  }
+
 template <>
 struct FastState<float> {
   using v2f = fast::v2f;
@@ -1673,7 +1767,7 @@ struct FastState<float> {
     if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
       if (e[0] == '1') return SPECINV_OK;
     }
-    if (cfg.n_fft == 2048 || cfg.n_fft == 1024) {
+    if (cfg.n_fft == 512 || cfg.n_fft == 1024 || cfg.n_fft == 2048 || cfg.n_fft == 4096) {
       xform_ok = true;              // any hop, any pad mode, centred or not
       xform_R = cfg.n_fft / 128;
     }
@@ -1684,8 +1778,8 @@ struct FastState<float> {
     OV = 0;
     for (int o : {2, 4, 8})
       if (cfg.hop_length * o == cfg.n_fft && R % o == 0) OV = o;
-    if (const char* e = getenv("SPECINV_FUSED_OV4_ONLY")) {
-      if (e[0] == '1' && OV != 4) OV = 0;
+    if (const char* e = getenv("SPECINV_DISABLE_FUSED")) {   // tests: put the shape on the frame kernel
+      if (e[0] == '1') OV = 0;
     }
     if (!cfg.center || OV == 0 || cfg.n_frames < OV + 2 || pad >= length) {
       // any other hop / centring: frame kernel on the wave-level FFT + gather overlap-add (k_semi)
@@ -1804,7 +1898,9 @@ struct FastState<float> {
   int begin(P& pl, int md, const void* spec_user, const void* mag_user, double* sum_m2_out) {
     const v2f* s = static_cast<const v2f*>(spec_user);
     const float* m = static_cast<const float*>(mag_user);
-    return R == 16 ? begin_t<16>(pl, md, s, m, sum_m2_out) : begin_t<8>(pl, md, s, m, sum_m2_out);
+    int rc = SPECINV_OK;
+    SPECINV_R_SWITCH(R, rc = begin_t<RR>(pl, md, s, m, sum_m2_out));
+    return rc;
   }
 
   // wave-level FFT usable for stand-alone transforms of this plan (any hop / frame count)
@@ -1826,11 +1922,11 @@ struct FastState<float> {
     a.pad = pl.pad;
     a.pad_mode = pad_mode >= 0 ? pad_mode : pl.cfg.pad_mode;
     a.scale = scale;
-    const size_t lds = xform_R == 16 ? fast::Geo<16>::lds_bytes(4) : fast::Geo<8>::lds_bytes(4);
+    size_t lds = 0;
+    const void* fn = nullptr;
+    SPECINV_R_SWITCH(xform_R, lds = fast::Geo<RR>::lds_bytes(4);
+                     fn = forward ? (const void*)fast::k_fast_stft<RR> : (const void*)fast::k_fast_inverse_frames<RR>);
     const unsigned grid = (unsigned)std::min<long long>((a.n_frames_total + 3) / 4, 256 * 12);
-    const void* fn;
-    if (xform_R == 16) fn = forward ? (const void*)fast::k_fast_stft<16> : (const void*)fast::k_fast_inverse_frames<16>;
-    else fn = forward ? (const void*)fast::k_fast_stft<8> : (const void*)fast::k_fast_inverse_frames<8>;
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&a};
     SI_HIP(hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, pl.stream));
@@ -1845,7 +1941,11 @@ struct FastState<float> {
     if constexpr (RR % 8 == 0) {
       if (OV == 8) fn = (const void*)fast::k_fused<RR, 8, MODE, EVAL>;
     }
-    if (OV == 4) fn = (const void*)fast::k_fused4<RR, MODE, EVAL>;
+    if constexpr (RR == 8 || RR == 16) {
+      if (OV == 4) fn = (const void*)fast::k_fused4<RR, MODE, EVAL>;     // the tuned copy for the headline shapes
+    } else {
+      if (OV == 4) fn = (const void*)fast::k_fused<RR, 4, MODE, EVAL>;
+    }
     if (OV == 2) fn = (const void*)fast::k_fused<RR, 2, MODE, EVAL>;
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1892,14 +1992,10 @@ struct FastState<float> {
     SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2, 3 * 1024) * sizeof(double)));
     for (int i = 0; i < n_iter; ++i) {
       const bool ev = eval_last && i == n_iter - 1;
-      int rc;
-      if (R == 16) {
-        if (mode == fast::MODE_GLA) rc = ev ? launch_semi<16, fast::MODE_GLA, true>(pl) : launch_semi<16, fast::MODE_GLA, false>(pl);
-        else rc = ev ? launch_semi<16, fast::MODE_ADMM, true>(pl) : launch_semi<16, fast::MODE_ADMM, false>(pl);
-      } else {
-        if (mode == fast::MODE_GLA) rc = ev ? launch_semi<8, fast::MODE_GLA, true>(pl) : launch_semi<8, fast::MODE_GLA, false>(pl);
-        else rc = ev ? launch_semi<8, fast::MODE_ADMM, true>(pl) : launch_semi<8, fast::MODE_ADMM, false>(pl);
-      }
+      int rc = SPECINV_OK;
+      SPECINV_R_SWITCH(R, if (mode == fast::MODE_GLA) rc = ev ? launch_semi<RR, fast::MODE_GLA, true>(pl)
+                                                               : launch_semi<RR, fast::MODE_GLA, false>(pl);
+                       else rc = ev ? launch_semi<RR, fast::MODE_ADMM, true>(pl) : launch_semi<RR, fast::MODE_ADMM, false>(pl));
       SI_TRY(rc);
     }
     n_partials = n_waves;
@@ -1940,14 +2036,10 @@ struct FastState<float> {
       a.inv1p = 1.0f / (float)(1.0 + (double)pl.coef);
       a.fwd_scale = pl.fc.fwd_scale;
       a.inv_scale = pl.fc.inv_scale;
-      int rc;
-      if (R == 16) {
-        if (mode == fast::MODE_GLA) rc = ev ? launch<16, fast::MODE_GLA, true>(pl, a) : launch<16, fast::MODE_GLA, false>(pl, a);
-        else rc = ev ? launch<16, fast::MODE_ADMM, true>(pl, a) : launch<16, fast::MODE_ADMM, false>(pl, a);
-      } else {
-        if (mode == fast::MODE_GLA) rc = ev ? launch<8, fast::MODE_GLA, true>(pl, a) : launch<8, fast::MODE_GLA, false>(pl, a);
-        else rc = ev ? launch<8, fast::MODE_ADMM, true>(pl, a) : launch<8, fast::MODE_ADMM, false>(pl, a);
-      }
+      int rc = SPECINV_OK;
+      SPECINV_R_SWITCH(R, if (mode == fast::MODE_GLA) rc = ev ? launch<RR, fast::MODE_GLA, true>(pl, a)
+                                                               : launch<RR, fast::MODE_GLA, false>(pl, a);
+                       else rc = ev ? launch<RR, fast::MODE_ADMM, true>(pl, a) : launch<RR, fast::MODE_ADMM, false>(pl, a));
       SI_TRY(rc);
       cur = nx;
     }
@@ -1962,8 +2054,9 @@ struct FastState<float> {
       const int hop = pl.cfg.hop_length;
       const long long total = (long long)pl.B() * nchunks * (OV - 1) * hop;
       const void* fn = nullptr;
-      if (R == 16) fn = OV == 8 ? (const void*)fast::k_add_tails<16, 8> : OV == 4 ? (const void*)fast::k_add_tails<16, 4> : (const void*)fast::k_add_tails<16, 2>;
-      else fn = OV == 8 ? (const void*)fast::k_add_tails<8, 8> : OV == 4 ? (const void*)fast::k_add_tails<8, 4> : (const void*)fast::k_add_tails<8, 2>;
+      SPECINV_R_SWITCH(R, if constexpr (RR % 8 == 0) { if (OV == 8) fn = (const void*)fast::k_add_tails<RR, 8>; }
+                       if (OV == 4) fn = (const void*)fast::k_add_tails<RR, 4>;
+                       if (OV == 2) fn = (const void*)fast::k_add_tails<RR, 2>);
       float* xo = out;
       const float* tl = xtail[cur].template as<float>();
       int Tn = pl.Tn(), nc = nchunks;
@@ -1980,15 +2073,9 @@ struct FastState<float> {
     SI_TRY(scratch.reserve((size_t)nf * pl.n_freq * sizeof(v2f)));
     const FastBuf& src = which == 0 ? Pb[cur] : Ub[cur];
     const FastBuf& mid = which == 0 ? Pmid[cur] : Umid[cur];
-    if (R == 16) {
-      const long long np = nf * fast::Geo<16>::H * 64;
-      hipLaunchKernelGGL((fast::k_pairs_to_spec<16>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
-                         src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf);
-    } else {
-      const long long np = nf * fast::Geo<8>::H * 64;
-      hipLaunchKernelGGL((fast::k_pairs_to_spec<8>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
-                         src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf);
-    }
+    SPECINV_R_SWITCH(R, const long long np = nf * fast::Geo<RR>::H * 64;
+                     hipLaunchKernelGGL((fast::k_pairs_to_spec<RR>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
+                                        src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf));
     SI_HIP(hipGetLastError());
     return pl.template transpose<cplx<float>>(scratch.template as<cplx<float>>(), out, pl.Tn(), pl.n_freq);
   }

@@ -52,7 +52,14 @@ def test_path_selection_at_the_edges():
     assert Plan(args_helper(torch.empty(1, 2048, 1), hop_length=512, window=w, onesided=False), 1, 40, torch.float32,
                 dev).path == "generic"
     w512 = torch.from_numpy(hann(512))
-    assert Plan(args_helper(torch.empty(1, 257, 1), hop_length=128, window=w512), 1, 40, torch.float32, dev).path == "generic"
+    assert Plan(args_helper(torch.empty(1, 257, 1), hop_length=128, window=w512), 1, 40, torch.float32, dev).path == "fused"
+    assert Plan(args_helper(torch.empty(1, 257, 1), hop_length=64, window=w512), 1, 40, torch.float32, dev).path == "frame"
+    w4k = torch.from_numpy(hann(4096))
+    assert Plan(args_helper(torch.empty(1, 2049, 1), hop_length=512, window=w4k), 1, 40, torch.float32, dev).path == "fused"
+    for n in (256, 400, 8192):      # below / between / above the wave-level sizes
+        wn = torch.from_numpy(hann(n))
+        assert Plan(args_helper(torch.empty(1, n // 2 + 1, 1), hop_length=n // 4, window=wn), 1, 40, torch.float32,
+                    dev).path == "generic"
     p = Plan(args_helper(probe, hop_length=512, window=w), 1, 6, torch.float32, dev)
     p.force_generic(True)
     assert p.path == "generic" and not p.fast_path

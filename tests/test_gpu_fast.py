@@ -168,7 +168,8 @@ def test_full_size_properties():
     assert np.abs(res["fast"][1] - res["f64"][1]).max() < 1e-5      # |dSC_lin| <= 1e-5 (north-star bar)
 
 
-@pytest.mark.parametrize("n_fft,hop,length", [(1024, 300, 9000), (2048, 512, 7 * 512), (2048, 333, 12000), (1024, 256, 2560)])
+@pytest.mark.parametrize("n_fft,hop,length", [(1024, 300, 9000), (2048, 512, 7 * 512), (2048, 333, 12000), (1024, 256, 2560),
+                                               (512, 128, 6000), (512, 77, 5000), (4096, 1024, 30000), (4096, 1500, 41000)])
 def test_fast_standalone_transforms(n_fft, hop, length):
     """specinv_stft / specinv_istft on the wave-level FFT (any hop) against the oracle and the generic kernels."""
     rng = np.random.default_rng(n_fft + hop)
@@ -245,7 +246,9 @@ def test_fast_transform_without_centering():
 
 # ---- hop = n_fft/8 (the reference's demo shape, main.py:13-14) and n_fft/2 on the fused kernel -------------------
 OV_SHAPES = [(1024, 128, 60, 2), (2048, 256, 45, 2), (2048, 1024, 20, 2), (1024, 512, 33, 3), (2048, 256, 10, 1),
-             (1024, 512, 4, 2)]
+             (1024, 512, 4, 2),
+             # n_fft 512 (R = 4 registers per lane, cross-lane radix 16) and 4096 (R = 32, cross-lane radix 2)
+             (512, 128, 70, 3), (512, 256, 41, 2), (4096, 1024, 24, 2), (4096, 512, 40, 1), (4096, 2048, 14, 2)]
 
 
 @pytest.mark.parametrize("n_fft,hop,frames,batch", OV_SHAPES)
@@ -271,7 +274,7 @@ def test_fused_other_overlaps_match_oracle(n_fft, hop, frames, batch, chunk):
     assert rel_l2(N(plan.state_spec(0)), st["pre_spec"]) < 3e-4
 
 
-@pytest.mark.parametrize("n_fft,hop,frames,batch", OV_SHAPES[:4])
+@pytest.mark.parametrize("n_fft,hop,frames,batch", OV_SHAPES[:4] + OV_SHAPES[6:])
 def test_fused_other_overlaps_admm_and_paths_agree(n_fft, hop, frames, batch):
     """ADMM on the fused kernel against the oracle; the same problem on the frame kernel and on the generic kernels."""
     rng = np.random.default_rng(21)
@@ -280,11 +283,11 @@ def test_fused_other_overlaps_admm_and_paths_agree(n_fft, hop, frames, batch):
     init = oracle.phase_init(mag, hop_length=hop, window=w)
     ref, st = oracle.admm(init, max_iter=3, rho=1.0, tol=0, hop_length=hop, window=w, return_state=True)
     fused = make_plan(n_fft, hop, frames, batch)
-    os.environ["SPECINV_FUSED_OV4_ONLY"] = "1"
+    os.environ["SPECINV_DISABLE_FUSED"] = "1"
     try:
         frame = make_plan(n_fft, hop, frames, batch)
     finally:
-        os.environ.pop("SPECINV_FUSED_OV4_ONLY", None)
+        os.environ.pop("SPECINV_DISABLE_FUSED", None)
     gen = make_plan(n_fft, hop, frames, batch)
     gen.force_generic(True)
     assert (fused.path, frame.path, gen.path) == ("fused", "frame", "generic")

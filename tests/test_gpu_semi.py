@@ -35,7 +35,8 @@ def make_plan(n_fft, hop, frames, batch, dtype=torch.float32, **kw):
 SHAPES = [(1024, 64, 40, 2, {}), (2048, 768, 21, 2, {}), (2048, 333, 17, 1, {}), (1024, 100, 33, 3, {}),
           (2048, 1024, 3, 2, {}), (1024, 256, 5, 2, {}), (2048, 512, 2, 1, dict(pad_mode="constant")),
           (1024, 256, 12, 2, dict(center=False, window=np.ones(1024, dtype=np.float32))),
-          (2048, 300, 10, 1, dict(pad_mode="circular")), (1024, 192, 16, 2, dict(normalized=True, pad_mode="replicate"))]
+          (2048, 300, 10, 1, dict(pad_mode="circular")), (512, 64, 50, 2, {}), (512, 100, 31, 2, {}),
+          (4096, 1000, 12, 1, {}), (4096, 1024, 5, 2, {}), (512, 128, 20, 2, dict(center=False, window=np.ones(512, dtype=np.float32))), (1024, 192, 16, 2, dict(normalized=True, pad_mode="replicate"))]
 
 
 @pytest.mark.parametrize("n_fft,hop,frames,batch,extra", SHAPES)
