@@ -203,7 +203,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic(args.workload if fused else args.workload + "_generic"),
-                         "kernel": "specinv::fast::k_fused<16,GLA>" if fused else "k_gla_frame+k_ola",
+                         "kernel": "specinv::fast::k_fused4<16, GLA>" if fused else "k_iter_pair+k_ola",
                          "launch_ms": launch_ms, "algorithmic_bytes_per_launch": launch_bytes,
                          "bytes_per_unit": unit_bytes},
         }

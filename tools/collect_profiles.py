@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-kernel = "specinv::fast::k_fused<16, 0, false>"
+kernel = "specinv::fast::k_fused4<16, 0, false>"
 out = os.path.join(ROOT, "profiles")
 stats = glob.glob(os.path.join(ROOT, f"gpurun_out/{tag}_kt/*/*kernel_stats.csv"))
 if stats:
@@ -45,7 +45,7 @@ json.dump(summary, open(os.path.join(out, f"{tag}_bench_pmc_k_fused.json"), "w")
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     fs, ws = counters["FETCH_SIZE"]["mean_per_launch"], counters["WRITE_SIZE"]["mean_per_launch"]
     json.dump({"C2": (2 * fs + ws) * 1024,
-               "_note": f"HBM bytes per launch of k_fused<16,0,false>: (2*FETCH_SIZE + WRITE_SIZE)*1024 from "
+               "_note": f"HBM bytes per launch of k_fused4<16,0,false>: (2*FETCH_SIZE + WRITE_SIZE)*1024 from "
                         f"profiles/{tag}_bench_pmc_k_fused.json; gfx950 FETCH_SIZE correction per MI355X_MICROARCH.md "
                         f"(HBM section)",
                "_fetch_size_kib": fs, "_write_size_kib": ws}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
