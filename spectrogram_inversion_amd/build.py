@@ -50,6 +50,9 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
     extra_flags = tuple(extra_flags) + tuple(os.environ.get("SPECINV_EXTRA_FLAGS", "").split())
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+           # the SLP vectoriser's packing choices cost registers in the wave-level FFT kernels: measured on one box,
+           # without it k_fused4 0.312 vs 0.318 ms, 2048/256 and 512/128 +10 %, RTISI-LA +14 % (tools/ab_generic.sh)
+           "-fno-slp-vectorize",
            *extra_flags, *srcs, "-o", global_out + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)

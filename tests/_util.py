@@ -23,6 +23,19 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
+def segment_errors(y, ref, seg):
+    """Per-segment error of a waveform, relative to the reference's RMS segment energy.  Griffin-Lim with
+    inconsistent magnitudes is locally chaotic: when a bin of some frame passes close to zero the projection
+    S*m/|S| is discontinuous there and two float32 implementations (or the reference in float32 and float64)
+    part ways in that neighbourhood only.  A robust gate looks at the distribution over segments."""
+    y, ref = np.asarray(y, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    y, ref = y.reshape(-1, y.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    n = (y.shape[1] // seg) * seg
+    e = ((y - ref)[:, :n].reshape(y.shape[0], -1, seg) ** 2).sum(-1)
+    r = (ref[:, :n].reshape(ref.shape[0], -1, seg) ** 2).sum(-1)
+    return np.sqrt(e / r.mean()).reshape(-1)
+
+
 def sc_linear(db):
     return 10.0 ** (np.asarray(db, dtype=np.float64) / 20.0)
 

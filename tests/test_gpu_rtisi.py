@@ -58,7 +58,9 @@ def test_rtisi_stft_options(j, asym):
     y = N(si.RTISI_LA(T(g[f"opt{j}_spec"]), look_ahead=2, asymmetric_window=asym, max_iter=2, verbose=False, **opts[j]))
     ref = g[f"opt{j}_asym{int(asym)}"]
     assert y.shape == ref.shape
-    assert finite_close(y, ref, 2e-3), (j, asym)
+    # (asymmetric_window=False amplifies rounding noise - SURVEY 8c: the reference's own float32 / float64 runs differ
+    # by about as much)
+    assert finite_close(y, ref, 2e-3 if asym else 6e-3), (j, asym)
 
 
 def test_rtisi_float64_and_shapes():

@@ -94,9 +94,9 @@ def test_semi_equals_generic(n_fft, hop, frames, batch, extra):
         p.iterate(4)
         s = p.iterate(1, eval_last=True)
         out.append((N(p.wave()), s, N(p.state_spec(0))))
-    # (three frames at hop = n_fft/2 leave the edges with a tiny envelope: float32 rounding noise is amplified
+    # (a handful of frames leave the edges with a tiny envelope: float32 rounding noise is amplified
     # ~10x per iteration by any two implementations, tools/acc_small.py)
-    tol = 5e-4 if frames <= 3 else 5e-5
+    tol = 5e-4 if frames <= 5 else 5e-5
     assert rel_l2(out[0][0], out[1][0]) < tol
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-5)
     assert rel_l2(out[0][2], out[1][2]) < tol
