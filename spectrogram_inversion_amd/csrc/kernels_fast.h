@@ -1755,6 +1755,7 @@ struct FastState<float> {
   int semi_grid = 0;
   int R = 0;
   int OV = 0;          // n_fft / hop of the fused kernel (2, 4 or 8)
+  bool state_in_place = true;
   int chunk = 32, nchunks = 0, n_waves = 0, n_partials = 0;
   int cur = 0;   // index of the buffers holding the current state
   int mode = fast::MODE_GLA;
@@ -1774,6 +1775,8 @@ struct FastState<float> {
     if (!xform_ok) return SPECINV_OK;
     R = xform_R;
     semi = false;
+    state_in_place = true;     // (same speed as ping-pong buffers, measured; a third less memory)
+    if (const char* e = getenv("SPECINV_STATE_INPLACE")) state_in_place = e[0] != '0';
     // fused kernel: hop = n_fft / 2, / 4 or / 8 (whole registers per hop-block), centred, enough frames
     OV = 0;
     for (int o : {2, 4, 8})
@@ -1822,9 +1825,10 @@ struct FastState<float> {
     const long long nf = (long long)pl.B() * pl.Tn();
     const size_t pbytes = (size_t)nf * G::H * 64 * sizeof(v4f);
     const size_t tail_bytes = (size_t)pl.B() * nchunks * (OV > 0 ? OV - 1 : 0) * hop * sizeof(float);
-    for (int i = 0; i < (semi ? 1 : 2); ++i) {     // k_semi updates its state in place
+    for (int i = 0; i < (semi ? 1 : 2); ++i) {     // x (and the chunk tails) ping-pong between iterations
       if (!semi) SI_TRY(xtail[i].reserve(tail_bytes));
       SI_TRY(xb[i].reserve((size_t)pl.B() * pl.length * sizeof(float)));
+      if (i == 1 && state_in_place) continue;      // the spectral state is updated in place
       SI_TRY(Pb[i].reserve(pbytes));
       SI_TRY(Pmid[i].reserve(nf * sizeof(v2f)));
       if (md == fast::MODE_ADMM) {
@@ -2014,14 +2018,16 @@ struct FastState<float> {
       a.x_out = xb[nx].template as<float>();
       a.xtail_in = xtail[cur].template as<float>();
       a.xtail_out = xtail[nx].template as<float>();
-      a.P_in = Pb[cur].template as<v4f>();
-      a.P_out = Pb[nx].template as<v4f>();
-      a.Pmid_in = Pmid[cur].template as<v2f>();
-      a.Pmid_out = Pmid[nx].template as<v2f>();
-      a.U_in = Ub[cur].template as<v4f>();
-      a.U_out = Ub[nx].template as<v4f>();
-      a.Umid_in = Umid[cur].template as<v2f>();
-      a.Umid_out = Umid[nx].template as<v2f>();
+      // the spectral state of a frame is read and written by the same lane: it can live in one buffer
+      const int ps = state_in_place ? 0 : cur, pn = state_in_place ? 0 : nx;
+      a.P_in = Pb[ps].template as<v4f>();
+      a.P_out = Pb[pn].template as<v4f>();
+      a.Pmid_in = Pmid[ps].template as<v2f>();
+      a.Pmid_out = Pmid[pn].template as<v2f>();
+      a.U_in = Ub[ps].template as<v4f>();
+      a.U_out = Ub[pn].template as<v4f>();
+      a.Umid_in = Umid[ps].template as<v2f>();
+      a.Umid_out = Umid[pn].template as<v2f>();
       a.m_pairs = mpairs.template as<v4f>();
       a.m_mid = mmid.template as<float>();
       a.window = pl.window.template as<float>();
@@ -2071,8 +2077,9 @@ struct FastState<float> {
   int get_state_spec(P& pl, int which, cplx<float>* out) {
     const long long nf = (long long)pl.B() * pl.Tn();
     SI_TRY(scratch.reserve((size_t)nf * pl.n_freq * sizeof(v2f)));
-    const FastBuf& src = which == 0 ? Pb[cur] : Ub[cur];
-    const FastBuf& mid = which == 0 ? Pmid[cur] : Umid[cur];
+    const int ps = (semi || state_in_place) ? 0 : cur;
+    const FastBuf& src = which == 0 ? Pb[ps] : Ub[ps];
+    const FastBuf& mid = which == 0 ? Pmid[ps] : Umid[ps];
     SPECINV_R_SWITCH(R, const long long np = nf * fast::Geo<RR>::H * 64;
                      hipLaunchKernelGGL((fast::k_pairs_to_spec<RR>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
                                         src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf));
