@@ -1,4 +1,4 @@
-// RTISI-LA on the wave-level FFT of kernels_fast.h (float32, onesided, hop = n_fft/4, n_fft in {1024, 2048}).
+// RTISI-LA on the wave-level FFT of kernels_fast.h (float32, onesided, hop = n_fft/4, n_fft in {512, 1024, 2048}).
 //
 // The recursion (reference: torch_specinv/methods.py:363-404) is serial per batch item, so what matters is
 // the latency of ONE inner step.  One workgroup owns one item; wave q owns look-ahead frame q for the whole
@@ -276,10 +276,12 @@ int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_it
   *used = false;
   const auto& cfg = pl.cfg;
   if (cfg.dtype != SPECINV_F32 || !cfg.onesided || cfg.hop_length * 4 != cfg.n_fft) return SPECINV_OK;
-  if (cfg.n_fft != 2048 && cfg.n_fft != 1024) return SPECINV_OK;
+  if (cfg.n_fft != 2048 && cfg.n_fft != 1024 && cfg.n_fft != 512) return SPECINV_OK;   // (4096: the per-wave tables
+                                                                                         // would not fit the registers)
   if (la > 7 || pl.force_generic) return SPECINV_OK;
   const int R = cfg.n_fft / 128;
-  const size_t lds = R == 16 ? fast::RtisiGeo<16>::lds_bytes(la) : fast::RtisiGeo<8>::lds_bytes(la);
+  const size_t lds = R == 16 ? fast::RtisiGeo<16>::lds_bytes(la) : R == 8 ? fast::RtisiGeo<8>::lds_bytes(la)
+                                                                          : fast::RtisiGeo<4>::lds_bytes(la);
   if (lds > 160 * 1024 - 1024) return SPECINV_OK;
   if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
     if (e[0] == '1') return SPECINV_OK;
@@ -292,12 +294,9 @@ int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_it
   SI_TRY(pl.fast.mpairs.reserve((size_t)nf * (H / 2) * 64 * sizeof(v4f)));
   SI_TRY(pl.fast.mmid.reserve(nf * sizeof(float)));
   const long long nm = nf * (H / 2) * 64;
-  if (R == 16)
-    hipLaunchKernelGGL((fast::k_mag_to_pairs<16>), dim3((unsigned)ceil_div(nm, 256)), dim3(256), 0, pl.stream,
-                       pl.mag.template as<float>(), pl.fast.mpairs.template as<v4f>(), pl.fast.mmid.template as<float>(), nf);
-  else
-    hipLaunchKernelGGL((fast::k_mag_to_pairs<8>), dim3((unsigned)ceil_div(nm, 256)), dim3(256), 0, pl.stream,
-                       pl.mag.template as<float>(), pl.fast.mpairs.template as<v4f>(), pl.fast.mmid.template as<float>(), nf);
+  SPECINV_R_SWITCH(R, hipLaunchKernelGGL((fast::k_mag_to_pairs<RR>), dim3((unsigned)ceil_div(nm, 256)), dim3(256), 0, pl.stream,
+                                         pl.mag.template as<float>(), pl.fast.mpairs.template as<v4f>(),
+                                         pl.fast.mmid.template as<float>(), nf));
   SI_HIP(hipGetLastError());
   SI_TRY(pl.frames_needed());
   fast::RtisiFastArgs a{};
@@ -318,7 +317,8 @@ int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_it
   const int threads = 64 * (la + 1);
   const void* fn;
   if (R == 16) fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<16, 256> : (const void*)fast::k_rtisi_fast<16, 512>;
-  else fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<8, 256> : (const void*)fast::k_rtisi_fast<8, 512>;
+  else if (R == 8) fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<8, 256> : (const void*)fast::k_rtisi_fast<8, 512>;
+  else fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<4, 256> : (const void*)fast::k_rtisi_fast<4, 512>;
   SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   void* kargs[] = {&a};
   SI_HIP(hipLaunchKernel(fn, dim3(pl.B()), dim3(threads), kargs, lds, pl.stream));

@@ -74,21 +74,24 @@ def test_rtisi_float64_and_shapes():
     assert y3.shape[0] == 1 and y3.dim() == 2
 
 
+@pytest.mark.parametrize("n_fft,la", [(2048, 3), (1024, -1), (512, 3), (512, 5)])
 @pytest.mark.parametrize("asym", [True, False])
-def test_rtisi_config3_shape_vs_oracle(asym):
-    """BASELINE config 3 frame size (n_fft 2048, hop 512, LA 3) on a short clip the oracle runs in seconds."""
+def test_rtisi_config3_shape_vs_oracle(asym, n_fft, la):
+    """BASELINE config 3 frame size (n_fft 2048, hop 512, LA 3) - and the other sizes of the wave-level kernel - on a
+    short clip the oracle runs in seconds."""
     rng = np.random.default_rng(33)
-    mag = rng.random((2, 1025, 12), dtype=np.float32)
-    w = hann(2048)
-    ref = oracle.rtisi_la(mag, look_ahead=3, asymmetric_window=asym, max_iter=5, alpha=0.99, hop_length=512, window=w)
-    y = N(si.RTISI_LA(T(mag), look_ahead=3, asymmetric_window=asym, max_iter=5, alpha=0.99, verbose=False,
-                      hop_length=512, window=torch.from_numpy(w)))
+    hop = n_fft // 4
+    mag = rng.random((2, n_fft // 2 + 1, 12), dtype=np.float32)
+    w = hann(n_fft)
+    ref = oracle.rtisi_la(mag, look_ahead=la, asymmetric_window=asym, max_iter=5, alpha=0.99, hop_length=hop, window=w)
+    y = N(si.RTISI_LA(T(mag), look_ahead=la, asymmetric_window=asym, max_iter=5, alpha=0.99, verbose=False,
+                      hop_length=hop, window=torch.from_numpy(w)))
     if asym:
         assert rel_l2(y, ref) < 1e-4, rel_l2(y, ref)
         return
     # asymmetric_window=False: the waveform decorrelates between any two float32 implementations
     # (SURVEY 8c); the reconstructions must still be equally consistent with the target
-    a = oracle.args_helper(1025, np.float32, hop_length=512, window=w)
+    a = oracle.args_helper(n_fft // 2 + 1, np.float32, hop_length=hop, window=w)
 
     def sc_lin(v):
         s = np.abs(oracle.stft(v, a))
