@@ -118,3 +118,42 @@ def test_large_batch_of_short_items():
         yi = N(si.griffin_lim(torch.from_numpy(mag[i]).to(DEV), max_iter=4, alpha=0.3, tol=0, verbose=False,
                               hop_length=256, window=w))
         np.testing.assert_array_equal(y[i], yi)          # bitwise: items do not interact
+
+
+@pytest.mark.parametrize("n_fft,hop,frames", [(1024, 256, 120_000), (512, 128, 200_000), (2048, 256, 40_000),
+                                             (1024, 300, 50_000)])
+def test_very_long_signal(n_fft, hop, frames):
+    """One item of up to 200 000 frames (30 M samples; 32-bit offsets inside a row, 64-bit across) against the float64
+    kernels: the beginning, the middle and the end of the waveform, the whole waveform and the spectral convergence."""
+    g = torch.Generator().manual_seed(frames)
+    mag = torch.rand((1, n_fft // 2 + 1, frames), generator=g) + 0.01
+    w = torch.from_numpy(hann(n_fft))
+    p32 = Plan(args_helper(mag, hop_length=hop, window=w), 1, frames, torch.float32, DEV)
+    p64 = Plan(args_helper(mag.double(), hop_length=hop, window=w.double()), 1, frames, torch.float64, DEV)
+    assert p32.path in ("fused", "frame") and p64.path == "generic"
+    c0 = p64.phase_init(mag.double().to(DEV))
+    p32.gla_init(c0.to(torch.complex64), None, 0.3)
+    p64.gla_init(c0, None, 0.3)
+    p32.iterate(4)
+    p64.iterate(4)
+    s32, s64 = p32.iterate(1, eval_last=True), p64.iterate(1, eval_last=True)
+    y32, y64 = p32.wave(), p64.wave()
+    assert y32.shape == (1, (frames - 1) * hop)
+    n = 50 * hop
+    for sl in (slice(0, n), slice(y64.shape[1] // 2, y64.shape[1] // 2 + n), slice(-n, None)):
+        assert rel_l2(N(y32[:, sl]), N(y64[:, sl])) < 2e-5
+    assert rel_l2(N(y32), N(y64)) < 1e-4                     # the north-star bar; (typically 2e-5)
+    assert abs(np.sqrt(s32[0] / s32[2]) - np.sqrt(s64[0] / s64[2])) < 1e-5
+
+
+def test_wide_batch():
+    """8 192 short items on the fused kernel (grid and batch-index arithmetic), spot-checked against solo runs."""
+    rng = np.random.default_rng(10)
+    mag = rng.random((8192, 257, 12), dtype=np.float32)
+    w = torch.from_numpy(hann(512))
+    y = N(si.griffin_lim(torch.from_numpy(mag).to(DEV), max_iter=3, alpha=0.3, tol=0, verbose=False, hop_length=128, window=w))
+    assert np.isfinite(y).all()
+    for i in (0, 4095, 8191):
+        yi = N(si.griffin_lim(torch.from_numpy(mag[i]).to(DEV), max_iter=3, alpha=0.3, tol=0, verbose=False,
+                              hop_length=128, window=w))
+        np.testing.assert_array_equal(y[i], yi)
