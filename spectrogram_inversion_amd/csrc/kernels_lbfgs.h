@@ -240,6 +240,86 @@ __global__ __launch_bounds__(64) void k_mel_forward_mfma(const cplx<float>* __re
   }
 }
 
+// Same contraction, one workgroup per 32 frames and ALL mel rows (MT tiles of 32): the spectrum - the large operand -
+// is read once.  The four waves split K (wave w takes the k-steps w, w+4, ...), each with wave-private LDS tiles
+// (no workgroup barrier inside the K loop: the LDS queue of a wave is in order), and add their accumulators through
+// LDS at the end.  The filterbank is read from a copy tiled per k-step as [k][m] (zero padded to 32 k x MT*32 m,
+// k_mel_tile): one k-step is MT*4 KB of contiguous, 16-byte aligned data - 16-byte loads, 16-byte LDS stores, and
+// conflict-free operand reads (consecutive m in consecutive lanes).  The |S| tile is kept [k][bt] with a padded row
+// for the same reason.  The next k-step's spectrum values are fetched before the MFMA block of the current one.
+template <int MT>
+__global__ __launch_bounds__(256) void k_mel_forward_splitk(const cplx<float>* __restrict__ spec,
+                                                            const float* __restrict__ mel_tiled, float* __restrict__ mm_out,
+                                                            int64_t BT, int F, int n_mels) {
+  using f4 = float __attribute__((ext_vector_type(4)));
+  constexpr int MW = MT * 32;                      // mel rows per k
+  extern __shared__ __attribute__((aligned(16))) float mel_smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sa = mel_smem + (size_t)wave * (32 * MW + 32 * 33);   // Mel tile [k][m]
+  float* sb = sa + 32 * MW;                                    // |S| tile [k][bt], row stride 33
+  const int64_t bt0 = (int64_t)blockIdx.x * 32;
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x16{0};
+  const int ksteps = (F + 31) / 32;
+  const int c = lane & 31, rh = lane >> 5;
+
+  cplx<float> sv[16];
+  auto fetch = [&](int ks) {
+    const int k = ks * 32 + c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = i * 2 + rh;
+      sv[i] = (k < F && bt0 + r < BT) ? spec[(bt0 + r) * F + k] : mk<float>(0.f, 0.f);
+    }
+  };
+  if (wave < ksteps) fetch(wave);
+  for (int ks = wave; ks < ksteps; ks += 4) {
+    const f4* mg = reinterpret_cast<const f4*>(mel_tiled + (size_t)ks * 32 * MW);
+    f4 mv[MT * 4];
+#pragma unroll
+    for (int i = 0; i < MT * 4; ++i) mv[i] = mg[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sb[c * 33 + i * 2 + rh] = __builtin_amdgcn_sqrtf(fmaf(sv[i].x, sv[i].x, sv[i].y * sv[i].y));
+#pragma unroll
+    for (int i = 0; i < MT * 4; ++i) reinterpret_cast<f4*>(sa)[i * 64 + lane] = mv[i];
+    if (ks + 4 < ksteps) fetch(ks + 4);                  // in flight during the MFMA block
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tiles are in LDS (and the compiler keeps the order)
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float b = sb[(kk + rh) * 33 + c];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = mfma_32x32x2(sa[(kk + rh) * MW + t * 32 + c], b, acc[t]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile reads done before the next k-step overwrites them
+  }
+  __syncthreads();
+  float* red = mel_smem;                                 // [wave][MT][16][64]
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave * MT + t) * 16 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < MT * 16 * 64; idx += 256) {
+    const int l = idx & 63, r = (idx >> 6) & 15, t = idx >> 10;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[((w * MT + t) * 16 + r) * 64 + l];
+    const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    const int64_t bt = bt0 + (l & 31);
+    if (m < n_mels && bt < BT) mm_out[bt * n_mels + m] = v;
+  }
+}
+
+// mel (n_mels, F) -> tiled[ks][k][m] with m padded to mw and k to 32 * ksteps (zeros)
+__global__ void k_mel_tile(const float* __restrict__ mel, float* __restrict__ tiled, int F, int n_mels, int mw, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int m = i % mw;
+  const int64_t k = i / mw;
+  tiled[i] = (m < n_mels && k < F) ? mel[(int64_t)m * F + k] : 0.f;
+}
+
 // dA[bt, f] = sum_m dM[bt, m] * Mel[m, f] ; G[bt, f] = dA * S/|S| * (interior ? 1/2 : 1)   (in place over S)
 // grid (ceil(BT/32), ceil(F/32)), one wave per block.
 __global__ __launch_bounds__(64) void k_mel_backward_mfma(cplx<float>* __restrict__ spec, const float* __restrict__ mel,
@@ -283,6 +363,67 @@ __global__ __launch_bounds__(64) void k_mel_backward_mfma(cplx<float>* __restric
       spec[idx] = mk<float>(s.x * g, s.y * g);
     }
   }
+}
+
+// Same contraction per workgroup of 32 frames: the dM tile (32 frames x all mel rows) is staged once as [m][bt]; each
+// wave then walks frequency tiles (wave w takes tiles w, w+4, ...), reading the filterbank from a copy tiled per
+// frequency tile as [m][f] (k_mel_tile_t) and the spectrum values of the tile before the MFMA block.
+template <int MT>
+__global__ __launch_bounds__(256) void k_mel_backward_tiles(cplx<float>* __restrict__ spec, const float* __restrict__ mel_tiled_t,
+                                                            const float* __restrict__ dM, int64_t BT, int F, int n_mels,
+                                                            int n_fft, int onesided) {
+  using f4 = float __attribute__((ext_vector_type(4)));
+  constexpr int MW = MT * 32;
+  extern __shared__ __attribute__((aligned(16))) float mel_smem[];
+  float* sd = mel_smem;                                   // dM tile [m][bt], row stride 33
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sm = mel_smem + MW * 33 + (size_t)wave * MW * 32;   // this wave's Mel tile [m][f]
+  const int64_t bt0 = (int64_t)blockIdx.x * 32;
+  const int c = lane & 31, rh = lane >> 5;
+  for (int e = threadIdx.x; e < 32 * MW; e += 256) {
+    const int bt = e / MW, m = e - bt * MW;
+    sd[m * 33 + bt] = (bt0 + bt < BT && m < n_mels) ? dM[(bt0 + bt) * n_mels + m] : 0.f;
+  }
+  __syncthreads();
+  const int ftiles = (F + 31) / 32;
+  for (int ft = wave; ft < ftiles; ft += 4) {
+    const int f = ft * 32 + c;
+    const f4* mg = reinterpret_cast<const f4*>(mel_tiled_t + (size_t)ft * MW * 32);
+#pragma unroll
+    for (int i = 0; i < MT * 4; ++i) reinterpret_cast<f4*>(sm)[i * 64 + lane] = mg[i * 64 + lane];
+    cplx<float> sv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * rh;
+      sv[r] = (bt0 + row < BT && f < F) ? spec[(bt0 + row) * F + f] : mk<float>(0.f, 0.f);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x16 acc = {0};
+#pragma unroll
+    for (int kk = 0; kk < MW; kk += 2) acc = mfma_32x32x2(sd[(kk + rh) * 33 + c], sm[(kk + rh) * 32 + c], acc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * rh;
+      if (bt0 + row < BT && f < F) {
+        const float mag = __builtin_amdgcn_sqrtf(fmaf(sv[r].x, sv[r].x, sv[r].y * sv[r].y));
+        float g = mag > 0.f ? acc[r] / mag : 0.f;
+        if (onesided && f != 0 && 2 * f != n_fft) g *= 0.5f;
+        spec[(bt0 + row) * F + f] = mk<float>(sv[r].x * g, sv[r].y * g);
+      }
+    }
+  }
+}
+
+// mel (n_mels, F) -> tiled_t[ft][m][f] with m padded to mw and f to 32 * ftiles (zeros)
+__global__ void k_mel_tile_t(const float* __restrict__ mel, float* __restrict__ tiled, int F, int n_mels, int mw, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int fl = i & 31;
+  const int m = (i >> 5) % mw;
+  const int64_t ft = i / ((int64_t)32 * mw);
+  const int64_t f = ft * 32 + fl;
+  tiled[i] = (m < n_mels && f < F) ? mel[(int64_t)m * F + f] : 0.f;
 }
 
 // ---- elementwise pieces -----------------------------------------------------------------------------------------
@@ -450,6 +591,23 @@ int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
     SI_TRY(pl.tf_mel.reserve((size_t)n_mels * pl.n_freq * sizeof(T)));
     SI_HIP(hipMemcpyAsync(pl.tf_mel.p, mel_fb, (size_t)n_mels * pl.n_freq * sizeof(T), hipMemcpyDeviceToDevice, pl.stream));
     pl.tf_mels = n_mels;
+    if constexpr (std::is_same<T, float>::value) {
+      const int mt = (n_mels + 31) / 32;
+      if (mt <= 4) {
+        const int ksteps = (pl.n_freq + 31) / 32;
+        const int64_t total = (int64_t)ksteps * 32 * mt * 32;
+        SI_TRY(pl.tf_mel_tiled.reserve((size_t)total * sizeof(float)));
+        hipLaunchKernelGGL(k_mel_tile, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream,
+                           pl.tf_mel.template as<float>(), pl.tf_mel_tiled.template as<float>(), pl.n_freq, n_mels, mt * 32,
+                           total);
+        SI_HIP(hipGetLastError());
+        SI_TRY(pl.tf_mel_tiled_t.reserve((size_t)total * sizeof(float)));
+        hipLaunchKernelGGL(k_mel_tile_t, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream,
+                           pl.tf_mel.template as<float>(), pl.tf_mel_tiled_t.template as<float>(), pl.n_freq, n_mels, mt * 32,
+                           total);
+        SI_HIP(hipGetLastError());
+      }
+    }
   } else {
     pl.tf_mels = 0;
   }
@@ -462,9 +620,24 @@ int tf_mel_forward(P& pl) {
   const int64_t BT = (int64_t)pl.B() * pl.Tn();
   SI_TRY(pl.tf_v.reserve((size_t)BT * pl.tf_mels * sizeof(T)));
   if constexpr (std::is_same<T, float>::value) {
-    hipLaunchKernelGGL(k_mel_forward_mfma, dim3((unsigned)ceil_div(BT, 32), (unsigned)ceil_div(pl.tf_mels, 32)), dim3(64), 0,
-                       pl.stream, pl.tf_spec.template as<cplx<float>>(), pl.tf_mel.template as<float>(),
-                       pl.tf_v.template as<float>(), BT, pl.n_freq, pl.tf_mels);
+    const int mt = (pl.tf_mels + 31) / 32;
+    if (mt <= 4) {
+      const void* fn = mt == 1 ? (const void*)k_mel_forward_splitk<1> : mt == 2 ? (const void*)k_mel_forward_splitk<2>
+                       : mt == 3 ? (const void*)k_mel_forward_splitk<3> : (const void*)k_mel_forward_splitk<4>;
+      const size_t lds = (size_t)4 * (32 * mt * 32 + 32 * 33) * sizeof(float);
+      SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const cplx<float>* sp = pl.tf_spec.template as<cplx<float>>();
+      const float* ml = pl.tf_mel_tiled.template as<float>();
+      float* out = pl.tf_v.template as<float>();
+      int64_t bt = BT;
+      int F = pl.n_freq, nm = pl.tf_mels;
+      void* kargs[] = {&sp, &ml, &out, &bt, &F, &nm};
+      SI_HIP(hipLaunchKernel(fn, dim3((unsigned)ceil_div(BT, 32)), dim3(256), kargs, lds, pl.stream));
+    } else {
+      hipLaunchKernelGGL(k_mel_forward_mfma, dim3((unsigned)ceil_div(BT, 32), (unsigned)ceil_div(pl.tf_mels, 32)), dim3(64), 0,
+                         pl.stream, pl.tf_spec.template as<cplx<float>>(), pl.tf_mel.template as<float>(),
+                         pl.tf_v.template as<float>(), BT, pl.n_freq, pl.tf_mels);
+    }
   } else {
     hipLaunchKernelGGL((k_mel_forward_valu<T>), dim3((unsigned)ceil_div(BT * pl.tf_mels, 256)), dim3(256), 0, pl.stream,
                        pl.tf_spec.template as<cplx<T>>(), pl.tf_mel.template as<T>(), pl.tf_v.template as<T>(), BT, pl.n_freq,
@@ -518,9 +691,24 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
                        pl.Tn(), pl.tf_mels, 1.0 / numel, pl.partials.template as<double>());
     SI_HIP(hipGetLastError());
     if constexpr (std::is_same<T, float>::value) {
-      hipLaunchKernelGGL(k_mel_backward_mfma, dim3((unsigned)ceil_div(BT, 32), (unsigned)ceil_div(pl.n_freq, 32)), dim3(64), 0,
-                         pl.stream, pl.tf_spec.template as<cplx<float>>(), pl.tf_mel.template as<float>(),
-                         pl.tf_v.template as<float>(), BT, pl.n_freq, pl.tf_mels, pl.N(), pl.cfg.onesided);
+      const int mt = (pl.tf_mels + 31) / 32;
+      if (mt <= 4) {
+        const void* fn = mt == 1 ? (const void*)k_mel_backward_tiles<1> : mt == 2 ? (const void*)k_mel_backward_tiles<2>
+                         : mt == 3 ? (const void*)k_mel_backward_tiles<3> : (const void*)k_mel_backward_tiles<4>;
+        const size_t lds = (size_t)(mt * 32 * 33 + 4 * mt * 32 * 32) * sizeof(float);
+        SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cplx<float>* sp = pl.tf_spec.template as<cplx<float>>();
+        const float* ml = pl.tf_mel_tiled_t.template as<float>();
+        const float* dm = pl.tf_v.template as<float>();
+        int64_t bt = BT;
+        int F = pl.n_freq, nm = pl.tf_mels, nf = pl.N(), os = pl.cfg.onesided;
+        void* kargs[] = {&sp, &ml, &dm, &bt, &F, &nm, &nf, &os};
+        SI_HIP(hipLaunchKernel(fn, dim3((unsigned)ceil_div(BT, 32)), dim3(256), kargs, lds, pl.stream));
+      } else {
+        hipLaunchKernelGGL(k_mel_backward_mfma, dim3((unsigned)ceil_div(BT, 32), (unsigned)ceil_div(pl.n_freq, 32)), dim3(64), 0,
+                           pl.stream, pl.tf_spec.template as<cplx<float>>(), pl.tf_mel.template as<float>(),
+                           pl.tf_v.template as<float>(), BT, pl.n_freq, pl.tf_mels, pl.N(), pl.cfg.onesided);
+      }
     } else {
       hipLaunchKernelGGL((k_mel_backward_valu<T>), dim3((unsigned)ceil_div(BT * pl.n_freq, 256)), dim3(256), 0, pl.stream,
                          pl.tf_spec.template as<C>(), pl.tf_mel.template as<T>(), pl.tf_v.template as<T>(), BT, pl.n_freq,

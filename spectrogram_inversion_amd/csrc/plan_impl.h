@@ -86,7 +86,7 @@ struct PlanT final : PlanBase {
   RtisiStream<T> rstream;
   DevBuf lb_scal;                       // device scalars of the L-BFGS two-loop recursion
   DevBuf eval_log;                      // per-evaluation sums of a run with deferred read-back
-  DevBuf tf_mel, tf_spec, tf_v;         // transform (L_BFGS) scratch
+  DevBuf tf_mel, tf_mel_tiled, tf_mel_tiled_t, tf_spec, tf_v;   // transform (L_BFGS) scratch
   std::vector<T> h_window;
   FrameCfg<T> fc{};
   size_t lds_bytes = 0;
