@@ -199,6 +199,11 @@ int specinv_vec_absmax_abssum(specinv_plan* plan, const void* x, int64_t n, doub
 int specinv_lbfgs_direction(specinv_plan* plan, const void* g, const void* const* s_list_host,
                             const void* const* y_list_host, const double* rho_host, int m, double h_diag,
                             void* d_out, int64_t n);
+/* fused passes of one L-BFGS iteration (torch.optim.LBFGS.step): the curvature pair y = g - g_prev, s = t*d with
+ * out_host = {y.s, y.y}; and the statistics of a step, out_host = {g.d, sum|g|, max|g|, max|d|}. */
+int specinv_lbfgs_pair(specinv_plan* plan, const void* g, const void* g_prev, const void* d, double t, void* y_out,
+                       void* s_out, int64_t n, double* out_host);
+int specinv_lbfgs_stats(specinv_plan* plan, const void* g, const void* d, int64_t n, double* out_host);
 
 #ifdef __cplusplus
 }

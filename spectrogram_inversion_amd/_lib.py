@@ -83,6 +83,8 @@ SIGNATURES = {
     "specinv_vec_axpy": (C.c_int, [_P, _D, _P, _P, _I64]),
     "specinv_vec_scale": (C.c_int, [_P, _D, _P, _P, _I64]),
     "specinv_vec_absmax_abssum": (C.c_int, [_P, _P, _I64, _DP]),
+    "specinv_lbfgs_pair": (C.c_int, [_P, _P, _P, _P, _D, _P, _P, _I64, _DP]),
+    "specinv_lbfgs_stats": (C.c_int, [_P, _P, _P, _I64, _DP]),
     "specinv_lbfgs_direction": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), _DP, C.c_int, _D, _P, _I64]),
 }
 

@@ -91,6 +91,132 @@ __global__ void k_scale(T alpha, const T* __restrict__ x, T* __restrict__ y, int
   if (i < n) y[i] = alpha * x[i];
 }
 
+// One pass for the curvature pair of an L-BFGS iteration: y = g - g_prev, s = t * d, partial sums of y.s and y.y
+template <typename T>
+__global__ void k_lbfgs_pair(const T* __restrict__ g, const T* __restrict__ gp, const T* __restrict__ d, T t,
+                             T* __restrict__ y, T* __restrict__ sv, int64_t n, double* __restrict__ part) {
+  __shared__ double red[16];
+  double ys = 0, yy = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const T yi = g[i] - gp[i];
+    const T si = t * d[i];
+    y[i] = yi;
+    sv[i] = si;
+    ys += (double)yi * (double)si;
+    yy += (double)yi * (double)yi;
+  }
+  const double a = block_sum(ys, red), b = block_sum(yy, red);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = a;
+    part[2 * blockIdx.x + 1] = b;
+  }
+}
+
+// One pass for what a step needs to know about g and d: g.d, max|g|, sum|g|, max|d|
+template <typename T>
+__global__ void k_lbfgs_stats(const T* __restrict__ g, const T* __restrict__ d, int64_t n, double* __restrict__ part) {
+  __shared__ double red[16];
+  __shared__ double mx[2][16];
+  double gd = 0, sg = 0, mg = 0, md = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double gi = (double)g[i], di = (double)d[i];
+    gd += gi * di;
+    const double ag = fabs(gi), ad = fabs(di);
+    sg += ag;
+    mg = ag > mg ? ag : mg;
+    md = ad > md ? ad : md;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o1 = __shfl_xor(mg, off, 64), o2 = __shfl_xor(md, off, 64);
+    mg = o1 > mg ? o1 : mg;
+    md = o2 > md ? o2 : md;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    mx[0][wave] = mg;
+    mx[1][wave] = md;
+  }
+  const double a = block_sum(gd, red), b = block_sum(sg, red);
+  if (threadIdx.x == 0) {
+    double m0 = 0, m1 = 0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) {
+      m0 = mx[0][w] > m0 ? mx[0][w] : m0;
+      m1 = mx[1][w] > m1 ? mx[1][w] : m1;
+    }
+    part[4 * blockIdx.x] = a;
+    part[4 * blockIdx.x + 1] = b;
+    part[4 * blockIdx.x + 2] = m0;
+    part[4 * blockIdx.x + 3] = m1;
+  }
+}
+
+// out[0..1] = sums of part[4i], part[4i+1]; out[2..3] = maxima of part[4i+2], part[4i+3]   (one workgroup, fixed order)
+__global__ void k_finish_stats(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double red[16];
+  __shared__ double mx[2][16];
+  double a = 0, b = 0, m0 = 0, m1 = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    a += part[4 * i];
+    b += part[4 * i + 1];
+    m0 = part[4 * i + 2] > m0 ? part[4 * i + 2] : m0;
+    m1 = part[4 * i + 3] > m1 ? part[4 * i + 3] : m1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o0 = __shfl_xor(m0, off, 64), o1 = __shfl_xor(m1, off, 64);
+    m0 = o0 > m0 ? o0 : m0;
+    m1 = o1 > m1 ? o1 : m1;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    mx[0][threadIdx.x >> 6] = m0;
+    mx[1][threadIdx.x >> 6] = m1;
+  }
+  const double ta = block_sum(a, red), tb = block_sum(b, red);
+  if (threadIdx.x == 0) {
+    double r0 = 0, r1 = 0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) {
+      r0 = mx[0][w] > r0 ? mx[0][w] : r0;
+      r1 = mx[1][w] > r1 ? mx[1][w] : r1;
+    }
+    out[0] = ta;
+    out[1] = tb;
+    out[2] = r0;
+    out[3] = r1;
+  }
+}
+
+template <typename P, typename T>
+int lb_pair(P& pl, const T* g, const T* gp, const T* d, double t, T* y, T* sv, int64_t n, double* out2) {
+  SI_CHECK(g && gp && d && y && sv && out2 && n > 0, SPECINV_EINVAL, "bad arguments");
+  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * 2, 3 * 1024) * sizeof(double)));
+  hipLaunchKernelGGL((k_lbfgs_pair<T>), dim3(nb), dim3(256), 0, pl.stream, g, gp, d, (T)t, y, sv, n,
+                     pl.partials.template as<double>());
+  SI_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), (int64_t)nb, 2,
+                     pl.sums.template as<double>());
+  SI_HIP(hipGetLastError());
+  SI_HIP(hipMemcpyAsync(out2, pl.sums.p, 2 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(hipStreamSynchronize(pl.stream));
+  return SPECINV_OK;
+}
+
+template <typename P, typename T>
+int lb_stats(P& pl, const T* g, const T* d, int64_t n, double* out4) {
+  SI_CHECK(g && d && out4 && n > 0, SPECINV_EINVAL, "bad arguments");
+  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * 4, 3 * 1024) * sizeof(double)));
+  hipLaunchKernelGGL((k_lbfgs_stats<T>), dim3(nb), dim3(256), 0, pl.stream, g, d, n, pl.partials.template as<double>());
+  SI_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_finish_stats, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), nb,
+                     pl.sums.template as<double>());
+  SI_HIP(hipGetLastError());
+  SI_HIP(hipMemcpyAsync(out4, pl.sums.p, 4 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(hipStreamSynchronize(pl.stream));
+  return SPECINV_OK;
+}
+
 template <typename P, typename T>
 int lb_dot(P& pl, const T* a, const T* b, int64_t n, double* out) {
   SI_CHECK(a && b && out && n > 0, SPECINV_EINVAL, "bad arguments");

@@ -628,6 +628,13 @@ struct PlanT final : PlanBase {
                       double h_diag, void* d_out, int64_t n) override {
     return lb_direction(*this, static_cast<const T*>(g), s_list, y_list, rho, m, h_diag, static_cast<T*>(d_out), n);
   }
+  int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out) override {
+    return lb_pair(*this, static_cast<const T*>(g), static_cast<const T*>(gp), static_cast<const T*>(d), t, static_cast<T*>(y),
+                   static_cast<T*>(sv), n, out);
+  }
+  int lbfgs_stats(const void* g, const void* d, int64_t n, double* out) override {
+    return lb_stats(*this, static_cast<const T*>(g), static_cast<const T*>(d), n, out);
+  }
 };
 
 }  // namespace specinv

@@ -332,5 +332,14 @@ int specinv_lbfgs_direction(specinv_plan* plan, const void* g, const void* const
   ENTER(plan);
   return plan->impl->lbfgs_direction(g, s_list_host, y_list_host, rho_host, m, h_diag, d_out, n);
 }
+int specinv_lbfgs_pair(specinv_plan* plan, const void* g, const void* g_prev, const void* d, double t, void* y_out,
+                       void* s_out, int64_t n, double* out_host) {
+  ENTER(plan);
+  return plan->impl->lbfgs_pair(g, g_prev, d, t, y_out, s_out, n, out_host);
+}
+int specinv_lbfgs_stats(specinv_plan* plan, const void* g, const void* d, int64_t n, double* out_host) {
+  ENTER(plan);
+  return plan->impl->lbfgs_stats(g, d, n, out_host);
+}
 
 }  // extern "C"

@@ -42,6 +42,12 @@ class HipVecOps:
     def direction(self, g, ss, ys, rho, h_diag):
         return self.plan.lbfgs_direction(g, ss, ys, rho, h_diag)
 
+    def pair(self, g, g_prev, d, t):
+        return self.plan.lbfgs_pair(g, g_prev, d, t)
+
+    def stats(self, g, d):
+        return self.plan.lbfgs_stats(g, d)
+
 
 def _cubic_step(xa, fa, ga, xb, fb, gb, bounds=None):
     """Minimiser of the cubic interpolating (xa, fa, ga) and (xb, fb, gb), clipped to bounds."""
@@ -169,11 +175,13 @@ class LBFGS:
     # ---- one optimizer.step ------------------------------------------------------------------
     def step(self, fg):
         ops, x = self.ops, self.x
+        fused = hasattr(ops, "pair") and hasattr(ops, "stats")     # one pass per group of vector operations
         loss, g = fg(x)
         first_loss = loss
         evals = 1
         self.func_evals += 1
-        if ops.absmax_abssum(g)[0] <= self.tol_grad:
+        g_absmax = ops.absmax_abssum(g)[0]
+        if g_absmax <= self.tol_grad:
             return first_loss
         d, t = self.d, self.t
         n_iter = 0
@@ -184,10 +192,13 @@ class LBFGS:
                 d = ops.scaled(-1.0, g)
                 self.ys, self.ss, self.rho, self.h_diag = [], [], [], 1.0
             else:
-                y = g.clone()
-                ops.axpy(-1.0, self.prev_grad, y)
-                s = ops.scaled(t, d)
-                ys = ops.dot(y, s)
+                if fused:
+                    y, s, ys, yy = ops.pair(g, self.prev_grad, d, t)
+                else:
+                    y = g.clone()
+                    ops.axpy(-1.0, self.prev_grad, y)
+                    s = ops.scaled(t, d)
+                    ys, yy = ops.dot(y, s), None
                 if ys > 1e-10:
                     if len(self.ys) == self.history_size:
                         self.ys.pop(0)
@@ -196,15 +207,19 @@ class LBFGS:
                     self.ys.append(y)
                     self.ss.append(s)
                     self.rho.append(1.0 / ys)
-                    self.h_diag = ys / ops.dot(y, y)
+                    self.h_diag = ys / (yy if yy is not None else ops.dot(y, y))
                 d = self._direction(g)
-            self.prev_grad = g.clone()
+            self.prev_grad = g if fused else g.clone()     # fg returns a fresh tensor: nothing writes into it later
             self.prev_loss = loss
+            if fused:
+                gtd, g_abssum, g_absmax, d_absmax = ops.stats(g, d)
+            else:
+                gtd, d_absmax = ops.dot(g, d), None
+                g_abssum = ops.absmax_abssum(g)[1] if self.total_iters == 1 else None
             if self.total_iters == 1:
-                t = min(1.0, 1.0 / ops.absmax_abssum(g)[1]) * self.lr
+                t = min(1.0, 1.0 / g_abssum) * self.lr
             else:
                 t = self.lr
-            gtd = ops.dot(g, d)
             if gtd > -self.tol_change:
                 break
             ls_evals = 0
@@ -223,7 +238,9 @@ class LBFGS:
             self.func_evals += ls_evals
             if n_iter == self.max_iter or evals >= self.max_eval or opt:
                 break
-            if abs(t) * ops.absmax_abssum(d)[0] <= self.tol_change:
+            if d_absmax is None:
+                d_absmax = ops.absmax_abssum(d)[0]
+            if abs(t) * d_absmax <= self.tol_change:
                 break
             if abs(loss - self.prev_loss) < self.tol_change:
                 break

@@ -406,6 +406,22 @@ class Plan:
                                                     g.numel()))
         return d
 
+    def lbfgs_pair(self, g, g_prev, d, t):
+        """y = g - g_prev, s = t*d in one pass; returns (y, s, y.s, y.y)."""
+        self._sync_stream()
+        y, s = torch.empty_like(g), torch.empty_like(g)
+        out = (C.c_double * 2)()
+        _lib.check(self.lib.specinv_lbfgs_pair(self._h, g.data_ptr(), g_prev.data_ptr(), d.data_ptr(), float(t), y.data_ptr(),
+                                               s.data_ptr(), g.numel(), out))
+        return y, s, out[0], out[1]
+
+    def lbfgs_stats(self, g, d):
+        """(g.d, sum|g|, max|g|, max|d|) in one pass."""
+        self._sync_stream()
+        out = (C.c_double * 4)()
+        _lib.check(self.lib.specinv_lbfgs_stats(self._h, g.data_ptr(), d.data_ptr(), g.numel(), out))
+        return out[0], out[1], out[2], out[3]
+
     def vec_absmax_abssum(self, x):
         self._sync_stream()
         out = (C.c_double * 2)()
