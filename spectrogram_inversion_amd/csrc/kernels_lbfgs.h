@@ -665,14 +665,24 @@ __global__ void k_grad_frames(FrameCfg<T> c, const cplx<T>* __restrict__ g, T* _
   spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
 }
 
-// overlap-add of the gradient frames over the padded signal and fold of the padded margins
+// Fold of the padded margins onto the signal: grad already holds the plain overlap-add of the gradient frames over
+// the signal's own positions (k_ola / k_ola_f4 without the envelope); every sample within `pad` of an edge also
+// receives what the padding copied from it (reflect / replicate / circular).  One thread per margin sample.
 template <typename T>
-__global__ void k_grad_fold(const T* __restrict__ frames, T* __restrict__ grad, int n_fft, int hop, int pad, int pad_mode,
-                            int n_frames, int64_t len, int64_t total) {
+__global__ void k_grad_fold_margins(const T* __restrict__ frames, T* __restrict__ grad, int n_fft, int hop, int pad,
+                                    int pad_mode, int n_frames, int64_t len, int64_t rows) {
+  const int64_t per_row = 2 * ((int64_t)pad + 1);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int64_t bi = i / len;
-  const int64_t n = i - bi * len;
+  if (i >= rows * per_row) return;
+  const int64_t bi = i / per_row, j = i - bi * per_row;
+  int64_t n;
+  if (j <= pad) {
+    n = j;                                            // left stretch 0 .. pad
+    if (n >= len) return;
+  } else {
+    n = len - 1 - pad + (j - pad - 1);                // right stretch len-1-pad .. len-1
+    if (n <= pad || n >= len) return;                 // (short signals: already covered by the left stretch)
+  }
   const T* fr = frames + bi * n_frames * n_fft;
   const int64_t covered = (int64_t)(n_frames - 1) * hop + n_fft;   // padded positions that receive any frame
   auto at = [&](int64_t np) -> T {                                 // gradient w.r.t. padded sample np
@@ -684,28 +694,26 @@ __global__ void k_grad_fold(const T* __restrict__ frames, T* __restrict__ grad, 
     for (int64_t t = t_lo; t <= t_hi; ++t) acc += fr[t * n_fft + (np - t * hop)];
     return acc;
   };
-  T g = at(n + pad);
-  if (pad > 0) {
-    switch (pad_mode) {
-      case SPECINV_PAD_REFLECT:
-        if (n >= 1 && n <= pad) g += at(pad - n);                               // left margin i = pad - n
-        if (n <= len - 2 && n >= len - 1 - pad) g += at(pad + len + (len - 2 - n));
-        break;
-      case SPECINV_PAD_REPLICATE:
-        if (n == 0)
-          for (int64_t j = 0; j < pad; ++j) g += at(j);
-        if (n == len - 1)
-          for (int64_t j = 0; j < pad; ++j) g += at(pad + len + j);
-        break;
-      case SPECINV_PAD_CIRCULAR:
-        if (n >= len - pad) g += at(n - (len - pad));
-        if (n < pad) g += at(pad + len + n);
-        break;
-      default:
-        break;
-    }
+  T g = 0;
+  switch (pad_mode) {
+    case SPECINV_PAD_REFLECT:
+      if (n >= 1 && n <= pad) g += at(pad - n);                               // left margin i = pad - n
+      if (n <= len - 2 && n >= len - 1 - pad) g += at(pad + len + (len - 2 - n));
+      break;
+    case SPECINV_PAD_REPLICATE:
+      if (n == 0)
+        for (int64_t q = 0; q < pad; ++q) g += at(q);
+      if (n == len - 1)
+        for (int64_t q = 0; q < pad; ++q) g += at(pad + len + q);
+      break;
+    case SPECINV_PAD_CIRCULAR:
+      if (n >= len - pad) g += at(n - (len - pad));
+      if (n < pad) g += at(pad + len + n);
+      break;
+    default:
+      break;
   }
-  grad[i] = g;
+  grad[bi * len + n] += g;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
@@ -848,10 +856,7 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
   // frames of the gradient: irfft-style inverse with the forward scale
   SI_TRY(pl.frames_needed());
   SI_TRY(pl.inverse_frames(pl.tf_spec.template as<C>(), pl.frames.template as<T>(), pl.fc.fwd_scale, len));
-  const int64_t total = (int64_t)pl.B() * len;
-  hipLaunchKernelGGL((k_grad_fold<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, pl.frames.template as<T>(),
-                     grad, pl.N(), pl.cfg.hop_length, pl.pad, pl.cfg.pad_mode, pl.Tn(), len, total);
-  SI_HIP(hipGetLastError());
+  SI_TRY(pl.launch_grad_fold(pl.frames.template as<T>(), grad, len));
   double s;
   SI_HIP(hipMemcpyAsync(&s, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
   SI_HIP(hipStreamSynchronize(pl.stream));

@@ -194,19 +194,36 @@ struct PlanT final : PlanBase {
     return c;
   }
 
-  int launch_ola(const T* fr, T* out, bool use_env) {
-    const int64_t total = (int64_t)B() * length;
+  // `len`: samples per row of `out` (default: the plan's length; another length with the same frame count is allowed
+  // for the un-normalised form only, the envelope belongs to the plan's length)
+  int launch_ola(const T* fr, T* out, bool use_env, int64_t len = -1) {
+    if (len < 0) len = length;
+    SI_CHECK(!use_env || len == length, SPECINV_EINVAL, "envelope division needs the plan's own signal length");
+    const int64_t total = (int64_t)B() * len;
     if constexpr (std::is_same<T, float>::value) {
-      if (cfg.hop_length % 4 == 0 && N() % 4 == 0 && pad % 4 == 0 && length % 4 == 0) {
+      if (cfg.hop_length % 4 == 0 && N() % 4 == 0 && pad % 4 == 0 && len % 4 == 0) {
         hipLaunchKernelGGL(k_ola_f4, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, stream, fr, env.as<float>(), out,
-                           N(), cfg.hop_length, pad, Tn(), length, total / 4, use_env ? 1 : 0);
+                           N(), cfg.hop_length, pad, Tn(), len, total / 4, use_env ? 1 : 0);
         SI_HIP(hipGetLastError());
         return SPECINV_OK;
       }
     }
     hipLaunchKernelGGL((k_ola<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, fr, env.as<T>(), out,
-                       N(), cfg.hop_length, pad, Tn(), length, total, use_env ? 1 : 0);
+                       N(), cfg.hop_length, pad, Tn(), len, total, use_env ? 1 : 0);
     SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+
+  // gradient of a centre-padded analysis w.r.t. the signal: overlap-add over the signal's own positions plus the
+  // fold of the padded margins (reflect / replicate / circular copies)
+  int launch_grad_fold(const T* fr, T* grad, int64_t len) {
+    SI_TRY(launch_ola(fr, grad, false, len));
+    if (pad > 0 && cfg.pad_mode != SPECINV_PAD_CONSTANT) {
+      const int64_t margin = (int64_t)B() * 2 * (pad + 1);
+      hipLaunchKernelGGL((k_grad_fold_margins<T>), dim3((unsigned)ceil_div(margin, 256)), dim3(256), 0, stream, fr, grad,
+                         N(), cfg.hop_length, pad, cfg.pad_mode, Tn(), len, (int64_t)B());
+      SI_HIP(hipGetLastError());
+    }
     return SPECINV_OK;
   }
 
@@ -548,10 +565,7 @@ struct PlanT final : PlanBase {
     }
     SI_TRY(frames_needed());
     SI_TRY(inverse_frames(tmp_spec.as<C>(), frames.as<T>(), fc.fwd_scale, len));
-    const int64_t total = (int64_t)B() * len;
-    hipLaunchKernelGGL((k_grad_fold<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, frames.as<T>(),
-                       static_cast<T*>(g_x_out), N(), cfg.hop_length, pad, cfg.pad_mode, Tn(), len, total);
-    SI_HIP(hipGetLastError());
+    SI_TRY(launch_grad_fold(frames.as<T>(), static_cast<T*>(g_x_out), len));
     return SPECINV_OK;
   }
 
