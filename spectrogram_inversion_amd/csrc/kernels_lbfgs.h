@@ -512,17 +512,25 @@ __global__ __launch_bounds__(256) void k_mel_backward_tiles(cplx<float>* __restr
   }
   __syncthreads();
   const int ftiles = (F + 31) / 32;
-  for (int ft = wave; ft < ftiles; ft += 4) {
+  cplx<float> sv[16], sn[16];
+  f4 mv[MT * 4], mn[MT * 4];
+  auto fetch = [&](int ft, cplx<float>(&svv)[16], f4(&mvv)[MT * 4]) {
     const int f = ft * 32 + c;
     const f4* mg = reinterpret_cast<const f4*>(mel_tiled_t + (size_t)ft * MW * 32);
 #pragma unroll
-    for (int i = 0; i < MT * 4; ++i) reinterpret_cast<f4*>(sm)[i * 64 + lane] = mg[i * 64 + lane];
-    cplx<float> sv[16];
+    for (int i = 0; i < MT * 4; ++i) mvv[i] = mg[i * 64 + lane];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * rh;
-      sv[r] = (bt0 + row < BT && f < F) ? spec[(bt0 + row) * F + f] : mk<float>(0.f, 0.f);
+      svv[r] = (bt0 + row < BT && f < F) ? spec[(bt0 + row) * F + f] : mk<float>(0.f, 0.f);
     }
+  };
+  if (wave < ftiles) fetch(wave, sv, mv);
+  for (int ft = wave; ft < ftiles; ft += 4) {
+    const int f = ft * 32 + c;
+#pragma unroll
+    for (int i = 0; i < MT * 4; ++i) reinterpret_cast<f4*>(sm)[i * 64 + lane] = mv[i];
+    if (ft + 4 < ftiles) fetch(ft + 4, sn, mn);          // the next tile's operands fly during this tile's MFMA block
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     f32x16 acc = {0};
 #pragma unroll
@@ -538,6 +546,10 @@ __global__ __launch_bounds__(256) void k_mel_backward_tiles(cplx<float>* __restr
         spec[(bt0 + row) * F + f] = mk<float>(sv[r].x * g, sv[r].y * g);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = sn[r];
+#pragma unroll
+    for (int i = 0; i < MT * 4; ++i) mv[i] = mn[i];
   }
 }
 
