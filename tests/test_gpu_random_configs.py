@@ -86,3 +86,58 @@ def test_random_configuration(seed):
     good = env > 1e-3 * env.max()
     assert np.array_equal(np.isfinite(y), np.isfinite(ref))
     assert finite_close(y[..., good], ref[..., good], tol), (seed, path)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_rtisi_configuration(seed):
+    """RTISI_LA (asymmetric window: the numerically stable variant) against the oracle, and the streaming form against
+    the whole-signal form, on random shapes."""
+    rng = np.random.default_rng(5000 + seed)
+    n_fft = int(rng.choice([64, 128, 200, 256, 512, 512, 1024, 1024, 2048]))
+    hop = int(rng.choice([n_fft // 4, n_fft // 4, n_fft // 2, n_fft // 8, n_fft // 3, int(rng.integers(n_fft // 8, n_fft))]))
+    dtype = np.float64 if rng.random() < 0.3 else np.float32
+    frames = int(rng.integers(3, 14))
+    batch = int(rng.integers(1, 3))
+    keep = (n_fft - 1) // hop
+    la = int(rng.choice([-1, 0, 1, 2, 3, min(keep + 1, 7)]))
+    iters = int(rng.integers(1, 4))
+    alpha = float(rng.choice([0.0, 0.5, 0.99]))
+    mag = (rng.random((batch, n_fft // 2 + 1, frames)) + 0.02).astype(dtype)
+    w = hann(n_fft, dtype)
+    ref = oracle.rtisi_la(mag, look_ahead=la, asymmetric_window=True, max_iter=iters, alpha=alpha, hop_length=hop, window=w)
+    tw = torch.from_numpy(w)
+    y = si.RTISI_LA(torch.from_numpy(mag).to(DEV), look_ahead=la, asymmetric_window=True, max_iter=iters, alpha=alpha,
+                    verbose=False, hop_length=hop, window=tw)
+    ref = np.asarray(ref).reshape(tuple(y.shape))
+    tol = 5e-4 if dtype == np.float32 else 1e-9
+    yn = y.cpu().numpy()
+    assert np.array_equal(np.isfinite(yn), np.isfinite(ref))
+    fin = np.isfinite(ref)
+    if dtype == np.float32:
+        # the recursion amplifies rounding differently from shape to shape (little overlap, many iterations): the
+        # yardstick is the oracle's own float32-vs-float64 distance on the same problem
+        w64 = hann(n_fft, np.float64)
+        ref64 = np.asarray(oracle.rtisi_la(mag.astype(np.float64), look_ahead=la, asymmetric_window=True, max_iter=iters,
+                                           alpha=alpha, hop_length=hop, window=w64)).reshape(yn.shape)
+        scale = np.abs(ref64[fin]).max()
+        noise = np.abs(ref[fin] - ref64[fin]).max() / scale
+        err = np.abs(yn[fin] - ref64[fin]).max() / scale
+        assert err <= max(tol, 2 * noise), (seed, n_fft, hop, la, iters, alpha, err, noise)
+    else:
+        assert finite_close(yn, ref, tol), (seed, n_fft, hop, la, iters, alpha, dtype)
+    good = fin.all(axis=0) if fin.ndim == 2 else fin
+    # streaming: same samples (bit-identical when both run the generic kernel, to rounding when the whole-signal
+    # call took the wave-level kernel)
+    s = si.RTISIStream(n_fft // 2 + 1, batch=batch, look_ahead=la, asymmetric_window=True, max_iter=iters, alpha=alpha,
+                       max_push=4, dtype=torch.from_numpy(mag).dtype, device=DEV, hop_length=hop, window=tw)
+    pieces, t = [], 0
+    while t < frames:
+        k = int(rng.integers(1, 5))
+        pieces.append(s.push(torch.from_numpy(mag[:, :, t:t + k]).to(DEV)))
+        t += k
+    pieces.append(s.flush())
+    z = torch.cat(pieces, 1)
+    assert z.shape == y.shape
+    zn = z.cpu().numpy()
+    assert np.array_equal(np.isfinite(zn), np.isfinite(yn))
+    assert finite_close(zn[..., good], yn[..., good], max(tol, 2 * noise) if dtype == np.float32 else tol)
