@@ -590,8 +590,8 @@ __global__ void k_log1p_to_user(const T* __restrict__ mm, T* __restrict__ v, int
 
 // MAG transform: loss partials and G = (2/numel) (|S| - T) S/|S| * (interior ? 1/2 : 1) in place over S
 template <typename T>
-__global__ void k_mag_loss_grad(cplx<T>* __restrict__ spec, const T* __restrict__ target, int Bn, int Tn, int F, int n_fft,
-                                int onesided, double inv_numel, double* __restrict__ part) {
+__global__ void k_mag_loss_grad(cplx<T>* __restrict__ spec, const T* __restrict__ target, int target_btf, int Bn, int Tn, int F,
+                                int n_fft, int onesided, double inv_numel, double* __restrict__ part) {
   __shared__ double red[16];
   double s2 = 0;
   const int64_t total = (int64_t)Bn * Tn * F;
@@ -601,7 +601,7 @@ __global__ void k_mag_loss_grad(cplx<T>* __restrict__ spec, const T* __restrict_
     const int64_t b = i / ((int64_t)F * Tn);
     const cplx<T> s = spec[i];
     const T mag = si_hypot(s.x, s.y);
-    const T d = mag - target[(b * F + f) * Tn + t];
+    const T d = mag - (target_btf ? target[i] : target[(b * F + f) * Tn + t]);
     s2 += (double)d * (double)d;
     T g = mag > T(0) ? (T)(2.0 * inv_numel) * d / mag : T(0);
     if (onesided && f != 0 && 2 * f != n_fft) g *= T(0.5);
@@ -827,8 +827,12 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
   double numel;
   if (pl.tf_kind == SPECINV_TF_MAG) {
     numel = (double)pl.nspec();
-    hipLaunchKernelGGL((k_mag_loss_grad<T>), dim3(nb), dim3(256), 0, pl.stream, pl.tf_spec.template as<C>(), target, pl.B(),
-                       pl.Tn(), pl.n_freq, pl.N(), pl.cfg.onesided, 1.0 / numel, pl.partials.template as<double>());
+    // the target comes in the caller's (B, F, T) layout; one tiled transpose makes the loss kernel's reads contiguous
+    SI_TRY(pl.tf_v.reserve((size_t)pl.nspec() * sizeof(T)));
+    SI_TRY((pl.template transpose<T>(target, pl.tf_v.template as<T>(), pl.n_freq, pl.Tn())));
+    hipLaunchKernelGGL((k_mag_loss_grad<T>), dim3(nb), dim3(256), 0, pl.stream, pl.tf_spec.template as<C>(),
+                       pl.tf_v.template as<T>(), 1, pl.B(), pl.Tn(), pl.n_freq, pl.N(), pl.cfg.onesided, 1.0 / numel,
+                       pl.partials.template as<double>());
     SI_HIP(hipGetLastError());
   } else {
     numel = (double)BT * pl.tf_mels;

@@ -52,3 +52,7 @@ if "C5" in which:
     for kw, tag in ((dict(), "defaults (max_iter=20, history=100)"), (dict(max_iter=50, history_size=10), "main.py:43 variant")):
         dt = timed(lambda: si.L_BFGS(target, tr, init_x0=x0.clone(), outer_max_iter=2, tol=0, eva_iter=10, verbose=False, **kw), reps=1)
         print(f"C5 L_BFGS 2 outer steps, {tag}: {dt:.3f} s")
+    trm = si.MagSTFT(n_fft, hop_length=hop, window=hann(n_fft))           # the objective of the reference's demo (main.py:22-43)
+    fwd, fg = trm.bind(x0, trm(xs))
+    dt = timed(lambda: fg(x0), reps=5)
+    print(f"C5' magnitude fwd+loss+grad B={B} T={T}: {dt*1e3:.2f} ms per evaluation  {B*T/dt/1e6:.2f} M evals*frames/s")
