@@ -198,7 +198,7 @@ int lb_pair(P& pl, const T* g, const T* gp, const T* d, double t, T* y, T* sv, i
                      pl.sums.template as<double>());
   SI_HIP(hipGetLastError());
   SI_HIP(hipMemcpyAsync(out2, pl.sums.p, 2 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
-  SI_HIP(hipStreamSynchronize(pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
   return SPECINV_OK;
 }
 
@@ -213,7 +213,7 @@ int lb_stats(P& pl, const T* g, const T* d, int64_t n, double* out4) {
                      pl.sums.template as<double>());
   SI_HIP(hipGetLastError());
   SI_HIP(hipMemcpyAsync(out4, pl.sums.p, 4 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
-  SI_HIP(hipStreamSynchronize(pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
   return SPECINV_OK;
 }
 
@@ -228,7 +228,7 @@ int lb_dot(P& pl, const T* a, const T* b, int64_t n, double* out) {
                      pl.sums.template as<double>());
   SI_HIP(hipGetLastError());
   SI_HIP(hipMemcpyAsync(out, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
-  SI_HIP(hipStreamSynchronize(pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
   return SPECINV_OK;
 }
 
@@ -259,7 +259,7 @@ int lb_absmax_abssum(P& pl, const T* x, int64_t n, double* out) {
                      pl.sums.template as<double>());
   SI_HIP(hipGetLastError());
   SI_HIP(hipMemcpyAsync(out, pl.sums.p, 2 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
-  SI_HIP(hipStreamSynchronize(pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
   return SPECINV_OK;
 }
 
@@ -875,7 +875,7 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
   SI_TRY(pl.launch_grad_fold(pl.frames.template as<T>(), grad, len));
   double s;
   SI_HIP(hipMemcpyAsync(&s, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
-  SI_HIP(hipStreamSynchronize(pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
   *loss = s / numel;
   return SPECINV_OK;
 }
