@@ -1,4 +1,4 @@
-// RTISI-LA on the wave-level FFT of kernels_fast.h (float32, onesided, hop = n_fft/4, n_fft in {512, 1024, 2048}).
+// RTISI-LA on the wave-level FFT of kernels_fast.h (float32, onesided, hop = n_fft/2, /4, /8, n_fft in {512, 1024, 2048}).
 //
 // The recursion (reference: torch_specinv/methods.py:363-404) is serial per batch item, so what matters is
 // the latency of ONE inner step.  One workgroup owns one item; wave q owns look-ahead frame q for the whole
@@ -29,10 +29,10 @@ struct RtisiFastArgs {
   float lr, fwd_scale, inv_scale;
 };
 
-template <int R>
+template <int R, int OV = 4>
 struct RtisiGeo {
   using G = Geo<R>;
-  static constexpr int K = 3;   // kept frames: (n_fft - 1) / hop with hop = n_fft / 4
+  static constexpr int K = OV - 1;   // kept frames: (n_fft - 1) / hop with hop = n_fft / OV
   // LDS (v2f units): ring | tw1 | per-wave transpose scratch | per-wave pre_spec exchange (pairs as 2 x v2f + mid)
   static constexpr size_t lds_bytes(int la) {
     const size_t waves = la + 1, nslots = K + la + 1;
@@ -41,10 +41,11 @@ struct RtisiGeo {
 };
 
 // MAXT: 256 (look_ahead <= 3: one wave per SIMD, the full 512-register file per lane) or 512
-template <int R, int MAXT>
+template <int R, int MAXT, int OV = 4>
 __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
   using G = Geo<R>;
-  constexpr int H = G::H, QU = G::QU, M = G::M, K = RtisiGeo<R>::K;
+  constexpr int H = G::H, QU = R / OV, M = G::M, K = RtisiGeo<R, OV>::K;
+  static_assert(R % OV == 0, "a hop-block must be whole registers");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int la = a.la, nslots = K + la + 1, nw = la + 1;
   v2f* ring = reinterpret_cast<v2f*>(smem);                 // [nslots][M]
@@ -142,12 +143,12 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
       // ---- this frame's samples = overlap-add of the ring frames that cover it (methods.py:365-370)
       v2f z[R];
 #pragma unroll
-      for (int qi = 0; qi < 4; ++qi) {
+      for (int qi = 0; qi < OV; ++qi) {
         const int blk = K + q + qi;                  // hop-block index counted from ring frame 0
 #pragma unroll
         for (int i2 = 0; i2 < QU; ++i2) z[qi * QU + i2] = v2f{0.0f, 0.0f};
 #pragma unroll
-        for (int d = 3; d >= 0; --d) {               // frame f = blk - d contributes its quarter d (f ascending)
+        for (int d = OV - 1; d >= 0; --d) {          // frame f = blk - d contributes its hop-block d (f ascending)
           const int f = blk - d;
           if (f >= 0 && f < nslots) {
             int slot = base + f;
@@ -275,13 +276,20 @@ int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_it
                       const float* d_wsyn, const float* d_a1, const float* d_a2, bool* used) {
   *used = false;
   const auto& cfg = pl.cfg;
-  if (cfg.dtype != SPECINV_F32 || !cfg.onesided || cfg.hop_length * 4 != cfg.n_fft) return SPECINV_OK;
+  if (cfg.dtype != SPECINV_F32 || !cfg.onesided) return SPECINV_OK;
   if (cfg.n_fft != 2048 && cfg.n_fft != 1024 && cfg.n_fft != 512) return SPECINV_OK;   // (4096: the per-wave tables
                                                                                          // would not fit the registers)
-  if (la > 7 || pl.force_generic) return SPECINV_OK;
   const int R = cfg.n_fft / 128;
-  const size_t lds = R == 16 ? fast::RtisiGeo<16>::lds_bytes(la) : R == 8 ? fast::RtisiGeo<8>::lds_bytes(la)
-                                                                          : fast::RtisiGeo<4>::lds_bytes(la);
+  int OV = 0;
+  for (int o : {2, 4, 8})
+    if (cfg.hop_length * o == cfg.n_fft && R % o == 0) OV = o;
+  if (OV == 0 || la > 7 || pl.force_generic) return SPECINV_OK;
+  size_t lds = 0;
+  SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
+    if constexpr (RR % 8 == 0) { if (OV == 8) lds = fast::RtisiGeo<RR, 8>::lds_bytes(la); }
+    if (OV == 4) lds = fast::RtisiGeo<RR, 4>::lds_bytes(la);
+    if (OV == 2) lds = fast::RtisiGeo<RR, 2>::lds_bytes(la);
+  });
   if (lds > 160 * 1024 - 1024) return SPECINV_OK;
   if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
     if (e[0] == '1') return SPECINV_OK;
@@ -315,10 +323,16 @@ int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_it
   a.fwd_scale = pl.fc.fwd_scale;
   a.inv_scale = pl.fc.inv_scale;
   const int threads = 64 * (la + 1);
-  const void* fn;
-  if (R == 16) fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<16, 256> : (const void*)fast::k_rtisi_fast<16, 512>;
-  else if (R == 8) fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<8, 256> : (const void*)fast::k_rtisi_fast<8, 512>;
-  else fn = threads <= 256 ? (const void*)fast::k_rtisi_fast<4, 256> : (const void*)fast::k_rtisi_fast<4, 512>;
+  const void* fn = nullptr;
+  const bool small = threads <= 256;
+  SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
+    if constexpr (RR % 8 == 0) {
+      if (OV == 8) fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 8> : (const void*)fast::k_rtisi_fast<RR, 512, 8>;
+    }
+    if (OV == 4) fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 4> : (const void*)fast::k_rtisi_fast<RR, 512, 4>;
+    if (OV == 2) fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 2> : (const void*)fast::k_rtisi_fast<RR, 512, 2>;
+  });
+  SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no wave-level RTISI kernel for this shape");
   SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   void* kargs[] = {&a};
   SI_HIP(hipLaunchKernel(fn, dim3(pl.B()), dim3(threads), kargs, lds, pl.stream));

@@ -74,20 +74,28 @@ def test_rtisi_float64_and_shapes():
     assert y3.shape[0] == 1 and y3.dim() == 2
 
 
-@pytest.mark.parametrize("n_fft,la", [(2048, 3), (1024, -1), (512, 3), (512, 5)])
+@pytest.mark.parametrize("n_fft,la,ov", [(2048, 3, 4), (1024, -1, 4), (512, 3, 4), (512, 5, 4), (1024, -1, 8), (1024, 2, 8),
+                                         (2048, 2, 2), (2048, -1, 8), (512, -1, 2), (1024, 7, 2)])
 @pytest.mark.parametrize("asym", [True, False])
-def test_rtisi_config3_shape_vs_oracle(asym, n_fft, la):
+def test_rtisi_config3_shape_vs_oracle(asym, n_fft, la, ov):
     """BASELINE config 3 frame size (n_fft 2048, hop 512, LA 3) - and the other sizes of the wave-level kernel - on a
     short clip the oracle runs in seconds."""
     rng = np.random.default_rng(33)
-    hop = n_fft // 4
-    mag = rng.random((2, n_fft // 2 + 1, 12), dtype=np.float32)
+    hop = n_fft // ov
+    mag = rng.random((2, n_fft // 2 + 1, 12 + 2 * ov), dtype=np.float32)
     w = hann(n_fft)
     ref = oracle.rtisi_la(mag, look_ahead=la, asymmetric_window=asym, max_iter=5, alpha=0.99, hop_length=hop, window=w)
     y = N(si.RTISI_LA(T(mag), look_ahead=la, asymmetric_window=asym, max_iter=5, alpha=0.99, verbose=False,
                       hop_length=hop, window=torch.from_numpy(w)))
     if asym:
-        assert rel_l2(y, ref) < 1e-4, rel_l2(y, ref)
+        # the recursion amplifies rounding from frame to frame: the yardstick is the oracle's own float32-vs-float64
+        # distance on the same problem (SURVEY 8c: 2-3e-3 for the reference itself on longer signals)
+        ref64 = oracle.rtisi_la(mag.astype(np.float64), look_ahead=la, asymmetric_window=asym, max_iter=5, alpha=0.99,
+                                hop_length=hop, window=hann(n_fft, np.float64))
+        noise = rel_l2(ref, ref64)
+        # (three float32 implementations - oracle, generic kernel, wave-level kernel - land between 1.7e-4 and 1.7e-3
+        # of the float64 result at hop = n_fft/8 after three inner iterations while agreeing to 5e-5 after one)
+        assert rel_l2(y, ref64) < max(1e-4, 5 * noise), (rel_l2(y, ref64), noise)
         return
     # asymmetric_window=False: the waveform decorrelates between any two float32 implementations
     # (SURVEY 8c); the reconstructions must still be equally consistent with the target
