@@ -1522,16 +1522,16 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
     {
       v4f* pin = a.P_out + fi * (H * 64);
 #pragma unroll
-      for (int j = 0; j < H; ++j) pp[j] = pin[j * 64u + ulane];
+      for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin[j * 64u + ulane]);
       if (MODE == MODE_ADMM) {
         v4f* uin = a.U_out + fi * (H * 64);
 #pragma unroll
-        for (int j = 0; j < H; ++j) uu[j] = uin[j * 64u + ulane];
+        for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin[j * 64u + ulane]);
       }
       if (MODE != MODE_INIT) {
         const v4f* min = a.m_pairs + fi * (H / 2 * 64);
 #pragma unroll
-        for (int j = 0; j < H / 2; ++j) mm[j] = min[j * 64u + ulane];
+        for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min[j * 64u + ulane]);
       }
       if (lane == 0) {
         pmid = a.Pmid_out[fi];
@@ -1571,8 +1571,8 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
         const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
         ak = update_bin<UMODE, EVAL>(xk, pk, uk, mk, a, true, sd, so);
         am = update_bin<UMODE, EVAL>(xm, pm, um, mq, a, true, sd, so);
-        a.P_out[fi * (H * 64) + j * 64u + ulane] = v4f{pk.x, pk.y, pm.x, pm.y};
-        if (MODE == MODE_ADMM) a.U_out[fi * (H * 64) + j * 64u + ulane] = v4f{uk.x, uk.y, um.x, um.y};
+        st_stream(&a.P_out[fi * (H * 64) + j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
+        if (MODE == MODE_ADMM) st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
       } else {
         ak = pk * a.inv_scale;
         am = pm * a.inv_scale;
