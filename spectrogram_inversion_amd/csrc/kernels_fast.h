@@ -1784,7 +1784,13 @@ struct FastState<float> {
     if (const char* e = getenv("SPECINV_DISABLE_FUSED")) {   // tests: put the shape on the frame kernel
       if (e[0] == '1') OV = 0;
     }
-    if (!cfg.center || OV == 0 || cfg.n_frames < OV + 2 || pad >= length) {
+    // small problems are latency-bound on the fused kernel (a wave walks >= 8 frames one after the other): below
+    // ~6 k frames the frame kernel, one frame per wave, finishes an iteration sooner (measured: 1 x 512 frames at
+    // n_fft 1024 10 vs 27 us, 16 x 256 26 vs 32 us; 16 x 512 at n_fft 2048 69 vs 55 us)
+    long long small_below = 6144;
+    if (const char* e = getenv("SPECINV_SMALL_FRAMES")) small_below = atoll(e);       // (tests pin the chunked kernel with 0)
+    const bool small = (long long)cfg.batch * cfg.n_frames < small_below;
+    if (!cfg.center || OV == 0 || cfg.n_frames < OV + 2 || pad >= length || small) {
       // any other hop / centring: frame kernel on the wave-level FFT + gather overlap-add (k_semi)
       if (const char* e = getenv("SPECINV_DISABLE_SEMI")) {
         if (e[0] == '1') return SPECINV_OK;

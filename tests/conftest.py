@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def chunked_kernel(monkeypatch):
+    """Small problems (< 6144 frames) normally go to the one-frame-per-wave kernel; tests of the fused, chunk-walking
+    kernel on small shapes switch that rule off (SPECINV_SMALL_FRAMES=0) and keep the plan cache from mixing the two."""
+    from spectrogram_inversion_amd.plan import clear_plan_cache
+    monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")
+    clear_plan_cache()
+    yield
+    clear_plan_cache()
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 

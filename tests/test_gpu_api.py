@@ -37,7 +37,7 @@ def test_reference_shape_contract(x_sizes, dtype, nfft):
         assert bool(torch.isfinite(y).all())
 
 
-def test_path_selection_at_the_edges():
+def test_path_selection_at_the_edges(chunked_kernel):
     w = torch.from_numpy(hann(2048))
     probe = torch.empty(1, 1025, 1)
     dev = torch.device(DEV)
@@ -76,7 +76,7 @@ def test_short_signals_off_the_fused_kernel(frames):
     assert rel_l2(y, ref) < 1e-4
 
 
-def test_warm_start_from_complex_spectrogram_on_fused_path():
+def test_warm_start_from_complex_spectrogram_on_fused_path(chunked_kernel):
     rng = np.random.default_rng(12)
     mag = rng.random((2, 513, 20), dtype=np.float32)
     w = hann(1024)
@@ -87,7 +87,7 @@ def test_warm_start_from_complex_spectrogram_on_fused_path():
     assert rel_l2(y, ref) < 1e-4
 
 
-def test_progress_and_early_stop_on_fused_path(capsys):
+def test_progress_and_early_stop_on_fused_path(capsys, chunked_kernel):
     rng = np.random.default_rng(13)
     mag = rng.random((1, 513, 24), dtype=np.float32)
     w = hann(1024)
@@ -137,3 +137,18 @@ def test_too_short_for_reflect_padding_is_rejected():
         si.griffin_lim(mag, max_iter=2, verbose=False, hop_length=128)
     y = si.griffin_lim(mag, max_iter=2, verbose=False, hop_length=128, pad_mode="constant")   # other pad modes are fine
     assert y.shape == (1, 128)
+
+
+def test_small_problems_take_the_frame_kernel():
+    """Below ~6 k frames an iteration finishes sooner with one frame per wave than with waves walking chunks."""
+    w = torch.from_numpy(hann(1024))
+    probe = torch.empty(1, 513, 1)
+    dev = torch.device(DEV)
+    assert Plan(args_helper(probe, hop_length=256, window=w), 1, 512, torch.float32, dev).path == "frame"     # BASELINE C1
+    assert Plan(args_helper(probe, hop_length=256, window=w), 16, 256, torch.float32, dev).path == "frame"
+    assert Plan(args_helper(probe, hop_length=256, window=w), 16, 512, torch.float32, dev).path == "fused"
+    rng = np.random.default_rng(3)
+    mag = rng.random((1, 513, 512), dtype=np.float32)
+    ref = oracle.griffin_lim(mag, max_iter=5, alpha=0.0, tol=0, hop_length=256, window=hann(1024))
+    y = N(si.griffin_lim(torch.from_numpy(mag).to(DEV), max_iter=5, alpha=0.0, tol=0, verbose=False, hop_length=256, window=w))
+    assert rel_l2(y, ref) < 1e-4

@@ -9,7 +9,7 @@ import torch
 import oracle
 from _util import hann, rel_l2, sc_linear
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("chunked_kernel")]
 
 from spectrogram_inversion_amd.plan import Plan, args_helper   # noqa: E402
 

@@ -108,7 +108,7 @@ def test_degenerate_shapes(shape, n_fft, hop):
             assert np.abs(y[fin] - ref[fin]).max() <= 1e-4 * max(1.0, np.abs(ref[fin]).max())
 
 
-def test_large_batch_of_short_items():
+def test_large_batch_of_short_items(chunked_kernel):
     """Many independent items (batch 512): sharding unit of the multi-GPU path; every item equals its solo run."""
     rng = np.random.default_rng(9)
     mag = rng.random((512, 513, 8), dtype=np.float32)
@@ -146,7 +146,7 @@ def test_very_long_signal(n_fft, hop, frames):
     assert abs(np.sqrt(s32[0] / s32[2]) - np.sqrt(s64[0] / s64[2])) < 1e-5
 
 
-def test_wide_batch():
+def test_wide_batch(chunked_kernel):
     """8 192 short items on the fused kernel (grid and batch-index arithmetic), spot-checked against solo runs."""
     rng = np.random.default_rng(10)
     mag = rng.random((8192, 257, 12), dtype=np.float32)
