@@ -179,7 +179,8 @@ def main():
 
     if rank == 0:
         units = args.steps * iters * batch * world * frames
-        fused = plan.fast_path
+        path = plan.path                       # "fused" | "frame" | "generic"
+        fused = path == "fused"
         out = {
             "metric": "Griffin-Lim iterations*frames/sec at n_fft=2048 hop=512" if args.workload == "C2"
                       else f"Griffin-Lim iterations*frames/sec ({args.workload})",
@@ -198,12 +199,14 @@ def main():
                                    f"n_frames={frames} maxiter={iters} alpha={alpha} hann center reflect tol=0 "
                                    f"eva_iter=10",
                        "global_batch": batch * world, "parallelism": f"batch-sharded x{world}, RCCL gather",
-                       "kernel_path": "fused wave-per-frame" if fused else "generic (frame kernel + overlap-add kernel)",
+                       "kernel_path": {"fused": "fused wave-per-frame", "frame": "wave-level frame kernel + overlap-add",
+                                       "generic": "generic (LDS FFT frame kernel + overlap-add)"}[path],
                        "step": "phase_init + ISTFT + iterations + gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_traffic(args.workload if fused else args.workload + "_generic"),
-                         "kernel": "specinv::fast::k_fused4<16, GLA>" if fused else "k_iter_pair+k_ola",
+                         "kernel": {"fused": f"specinv::fast::k_fused4<{n_fft // 128}, GLA>", "frame": "k_semi+k_ola_f4",
+                                    "generic": "k_iter_pair+k_ola"}[path],
                          "launch_ms": launch_ms, "algorithmic_bytes_per_launch": launch_bytes,
                          "bytes_per_unit": unit_bytes},
         }
