@@ -526,6 +526,17 @@ __device__ inline bool peak_omega(const T* __restrict__ col, int64_t fstride, in
   return true;
 }
 
+// peak test and omega from the three magnitudes around bin g (same operation order as peak_omega)
+template <typename T>
+__device__ inline bool peak_omega_vals(T a, T bb, T r, int g, int F, T two_pi, T n_fft, T hop, T& w) {
+#pragma clang fp contract(off)
+  if (g < 1 || g > F - 2) return false;
+  if (!(bb > r && bb > a)) return false;                // :597
+  const T p = T(0.5) * (a - r) / (a - T(2) * bb + r);   // :604
+  w = two_pi * (T(g) + p) / n_fft * hop;                // :605
+  return true;
+}
+
 template <typename T>
 __global__ void k_phase_init(const T* __restrict__ mag, cplx<T>* __restrict__ out, int B, int F, int Tn,
                              int n_fft, int hop) {
@@ -536,19 +547,29 @@ __global__ void k_phase_init(const T* __restrict__ mag, cplx<T>* __restrict__ ou
   const T* base = mag + (int64_t)bi * F * Tn;
   cplx<T>* orow = out + ((int64_t)bi * F + f) * Tn;
   const T two_pi = T(6.283185307179586476925286766559);
+  // the five rows f-2 .. f+2 of one time step; the next 64 time steps are fetched while the current ones are scanned
+  auto fetch = [&](int t, T (&v)[5]) {
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      const int g = f + d - 2;
+      v[d] = (t < Tn && g >= 0 && g < F) ? base[(int64_t)g * Tn + t] : T(0);
+    }
+  };
+  T cur[5], nxt[5];
+  fetch(lane, cur);
   double carry = 0;
   for (int t0 = 0; t0 < Tn; t0 += 64) {
     const int t = t0 + lane;
-    T om = 0, m0 = 0;
+    fetch(t + 64, nxt);
+    T om = 0;
+    const T m0 = cur[2];
     if (t < Tn) {
-      const T* col = base + t;
-      m0 = col[(int64_t)f * Tn];
       T w;
       // scatter order :607-609: own bin, else the k+1 write of a peak below, else the k-1
       // write of a peak above (later statements overwrite earlier ones)
-      if (peak_omega<T>(col, Tn, f, F, two_pi, T(n_fft), T(hop), w)) om = w;
-      else if (peak_omega<T>(col, Tn, f - 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
-      else if (peak_omega<T>(col, Tn, f + 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
+      if (peak_omega_vals<T>(cur[1], cur[2], cur[3], f, F, two_pi, T(n_fft), T(hop), w)) om = w;
+      else if (peak_omega_vals<T>(cur[0], cur[1], cur[2], f - 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
+      else if (peak_omega_vals<T>(cur[2], cur[3], cur[4], f + 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
     }
     double v = (double)om;
 #pragma unroll
@@ -564,6 +585,8 @@ __global__ void k_phase_init(const T* __restrict__ mag, cplx<T>* __restrict__ ou
       sincos((double)phi, &s, &cs);                        // :612
       orow[t] = mk<T>(m0 * (T)cs, m0 * (T)s);              // :614
     }
+#pragma unroll
+    for (int d = 0; d < 5; ++d) cur[d] = nxt[d];
   }
 }
 
