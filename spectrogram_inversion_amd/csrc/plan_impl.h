@@ -227,6 +227,15 @@ struct PlanT final : PlanBase {
     return SPECINV_OK;
   }
 
+  // threads per frame workgroup of the generic kernels: one per butterfly of the widest stage (n_fft / smallest radix),
+  // whole waves, at most 256
+  int frame_threads() const {
+    int rmin = 8;
+    for (int i = 0; i < fc.n_stages; ++i) rmin = std::min(rmin, fc.radix[i]);
+    const int want = (N() / std::max(2, rmin) + 63) / 64 * 64;
+    return std::min(256, std::max(64, want));
+  }
+
   int frames_needed() { return frames.reserve((size_t)B() * Tn() * N() * sizeof(T)); }
 
   // internal-layout spectrum -> x
@@ -253,7 +262,7 @@ struct PlanT final : PlanBase {
     FrameCfg<T> c = frame_cfg(len);
     c.pad_mode = pm;
     c.fwd_scale = sc;
-    hipLaunchKernelGGL((k_stft<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, c, xin, spec_btf);
+    hipLaunchKernelGGL((k_stft<T>), dim3(Tn(), B()), dim3(frame_threads()), lds_bytes, stream, c, xin, spec_btf);
     SI_HIP(hipGetLastError());
     return SPECINV_OK;
   }
@@ -267,7 +276,7 @@ struct PlanT final : PlanBase {
     }
     FrameCfg<T> c = frame_cfg(len);
     c.inv_scale = scale;
-    hipLaunchKernelGGL((k_grad_frames<T>), dim3(Tn(), B()), dim3(256), lds_bytes, stream, c, spec_btf, fr);
+    hipLaunchKernelGGL((k_grad_frames<T>), dim3(Tn(), B()), dim3(frame_threads()), lds_bytes, stream, c, spec_btf, fr);
     SI_HIP(hipGetLastError());
     return SPECINV_OK;
   }
@@ -403,7 +412,7 @@ struct PlanT final : PlanBase {
       const T inv1p = T(1) / (T)(1.0 + (double)coef);
       for (int i = 0; i < n_iter; ++i) {
         const bool ev = eval_last && i == n_iter - 1;
-        const dim3 grid((Tn() + 1) / 2, B()), blk(256);   // two frames per complex FFT
+        const dim3 grid((Tn() + 1) / 2, B()), blk(frame_threads());   // two frames per complex FFT
         if (method == Method::Gla) {
           if (ev)
             hipLaunchKernelGGL((k_iter_pair<T, 0, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
