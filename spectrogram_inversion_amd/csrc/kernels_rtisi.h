@@ -576,6 +576,12 @@ struct RtisiStream {
   T lr = 0;
   int64_t steps_done = 0, n_pushed = 0, emitted = 0;   // emitted: next padded sample to hand out
   T *mags = nullptr, *commits = nullptr;
+  // wave-level kernel (float32 shapes it covers): targets in pair layout, its frame ring / registers saved between launches
+  bool fast = false;
+  RtisiFastPick pick;
+  float* fstate = nullptr;
+  fast::v4f* mpairs = nullptr;
+  float* mmid = nullptr;
 };
 
 template <typename P, typename T>
@@ -588,10 +594,30 @@ int rtisi_stream_begin(P& pl, RtisiStream<T>& st, int look_ahead, int asym, int 
   st.mag_ring = la + 1 + cap;
   st.out_ring = keep + 1 + cap;
   const size_t mag_bytes = ((size_t)Bn * st.mag_ring * F * sizeof(T) + 63) & ~(size_t)63;
-  const size_t out_bytes = (size_t)Bn * st.out_ring * N * sizeof(T);
-  SI_TRY(rtisi_prepare(pl, look_ahead, pl.rs_state, mag_bytes + out_bytes, st.lay));
+  const size_t out_bytes = ((size_t)Bn * st.out_ring * N * sizeof(T) + 63) & ~(size_t)63;
+  st.fast = false;
+  size_t fast_bytes = 0, state_bytes = 0, pairs_bytes = 0, mid_bytes = 0;
+  if constexpr (std::is_same<T, float>::value) {
+    st.pick = rtisi_fast_pick(pl, la);
+    if (st.pick.fn != nullptr) {
+      st.fast = true;
+      const int Rr = st.pick.R, nslots = keep + la + 1, Hh = Rr / 2;
+      const size_t per_item = (size_t)nslots * (64 * Rr) + (size_t)(la + 1) * (2 * (Hh * 2 * 64) + 2 * 64);   // rtisi_state_v2f
+      state_bytes = ((size_t)Bn * per_item * sizeof(fast::v2f) + 63) & ~(size_t)63;
+      pairs_bytes = ((size_t)Bn * st.mag_ring * (Hh / 2) * 64 * sizeof(fast::v4f) + 63) & ~(size_t)63;
+      mid_bytes = ((size_t)Bn * st.mag_ring * sizeof(float) + 63) & ~(size_t)63;
+      fast_bytes = state_bytes + pairs_bytes + mid_bytes;
+    }
+  }
+  SI_TRY(rtisi_prepare(pl, look_ahead, pl.rs_state, mag_bytes + out_bytes + fast_bytes, st.lay));
   st.mags = reinterpret_cast<T*>(st.lay.extra);
   st.commits = reinterpret_cast<T*>(st.lay.extra + mag_bytes);
+  if (st.fast) {
+    char* fb = st.lay.extra + mag_bytes + out_bytes;
+    st.fstate = reinterpret_cast<float*>(fb);
+    st.mpairs = reinterpret_cast<fast::v4f*>(fb + state_bytes);
+    st.mmid = reinterpret_cast<float*>(fb + state_bytes + pairs_bytes);
+  }
   st.asym = asym ? 1 : 0;
   st.max_iter = max_iter;
   st.lr = (T)(alpha / (1.0 + alpha));
@@ -604,6 +630,37 @@ int rtisi_stream_begin(P& pl, RtisiStream<T>& st, int look_ahead, int asym, int 
 
 template <typename P, typename T>
 int rtisi_stream_steps(P& pl, RtisiStream<T>& st, int n_steps) {
+  if constexpr (std::is_same<T, float>::value) {
+    if (st.fast) {
+      fast::RtisiFastArgs a{};
+      a.m_pairs = st.mpairs;
+      a.m_mid = st.mmid;
+      a.frames_out = st.commits;
+      a.window = pl.window.template as<float>();
+      a.wsyn = st.lay.wsyn;
+      a.asym1 = st.lay.asym1;
+      a.asym2 = st.lay.asym2;
+      a.T = 0;
+      a.la = st.lay.la;
+      a.max_iter = st.max_iter;
+      a.asym = st.asym;
+      a.lr = st.lr;
+      a.fwd_scale = pl.fc.fwd_scale;
+      a.inv_scale = pl.fc.inv_scale;
+      a.i_begin = (int)st.steps_done;
+      a.i_end = (int)st.steps_done + n_steps;
+      a.resume = st.steps_done > 0;
+      a.n_valid = (int)st.n_pushed;
+      a.mag_ring = st.mag_ring;
+      a.out_ring = st.out_ring;
+      a.state = st.fstate;
+      SI_HIP(hipFuncSetAttribute(st.pick.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)st.pick.lds));
+      void* kargs[] = {&a};
+      SI_HIP(hipLaunchKernel(st.pick.fn, dim3(pl.B()), dim3(st.pick.threads), kargs, st.pick.lds, pl.stream));
+      st.steps_done += n_steps;
+      return SPECINV_OK;
+    }
+  }
   RtisiArgs<T> r{};
   r.c = pl.fc;
   r.mag = st.mags;
@@ -664,9 +721,29 @@ int rtisi_stream_push(P& pl, RtisiStream<T>& st, const T* mag_user, int k, T* x_
   SI_CHECK(st.steps_done + k < (int64_t)1 << 30, SPECINV_EUNSUPPORTED, "stream too long");
   *n_out = 0;
   const int F = pl.n_freq;
-  hipLaunchKernelGGL((k_rtisi_store_mag<T>), dim3((k + 31) / 32, (F + 31) / 32, pl.B()), dim3(32, 8), 0, pl.stream, mag_user,
-                     F, k, st.mags, st.mag_ring, st.n_pushed);
-  SI_HIP(hipGetLastError());
+  bool stored = false;
+  if constexpr (std::is_same<T, float>::value) {
+    if (st.fast) {
+      // (B, F, k) -> (B, k, F) -> pair layout at the ring rows of these frames
+      SI_TRY(pl.mag.reserve((size_t)pl.B() * pl.Tn() * F * sizeof(float)));
+      {
+        dim3 grid((k + 31) / 32, (F + 31) / 32, pl.B());
+        hipLaunchKernelGGL((k_transpose<float>), grid, dim3(32, 8), 0, pl.stream, mag_user, pl.mag.template as<float>(), F, k);
+        SI_HIP(hipGetLastError());
+      }
+      const long long total = (long long)pl.B() * k * (st.pick.R / 4) * 64;
+      SPECINV_R_SWITCH(st.pick.R, hipLaunchKernelGGL((fast::k_mag_to_pairs_ring<RR>), dim3((unsigned)ceil_div(total, 256)),
+                                                     dim3(256), 0, pl.stream, pl.mag.template as<float>(), st.mpairs, st.mmid,
+                                                     k, st.mag_ring, (long long)st.n_pushed, total));
+      SI_HIP(hipGetLastError());
+      stored = true;
+    }
+  }
+  if (!stored) {
+    hipLaunchKernelGGL((k_rtisi_store_mag<T>), dim3((k + 31) / 32, (F + 31) / 32, pl.B()), dim3(32, 8), 0, pl.stream, mag_user,
+                       F, k, st.mags, st.mag_ring, st.n_pushed);
+    SI_HIP(hipGetLastError());
+  }
   st.n_pushed += k;
   SI_TRY(rtisi_stream_steps(pl, st, k));
   return rtisi_stream_emit(pl, st, rtisi_stream_final(pl, st), x_out, out_stride, n_out);

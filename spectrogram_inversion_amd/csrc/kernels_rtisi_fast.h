@@ -27,7 +27,18 @@ struct RtisiFastArgs {
   const float* asym2;   // N
   int T, la, max_iter, asym;
   float lr, fwd_scale, inv_scale;
+  // step range [i_begin, i_end) of this launch; a stream resumes from `state` (what the previous launch left: the
+  // frame ring and each wave's pre_spec registers) and addresses targets / committed frames as rings of frames
+  int i_begin, i_end, resume, n_valid;
+  int mag_ring;          // 0: m_pairs is [B*T]; else [B*mag_ring], frame t at t % mag_ring
+  int out_ring;          // 0: frames_out is (B, T, N); else (B, out_ring, N)
+  float* state;          // NULL, or per item: ring | per wave (pre pairs, pre mid, shifted pairs, shifted mid)
 };
+
+template <int R>
+constexpr size_t rtisi_state_v2f(int nslots, int waves) {
+  return (size_t)nslots * Geo<R>::M + (size_t)waves * (2 * (Geo<R>::H * 2 * 64) + 2 * 64);
+}
 
 template <int R, int OV = 4>
 struct RtisiGeo {
@@ -62,7 +73,17 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     const int k1 = i / 64 + 1, l = i & 63;
     lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
   }
-  for (int i = threadIdx.x; i < (nslots - 1) * M; i += blockDim.x) ring[i] = v2f{0.0f, 0.0f};
+  v2f* st_ring = nullptr;
+  v2f* st_wave = nullptr;
+  if (a.state) {
+    st_ring = reinterpret_cast<v2f*>(a.state) + (size_t)bi * rtisi_state_v2f<R>(nslots, nw);
+    st_wave = st_ring + (size_t)nslots * M + (size_t)q * (2 * (H * 2 * 64) + 2 * 64);
+  }
+  if (a.resume) {
+    for (int i = threadIdx.x; i < nslots * M; i += blockDim.x) ring[i] = st_ring[i];
+  } else {
+    for (int i = threadIdx.x; i < (nslots - 1) * M; i += blockDim.x) ring[i] = v2f{0.0f, 0.0f};
+  }
 
   // per-wave register tables (sample 128u + 2 lane, +1  <->  register u)
   v2f wsyn[R], win0[R], win1[R];
@@ -81,9 +102,9 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
   }
 
   // ---- first frame (methods.py:353-358): irfft of the zero-phase first target frame into the newest slot
-  const long long f0 = (long long)bi * a.T;
+  const long long f0 = (long long)bi * (a.mag_ring ? a.mag_ring : a.T);
   __syncthreads();
-  if (q == 0) {
+  if (q == 0 && !a.resume) {
     v2f z[R], back[H];
     const v4f* mp = a.m_pairs + f0 * (H / 2 * 64);
 #pragma unroll
@@ -122,21 +143,33 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     pre[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     shifted[j] = pre[j];
   }
-  int base = 0;          // ring slot of frame 0 (oldest kept frame)
+  if (a.resume) {
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f p0 = st_wave[(2 * j) * 64 + lane], p1 = st_wave[(2 * j + 1) * 64 + lane];
+      pre[j] = v4f{p0.x, p0.y, p1.x, p1.y};
+      const v2f s0 = st_wave[H * 2 * 64 + 64 + (2 * j) * 64 + lane], s1 = st_wave[H * 2 * 64 + 64 + (2 * j + 1) * 64 + lane];
+      shifted[j] = v4f{s0.x, s0.y, s1.x, s1.y};
+    }
+    premid = st_wave[H * 2 * 64 + lane];
+    shiftedmid = st_wave[2 * (H * 2 * 64) + 64 + lane];
+  }
+  int base = a.i_begin % nslots;   // ring slot of the oldest kept frame
   const float half_scale = 0.5f * a.fwd_scale;
 
-  for (int i = 0; i < a.T + la; ++i) {
+  for (int i = a.i_begin; i < a.i_end; ++i) {
     // target of this wave's frame for the whole outer step (zero outside the spectrogram: methods.py:339)
     const int tt = i + q - la;
     v4f mm[H / 2];
     float mmid = 0.0f;
 #pragma unroll
     for (int j = 0; j < H / 2; ++j) mm[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    if (tt >= 0 && tt < a.T) {
-      const v4f* mp = a.m_pairs + (f0 + tt) * (H / 2 * 64);
+    if (tt >= 0 && tt < a.n_valid) {
+      const long long mrow = f0 + (a.mag_ring ? tt % a.mag_ring : tt);
+      const v4f* mp = a.m_pairs + mrow * (H / 2 * 64);
 #pragma unroll
       for (int j = 0; j < H / 2; ++j) mm[j] = mp[j * 64u + ulane];
-      if (lane == 0) mmid = a.m_mid[f0 + tt];
+      if (lane == 0) mmid = a.m_mid[mrow];
     }
 
     for (int it = 0; it < a.max_iter; ++it) {
@@ -235,7 +268,8 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     if (q == 0 && i >= la) {
       const v2f* src = ring + (size_t)s0 * M;
       const v2f* w = reinterpret_cast<const v2f*>(a.window);
-      v2f* dst = reinterpret_cast<v2f*>(a.frames_out + ((long long)bi * a.T + (i - la)) * (2 * M));
+      const long long orow = a.out_ring ? (long long)bi * a.out_ring + (i - la) % a.out_ring : (long long)bi * a.T + (i - la);
+      v2f* dst = reinterpret_cast<v2f*>(a.frames_out + orow * (2 * M));
 #pragma unroll
       for (int u = 0; u < R; ++u) dst[64u * u + ulane] = src[64 * u + lane] * w[64u * u + ulane];
     }
@@ -266,34 +300,99 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     base = base + 1 == nslots ? 0 : base + 1;
     __syncthreads();
   }
+  if (a.state) {   // what a later launch needs to carry on from step i_end
+    for (int i = threadIdx.x; i < nslots * M; i += blockDim.x) st_ring[i] = ring[i];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      st_wave[(2 * j) * 64 + lane] = v2f{pre[j].x, pre[j].y};
+      st_wave[(2 * j + 1) * 64 + lane] = v2f{pre[j].z, pre[j].w};
+      st_wave[H * 2 * 64 + 64 + (2 * j) * 64 + lane] = v2f{shifted[j].x, shifted[j].y};
+      st_wave[H * 2 * 64 + 64 + (2 * j + 1) * 64 + lane] = v2f{shifted[j].z, shifted[j].w};
+    }
+    st_wave[H * 2 * 64 + lane] = premid;
+    st_wave[2 * (H * 2 * 64) + 64 + lane] = shiftedmid;
+  }
+}
+
+// (B, k, F) frame-major magnitudes of a push -> pair layout at ring rows (t0 + j) % mag_ring of every item
+template <int R>
+__global__ void k_mag_to_pairs_ring(const float* __restrict__ mag, v4f* __restrict__ pairs, float* __restrict__ mid, int k,
+                                    int mag_ring, long long t0, long long total) {
+  using G = Geo<R>;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, j, c, lane)
+  if (i >= total) return;
+  const int lane = i & 63;
+  const int c = (i >> 6) % (G::H / 2);
+  const long long fj = i / (64 * (G::H / 2));
+  const long long b = fj / k, j = fj - b * k;
+  const float* sp = mag + fj * (G::M + 1);
+  const long long row = b * mag_ring + (t0 + j) % mag_ring;
+  const int k0 = lane + 64 * (2 * c), k1 = lane + 64 * (2 * c + 1);
+  pairs[(row * (G::H / 2) + c) * 64 + lane] = v4f{sp[k0], sp[G::M - k0], sp[k1], sp[G::M - k1]};
+  if (lane == 0 && c == 0) mid[row] = sp[G::M / 2];
 }
 
 }  // namespace fast
 
-// returns SPECINV_EUNSUPPORTED (without setting an error) when the configuration is not covered
+// which instantiation (if any) covers the plan at this look-ahead: kernel, its LDS bytes and geometry
+struct RtisiFastPick {
+  const void* fn = nullptr;
+  size_t lds = 0;
+  int R = 0, OV = 0, threads = 0;
+};
+
 template <typename P>
-int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_iter, double alpha, float* x_out,
-                      const float* d_wsyn, const float* d_a1, const float* d_a2, bool* used) {
-  *used = false;
+RtisiFastPick rtisi_fast_pick(P& pl, int la) {
+  RtisiFastPick k;
   const auto& cfg = pl.cfg;
-  if (cfg.dtype != SPECINV_F32 || !cfg.onesided) return SPECINV_OK;
-  if (cfg.n_fft != 2048 && cfg.n_fft != 1024 && cfg.n_fft != 512) return SPECINV_OK;   // (4096: the per-wave tables
-                                                                                         // would not fit the registers)
+  if (cfg.dtype != SPECINV_F32 || !cfg.onesided) return k;
+  if (cfg.n_fft != 2048 && cfg.n_fft != 1024 && cfg.n_fft != 512) return k;   // (4096: the per-wave tables would not
+                                                                              // fit the registers)
   const int R = cfg.n_fft / 128;
   int OV = 0;
   for (int o : {2, 4, 8})
     if (cfg.hop_length * o == cfg.n_fft && R % o == 0) OV = o;
-  if (OV == 0 || la > 7 || pl.force_generic) return SPECINV_OK;
-  size_t lds = 0;
-  SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
-    if constexpr (RR % 8 == 0) { if (OV == 8) lds = fast::RtisiGeo<RR, 8>::lds_bytes(la); }
-    if (OV == 4) lds = fast::RtisiGeo<RR, 4>::lds_bytes(la);
-    if (OV == 2) lds = fast::RtisiGeo<RR, 2>::lds_bytes(la);
-  });
-  if (lds > 160 * 1024 - 1024) return SPECINV_OK;
+  if (OV == 0 || la > 7 || pl.force_generic) return k;
   if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
-    if (e[0] == '1') return SPECINV_OK;
+    if (e[0] == '1') return k;
   }
+  size_t lds = 0;
+  const void* fn = nullptr;
+  const bool small = 64 * (la + 1) <= 256;
+  SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
+    if constexpr (RR % 8 == 0) {
+      if (OV == 8) {
+        lds = fast::RtisiGeo<RR, 8>::lds_bytes(la);
+        fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 8> : (const void*)fast::k_rtisi_fast<RR, 512, 8>;
+      }
+    }
+    if (OV == 4) {
+      lds = fast::RtisiGeo<RR, 4>::lds_bytes(la);
+      fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 4> : (const void*)fast::k_rtisi_fast<RR, 512, 4>;
+    }
+    if (OV == 2) {
+      lds = fast::RtisiGeo<RR, 2>::lds_bytes(la);
+      fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 2> : (const void*)fast::k_rtisi_fast<RR, 512, 2>;
+    }
+  });
+  if (fn == nullptr || lds > 160 * 1024 - 1024) return k;
+  k.fn = fn;
+  k.lds = lds;
+  k.R = R;
+  k.OV = OV;
+  k.threads = 64 * (la + 1);
+  return k;
+}
+
+// `*used` stays false (and nothing is launched) when the configuration is not covered
+template <typename P>
+int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_iter, double alpha, float* x_out,
+                      const float* d_wsyn, const float* d_a1, const float* d_a2, bool* used) {
+  *used = false;
+  const RtisiFastPick pick = rtisi_fast_pick(pl, la);
+  if (pick.fn == nullptr) return SPECINV_OK;
+  const int R = pick.R;
+  const size_t lds = pick.lds;
   using v4f = fast::v4f;
   const long long nf = (long long)pl.B() * pl.Tn();
   const int H = R / 2;
@@ -322,17 +421,15 @@ int rtisi_fast_launch(P& pl, const float* mag_user, int la, int asym, int max_it
   a.lr = (float)(alpha / (1.0 + alpha));
   a.fwd_scale = pl.fc.fwd_scale;
   a.inv_scale = pl.fc.inv_scale;
-  const int threads = 64 * (la + 1);
-  const void* fn = nullptr;
-  const bool small = threads <= 256;
-  SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
-    if constexpr (RR % 8 == 0) {
-      if (OV == 8) fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 8> : (const void*)fast::k_rtisi_fast<RR, 512, 8>;
-    }
-    if (OV == 4) fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 4> : (const void*)fast::k_rtisi_fast<RR, 512, 4>;
-    if (OV == 2) fn = small ? (const void*)fast::k_rtisi_fast<RR, 256, 2> : (const void*)fast::k_rtisi_fast<RR, 512, 2>;
-  });
-  SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no wave-level RTISI kernel for this shape");
+  a.i_begin = 0;
+  a.i_end = pl.Tn() + la;
+  a.resume = 0;
+  a.n_valid = pl.Tn();
+  a.mag_ring = 0;
+  a.out_ring = 0;
+  a.state = nullptr;
+  const int threads = pick.threads;
+  const void* fn = pick.fn;
   SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   void* kargs[] = {&a};
   SI_HIP(hipLaunchKernel(fn, dim3(pl.B()), dim3(threads), kargs, lds, pl.stream));
