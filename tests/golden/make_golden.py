@@ -529,9 +529,37 @@ def g12_autograd_rtisi():
     save("g12_autograd_rtisi", **out)
 
 
+def g13_wave_level_shapes():
+    """The reference itself at the shapes the wave-level kernels specialise in (fused hop = n_fft/2, /4, /8 at n_fft
+    512 ... 4096, and the frame kernel at another hop): Griffin-Lim and ADMM waveforms after a few iterations, RTISI-LA
+    with the asymmetric window."""
+    out, meta = {}, []
+    rng = np.random.default_rng(113)
+    for n_fft, hop, frames in [(1024, 128, 40), (2048, 1024, 14), (512, 128, 48), (4096, 1024, 12), (2048, 256, 24),
+                               (512, 256, 30), (1024, 160, 30), (4096, 2048, 10)]:
+        tag = f"{n_fft}_{hop}"
+        mag = (rng.random((1, n_fft // 2 + 1, frames)) + 0.02).astype(np.float32)
+        w = hann(n_fft, np.float32)
+        kw = dict(hop_length=hop, window=t(w))
+        init = M.phase_init(t(mag), **kw)
+        out[f"mag_{tag}"] = mag
+        out[f"init_{tag}"] = init.numpy()
+        out[f"gla_{tag}"] = M.griffin_lim(init, max_iter=5, alpha=0.3, tol=0, verbose=False, **kw).numpy()
+        out[f"admm_{tag}"] = M.ADMM(init, max_iter=3, rho=1.0, tol=0, verbose=False, **kw).numpy()
+        if n_fft <= 2048:
+            out[f"rtisi_{tag}"] = M.RTISI_LA(t(mag[:, :, :12]), look_ahead=-1 if hop * 8 > n_fft else 3, asymmetric_window=True,
+                                             max_iter=2, alpha=0.99, verbose=False, **kw).numpy()
+            out[f"rtisi64_{tag}"] = M.RTISI_LA(t(mag[:, :, :12].astype(np.float64)), look_ahead=-1 if hop * 8 > n_fft else 3,
+                                               asymmetric_window=True, max_iter=2, alpha=0.99, verbose=False,
+                                               hop_length=hop, window=t(hann(n_fft, np.float64))).numpy()
+        meta.append(tag)
+    out["meta"] = np.array(meta)
+    save("g13_wave_level_shapes", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     table = dict(g0=g0_stft, g1=g1_phase_init, g2=g2_gla, g3=g3_sweep, g4=g4_admm, g5=g5_rtisi,
-                 g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd, g11=g11_autograd_admm, g12=g12_autograd_rtisi)
+                 g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd, g11=g11_autograd_admm, g12=g12_autograd_rtisi, g13=g13_wave_level_shapes)
     for w in which:
         table[w]()

@@ -336,3 +336,35 @@ def test_fused_demo_shape_full_size_vs_float64():
     s32, s64 = p32.iterate(1, eval_last=True), p64.iterate(1, eval_last=True)
     assert rel_l2(N(p32.wave()), N(p64.wave())) < 1e-4
     assert abs(np.sqrt(s32[0] / s32[2]) - np.sqrt(s64[0] / s64[2])) < 1e-5
+
+
+# ---- the reference itself at the wave-level shapes (g13) -------------------------------------------------------------
+def _g13():
+    from _util import load_golden
+    return load_golden("g13_wave_level_shapes")
+
+
+@pytest.mark.parametrize("tag", [str(m) for m in _g13()["meta"]])
+def test_reference_fixture_at_wave_level_shapes(tag):
+    """Waveforms of the unmodified reference (torch CPU) after 5 Griffin-Lim / 3 ADMM iterations from the same start, and
+    RTISI-LA (asymmetric window, float32 and float64 reference runs as the yardstick)."""
+    g = _g13()
+    n_fft, hop = (int(v) for v in tag.split("_"))
+    w = torch.from_numpy(hann(n_fft))
+    init = T(g[f"init_{tag}"])
+    plan = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], torch.float32, dev())
+    assert plan.path == ("frame" if hop == 160 else "fused")
+    plan.gla_init(init, None, 0.3)
+    plan.iterate(5)
+    # gate = the north-star bar; typical 2e-6 ... 2e-5, 7e-5 at hop = n_fft/8 where the first samples sit on a tiny envelope
+    assert rel_l2(N(plan.wave()), g[f"gla_{tag}"]) < 1e-4, rel_l2(N(plan.wave()), g[f"gla_{tag}"])
+    plan.admm_init(init, None, 1.0)
+    plan.iterate(3)
+    assert rel_l2(N(plan.wave()), g[f"admm_{tag}"]) < 1e-4
+    if f"rtisi_{tag}" in g.files:
+        import spectrogram_inversion_amd as si
+        la = -1 if hop * 8 > n_fft else 3
+        y = N(si.RTISI_LA(T(g[f"mag_{tag}"][:, :, :12]), look_ahead=la, asymmetric_window=True, max_iter=2, alpha=0.99,
+                          verbose=False, hop_length=hop, window=w))
+        ref, ref64 = g[f"rtisi_{tag}"], g[f"rtisi64_{tag}"]
+        assert rel_l2(y, ref64) < max(1e-4, 3 * rel_l2(ref, ref64)), (rel_l2(y, ref64), rel_l2(ref, ref64))

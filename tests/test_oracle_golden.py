@@ -296,3 +296,22 @@ def test_float64():
     assert rel_l2(oracle.admm(init, max_iter=5, rho=0.1, tol=0, **kw), g["admm5"]) < 1e-10
     y = oracle.rtisi_la(g["mag"], look_ahead=2, asymmetric_window=True, max_iter=2, **kw)
     assert y.dtype == np.float64 and rel_l2(y, g["rtisi"]) < 1e-9
+
+
+# ---- G13: the shapes the wave-level kernels specialise in ----------------------------------- #
+@pytest.mark.parametrize("tag", [str(m) for m in load_golden("g13_wave_level_shapes")["meta"]])
+def test_wave_level_shapes(tag):
+    g = load_golden("g13_wave_level_shapes")
+    n_fft, hop = (int(v) for v in tag.split("_"))
+    w = hann(n_fft)
+    init = g[f"init_{tag}"]
+    assert rel_l2(oracle.phase_init(g[f"mag_{tag}"], hop_length=hop, window=w), init) < 1e-6
+    y = oracle.griffin_lim(init, max_iter=5, alpha=0.3, tol=0, hop_length=hop, window=w)
+    assert rel_l2(np.asarray(y).reshape(g[f"gla_{tag}"].shape), g[f"gla_{tag}"]) < 1e-4
+    z = oracle.admm(init, max_iter=3, rho=1.0, tol=0, hop_length=hop, window=w)
+    assert rel_l2(np.asarray(z).reshape(g[f"admm_{tag}"].shape), g[f"admm_{tag}"]) < 1e-4
+    if f"rtisi_{tag}" in g.files:
+        la = -1 if hop * 8 > n_fft else 3
+        r = oracle.rtisi_la(g[f"mag_{tag}"][:, :, :12].astype(np.float64), look_ahead=la, asymmetric_window=True, max_iter=2,
+                            alpha=0.99, hop_length=hop, window=hann(n_fft, np.float64))
+        assert rel_l2(np.asarray(r).reshape(g[f"rtisi64_{tag}"].shape), g[f"rtisi64_{tag}"]) < 1e-9
