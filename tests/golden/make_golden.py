@@ -536,7 +536,7 @@ def g13_wave_level_shapes():
     out, meta = {}, []
     rng = np.random.default_rng(113)
     for n_fft, hop, frames in [(1024, 128, 40), (2048, 1024, 14), (512, 128, 48), (4096, 1024, 12), (2048, 256, 24),
-                               (512, 256, 30), (1024, 160, 30), (4096, 2048, 10)]:
+                               (512, 256, 30), (1024, 160, 30), (4096, 2048, 10), (2048, 512, 40), (1024, 256, 40)]:
         tag = f"{n_fft}_{hop}"
         mag = (rng.random((1, n_fft // 2 + 1, frames)) + 0.02).astype(np.float32)
         w = hann(n_fft, np.float32)
