@@ -152,3 +152,41 @@ def test_small_problems_take_the_frame_kernel():
     ref = oracle.griffin_lim(mag, max_iter=5, alpha=0.0, tol=0, hop_length=256, window=hann(1024))
     y = N(si.griffin_lim(torch.from_numpy(mag).to(DEV), max_iter=5, alpha=0.0, tol=0, verbose=False, hop_length=256, window=w))
     assert rel_l2(y, ref) < 1e-4
+
+
+def test_c_abi_argument_errors():
+    """Null pointers / bad counts come back as SPECINV_EINVAL (-> AssertionError) with a message, never as a crash."""
+    import ctypes as C
+    from spectrogram_inversion_amd import _lib
+    lib = _lib.load()
+    plan = Plan(args_helper(torch.empty(1, 513, 1), hop_length=256, window=torch.from_numpy(hann(1024))), 2, 24,
+                torch.float32, torch.device(DEV))
+    h = plan._h
+    x = torch.zeros(2, plan.length, device=DEV)
+    n64 = C.c_int64(0)
+    out = (C.c_double * 4)()
+    calls = [
+        lambda: lib.specinv_stft(h, None, plan.length, x.data_ptr()),
+        lambda: lib.specinv_istft(h, None, x.data_ptr()),
+        lambda: lib.specinv_gla_init(h, None, None, 0.3),
+        lambda: lib.specinv_gla_init(h, None, x.data_ptr(), -1.0),
+        lambda: lib.specinv_gla_update(h, None, None, None, 0.3, None, None),
+        lambda: lib.specinv_istft_adjoint(h, None, None),
+        lambda: lib.specinv_rtisi_run(h, None, -1, 0, 25, 0.99, None),
+        lambda: lib.specinv_rtisi_run(h, x.data_ptr(), -1, 0, 0, 0.99, x.data_ptr()),
+        lambda: lib.specinv_rtisi_stream_begin(h, -1, 0, 0, 0.99),
+        lambda: lib.specinv_lbfgs_pair(h, None, None, None, 1.0, None, None, 10, out),
+        lambda: lib.specinv_lbfgs_stats(h, None, None, 10, out),
+        lambda: lib.specinv_vec_dot(h, None, None, 0, out),
+        lambda: lib.specinv_transform_setup(h, 7, None, 0),
+        lambda: lib.specinv_rtisi_record_elems(h, -1, 0, C.byref(n64)),
+    ]
+    for i, call in enumerate(calls):
+        rc = call()
+        assert rc == _lib.EINVAL, (i, rc)
+        assert len(lib.specinv_last_error()) > 0
+        with pytest.raises(AssertionError):
+            _lib.check(rc)
+    with pytest.raises(_lib.SpecinvError):
+        _lib.check(lib.specinv_rtisi_stream_push(h, x.data_ptr(), 1, x.data_ptr(), 1024, C.byref(n64)))   # no begin: ESTATE
+    assert lib.specinv_plan_fast_path(None) == _lib.EINVAL
