@@ -191,11 +191,12 @@ def test_fast_standalone_transforms(n_fft, hop, length):
         assert rel_l2(y * env, y_ref * env) < 3e-6
 
 
-def test_fast_logmel_gradient_vs_autograd_f32():
+@pytest.mark.parametrize("n_mels", [80, 20, 33, 128, 160])   # 1, 2, 3 and 4 tiles of 32 mel rows; 160: the one-tile-per-block fallback
+def test_fast_logmel_gradient_vs_autograd_f32(n_mels):
     import spectrogram_inversion_amd as si
     torch.manual_seed(5)
     x = 0.1 * torch.randn(2, 20 * 512, device=dev())
-    fb = torch.from_numpy(si.mel_filterbank(22050, 2048, 80)).to(dev())
+    fb = torch.from_numpy(si.mel_filterbank(22050, 2048, n_mels)).to(dev())
     win = torch.hann_window(2048, device=dev())
 
     def fn(v):
@@ -206,6 +207,7 @@ def test_fast_logmel_gradient_vs_autograd_f32():
     loss_ref = torch.nn.functional.mse_loss(fn(xt), target)
     (g_ref,) = torch.autograd.grad(loss_ref, xt)
     tr = si.LogMelSTFT(fb, 2048, hop_length=512, window=win)
+    assert rel_l2(N(tr(x)), N(fn(x))) < 2e-6
     _, fg = tr.bind(x, target)
     loss, grad = fg(x)
     assert abs(loss - loss_ref.item()) < 2e-5 * loss_ref.item()
