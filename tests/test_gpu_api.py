@@ -190,3 +190,29 @@ def test_c_abi_argument_errors():
     with pytest.raises(_lib.SpecinvError):
         _lib.check(lib.specinv_rtisi_stream_push(h, x.data_ptr(), 1, x.data_ptr(), 1024, C.byref(n64)))   # no begin: ESTATE
     assert lib.specinv_plan_fast_path(None) == _lib.EINVAL
+
+
+def test_side_stream_and_interleaved_plans():
+    """Calls issued under a non-default torch stream run on that stream (the plan follows torch's current stream on
+    every call); two plans used alternately do not disturb each other's state."""
+    rng = np.random.default_rng(21)
+    w = torch.from_numpy(hann(1024))
+    mag_a = torch.from_numpy(rng.random((2, 513, 30), dtype=np.float32)).to(DEV)
+    mag_b = torch.from_numpy(rng.random((3, 513, 44), dtype=np.float32)).to(DEV)
+    ref_a = si.griffin_lim(mag_a, max_iter=6, alpha=0.3, tol=0, verbose=False, hop_length=256, window=w)
+    ref_b = si.ADMM(mag_b, max_iter=4, rho=0.5, tol=0, verbose=False, hop_length=128, window=w)
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream(torch.device(DEV)))
+    with torch.cuda.stream(side):
+        y_a = si.griffin_lim(mag_a, max_iter=6, alpha=0.3, tol=0, verbose=False, hop_length=256, window=w)
+        y_b = si.ADMM(mag_b, max_iter=4, rho=0.5, tol=0, verbose=False, hop_length=128, window=w)
+    side.synchronize()
+    assert torch.equal(y_a, ref_a) and torch.equal(y_b, ref_b)
+    pa = Plan(args_helper(mag_a, hop_length=256, window=w), 2, 30, torch.float32, torch.device(DEV))
+    pb = Plan(args_helper(mag_b, hop_length=128, window=w), 3, 44, torch.float32, torch.device(DEV))
+    pa.gla_init(None, mag_a, 0.3)
+    pb.admm_init(None, mag_b, 0.5)
+    for _ in range(2):
+        pa.iterate(3)
+        pb.iterate(2)
+    assert torch.equal(pa.wave(), ref_a) and torch.equal(pb.wave(), ref_b)
