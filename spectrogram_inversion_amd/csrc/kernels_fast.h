@@ -1058,6 +1058,9 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
     v4f pp[H], uu[H], mm[H / 2];
     v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
     float mmid = 0.0f;
+#if SPECINV_PRIO
+    if (R < 32) __builtin_amdgcn_s_setprio(SPECINV_PRIO & 3);   // (one wave per SIMD at R = 32: nothing to outrank)
+#endif
     SPECINV_STATE_LOADS(fi);   // early: the loads fly during the forward FFT
 
     // ---- analysis: windowed frame -> registers; slide the sample window and prefetch the next hop-block
@@ -1072,6 +1075,9 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
       xq[NB - 1][i] = xn[i];
     }
     if (t + 1 < t_end) load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + OV, lane, a.pad_mode, xn);
+#if SPECINV_PRIO
+    if (R < 32) __builtin_amdgcn_s_setprio(0);
+#endif
 
 #if SPECINV_ABLATE & 4
 #elif SPECINV_TW_REGS
