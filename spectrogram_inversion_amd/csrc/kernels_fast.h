@@ -52,6 +52,9 @@
 #ifndef SPECINV_PRIO        // k_fused4: wave priority (bits 0-1) while a frame's state loads and the sample prefetch are being
 #define SPECINV_PRIO 1      // issued, so that they are not queued behind the other wave's FFT; +4: also around the output
 #endif                      // store.  Measured on two boxes (C2, ms per launch): 0 0.3023 / 0.3093, 1 0.2997, 3 0.3011 / 0.3042
+#ifndef SPECINV_WGW         // most waves per workgroup of k_fused4 (they share the window / twiddle tables in LDS): 8-wave
+#define SPECINV_WGW 8       // workgroups (one per CU) measured 2-3 % faster than 4-wave ones once every wave slot is filled
+#endif
 #ifndef SPECINV_NT
 #define SPECINV_NT 1         // nontemporal state streams (keeps the re-used samples in L2)
 #endif
@@ -681,7 +684,7 @@ __device__ __forceinline__ void load_block4(const float* __restrict__ xrow, cons
 }
 
 template <int R, int MODE, bool EVAL>
-__global__ __launch_bounds__(256, SPECINV_MINWAVES) void k_fused4(FastArgs a) {
+__global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(FastArgs a) {
   using G = Geo<R>;
   constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1979,10 +1982,18 @@ struct FastState<float> {
     }
     if (OV == 2) fn = (const void*)fast::k_fused<RR, 2, MODE, EVAL>;
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
-    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int wgw = 4;
+    size_t lds_used = lds;
+    if constexpr (RR == 8 || RR == 16) {
+      if (OV == 4) {
+        wgw = n_waves >= 2048 ? SPECINV_WGW : 4;     // fewer waves than slots: smaller workgroups reach more CUs
+        lds_used = G::lds_bytes(wgw);
+      }
+    }
+    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
     fast::FastArgs args = a;
     void* kargs[] = {&args};
-    SI_HIP(hipLaunchKernel(fn, dim3((n_waves + 3) / 4), dim3(256), kargs, lds, pl.stream));
+    SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds_used, pl.stream));
     return SPECINV_OK;
   }
 
