@@ -1829,19 +1829,35 @@ struct FastState<float> {
       supported = true;
       return SPECINV_OK;
     }
-    // frames per wave: enough waves to fill 256 CUs x 8 wave slots once; a chunk boundary costs OV - 1 split
-    // hop-blocks, and the reflected edge samples must not fall on split blocks (first / last chunk long enough)
-    const long long frames = (long long)cfg.batch * cfg.n_frames;
+    // Frames per wave.  A launch takes about rounds x (longest chunk) frame times, rounds = ceil(waves / wave slots):
+    // pick the chunk count that minimises it (the chip holds 2 waves of these kernels per SIMD, 3 at n_fft 512, 1 at
+    // 4096), e.g. 64 x 1024 frames -> 32 chunks of 32 (2048 waves, one round), 96 x 1024 -> 21 chunks of 49 (2016 waves,
+    // one round) instead of 32 chunks (3072 waves, two rounds).  A chunk boundary costs OV - 1 split hop-blocks, and the
+    // reflected edge samples must not fall on split blocks (first / last chunk long enough): chunks of >= 8 (16) frames.
     const int floor_ch = OV == 8 ? 16 : 8;
-    int ch = 32;
-    while (ch > floor_ch && frames / ch < 2048) ch /= 2;
+    const long long slots = 1024LL * (R >= 32 ? 1 : R <= 4 ? 3 : 2);
+    int best_nch = 1;
+    double best_cost = 1e300;
+    for (int nch = 1; nch <= std::max(1, cfg.n_frames / floor_ch); ++nch) {
+      const long long waves = (long long)cfg.batch * nch;
+      const long long rounds = (waves + slots - 1) / slots;
+      const int longest = (cfg.n_frames + nch - 1) / nch;
+      // (+2: what a chunk boundary costs - split blocks, pipeline fill; measured: 2 rounds of 16-frame chunks are 8 %
+      // slower than 1 round of 32.  Last factor: chunks beyond 32 frames measured ~5 % slower than two rounds of 32)
+      const double cost = (double)rounds * (longest + 2.0) * (1.0 + 0.0015 * std::max(0, longest - 32));
+      if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nch > best_nch)) {
+        best_cost = cost;
+        best_nch = nch;
+      }
+    }
+    nchunks = best_nch;
     if (const char* e = getenv("SPECINV_FAST_CHUNK")) {
       const int v = atoi(e);
-      if (v >= 4) ch = std::max(v, OV == 8 ? 13 : 4);
+      if (v >= 4) nchunks = std::max(1, cfg.n_frames / std::min(std::max(v, OV == 8 ? 13 : 4), cfg.n_frames));
     }
-    chunk = std::min(ch, cfg.n_frames);
-    nchunks = std::max(1, cfg.n_frames / chunk);   // frames split as evenly as possible, every chunk >= `chunk` (or all) frames
+    chunk = (cfg.n_frames + nchunks - 1) / nchunks;   // frames split as evenly as possible (sizes differ by at most one)
     n_waves = cfg.batch * nchunks;
+    if (getenv("SPECINV_DEBUG")) fprintf(stderr, "specinv: fused R=%d OV=%d chunks=%d of <=%d frames, %d waves (%lld slots)\n", R, OV, nchunks, chunk, n_waves, slots);
     supported = true;
     return SPECINV_OK;
   }
