@@ -161,3 +161,23 @@ def test_mel_filterbank():
     assert np.allclose(area[5:], 1.0, atol=0.08)
     g = load_golden("g6_lbfgs")
     np.testing.assert_array_equal(fb[:, ::64], g["mel_fb_check"])
+
+
+def test_mel_filterbank_options():
+    """HTK scale and un-normalised peaks (the options of the mel function the reference's README calls)."""
+    from spectrogram_inversion_amd.mel import hz_to_mel, mel_to_hz
+    f = np.array([0.0, 440.0, 1000.0, 4000.0, 11025.0])
+    for htk in (False, True):
+        np.testing.assert_allclose(mel_to_hz(hz_to_mel(f, htk), htk), f, rtol=1e-12, atol=1e-9)
+    assert abs(float(hz_to_mel(1000.0, True)) - 999.9855) < 1e-3                # 2595 log10(1 + f/700)
+    assert abs(float(hz_to_mel(1000.0)) - 15.0) < 1e-12                       # Slaney: 1 kHz = mel 15
+    peak1 = si.mel_filterbank(16000, 512, 40, norm=None)
+    assert peak1.shape == (40, 257) and 0.5 < peak1.max() <= 1.0 + 1e-6
+    htk = si.mel_filterbank(16000, 512, 40, htk=True)
+    sl = si.mel_filterbank(16000, 512, 40)
+    assert (np.diff(htk.argmax(1)) >= 0).all() and not np.allclose(htk, sl)
+    area = sl.sum(1) * (16000 / 512)
+    assert np.allclose(area[8:], 1.0, atol=0.1)
+    lim = si.mel_filterbank(16000, 512, 20, fmin=300.0, fmax=4000.0)
+    hz = np.linspace(0, 8000, 257)
+    assert lim[:, hz < 290].sum() == 0 and lim[:, hz > 4010].sum() == 0
