@@ -4,6 +4,7 @@ C ABI.  torch is used for device memory and streams only."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from collections import OrderedDict
 from dataclasses import dataclass
 
@@ -429,24 +430,34 @@ class Plan:
         return out[0], out[1]
 
 
-# small LRU of plans so that repeated calls with one configuration reuse device state
-_CACHE: "OrderedDict[tuple, Plan]" = OrderedDict()
+# small LRU of plans so that repeated calls with one configuration reuse device state.  A plan carries the state of one
+# run, so it must not be shared by two threads: the cache is per thread.
+_TLS = threading.local()
 _CACHE_MAX = 4
+
+
+def _cache() -> "OrderedDict[tuple, Plan]":
+    c = getattr(_TLS, "plans", None)
+    if c is None:
+        c = _TLS.plans = OrderedDict()
+    return c
 
 
 def get_plan(args: StftArgs, batch: int, n_frames: int, dtype: torch.dtype, device: torch.device) -> Plan:
     key = (str(device), dtype, batch, n_frames, args.n_fft, args.hop_length, args.center, args.pad_mode,
            args.normalized, args.onesided, args.window.to(torch.float64).numpy().tobytes())
-    plan = _CACHE.get(key)
+    cache = _cache()
+    plan = cache.get(key)
     if plan is None:
         plan = Plan(args, batch, n_frames, dtype, device)
-        _CACHE[key] = plan
-        while len(_CACHE) > _CACHE_MAX:
-            _CACHE.popitem(last=False)
+        cache[key] = plan
+        while len(cache) > _CACHE_MAX:
+            cache.popitem(last=False)
     else:
-        _CACHE.move_to_end(key)
+        cache.move_to_end(key)
     return plan
 
 
 def clear_plan_cache():
-    _CACHE.clear()
+    """Drop the calling thread's cached plans (their device memory is released with them)."""
+    _cache().clear()

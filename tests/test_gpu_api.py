@@ -10,7 +10,7 @@ from _util import hann, rel_l2
 pytestmark = pytest.mark.gpu
 
 import spectrogram_inversion_amd as si                              # noqa: E402
-from spectrogram_inversion_amd.plan import Plan, args_helper         # noqa: E402
+from spectrogram_inversion_amd.plan import Plan, args_helper, clear_plan_cache         # noqa: E402
 
 DEV = "cuda:0"
 
@@ -216,3 +216,69 @@ def test_side_stream_and_interleaved_plans():
         pa.iterate(3)
         pb.iterate(2)
     assert torch.equal(pa.wave(), ref_a) and torch.equal(pb.wave(), ref_b)
+
+
+def test_threads_with_their_own_plans():
+    """Two host threads running different methods at the same time (ctypes drops the GIL inside the library): each
+    thread has its own plan cache and stream, the results equal the serial ones bit for bit, and an error raised in
+    one thread leaves the other's `specinv_last_error` alone."""
+    import threading
+    rng = np.random.default_rng(33)
+    w = torch.from_numpy(hann(1024))
+    mags = [torch.from_numpy(rng.random((4, 513, 96), dtype=np.float32)).to(DEV) for _ in range(2)]
+    jobs = [lambda m: si.griffin_lim(m, max_iter=12, alpha=0.3, tol=0, verbose=False, hop_length=256, window=w),
+            lambda m: si.ADMM(m, max_iter=12, rho=0.2, tol=0, verbose=False, hop_length=256, window=w)]
+    serial = [[job(m) for m in mags] for job in jobs]
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(stream):
+                res = []
+                for rep in range(6):
+                    res = [jobs[i](m) for m in mags]
+                    if i == 0:
+                        with pytest.raises(AssertionError, match="reflect padding"):
+                            si.griffin_lim(torch.rand(1, 257, 2, device=DEV), max_iter=2, verbose=False, hop_length=128)
+            stream.synchronize()
+            out[i] = res
+        except BaseException as e:                                   # noqa: BLE001 - reported by the main thread
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        for a, b in zip(out[i], serial[i]):
+            assert torch.equal(a, b)
+
+
+def test_plans_release_their_device_memory():
+    """Creating, running and dropping plans over and over leaves the device's free memory where it started (the
+    library allocates with hipMalloc, outside torch's caching allocator)."""
+    import gc
+    rng = np.random.default_rng(34)
+    w = torch.from_numpy(hann(2048))
+    mag = torch.from_numpy(rng.random((8, 1025, 256), dtype=np.float32)).to(DEV)
+
+    def cycle(shapes):
+        for hop in shapes:
+            p = Plan(args_helper(mag, hop_length=hop, window=w), 8, 256, torch.float32, torch.device(DEV))
+            p.gla_init(None, mag, 0.3)
+            p.iterate(2)
+            p.wave()
+            del p
+        clear_plan_cache()
+        gc.collect()
+        torch.cuda.synchronize()
+
+    cycle([512, 333, 1024])                                          # warm up code objects and torch's pools
+    free0 = torch.cuda.mem_get_info(torch.device(DEV))[0]
+    for _ in range(10):
+        cycle([512, 333, 1024, 256])
+    free1 = torch.cuda.mem_get_info(torch.device(DEV))[0]
+    assert free0 - free1 < 8 << 20, (free0, free1)
