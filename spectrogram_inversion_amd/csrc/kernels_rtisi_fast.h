@@ -3,13 +3,15 @@
 // The recursion (reference: torch_specinv/methods.py:363-404) is serial per batch item, so what matters is
 // the latency of ONE inner step.  One workgroup owns one item; wave q owns look-ahead frame q for the whole
 // run.  Everything an inner step touches stays on the CU:
-//   * the frame ring (K kept + LA+1 look-ahead frames) lives in LDS;
-//   * each wave keeps its frame's previous spectrum (pre_spec, conjugate-pair order), its target magnitudes,
-//     its analysis window and the synthesis window in REGISTERS (one wave per SIMD: 512 VGPRs available);
-//   * per step a wave overlap-adds the <= 4 ring frames that cover its frame straight into registers, runs the
+//   * the frame ring (K kept + LA+1 look-ahead frames) lives in LDS, each frame already multiplied by the synthesis
+//     window, so the overlap-add is plain additions;
+//   * each wave keeps its frame's previous spectrum (pre_spec, conjugate-pair order), its target magnitudes, its
+//     analysis window and the part of the overlap-add that the kept frames contribute (constant during the inner
+//     iterations of a step) in REGISTERS; its own frame never leaves the registers between two inner iterations;
+//   * per inner iteration a wave adds the hop-blocks of the other look-ahead frames that cover its frame, runs the
 //     packed real FFT (in-register radix-R, lane-swap radix-4, one LDS transpose), applies momentum and the
 //     magnitude projection to the pairs, transforms back and writes the frame to the ring: 2 workgroup
-//     barriers per step, no global memory traffic except the once-per-frame target load and commit.
+//     barriers per iteration, no global memory traffic except the once-per-frame target load and commit.
 // Step latency drops from ~115 us (generic k_rtisi) to a few us.
 #pragma once
 #include "kernels_fast.h"
@@ -32,7 +34,7 @@ struct RtisiFastArgs {
   int i_begin, i_end, resume, n_valid;
   int mag_ring;          // 0: m_pairs is [B*T]; else [B*mag_ring], frame t at t % mag_ring
   int out_ring;          // 0: frames_out is (B, T, N); else (B, out_ring, N)
-  float* state;          // NULL, or per item: ring | per wave (pre pairs, pre mid, shifted pairs, shifted mid)
+  float* state;          // NULL, or per item: ring | per wave (pre pairs, pre mid; the rest of the record is unused)
 };
 
 template <int R>
@@ -44,10 +46,12 @@ template <int R, int OV = 4>
 struct RtisiGeo {
   using G = Geo<R>;
   static constexpr int K = OV - 1;   // kept frames: (n_fft - 1) / hop with hop = n_fft / OV
-  // LDS (v2f units): ring | tw1 | per-wave transpose scratch | per-wave pre_spec exchange (pairs as 2 x v2f + mid)
+  // LDS (v2f units): ring | tw1 | synthesis window, analysis window, the two asymmetric windows | one hop-block of
+  // zeros | per-wave transpose scratch, which doubles as the pre_spec exchange between two steps (pairs as 2 x v2f + mid)
+  static_assert(G::TR >= G::H * 2 * 64 + 64, "the pre_spec exchange must fit the transpose scratch");
   static constexpr size_t lds_bytes(int la) {
     const size_t waves = la + 1, nslots = K + la + 1;
-    return sizeof(v2f) * (nslots * G::M + (R - 1) * 64 + waves * G::TR + waves * (G::H * 2 * 64 + 64));
+    return sizeof(v2f) * (nslots * G::M + (R - 1) * 64 + 4 * G::M + (R / OV) * 64 + waves * G::TR);
   }
 };
 
@@ -62,8 +66,11 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
   v2f* ring = reinterpret_cast<v2f*>(smem);                 // [nslots][M]
   v2f* lds_tw1 = ring + (size_t)nslots * M;                 // [(R-1)*64]
   const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's look-ahead slot
-  v2f* tr = lds_tw1 + (R - 1) * 64 + q * G::TR;
-  v2f* xch = lds_tw1 + (R - 1) * 64 + nw * G::TR;           // [nw][H*2*64 + 64] pre_spec exchange
+  v2f* lds_wsyn = lds_tw1 + (R - 1) * 64;                   // [M] synthesis window w * hop / (w.w)
+  v2f* lds_win = lds_wsyn + M;                              // [3][M] analysis window w, asym1, asym2
+  v2f* lds_zero = lds_win + 3 * M;                          // [QU*64] what a frame outside the ring contributes
+  v2f* xch = lds_zero + QU * 64;                            // [nw][TR] pre_spec exchange at the end of a step, and
+  v2f* tr = xch + q * G::TR;                                // this wave's transpose scratch inside a step
   const int bi = blockIdx.x;
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
@@ -72,6 +79,15 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
   for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
     const int k1 = i / 64 + 1, l = i & 63;
     lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
+  }
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    lds_wsyn[i] = reinterpret_cast<const v2f*>(a.wsyn)[i];
+    lds_win[i] = reinterpret_cast<const v2f*>(a.window)[i];
+    if (a.asym) {
+      lds_win[M + i] = reinterpret_cast<const v2f*>(a.asym1)[i];
+      lds_win[2 * M + i] = reinterpret_cast<const v2f*>(a.asym2)[i];
+    }
+    if (i < QU * 64) lds_zero[i] = v2f{0.0f, 0.0f};
   }
   v2f* st_ring = nullptr;
   v2f* st_wave = nullptr;
@@ -85,21 +101,9 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     for (int i = threadIdx.x; i < (nslots - 1) * M; i += blockDim.x) ring[i] = v2f{0.0f, 0.0f};
   }
 
-  // per-wave register tables (sample 128u + 2 lane, +1  <->  register u)
-  v2f wsyn[R], win0[R], win1[R];
-  {
-    const v2f* ws = reinterpret_cast<const v2f*>(a.wsyn);
-    const v2f* w = reinterpret_cast<const v2f*>(a.window);
-    const bool newest = a.asym && q == la;                  // methods.py:371-383
-    const v2f* w0 = newest ? reinterpret_cast<const v2f*>(a.asym1) : w;   // first inner iteration
-    const v2f* w1 = newest ? reinterpret_cast<const v2f*>(a.asym2) : w;   // later iterations
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      wsyn[u] = ws[64u * u + ulane];
-      win0[u] = w0[64u * u + ulane];
-      win1[u] = w1[64u * u + ulane];
-    }
-  }
+  // analysis window of this wave's frame: the newest frame of an asymmetric run takes asym1 in the first inner
+  // iteration and asym2 afterwards (methods.py:371-383)
+  const bool newest = a.asym && q == la;
 
   // ---- first frame (methods.py:353-358): irfft of the zero-phase first target frame into the newest slot
   const long long f0 = (long long)bi * (a.mag_ring ? a.mag_ring : a.T);
@@ -130,29 +134,23 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     fft_inverse<R>(z, k, lds_tw1, tr);
     v2f* dst = ring + (size_t)(nslots - 1) * M;
 #pragma unroll
-    for (int u = 0; u < R; ++u) dst[64 * u + lane] = z[u];
+    for (int u = 0; u < R; ++u) dst[64 * u + lane] = z[u] * lds_wsyn[64 * u + lane];
   }
   __syncthreads();
 
-  v4f pre[H];            // this frame's pre_spec pairs (Re k, Im k, Re M-k, Im M-k)
+  // pre_spec pairs (Re k, Im k, Re M-k, Im M-k) the momentum term of the next inner iteration uses: this frame's own
+  // during a step; between steps the one of frame q+1, whose place this wave's frame takes (methods.py:389-392)
+  v4f pre[H];
   v2f premid = v2f{0.0f, 0.0f};
-  v4f shifted[H];        // pre_spec of frame q+1 at the end of the previous outer step (methods.py:391)
-  v2f shiftedmid = v2f{0.0f, 0.0f};
 #pragma unroll
-  for (int j = 0; j < H; ++j) {
-    pre[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    shifted[j] = pre[j];
-  }
+  for (int j = 0; j < H; ++j) pre[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
   if (a.resume) {
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       const v2f p0 = st_wave[(2 * j) * 64 + lane], p1 = st_wave[(2 * j + 1) * 64 + lane];
       pre[j] = v4f{p0.x, p0.y, p1.x, p1.y};
-      const v2f s0 = st_wave[H * 2 * 64 + 64 + (2 * j) * 64 + lane], s1 = st_wave[H * 2 * 64 + 64 + (2 * j + 1) * 64 + lane];
-      shifted[j] = v4f{s0.x, s0.y, s1.x, s1.y};
     }
     premid = st_wave[H * 2 * 64 + lane];
-    shiftedmid = st_wave[2 * (H * 2 * 64) + 64 + lane];
   }
   int base = a.i_begin % nslots;   // ring slot of the oldest kept frame
   const float half_scale = 0.5f * a.fwd_scale;
@@ -172,29 +170,56 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
       if (lane == 0) mmid = a.m_mid[mrow];
     }
 
+    // ---- overlap-add (methods.py:365-370), the part that does not change during the inner iterations: the kept
+    // frames (ring frames 0..K-1) that reach into this frame.  Frame kf covers hop-block qi of this frame with its own
+    // hop-block d = K - kf + q + qi if that is < OV; otherwise the block of zeros is added (no branches: a conditional
+    // update of z[] costs whole-array register copies)
+    v2f zc[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) zc[u] = v2f{0.0f, 0.0f};
+#pragma unroll
+    for (int kf = 0; kf < K; ++kf) {
+      int slot = base + kf;
+      if (slot >= nslots) slot -= nslots;
+#pragma unroll
+      for (int qi = 0; qi <= kf; ++qi) {
+        const int d = K - kf + q + qi;
+        const v2f* fr = d < OV ? ring + (size_t)slot * M + d * QU * 64 : lds_zero;
+#pragma unroll
+        for (int i2 = 0; i2 < QU; ++i2) zc[qi * QU + i2] += fr[64 * i2 + lane];
+      }
+    }
+    int so = base + K + q;
+    if (so >= nslots) so -= nslots;
+    v2f* own = ring + (size_t)so * M;                  // this wave's frame in the ring
+    const bool shift = i > 0 && q < la;                // pre holds frame q+1's spectrum of the previous step (:389-391)
+
     for (int it = 0; it < a.max_iter; ++it) {
-      // ---- this frame's samples = overlap-add of the ring frames that cover it (methods.py:365-370)
+      // ---- kept part + own frame + the hop-blocks of the other look-ahead frames q + dl that cover it
       v2f z[R];
 #pragma unroll
-      for (int qi = 0; qi < OV; ++qi) {
-        const int blk = K + q + qi;                  // hop-block index counted from ring frame 0
+      for (int u = 0; u < R; ++u) z[u] = zc[u] + own[64 * u + lane];
 #pragma unroll
-        for (int i2 = 0; i2 < QU; ++i2) z[qi * QU + i2] = v2f{0.0f, 0.0f};
+      for (int dl = 1 - OV; dl < OV; ++dl) {
+        if (dl == 0) continue;
+        const int qo = q + dl;
+        const bool ok = qo >= 0 && qo <= la;
+        int slot = base + K + qo;
+        if (slot >= nslots) slot -= nslots;
+        const v2f* fo = ring + (size_t)(ok ? slot : 0) * M;
 #pragma unroll
-        for (int d = OV - 1; d >= 0; --d) {          // frame f = blk - d contributes its hop-block d (f ascending)
-          const int f = blk - d;
-          if (f >= 0 && f < nslots) {
-            int slot = base + f;
-            if (slot >= nslots) slot -= nslots;
-            const v2f* fr = ring + (size_t)slot * M + d * QU * 64;
+        for (int qi = (dl > 0 ? dl : 0); qi < (dl > 0 ? OV : OV + dl); ++qi) {
+          const v2f* fr = ok ? fo + (qi - dl) * QU * 64 : lds_zero;   // its hop-block d = qi - dl
 #pragma unroll
-            for (int i2 = 0; i2 < QU; ++i2) z[qi * QU + i2] += fr[64 * i2 + lane] * wsyn[d * QU + i2];
-          }
+          for (int i2 = 0; i2 < QU; ++i2) z[qi * QU + i2] += fr[64 * i2 + lane];
         }
       }
       __syncthreads();                               // every wave has read the ring; slots may be rewritten
+      {
+        const v2f* win = newest ? lds_win + (it == 0 ? M : 2 * M) : lds_win;
 #pragma unroll
-      for (int u = 0; u < R; ++u) z[u] = z[u] * (it ? win1[u] : win0[u]);
+        for (int u = 0; u < R; ++u) z[u] = z[u] * win[64 * u + lane];
+      }
 
       fft_forward<R>(z, k, lds_tw1, tr);
 
@@ -205,9 +230,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         const v2f own = z[(m + 1) % R];
         rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
       }
-      const bool use_own = it > 0;                   // methods.py:387-388
-      const bool use_shift = it == 0 && i > 0 && q < la;   // :389-391
-      const float lr = (use_own || use_shift) ? a.lr : 0.0f;
+      const float lr = (it > 0 || shift) ? a.lr : 0.0f;   // methods.py:387-391
       v2f back[H];
 #pragma unroll
       for (int j = 0; j < H; ++j) {
@@ -218,7 +241,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         const v2f tw = cmul(mul_mi(wk), dd);
         const v2f xk = (e2 + tw) * half_scale;
         const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
-        const v4f p = use_own ? pre[j] : shifted[j];
+        const v4f p = pre[j];
         const v2f sk = v2f{fmaf(-lr, p.x, xk.x), fmaf(-lr, p.y, xk.y)};
         const v2f sm = v2f{fmaf(-lr, p.z, xm.x), fmaf(-lr, p.w, xm.y)};
         pre[j] = v4f{sk.x, sk.y, sm.x, sm.y};        // :392
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
       v2f zmid;
       {
         const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
-        const v2f p = use_own ? premid : shiftedmid;
+        const v2f p = premid;
         const v2f s = v2f{fmaf(-lr, p.x, xmid.x), fmaf(-lr, p.y, xmid.y)};
         premid = s;
         const float inv = __builtin_amdgcn_rcpf(fast_abs(s) + 1e-16f) * a.inv_scale;
@@ -254,25 +277,19 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
       }
       fft_inverse<R>(z, k, lds_tw1, tr);
 
-      int slot = base + K + q;
-      if (slot >= nslots) slot -= nslots;
-      v2f* dst = ring + (size_t)slot * M;
+      if (q == 0 && i >= la && it == a.max_iter - 1) {   // commit look-ahead slot 0 (methods.py:401-404)
+        const v2f* w = reinterpret_cast<const v2f*>(a.window);
+        const long long orow = a.out_ring ? (long long)bi * a.out_ring + (i - la) % a.out_ring : (long long)bi * a.T + (i - la);
+        v2f* out = reinterpret_cast<v2f*>(a.frames_out + orow * (2 * M));
 #pragma unroll
-      for (int u = 0; u < R; ++u) dst[64 * u + lane] = z[u];                 // :398
+        for (int u = 0; u < R; ++u) out[64u * u + ulane] = z[u] * w[64u * u + ulane];
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) own[64 * u + lane] = z[u] * lds_wsyn[64 * u + lane];   // :398
       __syncthreads();                               // new frames visible before the next overlap-add
     }
 
-    // ---- commit look-ahead slot 0 (methods.py:401-404), publish pre_spec for the frame-shifted momentum
-    int s0 = base + K;
-    if (s0 >= nslots) s0 -= nslots;
-    if (q == 0 && i >= la) {
-      const v2f* src = ring + (size_t)s0 * M;
-      const v2f* w = reinterpret_cast<const v2f*>(a.window);
-      const long long orow = a.out_ring ? (long long)bi * a.out_ring + (i - la) % a.out_ring : (long long)bi * a.T + (i - la);
-      v2f* dst = reinterpret_cast<v2f*>(a.frames_out + orow * (2 * M));
-#pragma unroll
-      for (int u = 0; u < R; ++u) dst[64u * u + ulane] = src[64 * u + lane] * w[64u * u + ulane];
-    }
+    // ---- slide: publish pre_spec, take over the one of the frame that moves into this wave's place
     {
       v2f* mine = xch + (size_t)q * (H * 2 * 64 + 64);
 #pragma unroll
@@ -288,9 +305,9 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         const v2f a0 = nxt[(2 * j) * 64 + lane], a1 = nxt[(2 * j + 1) * 64 + lane];
-        shifted[j] = v4f{a0.x, a0.y, a1.x, a1.y};
+        pre[j] = v4f{a0.x, a0.y, a1.x, a1.y};
       }
-      shiftedmid = nxt[H * 2 * 64];
+      premid = nxt[H * 2 * 64];
     }
     if (q == la) {   // the oldest frame's slot becomes the new (zero) newest frame
       v2f* fresh = ring + (size_t)base * M;
@@ -306,11 +323,8 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     for (int j = 0; j < H; ++j) {
       st_wave[(2 * j) * 64 + lane] = v2f{pre[j].x, pre[j].y};
       st_wave[(2 * j + 1) * 64 + lane] = v2f{pre[j].z, pre[j].w};
-      st_wave[H * 2 * 64 + 64 + (2 * j) * 64 + lane] = v2f{shifted[j].x, shifted[j].y};
-      st_wave[H * 2 * 64 + 64 + (2 * j + 1) * 64 + lane] = v2f{shifted[j].z, shifted[j].w};
     }
     st_wave[H * 2 * 64 + lane] = premid;
-    st_wave[2 * (H * 2 * 64) + 64 + lane] = shiftedmid;
   }
 }
 
