@@ -19,10 +19,12 @@ ap.add_argument("--method", default="gla")
 ap.add_argument("--launches", type=int, default=50)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--chunks", default="")
+ap.add_argument("--hop", type=int, default=0)
+ap.add_argument("--generic", action="store_true", help="force the generic kernels")
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
-n_fft, hop = args.n_fft, args.n_fft // 4
+n_fft, hop = args.n_fft, args.hop or args.n_fft // 4
 F = n_fft // 2 + 1
 w = torch.from_numpy((0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32))
 mag = torch.from_numpy(np.random.default_rng(0).random((args.batch, F, args.frames), dtype=np.float32)).to(dev)
@@ -32,6 +34,8 @@ for chunk in ([None] + [int(c) for c in args.chunks.split(",") if c]):
     if chunk:
         os.environ["SPECINV_FAST_CHUNK"] = str(chunk)
     plan = Plan(a, args.batch, args.frames, torch.float32, dev)
+    if args.generic:
+        plan.force_generic(True)
     if args.method == "gla":
         plan.gla_init(None, mag, 0.3)
     else:
@@ -47,6 +51,6 @@ for chunk in ([None] + [int(c) for c in args.chunks.split(",") if c]):
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / args.launches)
     gbs = per_unit * args.batch * args.frames / (best * 1e-3) / 1e9
-    print(f"chunk={chunk} fast={plan.fast_path} {best:.4f} ms/launch  {gbs:.0f} GB/s algorithmic "
+    print(f"chunk={chunk} path={plan.path} {best:.4f} ms/launch  {gbs:.0f} GB/s algorithmic "
           f"({100 * gbs / 8000:.1f}% of 8 TB/s)", flush=True)
     del plan
