@@ -19,6 +19,10 @@ struct FrameCfg {
   T inv_scale;     // 1/n_fft or n_fft^-1/2 (irfft norm backward / ortho)
   int n_stages;
   int radix[kMaxStages];
+  // per stage s (ns = product of the radices before it): ceil(2^32 / ns) and ceil(2^32 / (ns * radix)) for the
+  // division-free index split (exact for dividends < 2^16), and the twiddle stride n_fft / (ns * radix)
+  unsigned ns_magic[kMaxStages], m_magic[kMaxStages];
+  int tw_step[kMaxStages];
   const cplx<T>* tw;  // tw[n] = exp(-2 pi i n / n_fft)
   const T* window;    // n_fft
 };
@@ -135,12 +139,18 @@ struct Butterfly<T, 8, INV> {
   }
 };
 
+// j / d for 0 <= j < 2^16, d >= 1, magic = ceil(2^32 / d) (d = 1: magic wraps to 0 and is not used)
+__device__ __forceinline__ int div_magic(int j, int d, unsigned magic) {
+  return d == 1 ? j : (int)__umulhi((unsigned)j, magic);
+}
+
 template <typename T, int R, bool INV>
 __device__ __forceinline__ void fft_stage(const cplx<T>* __restrict__ a, cplx<T>* __restrict__ b, const FrameCfg<T>& c,
-                                          int ns, int tid, int nthr) {
-  const int N = c.n_fft, nb = N / R, tws = N / (ns * R);
+                                          int s, int ns, int tid, int nthr) {
+  const int N = c.n_fft, nb = (unsigned)N / (unsigned)R, tws = c.tw_step[s];
+  const unsigned magic = c.ns_magic[s];
   for (int j = tid; j < nb; j += nthr) {
-    const int blk = j / ns, k = j - blk * ns;
+    const int blk = div_magic(j, ns, magic), k = j - blk * ns;
     cplx<T> v[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) v[q] = a[j + q * nb];
@@ -163,12 +173,13 @@ __device__ __forceinline__ void fft_stage(const cplx<T>* __restrict__ a, cplx<T>
 // any radix: one output per thread, direct DFT_R
 template <typename T>
 __device__ inline void fft_stage_any(const cplx<T>* __restrict__ a, cplx<T>* __restrict__ b, const FrameCfg<T>& c, int R,
-                                     int ns, bool inverse, int tid, int nthr) {
-  const int N = c.n_fft, m = ns * R, stride = N / R, twstep = N / m;
+                                     int s, int ns, bool inverse, int tid, int nthr) {
+  const int N = c.n_fft, m = ns * R, stride = N / R, twstep = c.tw_step[s];
+  const unsigned magic_m = c.m_magic[s], magic_ns = c.ns_magic[s];
   for (int o = tid; o < N; o += nthr) {
-    const int block = o / m;
+    const int block = div_magic(o, m, magic_m);
     const int within = o - block * m;
-    const int r = within / ns;
+    const int r = div_magic(within, ns, magic_ns);
     const int k = within - r * ns;
     const int j = block * ns + k;
     const int e1 = k + r * ns;  // < m
@@ -193,13 +204,13 @@ __device__ inline void lds_fft_dir(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& 
   for (int s = 0; s < c.n_stages; ++s) {
     const int R = c.radix[s];
     switch (R) {
-      case 2: fft_stage<T, 2, INV>(a, b, c, ns, tid, nthr); break;
-      case 3: fft_stage<T, 3, INV>(a, b, c, ns, tid, nthr); break;
-      case 4: fft_stage<T, 4, INV>(a, b, c, ns, tid, nthr); break;
-      case 5: fft_stage<T, 5, INV>(a, b, c, ns, tid, nthr); break;
-      case 7: fft_stage<T, 7, INV>(a, b, c, ns, tid, nthr); break;
-      case 8: fft_stage<T, 8, INV>(a, b, c, ns, tid, nthr); break;
-      default: fft_stage_any<T>(a, b, c, R, ns, INV, tid, nthr); break;
+      case 2: fft_stage<T, 2, INV>(a, b, c, s, ns, tid, nthr); break;
+      case 3: fft_stage<T, 3, INV>(a, b, c, s, ns, tid, nthr); break;
+      case 4: fft_stage<T, 4, INV>(a, b, c, s, ns, tid, nthr); break;
+      case 5: fft_stage<T, 5, INV>(a, b, c, s, ns, tid, nthr); break;
+      case 7: fft_stage<T, 7, INV>(a, b, c, s, ns, tid, nthr); break;
+      case 8: fft_stage<T, 8, INV>(a, b, c, s, ns, tid, nthr); break;
+      default: fft_stage_any<T>(a, b, c, R, s, ns, INV, tid, nthr); break;
     }
     __syncthreads();
     cplx<T>* tmp = a;
@@ -331,10 +342,8 @@ __global__ void k_ola_f4(const float* __restrict__ frames, const float* __restri
 // Z'_f = H(Y_A)_f + i H(Y_B)_f comes back as a = Re z', b = Im z'.  Works for any n_fft and any radix.
 // One thread owns the bin pair (f, N-f) of both frames.
 template <typename T, int MODE>   // 0: Griffin-Lim (S0 = pre_spec), 1: ADMM (S0 = X, S1 = U)
-__device__ __forceinline__ cplx<T> update_one(cplx<T> r, cplx<T>* __restrict__ S0, cplx<T>* __restrict__ S1,
-                                              const T* __restrict__ mag, int64_t idx, T coef, T inv1p, bool eval,
-                                              double& s_d, double& s_o) {
-  const T m = mag[idx];
+__device__ __forceinline__ cplx<T> update_core(cplx<T> r, T m, cplx<T> s0, cplx<T> s1, T coef, T inv1p, bool eval,
+                                               double& s_d, double& s_o, cplx<T>& n0, cplx<T>& n1) {
   if (eval) {
     const T o = si_hypot(r.x, r.y);
     const double d = (double)o - (double)m;
@@ -342,23 +351,34 @@ __device__ __forceinline__ cplx<T> update_one(cplx<T> r, cplx<T>* __restrict__ S
     s_o += (double)o * (double)o;
   }
   if (MODE == 0) {                                             // methods.py:243-247
-    const cplx<T> p = S0[idx];
-    const cplx<T> sv = mk<T>(r.x - p.x * coef, r.y - p.y * coef);
-    S0[idx] = sv;
+    const cplx<T> sv = mk<T>(r.x - s0.x * coef, r.y - s0.y * coef);
+    n0 = sv;
     const T inv = T(1) / (si_hypot(sv.x, sv.y) + eps16<T>::value);
     return mk<T>((sv.x * m) * inv, (sv.y * m) * inv);
   } else {                                                     // methods.py:467-475
-    const cplx<T> xo = S0[idx], uo = S1[idx];
+    const cplx<T> xo = s0, uo = s1;
     const cplx<T> y = xo + uo;
     const cplx<T> z = mk<T>((coef * y.x + r.x) * inv1p, (coef * y.y + r.y) * inv1p);
     const cplx<T> un = (uo + xo) - z;
     cplx<T> xn = z - un;
     const T inv = T(1) / (si_hypot(xn.x, xn.y) + eps16<T>::value);
     xn = mk<T>((xn.x * m) * inv, (xn.y * m) * inv);
-    S0[idx] = xn;
-    S1[idx] = un;
+    n0 = xn;
+    n1 = un;
     return xn + un;
   }
+}
+
+template <typename T, int MODE>
+__device__ __forceinline__ cplx<T> update_one(cplx<T> r, cplx<T>* __restrict__ S0, cplx<T>* __restrict__ S1,
+                                              const T* __restrict__ mag, int64_t idx, T coef, T inv1p, bool eval,
+                                              double& s_d, double& s_o) {
+  cplx<T> n0, n1 = mk<T>(T(0), T(0));
+  const cplx<T> s1 = MODE == 1 ? S1[idx] : mk<T>(T(0), T(0));
+  const cplx<T> y = update_core<T, MODE>(r, mag[idx], S0[idx], s1, coef, inv1p, eval, s_d, s_o, n0, n1);
+  S0[idx] = n0;
+  if (MODE == 1) S1[idx] = n1;
+  return y;
 }
 
 template <typename T, int MODE, bool EVAL>
@@ -381,12 +401,22 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
     int bad = 0;
     {
       const int64_t sa = (int64_t)ta * c.hop - c.pad, sb = (int64_t)tb * c.hop - c.pad;
-      for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const T w = c.window[n];
-        const T va = load_padded(xr, c.length, sa + n, c.pad_mode) * w;
-        const T vb = tb >= 0 ? load_padded(xr, c.length, sb + n, c.pad_mode) * w : T(0);
-        bad |= !__builtin_isfinite(va) || !__builtin_isfinite(vb);
-        a[n] = mk<T>(va, vb);
+      if (sa >= 0 && tb >= 0 && sb + N <= c.length) {          // both frames inside the signal: no padding tests
+        const T *pa = xr + sa, *pb = xr + sb;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+          const T w = c.window[n];
+          const T va = pa[n] * w, vb = pb[n] * w;
+          bad |= !__builtin_isfinite(va) || !__builtin_isfinite(vb);
+          a[n] = mk<T>(va, vb);
+        }
+      } else {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+          const T w = c.window[n];
+          const T va = load_padded(xr, c.length, sa + n, c.pad_mode) * w;
+          const T vb = tb >= 0 ? load_padded(xr, c.length, sb + n, c.pad_mode) * w : T(0);
+          bad |= !__builtin_isfinite(va) || !__builtin_isfinite(vb);
+          a[n] = mk<T>(va, vb);
+        }
       }
     }
     const bool split = __syncthreads_or(bad) && tb >= 0;   // (also the barrier after the load)
@@ -398,21 +428,39 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
     lds_fft(a, b, c, false);
     const int64_t base_a = ((int64_t)bi * c.n_frames + ta) * F, base_b = ((int64_t)bi * c.n_frames + tb) * F;
     const bool has_b = tb >= 0;
-    for (int f = threadIdx.x; f <= N / 2; f += blockDim.x) {
-      const int g = f ? N - f : 0;
-      const cplx<T> zf = a[f], zg = a[g];
-      // spectra of the two frames at bin f (bin g holds their conjugates)
-      const cplx<T> ra = mk<T>((zf.x + zg.x) * hs, (zf.y - zg.y) * hs);
-      const cplx<T> rb = mk<T>((zf.y + zg.y) * hs, (zg.x - zf.x) * hs);
-      cplx<T> ha, hb;   // Hermitian parts of the updated spectra at bin f
-      if (c.onesided) {
-        ha = update_one<T, MODE>(ra, S0, S1, mag, base_a + f, coef, inv1p, EVAL, s_d, s_o);
-        hb = has_b ? update_one<T, MODE>(rb, S0, S1, mag, base_b + f, coef, inv1p, EVAL, s_d, s_o) : mk<T>(T(0), T(0));
+    if (c.onesided) {
+      // spectra of the two frames at bin f (bin g = N - f holds their conjugates) -> updated Hermitian parts
+      auto bin = [&](int f, T ma, cplx<T> a0, cplx<T> a1, T mb, cplx<T> b0, cplx<T> b1) {
+        const int g = f ? N - f : 0;
+        const cplx<T> zf = a[f], zg = a[g];
+        const cplx<T> ra = mk<T>((zf.x + zg.x) * hs, (zf.y - zg.y) * hs);
+        const cplx<T> rb = mk<T>((zf.y + zg.y) * hs, (zg.x - zf.x) * hs);
+        cplx<T> n0, n1, hb = mk<T>(T(0), T(0));
+        cplx<T> ha = update_core<T, MODE>(ra, ma, a0, a1, coef, inv1p, EVAL, s_d, s_o, n0, n1);
+        S0[base_a + f] = n0;
+        if (MODE == 1) S1[base_a + f] = n1;
+        if (has_b) {
+          hb = update_core<T, MODE>(rb, mb, b0, b1, coef, inv1p, EVAL, s_d, s_o, n0, n1);
+          S0[base_b + f] = n0;
+          if (MODE == 1) S1[base_b + f] = n1;
+        }
         if (g == f) {
           ha.y = T(0);
           hb.y = T(0);
         }
-      } else {
+        b[f] = mk<T>(ha.x - hb.y, ha.y + hb.x);
+        if (g != f) b[g] = mk<T>(ha.x + hb.y, hb.x - ha.y);
+      };
+      const cplx<T> zero = mk<T>(T(0), T(0));
+      for (int f = threadIdx.x; f <= N / 2; f += blockDim.x)
+        bin(f, mag[base_a + f], S0[base_a + f], MODE == 1 ? S1[base_a + f] : zero, has_b ? mag[base_b + f] : T(0),
+            has_b ? S0[base_b + f] : zero, (MODE == 1 && has_b) ? S1[base_b + f] : zero);
+    } else {
+      for (int f = threadIdx.x; f <= N / 2; f += blockDim.x) {
+        const int g = f ? N - f : 0;
+        const cplx<T> zf = a[f], zg = a[g];
+        const cplx<T> ra = mk<T>((zf.x + zg.x) * hs, (zf.y - zg.y) * hs);
+        const cplx<T> rb = mk<T>((zf.y + zg.y) * hs, (zg.x - zf.x) * hs);
         const cplx<T> yaf = update_one<T, MODE>(ra, S0, S1, mag, base_a + f, coef, inv1p, EVAL, s_d, s_o);
         const cplx<T> ybf = has_b ? update_one<T, MODE>(rb, S0, S1, mag, base_b + f, coef, inv1p, EVAL, s_d, s_o)
                                   : mk<T>(T(0), T(0));
@@ -421,11 +469,12 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
           yag = update_one<T, MODE>(conj(ra), S0, S1, mag, base_a + g, coef, inv1p, EVAL, s_d, s_o);
           if (has_b) ybg = update_one<T, MODE>(conj(rb), S0, S1, mag, base_b + g, coef, inv1p, EVAL, s_d, s_o);
         }
-        ha = mk<T>(T(0.5) * (yaf.x + yag.x), T(0.5) * (yaf.y - yag.y));
-        hb = mk<T>(T(0.5) * (ybf.x + ybg.x), T(0.5) * (ybf.y - ybg.y));
+        // Hermitian parts of the updated spectra at bin f
+        const cplx<T> ha = mk<T>(T(0.5) * (yaf.x + yag.x), T(0.5) * (yaf.y - yag.y));
+        const cplx<T> hb = mk<T>(T(0.5) * (ybf.x + ybg.x), T(0.5) * (ybf.y - ybg.y));
+        b[f] = mk<T>(ha.x - hb.y, ha.y + hb.x);
+        if (g != f) b[g] = mk<T>(ha.x + hb.y, hb.x - ha.y);
       }
-      b[f] = mk<T>(ha.x - hb.y, ha.y + hb.x);
-      if (g != f) b[g] = mk<T>(ha.x + hb.y, hb.x - ha.y);
     }
     __syncthreads();
     {

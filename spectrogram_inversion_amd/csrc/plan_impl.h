@@ -154,7 +154,14 @@ struct PlanT final : PlanBase {
     fc.fwd_scale = cfg.normalized ? (T)(1.0 / std::sqrt((double)n)) : T(1);
     fc.inv_scale = cfg.normalized ? (T)(1.0 / std::sqrt((double)n)) : (T)(1.0 / n);
     fc.n_stages = (int)rad.size();
-    for (size_t i = 0; i < rad.size(); ++i) fc.radix[i] = rad[i];
+    for (size_t i = 0, ns = 1; i < rad.size(); ++i) {
+      fc.radix[i] = rad[i];
+      const uint64_t m = (uint64_t)ns * rad[i];
+      fc.ns_magic[i] = (unsigned)(((1ull << 32) + ns - 1) / ns);      // ns = 1: wraps to 0, never used
+      fc.m_magic[i] = (unsigned)(((1ull << 32) + m - 1) / m);
+      fc.tw_step[i] = (int)(n / m);
+      ns = m;
+    }
     fc.tw = tw.as<C>();
     fc.window = window.as<T>();
     lds_bytes = 2 * (size_t)n * sizeof(C);
