@@ -243,6 +243,40 @@ def test_gla_vs_oracle(n_fft, hop, frames, batch):
     assert rel_l2(y, ref) < 1e-4, rel_l2(y, ref)
 
 
+@pytest.mark.parametrize("n_fft,hop,frames,onesided,dtype", [
+    (176, 44, 40, True, np.float32),      # 2^4 * 11: a prime factor above the unrolled butterflies (direct DFT stage)
+    (254, 64, 30, True, np.float32),      # 2 * 127
+    (1018, 255, 12, True, np.float32),    # 2 * 509, hop not dividing n_fft
+    (169, 43, 24, False, np.float32),     # 13^2, odd length: two-sided only
+    (97, 25, 30, False, np.float64),      # a prime length: one direct DFT
+    (286, 71, 20, True, np.float64),      # 2 * 11 * 13
+])
+def test_large_prime_factors_vs_oracle(n_fft, hop, frames, onesided, dtype):
+    """n_fft with prime factors the kernels have no unrolled butterfly for (>= 11): every such stage is a direct DFT with
+    one output per thread (`fft_stage_any`); Griffin-Lim, ADMM and the transforms against the oracle."""
+    rng = np.random.default_rng(n_fft)
+    F = n_fft // 2 + 1 if onesided else n_fft
+    mag = rng.random((2, F, frames)).astype(dtype)
+    w = hann(n_fft).astype(dtype)
+    kw = dict(hop_length=hop, onesided=onesided)
+    tol = 2e-4 if dtype == np.float32 else 1e-9
+    ref = oracle.griffin_lim(mag, max_iter=6, alpha=0.3, tol=0, window=w, **kw)
+    y = N(si.griffin_lim(T(mag), max_iter=6, alpha=0.3, tol=0, verbose=False, window=torch.from_numpy(w), **kw))
+    assert y.dtype == dtype and rel_l2(y, ref) < tol, rel_l2(y, ref)
+    ref = oracle.admm(mag, max_iter=3, rho=0.5, tol=0, window=w, **kw)
+    y = N(si.ADMM(T(mag), max_iter=3, rho=0.5, tol=0, verbose=False, window=torch.from_numpy(w), **kw))
+    assert rel_l2(y, ref) < tol, rel_l2(y, ref)
+    # RTISI-LA amplifies rounding noise along the signal (SURVEY 8c): the yardstick is what the oracle itself loses
+    # between float32 and float64 arithmetic on the same input
+    r = dict(look_ahead=1, asymmetric_window=True, max_iter=3, alpha=0.5)
+    ref64 = oracle.rtisi_la(mag.astype(np.float64), window=w.astype(np.float64), **r, **kw)
+    ref = oracle.rtisi_la(mag, window=w, **r, **kw)
+    y = N(si.RTISI_LA(T(mag), verbose=False, window=torch.from_numpy(w), **r, **kw))
+    e, e0 = segment_errors(y, ref64, 4 * hop), segment_errors(ref, ref64, 4 * hop)
+    assert np.median(e) < max(10 * tol, 5 * np.median(e0)), (np.median(e), np.median(e0))      # typical stretch
+    assert rel_l2(y, ref64) < max(10 * tol, 20 * rel_l2(ref, ref64)), (rel_l2(y, ref64), rel_l2(ref, ref64))   # no blow-up
+
+
 def test_state_spec_parity():
     rng = np.random.default_rng(11)
     mag = rng.random((2, 129, 30), dtype=np.float32)
