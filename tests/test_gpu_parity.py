@@ -250,6 +250,9 @@ def test_gla_vs_oracle(n_fft, hop, frames, batch):
     (169, 43, 24, False, np.float32),     # 13^2, odd length: two-sided only
     (97, 25, 30, False, np.float64),      # a prime length: one direct DFT
     (286, 71, 20, True, np.float64),      # 2 * 11 * 13
+    (448, 112, 16, True, np.float32),     # 2^6 * 7: the radix-7 butterfly
+    (8192, 2048, 6, True, np.float32),    # 128 KiB of LDS per frame pair (above the 48 KiB default limit)
+    (4096, 1024, 6, True, np.float64),    # the same in float64
 ])
 def test_large_prime_factors_vs_oracle(n_fft, hop, frames, onesided, dtype):
     """n_fft with prime factors the kernels have no unrolled butterfly for (>= 11): every such stage is a direct DFT with
@@ -269,12 +272,26 @@ def test_large_prime_factors_vs_oracle(n_fft, hop, frames, onesided, dtype):
     # RTISI-LA amplifies rounding noise along the signal: the yardstick is what the oracle itself loses
     # between float32 and float64 arithmetic on the same input
     r = dict(look_ahead=1, asymmetric_window=True, max_iter=3, alpha=0.5)
+    if 2 * n_fft * (16 if dtype == np.float64 else 8) > 120 * 1024:
+        # every look-ahead frame has its own pair of LDS buffers in the persistent RTISI kernel: refused, not rerouted
+        with pytest.raises(NotImplementedError, match="LDS"):
+            si.RTISI_LA(T(mag), verbose=False, window=torch.from_numpy(w), **r, **kw)
+        return
     ref64 = oracle.rtisi_la(mag.astype(np.float64), window=w.astype(np.float64), **r, **kw)
     ref = oracle.rtisi_la(mag, window=w, **r, **kw)
     y = N(si.RTISI_LA(T(mag), verbose=False, window=torch.from_numpy(w), **r, **kw))
     e, e0 = segment_errors(y, ref64, 4 * hop), segment_errors(ref, ref64, 4 * hop)
     assert np.median(e) < max(10 * tol, 5 * np.median(e0)), (np.median(e), np.median(e0))      # typical stretch
     assert rel_l2(y, ref64) < max(10 * tol, 20 * rel_l2(ref, ref64)), (rel_l2(y, ref64), rel_l2(ref, ref64))   # no blow-up
+
+
+def test_transform_too_large_for_lds_is_refused():
+    """2 * n_fft complex values must fit the 160 KiB of LDS: 16384 points in float32 (and 8192 in float64) are refused
+    with SPECINV_EUNSUPPORTED at plan creation, not run on some slower path."""
+    for n_fft, dtype in ((16384, torch.float32), (8192, torch.float64)):
+        mag = torch.rand(1, n_fft // 2 + 1, 4, dtype=dtype, device=dev())
+        with pytest.raises(NotImplementedError, match="LDS"):
+            si.griffin_lim(mag, max_iter=1, verbose=False, hop_length=n_fft // 4)
 
 
 def test_state_spec_parity():
