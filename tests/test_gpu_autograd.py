@@ -202,3 +202,44 @@ def test_rtisi_gradient_from_cpu_leaf():
     assert y.device.type == "cpu"
     y.square().sum().backward()
     assert sp.grad is not None and sp.grad.device.type == "cpu" and torch.isfinite(sp.grad).all()
+
+
+# ---- the reference's kwarg sweep with backward() (test/test_griffin.py:24-68, test_admm.py, test_rtisila.py:20-70) -----
+def _sweep():
+    for wl, win in ((None, None), (300, None), (300, "hann")):
+        for hop in (None, 128):
+            for center in (True, False):
+                for normalized in (False, True):
+                    for onesided in (False, True):
+                        yield dict(win_length=wl, window=win, hop_length=hop, center=center, normalized=normalized,
+                                   onesided=onesided)
+
+
+@pytest.mark.parametrize("pad_mode", ["reflect", "constant", "replicate", "circular"])
+@pytest.mark.parametrize("method", ["griffin_lim", "ADMM", "RTISI_LA"])
+def test_reference_kwarg_sweep_is_differentiable(method, pad_mode):
+    """Every stft-kwarg combination of the reference's `test_stft_args` (48 per pad mode; RTISI_LA also look_ahead in
+    {-1, 2} x asymmetric_window): magnitudes of torch.stft with `requires_grad`, 2 iterations, mse against the signal,
+    `backward()`.  Asserts what the reference asserts (rank, length, a gradient exists) plus its shape, and that it is
+    finite whenever the waveform is (no centring + a window that vanishes at the ends gives the reference's 0/0)."""
+    torch.manual_seed(5)
+    x = torch.randn(4410, device=DEV)
+    fn = getattr(si, method)
+    n_done = 0
+    for kw in _sweep():
+        kw = dict(kw, pad_mode=pad_mode)
+        if kw["window"] == "hann":
+            kw["window"] = torch.hann_window(300, device=DEV)
+        extras = [dict()] if method != "RTISI_LA" else [dict(look_ahead=la, asymmetric_window=a) for la in (-1, 2)
+                                                        for a in (True, False)]
+        for ex in extras:
+            sp = torch.stft(x, 512, return_complex=True, **kw).abs().requires_grad_(True)
+            y = fn(sp, max_iter=2, verbose=False, return_complex=False, **ex, **kw)
+            assert y.dim() == 1 and 0 < y.shape[0] <= x.shape[0] + 512
+            n = min(y.shape[0], x.shape[0])
+            torch.nn.functional.mse_loss(x[:n], y[:n]).backward()
+            assert sp.grad is not None and sp.grad.shape == sp.shape
+            if bool(torch.isfinite(y).all()):
+                assert bool(torch.isfinite(sp.grad).all()), (method, kw, ex)
+            n_done += 1
+    assert n_done == (48 if method != "RTISI_LA" else 192)
