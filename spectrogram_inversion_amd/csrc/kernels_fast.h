@@ -1384,6 +1384,10 @@ __device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, 
     const v2f* src = reinterpret_cast<const v2f*>(xrow + start);
 #pragma unroll
     for (int u = 0; u < R; ++u) z[u] = src[64u * u + (unsigned)lane];
+  } else if (start >= 0 && start + N <= len) {   // inside the signal at an odd offset: two 4-byte loads per register
+    const float* src = xrow + start;
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = v2f{src[128u * u + 2u * (unsigned)lane], src[128u * u + 2u * (unsigned)lane + 1u]};
   } else {
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -1520,11 +1524,114 @@ struct SemiArgs {
   int hop, pad;
 };
 
+// One frame of the frame kernels: state in, (samples -> spectrum -> update) unless MODE_INIT, state out, inverse
+// transform.  On return z holds the synthesis frame before its window (register u <-> samples 128u + 2 lane, +1).
+template <int R, int MODE, bool EVAL>
+__device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long long b, int t, int hop, int pad,
+                                           const LaneConst<R>& k, const v2f* lds_win, const v2f* lds_tw1, v2f* tr,
+                                           v2f (&z)[R], double& sd, double& so) {
+  using G = Geo<R>;
+  constexpr int H = G::H;
+  constexpr int UMODE = MODE == MODE_INIT ? MODE_GLA : MODE;
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const float half_scale = 0.5f * a.fwd_scale;
+  v4f pp[H], uu[H], mm[H / 2];
+  v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
+  float mmid = 0.0f;
+  {
+    v4f* pin = a.P_out + fi * (H * 64);
+#pragma unroll
+    for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin[j * 64u + ulane]);
+    if (MODE == MODE_ADMM) {
+      v4f* uin = a.U_out + fi * (H * 64);
+#pragma unroll
+      for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin[j * 64u + ulane]);
+    }
+    if (MODE != MODE_INIT) {
+      const v4f* min = a.m_pairs + fi * (H / 2 * 64);
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min[j * 64u + ulane]);
+    }
+    if (lane == 0) {
+      pmid = a.Pmid_out[fi];
+      if (MODE != MODE_INIT) mmid = a.m_mid[fi];
+      if (MODE == MODE_ADMM) umid = a.Umid_out[fi];
+    }
+  }
+  v2f rc[H];
+  if (MODE != MODE_INIT) {
+    load_frame_regs<R>(a.x_in + b * a.L, a.L, (long long)t * hop - pad, lane, a.pad_mode, lds_win, z);
+    fft_forward<R>(z, k, lds_tw1, tr);
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+  }
+  v2f back[H];
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+    v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
+    v2f ak, am;
+    if (MODE != MODE_INIT) {
+      const v2f zk = z[j], zm = rc[R - 1 - j - H];
+      const v2f e2 = add_conj(zk, zm);
+      const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
+      const v2f xk = (e2 + tw) * half_scale;
+      const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
+      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
+      if (MODE == MODE_ADMM) {
+        uk = v2f{uu[j].x, uu[j].y};
+        um = v2f{uu[j].z, uu[j].w};
+      }
+      const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+      const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+      ak = update_bin<UMODE, EVAL>(xk, pk, uk, mk, a, true, sd, so);
+      am = update_bin<UMODE, EVAL>(xm, pm, um, mq, a, true, sd, so);
+      st_stream(&a.P_out[fi * (H * 64) + j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
+      if (MODE == MODE_ADMM) st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+    } else {
+      ak = pk * a.inv_scale;
+      am = pm * a.inv_scale;
+    }
+    if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+      ak.y = 0.0f;
+      am.y = 0.0f;
+    }
+    const v2f e2i = add_conj(ak, am);
+    const v2f o2i = cmulc(sub_conj(ak, am), wk);
+    z[j] = add_i(e2i, o2i);
+    back[j] = conj_sub_i(e2i, o2i);
+  }
+  v2f zmid;
+  if (MODE != MODE_INIT) {
+    const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
+    const bool live0 = lane == 0;
+    const v2f am = update_bin<UMODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
+    if (live0) {
+      a.Pmid_out[fi] = pmid;
+      if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
+    }
+    zmid = am * v2f{2.0f, -2.0f};
+  } else {
+    zmid = pmid * v2f{2.0f * a.inv_scale, -2.0f * a.inv_scale};
+  }
+#pragma unroll
+  for (int m = H; m < R; ++m) {
+    const v2f got = shfl2(back[R - 1 - m], k.partner);
+    const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+    z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+  }
+  fft_inverse<R>(z, k, lds_tw1, tr);
+}
+
 template <int R, int MODE, bool EVAL>
 __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
   using G = Geo<R>;
-  constexpr int H = G::H, M = G::M;
-  constexpr int UMODE = MODE == MODE_INIT ? MODE_GLA : MODE;
+  constexpr int M = G::M;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* lds_win = reinterpret_cast<v2f*>(smem);
   v2f* lds_tw1 = lds_win + M;
@@ -1535,101 +1642,12 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
-  const float half_scale = 0.5f * a.fwd_scale;
   double sd = 0.0, so = 0.0;
   for (long long fi = (long long)blockIdx.x * 4 + wib; fi < s.n_frames_total; fi += (long long)gridDim.x * 4) {
     const long long b = fi / a.T;
     const int t = (int)(fi - b * a.T);
-    v4f pp[H], uu[H], mm[H / 2];
-    v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
-    float mmid = 0.0f;
-    {
-      v4f* pin = a.P_out + fi * (H * 64);
-#pragma unroll
-      for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin[j * 64u + ulane]);
-      if (MODE == MODE_ADMM) {
-        v4f* uin = a.U_out + fi * (H * 64);
-#pragma unroll
-        for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin[j * 64u + ulane]);
-      }
-      if (MODE != MODE_INIT) {
-        const v4f* min = a.m_pairs + fi * (H / 2 * 64);
-#pragma unroll
-        for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min[j * 64u + ulane]);
-      }
-      if (lane == 0) {
-        pmid = a.Pmid_out[fi];
-        if (MODE != MODE_INIT) mmid = a.m_mid[fi];
-        if (MODE == MODE_ADMM) umid = a.Umid_out[fi];
-      }
-    }
-    v2f z[R], rc[H];
-    if (MODE != MODE_INIT) {
-      load_frame_regs<R>(a.x_in + b * a.L, a.L, (long long)t * s.hop - s.pad, lane, a.pad_mode, lds_win, z);
-      fft_forward<R>(z, k, lds_tw1, tr);
-#pragma unroll
-      for (int m = H; m < R; ++m) {
-        const v2f got = shfl2(z[m], k.partner);
-        const v2f own = z[(m + 1) % R];
-        rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
-      }
-    }
-    v2f back[H];
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
-      v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
-      v2f ak, am;
-      if (MODE != MODE_INIT) {
-        const v2f zk = z[j], zm = rc[R - 1 - j - H];
-        const v2f e2 = add_conj(zk, zm);
-        const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
-        const v2f xk = (e2 + tw) * half_scale;
-        const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
-        v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
-        if (MODE == MODE_ADMM) {
-          uk = v2f{uu[j].x, uu[j].y};
-          um = v2f{uu[j].z, uu[j].w};
-        }
-        const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
-        const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
-        ak = update_bin<UMODE, EVAL>(xk, pk, uk, mk, a, true, sd, so);
-        am = update_bin<UMODE, EVAL>(xm, pm, um, mq, a, true, sd, so);
-        st_stream(&a.P_out[fi * (H * 64) + j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
-        if (MODE == MODE_ADMM) st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
-      } else {
-        ak = pk * a.inv_scale;
-        am = pm * a.inv_scale;
-      }
-      if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
-        ak.y = 0.0f;
-        am.y = 0.0f;
-      }
-      const v2f e2i = add_conj(ak, am);
-      const v2f o2i = cmulc(sub_conj(ak, am), wk);
-      z[j] = add_i(e2i, o2i);
-      back[j] = conj_sub_i(e2i, o2i);
-    }
-    v2f zmid;
-    if (MODE != MODE_INIT) {
-      const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
-      const bool live0 = lane == 0;
-      const v2f am = update_bin<UMODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
-      if (live0) {
-        a.Pmid_out[fi] = pmid;
-        if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
-      }
-      zmid = am * v2f{2.0f, -2.0f};
-    } else {
-      zmid = pmid * v2f{2.0f * a.inv_scale, -2.0f * a.inv_scale};
-    }
-#pragma unroll
-    for (int m = H; m < R; ++m) {
-      const v2f got = shfl2(back[R - 1 - m], k.partner);
-      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
-      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
-    }
-    fft_inverse<R>(z, k, lds_tw1, tr);
+    v2f z[R];
+    semi_frame<R, MODE, EVAL>(a, fi, b, t, s.hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
     v2f* out = reinterpret_cast<v2f*>(s.frames + fi * (2 * M));
 #pragma unroll
     for (int u = 0; u < R; ++u) out[64u * u + ulane] = z[u] * lds_win[64 * u + lane];
@@ -1642,6 +1660,129 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
       a.partials[2 * w + 1] = o;
     }
   }
+}
+
+// ---- the same, with the overlap-add on the chip (any hop <= n_fft, n_fft 512 ... 2048) ---------------------------------
+// A wave walks a chunk of consecutive frames of one item (like k_fused) and adds every synthesis frame into a private
+// ring of n_fft samples in LDS, in frame order - the order of k_ola's gather, so the sums round identically.  After
+// frame t the hop samples [t hop, (t+1) hop) are final: they are divided by the envelope and stored, and their ring
+// slots cleared.  No frame round trip through HBM.  At a chunk boundary the first n_fft - hop samples of the later
+// chunk lack what the earlier chunk's last frames add: the later chunk stores its own partial sums undivided, the
+// earlier one leaves the rest of its ring in `xtail`, and k_hop_tails adds the two and divides (a few MB per
+// iteration).  x ping-pongs between two buffers, the spectral state is updated in place.
+struct HopArgs {
+  FastArgs f;              // x_in, x_out, P_out (in place), U_out, m_pairs, ..., nchunks, n_waves, L, T, pad_mode, partials
+  const float* env;        // (L) overlap-add envelope
+  float* xtail;            // (B, nchunks, n_fft - hop)
+  int hop, pad;
+};
+
+__host__ __device__ inline int hop_chunk_begin(int c, int T, int nchunks) { return (int)((long long)c * T / nchunks); }
+
+template <int R, int MODE, bool EVAL>
+__global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
+  using G = Geo<R>;
+  constexpr int M = G::M, N = G::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const FastArgs& a = s.f;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwib = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  float* ring = reinterpret_cast<float*>(lds_tw1 + (R - 1) * 64 + nwib * G::TR) + wib * N;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * nwib + wib);
+  double sd = 0.0, so = 0.0;
+  if (w < a.n_waves) {
+    const int b = w / a.nchunks, c = w - b * a.nchunks;
+    const int t0 = hop_chunk_begin(c, a.T, a.nchunks), t1 = hop_chunk_begin(c + 1, a.T, a.nchunks);
+    const int hop = s.hop, keep = N - hop;
+    const float* env = s.env;
+    float* xo = a.x_out + (long long)b * a.L;
+#pragma unroll
+    for (int u = 0; u < R; ++u) reinterpret_cast<v2f*>(ring)[64 * u + lane] = v2f{0.0f, 0.0f};
+    // padded-signal position p <-> ring slot p mod N; samples below `raw_end` of a later chunk stay undivided
+    const long long raw_end = c > 0 ? (long long)t0 * hop + keep : -1;
+    int slot0 = (int)(((long long)t0 * hop) % N);          // ring slot of the frame's first sample
+    for (int t = t0; t < t1; ++t) {
+      const long long fi = (long long)b * a.T + t;
+      v2f z[R];
+      semi_frame<R, MODE, EVAL>(a, fi, b, t, hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
+      if ((slot0 & 1) == 0) {                              // register pairs stay aligned in the ring
+        v2f* r2 = reinterpret_cast<v2f*>(ring);
+        const int h0 = slot0 >> 1;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          int i = h0 + 64 * u + lane;
+          if (i >= M) i -= M;
+          r2[i] = r2[i] + z[u] * lds_win[64 * u + lane];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const v2f v = z[u] * lds_win[64 * u + lane];
+          int i = slot0 + 128 * u + 2 * lane;
+          if (i >= N) i -= N;
+          const int i1 = i + 1 == N ? 0 : i + 1;
+          ring[i] += v.x;
+          ring[i1] += v.y;
+        }
+      }
+      // the hop samples no later frame reaches
+      const long long p0 = (long long)t * hop;
+      for (int j = lane; j < hop; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        const float v = ring[i];
+        ring[i] = 0.0f;
+        const long long p = p0 + j, n = p - s.pad;
+        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? v : v / env[n];
+      }
+      slot0 += hop;
+      if (slot0 >= N) slot0 -= N;
+    }
+    // what is left in the ring: the end of the signal (last chunk), or the share of the next chunk's first samples
+    const long long p0 = (long long)t1 * hop;
+    if (c == a.nchunks - 1) {
+      for (int j = lane; j < keep; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        const long long p = p0 + j, n = p - s.pad;
+        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? ring[i] : ring[i] / env[n];
+      }
+    } else {
+      float* tl = s.xtail + ((long long)b * a.nchunks + c) * keep;
+      for (int j = lane; j < keep; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        tl[j] = ring[i];
+      }
+    }
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0 && w < a.n_waves) {
+      a.partials[2 * w] = d;
+      a.partials[2 * w + 1] = o;
+    }
+  }
+}
+
+// x[n] = (own partial sum + the previous chunk's tail) / envelope over the first n_fft - hop samples of chunks 1..
+__global__ void k_hop_tails(float* __restrict__ x, const float* __restrict__ xtail, const float* __restrict__ env, int T,
+                            int nchunks, int hop, int keep, int pad, long long L, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
+  if (i >= total) return;
+  const int j = (int)(i % keep);
+  const int c = (int)((i / keep) % (nchunks - 1)) + 1;
+  const long long b = i / ((long long)keep * (nchunks - 1));
+  const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+  if (n < 0 || n >= L) return;
+  float* px = x + b * L + n;
+  *px = (*px + xtail[(b * nchunks + (c - 1)) * keep + j]) / env[n];
 }
 
 // x += the tail partial sums (final waveform for get_wave)
@@ -1746,6 +1887,7 @@ template <typename T>
 struct FastState {
   bool supported = false;
   bool semi = false;
+  bool hopk = false;
   bool xform_ok = false;
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
@@ -1775,7 +1917,8 @@ struct FastState<float> {
   using v2f = fast::v2f;
   using v4f = fast::v4f;
   bool supported = false;
-  bool semi = false;   // k_semi + k_ola instead of k_fused (hop != n_fft/4 or centre = False)
+  bool semi = false;   // frame kernels instead of k_fused (hop != n_fft/2, /4, /8, centre = False, small problems)
+  bool hopk = false;   // ... k_hop (overlap-add in LDS, chunks of frames) rather than k_semi + k_ola
   int semi_grid = 0;
   int R = 0;
   int OV = 0;          // n_fft / hop of the fused kernel (2, 4 or 8)
@@ -1820,6 +1963,7 @@ struct FastState<float> {
         if (e[0] == '1') return SPECINV_OK;
       }
       semi = true;
+      hopk = false;
       OV = 0;
       chunk = cfg.n_frames;
       nchunks = 1;
@@ -1827,6 +1971,38 @@ struct FastState<float> {
       semi_grid = (int)std::min<long long>((nf + 3) / 4, 256 * 8);
       n_waves = semi_grid * 4;
       supported = true;
+      // Large enough problems keep the overlap-add on the chip (k_hop): a wave per chunk of frames, 8-wave workgroups,
+      // one per CU (2048 wave slots).  A chunk must emit the n_fft - hop samples it shares with its predecessor with
+      // its regular frames: at least (n_fft - 1) / hop + 1 frames.  n_fft 4096 does not fit (ring + scratch in LDS).
+      bool want_hop = R <= 16 && !small && cfg.hop_length >= 1 && cfg.hop_length <= cfg.n_fft && pad < length;
+      if (const char* e = getenv("SPECINV_DISABLE_HOP")) {
+        if (e[0] == '1') want_hop = false;
+      }
+      if (want_hop) {
+        const int floor_ch = std::max(8, (cfg.n_fft - 1) / cfg.hop_length + 1);
+        const long long slots = 2048;
+        int best_nch = 1;
+        double best_cost = 1e300;
+        for (int nch = 1; nch <= std::max(1, cfg.n_frames / floor_ch); ++nch) {
+          const long long waves = (long long)cfg.batch * nch;
+          const long long rounds = (waves + slots - 1) / slots;
+          const int longest = (cfg.n_frames + nch - 1) / nch;
+          const double cost = (double)rounds * (longest + 2.0) * (1.0 + 0.0015 * std::max(0, longest - 32));
+          if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && nch > best_nch)) {
+            best_cost = cost;
+            best_nch = nch;
+          }
+        }
+        if (const char* e = getenv("SPECINV_FAST_CHUNK")) {
+          const int v = atoi(e);
+          if (v >= 1) best_nch = std::max(1, cfg.n_frames / std::min(std::max(v, floor_ch), cfg.n_frames));
+        }
+        hopk = true;
+        nchunks = best_nch;
+        chunk = (cfg.n_frames + nchunks - 1) / nchunks;
+        n_waves = cfg.batch * nchunks;
+        if (getenv("SPECINV_DEBUG")) fprintf(stderr, "specinv: frame kernel with LDS overlap-add R=%d hop=%d chunks=%d of <=%d frames, %d waves\n", R, cfg.hop_length, nchunks, chunk, n_waves);
+      }
       return SPECINV_OK;
     }
     // Frames per wave.  A launch takes about rounds x (longest chunk) frame times, rounds = ceil(waves / wave slots):
@@ -1871,7 +2047,8 @@ struct FastState<float> {
     const long long nf = (long long)pl.B() * pl.Tn();
     const size_t pbytes = (size_t)nf * G::H * 64 * sizeof(v4f);
     const size_t tail_bytes = (size_t)pl.B() * nchunks * (OV > 0 ? OV - 1 : 0) * hop * sizeof(float);
-    for (int i = 0; i < (semi ? 1 : 2); ++i) {     // x (and the chunk tails) ping-pong between iterations
+    if (hopk) SI_TRY(xtail[0].reserve((size_t)pl.B() * nchunks * (pl.N() - hop) * sizeof(float) + 16));
+    for (int i = 0; i < ((semi && !hopk) ? 1 : 2); ++i) {     // x (and the chunk tails) ping-pong between iterations
       if (!semi) SI_TRY(xtail[i].reserve(tail_bytes));
       SI_TRY(xb[i].reserve((size_t)pl.B() * pl.length * sizeof(float)));
       if (i == 1 && state_in_place) continue;      // the spectral state is updated in place
@@ -1882,7 +2059,7 @@ struct FastState<float> {
         SI_TRY(Umid[i].reserve(nf * sizeof(v2f)));
       }
     }
-    if (semi) SI_TRY(pl.frames_needed());
+    if (semi && !hopk) SI_TRY(pl.frames_needed());
     SI_TRY(mpairs.reserve((size_t)nf * (G::H / 2) * 64 * sizeof(v4f)));
     SI_TRY(mmid.reserve(nf * sizeof(float)));
     SI_TRY(inv_env.reserve(pl.length * sizeof(float)));
@@ -1908,7 +2085,10 @@ struct FastState<float> {
     }
     if (semi) {
       // x0 = ISTFT(start spectrum): synthesis frames from the pair layout, then the gather overlap-add
-      SI_TRY((launch_semi<RR, fast::MODE_INIT, false>(pl)));
+      if constexpr (RR <= 16) {
+        if (hopk) SI_TRY((launch_hop<RR, fast::MODE_INIT, false>(pl)));
+      }
+      if (!hopk) SI_TRY((launch_semi<RR, fast::MODE_INIT, false>(pl)));
       SI_HIP(hipStreamSynchronize(pl.stream));   // *sum_m2_out is valid from here on
       return SPECINV_OK;
     }
@@ -2045,12 +2225,66 @@ struct FastState<float> {
     return pl.launch_ola(pl.frames.template as<float>(), xb[0].template as<float>(), true);
   }
 
+  // one iteration (or the initial ISTFT) of k_hop: reads x from xb[cur], writes xb[cur ^ 1], then mends the chunk seams
+  template <int RR, int MODE, bool EVAL, typename P>
+  int launch_hop(P& pl) {
+    using G = fast::Geo<RR>;
+    const int wgw = 8, hop = pl.cfg.hop_length, keep = pl.N() - hop;
+    const int nx = MODE == fast::MODE_INIT ? 0 : (cur ^ 1);
+    fast::HopArgs s{};
+    fast::FastArgs& a = s.f;
+    a.x_in = xb[cur].template as<float>();
+    a.x_out = xb[nx].template as<float>();
+    a.P_out = Pb[0].template as<v4f>();
+    a.Pmid_out = Pmid[0].template as<v2f>();
+    a.U_out = Ub[0].template as<v4f>();
+    a.Umid_out = Umid[0].template as<v2f>();
+    a.m_pairs = mpairs.template as<v4f>();
+    a.m_mid = mmid.template as<float>();
+    a.window = pl.window.template as<float>();
+    a.partials = pl.partials.template as<double>();
+    a.T = pl.Tn();
+    a.nchunks = nchunks;
+    a.n_waves = n_waves;
+    a.pad_mode = pl.cfg.pad_mode;
+    a.L = pl.length;
+    a.coef = pl.coef;
+    a.inv1p = 1.0f / (float)(1.0 + (double)pl.coef);
+    a.fwd_scale = pl.fc.fwd_scale;
+    a.inv_scale = pl.fc.inv_scale;
+    s.env = pl.env.template as<float>();
+    s.xtail = xtail[0].template as<float>();
+    s.hop = hop;
+    s.pad = pl.pad;
+    const size_t lds = G::lds_bytes(wgw) + (size_t)wgw * G::N * sizeof(float);
+    const void* fn = (const void*)fast::k_hop<RR, MODE, EVAL>;
+    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* kargs[] = {&s};
+    SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds, pl.stream));
+    if (nchunks > 1 && keep > 0) {
+      const long long total = (long long)pl.B() * (nchunks - 1) * keep;
+      hipLaunchKernelGGL(fast::k_hop_tails, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, a.x_out,
+                         (const float*)s.xtail, s.env, pl.Tn(), nchunks, hop, keep, pl.pad, (long long)pl.length, total);
+      SI_HIP(hipGetLastError());
+    }
+    cur = nx;
+    return SPECINV_OK;
+  }
+
   template <typename P>
   int iterate_semi(P& pl, int n_iter, bool eval_last) {
     SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2, 3 * 1024) * sizeof(double)));
     for (int i = 0; i < n_iter; ++i) {
       const bool ev = eval_last && i == n_iter - 1;
       int rc = SPECINV_OK;
+      if (hopk) {
+        SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
+          if (mode == fast::MODE_GLA) rc = ev ? launch_hop<RR, fast::MODE_GLA, true>(pl) : launch_hop<RR, fast::MODE_GLA, false>(pl);
+          else rc = ev ? launch_hop<RR, fast::MODE_ADMM, true>(pl) : launch_hop<RR, fast::MODE_ADMM, false>(pl);
+        });
+        SI_TRY(rc);
+        continue;
+      }
       SPECINV_R_SWITCH(R, if (mode == fast::MODE_GLA) rc = ev ? launch_semi<RR, fast::MODE_GLA, true>(pl)
                                                                : launch_semi<RR, fast::MODE_GLA, false>(pl);
                        else rc = ev ? launch_semi<RR, fast::MODE_ADMM, true>(pl) : launch_semi<RR, fast::MODE_ADMM, false>(pl));
@@ -2110,7 +2344,7 @@ struct FastState<float> {
   template <typename P>
   int get_wave(P& pl, float* out) {
     SI_HIP(hipMemcpyAsync(out, xb[cur].p, (size_t)pl.B() * pl.length * sizeof(float), hipMemcpyDeviceToDevice, pl.stream));
-    if (nchunks > 1) {
+    if (!semi && nchunks > 1) {
       const int hop = pl.cfg.hop_length;
       const long long total = (long long)pl.B() * nchunks * (OV - 1) * hop;
       const void* fn = nullptr;

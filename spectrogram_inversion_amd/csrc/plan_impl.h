@@ -182,7 +182,7 @@ struct PlanT final : PlanBase {
   }
 
   bool fast_path() const override { return fast.supported && !force_generic; }
-  int path_kind() const override { return fast_path() ? (fast.semi ? 2 : 1) : 0; }
+  int path_kind() const override { return fast_path() ? (fast.semi ? (fast.hopk ? 3 : 2) : 1) : 0; }
 
   // ------------------------------------------------------------------------------------
   // layout helpers: user (B, F, T) <-> internal (B, T, F)

@@ -144,7 +144,13 @@ class Plan:
     @property
     def path(self) -> str:
         """"fused" (one launch per iteration), "frame" (wave-level frame kernel + overlap-add) or "generic"."""
-        return ("generic", "fused", "frame")[self.lib.specinv_plan_fast_path(self._h)]
+        return ("generic", "fused", "frame", "frame")[self.lib.specinv_plan_fast_path(self._h)]
+
+    @property
+    def path_code(self) -> int:
+        """`specinv_plan_fast_path`: 0 generic, 1 fused, 2 frame kernel + gather overlap-add, 3 frame kernel over chunks
+        of frames with the overlap-add in LDS."""
+        return self.lib.specinv_plan_fast_path(self._h)
 
     def force_generic(self, on=True):
         _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))
