@@ -87,7 +87,7 @@ int specinv_plan_set_stream(specinv_plan* plan, void* hip_stream);
  * uses: 1 = fused (one launch per iteration: wave-level FFT, register overlap-add; float32, one-sided, centred,
  * n_fft 512 / 1024 / 2048 / 4096, hop = n_fft/2, /4 or /8, >= n_fft/hop + 2 frames), 2 = the same wave-level frame
  * kernel + gather overlap-add (those n_fft, any hop / centring), 3 = that frame kernel walking chunks of frames with
- * the overlap-add in LDS (n_fft <= 2048, hop <= n_fft, >= 6144 frames in the batch), 0 = generic LDS Stockham kernels
+ * the overlap-add in LDS (n_fft <= 2048, hop <= n_fft, >= 16384 frames in the batch at n_fft 2048, >= 32768 below), 0 = generic LDS Stockham kernels
  * (everything else). */
 int specinv_plan_n_freq(const specinv_plan* plan);
 int64_t specinv_plan_length(const specinv_plan* plan);

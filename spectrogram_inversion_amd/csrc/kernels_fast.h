@@ -1665,14 +1665,14 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
 // ---- the same, with the overlap-add on the chip (any hop <= n_fft, n_fft 512 ... 2048) ---------------------------------
 // A wave walks a chunk of consecutive frames of one item (like k_fused) and adds every synthesis frame into a private
 // ring of n_fft samples in LDS, in frame order - the order of k_ola's gather, so the sums round identically.  After
-// frame t the hop samples [t hop, (t+1) hop) are final: they are divided by the envelope and stored, and their ring
+// frame t the hop samples [t hop, (t+1) hop) are final: they are multiplied by the envelope's reciprocal and stored, and their ring
 // slots cleared.  No frame round trip through HBM.  At a chunk boundary the first n_fft - hop samples of the later
 // chunk lack what the earlier chunk's last frames add: the later chunk stores its own partial sums undivided, the
 // earlier one leaves the rest of its ring in `xtail`, and k_hop_tails adds the two and divides (a few MB per
 // iteration).  x ping-pongs between two buffers, the spectral state is updated in place.
 struct HopArgs {
   FastArgs f;              // x_in, x_out, P_out (in place), U_out, m_pairs, ..., nchunks, n_waves, L, T, pad_mode, partials
-  const float* env;        // (L) overlap-add envelope
+  const float* env;        // (L) reciprocal of the overlap-add envelope
   float* xtail;            // (B, nchunks, n_fft - hop)
   int hop, pad;
 };
@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
         const float v = ring[i];
         ring[i] = 0.0f;
         const long long p = p0 + j, n = p - s.pad;
-        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? v : v / env[n];
+        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? v : v * env[n];
       }
       slot0 += hop;
       if (slot0 >= N) slot0 -= N;
@@ -1751,7 +1751,7 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
         int i = slot0 + j;
         if (i >= N) i -= N;
         const long long p = p0 + j, n = p - s.pad;
-        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? ring[i] : ring[i] / env[n];
+        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? ring[i] : ring[i] * env[n];
       }
     } else {
       float* tl = s.xtail + ((long long)b * a.nchunks + c) * keep;
@@ -1771,7 +1771,7 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
   }
 }
 
-// x[n] = (own partial sum + the previous chunk's tail) / envelope over the first n_fft - hop samples of chunks 1..
+// x[n] = (own partial sum + the previous chunk's tail) * (1 / envelope) over the first n_fft - hop samples of chunks 1..
 __global__ void k_hop_tails(float* __restrict__ x, const float* __restrict__ xtail, const float* __restrict__ env, int T,
                             int nchunks, int hop, int keep, int pad, long long L, long long total) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
@@ -1782,7 +1782,7 @@ __global__ void k_hop_tails(float* __restrict__ x, const float* __restrict__ xta
   const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
   if (n < 0 || n >= L) return;
   float* px = x + b * L + n;
-  *px = (*px + xtail[(b * nchunks + (c - 1)) * keep + j]) / env[n];
+  *px = (*px + xtail[(b * nchunks + (c - 1)) * keep + j]) * env[n];
 }
 
 // x += the tail partial sums (final waveform for get_wave)
@@ -1974,7 +1974,12 @@ struct FastState<float> {
       // Large enough problems keep the overlap-add on the chip (k_hop): a wave per chunk of frames, 8-wave workgroups,
       // one per CU (2048 wave slots).  A chunk must emit the n_fft - hop samples it shares with its predecessor with
       // its regular frames: at least (n_fft - 1) / hop + 1 frames.  n_fft 4096 does not fit (ring + scratch in LDS).
-      bool want_hop = R <= 16 && !small && cfg.hop_length >= 1 && cfg.hop_length <= cfg.n_fft && pad < length;
+      // (a wave walks >= 8 frames one after the other there: measured against k_semi + k_ola, it pays from ~16 k frames
+      // at n_fft 2048 - 0.126 vs 0.142 ms per iteration - and ~32 k frames at 1024 and 512)
+      long long hop_from = R >= 16 ? 16384 : 32768;
+      if (const char* e = getenv("SPECINV_SMALL_FRAMES")) hop_from = atoll(e);          // (tests: 0 pins the chunked kernels)
+      bool want_hop = R <= 16 && (long long)cfg.batch * cfg.n_frames >= hop_from && !small && cfg.hop_length >= 1 &&
+                      cfg.hop_length <= cfg.n_fft && pad < length;
       if (const char* e = getenv("SPECINV_DISABLE_HOP")) {
         if (e[0] == '1') want_hop = false;
       }
@@ -2083,8 +2088,13 @@ struct FastState<float> {
       SI_HIP(hipMemsetAsync(Ub[0].p, 0, pbytes, pl.stream));
       SI_HIP(hipMemsetAsync(Umid[0].p, 0, nf * sizeof(v2f), pl.stream));
     }
+    if (hopk) {
+      hipLaunchKernelGGL(fast::k_reciprocal, dim3((unsigned)ceil_div(pl.length, 256)), dim3(256), 0, pl.stream,
+                         pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length);
+      SI_HIP(hipGetLastError());
+    }
     if (semi) {
-      // x0 = ISTFT(start spectrum): synthesis frames from the pair layout, then the gather overlap-add
+      // x0 = ISTFT(start spectrum): synthesis frames from the pair layout, then the overlap-add
       if constexpr (RR <= 16) {
         if (hopk) SI_TRY((launch_hop<RR, fast::MODE_INIT, false>(pl)));
       }
@@ -2252,7 +2262,7 @@ struct FastState<float> {
     a.inv1p = 1.0f / (float)(1.0 + (double)pl.coef);
     a.fwd_scale = pl.fc.fwd_scale;
     a.inv_scale = pl.fc.inv_scale;
-    s.env = pl.env.template as<float>();
+    s.env = inv_env.template as<float>();
     s.xtail = xtail[0].template as<float>();
     s.hop = hop;
     s.pad = pl.pad;

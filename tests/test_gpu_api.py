@@ -147,6 +147,15 @@ def test_small_problems_take_the_frame_kernel():
     assert Plan(args_helper(probe, hop_length=256, window=w), 1, 512, torch.float32, dev).path == "frame"     # BASELINE C1
     assert Plan(args_helper(probe, hop_length=256, window=w), 16, 256, torch.float32, dev).path == "frame"
     assert Plan(args_helper(probe, hop_length=256, window=w), 16, 512, torch.float32, dev).path == "fused"
+    # hops the fused kernel does not take: gather overlap-add for medium problems (path code 2), chunks of frames with
+    # the overlap-add in LDS from ~16 k frames at n_fft 2048 / ~32 k below (code 3); n_fft 4096 stays on code 2
+    assert Plan(args_helper(probe, hop_length=200, window=w), 16, 1024, torch.float32, dev).path_code == 2
+    assert Plan(args_helper(probe, hop_length=200, window=w), 32, 1024, torch.float32, dev).path_code == 3
+    w2, p2 = torch.from_numpy(hann(2048)), torch.empty(1, 1025, 1)
+    assert Plan(args_helper(p2, hop_length=441, window=w2), 8, 1024, torch.float32, dev).path_code == 2
+    assert Plan(args_helper(p2, hop_length=441, window=w2), 16, 1024, torch.float32, dev).path_code == 3
+    w4, p4 = torch.from_numpy(hann(4096)), torch.empty(1, 2049, 1)
+    assert Plan(args_helper(p4, hop_length=1000, window=w4), 64, 512, torch.float32, dev).path_code == 2
     rng = np.random.default_rng(3)
     mag = rng.random((1, 513, 512), dtype=np.float32)
     ref = oracle.griffin_lim(mag, max_iter=5, alpha=0.0, tol=0, hop_length=256, window=hann(1024))
