@@ -1771,6 +1771,140 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
   }
 }
 
+// ---- adjoint of the STFT without the frame round trip: inverse frames + plain overlap-add over the padded signal --------
+// k_fast_inverse_frames' body in k_hop's chunk / ring structure (no envelope): samples inside the signal go to `out`
+// (B, len), the `pad` samples on either side of it to `margins` (B, 2, pad) for the fold of the padding, chunk seams
+// through `xtail` + k_hop_tails_raw.
+struct HopInvArgs {
+  const v2f* spec;         // (B*T, F) frame-major, natural bin order
+  float* out;              // (B, len)
+  float* margins;          // (B, 2, pad)
+  float* xtail;            // (B, nchunks, n_fft - hop)
+  const float* window;
+  long long len;
+  int T, nchunks, n_waves, hop, pad;
+  float scale;
+};
+
+template <int R>
+__global__ __launch_bounds__(512, 1) void k_hop_inverse(HopInvArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, M = G::M, N = G::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwib = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  float* ring = reinterpret_cast<float*>(lds_tw1 + (R - 1) * 64 + nwib * G::TR) + wib * N;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * nwib + wib);
+  if (w >= a.n_waves) return;
+  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  const int t0 = hop_chunk_begin(c, a.T, a.nchunks), t1 = hop_chunk_begin(c + 1, a.T, a.nchunks);
+  const int hop = a.hop, keep = N - hop;
+  float* xo = a.out + (long long)b * a.len;
+  float* mg = a.margins + (long long)b * 2 * a.pad;
+  auto emit = [&](long long p, float v) {
+    const long long n = p - a.pad;
+    if (n >= 0 && n < a.len) xo[n] = v;
+    else if (n < 0) mg[p] = v;
+    else if (n - a.len < a.pad) mg[a.pad + (n - a.len)] = v;
+  };
+#pragma unroll
+  for (int u = 0; u < R; ++u) reinterpret_cast<v2f*>(ring)[64 * u + lane] = v2f{0.0f, 0.0f};
+  int slot0 = (int)(((long long)t0 * hop) % N);
+  for (int t = t0; t < t1; ++t) {
+    const long long fi = (long long)b * a.T + t;
+    const v2f* in = a.spec + fi * (M + 1);
+    v2f z[R], back[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const int kk = lane + 64 * j;
+      v2f ak = in[kk] * a.scale, am = in[M - kk] * a.scale;
+      if (j == 0 && lane == 0) {
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    v2f zmid = v2f{0.0f, 0.0f};
+    if (lane == 0) zmid = in[M / 2] * v2f{2.0f * a.scale, -2.0f * a.scale};
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+    fft_inverse<R>(z, k, lds_tw1, tr);
+    if ((slot0 & 1) == 0) {
+      v2f* r2 = reinterpret_cast<v2f*>(ring);
+      const int h0 = slot0 >> 1;
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        int i = h0 + 64 * u + lane;
+        if (i >= M) i -= M;
+        r2[i] = r2[i] + z[u] * lds_win[64 * u + lane];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const v2f v = z[u] * lds_win[64 * u + lane];
+        int i = slot0 + 128 * u + 2 * lane;
+        if (i >= N) i -= N;
+        const int i1 = i + 1 == N ? 0 : i + 1;
+        ring[i] += v.x;
+        ring[i1] += v.y;
+      }
+    }
+    const long long p0 = (long long)t * hop;
+    for (int j = lane; j < hop; j += 64) {
+      int i = slot0 + j;
+      if (i >= N) i -= N;
+      const float v = ring[i];
+      ring[i] = 0.0f;
+      emit(p0 + j, v);
+    }
+    slot0 += hop;
+    if (slot0 >= N) slot0 -= N;
+  }
+  const long long p0 = (long long)t1 * hop;
+  if (c == a.nchunks - 1) {
+    for (int j = lane; j < keep; j += 64) {
+      int i = slot0 + j;
+      if (i >= N) i -= N;
+      emit(p0 + j, ring[i]);
+    }
+  } else {
+    float* tl = a.xtail + ((long long)b * a.nchunks + c) * keep;
+    for (int j = lane; j < keep; j += 64) {
+      int i = slot0 + j;
+      if (i >= N) i -= N;
+      tl[j] = ring[i];
+    }
+  }
+}
+
+// out[n] += the previous chunk's tail over the first n_fft - hop samples of chunks 1.. (all inside the signal: a chunk
+// is at least (n_fft - 1) / hop + 1 frames long)
+__global__ void k_hop_tails_raw(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, int hop, int keep,
+                                int pad, long long L, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
+  if (i >= total) return;
+  const int j = (int)(i % keep);
+  const int c = (int)((i / keep) % (nchunks - 1)) + 1;
+  const long long b = i / ((long long)keep * (nchunks - 1));
+  const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+  if (n < 0 || n >= L) return;
+  x[b * L + n] += xtail[(b * nchunks + (c - 1)) * keep + j];
+}
+
 // x[n] = (own partial sum + the previous chunk's tail) * (1 / envelope) over the first n_fft - hop samples of chunks 1..
 __global__ void k_hop_tails(float* __restrict__ x, const float* __restrict__ xtail, const float* __restrict__ env, int T,
                             int nchunks, int hop, int keep, int pad, long long L, long long total) {
@@ -1893,6 +2027,11 @@ struct FastState {
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
   template <typename P>
   int launch_xform(P&, bool, const T*, long long, void*, T*, T, int = -1) { return fail(SPECINV_EUNSUPPORTED, "no fused path"); }
+  template <typename P>
+  int launch_inverse_ola(P&, const void*, T*, long long, T, T**, bool* used) {
+    *used = false;
+    return SPECINV_OK;
+  }
   template <typename P>
   int begin(P&, int, const void*, const void*, double*) { return fail(SPECINV_EUNSUPPORTED, "no fused path for this dtype"); }
   template <typename P>
@@ -2172,6 +2311,62 @@ struct FastState<float> {
     SI_HIP(hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, lds, pl.stream));
     return SPECINV_OK;
   }
+
+  // Adjoint of the analysis (gradient frames -> overlap-add over the padded signal) in one launch for big batches of
+  // frames; `*used` stays false when the shape is not covered (the caller then runs inverse frames + gather).
+  // `margins` receives the pad samples on either side of the signal.
+  template <typename P>
+  int launch_inverse_ola(P& pl, const fast::v2f* spec, float* out, long long len, float scale, float** margins, bool* used) {
+    *used = false;
+    if (!xform_ok || xform_R > 16 || pl.force_generic) return SPECINV_OK;
+    const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), B = pl.B();
+    long long from = xform_R >= 16 ? 16384 : 32768;
+    if (const char* e = getenv("SPECINV_SMALL_FRAMES")) from = atoll(e);
+    if (const char* e = getenv("SPECINV_DISABLE_HOP")) {
+      if (e[0] == '1') return SPECINV_OK;
+    }
+    if ((long long)B * T < from || hop < 1 || hop > N || pl.pad >= len) return SPECINV_OK;
+    // the kernel writes every sample of `out` only if the frames cover the padded signal exactly
+    if ((long long)(T - 1) * hop + N != len + 2LL * pl.pad) return SPECINV_OK;
+    const int floor_ch = std::max(8, (N - 1) / hop + 1);
+    const int nch = (int)std::max(1LL, std::min<long long>(T / floor_ch, std::max(1, 2048 / B)));
+    const int wgw = 8, keep = N - hop, n_w = B * nch;
+    SI_TRY(hop_inv_tail.reserve((size_t)B * nch * keep * sizeof(float) + 16));
+    SI_TRY(hop_inv_margins.reserve((size_t)B * 2 * std::max(1, pl.pad) * sizeof(float)));
+    fast::HopInvArgs a{};
+    a.spec = spec;
+    a.out = out;
+    a.margins = hop_inv_margins.template as<float>();
+    a.xtail = hop_inv_tail.template as<float>();
+    a.window = pl.window.template as<float>();
+    a.len = len;
+    a.T = T;
+    a.nchunks = nch;
+    a.n_waves = n_w;
+    a.hop = hop;
+    a.pad = pl.pad;
+    a.scale = scale;
+    size_t lds = 0;
+    const void* fn = nullptr;
+    SPECINV_R_SWITCH(xform_R, if constexpr (RR <= 16) {
+      lds = fast::Geo<RR>::lds_bytes(wgw) + (size_t)wgw * fast::Geo<RR>::N * sizeof(float);
+      fn = (const void*)fast::k_hop_inverse<RR>;
+    });
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no k_hop_inverse instantiation");
+    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* kargs[] = {&a};
+    SI_HIP(hipLaunchKernel(fn, dim3((n_w + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds, pl.stream));
+    if (nch > 1 && keep > 0) {
+      const long long total = (long long)B * (nch - 1) * keep;
+      hipLaunchKernelGGL(fast::k_hop_tails_raw, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, out,
+                         (const float*)a.xtail, T, nch, hop, keep, pl.pad, len, total);
+      SI_HIP(hipGetLastError());
+    }
+    *margins = a.margins;
+    *used = true;
+    return SPECINV_OK;
+  }
+  FastBuf hop_inv_tail, hop_inv_margins;
 
   template <int RR, int MODE, bool EVAL, typename P>
   int launch(P& pl, const fast::FastArgs& a) {

@@ -679,10 +679,12 @@ __global__ void k_grad_frames(FrameCfg<T> c, const cplx<T>* __restrict__ g, T* _
 
 // Fold of the padded margins onto the signal: grad already holds the plain overlap-add of the gradient frames over
 // the signal's own positions (k_ola / k_ola_f4 without the envelope); every sample within `pad` of an edge also
-// receives what the padding copied from it (reflect / replicate / circular).  One thread per margin sample.
+// receives what the padding copied from it (reflect / replicate / circular).  One thread per margin sample.  The
+// gradient w.r.t. a padded sample is gathered from `frames`, or read from `margins` (B, 2, pad: the pad samples left and
+// right of the signal, written by k_hop_inverse) when that is given.
 template <typename T>
 __global__ void k_grad_fold_margins(const T* __restrict__ frames, T* __restrict__ grad, int n_fft, int hop, int pad,
-                                    int pad_mode, int n_frames, int64_t len, int64_t rows) {
+                                    int pad_mode, int n_frames, int64_t len, int64_t rows, const T* __restrict__ margins) {
   const int64_t per_row = 2 * ((int64_t)pad + 1);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * per_row) return;
@@ -699,6 +701,12 @@ __global__ void k_grad_fold_margins(const T* __restrict__ frames, T* __restrict_
   const int64_t covered = (int64_t)(n_frames - 1) * hop + n_fft;   // padded positions that receive any frame
   auto at = [&](int64_t np) -> T {                                 // gradient w.r.t. padded sample np
     if (np < 0 || np >= covered) return T(0);
+    if (margins != nullptr) {
+      const T* mg = margins + bi * 2 * pad;
+      if (np < pad) return mg[np];
+      const int64_t r = np - pad - len;
+      return (r >= 0 && r < pad) ? mg[pad + r] : T(0);
+    }
     int64_t t_hi = np / hop;
     if (t_hi > n_frames - 1) t_hi = n_frames - 1;
     const int64_t t_lo = np - n_fft + 1 <= 0 ? 0 : (np - n_fft + hop) / hop;
@@ -870,9 +878,7 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
                      pl.sums.template as<double>());
   SI_HIP(hipGetLastError());
   // frames of the gradient: irfft-style inverse with the forward scale
-  SI_TRY(pl.frames_needed());
-  SI_TRY(pl.inverse_frames(pl.tf_spec.template as<C>(), pl.frames.template as<T>(), pl.fc.fwd_scale, len));
-  SI_TRY(pl.launch_grad_fold(pl.frames.template as<T>(), grad, len));
+  SI_TRY(pl.grad_from_spec(pl.tf_spec.template as<C>(), grad, pl.fc.fwd_scale, len));
   double s;
   SI_HIP(hipMemcpyAsync(&s, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
   SI_HIP(si_stream_wait_short(pl.stream));

@@ -223,15 +223,31 @@ struct PlanT final : PlanBase {
 
   // gradient of a centre-padded analysis w.r.t. the signal: overlap-add over the signal's own positions plus the
   // fold of the padded margins (reflect / replicate / circular copies)
-  int launch_grad_fold(const T* fr, T* grad, int64_t len) {
-    SI_TRY(launch_ola(fr, grad, false, len));
+  int launch_grad_fold(const T* fr, T* grad, int64_t len, const T* margins = nullptr) {
+    if (margins == nullptr) SI_TRY(launch_ola(fr, grad, false, len));
     if (pad > 0 && cfg.pad_mode != SPECINV_PAD_CONSTANT) {
       const int64_t margin = (int64_t)B() * 2 * (pad + 1);
       hipLaunchKernelGGL((k_grad_fold_margins<T>), dim3((unsigned)ceil_div(margin, 256)), dim3(256), 0, stream, fr, grad,
-                         N(), cfg.hop_length, pad, cfg.pad_mode, Tn(), len, (int64_t)B());
+                         N(), cfg.hop_length, pad, cfg.pad_mode, Tn(), len, (int64_t)B(), margins);
       SI_HIP(hipGetLastError());
     }
     return SPECINV_OK;
+  }
+
+  // gradient w.r.t. the signal from the gradient w.r.t. its spectrogram (internal layout, Hermitian weights applied):
+  // inverse frames with `scale`, overlap-add over the padded signal, fold of the margins.  Big float32 batches on the
+  // wave-level FFT do all of it on the chip (k_hop_inverse), everything else goes through the frames buffer.
+  int grad_from_spec(const C* spec_btf, T* grad, T scale, int64_t len) {
+    if constexpr (std::is_same<T, float>::value) {
+      bool used = false;
+      float* margins = nullptr;
+      SI_TRY(fast.launch_inverse_ola(*this, reinterpret_cast<const fast::v2f*>(spec_btf), grad, (long long)len, scale, &margins,
+                                     &used));
+      if (used) return launch_grad_fold(nullptr, grad, len, margins);
+    }
+    SI_TRY(frames_needed());
+    SI_TRY(inverse_frames(spec_btf, frames.template as<T>(), scale, len));
+    return launch_grad_fold(frames.template as<T>(), grad, len);
   }
 
   // threads per frame workgroup of the generic kernels: one per butterfly of the widest stage (n_fft / smallest radix),
@@ -579,10 +595,7 @@ struct PlanT final : PlanBase {
                          n_freq, N(), ns);
       SI_HIP(hipGetLastError());
     }
-    SI_TRY(frames_needed());
-    SI_TRY(inverse_frames(tmp_spec.as<C>(), frames.as<T>(), fc.fwd_scale, len));
-    SI_TRY(launch_grad_fold(frames.as<T>(), static_cast<T*>(g_x_out), len));
-    return SPECINV_OK;
+    return grad_from_spec(tmp_spec.as<C>(), static_cast<T*>(g_x_out), fc.fwd_scale, len);
   }
 
   int phase_init_adjoint(const void* magp, const void* g_spec, void* gmag) override {
