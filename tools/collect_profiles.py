@@ -15,11 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 kernel = "specinv::fast::k_fused4<16, 0, false>"
 out = os.path.join(ROOT, "profiles")
-stats = glob.glob(os.path.join(ROOT, f"gpurun_out/{tag}_kt/*/*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(ROOT, f"gpurun_out/{tag}_kt/*/*kernel_stats.csv")), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
+    shutil.copy(stats[-1],   # (gpurun merges new files next to older runs' files: take the newest)
+                os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
 # steady-state duration of the dominant kernel: launches of the timed steps only (the warm-up step pays first-touch)
-trace = glob.glob(os.path.join(ROOT, f"gpurun_out/{tag}_kt/*/*kernel_trace.csv"))
+trace = sorted(glob.glob(os.path.join(ROOT, f"gpurun_out/{tag}_kt/*/*kernel_trace.csv")), key=os.path.getmtime)[-1:]
 steady = None
 if trace:
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(trace[0]))
@@ -29,7 +30,12 @@ if trace:
         steady = {"launches": len(tail), "mean_us": sum(tail) / len(tail), "min_us": min(tail), "max_us": max(tail),
                   "all_launches_mean_us": sum(d) / len(d)}
 counters = {}
-for f in sorted(glob.glob(os.path.join(ROOT, f"gpurun_out/{tag}_pmc_*/*/*counter_collection.csv"))):
+newest = {}
+for f in glob.glob(os.path.join(ROOT, f"gpurun_out/{tag}_pmc_*/*/*counter_collection.csv")):
+    d = os.path.dirname(f)
+    if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+        newest[d] = f
+for f in sorted(newest.values()):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if kernel in r["Kernel_Name"]:
