@@ -2124,7 +2124,9 @@ struct FastState<float> {
       }
       if (want_hop) {
         const int floor_ch = std::max(8, (cfg.n_fft - 1) / cfg.hop_length + 1);
-        const long long slots = 2048;
+        // wave slots: one 8-wave workgroup per CU at n_fft 2048 (LDS), two at 1024, three at 512 (registers allow it)
+        long long slots = R >= 16 ? 2048 : R == 8 ? 4096 : 6144;
+        if (const char* e = getenv("SPECINV_HOP_SLOTS")) slots = atoll(e);
         int best_nch = 1;
         double best_cost = 1e300;
         for (int nch = 1; nch <= std::max(1, cfg.n_frames / floor_ch); ++nch) {
