@@ -121,7 +121,7 @@ def test_large_batch_of_short_items(chunked_kernel):
 
 
 @pytest.mark.parametrize("n_fft,hop,frames", [(1024, 256, 120_000), (512, 128, 200_000), (2048, 256, 40_000),
-                                             (1024, 300, 50_000)])
+                                             (1024, 300, 50_000), (2048, 333, 30_000)])   # last two: chunked frame kernel
 def test_very_long_signal(n_fft, hop, frames):
     """One item of up to 200 000 frames (30 M samples; 32-bit offsets inside a row, 64-bit across) against the float64
     kernels: the beginning, the middle and the end of the waveform, the whole waveform and the spectral convergence."""
@@ -131,6 +131,7 @@ def test_very_long_signal(n_fft, hop, frames):
     p32 = Plan(args_helper(mag, hop_length=hop, window=w), 1, frames, torch.float32, DEV)
     p64 = Plan(args_helper(mag.double(), hop_length=hop, window=w.double()), 1, frames, torch.float64, DEV)
     assert p32.path in ("fused", "frame") and p64.path == "generic"
+    assert p32.path_code == (1 if n_fft % hop == 0 else 3)
     c0 = p64.phase_init(mag.double().to(DEV))
     p32.gla_init(c0.to(torch.complex64), None, 0.3)
     p64.gla_init(c0, None, 0.3)
