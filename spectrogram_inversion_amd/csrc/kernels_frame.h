@@ -1,0 +1,557 @@
+// Frame kernels on the wave-level FFT of kernels_fast.h (float32, one-sided, n_fft 512 ... 4096, ANY hop / centring /
+// pad mode): the stand-alone transforms (k_fast_stft, k_fast_inverse_frames), one iteration a frame at a time
+// (k_semi + the gather overlap-add of kernels_generic.h), the same over chunks of frames with the overlap-add in an LDS
+// ring (k_hop + k_hop_tails), and the adjoint of the analysis in that structure (k_hop_inverse + k_hop_tails_raw).
+// Included by kernels_fast.h after the FFT / update primitives; the host side is FastState<float> there.
+#pragma once
+
+namespace specinv {
+namespace fast {
+
+// ---- stand-alone transforms on the wave-level FFT (any hop; used by specinv_stft and the L_BFGS objective) ----
+// windowed frame starting at signal index `start` (may reach into the reflect padding) -> registers
+template <int R>
+__device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, long long len, long long start, int lane,
+                                                int pad_mode, const v2f* __restrict__ lds_win, v2f (&z)[R]) {
+  constexpr int N = Geo<R>::N;
+  if (start >= 0 && start + N <= len && (start & 1) == 0) {
+    const v2f* src = reinterpret_cast<const v2f*>(xrow + start);
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = src[64u * u + (unsigned)lane];
+  } else if (start >= 0 && start + N <= len) {   // inside the signal at an odd offset: two 4-byte loads per register
+    const float* src = xrow + start;
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = v2f{src[128u * u + 2u * (unsigned)lane], src[128u * u + 2u * (unsigned)lane + 1u]};
+  } else {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const long long n0 = pad_index(start + 128 * u + 2 * lane, len, pad_mode);
+      const long long n1 = pad_index(start + 128 * u + 2 * lane + 1, len, pad_mode);
+      z[u] = v2f{n0 < 0 ? 0.0f : xrow[n0], n1 < 0 ? 0.0f : xrow[n1]};
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+}
+
+struct FastXformArgs {
+  const float* x;        // (B, len)
+  v2f* spec;             // (B*T, F) frame-major, natural bin order
+  float* frames;         // (B*T, N)
+  const float* window;
+  long long len, n_frames_total;
+  int T, hop, pad, pad_mode;
+  float scale;
+};
+
+template <int R>
+__device__ __forceinline__ void xform_tables(const float* __restrict__ window, v2f* lds_win, v2f* lds_tw1) {
+  constexpr int M = Geo<R>::M;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{window[2 * i], window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
+  }
+  __syncthreads();
+}
+
+// torch.stft (center, reflect, onesided): one wave per frame, spectrum written in natural bin order
+// (register j of lane l is bin l + 64 j: every store instruction covers 64 consecutive bins)
+template <int R>
+__global__ __launch_bounds__(256) void k_fast_stft(FastXformArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, M = G::M;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  for (long long fi = (long long)blockIdx.x * 4 + wib; fi < a.n_frames_total; fi += (long long)gridDim.x * 4) {
+    const long long b = fi / a.T;
+    const int t = (int)(fi - b * a.T);
+    v2f z[R];
+    load_frame_regs<R>(a.x + b * a.len, a.len, (long long)t * a.hop - a.pad, lane, a.pad_mode, lds_win, z);
+    fft_forward<R>(z, k, lds_tw1, tr);
+    v2f rc[H];
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+    v2f* out = a.spec + fi * (M + 1);
+    const float hs = 0.5f * a.scale;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f zk = z[j], zm = rc[R - 1 - j - H];
+      const v2f e2 = add_conj(zk, zm);
+      const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
+      const int kk = lane + 64 * j;
+      out[kk] = (e2 + tw) * hs;
+      out[M - kk] = (e2 - tw) * v2f{hs, -hs};
+    }
+    if (lane == 0) out[M / 2] = z[H] * v2f{a.scale, -a.scale};
+  }
+}
+
+// frames[n] = window[n] * scale * Re sum_k Xfull[k] e^{+2 pi i k n / N} for the Hermitian extension Xfull of the
+// stored onesided spectrum (imaginary parts of DC / Nyquist ignored): the synthesis half of an ISTFT and the
+// adjoint of the STFT (L_BFGS gradient).  Natural bin order in, one wave per frame.
+template <int R>
+__global__ __launch_bounds__(256) void k_fast_inverse_frames(FastXformArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, M = G::M;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  for (long long fi = (long long)blockIdx.x * 4 + wib; fi < a.n_frames_total; fi += (long long)gridDim.x * 4) {
+    const v2f* in = a.spec + fi * (M + 1);
+    v2f z[R], back[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const int kk = lane + 64 * j;
+      v2f ak = in[kk] * a.scale, am = in[M - kk] * a.scale;
+      if (j == 0 && lane == 0) {
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    v2f zmid = v2f{0.0f, 0.0f};
+    if (lane == 0) zmid = in[M / 2] * v2f{2.0f * a.scale, -2.0f * a.scale};
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+    fft_inverse<R>(z, k, lds_tw1, tr);
+    v2f* out = reinterpret_cast<v2f*>(a.frames + fi * (2 * M));
+#pragma unroll
+    for (int u = 0; u < R; ++u) out[64u * u + (unsigned)lane] = z[u] * lds_win[64 * u + lane];
+  }
+}
+
+// ---- one iteration for any hop / centring (n_fft 1024 / 2048): frame kernel + gather overlap-add ---------------
+// Same wave-level FFT, pair-layout state and update as k_fused, but a wave takes whole frames one at a time (samples
+// straight from x, any hop, any pad mode) and writes the windowed synthesis frame to `frames`; k_ola then does the
+// overlap-add / envelope division.  Costs one frame round trip (8 N bytes per frame) more than k_fused; used when
+// hop != n_fft/4 or centre = False.  MODE_INIT synthesises the stored spectrum as it is (the initial ISTFT).
+constexpr int MODE_INIT = 2;
+struct SemiArgs {
+  FastArgs f;              // x_in, P_in (updated in place), U_in, m_pairs, ..., L, T, pad_mode, coef, scales, partials
+  float* frames;           // (B*T, N)
+  long long n_frames_total;
+  int hop, pad;
+};
+
+// One frame of the frame kernels: state in, (samples -> spectrum -> update) unless MODE_INIT, state out, inverse
+// transform.  On return z holds the synthesis frame before its window (register u <-> samples 128u + 2 lane, +1).
+template <int R, int MODE, bool EVAL>
+__device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long long b, int t, int hop, int pad,
+                                           const LaneConst<R>& k, const v2f* lds_win, const v2f* lds_tw1, v2f* tr,
+                                           v2f (&z)[R], double& sd, double& so) {
+  using G = Geo<R>;
+  constexpr int H = G::H;
+  constexpr int UMODE = MODE == MODE_INIT ? MODE_GLA : MODE;
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const float half_scale = 0.5f * a.fwd_scale;
+  v4f pp[H], uu[H], mm[H / 2];
+  v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
+  float mmid = 0.0f;
+  {
+    v4f* pin = a.P_out + fi * (H * 64);
+#pragma unroll
+    for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin[j * 64u + ulane]);
+    if (MODE == MODE_ADMM) {
+      v4f* uin = a.U_out + fi * (H * 64);
+#pragma unroll
+      for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin[j * 64u + ulane]);
+    }
+    if (MODE != MODE_INIT) {
+      const v4f* min = a.m_pairs + fi * (H / 2 * 64);
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min[j * 64u + ulane]);
+    }
+    if (lane == 0) {
+      pmid = a.Pmid_out[fi];
+      if (MODE != MODE_INIT) mmid = a.m_mid[fi];
+      if (MODE == MODE_ADMM) umid = a.Umid_out[fi];
+    }
+  }
+  v2f rc[H];
+  if (MODE != MODE_INIT) {
+    load_frame_regs<R>(a.x_in + b * a.L, a.L, (long long)t * hop - pad, lane, a.pad_mode, lds_win, z);
+    fft_forward<R>(z, k, lds_tw1, tr);
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+  }
+  v2f back[H];
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+    v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
+    v2f ak, am;
+    if (MODE != MODE_INIT) {
+      const v2f zk = z[j], zm = rc[R - 1 - j - H];
+      const v2f e2 = add_conj(zk, zm);
+      const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
+      const v2f xk = (e2 + tw) * half_scale;
+      const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
+      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
+      if (MODE == MODE_ADMM) {
+        uk = v2f{uu[j].x, uu[j].y};
+        um = v2f{uu[j].z, uu[j].w};
+      }
+      const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+      const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+      ak = update_bin<UMODE, EVAL>(xk, pk, uk, mk, a, true, sd, so);
+      am = update_bin<UMODE, EVAL>(xm, pm, um, mq, a, true, sd, so);
+      st_stream(&a.P_out[fi * (H * 64) + j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
+      if (MODE == MODE_ADMM) st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+    } else {
+      ak = pk * a.inv_scale;
+      am = pm * a.inv_scale;
+    }
+    if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+      ak.y = 0.0f;
+      am.y = 0.0f;
+    }
+    const v2f e2i = add_conj(ak, am);
+    const v2f o2i = cmulc(sub_conj(ak, am), wk);
+    z[j] = add_i(e2i, o2i);
+    back[j] = conj_sub_i(e2i, o2i);
+  }
+  v2f zmid;
+  if (MODE != MODE_INIT) {
+    const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
+    const bool live0 = lane == 0;
+    const v2f am = update_bin<UMODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
+    if (live0) {
+      a.Pmid_out[fi] = pmid;
+      if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
+    }
+    zmid = am * v2f{2.0f, -2.0f};
+  } else {
+    zmid = pmid * v2f{2.0f * a.inv_scale, -2.0f * a.inv_scale};
+  }
+#pragma unroll
+  for (int m = H; m < R; ++m) {
+    const v2f got = shfl2(back[R - 1 - m], k.partner);
+    const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+    z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+  }
+  fft_inverse<R>(z, k, lds_tw1, tr);
+}
+
+template <int R, int MODE, bool EVAL>
+__global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
+  using G = Geo<R>;
+  constexpr int M = G::M;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const FastArgs& a = s.f;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  double sd = 0.0, so = 0.0;
+  for (long long fi = (long long)blockIdx.x * 4 + wib; fi < s.n_frames_total; fi += (long long)gridDim.x * 4) {
+    const long long b = fi / a.T;
+    const int t = (int)(fi - b * a.T);
+    v2f z[R];
+    semi_frame<R, MODE, EVAL>(a, fi, b, t, s.hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
+    v2f* out = reinterpret_cast<v2f*>(s.frames + fi * (2 * M));
+#pragma unroll
+    for (int u = 0; u < R; ++u) out[64u * u + ulane] = z[u] * lds_win[64 * u + lane];
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0) {
+      const long long w = (long long)blockIdx.x * 4 + wib;
+      a.partials[2 * w] = d;
+      a.partials[2 * w + 1] = o;
+    }
+  }
+}
+
+// ---- the same, with the overlap-add on the chip (any hop <= n_fft, n_fft 512 ... 2048) ---------------------------------
+// A wave walks a chunk of consecutive frames of one item (like k_fused) and adds every synthesis frame into a private
+// ring of n_fft samples in LDS, in frame order - the order of k_ola's gather, so the sums round identically.  After
+// frame t the hop samples [t hop, (t+1) hop) are final: they are multiplied by the envelope's reciprocal and stored, and their ring
+// slots cleared.  No frame round trip through HBM.  At a chunk boundary the first n_fft - hop samples of the later
+// chunk lack what the earlier chunk's last frames add: the later chunk stores its own partial sums undivided, the
+// earlier one leaves the rest of its ring in `xtail`, and k_hop_tails adds the two and divides (a few MB per
+// iteration).  x ping-pongs between two buffers, the spectral state is updated in place.
+struct HopArgs {
+  FastArgs f;              // x_in, x_out, P_out (in place), U_out, m_pairs, ..., nchunks, n_waves, L, T, pad_mode, partials
+  const float* env;        // (L) reciprocal of the overlap-add envelope
+  float* xtail;            // (B, nchunks, n_fft - hop)
+  int hop, pad;
+};
+
+__host__ __device__ inline int hop_chunk_begin(int c, int T, int nchunks) { return (int)((long long)c * T / nchunks); }
+
+template <int R, int MODE, bool EVAL>
+__global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
+  using G = Geo<R>;
+  constexpr int M = G::M, N = G::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const FastArgs& a = s.f;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwib = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  float* ring = reinterpret_cast<float*>(lds_tw1 + (R - 1) * 64 + nwib * G::TR) + wib * N;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * nwib + wib);
+  double sd = 0.0, so = 0.0;
+  if (w < a.n_waves) {
+    const int b = w / a.nchunks, c = w - b * a.nchunks;
+    const int t0 = hop_chunk_begin(c, a.T, a.nchunks), t1 = hop_chunk_begin(c + 1, a.T, a.nchunks);
+    const int hop = s.hop, keep = N - hop;
+    const float* env = s.env;
+    float* xo = a.x_out + (long long)b * a.L;
+#pragma unroll
+    for (int u = 0; u < R; ++u) reinterpret_cast<v2f*>(ring)[64 * u + lane] = v2f{0.0f, 0.0f};
+    // padded-signal position p <-> ring slot p mod N; samples below `raw_end` of a later chunk stay undivided
+    const long long raw_end = c > 0 ? (long long)t0 * hop + keep : -1;
+    int slot0 = (int)(((long long)t0 * hop) % N);          // ring slot of the frame's first sample
+    for (int t = t0; t < t1; ++t) {
+      const long long fi = (long long)b * a.T + t;
+      v2f z[R];
+      semi_frame<R, MODE, EVAL>(a, fi, b, t, hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
+      if ((slot0 & 1) == 0) {                              // register pairs stay aligned in the ring
+        v2f* r2 = reinterpret_cast<v2f*>(ring);
+        const int h0 = slot0 >> 1;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          int i = h0 + 64 * u + lane;
+          if (i >= M) i -= M;
+          r2[i] = r2[i] + z[u] * lds_win[64 * u + lane];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const v2f v = z[u] * lds_win[64 * u + lane];
+          int i = slot0 + 128 * u + 2 * lane;
+          if (i >= N) i -= N;
+          const int i1 = i + 1 == N ? 0 : i + 1;
+          ring[i] += v.x;
+          ring[i1] += v.y;
+        }
+      }
+      // the hop samples no later frame reaches
+      const long long p0 = (long long)t * hop;
+      for (int j = lane; j < hop; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        const float v = ring[i];
+        ring[i] = 0.0f;
+        const long long p = p0 + j, n = p - s.pad;
+        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? v : v * env[n];
+      }
+      slot0 += hop;
+      if (slot0 >= N) slot0 -= N;
+    }
+    // what is left in the ring: the end of the signal (last chunk), or the share of the next chunk's first samples
+    const long long p0 = (long long)t1 * hop;
+    if (c == a.nchunks - 1) {
+      for (int j = lane; j < keep; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        const long long p = p0 + j, n = p - s.pad;
+        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? ring[i] : ring[i] * env[n];
+      }
+    } else {
+      float* tl = s.xtail + ((long long)b * a.nchunks + c) * keep;
+      for (int j = lane; j < keep; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        tl[j] = ring[i];
+      }
+    }
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0 && w < a.n_waves) {
+      a.partials[2 * w] = d;
+      a.partials[2 * w + 1] = o;
+    }
+  }
+}
+
+// ---- adjoint of the STFT without the frame round trip: inverse frames + plain overlap-add over the padded signal --------
+// k_fast_inverse_frames' body in k_hop's chunk / ring structure (no envelope): samples inside the signal go to `out`
+// (B, len), the `pad` samples on either side of it to `margins` (B, 2, pad) for the fold of the padding, chunk seams
+// through `xtail` + k_hop_tails_raw.
+struct HopInvArgs {
+  const v2f* spec;         // (B*T, F) frame-major, natural bin order
+  float* out;              // (B, len)
+  float* margins;          // (B, 2, pad)
+  float* xtail;            // (B, nchunks, n_fft - hop)
+  const float* window;
+  long long len;
+  int T, nchunks, n_waves, hop, pad;
+  float scale;
+};
+
+template <int R>
+__global__ __launch_bounds__(512, 1) void k_hop_inverse(HopInvArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, M = G::M, N = G::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwib = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  float* ring = reinterpret_cast<float*>(lds_tw1 + (R - 1) * 64 + nwib * G::TR) + wib * N;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * nwib + wib);
+  if (w >= a.n_waves) return;
+  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  const int t0 = hop_chunk_begin(c, a.T, a.nchunks), t1 = hop_chunk_begin(c + 1, a.T, a.nchunks);
+  const int hop = a.hop, keep = N - hop;
+  float* xo = a.out + (long long)b * a.len;
+  float* mg = a.margins + (long long)b * 2 * a.pad;
+  auto emit = [&](long long p, float v) {
+    const long long n = p - a.pad;
+    if (n >= 0 && n < a.len) xo[n] = v;
+    else if (n < 0) mg[p] = v;
+    else if (n - a.len < a.pad) mg[a.pad + (n - a.len)] = v;
+  };
+#pragma unroll
+  for (int u = 0; u < R; ++u) reinterpret_cast<v2f*>(ring)[64 * u + lane] = v2f{0.0f, 0.0f};
+  int slot0 = (int)(((long long)t0 * hop) % N);
+  for (int t = t0; t < t1; ++t) {
+    const long long fi = (long long)b * a.T + t;
+    const v2f* in = a.spec + fi * (M + 1);
+    v2f z[R], back[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const int kk = lane + 64 * j;
+      v2f ak = in[kk] * a.scale, am = in[M - kk] * a.scale;
+      if (j == 0 && lane == 0) {
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    v2f zmid = v2f{0.0f, 0.0f};
+    if (lane == 0) zmid = in[M / 2] * v2f{2.0f * a.scale, -2.0f * a.scale};
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+    fft_inverse<R>(z, k, lds_tw1, tr);
+    if ((slot0 & 1) == 0) {
+      v2f* r2 = reinterpret_cast<v2f*>(ring);
+      const int h0 = slot0 >> 1;
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        int i = h0 + 64 * u + lane;
+        if (i >= M) i -= M;
+        r2[i] = r2[i] + z[u] * lds_win[64 * u + lane];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const v2f v = z[u] * lds_win[64 * u + lane];
+        int i = slot0 + 128 * u + 2 * lane;
+        if (i >= N) i -= N;
+        const int i1 = i + 1 == N ? 0 : i + 1;
+        ring[i] += v.x;
+        ring[i1] += v.y;
+      }
+    }
+    const long long p0 = (long long)t * hop;
+    for (int j = lane; j < hop; j += 64) {
+      int i = slot0 + j;
+      if (i >= N) i -= N;
+      const float v = ring[i];
+      ring[i] = 0.0f;
+      emit(p0 + j, v);
+    }
+    slot0 += hop;
+    if (slot0 >= N) slot0 -= N;
+  }
+  const long long p0 = (long long)t1 * hop;
+  if (c == a.nchunks - 1) {
+    for (int j = lane; j < keep; j += 64) {
+      int i = slot0 + j;
+      if (i >= N) i -= N;
+      emit(p0 + j, ring[i]);
+    }
+  } else {
+    float* tl = a.xtail + ((long long)b * a.nchunks + c) * keep;
+    for (int j = lane; j < keep; j += 64) {
+      int i = slot0 + j;
+      if (i >= N) i -= N;
+      tl[j] = ring[i];
+    }
+  }
+}
+
+// out[n] += the previous chunk's tail over the first n_fft - hop samples of chunks 1.. (all inside the signal: a chunk
+// is at least (n_fft - 1) / hop + 1 frames long)
+__global__ void k_hop_tails_raw(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, int hop, int keep,
+                                int pad, long long L, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
+  if (i >= total) return;
+  const int j = (int)(i % keep);
+  const int c = (int)((i / keep) % (nchunks - 1)) + 1;
+  const long long b = i / ((long long)keep * (nchunks - 1));
+  const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+  if (n < 0 || n >= L) return;
+  x[b * L + n] += xtail[(b * nchunks + (c - 1)) * keep + j];
+}
+
+// x[n] = (own partial sum + the previous chunk's tail) * (1 / envelope) over the first n_fft - hop samples of chunks 1..
+__global__ void k_hop_tails(float* __restrict__ x, const float* __restrict__ xtail, const float* __restrict__ env, int T,
+                            int nchunks, int hop, int keep, int pad, long long L, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
+  if (i >= total) return;
+  const int j = (int)(i % keep);
+  const int c = (int)((i / keep) % (nchunks - 1)) + 1;
+  const long long b = i / ((long long)keep * (nchunks - 1));
+  const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+  if (n < 0 || n >= L) return;
+  float* px = x + b * L + n;
+  *px = (*px + xtail[(b * nchunks + (c - 1)) * keep + j]) * env[n];
+}
+
+}  // namespace fast
+}  // namespace specinv
