@@ -194,6 +194,15 @@ int specinv_vec_dot(specinv_plan* plan, const void* a, const void* b, int64_t n,
 int specinv_vec_axpy(specinv_plan* plan, double alpha, const void* x, void* y, int64_t n);
 int specinv_vec_scale(specinv_plan* plan, double alpha, const void* x, void* y, int64_t n);
 int specinv_vec_absmax_abssum(specinv_plan* plan, const void* x, int64_t n, double out_host[2]);
+/* Many vectors in one pass: out_host[j] = g . v_j for the k device vectors whose addresses are in the HOST array
+ * vecs_host; and out = sum_j coef_host[j] * v_j (float64 accumulation, rounded once).  With the k = 2m vectors of the
+ * L-BFGS memory these two passes carry the whole two-loop recursion (the recursion itself then runs on the m x m
+ * Gram matrices s_i.y_j, y_i.y_j on the host, which follow from the g . v_j of consecutive iterations by linearity):
+ * 2 (2m + 1) vector reads per iteration instead of 10 m (`lbfgs.py:LBFGS._direction_gram`). */
+int specinv_vec_multi_dot(specinv_plan* plan, const void* g, const void* const* vecs_host, int k, int64_t n,
+                          double* out_host);
+int specinv_vec_lincomb(specinv_plan* plan, const void* const* vecs_host, const double* coef_host, int k, int64_t n,
+                        void* out);
 /* The whole L-BFGS two-loop recursion d = -H g on the device (torch.optim.LBFGS.step's "compute the approximate
  * inverse Hessian multiplied by the gradient"): s_list_host / y_list_host are HOST arrays of m device pointers
  * (old_stps / old_dirs, oldest first), rho_host[m] = 1 / (y_i . s_i).  All 2m dot products stay on the device

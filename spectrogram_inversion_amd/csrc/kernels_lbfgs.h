@@ -263,6 +263,157 @@ int lb_absmax_abssum(P& pl, const T* x, int64_t n, double* out) {
   return SPECINV_OK;
 }
 
+// ---- many vectors in one pass (the L-BFGS recursion written on Gram matrices needs g . v_j for the whole memory and one
+// linear combination of it: two passes over the 2 m vectors instead of four dependent ones per pair) ----------------
+constexpr int kMultiVec = 64;   // vectors per launch (their addresses travel as kernel arguments)
+template <typename T>
+struct MultiVecArgs {
+  const T* v[kMultiVec];
+  double c[kMultiVec];
+  int k;
+};
+
+// part[j * gridDim.x + block] = sum over the block's elements of g[e] * v_j[e]  (float64 accumulation, fixed order).
+// A block keeps kSlab elements per thread of g in registers and streams the k vectors past them, 16 bytes per lane and
+// load; one wave reduction per (block pass, j).
+template <typename T>
+__global__ __launch_bounds__(256) void k_multi_dot(const T* __restrict__ g, MultiVecArgs<T> a, int64_t n,
+                                                   double* __restrict__ part) {
+  constexpr int W = 16 / sizeof(T);                 // elements per 16-byte load
+  constexpr int Q = 8;                              // 16-byte pieces per thread and pass
+  typedef T VT __attribute__((ext_vector_type(W)));
+  __shared__ double acc[4][kMultiVec];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int j = lane; j < a.k; j += 64) acc[wv][j] = 0.0;
+  const int64_t nv = n / W;                         // whole 16-byte pieces; the tail is handled by block 0 below
+  const int64_t pass = (int64_t)blockDim.x * Q;
+  for (int64_t base = (int64_t)blockIdx.x * pass; base < nv; base += (int64_t)gridDim.x * pass) {
+    VT gv[Q];
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      const int64_t i = base + (int64_t)e * blockDim.x + threadIdx.x;
+      if (i < nv) gv[e] = reinterpret_cast<const VT*>(g)[i];
+      else
+        for (int c = 0; c < W; ++c) gv[e][c] = T(0);
+    }
+    for (int j = 0; j < a.k; ++j) {
+      const VT* __restrict__ v = reinterpret_cast<const VT*>(a.v[j]);
+      VT vv[Q];
+#pragma unroll
+      for (int e = 0; e < Q; ++e) {
+        const int64_t i = base + (int64_t)e * blockDim.x + threadIdx.x;
+        if (i < nv) vv[e] = v[i];
+        else
+          for (int c = 0; c < W; ++c) vv[e][c] = T(0);
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int e = 0; e < Q; ++e)
+#pragma unroll
+        for (int c = 0; c < W; ++c) s += (double)gv[e][c] * (double)vv[e][c];
+      s = wave_sum(s);
+      if (lane == 0) acc[wv][j] += s;               // wave-private slot: no atomics, fixed order
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {        // the n % W trailing elements
+    for (int j = 0; j < a.k; ++j) {
+      double s = 0.0;
+      for (int64_t i = nv * W; i < n; ++i) s += (double)g[i] * (double)a.v[j][i];
+      acc[0][j] += s;
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.k; j += blockDim.x)
+    part[(int64_t)j * gridDim.x + blockIdx.x] = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
+}
+
+// out[j] = sum_b part[j * nb + b]
+__global__ void k_multi_finish(const double* __restrict__ part, int nb, double* __restrict__ out) {
+  __shared__ double red[16];
+  const int j = blockIdx.x;
+  double s = 0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += part[(int64_t)j * nb + i];
+  const double t = block_sum(s, red);
+  if (threadIdx.x == 0) out[j] = t;
+}
+
+// out[e] = (accumulate ? out[e] : 0) + sum_j c_j * v_j[e], summed in float64 in the order of j, rounded once; one
+// 16-byte piece per thread (the trailing n % W elements by the last thread)
+template <typename T>
+__global__ __launch_bounds__(256) void k_lincomb(MultiVecArgs<T> a, int accumulate, T* __restrict__ out, int64_t n) {
+  constexpr int W = 16 / sizeof(T);
+  typedef T VT __attribute__((ext_vector_type(W)));
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nv = n / W;
+  if (i < nv) {
+    double s[W];
+    const VT o = accumulate ? reinterpret_cast<const VT*>(out)[i] : VT(0);
+#pragma unroll
+    for (int c = 0; c < W; ++c) s[c] = (double)o[c];
+#pragma unroll 4
+    for (int j = 0; j < a.k; ++j) {
+      const VT v = reinterpret_cast<const VT*>(a.v[j])[i];
+#pragma unroll
+      for (int c = 0; c < W; ++c) s[c] += a.c[j] * (double)v[c];
+    }
+    VT r;
+#pragma unroll
+    for (int c = 0; c < W; ++c) r[c] = (T)s[c];
+    reinterpret_cast<VT*>(out)[i] = r;
+  } else if (i == nv) {
+    for (int64_t e = nv * W; e < n; ++e) {
+      double s = accumulate ? (double)out[e] : 0.0;
+      for (int j = 0; j < a.k; ++j) s += a.c[j] * (double)a.v[j][e];
+      out[e] = (T)s;
+    }
+  }
+}
+
+template <typename P, typename T>
+int lb_multi_dot(P& pl, const T* g, const void* const* vecs, int k, int64_t n, double* out) {
+  SI_CHECK(g && vecs && out && k > 0 && n > 0, SPECINV_EINVAL, "bad arguments");
+  SI_CHECK(((uintptr_t)g & 15) == 0, SPECINV_EINVAL, "g is not 16-byte aligned");
+  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8 * 4)));
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * kMultiVec, 3 * 1024) * sizeof(double)));
+  SI_TRY(pl.lb_scal.reserve((size_t)std::max(k, 4) * sizeof(double)));
+  double* dots = pl.lb_scal.template as<double>();
+  for (int j0 = 0; j0 < k; j0 += kMultiVec) {
+    MultiVecArgs<T> a{};
+    a.k = std::min(kMultiVec, k - j0);
+    for (int j = 0; j < a.k; ++j) {
+      SI_CHECK(vecs[j0 + j] != nullptr && ((uintptr_t)vecs[j0 + j] & 15) == 0, SPECINV_EINVAL,
+               "vector %d is NULL or not 16-byte aligned", j0 + j);
+      a.v[j] = static_cast<const T*>(vecs[j0 + j]);
+    }
+    hipLaunchKernelGGL((k_multi_dot<T>), dim3(nb), dim3(256), 0, pl.stream, g, a, n, pl.partials.template as<double>());
+    hipLaunchKernelGGL(k_multi_finish, dim3(a.k), dim3(256), 0, pl.stream, pl.partials.template as<double>(), nb, dots + j0);
+    SI_HIP(hipGetLastError());
+  }
+  SI_HIP(hipMemcpyAsync(out, dots, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
+  return SPECINV_OK;
+}
+
+template <typename P, typename T>
+int lb_lincomb(P& pl, const void* const* vecs, const double* coef, int k, int64_t n, T* out) {
+  SI_CHECK(vecs && coef && out && k > 0 && n > 0, SPECINV_EINVAL, "bad arguments");
+  SI_CHECK(((uintptr_t)out & 15) == 0, SPECINV_EINVAL, "out is not 16-byte aligned");
+  for (int j0 = 0; j0 < k; j0 += kMultiVec) {
+    MultiVecArgs<T> a{};
+    a.k = std::min(kMultiVec, k - j0);
+    for (int j = 0; j < a.k; ++j) {
+      SI_CHECK(vecs[j0 + j] != nullptr && ((uintptr_t)vecs[j0 + j] & 15) == 0, SPECINV_EINVAL,
+               "vector %d is NULL or not 16-byte aligned", j0 + j);
+      a.v[j] = static_cast<const T*>(vecs[j0 + j]);
+      a.c[j] = coef[j0 + j];
+    }
+    const int64_t pieces = n / (16 / (int64_t)sizeof(T)) + 1;      // + the thread that takes the trailing elements
+    hipLaunchKernelGGL((k_lincomb<T>), dim3((unsigned)ceil_div(pieces, 256)), dim3(256), 0, pl.stream, a, j0 > 0 ? 1 : 0, out, n);
+    SI_HIP(hipGetLastError());
+  }
+  return SPECINV_OK;
+}
+
 // ---- two-loop recursion with device-resident scalars -----------------------------------------------------
 // slot = scale * sum(partials)      (al_i = rho_i * (s_i . q))
 __global__ void k_finish_scaled(const double* __restrict__ part, int n, double scale, double* __restrict__ slot) {

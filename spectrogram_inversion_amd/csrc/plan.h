@@ -71,6 +71,8 @@ struct PlanBase {
   virtual int vec_absmax_abssum(const void* x, int64_t n, double out[2]) = 0;
   virtual int lbfgs_direction(const void* g, const void* const* s_list, const void* const* y_list, const double* rho,
                               int m, double h_diag, void* d_out, int64_t n) = 0;
+  virtual int vec_multi_dot(const void* g, const void* const* vecs, int k, int64_t n, double* out) = 0;
+  virtual int vec_lincomb(const void* const* vecs, const double* coef, int k, int64_t n, void* out) = 0;
   virtual int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out) = 0;
   virtual int lbfgs_stats(const void* g, const void* d, int64_t n, double* out) = 0;
 

@@ -671,6 +671,12 @@ struct PlanT final : PlanBase {
                       double h_diag, void* d_out, int64_t n) override {
     return lb_direction(*this, static_cast<const T*>(g), s_list, y_list, rho, m, h_diag, static_cast<T*>(d_out), n);
   }
+  int vec_multi_dot(const void* g, const void* const* vecs, int k, int64_t n, double* out) override {
+    return lb_multi_dot(*this, static_cast<const T*>(g), vecs, k, n, out);
+  }
+  int vec_lincomb(const void* const* vecs, const double* coef, int k, int64_t n, void* out) override {
+    return lb_lincomb(*this, vecs, coef, k, n, static_cast<T*>(out));
+  }
   int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out) override {
     return lb_pair(*this, static_cast<const T*>(g), static_cast<const T*>(gp), static_cast<const T*>(d), t, static_cast<T*>(y),
                    static_cast<T*>(sv), n, out);

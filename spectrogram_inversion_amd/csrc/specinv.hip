@@ -326,6 +326,17 @@ int specinv_vec_absmax_abssum(specinv_plan* plan, const void* x, int64_t n, doub
   return plan->impl->vec_absmax_abssum(x, n, out_host);
 }
 
+int specinv_vec_multi_dot(specinv_plan* plan, const void* g, const void* const* vecs_host, int k, int64_t n,
+                          double* out_host) {
+  ENTER(plan);
+  return plan->impl->vec_multi_dot(g, vecs_host, k, n, out_host);
+}
+int specinv_vec_lincomb(specinv_plan* plan, const void* const* vecs_host, const double* coef_host, int k, int64_t n,
+                        void* out) {
+  ENTER(plan);
+  return plan->impl->vec_lincomb(vecs_host, coef_host, k, n, out);
+}
+
 int specinv_lbfgs_direction(specinv_plan* plan, const void* g, const void* const* s_list_host,
                             const void* const* y_list_host, const double* rho_host, int m, double h_diag, void* d_out,
                             int64_t n) {

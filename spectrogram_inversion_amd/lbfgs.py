@@ -12,7 +12,9 @@ reduction kernels through a `VecOps` backend, with dot products accumulated in f
 from __future__ import annotations
 
 import math
+import os
 
+import numpy as np
 import torch
 
 from .plan import StftArgs, get_plan
@@ -41,6 +43,12 @@ class HipVecOps:
 
     def direction(self, g, ss, ys, rho, h_diag):
         return self.plan.lbfgs_direction(g, ss, ys, rho, h_diag)
+
+    def multi_dot(self, g, vecs):
+        return self.plan.vec_multi_dot(g, vecs)
+
+    def lincomb(self, vecs, coefs):
+        return self.plan.vec_lincomb(vecs, coefs)
 
     def pair(self, g, g_prev, d, t):
         return self.plan.lbfgs_pair(g, g_prev, d, t)
@@ -84,15 +92,64 @@ class LBFGS:
         self.func_evals = 0
         self.d = None
         self.t = None
-        self.ys, self.ss, self.rho = [], [], []
-        self.h_diag = 1.0
+        # the recursion on Gram matrices (two passes over the memory) needs the one-pass vector kernels
+        self.gram = hasattr(self.ops, "multi_dot") and hasattr(self.ops, "lincomb") and os.environ.get("SPECINV_LBFGS_GRAM", "1") != "0"
+        self._forget()
         self.prev_grad = None
         self.prev_loss = None
 
     # ---- pieces -----------------------------------------------------------------------------
+    def _forget(self):
+        self.ys, self.ss, self.rho, self.h_diag = [], [], [], 1.0
+        self._sy = np.zeros((0, 0))            # s_i . y_j (used for i <= j)
+        self._yy = np.zeros((0, 0))            # y_i . y_j
+        self._sg = self._yg = None             # s_i . g, y_i . g of the previous direction
+        self._pushed = None                    # (y.s, y.y) of a pair appended since the previous direction
+
+    def _drop_oldest(self):
+        self.ys.pop(0)
+        self.ss.pop(0)
+        self.rho.pop(0)
+        if self.gram:
+            self._sy, self._yy = self._sy[1:, 1:], self._yy[1:, 1:]
+            if self._sg is not None:
+                self._sg, self._yg = self._sg[1:], self._yg[1:]
+
+    def _direction_gram(self, g):
+        """-H g with two passes over the memory.  The two-loop recursion only needs the scalars s_i . q, y_i . r; with
+        q = g - sum_j al_j y_j and r = gamma q + sum_j (al_j - be_j) s_j these follow from s_i . g, y_i . g (one pass:
+        `multi_dot`) and the Gram matrices s_i . y_j, y_i . y_j.  A new pair's Gram column needs no pass of its own:
+        y_new = g - g_prev, so v . y_new = v . g - v . g_prev, both already known.  The direction is one linear
+        combination of g and the memory (`lincomb`).  Same algebra as `_direction`, different rounding."""
+        ops, m = self.ops, len(self.ss)
+        dots = np.asarray(ops.multi_dot(g, self.ss + self.ys), dtype=np.float64)
+        sg, yg = dots[:m], dots[m:]
+        if self._pushed is not None:
+            ys_new, yy_new = self._pushed
+            sy, yy = np.zeros((m, m)), np.zeros((m, m))
+            sy[:m - 1, :m - 1], yy[:m - 1, :m - 1] = self._sy, self._yy
+            if m > 1:
+                sy[:m - 1, m - 1] = sg[:m - 1] - self._sg          # s_i . y_new
+                yy[:m - 1, m - 1] = yy[m - 1, :m - 1] = yg[:m - 1] - self._yg
+            sy[m - 1, m - 1], yy[m - 1, m - 1] = ys_new, yy_new
+            self._sy, self._yy, self._pushed = sy, yy, None
+        self._sg, self._yg = sg, yg
+        rho, gamma = np.asarray(self.rho, dtype=np.float64), float(self.h_diag)
+        al = np.zeros(m)
+        for i in range(m - 1, -1, -1):
+            al[i] = rho[i] * (sg[i] - np.dot(al[i + 1:], self._sy[i, i + 1:]))
+        yq = yg - self._yy @ al                                  # y_i . q
+        c = np.zeros(m)                                          # al_i - be_i
+        for i in range(m):
+            c[i] = al[i] - rho[i] * (gamma * yq[i] + np.dot(c[:i], self._sy[:i, i]))
+        # d = -(gamma (g - sum al_j y_j) + sum c_i s_i)
+        return ops.lincomb([g] + self.ys + self.ss, [-gamma] + list(gamma * al) + list(-c))
+
     def _direction(self, g):
         """Two-loop recursion: returns -H g for the current memory."""
         ops = self.ops
+        if self.gram and self.ss:
+            return self._direction_gram(g)
         if hasattr(ops, "direction"):          # device-resident scalars: no host sync inside the recursion
             return ops.direction(g, self.ss, self.ys, self.rho, self.h_diag)
         m = len(self.ys)
@@ -190,7 +247,7 @@ class LBFGS:
             self.total_iters += 1
             if self.total_iters == 1:
                 d = ops.scaled(-1.0, g)
-                self.ys, self.ss, self.rho, self.h_diag = [], [], [], 1.0
+                self._forget()
             else:
                 if fused:
                     y, s, ys, yy = ops.pair(g, self.prev_grad, d, t)
@@ -201,13 +258,13 @@ class LBFGS:
                     ys, yy = ops.dot(y, s), None
                 if ys > 1e-10:
                     if len(self.ys) == self.history_size:
-                        self.ys.pop(0)
-                        self.ss.pop(0)
-                        self.rho.pop(0)
+                        self._drop_oldest()
                     self.ys.append(y)
                     self.ss.append(s)
                     self.rho.append(1.0 / ys)
-                    self.h_diag = ys / (yy if yy is not None else ops.dot(y, y))
+                    yy = yy if yy is not None else ops.dot(y, y)
+                    self.h_diag = ys / yy
+                    self._pushed = (ys, yy)
                 d = self._direction(g)
             self.prev_grad = g if fused else g.clone()     # fg returns a fresh tensor: nothing writes into it later
             self.prev_loss = loss

@@ -413,6 +413,28 @@ class Plan:
                                                     g.numel()))
         return d
 
+    def vec_multi_dot(self, g, vecs):
+        """[g . v for v in vecs] in one pass over g and the vectors (float64 accumulation)."""
+        self._sync_stream()
+        k = len(vecs)
+        g = g if g.data_ptr() % 16 == 0 else g.clone()                    # (the kernels load 16 bytes per lane)
+        vecs = [t if t.data_ptr() % 16 == 0 else t.clone() for t in vecs]
+        vp = (C.c_void_p * k)(*[t.data_ptr() for t in vecs])
+        out = (C.c_double * k)()
+        _lib.check(self.lib.specinv_vec_multi_dot(self._h, g.data_ptr(), vp, k, g.numel(), out))
+        return list(out)
+
+    def vec_lincomb(self, vecs, coefs):
+        """sum_j coefs[j] * vecs[j] in one pass (float64 accumulation, rounded once)."""
+        self._sync_stream()
+        k = len(vecs)
+        out = torch.empty_like(vecs[0])
+        vecs = [t if t.data_ptr() % 16 == 0 else t.clone() for t in vecs]
+        vp = (C.c_void_p * k)(*[t.data_ptr() for t in vecs])
+        cf = (C.c_double * k)(*[float(c) for c in coefs])
+        _lib.check(self.lib.specinv_vec_lincomb(self._h, vp, cf, k, out.numel(), out.data_ptr()))
+        return out
+
     def lbfgs_pair(self, g, g_prev, d, t):
         """y = g - g_prev, s = t*d in one pass; returns (y, s, y.s, y.y)."""
         self._sync_stream()

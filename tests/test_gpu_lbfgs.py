@@ -187,3 +187,57 @@ def test_l_bfgs_generic_callable_and_shapes():
     ya = si.L_BFGS(spec, trsfn, init_x0=x0.clone(), outer_max_iter=1, max_iter=4, verbose=False, tol=0)
     yb = si.L_BFGS(spec, MagSTFT(256), init_x0=x0.clone(), outer_max_iter=1, max_iter=4, verbose=False, tol=0)
     assert rel_l2(N(yb), N(ya)) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("k,n", [(1, 1000), (7, 100003), (64, 50000), (150, 20011)])
+def test_many_vector_passes(k, n, dtype):
+    """g . v_j for k vectors in one pass, and one linear combination of them (more than 64 vectors: several launches)."""
+    ops = HipVecOps(dtype, dev())
+    rng = np.random.default_rng(k + n)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    g = rng.standard_normal(n).astype(npdt)
+    vs = [rng.standard_normal(n).astype(npdt) for _ in range(k)]
+    tv = [T(v) for v in vs]
+    dots = ops.multi_dot(T(g), tv)
+    want = [float(np.dot(g.astype(np.float64), v.astype(np.float64))) for v in vs]
+    assert np.allclose(dots, want, rtol=0, atol=(1e-9 if dtype == torch.float64 else 1e-6) * n ** 0.5)
+    coef = rng.standard_normal(k)
+    out = N(ops.lincomb(tv, coef))
+    ref = sum(c * v.astype(np.float64) for c, v in zip(coef, vs))
+    assert rel_l2(out, ref) < (1e-15 if dtype == torch.float64 else 1e-7)
+
+
+@pytest.mark.parametrize("history", [3, 6])
+def test_gram_direction_follows_the_two_loop_recursion(history):
+    """The recursion on Gram matrices (2 passes over the memory) against the two-loop recursion with one dot / axpy
+    per pair on the same memory, at every iteration of an optimisation (including those that drop the oldest pair)."""
+    rng = np.random.default_rng(history)
+    n = 4096
+    A = rng.standard_normal((n, n // 8)).astype(np.float32)
+    q = T(A @ A.T / n + 1e-3 * np.eye(n, dtype=np.float32))          # an ill-conditioned SPD quadratic
+    b = T(rng.standard_normal(n).astype(np.float32))
+
+    def fg(x):
+        qx = q @ x
+        return float(0.5 * torch.dot(x, qx) - torch.dot(b, x)), qx - b
+
+    x = torch.zeros(n, device=dev())
+    opt = LBFGS(x, max_iter=40, history_size=history, line_search_fn="strong_wolfe", tolerance_change=1e-12, tolerance_grad=0)
+    assert opt.gram
+    errs, sizes = [], []
+    gram_direction = opt._direction
+
+    def both(g):
+        d = gram_direction(g)
+        ref = opt.ops.direction(g, opt.ss, opt.ys, opt.rho, opt.h_diag)
+        errs.append(rel_l2(N(d), N(ref)))
+        sizes.append(len(opt.ss))
+        return d
+
+    opt._direction = both
+    f_start = fg(x)[0]
+    opt.step(fg)
+    assert len(errs) > history + 3 and max(sizes) == history and sizes.count(history) > 3      # pairs were dropped
+    assert max(errs) < 2e-5, errs
+    assert fg(x)[0] < f_start - 1.0
