@@ -115,10 +115,24 @@ class TorchVecOps:
         return float(x.abs().max()), float(x.abs().sum())
 
 
+class GramTorchVecOps(TorchVecOps):
+    """The same plus the two many-vector passes: switches the optimiser to the recursion on Gram matrices."""
+
+    def multi_dot(self, g, vecs):
+        return [float(torch.dot(g.reshape(-1).double(), v.reshape(-1).double())) for v in vecs]
+
+    def lincomb(self, vecs, coefs):
+        out = torch.zeros_like(vecs[0], dtype=torch.float64)
+        for c, v in zip(coefs, vecs):
+            out += float(c) * v.double()
+        return out.to(vecs[0].dtype)
+
+
+@pytest.mark.parametrize("backend", [TorchVecOps, GramTorchVecOps])
 @pytest.mark.parametrize("tag,kw", [("wolfe", dict(max_iter=40, history_size=5, line_search_fn="strong_wolfe")),
                                     ("wolfe_h100", dict(max_iter=25, line_search_fn="strong_wolfe")),
                                     ("fixed", dict(max_iter=30, lr=1e-3, history_size=4))])
-def test_lbfgs_control_flow_retraces_torch(tag, kw):
+def test_lbfgs_control_flow_retraces_torch(tag, kw, backend):
     g = load_golden("g9_lbfgs_rosen")
     x = torch.from_numpy(g["x0"].copy())
     losses = []
@@ -132,7 +146,8 @@ def test_lbfgs_control_flow_retraces_torch(tag, kw):
         losses.append(f)
         return f, gr
 
-    opt = LBFGS(x, vec_ops=TorchVecOps(), **kw)
+    opt = LBFGS(x, vec_ops=backend(), **kw)
+    assert opt.gram == (backend is GramTorchVecOps)
     for _ in range(2):
         opt.step(fg)
     ref = g[f"losses_{tag}"]
