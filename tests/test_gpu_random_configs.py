@@ -2,6 +2,8 @@
 method): the device result after a few iterations against the oracle.  A safety net over the many kernel variants
 (fused with hop = n_fft/2, /4, /8 at n_fft 512 ... 4096, frame kernel, generic radix schedules); every case prints
 the path it took.  Needs an MI355X: `-m gpu`."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -52,9 +54,18 @@ def draw(seed, wave_level=False):
     return n_fft, kw, mag, method, coef
 
 
-@pytest.mark.parametrize("seed", list(range(60)) + list(range(100, 160)))
+# SPECINV_EXTRA_SEEDS="a:b" adds seeds a..b-1 (even: the full draw, odd: wave-level shapes) for an occasional wider sweep
+# (1000:1800 -> 905 pass; 1291, a rectangular win_length < n_fft window with hop = n_fft/2, is ill-conditioned at the
+# signal's end: every kernel path AND the float32 oracle leave the float64 oracle by 2e-2 there after 3 iterations,
+# tools/dbg_seed.py 1291)
+_extra = os.environ.get("SPECINV_EXTRA_SEEDS", "")
+EXTRA = list(range(*map(int, _extra.split(":")))) if _extra else []
+
+
+@pytest.mark.parametrize("seed", list(range(60)) + list(range(100, 160)) + EXTRA)
 def test_random_configuration(seed, request):
-    n_fft, kw, mag, method, coef = draw(seed, wave_level=seed >= 100)    # seeds >= 100: float32 one-sided pow-2 sizes only
+    # seeds 100..159 (and the odd extra ones): float32 one-sided pow-2 sizes only
+    n_fft, kw, mag, method, coef = draw(seed, wave_level=(100 <= seed < 160) or (seed >= 1000 and seed % 2 == 1))
     if seed % 3:
         request.getfixturevalue("chunked_kernel")    # these shapes are all small: keep the fused kernel in the sweep
     pad = n_fft // 2 if kw["center"] else 0
