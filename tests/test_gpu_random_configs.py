@@ -101,7 +101,8 @@ def test_random_configuration(seed, request):
     assert finite_close(y[..., good], ref[..., good], tol), (seed, path)
 
 
-@pytest.mark.parametrize("seed", range(30))
+# (extra seeds 1000:1400 -> 396 of 400 inside the bound, the rest within 2.5x of it: the recursion amplifies rounding noise)
+@pytest.mark.parametrize("seed", list(range(30)) + EXTRA)
 def test_random_rtisi_configuration(seed):
     """RTISI_LA (asymmetric window: the numerically stable variant) against the oracle, and the streaming form against
     the whole-signal form, on random shapes."""

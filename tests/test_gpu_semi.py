@@ -1,5 +1,7 @@
 """The any-hop wave-level iteration (k_semi + k_ola: n_fft 1024 / 2048 with hop != n_fft/4 or centre = False)
 against the oracle and the generic kernels, through the C ABI.  Needs an MI355X: `-m gpu`."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -222,7 +224,14 @@ def test_chunked_frame_kernel_many_chunks_long_signal(chunked_kernel):
     assert np.abs(y - ref.reshape(y.shape)).max() < 1e-3 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("seed", range(40))
+# SPECINV_EXTRA_SEEDS="a:b": more seeds for an occasional wider sweep (1000:1600 -> 595 of 600 within the tolerance; the
+# others hold one of Griffin-Lim's local chaotic events - a bin passing close to zero - where k_hop, k_semi and the
+# float32 oracle all leave the float64 oracle by 1e-4 ... 1e-3 in the same three hop-blocks, tools/dbg_hop_seed.py)
+_extra = os.environ.get("SPECINV_EXTRA_SEEDS", "")
+EXTRA = list(range(*map(int, _extra.split(":")))) if _extra else []
+
+
+@pytest.mark.parametrize("seed", list(range(40)) + EXTRA)
 def test_chunked_frame_kernel_random_shapes(seed, chunked_kernel, monkeypatch):
     """Random (n_fft, hop, frames, batch, centring, pad mode, method): the chunked kernel with the overlap-add in LDS
     and the frame-at-a-time kernel + gather run the same per-frame arithmetic, so after 3 iterations from the same
