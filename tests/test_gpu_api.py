@@ -291,3 +291,35 @@ def test_plans_release_their_device_memory():
         cycle([512, 333, 1024, 256])
     free1 = torch.cuda.mem_get_info(torch.device(DEV))[0]
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+def test_results_are_bitwise_reproducible(chunked_kernel):
+    """Every sum on the device has a fixed order (no atomics): the same call gives the same bits again, on every kernel
+    path - fused, frame (gather and LDS overlap-add), generic, both RTISI kernels, the L-BFGS objective."""
+    rng = np.random.default_rng(77)
+
+    def mag(n_fft, frames, batch=3, dtype=np.float32):
+        return torch.from_numpy(rng.random((batch, n_fft // 2 + 1, frames)).astype(dtype) + 0.01).to(DEV)
+
+    w1k, w2k = torch.from_numpy(hann(1024)), torch.from_numpy(hann(2048))
+    cases = [
+        ("fused", lambda m: si.griffin_lim(m, max_iter=12, alpha=0.3, tol=0, verbose=False, hop_length=256, window=w1k), mag(1024, 96)),
+        ("frame, LDS overlap-add", lambda m: si.ADMM(m, max_iter=8, rho=0.3, tol=0, verbose=False, hop_length=333, window=w2k), mag(2048, 70)),
+        ("generic", lambda m: si.griffin_lim(m, max_iter=8, alpha=0.5, tol=0, verbose=False, hop_length=100, window=torch.from_numpy(hann(400))), mag(400, 80)),
+        ("generic f64", lambda m: si.griffin_lim(m, max_iter=6, alpha=0.5, tol=0, verbose=False, hop_length=128, window=torch.from_numpy(hann(512, np.float64))), mag(512, 40, dtype=np.float64)),
+        ("rtisi wave-level", lambda m: si.RTISI_LA(m, look_ahead=3, asymmetric_window=True, max_iter=6, verbose=False, hop_length=256, window=w1k), mag(1024, 60)),
+        ("rtisi generic", lambda m: si.RTISI_LA(m, look_ahead=2, max_iter=4, verbose=False, hop_length=100, window=torch.from_numpy(hann(400))), mag(400, 40)),
+    ]
+    for name, fn, m in cases:
+        first = fn(m)
+        for _ in range(3):
+            again = fn(m)
+            assert torch.equal(torch.nan_to_num(first), torch.nan_to_num(again)), name
+    x = 0.1 * torch.randn(2, 39 * 512, device=DEV)
+    fb = torch.from_numpy(si.mel_filterbank(22050, 2048, 80)).to(DEV)
+    tr = si.LogMelSTFT(fb, 2048, hop_length=512, window=w2k.to(DEV))
+    _, fg = tr.bind(x, tr(x + 0.01))
+    l0, g0 = fg(x)
+    for _ in range(3):
+        l1, g1 = fg(x)
+        assert l0 == l1 and torch.equal(g0, g1)
