@@ -11,8 +11,8 @@ namespace fast {
 // ---- stand-alone transforms on the wave-level FFT (any hop; used by specinv_stft and the L_BFGS objective) ----
 // windowed frame starting at signal index `start` (may reach into the reflect padding) -> registers
 template <int R>
-__device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, long long len, long long start, int lane,
-                                                int pad_mode, const v2f* __restrict__ lds_win, v2f (&z)[R]) {
+__device__ __forceinline__ void load_frame_raw(const float* __restrict__ xrow, long long len, long long start, int lane,
+                                               int pad_mode, v2f (&z)[R]) {
   constexpr int N = Geo<R>::N;
   if (start >= 0 && start + N <= len && (start & 1) == 0) {
     const v2f* src = reinterpret_cast<const v2f*>(xrow + start);
@@ -30,6 +30,12 @@ __device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, 
       z[u] = v2f{n0 < 0 ? 0.0f : xrow[n0], n1 < 0 ? 0.0f : xrow[n1]};
     }
   }
+}
+
+template <int R>
+__device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, long long len, long long start, int lane,
+                                                int pad_mode, const v2f* __restrict__ lds_win, v2f (&z)[R]) {
+  load_frame_raw<R>(xrow, len, start, lane, pad_mode, z);
 #pragma unroll
   for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
 }
@@ -160,7 +166,8 @@ struct SemiArgs {
 
 // One frame of the frame kernels: state in, (samples -> spectrum -> update) unless MODE_INIT, state out, inverse
 // transform.  On return z holds the synthesis frame before its window (register u <-> samples 128u + 2 lane, +1).
-template <int R, int MODE, bool EVAL>
+// PRE: z already holds the frame's samples (unwindowed), fetched by the caller one frame ahead.
+template <int R, int MODE, bool EVAL, bool PRE = false>
 __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long long b, int t, int hop, int pad,
                                            const LaneConst<R>& k, const v2f* lds_win, const v2f* lds_tw1, v2f* tr,
                                            v2f (&z)[R], double& sd, double& so) {
@@ -195,7 +202,12 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
   }
   v2f rc[H];
   if (MODE != MODE_INIT) {
-    load_frame_regs<R>(a.x_in + b * a.L, a.L, (long long)t * hop - pad, lane, a.pad_mode, lds_win, z);
+    if (PRE) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    } else {
+      load_frame_regs<R>(a.x_in + b * a.L, a.L, (long long)t * hop - pad, lane, a.pad_mode, lds_win, z);
+    }
     fft_forward<R>(z, k, lds_tw1, tr);
 #pragma unroll
     for (int m = H; m < R; ++m) {
@@ -341,10 +353,20 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
     // padded-signal position p <-> ring slot p mod N; samples below `raw_end` of a later chunk stay undivided
     const long long raw_end = c > 0 ? (long long)t0 * hop + keep : -1;
     int slot0 = (int)(((long long)t0 * hop) % N);          // ring slot of the frame's first sample
+    // the samples of frame t + 1 are requested before frame t is transformed (they come from L2 / HBM with a latency
+    // that two waves per SIMD do not hide)
+    constexpr bool PRE = MODE != MODE_INIT;
+    v2f zn[R];
+    if (PRE) load_frame_raw<R>(a.x_in + (long long)b * a.L, a.L, (long long)t0 * hop - s.pad, lane, a.pad_mode, zn);
     for (int t = t0; t < t1; ++t) {
       const long long fi = (long long)b * a.T + t;
       v2f z[R];
-      semi_frame<R, MODE, EVAL>(a, fi, b, t, hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
+      if (PRE) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) z[u] = zn[u];
+        if (t + 1 < t1) load_frame_raw<R>(a.x_in + (long long)b * a.L, a.L, (long long)(t + 1) * hop - s.pad, lane, a.pad_mode, zn);
+      }
+      semi_frame<R, MODE, EVAL, PRE>(a, fi, b, t, hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
       if ((slot0 & 1) == 0) {                              // register pairs stay aligned in the ring
         v2f* r2 = reinterpret_cast<v2f*>(ring);
         const int h0 = slot0 >> 1;
