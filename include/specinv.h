@@ -51,7 +51,7 @@ typedef struct specinv_stft_cfg {
   int32_t n_fft;
   int32_t hop_length;
   int32_t n_frames;      /* T */
-  int32_t batch;         /* B */
+  int32_t batch;         /* B, at most 65535 (the batch is a grid dimension of the layout kernels) */
   int32_t center;        /* bool */
   int32_t pad_mode;      /* SPECINV_PAD_* ; only read by the forward STFT when center != 0 */
   int32_t normalized;    /* bool: 'ortho' scaling both ways (methods.py:142-146) */
@@ -92,6 +92,13 @@ int specinv_plan_set_stream(specinv_plan* plan, void* hip_stream);
 int specinv_plan_n_freq(const specinv_plan* plan);
 int64_t specinv_plan_length(const specinv_plan* plan);
 int specinv_plan_fast_path(const specinv_plan* plan);
+/* Device memory currently held by the plan's own buffers, in bytes (state, scratch, tables; grows as entry points
+ * reserve what they need).  The host layer caps its plan cache with it. */
+int64_t specinv_plan_device_bytes(const specinv_plan* plan);
+/* Launch geometry of the iteration kernel (diagnostics; the tests assert that the benchmark's geometry is the one they
+ * cover): out = { waves per workgroup, chunks of frames per item, waves per launch, kernel }, kernel: 0 generic
+ * k_iter_pair, 1 k_fused4 (hop = n_fft/4 at n_fft 1024 / 2048), 2 k_fused<R, OV>, 3 k_semi, 4 k_hop. */
+int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]);
 /* 0: allow the fast path when the configuration supports it (default); 1: force the generic kernels. */
 int specinv_plan_force_generic(specinv_plan* plan, int on);
 

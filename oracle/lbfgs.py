@@ -304,9 +304,9 @@ def lbfgs_minimize(fg, x, state: LbfgsState, lr=1.0, max_iter=20, max_eval=None,
             def phi(step):
                 return fg(x0 + dt(step) * d)
 
+            # (torch.optim.LBFGS.step does not forward tolerance_change: the search keeps its default 1e-9)
             loss, g, t, ls_evals = _strong_wolfe(
-                phi, t, d, loss, g, gtd, tol_change=tolerance_change,
-                max_ls=max_eval - evals)
+                phi, t, d, loss, g, gtd, max_ls=max_eval - evals)
             x += dt(t) * d
             opt = np.abs(g).max() <= tolerance_grad
         else:

@@ -48,25 +48,25 @@ class _GriffinLimFn(torch.autograd.Function):
                     break
                 previous = loss
         ctx.plan, ctx.lr, ctx.real_in = plan, lr, real_in
-        ctx.saved_spectra = saved
-        ctx.save_for_backward(mag, c0)
+        # the recorded spectra are ordinary saved tensors: autograd's hooks and release rules apply to them, and
+        # backward may run again under retain_graph=True like on the reference's op graph
+        ctx.save_for_backward(mag, c0, *saved)
         return x
 
     @staticmethod
     def backward(ctx, g_y):
         plan, lr = ctx.plan, ctx.lr
-        mag, c0 = ctx.saved_tensors
+        mag, c0, *spectra = ctx.saved_tensors
         gx = g_y.detach().to(plan.dtype).contiguous()
         gm = torch.zeros_like(mag)
         gp = None
-        for s_k in reversed(ctx.saved_spectra):
+        for s_k in reversed(spectra):
             gq = plan.istft_adjoint(gx)
             gr, gp = plan.gla_update_adjoint(gq, gp, s_k, mag, lr, gm)
             gx = plan.stft_adjoint(gr, plan.length)
         gc = plan.istft_adjoint(gx)                                    # x0 = ISTFT(C0)
         if gp is not None:
             gc = gc + gp                                               # pre_spec_0 = C0
-        ctx.saved_spectra = None
         grad = _input_grad(ctx, plan, mag, c0, gc, gm)
         return grad, None, None, None, None, None, None, None
 
@@ -115,25 +115,23 @@ class _ADMMFn(torch.autograd.Function):
                     break
                 previous = loss
         ctx.plan, ctx.rho, ctx.real_in = plan, rho, real_in
-        ctx.saved_spectra = saved
-        ctx.save_for_backward(mag, c0)
+        ctx.save_for_backward(mag, c0, *saved)
         return x
 
     @staticmethod
     def backward(ctx, g_y):
         plan, rho = ctx.plan, ctx.rho
-        mag, c0 = ctx.saved_tensors
+        mag, c0, *spectra = ctx.saved_tensors
         gx = g_y.detach().to(plan.dtype).contiguous()
         gm = torch.zeros_like(mag)
         gX = gU = None
-        for v_k in reversed(ctx.saved_spectra):
+        for v_k in reversed(spectra):
             gyn = plan.istft_adjoint(gx)
             gr, gX, gU = plan.admm_update_adjoint(gyn, gX, gU, v_k, mag, rho, gm)
             gx = plan.stft_adjoint(gr, plan.length)
         gc = plan.istft_adjoint(gx)                                    # x0 = ISTFT(C0)
         if gX is not None:
             gc = gc + gX                                               # X0 = C0 (U0 = 0 is a constant)
-        ctx.saved_spectra = None
         return _input_grad(ctx, plan, mag, c0, gc, gm), None, None, None, None, None, None, None
 
 

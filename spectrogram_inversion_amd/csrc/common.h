@@ -33,6 +33,16 @@ inline hipError_t si_stream_wait_short(hipStream_t stream) {
   return hipStreamSynchronize(stream);
 }
 
+// Device-memory accounting: an allocation made inside an ABI call is charged to the plan that call entered
+// (specinv_plan_device_bytes; the host layer caps its plan cache by bytes).
+inline int64_t*& bytes_sink() {
+  static thread_local int64_t* sink = nullptr;
+  return sink;
+}
+inline void account_bytes(int64_t delta) {
+  if (bytes_sink()) *bytes_sink() += delta;
+}
+
 #define SI_CHECK(cond, code, ...)                       \
   do {                                                  \
     if (!(cond)) return ::specinv::fail(code, __VA_ARGS__); \

@@ -60,6 +60,9 @@
 #ifndef SPECINV_NT
 #define SPECINV_NT 1         // nontemporal state streams (keeps the re-used samples in L2)
 #endif
+#ifndef SPECINV_IEEE        // 1: correctly rounded sqrt / division in the projection and a true division by the envelope
+#define SPECINV_IEEE 0      //    (the reference's operations, methods.py:132,246-247) instead of v_sqrt_f32 / v_rcp_f32 and
+#endif                      //    a multiplication by 1/envelope: the accuracy study of tools/dbg_acc.py, profiles/r02_ieee_study.txt
 
 namespace specinv {
 namespace fast {
@@ -523,7 +526,19 @@ struct FastArgs {
   float inv_scale;  // 1/N or N^-1/2
 };
 
+#if SPECINV_IEEE
+__device__ __forceinline__ float fast_abs(v2f s) { return __fsqrt_rn(fmaf(s.x, s.x, s.y * s.y)); }
+__device__ __forceinline__ float fast_rcp(float v) { return __fdiv_rn(1.0f, v); }
+// the envelope table holds the envelope itself
+__device__ __forceinline__ v2f env_apply(v2f v, v2f e) { return v2f{__fdiv_rn(v.x, e.x), __fdiv_rn(v.y, e.y)}; }
+__device__ __forceinline__ float env_apply(float v, float e) { return __fdiv_rn(v, e); }
+#else
 __device__ __forceinline__ float fast_abs(v2f s) { return __builtin_amdgcn_sqrtf(fmaf(s.x, s.x, s.y * s.y)); }
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+// the envelope table holds 1 / envelope
+__device__ __forceinline__ v2f env_apply(v2f v, v2f e) { return v * e; }
+__device__ __forceinline__ float env_apply(float v, float e) { return v * e; }
+#endif
 
 // Frequency-domain update of one bin.  `r` is the STFT bin, `p`/`u` the stored state, `m` the target.
 // Returns the bin to synthesise from (already multiplied by isc); writes the new state.
@@ -542,16 +557,26 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const 
     // methods.py:243-247: S = R - lr*P ; P <- S ; S * m / (|S| + 1e-16)
     const v2f s = v2f{fmaf(-a.coef, p.x, r.x), fmaf(-a.coef, p.y, r.y)};
     p = s;
-    const float inv = __builtin_amdgcn_rcpf(fast_abs(s) + 1e-16f) * a.inv_scale;
+#if SPECINV_IEEE
+    const float den = fast_abs(s) + 1e-16f;
+    return v2f{__fdiv_rn(s.x * m, den) * a.inv_scale, __fdiv_rn(s.y * m, den) * a.inv_scale};
+#else
+    const float inv = fast_rcp(fast_abs(s) + 1e-16f) * a.inv_scale;
     return v2f{(s.x * m) * inv, (s.y * m) * inv};
+#endif
   } else {
     // methods.py:467-475
     const v2f y = p + u;
     const v2f z = v2f{fmaf(a.coef, y.x, r.x) * a.inv1p, fmaf(a.coef, y.y, r.y) * a.inv1p};
     const v2f un = (u + p) - z;
     v2f xn = z - un;
-    const float inv = __builtin_amdgcn_rcpf(fast_abs(xn) + 1e-16f);
+#if SPECINV_IEEE
+    const float den = fast_abs(xn) + 1e-16f;
+    xn = v2f{__fdiv_rn(xn.x * m, den), __fdiv_rn(xn.y * m, den)};
+#else
+    const float inv = fast_rcp(fast_abs(xn) + 1e-16f);
     xn = v2f{(xn.x * m) * inv, (xn.y * m) * inv};
+#endif
     p = xn;
     u = un;
     return (xn + un) * a.inv_scale;
@@ -941,7 +966,7 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = (acc[i] + z[i]) * envp[64u * i + ulane];
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
     }
 #if SPECINV_PRIO & 4
     __builtin_amdgcn_s_setprio(0);
@@ -959,7 +984,7 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
     const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
     v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-    for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[i] * envp[64u * i + ulane];
+    for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[i], envp[64u * i + ulane]);
   } else {
     // what this chunk's last three frames contribute to the next chunk's first three hop-blocks
     v2f* tl = reinterpret_cast<v2f*>(a.xtail_out + ((long long)b * a.nchunks + c) * 3 * HOP);
@@ -967,7 +992,7 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
     for (int q = 0; q < 3; ++q) {
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + (long long)(t_end + q - 2) * HOP);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = acc[q * QU + i] * envp[64u * i + ulane];
+      for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
     }
   }
   if (EVAL) {
@@ -1173,7 +1198,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = (acc[i] + z[i]) * envp[64u * i + ulane];
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
     }
 #pragma unroll
     for (int i = 0; i < QU; ++i) {
@@ -1190,7 +1215,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[q * QU + i] * envp[64u * i + ulane];
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
     }
   } else {
     // what this chunk's last NB frames contribute to the next chunk's first NB hop-blocks
@@ -1199,7 +1224,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
     for (int q = 0; q < NB; ++q) {
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + (long long)(t_end + q - PB) * HOP);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = acc[q * QU + i] * envp[64u * i + ulane];
+      for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
     }
   }
   if (EVAL) {
@@ -1283,7 +1308,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = (acc[i] + z[i]) * envp[64u * i + ulane];
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
     }
 #pragma unroll
     for (int i = 0; i < QU; ++i) {
@@ -1299,7 +1324,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = acc[q * QU + i] * envp[64u * i + ulane];
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
     }
   }
 }
@@ -1453,7 +1478,7 @@ __global__ void k_mag_to_pairs(const float* __restrict__ mag, v4f* __restrict__ 
 
 __global__ void k_reciprocal(const float* __restrict__ in, float* __restrict__ out, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = 1.0f / in[i];
+  if (i < n) out[i] = SPECINV_IEEE ? in[i] : 1.0f / in[i];
 }
 
 }  // namespace fast
@@ -1463,11 +1488,17 @@ struct FastBuf {
   void* p = nullptr;
   size_t bytes = 0;
   ~FastBuf() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      account_bytes(-(int64_t)bytes);
+    }
   }
   int reserve(size_t n) {
     if (p && n <= bytes) return SPECINV_OK;
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      account_bytes(-(int64_t)bytes);
+    }
     p = nullptr;
     bytes = 0;
     hipError_t e = hipMalloc(&p, n ? n : 16);
@@ -1476,6 +1507,7 @@ struct FastBuf {
       return fail(SPECINV_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
     }
     bytes = n;
+    account_bytes((int64_t)n);
     return SPECINV_OK;
   }
   template <typename U>
@@ -1490,6 +1522,7 @@ struct FastState {
   bool xform_ok = false;
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
+  void geometry(int out[4]) const { out[0] = out[1] = out[2] = out[3] = 0; }
   template <typename P>
   int launch_xform(P&, bool, const T*, long long, void*, T*, T, int = -1) { return fail(SPECINV_EUNSUPPORTED, "no fused path"); }
   template <typename P>
@@ -1527,6 +1560,7 @@ struct FastState<float> {
   int R = 0;
   int OV = 0;          // n_fft / hop of the fused kernel (2, 4 or 8)
   bool state_in_place = true;
+  bool use_template = false;   // tests: run k_fused<R, 4> where the tuned copy k_fused4<R> would run (SPECINV_FUSED_TEMPLATE=1)
   int chunk = 32, nchunks = 0, n_waves = 0, n_partials = 0;
   int cur = 0;   // index of the buffers holding the current state
   int mode = fast::MODE_GLA;
@@ -1548,6 +1582,8 @@ struct FastState<float> {
     semi = false;
     state_in_place = true;     // (same speed as ping-pong buffers, measured; a third less memory)
     if (const char* e = getenv("SPECINV_STATE_INPLACE")) state_in_place = e[0] != '0';
+    use_template = false;
+    if (const char* e = getenv("SPECINV_FUSED_TEMPLATE")) use_template = e[0] == '1';
     // fused kernel: hop = n_fft / 2, / 4 or / 8 (whole registers per hop-block), centred, enough frames
     OV = 0;
     for (int o : {2, 4, 8})
@@ -1835,29 +1871,42 @@ struct FastState<float> {
   }
   FastBuf hop_inv_tail, hop_inv_margins;
 
+  // waves per workgroup of the fused iteration kernel: k_fused4 takes 8-wave workgroups (one per CU) once every wave
+  // slot is filled; fewer waves than slots: smaller workgroups reach more CUs
+  int fused_wgw() const {
+    if ((R == 8 || R == 16) && OV == 4 && !use_template) return n_waves >= 2048 ? SPECINV_WGW : 4;
+    return 4;
+  }
+  // {waves per workgroup, chunks per item, waves, kernel: 1 k_fused4, 2 k_fused<R, OV>, 3 k_semi, 4 k_hop}
+  void geometry(int out[4]) const {
+    if (semi) {
+      out[0] = hopk ? 8 : 4;
+      out[3] = hopk ? 4 : 3;
+    } else {
+      out[0] = fused_wgw();
+      out[3] = ((R == 8 || R == 16) && OV == 4 && !use_template) ? 1 : 2;
+    }
+    out[1] = nchunks;
+    out[2] = n_waves;
+  }
+
   template <int RR, int MODE, bool EVAL, typename P>
   int launch(P& pl, const fast::FastArgs& a) {
     using G = fast::Geo<RR>;
-    const size_t lds = G::lds_bytes(4);
     const void* fn = nullptr;
     if constexpr (RR % 8 == 0) {
       if (OV == 8) fn = (const void*)fast::k_fused<RR, 8, MODE, EVAL>;
     }
     if constexpr (RR == 8 || RR == 16) {
-      if (OV == 4) fn = (const void*)fast::k_fused4<RR, MODE, EVAL>;     // the tuned copy for the headline shapes
+      if (OV == 4)                                                       // the tuned copy for the headline shapes
+        fn = use_template ? (const void*)fast::k_fused<RR, 4, MODE, EVAL> : (const void*)fast::k_fused4<RR, MODE, EVAL>;
     } else {
       if (OV == 4) fn = (const void*)fast::k_fused<RR, 4, MODE, EVAL>;
     }
     if (OV == 2) fn = (const void*)fast::k_fused<RR, 2, MODE, EVAL>;
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
-    int wgw = 4;
-    size_t lds_used = lds;
-    if constexpr (RR == 8 || RR == 16) {
-      if (OV == 4) {
-        wgw = n_waves >= 2048 ? SPECINV_WGW : 4;     // fewer waves than slots: smaller workgroups reach more CUs
-        lds_used = G::lds_bytes(wgw);
-      }
-    }
+    const int wgw = fused_wgw();
+    const size_t lds_used = G::lds_bytes(wgw);
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
     fast::FastArgs args = a;
     void* kargs[] = {&args};

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
         const float v = ring[i];
         ring[i] = 0.0f;
         const long long p = p0 + j, n = p - s.pad;
-        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? v : v * env[n];
+        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? v : env_apply(v, env[n]);
       }
       slot0 += hop;
       if (slot0 >= N) slot0 -= N;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
         int i = slot0 + j;
         if (i >= N) i -= N;
         const long long p = p0 + j, n = p - s.pad;
-        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? ring[i] : ring[i] * env[n];
+        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? ring[i] : env_apply(ring[i], env[n]);
       }
     } else {
       float* tl = s.xtail + ((long long)b * a.nchunks + c) * keep;
@@ -572,7 +572,7 @@ __global__ void k_hop_tails(float* __restrict__ x, const float* __restrict__ xta
   const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
   if (n < 0 || n >= L) return;
   float* px = x + b * L + n;
-  *px = (*px + xtail[(b * nchunks + (c - 1)) * keep + j]) * env[n];
+  *px = env_apply(*px + xtail[(b * nchunks + (c - 1)) * keep + j], env[n]);
 }
 
 }  // namespace fast

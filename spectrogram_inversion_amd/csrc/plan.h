@@ -18,11 +18,13 @@ struct PlanBase {
   hipStream_t stream = nullptr;
   Method method = Method::None;
   bool force_generic = false;
+  int64_t dev_bytes = 0;   // device memory held by the plan's buffers (account_bytes)
 
   virtual ~PlanBase() = default;
   virtual int setup() = 0;
   virtual bool fast_path() const = 0;
   virtual int path_kind() const = 0;   // 0 generic, 1 fused, 2 frame kernel + overlap-add
+  virtual void launch_geometry(int out[4]) const = 0;
 
   virtual int stft(const void* x, int64_t len, void* spec_out) = 0;
   virtual int istft(const void* spec, void* x_out) = 0;

@@ -23,7 +23,10 @@ struct DevBuf {
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      account_bytes(-(int64_t)bytes);
+    }
     p = nullptr;
     bytes = 0;
   }
@@ -38,6 +41,7 @@ struct DevBuf {
       return fail(SPECINV_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
     }
     bytes = n;
+    account_bytes((int64_t)n);
     return SPECINV_OK;
   }
   template <typename U>
@@ -183,6 +187,16 @@ struct PlanT final : PlanBase {
 
   bool fast_path() const override { return fast.supported && !force_generic; }
   int path_kind() const override { return fast_path() ? (fast.semi ? (fast.hopk ? 3 : 2) : 1) : 0; }
+  void launch_geometry(int out[4]) const override {
+    if (fast_path()) {
+      fast.geometry(out);
+    } else {                                   // generic: one workgroup per frame pair
+      out[0] = frame_threads() / 64;
+      out[1] = (Tn() + 1) / 2;
+      out[2] = out[0] * out[1] * B();
+      out[3] = 0;
+    }
+  }
 
   // ------------------------------------------------------------------------------------
   // layout helpers: user (B, F, T) <-> internal (B, T, F)
@@ -614,7 +628,13 @@ struct PlanT final : PlanBase {
     return SPECINV_OK;
   }
 
+  // RTISI-LA stages its target and its committed frames in the buffers that hold the target / frame scratch of a
+  // running griffin_lim / ADMM state: such a state ends here (a later iterate() fails with SPECINV_ESTATE instead of
+  // iterating against the wrong target)
+  void rtisi_takes_buffers() { method = Method::None; }
+
   int rtisi_run(const void* magp, int look_ahead, int asym, int max_iter, double alpha, void* x_out) override {
+    rtisi_takes_buffers();
     return rtisi_launch(*this, static_cast<const T*>(magp), look_ahead, asym, max_iter, alpha, static_cast<T*>(x_out));
   }
 
@@ -625,19 +645,23 @@ struct PlanT final : PlanBase {
   }
   int rtisi_run_recorded(const void* magp, int look_ahead, int asym, int max_iter, double alpha, void* x_out,
                          void* rec_out) override {
+    rtisi_takes_buffers();
     return rtisi_launch_recorded(*this, static_cast<const T*>(magp), look_ahead, asym, max_iter, alpha,
                                  static_cast<T*>(x_out), static_cast<C*>(rec_out));
   }
   int rtisi_adjoint(const void* magp, const void* rec, const void* g_x, int look_ahead, int asym, int max_iter, double alpha,
                     void* gmag_out) override {
+    rtisi_takes_buffers();
     return rtisi_adjoint_launch(*this, static_cast<const T*>(magp), static_cast<const C*>(rec), static_cast<const T*>(g_x),
                                 look_ahead, asym, max_iter, alpha, static_cast<T*>(gmag_out));
   }
 
   int rtisi_stream_begin(int look_ahead, int asym, int max_iter, double alpha) override {
+    rtisi_takes_buffers();
     return specinv::rtisi_stream_begin(*this, rstream, look_ahead, asym, max_iter, alpha);
   }
   int rtisi_stream_push(const void* magp, int k, void* x_out, int64_t out_stride, int64_t* n_out) override {
+    rtisi_takes_buffers();
     return specinv::rtisi_stream_push(*this, rstream, static_cast<const T*>(magp), k, static_cast<T*>(x_out), out_stride, n_out);
   }
   int rtisi_stream_flush(void* x_out, int64_t out_stride, int64_t* n_out) override {

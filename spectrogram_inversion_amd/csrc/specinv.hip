@@ -116,6 +116,30 @@ int PlanBase::run_loop(int max_iter, int eva_iter, double tol, int metric, speci
 
 using namespace specinv;
 
+// Calls run on the plan's device; the calling thread's current device (which torch reads back with hipGetDevice) is
+// restored on every return path.
+struct DeviceGuard {
+  int prev = -1, want = -1;
+  hipError_t enter(int device, int64_t* sink = nullptr) {
+    want = device;
+    bytes_sink() = sink;
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) {
+      prev = -1;
+      return e;
+    }
+    if (prev == want) {
+      prev = -1;                // nothing to restore
+      return hipSuccess;
+    }
+    return hipSetDevice(want);
+  }
+  ~DeviceGuard() {
+    bytes_sink() = nullptr;
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 #define PLAN_OR_FAIL(p) SI_CHECK((p) != nullptr && (p)->impl, SPECINV_EINVAL, "plan is NULL")
 
 extern "C" {
@@ -130,7 +154,10 @@ int specinv_plan_create(const specinv_stft_cfg* cfg, specinv_plan** out) {
   SI_CHECK(p, SPECINV_ENOMEM, "out of host memory");
   p->impl = cfg->dtype == SPECINV_F32 ? make_plan_f32() : make_plan_f64();
   p->impl->cfg = *cfg;
+  DeviceGuard guard_;                     // setup() selects the plan's device
+  (void)guard_.enter(cfg->device, &p->impl->dev_bytes);
   const int rc = p->impl->setup();
+  bytes_sink() = nullptr;                 // (p may be deleted below)
   if (rc != SPECINV_OK) {
     delete p;
     return rc;
@@ -141,7 +168,8 @@ int specinv_plan_create(const specinv_stft_cfg* cfg, specinv_plan** out) {
 
 int specinv_plan_destroy(specinv_plan* plan) {
   if (plan) {
-    if (plan->impl) (void)hipSetDevice(plan->impl->cfg.device);
+    DeviceGuard guard_;
+    if (plan->impl) (void)guard_.enter(plan->impl->cfg.device);
     delete plan;
   }
   return SPECINV_OK;
@@ -156,6 +184,14 @@ int specinv_plan_set_stream(specinv_plan* plan, void* hip_stream) {
 int specinv_plan_n_freq(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->n_freq : SPECINV_EINVAL; }
 int64_t specinv_plan_length(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->length : SPECINV_EINVAL; }
 int specinv_plan_fast_path(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->path_kind() : SPECINV_EINVAL; }
+int64_t specinv_plan_device_bytes(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->dev_bytes : SPECINV_EINVAL; }
+int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]) {
+  SI_CHECK(plan != nullptr && plan->impl && out, SPECINV_EINVAL, "null argument");
+  int g[4] = {0, 0, 0, 0};
+  plan->impl->launch_geometry(g);
+  for (int i = 0; i < 4; ++i) out[i] = g[i];
+  return SPECINV_OK;
+}
 int specinv_plan_force_generic(specinv_plan* plan, int on) {
   PLAN_OR_FAIL(plan);
   SI_CHECK(plan->impl->method == Method::None, SPECINV_ESTATE, "cannot switch paths while a method is running");
@@ -165,7 +201,8 @@ int specinv_plan_force_generic(specinv_plan* plan, int on) {
 
 #define ENTER(plan)                                 \
   PLAN_OR_FAIL(plan);                               \
-  SI_HIP(hipSetDevice((plan)->impl->cfg.device))
+  DeviceGuard guard_;                               \
+  SI_HIP(guard_.enter((plan)->impl->cfg.device, &(plan)->impl->dev_bytes))
 
 int specinv_stft(specinv_plan* plan, const void* x, int64_t length, void* spec_out) {
   ENTER(plan);

@@ -18,6 +18,8 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from tqdm import tqdm
+
 from . import _lib
 from .metrics import _from_sums
 
@@ -115,3 +117,111 @@ def run_loop_global(plan, max_iter, eva_iter=10, tol=0.0, metric="sc", callback=
             break
         previous = loss
     return done, evals
+
+
+# ---- one-call sharded inversions ---------------------------------------------------------------------------
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _device_plan(spec_local, stft_kwargs):
+    """The HIP plan of this rank's shard on the current device."""
+    from .plan import args_helper, get_plan, require_gpu
+    args = args_helper(spec_local, **stft_kwargs)
+    if args.complex_window:
+        raise RuntimeError("complex windows are not supported (torch_specinv/methods.py:127 raises on them too)")
+    device = require_gpu(spec_local.device if spec_local.device.type == "cuda" else None)
+    rdtype = spec_local.real.dtype if spec_local.is_complex() else spec_local.dtype
+    return get_plan(args, spec_local.shape[0], spec_local.shape[2], rdtype, device)
+
+
+def _sharded(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, dst, group, spec_is_local, plan_factory,
+             stft_kwargs):
+    assert eva_iter > 0 and max_iter > 0 and tol >= 0
+    assert isinstance(metric, str) and metric.upper() in _lib.METRICS
+    assert spec.dim() == 3, "sharded inversion takes a (B, F, T) batch"
+    world, rank = _world(group)
+    if spec_is_local:
+        local = spec
+    else:
+        assert spec.shape[0] >= world, "fewer items than ranks"
+        lo, hi = shard_bounds(spec.shape[0], world, rank)
+        local = spec[lo:hi]
+    plan = (plan_factory or _device_plan)(local, stft_kwargs)
+    if local.device != plan.device:
+        local = local.to(plan.device)
+    init = getattr(plan, which + "_init")
+    if local.is_complex():
+        init(local, None, coef)              # warm start, target = |spec| (methods.py:110)
+    else:
+        init(None, local, coef)              # phase_init on the device (methods.py:106)
+    watch = (verbose and rank == dst) or tol > 0
+    if world == 1 or not watch:
+        # nothing couples the ranks before the gather: the library's own loop (evaluations stay on the device
+        # when tol == 0 and nobody watches)
+        if world == 1 and verbose:
+            name = metric.upper()
+            with tqdm(total=max_iter) as pbar:
+                def cb(_i, m, loss):
+                    pbar.set_postfix(**{name: m}, loss=loss)
+                    pbar.update(eva_iter)
+                    return 0
+                done, evals = plan.run(max_iter, eva_iter, tol, metric, callback=cb)
+        else:
+            done, evals = plan.run(max_iter, eva_iter, tol, metric)
+    else:
+        # `_training_loop`'s metric and stop rule are whole-batch quantities (methods.py:181-190): every evaluation
+        # all-reduces the three sums, every rank takes the same decision at the same iteration.  (`verbose` must be
+        # the same on all ranks - the bar itself is only drawn by `dst`.)
+        name = metric.upper()
+        with tqdm(total=max_iter, disable=not (verbose and rank == dst)) as pbar:
+            def cb(_i, m, loss):
+                pbar.set_postfix(**{name: m}, loss=loss)
+                pbar.update(eva_iter)
+                return 0
+            done, evals = run_loop_global(plan, max_iter, eva_iter, tol, metric, callback=cb, group=group)
+    x = gather_waveforms(plan.wave(), dst=dst, group=group) if world > 1 else plan.wave()
+    return x, done, evals
+
+
+def griffin_lim_sharded(spec, max_iter=200, tol=1e-6, alpha=0.99, verbose=True, eva_iter=10, metric="sc", dst=0,
+                        group=None, spec_is_local=False, return_info=False, _plan_factory=None, **stft_kwargs):
+    r"""`griffin_lim` (torch_specinv/methods.py:193-270) over all ranks of `group`: the (B, F, T) batch is split into
+    contiguous shards (`shard_bounds`), every rank inverts its shard on its own GPU, the whole-batch metric / early-stop
+    rule of `_training_loop` (:181-190) is kept by all-reducing three sums per evaluation (only when `tol > 0` or
+    progress is shown), and one RCCL gather brings the (B, L) waveforms to rank `dst`.  Call it on every rank with the
+    same arguments; `spec` is the whole batch (or this rank's shard with `spec_is_local=True`).  Returns the waveforms
+    on `dst`, None elsewhere (with `return_info`: also the iterations done and the evaluation trace)."""
+    assert alpha >= 0
+    x, done, evals = _sharded("gla", spec, alpha, max_iter, tol, verbose, eva_iter, metric, dst, group, spec_is_local,
+                              _plan_factory, stft_kwargs)
+    return (x, done, evals) if return_info else x
+
+
+def ADMM_sharded(spec, max_iter=1000, tol=1e-6, rho=0.1, verbose=1, eva_iter=10, metric="sc", dst=0, group=None,
+                 spec_is_local=False, return_info=False, _plan_factory=None, **stft_kwargs):
+    r"""`ADMM` (torch_specinv/methods.py:415-506) sharded like `griffin_lim_sharded` - BASELINE.json's configs[3]."""
+    x, done, evals = _sharded("admm", spec, rho, max_iter, tol, verbose, eva_iter, metric, dst, group, spec_is_local,
+                              _plan_factory, stft_kwargs)
+    return (x, done, evals) if return_info else x
+
+
+def RTISI_LA_sharded(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, alpha=0.99, dst=0, group=None,
+                     spec_is_local=False, **stft_kwargs):
+    r"""`RTISI_LA` (torch_specinv/methods.py:273-412) sharded over the batch: items are independent and there is no
+    whole-batch rule, so the only exchange is the final gather."""
+    from .methods import RTISI_LA
+    assert spec.dim() == 3, "sharded inversion takes a (B, F, T) batch"
+    world, rank = _world(group)
+    local = spec
+    if not spec_is_local:
+        lo, hi = shard_bounds(spec.shape[0], world, rank)
+        local = spec[lo:hi]
+    from .plan import require_gpu
+    dev = require_gpu(local.device if local.device.type == "cuda" else None)
+    x = RTISI_LA(local.to(dev), look_ahead, asymmetric_window, max_iter, alpha, verbose=False, **stft_kwargs)
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    return gather_waveforms(x, dst=dst, group=group) if world > 1 else x

@@ -200,7 +200,9 @@ class LBFGS:
         stalled = False
         lo, hi = (0, 1) if br[0][1] <= br[-1][1] else (1, 0)
         while not done and it < max_ls:
-            if abs(br[1][0] - br[0][0]) * d_norm < self.tol_change:
+            # torch.optim.LBFGS.step does not forward its tolerance_change to the line search: the bracket test always
+            # uses _strong_wolfe's own default of 1e-9
+            if abs(br[1][0] - br[0][0]) * d_norm < 1e-9:
                 break
             t = _cubic_step(br[0][0], br[0][1], br[0][3], br[1][0], br[1][1], br[1][3])
             bmax, bmin = max(br[0][0], br[1][0]), min(br[0][0], br[1][0])

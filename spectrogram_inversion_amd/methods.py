@@ -12,6 +12,8 @@ Differences that are deliberate:
 """
 from __future__ import annotations
 
+import inspect
+
 import torch
 from tqdm import tqdm
 
@@ -36,6 +38,15 @@ def _finish(x, spec, out_device):
     return x.to(out_device)
 
 
+def _no_complex_window(args):
+    """The reference gets as far as its first overlap-add with a complex window and fails there: conv_transpose1d of
+    the real frames with the complex `diag(window)` weight (methods.py:95,127), `asym_window1 += window` in RTISI_LA
+    (:327).  Same exception type here, before any work is queued.  (`phase_init` never reads the window: it accepts one.)"""
+    if args.complex_window:
+        raise RuntimeError("complex windows are not supported: the reference's overlap-add (F.conv_transpose1d of real "
+                           "frames with a complex diag(window) weight, torch_specinv/methods.py:127) raises on them too")
+
+
 def _run_loop(plan, max_iter, tol, verbose, eva_iter, metric):
     """Drives the library's `_training_loop` (methods.py:153-190) and mirrors its tqdm bar."""
     assert eva_iter > 0
@@ -55,6 +66,7 @@ def _iterative(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, stft
     spec3 = _format_spec(spec)
     real_in = not spec3.is_complex()
     args = args_helper(spec3, **stft_kwargs)
+    _no_complex_window(args)
     device = require_gpu(spec3.device)
     rdtype = spec3.real.dtype if spec3.is_complex() else spec3.dtype
     plan = get_plan(args, spec3.shape[0], spec3.shape[2], rdtype, device)
@@ -100,25 +112,56 @@ def ADMM(spec, max_iter=1000, tol=1e-6, rho=0.1, verbose=1, eva_iter=10, metric=
     return _iterative("admm", spec, rho, max_iter, tol, verbose, eva_iter, metric, stft_kwargs)
 
 
+_STFT_KWARGS = tuple(p for p in inspect.signature(torch.stft).parameters if p not in ("input", "n_fft"))
+
+
 def RTISI_LA(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, alpha=0.99, verbose=1, **stft_kwargs):
     r"""Real-Time Iterative Spectrogram Inversion with Look-Ahead (reference: methods.py:273-412).
 
-    The whole frame-serial recursion runs inside one kernel launch per batch (one workgroup
-    per batch item), so `verbose` has no per-frame progress to show.
+    The whole frame-serial recursion runs inside one kernel launch per batch (one workgroup per batch item).  With
+    `verbose` the frames are fed in blocks through the resumable form of the same kernel (`specinv_rtisi_stream_push`,
+    the same samples bit for bit) and the bar advances per block; the reference's bar counts the same
+    `frames + look_ahead` steps (:362,400).
     """
     assert max_iter > 0
     assert alpha >= 0
     assert not spec.is_complex()
     spec3 = _format_spec(spec)
     args = args_helper(spec3, **stft_kwargs)
+    if not asymmetric_window:
+        # this branch of the reference hands the caller's kwargs to torch.stft as they are (:308-310,385): a name
+        # torch.stft does not know is a TypeError there, not a silently dropped one
+        for key in stft_kwargs:
+            if key not in _STFT_KWARGS:
+                raise TypeError(f"stft() got an unexpected keyword argument '{key}'")
+    _no_complex_window(args)
     device = require_gpu(spec3.device)
-    plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
     if torch.is_grad_enabled() and spec.requires_grad:
         from .autograd import rtisi_differentiable
+        plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
         x = rtisi_differentiable(spec3.to(device), plan, look_ahead, asymmetric_window, max_iter, alpha)
+    elif verbose and spec3.shape[2] >= 32:
+        x = _rtisi_with_progress(spec3.to(device), look_ahead, asymmetric_window, max_iter, alpha, stft_kwargs)
     else:
+        plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
         x = plan.rtisi(spec3, look_ahead, asymmetric_window, max_iter, alpha)
     return _finish(x, spec, spec.device)
+
+
+def _rtisi_with_progress(spec3, look_ahead, asymmetric_window, max_iter, alpha, stft_kwargs):
+    from .streaming import RTISIStream
+    frames = spec3.shape[2]
+    block = min(64, max(8, frames // 16))
+    stream = RTISIStream(spec3.shape[1], spec3.shape[0], look_ahead, asymmetric_window, max_iter, alpha, max_push=block,
+                         dtype=spec3.dtype, device=spec3.device, **stft_kwargs)
+    pieces = []
+    with tqdm(total=frames + stream.look_ahead) as pbar:                  # methods.py:362
+        for j in range(0, frames, block):
+            pieces.append(stream.push(spec3[:, :, j:j + block]))
+            pbar.update(min(block, frames - j))
+        pieces.append(stream.flush())
+        pbar.update(stream.look_ahead)
+    return torch.cat(pieces, 1)
 
 
 def phase_init(spec, **stft_kwargs):
@@ -151,8 +194,12 @@ def L_BFGS(spec, transform_fn, samples=None, init_x0=None, outer_max_iter=1000, 
     device = require_gpu(spec.device)
     if init_x0 is None:
         init_x0 = spec.new_empty(*samples).normal_(std=1e-6)             # methods.py:538
-    out_device = init_x0.device
-    x = init_x0.detach().to(device=device).clone().contiguous()
+    # the reference optimises `nn.Parameter(init_x0)` (methods.py:539), i.e. the caller's tensor in place, and returns
+    # a view of it (:569): same here - straight on its storage when it already lives on the device, through a
+    # staging copy otherwise
+    x0 = init_x0.detach()
+    in_place = x0.device == device and x0.is_contiguous() and x0.dtype in (torch.float32, torch.float64)
+    x = x0 if in_place else x0.to(device=device).clone().contiguous()
     target = spec.detach().to(device)
 
     if isinstance(transform_fn, DeviceTransform):
@@ -188,4 +235,6 @@ def L_BFGS(spec, transform_fn, samples=None, init_x0=None, outer_max_iter=1000, 
                 elif (previous_loss - l2) / init_loss < tol and previous_loss > l2:
                     break
                 previous_loss = l2
-    return x.to(out_device)
+    if not in_place:
+        x0.copy_(x)
+    return x0

@@ -4,6 +4,7 @@ C ABI.  torch is used for device memory and streams only."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from collections import OrderedDict
 from dataclasses import dataclass
@@ -29,6 +30,7 @@ class StftArgs:
     pad_mode: str
     normalized: bool
     onesided: bool
+    complex_window: bool = False
 
     @property
     def n_freq(self):
@@ -67,8 +69,13 @@ def args_helper(spec: torch.Tensor, **stft_kwargs) -> StftArgs:
     if window is None:                                                # :76-77
         window = torch.ones(win_length, dtype=dtype)
     assert n_fft >= win_length                                        # :79
-    if window.is_complex():
-        raise NotImplementedError("complex windows are not supported on the device path")
+    # A complex window only decides `onesided` (:59-63) as far as the reference gets: phase_init never touches the
+    # window values (:592-605), and griffin_lim / ADMM / RTISI_LA raise RuntimeError on it (conv_transpose1d of the
+    # real frames with the complex diag(window) weight, :95,127; `asym_window1 += window`, :327).  The plan keeps
+    # |window| so that phase_init has its shape; the iterative entry points refuse (methods._no_complex_window).
+    complex_window = bool(window.is_complex())
+    if complex_window:
+        window = window.detach().abs()
     window = window.detach().to(device="cpu", dtype=dtype).reshape(-1)
     assert window.numel() == win_length
     if n_fft > win_length:                                            # :80-83
@@ -77,7 +84,7 @@ def args_helper(spec: torch.Tensor, **stft_kwargs) -> StftArgs:
         window = torch.nn.functional.pad(window, [left, right])
         win_length = n_fft
     return StftArgs(int(n_fft), int(win_length), int(hop_length), window.contiguous(), bool(center),
-                    str(pad_mode), bool(normalized), bool(onesided))
+                    str(pad_mode), bool(normalized), bool(onesided), complex_window)
 
 
 def require_gpu(device: torch.device | None = None) -> torch.device:
@@ -116,11 +123,14 @@ class Plan:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            try:
-                self.lib.specinv_plan_destroy(h)
-            except Exception:
-                pass
+        destroy = getattr(getattr(self, "lib", None), "specinv_plan_destroy", None)
+        if h and destroy is not None:          # (None only while the interpreter is being torn down)
+            destroy(h)
+
+    @property
+    def device_bytes(self) -> int:
+        """Device memory the plan's buffers hold right now (`specinv_plan_device_bytes`)."""
+        return int(self.lib.specinv_plan_device_bytes(self._h))
 
     # -- helpers ------------------------------------------------------------------------
     def _sync_stream(self):
@@ -151,6 +161,14 @@ class Plan:
         """`specinv_plan_fast_path`: 0 generic, 1 fused, 2 frame kernel + gather overlap-add, 3 frame kernel over chunks
         of frames with the overlap-add in LDS."""
         return self.lib.specinv_plan_fast_path(self._h)
+
+    @property
+    def launch_geometry(self) -> dict:
+        """Diagnostics: how the iteration kernel is launched (`specinv_plan_launch_geometry`)."""
+        out = (C.c_int32 * 4)()
+        _lib.check(self.lib.specinv_plan_launch_geometry(self._h, out))
+        kernel = ("k_iter_pair", "k_fused4", "k_fused", "k_semi", "k_hop")[out[3]]
+        return {"waves_per_workgroup": out[0], "chunks": out[1], "waves": out[2], "kernel": kernel}
 
     def force_generic(self, on=True):
         _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))
@@ -459,9 +477,12 @@ class Plan:
 
 
 # small LRU of plans so that repeated calls with one configuration reuse device state.  A plan carries the state of one
-# run, so it must not be shared by two threads: the cache is per thread.
+# run, so it must not be shared by two threads: the cache is per thread.  It is bounded by count and by the device
+# memory the cached plans hold (a BASELINE C2 plan is 1.2 GB): least recently used plans go first, the plan just
+# asked for always stays.
 _TLS = threading.local()
 _CACHE_MAX = 4
+_CACHE_MAX_BYTES = int(float(os.environ.get("SPECINV_PLAN_CACHE_GB", "4")) * (1 << 30))
 
 
 def _cache() -> "OrderedDict[tuple, Plan]":
@@ -479,10 +500,11 @@ def get_plan(args: StftArgs, batch: int, n_frames: int, dtype: torch.dtype, devi
     if plan is None:
         plan = Plan(args, batch, n_frames, dtype, device)
         cache[key] = plan
-        while len(cache) > _CACHE_MAX:
-            cache.popitem(last=False)
     else:
         cache.move_to_end(key)
+    # (plans grow as they are used, so the byte bound is re-checked on every request)
+    while len(cache) > 1 and (len(cache) > _CACHE_MAX or sum(p.device_bytes for p in cache.values()) > _CACHE_MAX_BYTES):
+        cache.popitem(last=False)
     return plan
 
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .plan import StftArgs, get_plan, require_gpu
+from .plan import Plan, StftArgs, require_gpu
 
 
 class DeviceTransform:
@@ -25,6 +25,7 @@ class DeviceTransform:
         self.n_fft, self.hop_length, self.win_length = int(n_fft), int(hop_length), int(win_length)
         self.window = window
         self.center, self.pad_mode, self.normalized, self.onesided = bool(center), pad_mode, bool(normalized), bool(onesided)
+        self._plans = {}
 
     def _args(self, dtype) -> StftArgs:
         w = self.window
@@ -42,10 +43,18 @@ class DeviceTransform:
         return None
 
     def _plan(self, x2):
-        args = self._args(x2.dtype)
+        """The transform's own plan for this signal shape: a plan carries the transform kind and the (tiled) filterbank
+        as state, so it is never taken from the cache the iterative methods share, and it is set up once."""
         device = require_gpu(x2.device)
-        plan = get_plan(args, x2.shape[0], args.frame_count(x2.shape[1]), x2.dtype, device)
-        plan.transform_setup(self.kind, self._mel())
+        key = (tuple(x2.shape), x2.dtype, str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            args = self._args(x2.dtype)
+            plan = Plan(args, x2.shape[0], args.frame_count(x2.shape[1]), x2.dtype, device)
+            plan.transform_setup(self.kind, self._mel())
+            if len(self._plans) >= 2:                  # a transform is normally used at one shape
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = plan
         return plan
 
     def __call__(self, x):

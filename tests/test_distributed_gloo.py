@@ -1,5 +1,7 @@
-"""The N > 1 path on CPU: two gloo processes shard a batch, run the (oracle-backed) per-rank inversion,
-all-reduce the evaluation sums and gather the waveforms - the same host code the RCCL runs use."""
+"""The N > 1 path on CPU: two gloo processes shard a batch through the one-call entry points
+(`griffin_lim_sharded`, `ADMM_sharded`), run the (oracle-backed) per-rank inversion, all-reduce the evaluation
+sums and gather the waveforms - the same host code the RCCL runs use (`tests/test_gpu_nccl.py` drives it with the
+HIP plan on a real device)."""
 import os
 import sys
 
@@ -13,18 +15,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OraclePlan:
-    """Stands in for spectrogram_inversion_amd.plan.Plan on CPU (test-only): iterate() steps the oracle's
-    Griffin-Lim state and returns the same four sums the HIP plan returns."""
+    """Stands in for spectrogram_inversion_amd.plan.Plan on CPU (test-only): the same `gla_init` / `admm_init` /
+    `iterate` / `run` / `wave` surface, stepping the oracle's Griffin-Lim / ADMM state; iterate() returns the same
+    four sums the HIP plan returns."""
 
-    def __init__(self, mag, hop, window, alpha):
+    def __init__(self, mag_like, stft_kwargs):
         import oracle
         self.o = oracle
         self.device = torch.device("cpu")
-        self.a = oracle.args_helper(mag.shape[1], np.float32, hop_length=hop, window=window)
-        self.target = mag
-        self.pre = oracle.phase_init(mag, hop_length=hop, window=window)
-        self.x, self.env = oracle.istft(self.pre, self.a)
+        self.kw = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in stft_kwargs.items()}
+        self.a = oracle.args_helper(mag_like.shape[1], np.float32, **self.kw)
+
+    def _init(self, init_spec, mag):
+        o = self.o
+        if init_spec is not None:
+            c = init_spec.numpy()
+            self.target = np.abs(c)
+        else:
+            self.target = mag.numpy()
+            c = o.phase_init(self.target, **self.kw)
+        self.x, self.env = o.istft(c, self.a)
+        return c
+
+    def gla_init(self, init_spec, mag, alpha):
+        self.pre = self._init(init_spec, mag)
         self.lr = np.float32(alpha / (1 + alpha))
+        self.method = "gla"
+
+    def admm_init(self, init_spec, mag, rho):
+        c = self._init(init_spec, mag)
+        self.X, self.Y, self.U = c, c.copy(), np.zeros_like(c)
+        self.rho = np.float32(rho)
+        self.method = "admm"
 
     def iterate(self, n, eval_last=False):
         o = self.o
@@ -32,9 +54,17 @@ class OraclePlan:
         for _ in range(n):
             new = o.stft(self.x.astype(np.float32), self.a)
             out = np.abs(new)
-            new = new - self.pre * self.lr
-            self.pre = new
-            new = new * self.target / (np.abs(new) + np.float32(1e-16))
+            if self.method == "gla":
+                new = new - self.pre * self.lr
+                self.pre = new
+                new = new * self.target / (np.abs(new) + np.float32(1e-16))
+            else:
+                z = (self.rho * self.Y + new) / (np.float32(1) + self.rho)
+                u = self.U + self.X - z
+                x_ = z - u
+                x_ = x_ * self.target / (np.abs(x_) + np.float32(1e-16))
+                self.X, self.U, self.Y = x_, u, x_ + u
+                new = self.Y
             self.x, _ = o.istft(new, self.a, envelope=self.env)
         if eval_last:
             d = out.astype(np.float64) - self.target
@@ -42,32 +72,70 @@ class OraclePlan:
                     float((self.target.astype(np.float64) ** 2).sum()), float(out.size)]
         return None
 
+    def run(self, max_iter, eva_iter=10, tol=0.0, metric="sc", callback=None):
+        """Rank-local `_training_loop` (what `Plan.run` does inside the library); only reached with tol == 0."""
+        from spectrogram_inversion_amd.metrics import _from_sums
+        assert tol == 0.0
+        done, evals = 0, []
+        while done < max_iter:
+            until = eva_iter - (done % eva_iter)
+            if done + until > max_iter:
+                self.iterate(max_iter - done)
+                done = max_iter
+                break
+            s = self.iterate(until, eval_last=True)
+            done += until
+            evals.append((done - 1, _from_sums(metric.upper(), s), s[0] / s[3]))
+        return done, evals
+
     def wave(self):
         return torch.from_numpy(self.x.astype(np.float32))
 
 
-def _worker(rank, world, port, tmp):
+def _factory(local, stft_kwargs):
+    return OraclePlan(local, stft_kwargs)
+
+
+def _hann(n):
+    return (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)).astype(np.float32)
+
+
+def _init(rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from spectrogram_inversion_amd.distributed import gather_waveforms, run_loop_global, shard_bounds
+
+
+def _worker(rank, world, port, tmp):
+    _init(rank, world, port)
+    from spectrogram_inversion_amd.distributed import ADMM_sharded, gather_waveforms, griffin_lim_sharded
     rng = np.random.default_rng(5)
     n_items, hop = 5, 64                                    # 5 items over 2 ranks: ragged shards (3 + 2)
-    mag = rng.random((n_items, 129, 12), dtype=np.float32)
-    win = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(256) / 256)).astype(np.float32)
-    lo, hi = shard_bounds(n_items, world, rank)
-    plan = OraclePlan(mag[lo:hi], hop, win, 0.3)
-    done, evals = run_loop_global(plan, 6, eva_iter=3, tol=0.0, metric="sc")
-    x = gather_waveforms(plan.wave(), dst=0)
+    mag = torch.from_numpy(rng.random((n_items, 129, 12), dtype=np.float32))
+    kw = dict(hop_length=hop, window=torch.from_numpy(_hann(256)))
+    out = {}
+    # (1) fixed iteration count, progress watched on rank 0 only: whole-batch sums by all-reduce
+    x, done, evals = griffin_lim_sharded(mag, max_iter=6, tol=0.0, alpha=0.3, verbose=False, eva_iter=3, return_info=True,
+                                         _plan_factory=_factory, **kw)
+    # the no-coupling branch returns each rank's LOCAL evaluation sums; the coupled one is asked for next
+    x2, done2, evals2 = griffin_lim_sharded(mag, max_iter=6, tol=1e-30, alpha=0.3, verbose=False, eva_iter=3,
+                                            return_info=True, _plan_factory=_factory, **kw)
+    # (2) ADMM with a tolerance that fires: both ranks must stop at the same iteration (methods.py:186-190)
+    y, done_a, evals_a = ADMM_sharded(mag, max_iter=60, tol=2e-2, rho=1.0, verbose=False, eva_iter=2, return_info=True,
+                                      _plan_factory=_factory, **kw)
+    both = [None, None]
+    dist.all_gather_object(both, (done_a, len(evals_a)))
+    assert both[0] == both[1], both
     if rank == 0:
-        np.savez(os.path.join(tmp, "out.npz"), x=x.numpy(), evals=np.array(evals), done=done)
+        np.savez(os.path.join(tmp, "out.npz"), x=x.numpy(), x2=x2.numpy(), evals2=np.array(evals2), done=done, done2=done2,
+                 y=y.numpy(), done_a=done_a, evals_a=np.array(evals_a))
     else:
-        assert x is None
+        assert x is None and x2 is None and y is None
     # equal shards take the dist.gather branch
-    y = gather_waveforms(torch.full((2, 7), float(rank)), dst=0)
+    z = gather_waveforms(torch.full((2, 7), float(rank)), dst=0)
     if rank == 0:
-        assert y.shape == (4, 7) and y[:2].eq(0).all() and y[2:].eq(1).all()
+        assert z.shape == (4, 7) and z[:2].eq(0).all() and z[2:].eq(1).all()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -90,21 +158,27 @@ def test_two_rank_sharded_inversion_matches_single_process(tmp_path):
     got = np.load(os.path.join(tmp_path, "out.npz"))
     rng = np.random.default_rng(5)
     mag = rng.random((5, 129, 12), dtype=np.float32)
-    win = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(256) / 256)).astype(np.float32)
+    win = _hann(256)
     trace = []
     ref = oracle.griffin_lim(mag, max_iter=6, alpha=0.3, tol=0, eva_iter=3, hop_length=64, window=win, trace=trace)
-    assert int(got["done"]) == 6
+    assert int(got["done"]) == 6 and int(got["done2"]) == 6
     np.testing.assert_allclose(got["x"], ref, rtol=1e-5, atol=1e-6)          # gathered in batch order
+    np.testing.assert_allclose(got["x2"], ref, rtol=1e-5, atol=1e-6)
     # whole-batch metric / loss (methods.py:181-182) from all-reduced per-rank sums
     want = np.array([[i, m, l] for i, m, l in trace])
-    np.testing.assert_allclose(got["evals"], want, rtol=1e-6)
+    np.testing.assert_allclose(got["evals2"], want, rtol=1e-6)
+    # ADMM, tolerance fires: the sharded run stops where the single-process whole-batch run stops
+    trace_a = []
+    ref_a, st = oracle.admm(mag, max_iter=60, rho=1.0, tol=2e-2, eva_iter=2, hop_length=64, window=win, trace=trace_a,
+                            return_state=True)
+    assert 2 < st["iters"] < 60, st["iters"]                                  # (the rule really fired)
+    assert int(got["done_a"]) == st["iters"]
+    np.testing.assert_allclose(got["y"], ref_a, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got["evals_a"], np.array([[i, m, l] for i, m, l in trace_a]), rtol=1e-6)
 
 
 def _async_worker(rank, world, port):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     from spectrogram_inversion_amd.distributed import gather_waveforms
     handles = [gather_waveforms(torch.full((3, 5), float(10 * k + rank)), dst=0, sizes=[3] * world, async_op=True)
                for k in range(3)]                       # several gathers in flight, completed later in order
