@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Griffin-Lim iterations*frames/s (BASELINE.json metric).
+"""Benchmarks of the BASELINE.json configurations on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): griffin_lim, batch 64 PER GPU (weak scaling),
-n_fft=2048, hop=512, n_frames=1024, 100 iterations, alpha=0.3, periodic Hann window,
-center/reflect, tol=0, eva_iter=10, metric 'sc'; magnitudes uniform[0,1) from
-default_rng(1234 + rank).  One "step" = one complete inversion of the batch:
-phase_init + initial ISTFT + 100 fused iterations (+ the RCCL gather of the waveforms to
-rank 0 when N > 1).  Inputs are resident in HBM before the timed region; plan creation is
-outside it.
+Default (the headline, BASELINE.json configs[1], "C2"): griffin_lim, batch 64 PER GPU (weak scaling),
+n_fft=2048, hop=512, n_frames=1024, 100 iterations, alpha=0.3, periodic Hann window, center/reflect, tol=0,
+eva_iter=10, metric 'sc'; magnitudes uniform[0,1) from default_rng(1234 + rank).  One "step" = one
+complete inversion of the batch: phase_init + initial ISTFT + 100 fused iterations (+ the RCCL gather of the
+waveforms to rank 0 when N > 1).  Inputs are resident in HBM before the timed region; plan creation is outside.
+
+Other workloads (`--workload`), same JSON contract:
+  C1  griffin_lim B=1 n_fft=1024 hop=256 T=512 50 it alpha=0 (the reference's CPU-runnable case)
+  C3  RTISI_LA B=32/GPU n_fft=2048 hop=512 T=1024 look_ahead=3 25 it (frame-serial per item; `--asym` for the
+      asymmetric-window form)
+  C4  ADMM B=32/GPU (256 over 8 GPUs) n_fft=1024 hop=256 T=2048 rho=0.1 200 it, batch-sharded + RCCL gather
+  C5  L_BFGS from 80-bin log-mel B=16 n_fft=2048 hop=512 T=1024: a step = `--outer` optimizer.step calls of 20
+      closure evaluations each (whole batch = one optimisation problem: replicas only for N > 1)
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
+        --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1 [--workload C4]
 
-Rank 0 prints ONE JSON line (see the driver contract) with `roofline` (dominant-kernel
-achieved HBM GB/s from HIP events on the launch stream) and `cpu_baseline` (the NumPy oracle
-timed on the host cores on a bounded sample of the same workload; N=1, rank 0 only).
+Rank 0 prints ONE JSON line (see the driver contract) with `roofline` (dominant-kernel achieved HBM GB/s from HIP
+events on the launch stream), `check` (an independent re-evaluation of the result outside the timed region) and
+`cpu_baseline` (the NumPy oracle timed on the host cores on a bounded sample of the same workload; N=1, rank 0).
 """
 import argparse
 import json
@@ -31,57 +37,123 @@ import numpy as np
 import torch
 
 WORKLOADS = {
-    # name: (batch per GPU, n_fft, hop, frames, iterations, alpha)
-    "C2": (64, 2048, 512, 1024, 100, 0.3),
-    "C1": (1, 1024, 256, 512, 50, 0.0),
+    # name: (method, batch per GPU, n_fft, hop, frames, iterations, coefficient)
+    "C2": ("griffin_lim", 64, 2048, 512, 1024, 100, 0.3),
+    "C1": ("griffin_lim", 1, 1024, 256, 512, 50, 0.0),
+    "C3": ("RTISI_LA", 32, 2048, 512, 1024, 25, 0.99),
+    "C4": ("ADMM", 32, 1024, 256, 2048, 200, 0.1),
+    "C5": ("L_BFGS", 16, 2048, 512, 1024, 20, None),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_MELS, SR, LOOK_AHEAD = 80, 22050, 3
 
 
 def hann(n):
     return (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)).astype(np.float32)
 
 
-def algorithmic_bytes_per_unit(hop, n_freq, alpha):
-    """one frame through one iteration, fp32: x read+write 8*hop, target 4F,
-    pre_spec read+write 16F (alpha != 0); 8*hop + 4F when alpha == 0."""
-    return 8 * hop + (20 if alpha != 0 else 4) * n_freq
+def algorithmic_bytes_per_unit(method, hop, n_freq, coef):
+    """SURVEY 8d, one frame through one iteration / evaluation, fp32.  griffin_lim: x read+write 8*hop, target 4F,
+    pre_spec read+write 16F (8*hop + 4F when alpha == 0); ADMM: X, U read+write 32F + target 4F; L_BFGS objective:
+    x read + gradient write 8*hop, target 4*n_mels; RTISI_LA: target read 4F + committed frame 4*hop per frame
+    (state lives in LDS: the figure is not what bounds that kernel)."""
+    if method == "griffin_lim":
+        return 8 * hop + (20 if coef != 0 else 4) * n_freq
+    if method == "ADMM":
+        return 8 * hop + 36 * n_freq
+    if method == "L_BFGS":
+        return 8 * hop + 4 * N_MELS
+    return 4 * n_freq + 4 * hop
 
 
-def cpu_baseline(n_fft, hop, frames, alpha, budget_s=15.0):
-    """The oracle (a port of the reference's algorithm) on the host cores, bounded sample."""
+def _timed_oracle(run, units_per_iter, budget_s, first=2, cap=400):
+    iters = first
+    while True:
+        t0 = time.perf_counter()
+        run(iters)
+        dt = time.perf_counter() - t0
+        if dt >= budget_s / 2 or iters >= cap:
+            return iters, dt, iters * units_per_iter / dt
+        iters = min(cap, max(iters * 2, int(iters * budget_s / max(dt, 1e-3))))
+
+
+def cpu_baseline(method, n_fft, hop, frames, coef, budget_s=15.0):
+    """The oracle (a port of the reference's algorithm) on the host cores, bounded sample of the same workload."""
     import oracle
     from oracle import stftlib
     cores = os.cpu_count() or 1
     stftlib.WORKERS = cores
-    b = 8
     rng = np.random.default_rng(99)
-    mag = rng.random((b, n_fft // 2 + 1, frames), dtype=np.float32)
     w = hann(n_fft)
-    init = oracle.phase_init(mag, hop_length=hop, window=w)
-    oracle.griffin_lim(init, max_iter=1, alpha=alpha, tol=0, hop_length=hop, window=w)     # warm caches
-    iters = 2
-    while True:
-        t0 = time.perf_counter()
-        oracle.griffin_lim(init, max_iter=iters, alpha=alpha, tol=0, eva_iter=10, hop_length=hop, window=w)
-        dt = time.perf_counter() - t0
-        if dt >= budget_s / 2 or iters >= 400:
-            break
-        iters = min(400, max(iters * 2, int(iters * budget_s / max(dt, 1e-3))))
-    stftlib.WORKERS = 1
-    return {"value": iters * b * frames / dt, "unit": "iterations*frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle.griffin_lim batch={b} n_fft={n_fft} hop={hop} n_frames={frames} "
-                      f"{iters} iterations alpha={alpha} ({dt:.1f} s, scipy.fft workers={cores})"}
+    n_freq = n_fft // 2 + 1
+    try:
+        if method in ("griffin_lim", "ADMM"):
+            b = 8 if method == "griffin_lim" else 4
+            mag = rng.random((b, n_freq, frames), dtype=np.float32)
+            init = oracle.phase_init(mag, hop_length=hop, window=w)
+            if method == "griffin_lim":
+                def run(n):
+                    oracle.griffin_lim(init, max_iter=n, alpha=coef, tol=0, eva_iter=10, hop_length=hop, window=w)
+            else:
+                def run(n):
+                    oracle.admm(init, max_iter=n, rho=coef, tol=0, eva_iter=10, hop_length=hop, window=w)
+            run(1)                                                                     # warm caches
+            iters, dt, rate = _timed_oracle(run, b * frames, budget_s)
+            return {"value": rate, "unit": "iterations*frames/s", "cores": cores, "kind": "port",
+                    "sample": f"oracle.{'griffin_lim' if method == 'griffin_lim' else 'admm'} batch={b} n_fft={n_fft} "
+                              f"hop={hop} n_frames={frames} {iters} iterations coef={coef} ({dt:.1f} s, scipy.fft "
+                              f"workers={cores})"}
+        if method == "RTISI_LA":
+            b, t, its = 2, 12, 25
+            mag = rng.random((b, n_freq, t), dtype=np.float32)
+            t0 = time.perf_counter()
+            oracle.rtisi_la(mag, look_ahead=LOOK_AHEAD, asymmetric_window=False, max_iter=its, alpha=coef,
+                            hop_length=hop, window=w)
+            dt = time.perf_counter() - t0
+            return {"value": its * b * t / dt, "unit": "iterations*frames/s", "cores": 1, "kind": "port",
+                    "sample": f"oracle.rtisi_la batch={b} n_fft={n_fft} hop={hop} n_frames={t} look_ahead={LOOK_AHEAD} "
+                              f"{its} iterations ({dt:.1f} s, frame-serial NumPy loop)"}
+        from oracle import lbfgs as olb
+        from spectrogram_inversion_amd.mel import mel_filterbank
+        b, t = 2, 256
+        a = oracle.args_helper(n_freq, np.float32, hop_length=hop, window=w)
+        tr = olb.LogMelStft(a, mel_filterbank(SR, n_fft, N_MELS).astype(np.float32))
+        xs = (0.1 * rng.standard_normal((b, (t - 1) * hop))).astype(np.float32)
+        target = tr.forward(xs)
+        x0 = (1e-6 * rng.standard_normal(xs.shape)).astype(np.float32)
+        tr.loss_grad(x0, target)
+
+        def run(n):
+            for _ in range(n):
+                tr.loss_grad(x0, target)
+        iters, dt, rate = _timed_oracle(run, b * t, budget_s, first=2, cap=200)
+        return {"value": rate, "unit": "evaluations*frames/s", "cores": cores, "kind": "port",
+                "sample": f"oracle LogMelStft.loss_grad batch={b} n_fft={n_fft} hop={hop} n_frames={t} n_mels={N_MELS} "
+                          f"{iters} evaluations ({dt:.1f} s, scipy.fft workers={cores})"}
+    finally:
+        stftlib.WORKERS = 1
 
 
-def load_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary, if any."""
+def load_traffic(key):
+    """HBM bytes per launch of the dominant kernel: a STORED figure from the committed PMC summary (profiles/traffic.json,
+    tools/pmc_summary.py), not measured in this run - PMC passes need rocprofv3 around the process."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get(workload)
+            return json.load(fh).get(key)
     except (OSError, ValueError):
         return None
+
+
+def sc_lin_f64(x_item, mag_item, hop, window, dev):
+    """||  |STFT(x)| - m || / || m ||  of one item, evaluated by the float64 generic kernels."""
+    from spectrogram_inversion_amd.plan import Plan, args_helper
+    m = mag_item.to(torch.float64)[None]
+    a = args_helper(m, hop_length=hop, window=window.double())
+    p = Plan(a, 1, m.shape[2], torch.float64, dev)
+    s = p.stft(x_item.to(torch.float64)[None])
+    out = (torch.linalg.norm(s.abs() - m) / torch.linalg.norm(m)).item()
+    return out, p
 
 
 def main():
@@ -91,7 +163,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
+    ap.add_argument("--asym", action="store_true", help="C3: asymmetric_window=True")
+    ap.add_argument("--outer", type=int, default=2, help="C5: optimizer.step calls per bench step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
     args = ap.parse_args()
 
@@ -109,40 +184,110 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    import spectrogram_inversion_amd as si            # noqa: F401
+    import spectrogram_inversion_amd as si
     from spectrogram_inversion_amd.distributed import gather_waveforms
     from spectrogram_inversion_amd.plan import args_helper, get_plan
 
-    batch, n_fft, hop, frames, iters, alpha = WORKLOADS[args.workload]
+    method, batch, n_fft, hop, frames, iters, coef = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
     n_freq = n_fft // 2 + 1
     rng = np.random.default_rng(1234 + rank)
-    mag = torch.from_numpy(rng.random((batch, n_freq, frames), dtype=np.float32)).to(dev)
     window = torch.from_numpy(hann(n_fft))
-    a = args_helper(mag, hop_length=hop, window=window)
-    plan = get_plan(a, batch, frames, torch.float32, dev)
-    if args.generic:
-        plan.force_generic(True)
-
-    run_events = []
+    events = []           # (start, stop, launches) of the dominant kernel inside the timed region
     pending = []
+    state = {}
 
-    def step():
-        plan.gla_init(None, mag, alpha)                 # phase_init + initial ISTFT
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()                                     # HIP events on the stream the kernels are launched on
-        done, _ = plan.run(iters, 10, 0.0, "sc")        # 100 iterations, evaluation every 10
-        e1.record()
-        run_events.append((e0, e1))
-        x = plan.wave()
-        if world > 1:
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    def finish_step(x):
+        if world > 1 and method != "L_BFGS":
             # RCCL gather of the (B, L) waveforms to rank 0; it runs on RCCL's stream, so the next step's kernels
             # overlap it - every gather is completed (`result()`) inside the timed region
             if pending:
                 pending.pop().result()
             pending.append(gather_waveforms(x, dst=0, sizes=[batch] * world, async_op=True))
-        return done, x
+        state["x"] = x
+
+    if method in ("griffin_lim", "ADMM"):
+        mag = torch.from_numpy(rng.random((batch, n_freq, frames), dtype=np.float32)).to(dev)
+        plan = get_plan(args_helper(mag, hop_length=hop, window=window), batch, frames, torch.float32, dev)
+        if args.generic:
+            plan.force_generic(True)
+        init = plan.gla_init if method == "griffin_lim" else plan.admm_init
+
+        def step():
+            init(None, mag, coef)                           # phase_init + initial ISTFT
+            e0, e1 = ev(), ev()
+            e0.record()                                     # HIP events on the stream the kernels are launched on
+            done, _ = plan.run(iters, 10, 0.0, "sc")        # evaluation every 10, sums stay on the device
+            e1.record()
+            assert done == iters
+            events.append((e0, e1, iters))
+            finish_step(plan.wave())
+        units_per_step = iters * batch * frames
+        unit = "iterations*frames/s"
+        path = plan.path
+        geo = plan.launch_geometry
+        kernel = {"k_fused4": f"specinv::fast::k_fused4<{n_fft // 128}, {'GLA' if method == 'griffin_lim' else 'ADMM'}>",
+                  "k_fused": f"specinv::fast::k_fused<{n_fft // 128}, {n_fft // hop}>", "k_semi": "k_semi+k_ola_f4",
+                  "k_hop": "k_hop", "k_iter_pair": "k_iter_pair+k_ola"}[geo["kernel"]]
+        launches_per_step = iters
+        length = plan.length
+    elif method == "RTISI_LA":
+        mag = torch.from_numpy(rng.random((batch, n_freq, frames), dtype=np.float32)).to(dev)
+        plan = get_plan(args_helper(mag, hop_length=hop, window=window), batch, frames, torch.float32, dev)
+        if args.generic:
+            plan.force_generic(True)
+
+        def step():
+            e0, e1 = ev(), ev()
+            e0.record()
+            x = plan.rtisi(mag, LOOK_AHEAD, args.asym, iters, coef)
+            e1.record()
+            events.append((e0, e1, 1))
+            finish_step(x)
+        units_per_step = iters * batch * frames
+        unit = "iterations*frames/s"
+        path, geo = plan.path, {"kernel": "k_rtisi_fast" if plan.fast_path else "k_rtisi"}
+        kernel = f"specinv::k_rtisi_fast<{n_fft // 128}>" if plan.fast_path else "specinv::k_rtisi"
+        launches_per_step = 1
+        length = plan.length
+    else:
+        length = (frames - 1) * hop
+        fb = torch.from_numpy(si.mel_filterbank(SR, n_fft, N_MELS)).to(dev)
+        tr = si.LogMelSTFT(fb, n_fft, hop_length=hop, window=window)
+        gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        xs = (0.1 * torch.randn(batch, length, generator=gen)).to(dev)
+        target = tr(xs)
+        x_init = (1e-6 * torch.randn(batch, length, generator=gen)).to(dev)
+        fwd, fg_raw = tr.bind(x_init, target)
+        counters = {"evals": 0}
+
+        def fg(v):
+            e0, e1 = ev(), ev()
+            e0.record()
+            out = fg_raw(v)
+            e1.record()
+            events.append((e0, e1, 1))
+            counters["evals"] += 1
+            return out
+
+        from spectrogram_inversion_amd.lbfgs import LBFGS
+
+        def step():
+            x = x_init.clone()
+            opt = LBFGS(x, device=dev)                       # torch.optim.LBFGS defaults: max_iter 20, history 100, lr 1
+            for _ in range(args.outer):
+                opt.step(fg)
+            finish_step(x)
+        units_per_step = None                               # closure evaluations are counted
+        unit = "evaluations*frames/s"
+        path, geo = "fused", {"kernel": "objective"}
+        kernel = "L-BFGS objective (forward + loss + gradient)"
+        launches_per_step = None
+        plan = None
 
     def fence():
         out = pending.pop().result() if pending else None
@@ -154,38 +299,50 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    run_events.clear()
+    events.clear()
+    if method == "L_BFGS":
+        counters["evals"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        done, x = step()
+        step()
     gathered = fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        x = gathered
+    x = gathered if (world > 1 and method != "L_BFGS") else state["x"]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert done == iters
     if rank == 0:
-        assert x.shape == (batch * world, plan.length) and bool(torch.isfinite(x).all())
+        want = (batch * world if method != "L_BFGS" else batch, length)
+        assert tuple(x.shape) == want, (tuple(x.shape), want)
 
-    # dominant kernel: the per-iteration launch.  Average duration over the timed region = HIP-event time of
-    # each step's 100-iteration run / 100 (90 plain + 10 evaluating launches, back to back on one stream).
-    launch_ms = sum(a.elapsed_time(b) for a, b in run_events) / (len(run_events) * iters)
-    unit_bytes = algorithmic_bytes_per_unit(hop, n_freq, alpha)
+    # dominant kernel: average duration over the timed region from the HIP events (launches back to back on one stream)
+    n_launch = sum(n for _, _, n in events)
+    launch_ms = sum(a.elapsed_time(b) for a, b, _ in events) / max(1, n_launch)
+    unit_bytes = algorithmic_bytes_per_unit(method, hop, n_freq, coef)
     launch_bytes = unit_bytes * batch * frames
     achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
 
     if rank == 0:
-        units = args.steps * iters * batch * world * frames
-        path = plan.path                       # "fused" | "frame" | "generic"
-        fused = path == "fused"
+        if method == "L_BFGS":
+            units = counters["evals"] * batch * frames * world
+        else:
+            units = args.steps * units_per_step * world
+        desc = {
+            "griffin_lim": f"griffin_lim batch={batch}/GPU n_fft={n_fft} hop={hop} n_frames={frames} maxiter={iters} "
+                           f"alpha={coef} hann center reflect tol=0 eva_iter=10",
+            "ADMM": f"ADMM batch={batch}/GPU n_fft={n_fft} hop={hop} n_frames={frames} rho={coef} maxiter={iters} hann "
+                    f"tol=0 eva_iter=10",
+            "RTISI_LA": f"RTISI_LA batch={batch}/GPU n_fft={n_fft} hop={hop} n_frames={frames} look_ahead={LOOK_AHEAD} "
+                        f"maxiter={iters} alpha={coef} asymmetric_window={args.asym} hann",
+            "L_BFGS": f"L_BFGS log-mel-{N_MELS} batch={batch} n_fft={n_fft} hop={hop} n_frames={frames} {args.outer} "
+                      f"optimizer.step x 20 closure evaluations, history 100, lr 1",
+        }[method]
         out = {
             "metric": "Griffin-Lim iterations*frames/sec at n_fft=2048 hop=512" if args.workload == "C2"
-                      else f"Griffin-Lim iterations*frames/sec ({args.workload})",
+                      else f"{method} {unit.split('/')[0]}/sec ({args.workload})",
             "value": units / elapsed,
-            "unit": "iterations*frames/s",
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -195,26 +352,85 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: griffin_lim batch={batch}/GPU n_fft={n_fft} hop={hop} "
-                                   f"n_frames={frames} maxiter={iters} alpha={alpha} hann center reflect tol=0 "
-                                   f"eva_iter=10",
-                       "global_batch": batch * world, "parallelism": f"batch-sharded x{world}, RCCL gather",
-                       "kernel_path": {"fused": "fused wave-per-frame", "frame": "wave-level frame kernel + overlap-add",
-                                       "generic": "generic (LDS FFT frame kernel + overlap-add)"}[path],
-                       "step": "phase_init + ISTFT + iterations + gather"},
+            "config": {"workload": f"{args.workload}: {desc}",
+                       "global_batch": batch * world,
+                       "parallelism": (f"batch-sharded x{world}, RCCL gather" if method != "L_BFGS"
+                                       else f"replicas x{world} (one optimisation problem per GPU)"),
+                       "kernel_path": path, "launch_geometry": geo,
+                       "step": {"griffin_lim": "phase_init + ISTFT + iterations + gather",
+                                "ADMM": "phase_init + ISTFT + iterations + gather",
+                                "RTISI_LA": "persistent RTISI-LA launch + overlap-add + gather",
+                                "L_BFGS": "optimizer.step calls (objective evaluations + two-loop recursion)"}[method]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(args.workload if fused else args.workload + "_generic"),
-                         "kernel": {"fused": f"specinv::fast::k_fused4<{n_fft // 128}, GLA>", "frame": "k_semi+k_ola_f4",
-                                    "generic": "k_iter_pair+k_ola"}[path],
-                         "launch_ms": launch_ms, "algorithmic_bytes_per_launch": launch_bytes,
-                         "bytes_per_unit": unit_bytes},
+                         "traffic": load_traffic(args.workload if path != "generic" else args.workload + "_generic"),
+                         "traffic_source": "stored: profiles/traffic.json (rocprofv3 --pmc summary), not measured in this run",
+                         "kernel": kernel, "launch_ms": launch_ms, "launches_timed": n_launch,
+                         "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_unit": unit_bytes},
         }
+        if method == "RTISI_LA":
+            steps_dep = (frames + LOOK_AHEAD) * iters
+            out["roofline"]["note"] = ("serial-latency-bound (dependent inner steps; state in LDS / registers): the HBM "
+                                       "fraction is not what limits this kernel")
+            out["roofline"]["dependent_steps_per_s"] = steps_dep / (launch_ms * 1e-3)
+        if method == "L_BFGS":
+            out["roofline"]["evaluations_timed"] = counters["evals"]
+        if not args.no_check:
+            out["check"] = check(method, x, locals())
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n_fft, hop, frames, alpha)
+            out["cpu_baseline"] = cpu_baseline(method, n_fft, hop, frames, coef if coef is not None else 0.0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def check(method, x, env):
+    """Independent re-evaluation of item 0 of the result, outside the timed region: the spectral convergence of the
+    float32 result as the float64 generic kernels measure it, against a complete float64 re-run from the same
+    starting spectrum (linear scale; the north-star bar for Griffin-Lim is 1e-5)."""
+    dev, hop, window, iters, coef = env["dev"], env["hop"], env["window"], env["iters"], env["coef"]
+    if method == "L_BFGS":
+        # the loss the objective kernel reports against the loss recomputed from its own forward pass by the metric
+        # kernel, and the directional derivative of the loss against g . d
+        fwd, fg_raw, x0, target = env["fwd"], env["fg_raw"], env["x_init"], env["target"]
+        xr = (x0 + 1e-3 * torch.randn_like(x0)).contiguous()
+        loss, g = fg_raw(xr)
+        v = fwd(xr)
+        mse = float(((v.double() - target.double()) ** 2).mean())
+        d = g / g.norm()                                   # steepest direction: g . d = |g|
+        eps = 1e-3 * abs(loss) / float(g.norm())            # the loss moves by ~0.1 % either way
+        lp, _ = fg_raw((xr + eps * d).contiguous())
+        lm, _ = fg_raw((xr - eps * d).contiguous())
+        fd, gd = (lp - lm) / (2 * eps), float((g.double() * d.double()).sum())
+        ok = abs(loss - mse) <= 1e-5 * abs(mse) and abs(fd - gd) <= 2e-2 * abs(gd)
+        return {"what": "objective loss vs mse(forward, target); central difference vs g.d", "loss": loss, "mse": mse,
+                "directional_fd": fd, "directional_g": gd, "ok": bool(ok)}
+    mag = env["mag"]
+    from spectrogram_inversion_amd.plan import Plan, args_helper
+    sc32, p64 = sc_lin_f64(x[0], mag[0], hop, window, dev)
+    if method == "RTISI_LA":
+        a = args_helper(mag[:1], hop_length=hop, window=window)
+        pg = Plan(a, 1, mag.shape[2], torch.float32, dev)
+        pg.force_generic(True)
+        xg = pg.rtisi(mag[:1], LOOK_AHEAD, env["args"].asym, iters, coef)
+        scg, _ = sc_lin_f64(xg[0], mag[0], hop, window, dev)
+        tol = 2e-3
+        return {"what": "SC_lin of item 0 (float64 evaluation) vs the generic RTISI-LA kernel", "sc_lin": sc32,
+                "sc_lin_ref": scg, "abs_diff": abs(sc32 - scg), "tol": tol, "ok": bool(abs(sc32 - scg) <= tol)}
+    # float64 re-run of item 0 from the float32 phase_init
+    a32 = args_helper(mag[:1], hop_length=hop, window=window)
+    p32 = Plan(a32, 1, mag.shape[2], torch.float32, dev)
+    c0 = p32.phase_init(mag[:1]).to(torch.complex128)
+    if method == "griffin_lim":
+        p64.gla_init(c0, None, coef)
+    else:
+        p64.admm_init(c0, None, coef)
+    p64.iterate(iters)
+    x64 = p64.wave()
+    sc64, _ = sc_lin_f64(x64[0], mag[0], hop, window, dev)
+    tol = 1e-5 if method == "griffin_lim" else 3e-3      # ADMM at rho = 0.1 is chaotic w.r.t. rounding (SURVEY 8c)
+    return {"what": "SC_lin of item 0 (float64 evaluation) vs a float64 re-run of the same iterations", "sc_lin": sc32,
+            "sc_lin_ref": sc64, "abs_diff": abs(sc32 - sc64), "tol": tol, "ok": bool(abs(sc32 - sc64) <= tol)}
 
 
 if __name__ == "__main__":

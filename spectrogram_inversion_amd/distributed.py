@@ -51,10 +51,11 @@ def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None
     (sum B_r, L) tensor on `dst`, None elsewhere.  `sizes` (the per-rank batch sizes) may be
     passed when known, e.g. equal shards, to skip the size exchange.  With `async_op=True` (equal
     shards only) a `PendingGather` is returned instead and the transfer overlaps later work."""
+    if not dist.is_initialized():
+        return PendingGather(None, x_local, None) if async_op else x_local
+    # (a one-rank group still goes through the collective: the same code path at every world size)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
-        return PendingGather(None, x_local, None) if async_op else x_local
     if sizes is None:
         # batch sizes of all ranks: one small tensor all-gather on the data's own device / backend
         mine = torch.tensor([x_local.shape[0]], dtype=torch.int64, device=x_local.device)
@@ -103,7 +104,7 @@ def run_loop_global(plan, max_iter, eva_iter=10, tol=0.0, metric="sc", callback=
             done = max_iter
             break
         s = torch.tensor(plan.iterate(until, eval_last=True), dtype=torch.float64, device=plan.device)
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_initialized():
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
         s = s.tolist()
         done += until
@@ -157,11 +158,11 @@ def _sharded(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, dst, g
         init(local, None, coef)              # warm start, target = |spec| (methods.py:110)
     else:
         init(None, local, coef)              # phase_init on the device (methods.py:106)
-    watch = (verbose and rank == dst) or tol > 0
-    if world == 1 or not watch:
+    watch = bool(verbose) or tol > 0
+    if not (dist.is_available() and dist.is_initialized()) or not watch:
         # nothing couples the ranks before the gather: the library's own loop (evaluations stay on the device
         # when tol == 0 and nobody watches)
-        if world == 1 and verbose:
+        if verbose:
             name = metric.upper()
             with tqdm(total=max_iter) as pbar:
                 def cb(_i, m, loss):
@@ -182,7 +183,7 @@ def _sharded(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, dst, g
                 pbar.update(eva_iter)
                 return 0
             done, evals = run_loop_global(plan, max_iter, eva_iter, tol, metric, callback=cb, group=group)
-    x = gather_waveforms(plan.wave(), dst=dst, group=group) if world > 1 else plan.wave()
+    x = gather_waveforms(plan.wave(), dst=dst, group=group)
     return x, done, evals
 
 
@@ -224,4 +225,4 @@ def RTISI_LA_sharded(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, 
     x = RTISI_LA(local.to(dev), look_ahead, asymmetric_window, max_iter, alpha, verbose=False, **stft_kwargs)
     if x.dim() == 1:
         x = x.unsqueeze(0)
-    return gather_waveforms(x, dst=dst, group=group) if world > 1 else x
+    return gather_waveforms(x, dst=dst, group=group)

@@ -323,3 +323,93 @@ def test_results_are_bitwise_reproducible(chunked_kernel):
     for _ in range(3):
         l1, g1 = fg(x)
         assert l0 == l1 and torch.equal(g0, g1)
+
+
+# ---- boundary behaviours added in round 2 ----------------------------------------------------------------------------------
+def test_phase_init_accepts_a_complex_window():
+    """`phase_init` never reads the window (methods.py:592-605); a complex one only makes the spectrum two-sided (:59-63)."""
+    mag = torch.rand(2, 256, 12, device=DEV)
+    w = torch.hann_window(256).to(torch.complex64) * torch.exp(1j * torch.linspace(0, 1, 256))
+    out = si.phase_init(mag, window=w, hop_length=64)
+    ref = si.phase_init(mag, onesided=False, hop_length=64)
+    assert out.dtype == torch.complex64 and torch.equal(torch.view_as_real(out), torch.view_as_real(ref))
+
+
+def test_rtisi_progress_bar_path_gives_the_same_samples(capsys):
+    """`verbose` feeds the frames in blocks through the resumable kernel and advances a bar of frames + look_ahead
+    steps (methods.py:362,400): the same samples bit for bit as the one-launch run, on both RTISI kernels."""
+    rng = np.random.default_rng(41)
+    for n_fft, hop, frames in ((1024, 256, 70), (400, 100, 45)):
+        mag = torch.from_numpy(rng.random((2, n_fft // 2 + 1, frames), dtype=np.float32)).to(DEV)
+        kw = dict(look_ahead=3, asymmetric_window=True, max_iter=4, hop_length=hop, window=torch.from_numpy(hann(n_fft)))
+        quiet = si.RTISI_LA(mag, verbose=False, **kw)
+        loud = si.RTISI_LA(mag, verbose=True, **kw)
+        err = capsys.readouterr().err
+        assert f"{frames + 3}/{frames + 3}" in err, err[-200:]
+        assert torch.equal(quiet, loud)
+
+
+def test_rtisi_ends_a_running_state_instead_of_corrupting_it():
+    """RTISI_LA stages its target in the buffers a running griffin_lim / ADMM state of the same plan uses: the state is
+    invalidated (SPECINV_ESTATE on the next iterate), never silently iterated against the wrong target."""
+    from spectrogram_inversion_amd import _lib
+    mag = torch.rand(2, 513, 24, device=DEV)
+    plan = Plan(args_helper(mag, hop_length=256, window=torch.from_numpy(hann(1024))), 2, 24, torch.float32, torch.device(DEV))
+    plan.gla_init(None, mag, 0.3)
+    plan.iterate(2)
+    plan.rtisi(mag, 2, True, 2, 0.5)
+    with pytest.raises(_lib.SpecinvError, match="iterate called before"):
+        plan.iterate(1)
+    plan.gla_init(None, mag, 0.3)                                   # a fresh init works again
+    plan.iterate(1)
+
+
+def test_plan_cache_is_bounded_by_bytes(monkeypatch):
+    from spectrogram_inversion_amd import plan as plan_mod
+    clear_plan_cache()
+    monkeypatch.setattr(plan_mod, "_CACHE_MAX_BYTES", 64 << 20)
+    w = torch.from_numpy(hann(1024))
+    sizes = []
+    for frames in (200, 210, 220):                                   # ~27 MB of state each
+        mag = torch.rand(8, 513, frames, device=DEV)
+        si.griffin_lim(mag, max_iter=1, verbose=False, hop_length=256, window=w)
+        cache = plan_mod._cache()
+        sizes.append((len(cache), sum(p.device_bytes for p in cache.values())))
+    assert all(b <= 64 << 20 for _, b in sizes[1:]) and sizes[-1][0] <= 2, sizes
+    assert next(reversed(plan_mod._cache().values())).n_frames == 220       # the plan just used always stays
+    p = next(reversed(plan_mod._cache().values()))
+    assert 8 * 513 * 220 * 12 < p.device_bytes < 64 << 20                   # at least pre_spec + target
+    clear_plan_cache()
+
+
+def test_l_bfgs_optimises_init_x0_in_place():
+    """`nn.Parameter(init_x0)` shares init_x0's storage (methods.py:539) and the reference returns a view of it (:569)."""
+    x_true = 0.1 * torch.randn(2, 30 * 128, device=DEV)
+    tr = si.MagSTFT(512, hop_length=128, window=torch.from_numpy(hann(512)))
+    target = tr(x_true)
+    x0 = 1e-3 * torch.randn_like(x_true)
+    before = x0.clone()
+    out = si.L_BFGS(target, tr, init_x0=x0, outer_max_iter=2, max_iter=5, verbose=False)
+    assert out.data_ptr() == x0.data_ptr() and not torch.equal(x0, before)
+    x0c = before.cpu()
+    out = si.L_BFGS(target, tr, init_x0=x0c, outer_max_iter=2, max_iter=5, verbose=False)
+    assert out.device.type == "cpu" and out.data_ptr() == x0c.data_ptr() and torch.allclose(out, x0.cpu(), atol=1e-6)
+
+
+def test_two_transforms_on_one_stft_shape_do_not_interfere():
+    """Each DeviceTransform owns its plan (kind + filterbank are plan state): closures of a |STFT| transform and of two
+    log-mel transforms with different filterbanks stay valid while the others are evaluated."""
+    x = 0.1 * torch.randn(2, 40 * 256, device=DEV)
+    w = torch.from_numpy(hann(1024))
+    fb1 = torch.from_numpy(si.mel_filterbank(22050, 1024, 40)).to(DEV)
+    fb2 = torch.from_numpy(si.mel_filterbank(16000, 1024, 64)).to(DEV)
+    tm, t1, t2 = si.MagSTFT(1024, hop_length=256, window=w), si.LogMelSTFT(fb1, 1024, hop_length=256, window=w), \
+        si.LogMelSTFT(fb2, 1024, hop_length=256, window=w)
+    refs = [t(x) for t in (tm, t1, t2)]
+    bound = [t.bind(x, r) for t, r in zip((tm, t1, t2), refs)]
+    for _ in range(2):
+        for (fwd, fg), r in zip(bound, refs):                        # interleaved use of the three closures
+            assert torch.equal(fwd(x), r)
+            loss, g = fg(x)
+            assert loss < 1e-12 and g.shape == x.shape
+    assert refs[0].shape[1] == 513 and refs[1].shape[1] == 40 and refs[2].shape[1] == 64

@@ -243,3 +243,16 @@ def test_reference_kwarg_sweep_is_differentiable(method, pad_mode):
                 assert bool(torch.isfinite(sp.grad).all()), (method, kw, ex)
             n_done += 1
     assert n_done == (48 if method != "RTISI_LA" else 192)
+
+
+@pytest.mark.parametrize("fn,kw", [(si.griffin_lim, dict(alpha=0.5)), (si.ADMM, dict(rho=0.5))])
+def test_backward_twice_with_retain_graph(fn, kw):
+    """The reference's result is an ordinary autograd graph: a second backward under retain_graph=True works and gives
+    the same gradient; without it the graph is released and autograd says so."""
+    spec = torch.rand(2, 65, 20, dtype=torch.float64, device=DEV, requires_grad=True)
+    y = fn(spec, max_iter=3, tol=0, verbose=False, hop_length=32, **kw)
+    (g1,) = torch.autograd.grad(y.square().sum(), spec, retain_graph=True)
+    (g2,) = torch.autograd.grad(y.square().sum(), spec)
+    assert torch.equal(g1, g2) and g1.abs().sum() > 0
+    with pytest.raises(RuntimeError, match="second time|already been freed"):
+        torch.autograd.grad(y.square().sum(), spec)

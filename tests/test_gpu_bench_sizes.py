@@ -1,0 +1,194 @@
+"""Every BASELINE.json configuration at the size `bench.py` runs it, on the launch geometry `bench.py` gets.
+
+The wave-level kernels pick their geometry from the problem size (8-wave workgroups of `k_fused4` once the launch
+fills every wave slot: 2048 waves, i.e. BASELINE C2 at B = 64 and the C4 shard at B = 32), so small-shape tests do
+not run the code the benchmark runs.  These do, against (a) the CPU oracle on a few whole items - batch items are
+independent (torch_specinv/methods.py:237-250, :458-483, :363-404), three of them are seconds on the CPU - and
+(b) the float64 generic kernels on the whole batch.  Needs an MI355X: `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _util import hann, rel_l2, segment_errors
+
+pytestmark = pytest.mark.gpu
+
+import spectrogram_inversion_amd as si                               # noqa: E402
+from spectrogram_inversion_amd.plan import Plan, args_helper          # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_plan(n_fft, hop, frames, batch, dtype=torch.float32, generic=False):
+    np_dt = np.float32 if dtype == torch.float32 else np.float64
+    a = args_helper(torch.empty(1, n_fft // 2 + 1, 1, dtype=dtype), hop_length=hop, window=torch.from_numpy(hann(n_fft, np_dt)))
+    p = Plan(a, batch, frames, dtype, DEV)
+    if generic:
+        p.force_generic(True)
+    return p
+
+
+def sc_lin(s):
+    """linear spectral convergence from the evaluation sums {sum (|S|-m)^2, sum |S|^2, sum m^2, count}"""
+    return float(np.sqrt(s[0] / s[2]))
+
+
+def bench_mag(batch, n_freq, frames, seed=1234):
+    """bench.py's synthetic input of rank 0: uniform [0, 1) magnitudes from default_rng(1234)"""
+    return np.random.default_rng(seed).random((batch, n_freq, frames), dtype=np.float32)
+
+
+# ---- C2: griffin_lim B=64 n_fft=2048 hop=512 T=1024 alpha=0.3 (the headline) ------------------------------------------
+def test_c2_headline_geometry_vs_oracle_and_float64():
+    n_fft, hop, frames, batch, alpha = 2048, 512, 1024, 64, 0.3
+    mag_np = bench_mag(batch, n_fft // 2 + 1, frames)
+    mag = torch.from_numpy(mag_np).to(DEV)
+    p32 = make_plan(n_fft, hop, frames, batch)
+    geo = p32.launch_geometry
+    # the geometry of the headline number: one 8-wave workgroup per CU, 2048 waves of 32 frames
+    assert geo == {"waves_per_workgroup": 8, "chunks": 32, "waves": 2048, "kernel": "k_fused4"}, geo
+    w = hann(n_fft)
+    items = [0, 31, 63]
+    # phase_init at full size: the three items against the oracle (<= 4 ulp of the magnitude, like g1)
+    c0 = p32.phase_init(mag)
+    c0_ref = oracle.phase_init(mag_np[items], hop_length=hop, window=w)
+    err = np.abs(N(c0[items]) - c0_ref).max()
+    assert err <= 4 * np.finfo(np.float32).eps * np.abs(c0_ref).max(), err
+    # 10 iterations from the same starting spectrum: waveform rel-L2 <= 1e-4 (the north-star bar)
+    p32.gla_init(c0, None, alpha)
+    p32.iterate(10)
+    y10 = N(p32.wave()[items])
+    ref = oracle.griffin_lim(N(c0[items]), max_iter=10, alpha=alpha, tol=0, hop_length=hop, window=w)
+    for k, it in enumerate(items):
+        assert rel_l2(y10[k], ref[k]) < 1e-4, (it, rel_l2(y10[k], ref[k]))
+    # 30 iterations, the whole batch against the generic kernels in float64: |dSC_lin| <= 1e-5, and on the waveform the
+    # bulk of every item (isolated near-zero bins of inconsistent random magnitudes decorrelate locally, _util.segment_errors)
+    s32 = p32.iterate(20, eval_last=True)
+    y32 = N(p32.wave())
+    del p32
+    p64 = make_plan(n_fft, hop, frames, batch, torch.float64)
+    assert p64.path == "generic"
+    p64.gla_init(c0.to(torch.complex128), None, alpha)
+    s64 = p64.iterate(30, eval_last=True)
+    y64 = N(p64.wave())
+    assert abs(sc_lin(s32) - sc_lin(s64)) < 1e-5, (sc_lin(s32), sc_lin(s64))
+    for b in range(batch):
+        seg = segment_errors(y32[b], y64[b], hop)
+        assert np.median(seg) < 1e-4, (b, np.median(seg))
+        assert rel_l2(y32[b], y64[b]) < 2e-3, (b, rel_l2(y32[b], y64[b]))
+    # the evaluating launch (EVAL instantiation, 8-wave geometry too): its sums against the float64 run
+    np.testing.assert_allclose(s32[:3], s64[:3], rtol=2e-5)
+
+
+# ---- C4 shard: ADMM B=32 n_fft=1024 hop=256 T=2048 rho=0.1 ------------------------------------------------------------
+def test_c4_shard_geometry_vs_oracle_and_float64():
+    n_fft, hop, frames, batch, rho = 1024, 256, 2048, 32, 0.1
+    mag_np = bench_mag(batch, n_fft // 2 + 1, frames)
+    mag = torch.from_numpy(mag_np).to(DEV)
+    p32 = make_plan(n_fft, hop, frames, batch)
+    geo = p32.launch_geometry
+    assert geo == {"waves_per_workgroup": 8, "chunks": 64, "waves": 2048, "kernel": "k_fused4"}, geo
+    w = hann(n_fft)
+    items = [0, 15, 31]
+    c0 = p32.phase_init(mag)
+    p32.admm_init(c0, None, rho)
+    # waveforms after 1, 2 and 5 iterations against the oracle: rho = 0.1 amplifies rounding ~10x per iteration in the
+    # reference itself - the tolerances of the g4 fixture test
+    done = 0
+    for it, tol in ((1, 5e-6), (2, 5e-5), (5, 5e-4)):
+        p32.iterate(it - done)
+        done = it
+        y = N(p32.wave()[items])
+        ref = oracle.admm(N(c0[items]), max_iter=it, rho=rho, tol=0, hop_length=hop, window=w)
+        for k, b in enumerate(items):
+            assert rel_l2(y[k], ref[k]) < tol, (it, b, rel_l2(y[k], ref[k]))
+    # 200 iterations (the benchmark's count) against float64: the metric (chaotic regime: |dSC_lin| <= 3e-3)
+    s32 = p32.iterate(195, eval_last=True)
+    x_state = N(p32.state_spec(0)[:1])
+    del p32
+    p64 = make_plan(n_fft, hop, frames, batch, torch.float64)
+    p64.admm_init(c0.to(torch.complex128), None, rho)
+    s64 = p64.iterate(200, eval_last=True)
+    assert abs(sc_lin(s32) - sc_lin(s64)) < 3e-3, (sc_lin(s32), sc_lin(s64))
+    # the projection keeps |X| = m wherever |X| is not tiny: a property that holds at any iteration count
+    rel = np.abs(np.abs(x_state) - mag_np[:1]) / np.maximum(mag_np[:1], 1e-3)
+    assert np.quantile(rel, 0.999) < 1e-5, np.quantile(rel, 0.999)
+
+
+# ---- C3: RTISI_LA B=32 n_fft=2048 hop=512 T=1024 look_ahead=3 25 it ---------------------------------------------------
+@pytest.mark.parametrize("asym", [True, False])
+def test_c3_full_size_vs_oracle_prefix_and_generic(asym):
+    n_fft, hop, frames, batch, la, its, alpha = 2048, 512, 1024, 32, 3, 25, 0.99
+    mag_np = bench_mag(batch, n_fft // 2 + 1, frames)
+    mag = torch.from_numpy(mag_np).to(DEV)
+    w = hann(n_fft)
+    p32 = make_plan(n_fft, hop, frames, batch)
+    assert p32.fast_path
+    y = N(p32.rtisi(mag, la, asym, its, alpha))
+    assert y.shape == (batch, (frames - 1) * hop) and np.isfinite(y).all()
+    a = oracle.args_helper(n_fft // 2 + 1, np.float32, hop_length=hop, window=w)
+
+    def sc_of(v, m):
+        s = np.abs(oracle.stft(v[None].astype(np.float32), a))
+        return float(np.linalg.norm(s - m[None, :, :s.shape[-1]]) / np.linalg.norm(m[None, :, :s.shape[-1]]))
+
+    # (a) the recursion is causal: committed frame i only sees target frames <= i + look_ahead (methods.py:363-404), so
+    # the first 64 frames of item 0 equal a run of the oracle on a 72-frame prefix of the target
+    pre, cmp_frames = 72, 60
+    ref = oracle.rtisi_la(mag_np[:1, :, :pre], look_ahead=la, asymmetric_window=asym, max_iter=its, alpha=alpha,
+                          hop_length=hop, window=w)[0]
+    n = cmp_frames * hop
+    if asym:
+        ref64 = oracle.rtisi_la(mag_np[:1, :, :pre].astype(np.float64), look_ahead=la, asymmetric_window=asym, max_iter=its,
+                                alpha=alpha, hop_length=hop, window=hann(n_fft, np.float64))[0]
+        noise = rel_l2(ref[:n], ref64[:n])
+        assert rel_l2(y[0, :n], ref64[:n]) < max(1e-4, 5 * noise), (rel_l2(y[0, :n], ref64[:n]), noise)
+    else:
+        # the zero-phase first frame makes two float32 runs decorrelate: equally consistent instead
+        m60 = mag_np[0, :, :cmp_frames - 4]
+        assert abs(sc_of(y[0, :n], m60) - sc_of(ref[:n], m60)) < 2e-3
+    # (b) the whole batch against the generic persistent kernel: spectral convergence per item (|dSC_lin| <= 2e-3)
+    pg = make_plan(n_fft, hop, frames, batch, generic=True)
+    yg = N(pg.rtisi(mag, la, asym, its, alpha))
+    for b in (0, 7, 16, 31):
+        d = abs(sc_of(y[b], mag_np[b]) - sc_of(yg[b], mag_np[b]))
+        assert d < 2e-3, (b, d)
+    if asym:
+        assert np.median([rel_l2(y[b], yg[b]) for b in range(batch)]) < 2e-2
+
+
+# ---- C5: L_BFGS objective, log-mel-80, B=16 n_fft=2048 hop=512 T=1024 ---------------------------------------------------
+def test_c5_objective_full_size_vs_torch_autograd():
+    n_fft, hop, frames, batch, n_mels = 2048, 512, 1024, 16, 80
+    length = (frames - 1) * hop
+    fb = torch.from_numpy(si.mel_filterbank(22050, n_fft, n_mels))
+    w = torch.from_numpy(hann(n_fft))
+    g = torch.Generator().manual_seed(5)
+    xs = 0.1 * torch.randn(batch, length, generator=g)
+    x0 = 0.05 * torch.randn(batch, length, generator=g)          # (a point with a gradient well above rounding)
+    tr = si.LogMelSTFT(fb.to(DEV), n_fft, hop_length=hop, window=w)
+    target = tr(xs.to(DEV))
+    fwd, fg = tr.bind(x0.to(DEV), target)
+    loss, grad = fg(x0.to(DEV))
+    v = fwd(x0.to(DEV))
+    # reference: torch autograd on the CPU in float64 (methods.py:545-550 with transform_fn = log1p(mel @ |stft|))
+    fb64, w64 = fb.double(), w.double()
+
+    def transform(x):
+        s = torch.stft(x, n_fft, hop_length=hop, window=w64, return_complex=True).abs()
+        return torch.log1p(torch.matmul(fb64, s))
+
+    t64 = transform(xs.double())
+    xr = x0.double().requires_grad_(True)
+    vr = transform(xr)
+    lr = torch.nn.functional.mse_loss(vr, t64)
+    (gr,) = torch.autograd.grad(lr, xr)
+    assert rel_l2(N(target), t64.numpy()) < 1e-5
+    assert rel_l2(N(v), vr.detach().numpy()) < 1e-5
+    assert abs(loss - float(lr)) < 1e-5 * float(lr), (loss, float(lr))
+    assert rel_l2(N(grad), gr.numpy()) < 1e-5, rel_l2(N(grad), gr.numpy())

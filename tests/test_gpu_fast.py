@@ -409,3 +409,39 @@ def test_gradient_with_the_overlap_add_on_chip(pad_mode, n_fft, hop, frames, cen
     loss2, grad2 = ours()
     assert rel_l2(N(grad), N(grad2)) < 2e-6, rel_l2(N(grad), N(grad2))
     assert not torch.equal(grad, grad2) or hop == n_fft      # (different code ran: the sums round differently somewhere)
+
+
+# ---- the tuned copy of the hop = n_fft/4 kernel against the template it was copied from ---------------------------------
+@pytest.mark.parametrize("n_fft,batch,frames", [(1024, 3, 70), (2048, 2, 50), (2048, 64, 1024), (1024, 32, 2048)])
+@pytest.mark.parametrize("method", ["gla", "admm"])
+def test_tuned_copy_equals_template(monkeypatch, n_fft, batch, frames, method):
+    """`k_fused4<R>` (kernels_fast.h) is a hand-tuned copy of `k_fused<R, 4>`: whatever is fixed in one must be fixed in
+    the other.  SPECINV_FUSED_TEMPLATE=1 makes a plan run the template where the copy would run; waveform, spectral state
+    and evaluation sums must agree bit for bit, plain and evaluating launches, small launches (4-wave workgroups) and the
+    benchmark geometries (8-wave workgroups of the copy: C2 at B = 64, the C4 shard at B = 32)."""
+    hop = n_fft // 4
+    DEV = dev()
+    rng = np.random.default_rng(n_fft + frames)
+    mag = torch.from_numpy(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)).to(DEV)
+    w = torch.from_numpy(hann(n_fft))
+    out = []
+    for template in ("0", "1"):
+        monkeypatch.setenv("SPECINV_FUSED_TEMPLATE", template)
+        p = Plan(args_helper(mag, hop_length=hop, window=w), batch, frames, torch.float32, DEV)
+        geo = p.launch_geometry
+        assert geo["kernel"] == ("k_fused" if template == "1" else "k_fused4"), geo
+        if template == "0" and batch * frames >= 65536:
+            assert geo["waves_per_workgroup"] == 8 and geo["waves"] == 2048, geo
+        (p.gla_init if method == "gla" else p.admm_init)(None, mag, 0.3)
+        p.iterate(2)
+        s = p.iterate(2, eval_last=True)
+        p.iterate(1)
+        out.append((p.wave(), p.state_spec(0), p.state_spec(1) if method == "admm" else None, s))
+        del p
+    (xa, pa, ua, sa), (xb, pb, ub, sb) = out
+    assert torch.equal(xa, xb)
+    assert torch.equal(torch.view_as_real(pa), torch.view_as_real(pb))
+    if ua is not None:
+        assert torch.equal(torch.view_as_real(ua), torch.view_as_real(ub))
+    # (the sums are per-wave partial sums added in wave order: a different wave count adds them in a different order)
+    np.testing.assert_allclose(sa, sb, rtol=1e-12)

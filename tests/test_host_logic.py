@@ -69,6 +69,29 @@ def test_argument_errors_precede_device_use():
         si.phase_init(mag.to(torch.complex64))              # :586
 
 
+def test_complex_window_and_unknown_kwargs_follow_the_reference():
+    """What the unmodified reference does (run in the build container, torch 2.10): a complex window makes `onesided`
+    default to False (methods.py:59-63) and is accepted by `phase_init`, which never reads it; griffin_lim / ADMM /
+    RTISI_LA raise RuntimeError on it (conv_transpose1d of real frames with the complex diag(window) weight, :127).
+    RTISI_LA forwards the raw kwargs to torch.stft on the non-asymmetric path (:308-310,385): an unknown name is a
+    TypeError there, while the asymmetric path and griffin_lim / ADMM silently drop it (:42-46)."""
+    w = torch.hann_window(256).to(torch.complex64) * torch.exp(1j * torch.linspace(0, 1, 256))
+    a = args_helper(torch.empty(2, 256, 9), window=w)
+    assert a.complex_window and not a.onesided and a.n_fft == 256 and a.window.dtype == torch.float32
+    mag = torch.rand(2, 256, 9)
+    for fn in (si.griffin_lim, si.ADMM, si.RTISI_LA):
+        with pytest.raises(RuntimeError, match="complex windows"):
+            fn(mag, window=w, verbose=False)
+    with pytest.raises(TypeError, match="unexpected keyword argument 'maxiter'"):
+        si.RTISI_LA(torch.rand(2, 129, 9), maxiter=3, verbose=False)
+    with pytest.raises(TypeError, match="unexpected keyword argument 'n_fft'"):
+        si.RTISI_LA(torch.rand(2, 129, 9), n_fft=256, verbose=False)
+    if not torch.cuda.is_available():
+        # the asymmetric path drops the unknown name and gets as far as asking for the device
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            si.RTISI_LA(torch.rand(2, 129, 9), asymmetric_window=True, maxiter=3, verbose=False)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
 def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
