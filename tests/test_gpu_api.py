@@ -358,7 +358,7 @@ def test_rtisi_ends_a_running_state_instead_of_corrupting_it():
     plan.gla_init(None, mag, 0.3)
     plan.iterate(2)
     plan.rtisi(mag, 2, True, 2, 0.5)
-    with pytest.raises(_lib.SpecinvError, match="iterate called before"):
+    with pytest.raises(_lib.SpecinvError, match="has not been called|iterate called before"):
         plan.iterate(1)
     plan.gla_init(None, mag, 0.3)                                   # a fresh init works again
     plan.iterate(1)
