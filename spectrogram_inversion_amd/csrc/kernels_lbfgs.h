@@ -14,6 +14,8 @@
 
 #include "common.h"
 #include "kernels_generic.h"
+#include "kernels_fast.h"
+#include "kernels_objective.h"
 
 namespace specinv {
 
@@ -888,6 +890,86 @@ __global__ void k_grad_fold_margins(const T* __restrict__ frames, T* __restrict_
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
+// 16-row mel tiles the one-launch objective is instantiated for (0: not covered)
+inline int obj_mel_tiles(int n_mels) {
+  const int mt = (n_mels + 15) / 16;
+  return mt <= 3 ? 3 : mt <= 4 ? 4 : mt <= 5 ? 5 : mt <= 8 ? 8 : 0;
+}
+
+// loss and gradient of the log-mel objective in one launch (+ the seam / padding passes of the unfused path).
+// `*used` stays false when the configuration is not covered: the caller then runs the kernel chain.
+template <typename P>
+int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, double* loss, float* grad, bool* used) {
+  *used = false;
+  if (pl.tf_kind != SPECINV_TF_LOGMEL || pl.tf_obj_mt == 0 || pl.force_generic) return SPECINV_OK;
+  if (const char* e = getenv("SPECINV_DISABLE_FUSED_OBJECTIVE")) {
+    if (e[0] == '1') return SPECINV_OK;
+  }
+  const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), B = pl.B(), pad = pl.pad, R = pl.fast.xform_R, MT = pl.tf_obj_mt;
+  if (hop > N || pad >= len) return SPECINV_OK;
+  if ((long long)(T - 1) * hop + N != len + 2LL * pad) return SPECINV_OK;       // the frames must cover the padded signal exactly
+  const int nch = (T + fast::kObjTile - 1) / fast::kObjTile;
+  if (nch > 1 && T / nch < (N - 1) / hop + 1) return SPECINV_OK;                // a seam must not reach a tile's own tail
+  const int uni = R == 16 ? std::max(fast::kObjWaves * fast::Geo<16>::TR * 2, fast::kObjWaves * MT * 256)
+                          : std::max(fast::kObjWaves * fast::Geo<8>::TR * 2, fast::kObjWaves * MT * 256);
+  if ((fast::kObjTile - 1) * hop + N > uni) return SPECINV_OK;                  // the tile's output span lives in that scratch
+  const int keep = N - hop;
+  const int64_t n_tiles = (int64_t)B * nch;
+  SI_TRY(pl.fast.hop_inv_tail.reserve((size_t)n_tiles * std::max(1, keep) * sizeof(float) + 16));
+  SI_TRY(pl.fast.hop_inv_margins.reserve((size_t)B * 2 * std::max(1, pad) * sizeof(float)));
+  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_tiles, 3 * 1024) * sizeof(double)));
+  const double numel = (double)B * T * pl.tf_mels;
+  fast::ObjArgs a{};
+  a.x = x;
+  a.grad = grad;
+  a.margins = pl.fast.hop_inv_margins.template as<float>();
+  a.xtail = pl.fast.hop_inv_tail.template as<float>();
+  a.target = target;
+  a.melA = pl.tf_mel_a.template as<fast::f32x4>();
+  a.melB = pl.tf_mel_b.template as<fast::f32x4>();
+  a.window = pl.window.template as<float>();
+  a.partials = pl.partials.template as<double>();
+  a.len = len;
+  a.T = T;
+  a.nchunks = nch;
+  a.hop = hop;
+  a.pad = pad;
+  a.pad_mode = pl.cfg.pad_mode;
+  a.n_mels = pl.tf_mels;
+  a.fwd_scale = pl.fc.fwd_scale;
+  a.dscale = (float)(2.0 / numel);
+  const void* fn = nullptr;
+  size_t lds = 0;
+#define SPECINV_OBJ_CASE(RR, MM)                                   \
+  if (R == RR && MT == MM) {                                       \
+    fn = (const void*)fast::k_objective_logmel<RR, MM>;            \
+    lds = fast::ObjGeo<RR, MM>::lds_bytes();                       \
+  }
+  SPECINV_OBJ_CASE(16, 3) SPECINV_OBJ_CASE(16, 4) SPECINV_OBJ_CASE(16, 5) SPECINV_OBJ_CASE(16, 8)
+  SPECINV_OBJ_CASE(8, 3) SPECINV_OBJ_CASE(8, 4) SPECINV_OBJ_CASE(8, 5) SPECINV_OBJ_CASE(8, 8)
+#undef SPECINV_OBJ_CASE
+  if (fn == nullptr || lds > 160 * 1024) return SPECINV_OK;
+  SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  void* kargs[] = {&a};
+  SI_HIP(hipLaunchKernel(fn, dim3((unsigned)n_tiles), dim3(64 * fast::kObjWaves), kargs, lds, pl.stream));
+  if (nch > 1 && keep > 0) {
+    const long long total = (long long)B * (nch - 1) * keep;
+    hipLaunchKernelGGL(fast::k_hop_tails_raw, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, grad,
+                       (const float*)a.xtail, T, nch, hop, keep, pad, (long long)len, total);
+    SI_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), n_tiles, 1,
+                     pl.sums.template as<double>());
+  SI_HIP(hipGetLastError());
+  SI_TRY(pl.launch_grad_fold(nullptr, grad, len, a.margins));
+  double s;
+  SI_HIP(hipMemcpyAsync(&s, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
+  *loss = s / numel;
+  *used = true;
+  return SPECINV_OK;
+}
+
 template <typename P, typename T>
 int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
   SI_CHECK(kind == SPECINV_TF_MAG || kind == SPECINV_TF_LOGMEL, SPECINV_EINVAL, "unknown transform kind %d", kind);
@@ -912,9 +994,24 @@ int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
                            total);
         SI_HIP(hipGetLastError());
       }
+      // operand tiles of the one-launch objective (kernels_objective.h): one-sided spectra on the wave-level FFT
+      pl.tf_obj_mt = 0;
+      const int mt16 = obj_mel_tiles(n_mels);
+      if (mt16 > 0 && pl.cfg.onesided && pl.fast.xform_ok && (pl.fast.xform_R == 8 || pl.fast.xform_R == 16)) {
+        const int kq = (pl.n_freq + 15) / 16;
+        const int64_t total = (int64_t)kq * mt16 * 256;
+        SI_TRY(pl.tf_mel_a.reserve((size_t)total * sizeof(float)));
+        SI_TRY(pl.tf_mel_b.reserve((size_t)total * sizeof(float)));
+        hipLaunchKernelGGL(fast::k_mel_tile16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream,
+                           pl.tf_mel.template as<float>(), pl.tf_mel_a.template as<float>(), pl.tf_mel_b.template as<float>(),
+                           pl.n_freq, n_mels, kq, mt16);
+        SI_HIP(hipGetLastError());
+        pl.tf_obj_mt = mt16;
+      }
     }
   } else {
     pl.tf_mels = 0;
+    pl.tf_obj_mt = 0;
   }
   pl.tf_kind = kind;
   return SPECINV_OK;
@@ -979,6 +1076,19 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
   SI_CHECK(x && target && loss && grad, SPECINV_EINVAL, "null pointer");
   using C = cplx<T>;
   const int64_t BT = (int64_t)pl.B() * pl.Tn();
+  {
+    const int64_t tcheck = 1 + (len + 2 * pl.pad - pl.N()) / pl.cfg.hop_length;
+    SI_CHECK(len + 2 * pl.pad >= pl.N() && tcheck == pl.Tn(), SPECINV_EINVAL,
+             "signal length %lld gives %lld frames, plan has %d", (long long)len, (long long)tcheck, pl.Tn());
+  }
+  if constexpr (std::is_same<T, float>::value) {
+    bool used = false;
+    SI_TRY(tf_loss_grad_fused(pl, x, len, target, loss, grad, &used));
+    if (used) return SPECINV_OK;
+  }
+  if (const char* e = getenv("SPECINV_REQUIRE_FUSED_OBJECTIVE")) {     // tests: the shape must be on the one-launch kernel
+    SI_CHECK(e[0] != '1', SPECINV_EUNSUPPORTED, "the one-launch objective does not cover this configuration");
+  }
   SI_TRY(pl.tf_spec.reserve(pl.nspec() * sizeof(C)));
   SI_TRY(pl.stft_internal(x, len, pl.tf_spec.template as<C>()));
   const int nb = 1024;

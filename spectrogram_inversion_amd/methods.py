@@ -19,7 +19,7 @@ from tqdm import tqdm
 
 from . import _lib
 from .lbfgs import LBFGS as _LBFGS
-from .plan import args_helper, get_plan, require_gpu
+from .plan import args_helper, get_plan, require_gpu, trim_plan_cache
 from .transforms import DeviceTransform
 
 __all__ = ["griffin_lim", "RTISI_LA", "ADMM", "L_BFGS", "phase_init"]
@@ -33,6 +33,7 @@ def _format_spec(spec):
 
 def _finish(x, spec, out_device):
     """methods.py:267-270: squeeze unless the input was exactly (1, F, T)."""
+    trim_plan_cache()
     if not (spec.shape[0] == 1 and spec.dim() == 3):
         x = x.squeeze(0)
     return x.to(out_device)

@@ -502,10 +502,16 @@ def get_plan(args: StftArgs, batch: int, n_frames: int, dtype: torch.dtype, devi
         cache[key] = plan
     else:
         cache.move_to_end(key)
-    # (plans grow as they are used, so the byte bound is re-checked on every request)
+    trim_plan_cache()
+    return plan
+
+
+def trim_plan_cache():
+    """Enforce the cache bounds.  Plans reserve their buffers as they are used, so the public functions call this
+    again when they are done with a plan; the most recently used plan always stays."""
+    cache = _cache()
     while len(cache) > 1 and (len(cache) > _CACHE_MAX or sum(p.device_bytes for p in cache.values()) > _CACHE_MAX_BYTES):
         cache.popitem(last=False)
-    return plan
 
 
 def clear_plan_cache():

@@ -241,3 +241,64 @@ def test_gram_direction_follows_the_two_loop_recursion(history):
     assert len(errs) > history + 3 and max(sizes) == history and sizes.count(history) > 3      # pairs were dropped
     assert max(errs) < 2e-5, errs
     assert fg(x)[0] < f_start - 1.0
+
+
+# ---- the one-launch log-mel objective (kernels_objective.h) -------------------------------------------------------------
+@pytest.mark.parametrize("n_fft,hop,frames,batch,n_mels,kw", [
+    (2048, 512, 40, 3, 80, {}),                                   # BASELINE config 5's frame size
+    (2048, 512, 37, 2, 80, dict(pad_mode="constant")),            # a tile of 5 frames at the end
+    (2048, 512, 16, 1, 80, dict(pad_mode="replicate")),           # exactly one tile
+    (2048, 512, 33, 2, 80, dict(pad_mode="circular")),
+    (2048, 1024, 24, 2, 80, {}),                                  # hop = n_fft/2
+    (2048, 700, 21, 2, 64, {}),                                   # hop not dividing n_fft (even offsets)
+    (2048, 333, 48, 2, 40, {}),                                   # odd hop: scalar overlap-add
+    (1024, 256, 50, 3, 40, {}),
+    (1024, 128, 64, 2, 128, {}),                                  # 8 mel tiles, hop = n_fft/8 (tiles of exactly 16 frames)
+    (1024, 256, 40, 2, 20, dict(normalized=True)),                # padded mel tile, ortho scaling
+    (2048, 512, 20, 2, 80, dict(center=False)),                   # no padding: signal of (T-1) hop + n_fft samples
+])
+def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frames, batch, n_mels, kw):
+    """`specinv_transform_loss_grad` for the log-mel transform as ONE kernel (spectrum kept on the chip) against the same
+    objective as a chain of kernels (spectrum through HBM) and against the float64 oracle: loss and gradient."""
+    rng = np.random.default_rng(n_fft + hop + frames)
+    center = kw.get("center", True)
+    length = (frames - 1) * hop + (0 if center else n_fft)
+    fb = si.mel_filterbank(22050, n_fft, n_mels)
+    w = hann(n_fft)
+    xs = (0.1 * rng.standard_normal((batch, length))).astype(np.float32)
+    x0 = (0.05 * rng.standard_normal((batch, length))).astype(np.float32)
+    out = {}
+    for mode in ("fused", "chain"):
+        monkeypatch.setenv("SPECINV_DISABLE_FUSED_OBJECTIVE", "1" if mode == "chain" else "0")
+        monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1" if mode == "fused" else "0")
+        tr = LogMelSTFT(T(fb), n_fft, hop_length=hop, window=torch.from_numpy(w), **kw)
+        target = tr(T(xs))
+        _, fg = tr.bind(T(x0), target)
+        loss, grad = fg(T(x0))
+        loss2, grad2 = fg(T(x0))
+        assert loss == loss2 and torch.equal(grad, grad2)           # fixed summation order: bitwise reproducible
+        out[mode] = (loss, N(grad), N(target))
+    (lf, gf, tf), (lc, gc, tc) = out["fused"], out["chain"]
+    assert np.array_equal(tf, tc)
+    assert abs(lf - lc) < 2e-6 * abs(lc), (lf, lc)
+    assert rel_l2(gf, gc) < 3e-6, rel_l2(gf, gc)
+    a = oracle.args_helper(n_fft // 2 + 1, np.float64, hop_length=hop, window=w.astype(np.float64), **kw)
+    ref = LogMelStft(a, fb.astype(np.float64))
+    lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
+    assert abs(lf - lo) < 1e-5 * abs(lo), (lf, lo)
+    assert rel_l2(gf, go) < 1e-5, rel_l2(gf, go)
+
+
+def test_one_launch_objective_falls_back_where_it_does_not_fit(monkeypatch):
+    """Configurations the one-launch kernel does not cover (hop > n_fft/2 at n_fft 2048: the tile's output span does not fit
+    the LDS scratch; n_fft 512; more than 128 mel bands; float64) run the kernel chain - same results as ever."""
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    fb = si.mel_filterbank(22050, 2048, 80)
+    x = 0.1 * torch.randn(2, 19 * 1500, device=dev())
+    tr = LogMelSTFT(T(fb), 2048, hop_length=1500, window=torch.from_numpy(hann(2048)))
+    _, fg = tr.bind(x, tr(x + 0.01))
+    with pytest.raises(NotImplementedError, match="one-launch objective"):
+        fg(x)
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "0")
+    loss, g = fg(x)
+    assert loss > 0 and torch.isfinite(g).all()
