@@ -906,13 +906,10 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     if (e[0] == '1') return SPECINV_OK;
   }
   const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), B = pl.B(), pad = pl.pad, R = pl.fast.xform_R, MT = pl.tf_obj_mt;
-  if (hop > N || pad >= len) return SPECINV_OK;
+  if (hop > N || hop < 2 || pad >= len) return SPECINV_OK;
   if ((long long)(T - 1) * hop + N != len + 2LL * pad) return SPECINV_OK;       // the frames must cover the padded signal exactly
   const int nch = (T + fast::kObjTile - 1) / fast::kObjTile;
   if (nch > 1 && T / nch < (N - 1) / hop + 1) return SPECINV_OK;                // a seam must not reach a tile's own tail
-  const int uni = R == 16 ? std::max(fast::kObjWaves * fast::Geo<16>::TR * 2, fast::kObjWaves * MT * 256)
-                          : std::max(fast::kObjWaves * fast::Geo<8>::TR * 2, fast::kObjWaves * MT * 256);
-  if ((fast::kObjTile - 1) * hop + N > uni) return SPECINV_OK;                  // the tile's output span lives in that scratch
   const int keep = N - hop;
   const int64_t n_tiles = (int64_t)B * nch;
   SI_TRY(pl.fast.hop_inv_tail.reserve((size_t)n_tiles * std::max(1, keep) * sizeof(float) + 16));
@@ -927,6 +924,7 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   a.target = target;
   a.melA = pl.tf_mel_a.template as<fast::f32x4>();
   a.melB = pl.tf_mel_b.template as<fast::f32x4>();
+  a.tab = pl.tf_obj_tab.template as<int>();
   a.window = pl.window.template as<float>();
   a.partials = pl.partials.template as<double>();
   a.len = len;
@@ -938,6 +936,7 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   a.n_mels = pl.tf_mels;
   a.fwd_scale = pl.fc.fwd_scale;
   a.dscale = (float)(2.0 / numel);
+  a.hop_magic = (unsigned)(((1ull << 32) + hop - 1) / hop);
   const void* fn = nullptr;
   size_t lds = 0;
 #define SPECINV_OBJ_CASE(RR, MM)                                   \
@@ -950,8 +949,33 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
 #undef SPECINV_OBJ_CASE
   if (fn == nullptr || lds > 160 * 1024) return SPECINV_OK;
   SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#if SPECINV_OBJ_STAMPS
+  static unsigned long long* d_stamps = nullptr;
+  if (!d_stamps) SI_HIP(hipMalloc(&d_stamps, (size_t)n_tiles * 16 * sizeof(unsigned long long)));
+  a.stamps = d_stamps;
+#endif
   void* kargs[] = {&a};
   SI_HIP(hipLaunchKernel(fn, dim3((unsigned)n_tiles), dim3(64 * fast::kObjWaves), kargs, lds, pl.stream));
+#if SPECINV_OBJ_STAMPS
+  {
+    std::vector<unsigned long long> h((size_t)n_tiles * 16);
+    SI_HIP(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    static int calls = 0;
+    if (++calls == 5) {
+      const char* names[12] = {"tables", "twiddle regs", "analysis (2 frames)", "barrier", "forward GEMM", "barrier",
+                               "reduce+log1p+dM", "backward GEMM", "barrier", "synthesis (2 frames)", "barrier", "overlap-add"};
+      double tot[13] = {0};
+      for (int64_t t = 0; t < n_tiles; ++t)
+        for (int i = 1; i <= 12; ++i) tot[i] += (double)(h[t * 16 + i] - h[t * 16 + i - 1]);
+      fprintf(stderr, "k_objective_logmel phase cycles (s_memtime, 100 MHz ticks x clock ratio; mean over %lld tiles, wave 0):\n", (long long)n_tiles);
+      for (int i = 1; i <= 11; ++i) fprintf(stderr, "  %-22s %9.0f\n", names[i - 1], tot[i] / n_tiles);
+      fprintf(stderr, "  %-22s %9.0f\n", "write-out", tot[12] / n_tiles);
+      double all = 0;
+      for (int64_t t = 0; t < n_tiles; ++t) all += (double)(h[t * 16 + 12] - h[t * 16]);
+      fprintf(stderr, "  %-22s %9.0f\n", "whole tile", all / n_tiles);
+    }
+  }
+#endif
   if (nch > 1 && keep > 0) {
     const long long total = (long long)B * (nch - 1) * keep;
     hipLaunchKernelGGL(fast::k_hop_tails_raw, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, grad,
@@ -998,14 +1022,17 @@ int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
       pl.tf_obj_mt = 0;
       const int mt16 = obj_mel_tiles(n_mels);
       if (mt16 > 0 && pl.cfg.onesided && pl.fast.xform_ok && (pl.fast.xform_R == 8 || pl.fast.xform_R == 16)) {
-        const int kq = (pl.n_freq + 15) / 16;
-        const int64_t total = (int64_t)kq * mt16 * 256;
-        SI_TRY(pl.tf_mel_a.reserve((size_t)total * sizeof(float)));
-        SI_TRY(pl.tf_mel_b.reserve((size_t)total * sizeof(float)));
-        hipLaunchKernelGGL(fast::k_mel_tile16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream,
-                           pl.tf_mel.template as<float>(), pl.tf_mel_a.template as<float>(), pl.tf_mel_b.template as<float>(),
-                           pl.n_freq, n_mels, kq, mt16);
-        SI_HIP(hipGetLastError());
+        std::vector<float> h_mel((size_t)n_mels * pl.n_freq), hA, hB;
+        std::vector<int> h_tab;
+        SI_HIP(hipMemcpyAsync(h_mel.data(), pl.tf_mel.p, h_mel.size() * sizeof(float), hipMemcpyDeviceToHost, pl.stream));
+        SI_HIP(hipStreamSynchronize(pl.stream));
+        fast::obj_build_blocks(h_mel.data(), pl.n_freq, n_mels, mt16, hA, hB, h_tab);
+        SI_TRY(pl.tf_mel_a.reserve(hA.size() * sizeof(float)));
+        SI_TRY(pl.tf_mel_b.reserve(hB.size() * sizeof(float)));
+        SI_TRY(pl.tf_obj_tab.reserve(h_tab.size() * sizeof(int)));
+        SI_HIP(hipMemcpy(pl.tf_mel_a.p, hA.data(), hA.size() * sizeof(float), hipMemcpyHostToDevice));
+        SI_HIP(hipMemcpy(pl.tf_mel_b.p, hB.data(), hB.size() * sizeof(float), hipMemcpyHostToDevice));
+        SI_HIP(hipMemcpy(pl.tf_obj_tab.p, h_tab.data(), h_tab.size() * sizeof(int), hipMemcpyHostToDevice));
         pl.tf_obj_mt = mt16;
       }
     }

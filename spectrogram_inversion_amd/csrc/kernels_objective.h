@@ -12,13 +12,16 @@
 //   4. backward contraction dA = Mel^T dM on the matrix cores, the waves split the bin tiles; dA overwrites the |S| tile;
 //   5. each wave forms G = dA S/|S| (interior bins halved: the Hermitian extension) for its two frames, runs the inverse
 //      FFT and applies the window;
-//   6. the frames are overlap-added into one LDS span of the tile in a fixed order (waves whose frames overlap take
-//      turns), the span's first frames*hop samples go to the gradient, the remaining n_fft - hop (what the tile adds
-//      to its successor's samples) to `xtail`; k_hop_tails_raw and k_grad_fold_margins of the unfused path finish
-//      the seams and the padding.
+//   6. the windowed frames are staged in LDS (the tiles are free by then) and every output sample gathers the frames
+//      that cover it in frame order; the span's first frames*hop samples go to the gradient, the remaining n_fft - hop
+//      (what the tile adds to its successor's samples) to `xtail`; k_hop_tails_raw and k_grad_fold_margins of the
+//      unfused path finish the seams and the padding.
 // HBM traffic per frame: 4*hop read + 4*hop written + 4*n_mels target (+ the seams, + the filterbank, which every
-// workgroup streams from L2): SURVEY 8d's 8h + 4 n_mels.  The filterbank is read from two copies tiled in operand order
-// (k_mel_tile16): one 16-byte load per lane feeds four MFMAs.
+// workgroup streams from L2): SURVEY 8d's 8h + 4 n_mels.
+// The filterbank is cut into 16 x 16 blocks (16 mel rows x 16 bins) stored in MFMA operand order, one copy per
+// contraction: one 16-byte load per lane feeds four MFMAs.  Blocks that are entirely zero are left out of the block list
+// (obj_build_blocks): adding 0 * x changes nothing, so the result is bit for bit that of the dense contraction, and a mel
+// filterbank - triangles around the diagonal - keeps ~1/3 of its blocks.  A dense matrix keeps all of them.
 #pragma once
 
 namespace specinv {
@@ -30,6 +33,15 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+#ifndef SPECINV_OBJ_STAMPS        // diagnostic build: s_memtime at the phase boundaries of wave 0 of every workgroup
+#define SPECINV_OBJ_STAMPS 0      // (tools/obj_stamps.py; the shipped kernel executes no stamp)
+#endif
+#if SPECINV_OBJ_STAMPS
+#define OBJ_STAMP(i) do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define OBJ_STAMP(i) do { } while (0)
+#endif
+
 constexpr int kObjWaves = 8;      // waves per workgroup
 constexpr int kObjTile = 16;      // frames per tile (the N of the MFMA), two per wave
 constexpr int kObjRow = 17;       // LDS row stride of the [bin][frame] tiles (odd: column reads are conflict-free)
@@ -40,14 +52,31 @@ struct ObjArgs {
   float* margins;          // (B, 2, pad): gradient w.r.t. the padded samples either side of the signal
   float* xtail;            // (B, nchunks, n_fft - hop)
   const float* target;     // (B, n_mels, T), the caller's layout
-  const f32x4* melA;       // forward operand tiles  [KQ][MT][64] x 4 k-steps
-  const f32x4* melB;       // backward operand tiles [KQ][MT][64] x 4 k-steps
+  const f32x4* melA;       // forward operand blocks  [E][64] x 4 k-steps: A[i = mel row][k = bin]
+  const f32x4* melB;       // backward operand blocks [E][64] x 4 k-steps: A[i = bin][k = mel row]
+  const int* tab;          // block list, see ObjTab
   const float* window;
   double* partials;        // [B * nchunks] squared-error sums
   long long len;
   int T, nchunks, hop, pad, pad_mode, n_mels;
   float fwd_scale;
   float dscale;            // 2 / numel
+  unsigned hop_magic;      // ceil(2^32 / hop) (hop > 1), for the division-free frame lookup of the overlap-add
+#if SPECINV_OBJ_STAMPS
+  unsigned long long* stamps;   // [tiles][16]
+#endif
+};
+
+// Layout of the block table (ints): the non-zero blocks are sorted by bin group, then mel group.
+//   [0 .. 8]            forward: wave w takes blocks [tab[w], tab[w+1])
+//   [9 .. 17]           backward: wave w takes bin groups [tab[9+w], tab[9+w+1])  (balanced by block count)
+//   [18 .. 18+KQ]       first block of bin group g (KQ + 1 entries)
+//   [19+KQ .. +E)       mel group of block e
+//   [19+KQ+E .. +E)     bin group of block e
+struct ObjTab {
+  static constexpr int FWD = 0, BWD = 9, BEGIN = 18;
+  static constexpr int mel_group(int KQ) { return 19 + KQ; }
+  static constexpr int bin_group(int KQ, int E) { return 19 + KQ + E; }
 };
 
 template <int R, int MT>
@@ -58,7 +87,7 @@ struct ObjGeo {
   static constexpr int FP = 16 * KQ;                  // rows of the |S| / dA tile
   static constexpr int UNI_TR = kObjWaves * G::TR * 2;            // floats: FFT transpose scratch of the waves
   static constexpr int UNI_RED = kObjWaves * MT * 4 * 64;         // floats: partial accumulators of the forward contraction
-  static constexpr int UNI = UNI_TR > UNI_RED ? UNI_TR : UNI_RED; // (the output span must fit too: checked on the host)
+  static constexpr int UNI = UNI_TR > UNI_RED ? UNI_TR : UNI_RED;
   static constexpr size_t lds_bytes() {
     return sizeof(v2f) * G::M + sizeof(float) * ((size_t)FP * kObjRow + 16 * MT * kObjRow + UNI);
   }
@@ -80,18 +109,48 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
 
-  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
-  for (int i = threadIdx.x; i < (FP - F) * RS; i += blockDim.x) tile[F * RS + i] = 0.0f;   // rows the zero-padded filterbank meets
-  TwRegs<R> twr;
-#pragma unroll
-  for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = unit(2.0f * (float)((lane * k1) % M) / (float)M);   // W_M^(lane*k1)
-
   const int b = blockIdx.x / a.nchunks, c = blockIdx.x - b * a.nchunks;
   const int t0 = hop_chunk_begin(c, a.T, a.nchunks), t1 = hop_chunk_begin(c + 1, a.T, a.nchunks);
   const int nfr = t1 - t0;                                  // <= 16
   const float* xrow = a.x + (long long)b * a.len;
+  // the samples of this wave's two frames are requested first: they fly while the tables are built
+  v2f zin[2][R];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = 2 * wib + i;
+    if (n < nfr) {
+      load_frame_raw<R>(xrow, a.len, (long long)(t0 + n) * a.hop - a.pad, lane, a.pad_mode, zin[i]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < R; ++u) zin[i][u] = v2f{0.0f, 0.0f};   // a frame beyond the tile: zeros all the way through
+    }
+  }
+  // ... and so are the target values this lane will compare against in step 3 (output (m, n) of the forward contraction)
+  constexpr int NQ = (4 * MT + kObjWaves - 1) / kObjWaves;
+  float tgt[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = wib + kObjWaves * i, m = 16 * (q >> 2) + 4 * (lane >> 4) + (q & 3), n = lane & 15;
+    tgt[i] = (q < 4 * MT && m < a.n_mels && n < nfr) ? a.target[((long long)b * a.n_mels + m) * a.T + t0 + n] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (FP - F) * RS; i += blockDim.x) tile[F * RS + i] = 0.0f;   // rows the zero-padded filterbank meets
+  OBJ_STAMP(0);
+  {
+    v2f* twt = reinterpret_cast<v2f*>(uni);                   // W_M^(l*k1), (R-1) x 64 entries: built once, kept in registers
+    for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+      const int k1 = i / 64 + 1, l = i & 63;
+      twt[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
+    }
+  }
+
   const float hs = 0.5f * a.fwd_scale;
   __syncthreads();
+  TwRegs<R> twr;
+#pragma unroll
+  for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = reinterpret_cast<const v2f*>(uni)[(k1 - 1) * 64 + lane];
+  __syncthreads();                                            // (the staging area is the FFT scratch from here on)
+  OBJ_STAMP(1);
 
   // ---- 1. analysis of this wave's two frames ---------------------------------------------------------------------------
   v2f un[2][H], um[2][H], umid[2];
@@ -99,14 +158,8 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   for (int i = 0; i < 2; ++i) {
     const int n = 2 * wib + i;
     v2f z[R];
-    if (n < nfr) {
-      load_frame_raw<R>(xrow, a.len, (long long)(t0 + n) * a.hop - a.pad, lane, a.pad_mode, z);
-    } else {
 #pragma unroll
-      for (int u = 0; u < R; ++u) z[u] = v2f{0.0f, 0.0f};   // a frame beyond the tile: zeros all the way through
-    }
-#pragma unroll
-    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    for (int u = 0; u < R; ++u) z[u] = zin[i][u] * lds_win[64 * u + lane];
     fft_forward_t<R>(z, k, twr, tr);
     v2f rc[H];
 #pragma unroll
@@ -127,104 +180,128 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       const int kk = lane + 64 * j;
       tile[kk * RS + n] = ak;
       tile[(M - kk) * RS + n] = am;
-      un[i][j] = ak > 0.0f ? v2f{xk.x / ak, xk.y / ak} : v2f{0.0f, 0.0f};   // G = dA * S/|S|, 0 where |S| = 0
-      um[i][j] = am > 0.0f ? v2f{xm.x / am, xm.y / am} : v2f{0.0f, 0.0f};
+      const float ik = ak > 0.0f ? fast_rcp(ak) : 0.0f, im = am > 0.0f ? fast_rcp(am) : 0.0f;
+      un[i][j] = xk * ik;                                                      // G = dA * S/|S|, 0 where |S| = 0
+      um[i][j] = xm * im;
     }
     const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};                  // bin M/2 (lane 0)
     const float amid = fast_abs(xmid);
     if (lane == 0) tile[(M / 2) * RS + n] = amid;
-    umid[i] = amid > 0.0f ? v2f{xmid.x / amid, xmid.y / amid} : v2f{0.0f, 0.0f};
+    umid[i] = xmid * (amid > 0.0f ? fast_rcp(amid) : 0.0f);
   }
+  OBJ_STAMP(2);
   __syncthreads();
+  OBJ_STAMP(3);
 
-  // ---- 2. forward contraction mm[m, n] = sum_f Mel[m, f] |S|[f, n]: the waves split K ----------------------------------
+  // ---- 2. forward contraction mm[m, n] = sum_f Mel[m, f] |S|[f, n]: the waves split the list of non-zero blocks -------
+  const int n_blk = a.tab[ObjTab::BEGIN + KQ];
+  const int* blk_mg = a.tab + ObjTab::mel_group(KQ);
+  const int* blk_fg = a.tab + ObjTab::bin_group(KQ, n_blk);
   {
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int q0 = (KQ * wib) / kObjWaves, q1 = (KQ * (wib + 1)) / kObjWaves;
-    f32x4 av[MT], an[MT];
+    const int e0 = a.tab[ObjTab::FWD + wib], e1 = a.tab[ObjTab::FWD + wib + 1];
+    f32x4 av[4];                                            // ring of operand blocks in flight (L2 latency >> 4 MFMAs)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) av[mt] = a.melA[((long long)q0 * MT + mt) * 64 + lane];
-    for (int kq = q0; kq < q1; ++kq) {
-      const int kn = kq + 1 < q1 ? kq + 1 : kq;                // next group's operands fly during this group's MFMAs
+    for (int i = 0; i < 4; ++i) av[i] = a.melA[(long long)min(e0 + i, n_blk - 1) * 64 + lane];
+    for (int e = e0; e < e1; e += 4) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) an[mt] = a.melA[((long long)kn * MT + mt) * 64 + lane];
-      float bv[4];
+      for (int i = 0; i < 4; ++i) {
+        if (e + i < e1) {
+          const int fg = blk_fg[e + i], mg = blk_mg[e + i];
+          float bv[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = tile[(16 * kq + 4 * j + (lane >> 4)) * RS + (lane & 15)];
+          for (int j = 0; j < 4; ++j) bv[j] = tile[(16 * fg + 4 * j + (lane >> 4)) * RS + (lane & 15)];
+          const f32x4 cur = av[i];
+          av[i] = a.melA[(long long)min(e + i + 4, n_blk - 1) * 64 + lane];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+          for (int mt = 0; mt < MT; ++mt)
+            if (mg == mt) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma_16x16x4(av[mt][j], bv[j], acc[mt]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
+              for (int j = 0; j < 4; ++j) acc[mt] = mfma_16x16x4(cur[j], bv[j], acc[mt]);
+            }
+        }
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) uni[((wib * MT + mt) * 4 + r) * 64 + lane] = acc[mt][r];
   }
+  OBJ_STAMP(4);
   __syncthreads();
+  OBJ_STAMP(5);
 
   // ---- 3. V = log1p(mm), squared error, dM = 2/numel (V - T) / (1 + mm) ------------------------------------------------
   {
     double s2 = 0.0;
-    for (int q = wib; q < 4 * MT; q += kObjWaves) {
-      const int mt = q >> 2, r = q & 3;
-      float v = 0.0f;
 #pragma unroll
-      for (int w = 0; w < kObjWaves; ++w) v += uni[((w * MT + mt) * 4 + r) * 64 + lane];   // fixed order
-      const int m = 16 * mt + 4 * (lane >> 4) + r, n = lane & 15;   // D[i = m][j = n]: col = lane & 15, row = 4 (lane >> 4) + r
-      float dm = 0.0f;
-      if (m < a.n_mels && n < nfr) {
-        const float d = log1pf(v) - a.target[((long long)b * a.n_mels + m) * a.T + t0 + n];
-        s2 += (double)d * (double)d;
-        dm = a.dscale * d / (1.0f + v);
+    for (int i = 0; i < NQ; ++i) {
+      const int q = wib + kObjWaves * i;
+      if (q < 4 * MT) {
+        const int mt = q >> 2, r = q & 3;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kObjWaves; ++w) v += uni[((w * MT + mt) * 4 + r) * 64 + lane];   // fixed order
+        const int m = 16 * mt + 4 * (lane >> 4) + r, n = lane & 15;   // D[i = m][j = n]: col = lane & 15, row = 4 (lane >> 4) + r
+        float dm = 0.0f;
+        if (m < a.n_mels && n < nfr) {
+          const float d = log1pf(v) - tgt[i];
+          s2 += (double)d * (double)d;
+          dm = a.dscale * d / (1.0f + v);
+        }
+        dmt[m * RS + n] = dm;
       }
-      dmt[m * RS + n] = dm;
     }
     s2 = wave_sum(s2);
     if (lane == 0) lsum[wib] = s2;
   }
   __syncthreads();
+  OBJ_STAMP(6);
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int w = 0; w < kObjWaves; ++w) tot += lsum[w];
     a.partials[blockIdx.x] = tot;
   }
 
-  // ---- 4. backward contraction dA[f, n] = sum_m Mel[m, f] dM[m, n]: the waves split the bin tiles ------------------------
+  // ---- 4. backward contraction dA[f, n] = sum_m Mel[m, f] dM[m, n]: the waves split the bin groups ----------------------
   {
-    float bb[MT][4];
+    const int g0 = a.tab[ObjTab::BWD + wib], g1 = a.tab[ObjTab::BWD + wib + 1];
+    const int e0 = a.tab[ObjTab::BEGIN + g0], e1 = a.tab[ObjTab::BEGIN + g1];
+    f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    int g = g0;
+    auto flush = [&](int upto) {                            // bin groups [g, upto) are complete (groups without a block: zeros)
+      for (; g < upto; ++g) {
 #pragma unroll
-    for (int kq = 0; kq < MT; ++kq)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bb[kq][j] = dmt[(16 * kq + 4 * j + (lane >> 4)) * RS + (lane & 15)];
-    for (int ft = wib; ft < KQ; ft += 2 * kObjWaves) {
-      const int f2 = ft + kObjWaves < KQ ? ft + kObjWaves : ft;   // two tiles in flight: independent accumulator chains
-      f32x4 a0[MT], a1[MT];
-#pragma unroll
-      for (int kq = 0; kq < MT; ++kq) {
-        a0[kq] = a.melB[((long long)ft * MT + kq) * 64 + lane];
-        a1[kq] = a.melB[((long long)f2 * MT + kq) * 64 + lane];
+        for (int r = 0; r < 4; ++r) tile[(16 * g + 4 * (lane >> 4) + r) * RS + (lane & 15)] = c[r];
+        c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
-      f32x4 c0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, c1 = c0;
+    };
+    f32x4 av[4];
 #pragma unroll
-      for (int kq = 0; kq < MT; ++kq)
+    for (int i = 0; i < 4; ++i) av[i] = a.melB[(long long)min(e0 + i, n_blk - 1) * 64 + lane];
+    for (int e = e0; e < e1; e += 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          c0 = mfma_16x16x4(a0[kq][j], bb[kq][j], c0);
-          c1 = mfma_16x16x4(a1[kq][j], bb[kq][j], c1);
+      for (int i = 0; i < 4; ++i) {
+        if (e + i < e1) {
+          const int fg = blk_fg[e + i], mg = blk_mg[e + i];
+          flush(fg);
+          float bv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[j] = dmt[(16 * mg + 4 * j + (lane >> 4)) * RS + (lane & 15)];
+          const f32x4 cur = av[i];
+          av[i] = a.melB[(long long)min(e + i + 4, n_blk - 1) * 64 + lane];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c = mfma_16x16x4(cur[j], bv[j], c);
         }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        tile[(16 * ft + 4 * (lane >> 4) + r) * RS + (lane & 15)] = c0[r];
-        if (f2 != ft) tile[(16 * f2 + 4 * (lane >> 4) + r) * RS + (lane & 15)] = c1[r];
       }
     }
+    flush(g1);
   }
+  OBJ_STAMP(7);
   __syncthreads();
+  OBJ_STAMP(8);
 
   // ---- 5. gradient frames: G = dA S/|S| (Hermitian weights), inverse FFT, window --------------------------------------------
   v2f fr[2][R];
@@ -261,75 +338,129 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
 #pragma unroll
     for (int u = 0; u < R; ++u) fr[i][u] = z[u] * lds_win[64 * u + lane];
   }
+  OBJ_STAMP(9);
   __syncthreads();                                            // every inverse transform is done: the scratch becomes the span
+  OBJ_STAMP(10);
 
-  // ---- 6. overlap-add in LDS, fixed order -------------------------------------------------------------------------------------
-  float* span = uni;
-  const int span_len = (nfr - 1) * a.hop + N;
-  for (int s = threadIdx.x; s < span_len; s += blockDim.x) span[s] = 0.0f;
-  __syncthreads();
-  // wave w's frames reach into the frames of waves w+1 .. w+P-1: P groups of waves take turns
-  int P = (a.hop + N - 1) / (2 * a.hop) + 1;
-  if (P > kObjWaves) P = kObjWaves;
-  for (int ph = 0; ph < P; ++ph) {
-    if (wib % P == ph) {
+  // ---- 6. overlap-add: the windowed frames go to LDS (the |S| / dA tile, the dM tile and the scratch are one region of
+  // >= 16 n_fft floats, all free by now), then every output sample gathers the <= n_fft/hop frames that cover it, in
+  // frame order - the order of k_ola's gather in the unfused path, so the sums round the same way ---------------------------
+  float* frames = tile;
+  static_assert((size_t)FP * RS + 16 * MT * RS + OG::UNI >= (size_t)kObjTile * N, "the frame buffers do not fit");
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int n = 2 * wib + i;
-        if (n < nfr) {
-          const int off = n * a.hop;
-          if ((off & 1) == 0) {
-            v2f* s2 = reinterpret_cast<v2f*>(span + off);
+  for (int i = 0; i < 2; ++i) {
+    v2f* f2 = reinterpret_cast<v2f*>(frames + (2 * wib + i) * N);
 #pragma unroll
-            for (int u = 0; u < R; ++u) s2[64 * u + lane] = s2[64 * u + lane] + fr[i][u];
-          } else {
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-              span[off + 128 * u + 2 * lane] += fr[i][u].x;
-              span[off + 128 * u + 2 * lane + 1] += fr[i][u].y;
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
+    for (int u = 0; u < R; ++u) f2[64 * u + lane] = fr[i][u];
   }
+  __syncthreads();
+  OBJ_STAMP(11);
   // the tile's own frames*hop samples are final up to the previous tile's tail; the rest of the span is this tile's tail
+  const int span_len = (nfr - 1) * a.hop + N;
   const long long p0 = (long long)t0 * a.hop;
   const int owned = nfr * a.hop, keep = N - a.hop;
   const bool last = c == a.nchunks - 1;
   float* go = a.grad + (long long)b * a.len;
-  float* mg = a.margins + (long long)b * 2 * a.pad;
+  float* mgn = a.margins + (long long)b * 2 * a.pad;
   float* tl = a.xtail + ((long long)b * a.nchunks + c) * keep;
-  for (int s = threadIdx.x; s < span_len; s += blockDim.x) {
-    const float v = span[s];
-    if (s < owned || last) {
-      const long long nn = p0 + s - a.pad;
-      if (nn >= 0 && nn < a.len) go[nn] = v;
-      else if (nn < 0) mg[p0 + s] = v;
-      else if (nn - a.len < a.pad) mg[a.pad + (nn - a.len)] = v;
-    } else {
-      tl[s - owned] = v;
+  const long long n0 = p0 - a.pad;                          // signal index of span[0]
+  const int lim = last ? span_len : owned;                  // span[0, lim) -> gradient / margins, span[lim, span_len) -> tail
+  if (((a.hop | a.pad) & 3) == 0 && n0 >= 0 && n0 + lim <= a.len && (a.len & 3) == 0) {
+    // the common case: 16-byte pieces, everything inside the signal
+    v4f* g4 = reinterpret_cast<v4f*>(go + n0);
+    v4f* t4 = reinterpret_cast<v4f*>(tl);
+    for (int s4 = threadIdx.x; s4 < span_len / 4; s4 += blockDim.x) {
+      const int s = 4 * s4;
+      // frames n_lo .. n_hi cover sample s (division by the hop: multiplication by ceil(2^32 / hop), exact below 2^16)
+      const int n_lo = s < N ? 0 : (int)__umulhi((unsigned)(s - N), a.hop_magic) + 1;
+      int n_hi = (int)__umulhi((unsigned)s, a.hop_magic);
+      if (n_hi > nfr - 1) n_hi = nfr - 1;
+      v4f acc = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int nb = n_lo; nb <= n_hi; nb += 4) {            // four reads in flight, added in frame order
+        v4f t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + q <= n_hi ? nb + q : n_hi;
+          t[q] = *reinterpret_cast<const v4f*>(frames + n * N + (s - n * a.hop));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (nb + q <= n_hi) acc = acc + t[q];
+      }
+      if (s < lim) g4[s4] = acc;
+      else t4[s4 - lim / 4] = acc;
+    }
+  } else {
+    for (int s = threadIdx.x; s < span_len; s += blockDim.x) {
+      int n_lo = s < N ? 0 : (s - N) / a.hop + 1, n_hi = s / a.hop;
+      if (n_hi > nfr - 1) n_hi = nfr - 1;
+      float v = 0.0f;
+      for (int n = n_lo; n <= n_hi; ++n) v += frames[n * N + (s - n * a.hop)];
+      if (s < lim) {
+        const long long nn = n0 + s;
+        if (nn >= 0 && nn < a.len) go[nn] = v;
+        else if (nn < 0) mgn[p0 + s] = v;
+        else if (nn - a.len < a.pad) mgn[a.pad + (nn - a.len)] = v;
+      } else {
+        tl[s - owned] = v;
+      }
     }
   }
+  OBJ_STAMP(12);
 }
 
-// filterbank (n_mels, F) -> the two operand-ordered copies, zero padded:
-//   A[((kq * MT + mt) * 64 + lane) * 4 + j] = Mel[16 mt + (lane & 15)][16 kq + 4 j + (lane >> 4)]     (forward: A[i = m][k = f])
-//   B[((ft * MT + kq) * 64 + lane) * 4 + j] = Mel[16 kq + 4 j + (lane >> 4)][16 ft + (lane & 15)]     (backward: A[i = f][k = m])
-__global__ void k_mel_tile16(const float* __restrict__ mel, float* __restrict__ A, float* __restrict__ B, int F, int n_mels,
-                             int KQ, int MT) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)KQ * MT * 256) return;
-  const int j = i & 3, lane = (i >> 2) & 63;
-  const int inner = (int)((i >> 8) % MT), outer = (int)(i / (256LL * MT));
-  {
-    const int m = 16 * inner + (lane & 15), f = 16 * outer + 4 * j + (lane >> 4);
-    A[i] = (m < n_mels && f < F) ? mel[(long long)m * F + f] : 0.0f;
+// Host side: cut the filterbank (n_mels x F, row-major, host copy) into 16 x 16 blocks, keep the non-zero ones in
+// operand order and build the block table (ObjTab).
+inline void obj_build_blocks(const float* mel, int F, int n_mels, int MT, std::vector<float>& A, std::vector<float>& B,
+                             std::vector<int>& tab) {
+  const int KQ = (F + 15) / 16;
+  std::vector<int> begin(KQ + 1, 0), mgs, fgs;
+  for (int fg = 0; fg < KQ; ++fg) {
+    begin[fg] = (int)mgs.size();
+    for (int mg = 0; mg < MT; ++mg) {
+      bool any = false;
+      for (int m = 16 * mg; m < std::min(n_mels, 16 * mg + 16) && !any; ++m)
+        for (int f = 16 * fg; f < std::min(F, 16 * fg + 16); ++f)
+          if (mel[(size_t)m * F + f] != 0.0f) {
+            any = true;
+            break;
+          }
+      if (any) {
+        mgs.push_back(mg);
+        fgs.push_back(fg);
+      }
+    }
   }
-  {
-    const int m = 16 * inner + 4 * j + (lane >> 4), f = 16 * outer + (lane & 15);
-    B[i] = (m < n_mels && f < F) ? mel[(long long)m * F + f] : 0.0f;
+  if (mgs.empty()) {                       // an all-zero filterbank still needs one (zero) block to point the loads at
+    mgs.push_back(0);
+    fgs.push_back(0);
+    for (int fg = 1; fg <= KQ; ++fg) begin[fg] = 1;
+  }
+  const int E = (int)mgs.size();
+  begin[KQ] = E;
+  auto at = [&](int m, int f) { return (m < n_mels && f < F) ? mel[(size_t)m * F + f] : 0.0f; };
+  A.assign((size_t)E * 256, 0.0f);
+  B.assign((size_t)E * 256, 0.0f);
+  for (int e = 0; e < E; ++e)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int j = 0; j < 4; ++j) {
+        // forward: A[i = mel row = lane & 15][k = bin = 4 j + (lane >> 4)]; backward: A[i = bin][k = mel row]
+        A[((size_t)e * 64 + lane) * 4 + j] = at(16 * mgs[e] + (lane & 15), 16 * fgs[e] + 4 * j + (lane >> 4));
+        B[((size_t)e * 64 + lane) * 4 + j] = at(16 * mgs[e] + 4 * j + (lane >> 4), 16 * fgs[e] + (lane & 15));
+      }
+  tab.assign(ObjTab::bin_group(KQ, E) + E, 0);
+  for (int w = 0; w <= kObjWaves; ++w) tab[ObjTab::FWD + w] = (int)((long long)E * w / kObjWaves);
+  for (int w = 0; w <= kObjWaves; ++w) {   // first bin group that starts at or after block E w / 8
+    const int want = (int)((long long)E * w / kObjWaves);
+    int g = 0;
+    while (g < KQ && begin[g] < want) ++g;
+    tab[ObjTab::BWD + w] = w == kObjWaves ? KQ : g;
+  }
+  tab[ObjTab::BWD] = 0;
+  for (int g = 0; g <= KQ; ++g) tab[ObjTab::BEGIN + g] = begin[g];
+  for (int e = 0; e < E; ++e) {
+    tab[ObjTab::mel_group(KQ) + e] = mgs[e];
+    tab[ObjTab::bin_group(KQ, E) + e] = fgs[e];
   }
 }
 

@@ -91,7 +91,7 @@ struct PlanT final : PlanBase {
   DevBuf lb_scal;                       // device scalars of the L-BFGS two-loop recursion
   DevBuf eval_log;                      // per-evaluation sums of a run with deferred read-back
   DevBuf tf_mel, tf_mel_tiled, tf_mel_tiled_t, tf_spec, tf_v;   // transform (L_BFGS) scratch
-  DevBuf tf_mel_a, tf_mel_b;            // filterbank in MFMA operand order (one-launch objective)
+  DevBuf tf_mel_a, tf_mel_b, tf_obj_tab;   // non-zero filterbank blocks in MFMA operand order + block table (one-launch objective)
   int tf_obj_mt = 0;                    // its 16-row mel tiles (0: the objective runs as a kernel chain)
   std::vector<T> h_window;
   FrameCfg<T> fc{};

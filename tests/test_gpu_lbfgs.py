@@ -252,6 +252,7 @@ def test_gram_direction_follows_the_two_loop_recursion(history):
     (2048, 1024, 24, 2, 80, {}),                                  # hop = n_fft/2
     (2048, 700, 21, 2, 64, {}),                                   # hop not dividing n_fft (even offsets)
     (2048, 333, 48, 2, 40, {}),                                   # odd hop: scalar overlap-add
+    (2048, 1500, 20, 2, 80, {}),                                  # hardly any overlap
     (1024, 256, 50, 3, 40, {}),
     (1024, 128, 64, 2, 128, {}),                                  # 8 mel tiles, hop = n_fft/8 (tiles of exactly 16 frames)
     (1024, 256, 40, 2, 20, dict(normalized=True)),                # padded mel tile, ortho scaling
@@ -290,15 +291,50 @@ def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frame
 
 
 def test_one_launch_objective_falls_back_where_it_does_not_fit(monkeypatch):
-    """Configurations the one-launch kernel does not cover (hop > n_fft/2 at n_fft 2048: the tile's output span does not fit
-    the LDS scratch; n_fft 512; more than 128 mel bands; float64) run the kernel chain - same results as ever."""
-    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
-    fb = si.mel_filterbank(22050, 2048, 80)
-    x = 0.1 * torch.randn(2, 19 * 1500, device=dev())
-    tr = LogMelSTFT(T(fb), 2048, hop_length=1500, window=torch.from_numpy(hann(2048)))
+    """Configurations the one-launch kernel does not cover (n_fft other than 1024 / 2048; a signal whose last samples no
+    frame reaches; more than 128 mel bands; float64; two-sided spectra) run the kernel chain - same results as ever."""
+    fb = si.mel_filterbank(22050, 512, 40)
+    x = 0.1 * torch.randn(2, 30 * 128, device=dev())
+    tr = LogMelSTFT(T(fb), 512, hop_length=128, window=torch.from_numpy(hann(512)))
     _, fg = tr.bind(x, tr(x + 0.01))
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
     with pytest.raises(NotImplementedError, match="one-launch objective"):
         fg(x)
     monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "0")
     loss, g = fg(x)
     assert loss > 0 and torch.isfinite(g).all()
+    # 7 samples beyond the last frame: they get a zero gradient from the chain, the one-launch kernel is not used
+    fb = si.mel_filterbank(22050, 1024, 40)
+    x = 0.1 * torch.randn(2, 30 * 256 + 7, device=dev())
+    tr = LogMelSTFT(T(fb), 1024, hop_length=256, window=torch.from_numpy(hann(1024)))
+    _, fg = tr.bind(x, tr(x + 0.01))
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    with pytest.raises(NotImplementedError, match="one-launch objective"):
+        fg(x)
+
+
+@pytest.mark.parametrize("n_mels", [80, 33])
+def test_one_launch_objective_with_a_dense_matrix(monkeypatch, n_mels):
+    """The block list leaves out all-zero 16 x 16 blocks of the filterbank; a dense (random, signed-free) matrix keeps
+    every block, a matrix with one non-zero entry keeps one - both against the float64 oracle."""
+    n_fft, hop, frames, batch = 1024, 256, 40, 2
+    rng = np.random.default_rng(n_mels)
+    w = hann(n_fft)
+    xs = (0.1 * rng.standard_normal((batch, (frames - 1) * hop))).astype(np.float32)
+    x0 = (0.05 * rng.standard_normal(xs.shape)).astype(np.float32)
+    dense = (0.02 * rng.random((n_mels, n_fft // 2 + 1))).astype(np.float32)
+    single = np.zeros_like(dense)
+    single[n_mels - 1, 300] = 0.5
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    for fb in (dense, single, np.zeros_like(dense)):
+        tr = LogMelSTFT(T(fb), n_fft, hop_length=hop, window=torch.from_numpy(w))
+        _, fg = tr.bind(T(x0), tr(T(xs)))
+        loss, grad = fg(T(x0))
+        a = oracle.args_helper(n_fft // 2 + 1, np.float64, hop_length=hop, window=w.astype(np.float64))
+        ref = LogMelStft(a, fb.astype(np.float64))
+        lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
+        if not fb.any():
+            assert loss == 0.0 and not N(grad).any()
+            continue
+        assert abs(loss - lo) < 1e-5 * abs(lo), (loss, lo)
+        assert rel_l2(N(grad), go) < 1e-5, rel_l2(N(grad), go)
