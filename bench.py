@@ -265,14 +265,19 @@ def main():
         fwd, fg_raw = tr.bind(x_init, target)
         counters = {"evals": 0}
 
-        def fg(v):
+        def timed_eval(call):
             e0, e1 = ev(), ev()
-            e0.record()
-            out = fg_raw(v)
+            e0.record()                                     # HIP events on the stream the objective is launched on
+            out = call()
             e1.record()
             events.append((e0, e1, 1))
             counters["evals"] += 1
             return out
+
+        def fg(v):
+            return timed_eval(lambda: fg_raw(v))
+
+        fg.dev = lambda v, loss_ptr: timed_eval(lambda: fg_raw.dev(v, loss_ptr))   # loss left on the device: no sync per evaluation
 
         from spectrogram_inversion_amd.lbfgs import LBFGS
 

@@ -223,6 +223,21 @@ int specinv_lbfgs_pair(specinv_plan* plan, const void* g, const void* g_prev, co
                        void* s_out, int64_t n, double* out_host);
 int specinv_lbfgs_stats(specinv_plan* plan, const void* g, const void* d, int64_t n, double* out_host);
 
+/* The same passes with their scalar results left in DEVICE memory (doubles) and no host synchronisation, so that one
+ * L-BFGS iteration (objective, step statistics, curvature pair, memory products) is enqueued back to back and the host
+ * reads everything it needs for its decisions (torch.optim.LBFGS.step: y.s > 1e-10, the tolerance tests) with ONE
+ * synchronisation: specinv_read_doubles.  pair: out_dev[4] = {y.s, y.y, g.g, g.g_prev}; stats: out_dev[4] as above;
+ * multi_dot: out_dev[k]; loss_grad: *loss_dev = the loss. */
+int specinv_transform_loss_grad_dev(specinv_plan* plan, const void* x, int64_t length, const void* target,
+                                    double* loss_dev, void* grad_out);
+int specinv_vec_multi_dot_dev(specinv_plan* plan, const void* g, const void* const* vecs_host, int k, int64_t n,
+                              double* out_dev);
+int specinv_lbfgs_pair_dev(specinv_plan* plan, const void* g, const void* g_prev, const void* d, double t, void* y_out,
+                           void* s_out, int64_t n, double* out_dev);
+int specinv_lbfgs_stats_dev(specinv_plan* plan, const void* g, const void* d, int64_t n, double* out_dev);
+/* n doubles from device memory to the host, after everything enqueued on the plan's stream so far */
+int specinv_read_doubles(specinv_plan* plan, const double* src_dev, int n, double* out_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,24 +93,30 @@ __global__ void k_scale(T alpha, const T* __restrict__ x, T* __restrict__ y, int
   if (i < n) y[i] = alpha * x[i];
 }
 
-// One pass for the curvature pair of an L-BFGS iteration: y = g - g_prev, s = t * d, partial sums of y.s and y.y
+// One pass for the curvature pair of an L-BFGS iteration: y = g - g_prev, s = t * d, partial sums of y.s, y.y, g.g and
+// g.g_prev (the last two give the new pair's products with g by linearity: y.g = g.g - g_prev.g)
 template <typename T>
 __global__ void k_lbfgs_pair(const T* __restrict__ g, const T* __restrict__ gp, const T* __restrict__ d, T t,
                              T* __restrict__ y, T* __restrict__ sv, int64_t n, double* __restrict__ part) {
   __shared__ double red[16];
-  double ys = 0, yy = 0;
+  double ys = 0, yy = 0, gg = 0, ggp = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const T yi = g[i] - gp[i];
+    const T gi = g[i], pi = gp[i];
+    const T yi = gi - pi;
     const T si = t * d[i];
     y[i] = yi;
     sv[i] = si;
     ys += (double)yi * (double)si;
     yy += (double)yi * (double)yi;
+    gg += (double)gi * (double)gi;
+    ggp += (double)gi * (double)pi;
   }
-  const double a = block_sum(ys, red), b = block_sum(yy, red);
+  const double a = block_sum(ys, red), b = block_sum(yy, red), c = block_sum(gg, red), e = block_sum(ggp, red);
   if (threadIdx.x == 0) {
-    part[2 * blockIdx.x] = a;
-    part[2 * blockIdx.x + 1] = b;
+    part[4 * blockIdx.x] = a;
+    part[4 * blockIdx.x + 1] = b;
+    part[4 * blockIdx.x + 2] = c;
+    part[4 * blockIdx.x + 3] = e;
   }
 }
 
@@ -188,33 +194,38 @@ __global__ void k_finish_stats(const double* __restrict__ part, int n, double* _
   }
 }
 
+// Results go to the host (`out_host`: the call synchronises) or to device memory (`out_dev`: nothing waits; the partial
+// sums then live in a scratch of their own, `pl.lb_part`, slot `part_slot`, so that back-to-back passes do not share one).
 template <typename P, typename T>
-int lb_pair(P& pl, const T* g, const T* gp, const T* d, double t, T* y, T* sv, int64_t n, double* out2) {
-  SI_CHECK(g && gp && d && y && sv && out2 && n > 0, SPECINV_EINVAL, "bad arguments");
+int lb_pair(P& pl, const T* g, const T* gp, const T* d, double t, T* y, T* sv, int64_t n, double* out2_host,
+            double* out4_dev = nullptr) {
+  SI_CHECK(g && gp && d && y && sv && (out2_host || out4_dev) && n > 0, SPECINV_EINVAL, "bad arguments");
   const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
-  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * 2, 3 * 1024) * sizeof(double)));
-  hipLaunchKernelGGL((k_lbfgs_pair<T>), dim3(nb), dim3(256), 0, pl.stream, g, gp, d, (T)t, y, sv, n,
-                     pl.partials.template as<double>());
+  SI_TRY(pl.lb_part.reserve((size_t)4 * 4 * 1024 * sizeof(double)));
+  double* part = pl.lb_part.template as<double>();                      // slot 0 of 4
+  hipLaunchKernelGGL((k_lbfgs_pair<T>), dim3(nb), dim3(256), 0, pl.stream, g, gp, d, (T)t, y, sv, n, part);
   SI_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), (int64_t)nb, 2,
-                     pl.sums.template as<double>());
+  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, part, (int64_t)nb, 4,
+                     out4_dev ? out4_dev : pl.sums.template as<double>());
   SI_HIP(hipGetLastError());
-  SI_HIP(hipMemcpyAsync(out2, pl.sums.p, 2 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  if (out4_dev) return SPECINV_OK;
+  SI_HIP(hipMemcpyAsync(out2_host, pl.sums.p, 2 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
   SI_HIP(si_stream_wait_short(pl.stream));
   return SPECINV_OK;
 }
 
 template <typename P, typename T>
-int lb_stats(P& pl, const T* g, const T* d, int64_t n, double* out4) {
-  SI_CHECK(g && d && out4 && n > 0, SPECINV_EINVAL, "bad arguments");
+int lb_stats(P& pl, const T* g, const T* d, int64_t n, double* out4_host, double* out4_dev = nullptr) {
+  SI_CHECK(g && d && (out4_host || out4_dev) && n > 0, SPECINV_EINVAL, "bad arguments");
   const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
-  SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * 4, 3 * 1024) * sizeof(double)));
-  hipLaunchKernelGGL((k_lbfgs_stats<T>), dim3(nb), dim3(256), 0, pl.stream, g, d, n, pl.partials.template as<double>());
+  SI_TRY(pl.lb_part.reserve((size_t)4 * 4 * 1024 * sizeof(double)));
+  double* part = pl.lb_part.template as<double>() + 4 * 1024;           // slot 1 of 4
+  hipLaunchKernelGGL((k_lbfgs_stats<T>), dim3(nb), dim3(256), 0, pl.stream, g, d, n, part);
   SI_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_finish_stats, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), nb,
-                     pl.sums.template as<double>());
+  hipLaunchKernelGGL(k_finish_stats, dim3(1), dim3(256), 0, pl.stream, part, nb, out4_dev ? out4_dev : pl.sums.template as<double>());
   SI_HIP(hipGetLastError());
-  SI_HIP(hipMemcpyAsync(out4, pl.sums.p, 4 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  if (out4_dev) return SPECINV_OK;
+  SI_HIP(hipMemcpyAsync(out4_host, pl.sums.p, 4 * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
   SI_HIP(si_stream_wait_short(pl.stream));
   return SPECINV_OK;
 }
@@ -372,13 +383,13 @@ __global__ __launch_bounds__(256) void k_lincomb(MultiVecArgs<T> a, int accumula
 }
 
 template <typename P, typename T>
-int lb_multi_dot(P& pl, const T* g, const void* const* vecs, int k, int64_t n, double* out) {
-  SI_CHECK(g && vecs && out && k > 0 && n > 0, SPECINV_EINVAL, "bad arguments");
+int lb_multi_dot(P& pl, const T* g, const void* const* vecs, int k, int64_t n, double* out, double* out_dev = nullptr) {
+  SI_CHECK(g && vecs && (out || out_dev) && k > 0 && n > 0, SPECINV_EINVAL, "bad arguments");
   SI_CHECK(((uintptr_t)g & 15) == 0, SPECINV_EINVAL, "g is not 16-byte aligned");
   const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8 * 4)));
   SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nb * kMultiVec, 3 * 1024) * sizeof(double)));
   SI_TRY(pl.lb_scal.reserve((size_t)std::max(k, 4) * sizeof(double)));
-  double* dots = pl.lb_scal.template as<double>();
+  double* dots = out_dev ? out_dev : pl.lb_scal.template as<double>();
   for (int j0 = 0; j0 < k; j0 += kMultiVec) {
     MultiVecArgs<T> a{};
     a.k = std::min(kMultiVec, k - j0);
@@ -391,6 +402,7 @@ int lb_multi_dot(P& pl, const T* g, const void* const* vecs, int k, int64_t n, d
     hipLaunchKernelGGL(k_multi_finish, dim3(a.k), dim3(256), 0, pl.stream, pl.partials.template as<double>(), nb, dots + j0);
     SI_HIP(hipGetLastError());
   }
+  if (out_dev) return SPECINV_OK;
   SI_HIP(hipMemcpyAsync(out, dots, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, pl.stream));
   SI_HIP(si_stream_wait_short(pl.stream));
   return SPECINV_OK;
@@ -896,10 +908,23 @@ inline int obj_mel_tiles(int n_mels) {
   return mt <= 3 ? 3 : mt <= 4 ? 4 : mt <= 5 ? 5 : mt <= 8 ? 8 : 0;
 }
 
+// loss = sum(partials) / numel, to the host (synchronises) or to a device scalar (nothing waits)
+template <typename P>
+int tf_finish_loss(P& pl, int64_t n_part, double numel, double* loss_host, double* loss_dev) {
+  hipLaunchKernelGGL(k_finish_scaled, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), (int)n_part, 1.0 / numel,
+                     loss_dev ? loss_dev : pl.sums.template as<double>());
+  SI_HIP(hipGetLastError());
+  if (loss_dev) return SPECINV_OK;
+  SI_HIP(hipMemcpyAsync(loss_host, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
+  return SPECINV_OK;
+}
+
 // loss and gradient of the log-mel objective in one launch (+ the seam / padding passes of the unfused path).
 // `*used` stays false when the configuration is not covered: the caller then runs the kernel chain.
 template <typename P>
-int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, double* loss, float* grad, bool* used) {
+int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, double* loss, float* grad, bool* used,
+                       double* loss_dev = nullptr) {
   *used = false;
   if (pl.tf_kind != SPECINV_TF_LOGMEL || pl.tf_obj_mt == 0 || pl.force_generic) return SPECINV_OK;
   if (const char* e = getenv("SPECINV_DISABLE_FUSED_OBJECTIVE")) {
@@ -982,16 +1007,9 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
                        (const float*)a.xtail, T, nch, hop, keep, pad, (long long)len, total);
     SI_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), n_tiles, 1,
-                     pl.sums.template as<double>());
-  SI_HIP(hipGetLastError());
   SI_TRY(pl.launch_grad_fold(nullptr, grad, len, a.margins));
-  double s;
-  SI_HIP(hipMemcpyAsync(&s, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
-  SI_HIP(si_stream_wait_short(pl.stream));
-  *loss = s / numel;
   *used = true;
-  return SPECINV_OK;
+  return tf_finish_loss(pl, n_tiles, numel, loss, loss_dev);
 }
 
 template <typename P, typename T>
@@ -1098,9 +1116,9 @@ int tf_forward(P& pl, const T* x, int64_t len, T* v_out) {
 }
 
 template <typename P, typename T>
-int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, T* grad) {
+int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, T* grad, double* loss_dev = nullptr) {
   SI_CHECK(pl.tf_kind >= 0, SPECINV_ESTATE, "specinv_transform_setup has not been called");
-  SI_CHECK(x && target && loss && grad, SPECINV_EINVAL, "null pointer");
+  SI_CHECK(x && target && (loss || loss_dev) && grad, SPECINV_EINVAL, "null pointer");
   using C = cplx<T>;
   const int64_t BT = (int64_t)pl.B() * pl.Tn();
   {
@@ -1110,7 +1128,7 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
   }
   if constexpr (std::is_same<T, float>::value) {
     bool used = false;
-    SI_TRY(tf_loss_grad_fused(pl, x, len, target, loss, grad, &used));
+    SI_TRY(tf_loss_grad_fused(pl, x, len, target, loss, grad, &used, loss_dev));
     if (used) return SPECINV_OK;
   }
   if (const char* e = getenv("SPECINV_REQUIRE_FUSED_OBJECTIVE")) {     // tests: the shape must be on the one-launch kernel
@@ -1162,15 +1180,15 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
     }
     SI_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), (int64_t)nb, 1,
-                     pl.sums.template as<double>());
+  // (the sum is finished before the next kernel that uses the partials scratch)
+  hipLaunchKernelGGL(k_finish_scaled, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), nb, 1.0 / numel,
+                     loss_dev ? loss_dev : pl.sums.template as<double>());
   SI_HIP(hipGetLastError());
   // frames of the gradient: irfft-style inverse with the forward scale
   SI_TRY(pl.grad_from_spec(pl.tf_spec.template as<C>(), grad, pl.fc.fwd_scale, len));
-  double s;
-  SI_HIP(hipMemcpyAsync(&s, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  if (loss_dev) return SPECINV_OK;
+  SI_HIP(hipMemcpyAsync(loss, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
   SI_HIP(si_stream_wait_short(pl.stream));
-  *loss = s / numel;
   return SPECINV_OK;
 }
 

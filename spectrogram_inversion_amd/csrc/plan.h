@@ -66,17 +66,20 @@ struct PlanBase {
 
   virtual int transform_setup(int kind, const void* mel_fb, int n_mels) = 0;
   virtual int transform_forward(const void* x, int64_t len, void* v_out) = 0;
-  virtual int transform_loss_grad(const void* x, int64_t len, const void* target, double* loss, void* grad) = 0;
+  virtual int transform_loss_grad(const void* x, int64_t len, const void* target, double* loss, void* grad,
+                                  double* loss_dev = nullptr) = 0;
   virtual int vec_dot(const void* a, const void* b, int64_t n, double* out) = 0;
   virtual int vec_axpy(double alpha, const void* x, void* y, int64_t n) = 0;
   virtual int vec_scale(double alpha, const void* x, void* y, int64_t n) = 0;
   virtual int vec_absmax_abssum(const void* x, int64_t n, double out[2]) = 0;
   virtual int lbfgs_direction(const void* g, const void* const* s_list, const void* const* y_list, const double* rho,
                               int m, double h_diag, void* d_out, int64_t n) = 0;
-  virtual int vec_multi_dot(const void* g, const void* const* vecs, int k, int64_t n, double* out) = 0;
+  virtual int vec_multi_dot(const void* g, const void* const* vecs, int k, int64_t n, double* out, double* out_dev = nullptr) = 0;
   virtual int vec_lincomb(const void* const* vecs, const double* coef, int k, int64_t n, void* out) = 0;
-  virtual int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out) = 0;
-  virtual int lbfgs_stats(const void* g, const void* d, int64_t n, double* out) = 0;
+  virtual int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out,
+                         double* out_dev = nullptr) = 0;
+  virtual int lbfgs_stats(const void* g, const void* d, int64_t n, double* out, double* out_dev = nullptr) = 0;
+  virtual int read_doubles(const double* src_dev, int n, double* out_host) = 0;
 
   // _training_loop (methods.py:153-190) driving `iterate`
   int run_loop(int max_iter, int eva_iter, double tol, int metric, specinv_eval* evals, int* n_evals,

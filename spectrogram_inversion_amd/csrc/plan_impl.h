@@ -88,7 +88,7 @@ struct PlanT final : PlanBase {
   DevBuf rt_state;                      // RTISI per-item state
   DevBuf rs_state;                      // ... of the streaming recursion (survives between pushes)
   RtisiStream<T> rstream;
-  DevBuf lb_scal;                       // device scalars of the L-BFGS two-loop recursion
+  DevBuf lb_scal, lb_part;              // device scalars / partial sums of the L-BFGS passes
   DevBuf eval_log;                      // per-evaluation sums of a run with deferred read-back
   DevBuf tf_mel, tf_mel_tiled, tf_mel_tiled_t, tf_spec, tf_v;   // transform (L_BFGS) scratch
   DevBuf tf_mel_a, tf_mel_b, tf_obj_tab;   // non-zero filterbank blocks in MFMA operand order + block table (one-launch objective)
@@ -677,9 +677,9 @@ struct PlanT final : PlanBase {
   int transform_forward(const void* xin, int64_t len, void* v_out) override {
     return tf_forward(*this, static_cast<const T*>(xin), len, static_cast<T*>(v_out));
   }
-  int transform_loss_grad(const void* xin, int64_t len, const void* target, double* loss, void* grad) override {
+  int transform_loss_grad(const void* xin, int64_t len, const void* target, double* loss, void* grad, double* loss_dev) override {
     return tf_loss_grad(*this, static_cast<const T*>(xin), len, static_cast<const T*>(target), loss,
-                        static_cast<T*>(grad));
+                        static_cast<T*>(grad), loss_dev);
   }
   int vec_dot(const void* a, const void* b, int64_t n, double* out) override {
     return lb_dot(*this, static_cast<const T*>(a), static_cast<const T*>(b), n, out);
@@ -697,18 +697,25 @@ struct PlanT final : PlanBase {
                       double h_diag, void* d_out, int64_t n) override {
     return lb_direction(*this, static_cast<const T*>(g), s_list, y_list, rho, m, h_diag, static_cast<T*>(d_out), n);
   }
-  int vec_multi_dot(const void* g, const void* const* vecs, int k, int64_t n, double* out) override {
-    return lb_multi_dot(*this, static_cast<const T*>(g), vecs, k, n, out);
+  int vec_multi_dot(const void* g, const void* const* vecs, int k, int64_t n, double* out, double* out_dev) override {
+    return lb_multi_dot(*this, static_cast<const T*>(g), vecs, k, n, out, out_dev);
   }
   int vec_lincomb(const void* const* vecs, const double* coef, int k, int64_t n, void* out) override {
     return lb_lincomb(*this, vecs, coef, k, n, static_cast<T*>(out));
   }
-  int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out) override {
+  int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out,
+                 double* out_dev) override {
     return lb_pair(*this, static_cast<const T*>(g), static_cast<const T*>(gp), static_cast<const T*>(d), t, static_cast<T*>(y),
-                   static_cast<T*>(sv), n, out);
+                   static_cast<T*>(sv), n, out, out_dev);
   }
-  int lbfgs_stats(const void* g, const void* d, int64_t n, double* out) override {
-    return lb_stats(*this, static_cast<const T*>(g), static_cast<const T*>(d), n, out);
+  int lbfgs_stats(const void* g, const void* d, int64_t n, double* out, double* out_dev) override {
+    return lb_stats(*this, static_cast<const T*>(g), static_cast<const T*>(d), n, out, out_dev);
+  }
+  int read_doubles(const double* src_dev, int n, double* out_host) override {
+    SI_CHECK(src_dev && out_host && n > 0, SPECINV_EINVAL, "bad arguments");
+    SI_HIP(hipMemcpyAsync(out_host, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    SI_HIP(si_stream_wait_short(stream));
+    return SPECINV_OK;
   }
 };
 

@@ -346,6 +346,12 @@ int specinv_transform_loss_grad(specinv_plan* plan, const void* x, int64_t lengt
   ENTER(plan);
   return plan->impl->transform_loss_grad(x, length, target, loss_host, grad_out);
 }
+int specinv_transform_loss_grad_dev(specinv_plan* plan, const void* x, int64_t length, const void* target,
+                                    double* loss_dev, void* grad_out) {
+  ENTER(plan);
+  SI_CHECK(loss_dev, SPECINV_EINVAL, "loss_dev is NULL");
+  return plan->impl->transform_loss_grad(x, length, target, nullptr, grad_out, loss_dev);
+}
 int specinv_vec_dot(specinv_plan* plan, const void* a, const void* b, int64_t n, double* out_host) {
   ENTER(plan);
   return plan->impl->vec_dot(a, b, n, out_host);
@@ -388,6 +394,28 @@ int specinv_lbfgs_pair(specinv_plan* plan, const void* g, const void* g_prev, co
 int specinv_lbfgs_stats(specinv_plan* plan, const void* g, const void* d, int64_t n, double* out_host) {
   ENTER(plan);
   return plan->impl->lbfgs_stats(g, d, n, out_host);
+}
+
+int specinv_vec_multi_dot_dev(specinv_plan* plan, const void* g, const void* const* vecs_host, int k, int64_t n,
+                              double* out_dev) {
+  ENTER(plan);
+  SI_CHECK(out_dev, SPECINV_EINVAL, "out_dev is NULL");
+  return plan->impl->vec_multi_dot(g, vecs_host, k, n, nullptr, out_dev);
+}
+int specinv_lbfgs_pair_dev(specinv_plan* plan, const void* g, const void* g_prev, const void* d, double t, void* y_out,
+                           void* s_out, int64_t n, double* out_dev) {
+  ENTER(plan);
+  SI_CHECK(out_dev, SPECINV_EINVAL, "out_dev is NULL");
+  return plan->impl->lbfgs_pair(g, g_prev, d, t, y_out, s_out, n, nullptr, out_dev);
+}
+int specinv_lbfgs_stats_dev(specinv_plan* plan, const void* g, const void* d, int64_t n, double* out_dev) {
+  ENTER(plan);
+  SI_CHECK(out_dev, SPECINV_EINVAL, "out_dev is NULL");
+  return plan->impl->lbfgs_stats(g, d, n, nullptr, out_dev);
+}
+int specinv_read_doubles(specinv_plan* plan, const double* src_dev, int n, double* out_host) {
+  ENTER(plan);
+  return plan->impl->read_doubles(src_dev, n, out_host);
 }
 
 }  // extern "C"

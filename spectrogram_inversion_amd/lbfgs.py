@@ -56,6 +56,32 @@ class HipVecOps:
     def stats(self, g, d):
         return self.plan.lbfgs_stats(g, d)
 
+    # -- packed form: results stay in a device "board" of doubles; `read` is the only synchronisation -----------------
+    packed = True
+
+    def board(self, n):
+        return torch.zeros(n, dtype=torch.float64, device=self.plan.device)
+
+    def eval_into(self, fg, x, board, slot):
+        """gradient of the objective at x; the loss goes to board[slot]"""
+        if hasattr(fg, "dev"):
+            return fg.dev(x, board.data_ptr() + 8 * slot)
+        loss, g = fg(x)                                    # a generic callable: its loss is already on the host
+        board[slot:slot + 1].fill_(float(loss))
+        return g
+
+    def stats_into(self, g, d, board, slot):
+        self.plan.lbfgs_stats_dev(g, d, board.data_ptr() + 8 * slot)
+
+    def pair_into(self, g, g_prev, d, t, board, slot):
+        return self.plan.lbfgs_pair_dev(g, g_prev, d, t, board.data_ptr() + 8 * slot)
+
+    def multi_dot_into(self, g, vecs, board, slot):
+        self.plan.vec_multi_dot_dev(g, vecs, board.data_ptr() + 8 * slot)
+
+    def read(self, board, n):
+        return self.plan.read_doubles(board.data_ptr(), n)
+
 
 def _cubic_step(xa, fa, ga, xb, fb, gb, bounds=None):
     """Minimiser of the cubic interpolating (xa, fa, ga) and (xb, fb, gb), clipped to bounds."""
@@ -97,6 +123,7 @@ class LBFGS:
         self._forget()
         self.prev_grad = None
         self.prev_loss = None
+        self._board = None
 
     # ---- pieces -----------------------------------------------------------------------------
     def _forget(self):
@@ -124,6 +151,14 @@ class LBFGS:
         ops, m = self.ops, len(self.ss)
         dots = np.asarray(ops.multi_dot(g, self.ss + self.ys), dtype=np.float64)
         sg, yg = dots[:m], dots[m:]
+        self._gram_append(sg, yg)
+        # d = -(gamma (g - sum al_j y_j) + sum c_i s_i)
+        return ops.lincomb([g] + self.ys + self.ss, self._gram_coefficients(sg, yg))
+
+    def _gram_append(self, sg, yg):
+        """Bring the Gram matrices s_i.y_j, y_i.y_j up to date with the memory (a pair may have been appended since the
+        previous direction) from the products `sg`, `yg` of the current gradient with the memory."""
+        m = len(self.ss)
         if self._pushed is not None:
             ys_new, yy_new = self._pushed
             sy, yy = np.zeros((m, m)), np.zeros((m, m))
@@ -134,6 +169,10 @@ class LBFGS:
             sy[m - 1, m - 1], yy[m - 1, m - 1] = ys_new, yy_new
             self._sy, self._yy, self._pushed = sy, yy, None
         self._sg, self._yg = sg, yg
+
+    def _gram_coefficients(self, sg, yg):
+        """Coefficients of d = -H g as a linear combination of [g] + ys + ss (the two-loop recursion on scalars)."""
+        m = len(self.ss)
         rho, gamma = np.asarray(self.rho, dtype=np.float64), float(self.h_diag)
         al = np.zeros(m)
         for i in range(m - 1, -1, -1):
@@ -142,8 +181,7 @@ class LBFGS:
         c = np.zeros(m)                                          # al_i - be_i
         for i in range(m):
             c[i] = al[i] - rho[i] * (gamma * yq[i] + np.dot(c[:i], self._sy[:i, i]))
-        # d = -(gamma (g - sum al_j y_j) + sum c_i s_i)
-        return ops.lincomb([g] + self.ys + self.ss, [-gamma] + list(gamma * al) + list(-c))
+        return [-gamma] + list(gamma * al) + list(-c)
 
     def _direction(self, g):
         """Two-loop recursion: returns -H g for the current memory."""
@@ -231,8 +269,102 @@ class LBFGS:
             lo = 0
         return br[lo][1], br[lo][2], br[lo][0], evals
 
+    # ---- one optimizer.step, one host synchronisation per inner iteration ------------------------
+    def _batch(self, fg, x, d, t):
+        """Everything the next decisions need, enqueued back to back and fetched with ONE read: the objective at x (loss,
+        gradient g), the step statistics {g.d, sum|g|, max|g|, max|d|} and - once there is a previous gradient - the
+        curvature pair y = g - g_prev, s = t d with {y.s, y.y, g.g, g.g_prev} and the products of g with the memory."""
+        ops = self.ops
+        m = len(self.ss)
+        have_prev = self.total_iters >= 1
+        if self._board is None or self._board.numel() < 9 + 2 * self.history_size:
+            self._board = ops.board(9 + 2 * self.history_size)
+        bd = self._board
+        g = ops.eval_into(fg, x, bd, 0)
+        ops.stats_into(g, d if have_prev else g, bd, 1)
+        y = s = None
+        if have_prev:
+            y, s = ops.pair_into(g, self.prev_grad, d, t, bd, 5)
+            if m:
+                ops.multi_dot_into(g, self.ss + self.ys, bd, 9)
+        v = ops.read(bd, 9 + 2 * m if have_prev else 5)
+        out = dict(g=g, loss=v[0], gd=v[1], g_abssum=v[2], g_absmax=v[3], d_absmax=v[4], have_prev=have_prev, m=m)
+        if have_prev:
+            out.update(y=y, s=s, ys=v[5], yy=v[6], gg=v[7], ggp=v[8], sg=np.asarray(v[9:9 + m], dtype=np.float64),
+                       yg=np.asarray(v[9 + m:9 + 2 * m], dtype=np.float64))
+        return out
+
+    def _step_packed(self, fg):
+        """`step` for a backend with device-resident results (no line search): the same decisions in the same order as
+        torch.optim.LBFGS.step, taken from one packed read-back per inner iteration.  The products of the new pair with
+        the gradient follow by linearity (s.g = t d.g, y.g = g.g - g_prev.g), and so does g.d of the new direction, a
+        linear combination of vectors whose products with g are all known."""
+        ops, x = self.ops, self.x
+        b = self._batch(fg, x, self.d, self.t)
+        loss = first_loss = b["loss"]
+        evals = 1
+        self.func_evals += 1
+        if b["g_absmax"] <= self.tol_grad:
+            return first_loss
+        d, t = self.d, self.t
+        n_iter = 0
+        while n_iter < self.max_iter:
+            n_iter += 1
+            self.total_iters += 1
+            g = b["g"]
+            if self.total_iters == 1:
+                self._forget()
+                gtd = -b["gd"]                                 # statistics were taken with d = g: g.g
+                vecs, coefs = None, None
+            else:
+                sg, yg = b["sg"], b["yg"]
+                if b["ys"] > 1e-10:
+                    if len(self.ys) == self.history_size:
+                        self._drop_oldest()
+                        if b["m"] == self.history_size:
+                            sg, yg = sg[1:], yg[1:]
+                    self.ys.append(b["y"])
+                    self.ss.append(b["s"])
+                    self.rho.append(1.0 / b["ys"])
+                    self.h_diag = b["ys"] / b["yy"]
+                    self._pushed = (b["ys"], b["yy"])
+                    sg = np.append(sg, t * b["gd"])            # s_new . g = t (d . g)
+                    yg = np.append(yg, b["gg"] - b["ggp"])     # y_new . g = g . g - g_prev . g
+                self._gram_append(sg, yg)
+                coefs = self._gram_coefficients(sg, yg)
+                vecs = [g] + self.ys + self.ss
+                m = len(self.ss)
+                gtd = coefs[0] * b["gg"] + float(np.dot(coefs[1:1 + m], yg)) + float(np.dot(coefs[1 + m:], sg))
+            self.prev_grad = g
+            self.prev_loss = loss
+            t = min(1.0, 1.0 / b["g_abssum"]) * self.lr if self.total_iters == 1 else self.lr
+            d = ops.scaled(-1.0, g) if vecs is None else ops.lincomb(vecs, coefs)
+            if gtd > -self.tol_change:
+                break
+            ops.axpy(t, d, x)
+            ls_evals = 0
+            opt = False
+            if n_iter != self.max_iter:
+                b = self._batch(fg, x, d, t)
+                loss = b["loss"]
+                opt = b["g_absmax"] <= self.tol_grad
+                ls_evals = 1
+            evals += ls_evals
+            self.func_evals += ls_evals
+            if n_iter == self.max_iter or evals >= self.max_eval or opt:
+                break
+            if abs(t) * b["d_absmax"] <= self.tol_change:
+                break
+            if abs(loss - self.prev_loss) < self.tol_change:
+                break
+        self.d, self.t = d, t
+        return first_loss
+
     # ---- one optimizer.step ------------------------------------------------------------------
     def step(self, fg):
+        if self.line_search is None and self.gram and getattr(self.ops, "packed", False) and \
+                os.environ.get("SPECINV_LBFGS_PACKED", "1") != "0":
+            return self._step_packed(fg)
         ops, x = self.ops, self.x
         fused = hasattr(ops, "pair") and hasattr(ops, "stats")     # one pass per group of vector operations
         loss, g = fg(x)

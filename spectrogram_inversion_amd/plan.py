@@ -469,6 +469,42 @@ class Plan:
         _lib.check(self.lib.specinv_lbfgs_stats(self._h, g.data_ptr(), d.data_ptr(), g.numel(), out))
         return out[0], out[1], out[2], out[3]
 
+    # -- the same passes with device-resident results (one L-BFGS iteration = one host synchronisation) ----------------
+    def transform_loss_grad_dev(self, x: torch.Tensor, target: torch.Tensor, loss_ptr: int) -> torch.Tensor:
+        self._sync_stream()
+        x = self._in(x, self.dtype)
+        target = self._in(target, self.dtype, (self.batch, self.n_out, self.n_frames))
+        grad = torch.empty_like(x)
+        _lib.check(self.lib.specinv_transform_loss_grad_dev(self._h, x.data_ptr(), x.shape[-1], target.data_ptr(), loss_ptr,
+                                                            grad.data_ptr()))
+        return grad
+
+    def vec_multi_dot_dev(self, g, vecs, out_ptr: int):
+        self._sync_stream()
+        k = len(vecs)
+        assert g.data_ptr() % 16 == 0 and all(t.data_ptr() % 16 == 0 for t in vecs)
+        vp = (C.c_void_p * k)(*[t.data_ptr() for t in vecs])
+        _lib.check(self.lib.specinv_vec_multi_dot_dev(self._h, g.data_ptr(), vp, k, g.numel(), out_ptr))
+
+    def lbfgs_pair_dev(self, g, g_prev, d, t, out_ptr: int):
+        """y = g - g_prev, s = t*d; {y.s, y.y, g.g, g.g_prev} to device memory.  Returns (y, s)."""
+        self._sync_stream()
+        y, s = torch.empty_like(g), torch.empty_like(g)
+        _lib.check(self.lib.specinv_lbfgs_pair_dev(self._h, g.data_ptr(), g_prev.data_ptr(), d.data_ptr(), float(t), y.data_ptr(),
+                                                   s.data_ptr(), g.numel(), out_ptr))
+        return y, s
+
+    def lbfgs_stats_dev(self, g, d, out_ptr: int):
+        """{g.d, sum|g|, max|g|, max|d|} to device memory."""
+        self._sync_stream()
+        _lib.check(self.lib.specinv_lbfgs_stats_dev(self._h, g.data_ptr(), d.data_ptr(), g.numel(), out_ptr))
+
+    def read_doubles(self, ptr: int, n: int):
+        self._sync_stream()
+        out = (C.c_double * n)()
+        _lib.check(self.lib.specinv_read_doubles(self._h, ptr, n, out))
+        return list(out)
+
     def vec_absmax_abssum(self, x):
         self._sync_stream()
         out = (C.c_double * 2)()

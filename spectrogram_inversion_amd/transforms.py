@@ -75,6 +75,11 @@ class DeviceTransform:
             loss, g = plan.transform_loss_grad(v.reshape(x2.shape), tgt)
             return loss, g.reshape(v.shape)
 
+        def fg_dev(v, loss_ptr):
+            """gradient now, loss left in device memory at `loss_ptr` (no host synchronisation)"""
+            return plan.transform_loss_grad_dev(v.reshape(x2.shape), tgt, loss_ptr).reshape(v.shape)
+
+        fg.dev = fg_dev
         return fwd, fg
 
 

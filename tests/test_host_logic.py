@@ -151,6 +151,82 @@ class GramTorchVecOps(TorchVecOps):
         return out.to(vecs[0].dtype)
 
 
+class PackedTorchVecOps(GramTorchVecOps):
+    """... plus the packed interface of the HIP backend (results parked on a "board", one read per iteration): drives
+    `LBFGS._step_packed`, the loop the GPU runs, on CPU tensors.  `reads` counts the synchronisation points."""
+    packed = True
+
+    def __init__(self):
+        self.reads = 0
+
+    def board(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def eval_into(self, fg, x, board, slot):
+        loss, g = fg(x)
+        board[slot] = loss
+        return g
+
+    def stats_into(self, g, d, board, slot):
+        g64, d64 = g.double().reshape(-1), d.double().reshape(-1)
+        board[slot:slot + 4] = torch.stack([torch.dot(g64, d64), g64.abs().sum(), g64.abs().max(), d64.abs().max()])
+
+    def pair_into(self, g, g_prev, d, t, board, slot):
+        y, s = g - g_prev, d * t
+        g64 = g.double().reshape(-1)
+        board[slot:slot + 4] = torch.stack([torch.dot(y.double().reshape(-1), s.double().reshape(-1)),
+                                            torch.dot(y.double().reshape(-1), y.double().reshape(-1)), torch.dot(g64, g64),
+                                            torch.dot(g64, g_prev.double().reshape(-1))])
+        return y, s
+
+    def multi_dot_into(self, g, vecs, board, slot):
+        board[slot:slot + len(vecs)] = torch.tensor(self.multi_dot(g, vecs), dtype=torch.float64)
+
+    def read(self, board, n):
+        self.reads += 1
+        return board[:n].tolist()
+
+
+@pytest.mark.parametrize("tag,kw", [("fixed", dict(max_iter=30, lr=1e-3, history_size=4)),
+                                    ("fixed_h2", dict(max_iter=12, lr=1e-3, history_size=2))])
+def test_lbfgs_packed_loop_retraces_torch(tag, kw):
+    """The one-synchronisation-per-iteration loop (`_step_packed`) against torch.optim.LBFGS itself: same losses, same
+    iterate, and exactly one read per objective evaluation."""
+    g = load_golden("g9_lbfgs_rosen")
+    x = torch.from_numpy(g["x0"].copy())
+    xt = torch.nn.Parameter(torch.from_numpy(g["x0"].copy()))
+    losses, ref = [], []
+
+    def rosen(v):
+        a, b = v[1:] - v[:-1] ** 2, 1.0 - v[:-1]
+        return (100.0 * a * a + b * b).sum()
+
+    def fg(v):
+        p = v.detach().clone().requires_grad_(True)
+        f = rosen(p)
+        (gr,) = torch.autograd.grad(f, p)
+        losses.append(float(f))
+        return float(f), gr
+
+    topt = torch.optim.LBFGS([xt], **kw)
+
+    def closure():
+        topt.zero_grad()
+        f = rosen(xt)
+        f.backward()
+        ref.append(float(f))
+        return f
+
+    ops = PackedTorchVecOps()
+    opt = LBFGS(x, vec_ops=ops, **kw)
+    for _ in range(3):
+        opt.step(fg)
+        topt.step(closure)
+    assert ops.reads == len(losses) == len(ref)
+    np.testing.assert_allclose(losses, ref, rtol=5e-4, atol=1e-7)
+    np.testing.assert_allclose(x.numpy(), xt.detach().numpy(), rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("backend", [TorchVecOps, GramTorchVecOps])
 @pytest.mark.parametrize("tag,kw", [("wolfe", dict(max_iter=40, history_size=5, line_search_fn="strong_wolfe")),
                                     ("wolfe_h100", dict(max_iter=25, line_search_fn="strong_wolfe")),
