@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/profile_workloads.sh (gpurun_out/<tag>_<W>_*) into the committed summaries under
+profiles/: per workload the kernel-trace statistics (<tag>_<W>_kernel_stats.csv), the PMC means of its dominant kernels
+(<tag>_<W>_pmc.json) and profiles/traffic.json (HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: on gfx950
+FETCH_SIZE counts a 16-B/lane streaming read at half its bytes, MI355X_MICROARCH.md, HBM section)."""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+DOMINANT = {
+    "C2": ["specinv::fast::k_fused4<16, 0, false>", "specinv::fast::k_fused4<16, 0, true>", "specinv::k_phase_init<float>"],
+    "C4": ["specinv::fast::k_fused4<8, 1, false>", "specinv::fast::k_fused4<8, 1, true>"],
+    "C3": ["specinv::fast::k_rtisi_fast<16, 256, 4>"],
+    "C5": ["specinv::fast::k_objective_logmel<16, 5>", "specinv::k_lincomb<float>", "specinv::k_lbfgs_pair<float>",
+           "specinv::k_lbfgs_stats<float>", "specinv::k_axpy<float>"],
+}
+ALGO = {"C2": 64 * 1024 * 24596, "C4": 32 * 2048 * 20516, "C3": None, "C5": 16 * 1024 * 4416}
+out = os.path.join(ROOT, "profiles")
+traffic_path = os.path.join(out, "traffic.json")
+try:
+    traffic = json.load(open(traffic_path))
+except (OSError, ValueError):
+    traffic = {}
+
+
+def newest(pattern):
+    f = sorted(glob.glob(os.path.join(ROOT, pattern)), key=os.path.getmtime)
+    return f[-1] if f else None
+
+
+for W, kernels in DOMINANT.items():
+    stats = newest(f"gpurun_out/{tag}_{W}_kt/*/*kernel_stats.csv")
+    if not stats:
+        continue
+    shutil.copy(stats, os.path.join(out, f"{tag}_{W}_kernel_stats.csv"))
+    trace = newest(f"gpurun_out/{tag}_{W}_kt/*/*kernel_trace.csv")
+    summary = {"command": f"rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --workload {W} --steps 2 --warmup 1 "
+                          f"--no-cpu-baseline --no-check (one run per counter group, tools/profile_workloads.sh)", "kernels": {}}
+    rows = list(csv.DictReader(open(trace))) if trace else []
+    for kern in kernels:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if kern in r["Kernel_Name"]]
+        entry = {}
+        if d:
+            tail = d[len(d) // 3:]                       # launches of the two timed steps (the warm-up step pays first touch)
+            entry["kernel_trace"] = {"launches": len(d), "mean_us": sum(d) / len(d), "steady_mean_us": sum(tail) / len(tail),
+                                     "min_us": min(d), "max_us": max(d)}
+        counters = {}
+        for grp in ("fetch", "write", "sq", "inst", "mfma"):
+            f = newest(f"gpurun_out/{tag}_{W}_pmc_{grp}/*/*counter_collection.csv")
+            if not f:
+                continue
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if kern in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for k, v in agg.items():
+                counters[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+        entry["counters"] = counters
+        if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+            entry["hbm_bytes_per_launch"] = (2 * counters["FETCH_SIZE"]["mean_per_launch"] + counters["WRITE_SIZE"]["mean_per_launch"]) * 1024
+        c = counters
+        if "SQ_WAVE_CYCLES" in c:
+            wc = c["SQ_WAVE_CYCLES"]["mean_per_launch"]
+            entry["wave_cycle_shares"] = {k: c[k]["mean_per_launch"] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                                                                                   "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS") if k in c}
+        summary["kernels"][kern] = entry
+    json.dump(summary, open(os.path.join(out, f"{tag}_{W}_pmc.json"), "w"), indent=1)
+    first = summary["kernels"].get(kernels[0], {})
+    if "hbm_bytes_per_launch" in first:
+        traffic[W] = first["hbm_bytes_per_launch"]
+        traffic[f"_{W}_note"] = (f"{kernels[0]}: (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/{tag}_{W}_pmc.json"
+                                 + (f"; algorithmic {ALGO[W]} B" if ALGO[W] else ""))
+    kt = first.get("kernel_trace", {})
+    print(W, kernels[0], "steady %.1f us" % kt.get("steady_mean_us", float("nan")),
+          "traffic %.4g B" % first.get("hbm_bytes_per_launch", float("nan")),
+          ("= %.3f x algorithmic" % (first["hbm_bytes_per_launch"] / ALGO[W])) if ALGO[W] and "hbm_bytes_per_launch" in first else "")
+json.dump(traffic, open(traffic_path, "w"), indent=1)
