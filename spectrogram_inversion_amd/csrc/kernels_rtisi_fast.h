@@ -154,6 +154,11 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
   }
   int base = a.i_begin % nslots;   // ring slot of the oldest kept frame
   const float half_scale = 0.5f * a.fwd_scale;
+  // pass-1 twiddles of the FFT in registers (one wave per SIMD: the register file is not the constraint, and every LDS
+  // read of a lone wave is exposed latency)
+  TwRegs<R> twr;
+#pragma unroll
+  for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = lds_tw1[(k1 - 1) * 64 + lane];
 
   for (int i = a.i_begin; i < a.i_end; ++i) {
     // target of this wave's frame for the whole outer step (zero outside the spectrogram: methods.py:339)
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         for (int u = 0; u < R; ++u) z[u] = z[u] * win[64 * u + lane];
       }
 
-      fft_forward<R>(z, k, lds_tw1, tr);
+      fft_forward_t<R>(z, k, twr, tr);
 
       v2f rc[H];
 #pragma unroll
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
         z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
       }
-      fft_inverse<R>(z, k, lds_tw1, tr);
+      fft_inverse_t<R>(z, k, twr, tr);
 
       if (q == 0 && i >= la && it == a.max_iter - 1) {   // commit look-ahead slot 0 (methods.py:401-404)
         const v2f* w = reinterpret_cast<const v2f*>(a.window);
