@@ -235,6 +235,9 @@ int specinv_vec_multi_dot_dev(specinv_plan* plan, const void* g, const void* con
 int specinv_lbfgs_pair_dev(specinv_plan* plan, const void* g, const void* g_prev, const void* d, double t, void* y_out,
                            void* s_out, int64_t n, double* out_dev);
 int specinv_lbfgs_stats_dev(specinv_plan* plan, const void* g, const void* d, int64_t n, double* out_dev);
+/* both in one pass over g, g_prev, d: out_dev[8] = {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev} */
+int specinv_lbfgs_pair_stats_dev(specinv_plan* plan, const void* g, const void* g_prev, const void* d, double t,
+                                 void* y_out, void* s_out, int64_t n, double* out_dev);
 /* n doubles from device memory to the host, after everything enqueued on the plan's stream so far */
 int specinv_read_doubles(specinv_plan* plan, const double* src_dev, int n, double* out_host);
 

@@ -94,6 +94,7 @@ SIGNATURES = {
     "specinv_vec_multi_dot_dev": (C.c_int, [_P, _P, C.POINTER(_P), C.c_int, _I64, _P]),
     "specinv_lbfgs_pair_dev": (C.c_int, [_P, _P, _P, _P, _D, _P, _P, _I64, _P]),
     "specinv_lbfgs_stats_dev": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "specinv_lbfgs_pair_stats_dev": (C.c_int, [_P, _P, _P, _P, _D, _P, _P, _I64, _P]),
     "specinv_read_doubles": (C.c_int, [_P, _P, C.c_int, _DP]),
 }
 

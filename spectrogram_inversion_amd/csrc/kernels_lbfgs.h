@@ -194,6 +194,110 @@ __global__ void k_finish_stats(const double* __restrict__ part, int n, double* _
   }
 }
 
+// The curvature pair and the step statistics in ONE pass over g, g_prev, d (what an L-BFGS iteration needs to know about
+// the new gradient): partials per block = {g.d, sum|g|, y.s, y.y, g.g, g.g_prev, max|g|, max|d|}
+template <typename T>
+__global__ void k_lbfgs_pair_stats(const T* __restrict__ g, const T* __restrict__ gp, const T* __restrict__ d, T t,
+                                   T* __restrict__ y, T* __restrict__ sv, int64_t n, double* __restrict__ part) {
+  __shared__ double red[16];
+  __shared__ double mx[2][16];
+  double s[6] = {0, 0, 0, 0, 0, 0}, mg = 0, md = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const T gi = g[i], pi = gp[i], di = d[i];
+    const T yi = gi - pi;
+    const T si = t * di;
+    y[i] = yi;
+    sv[i] = si;
+    const double g64 = (double)gi, d64 = (double)di, ag = fabs(g64), ad = fabs(d64);
+    s[0] += g64 * d64;
+    s[1] += ag;
+    s[2] += (double)yi * (double)si;
+    s[3] += (double)yi * (double)yi;
+    s[4] += g64 * g64;
+    s[5] += g64 * (double)pi;
+    mg = ag > mg ? ag : mg;
+    md = ad > md ? ad : md;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o1 = __shfl_xor(mg, off, 64), o2 = __shfl_xor(md, off, 64);
+    mg = o1 > mg ? o1 : mg;
+    md = o2 > md ? o2 : md;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    mx[0][threadIdx.x >> 6] = mg;
+    mx[1][threadIdx.x >> 6] = md;
+  }
+  double tot[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) tot[c] = block_sum(s[c], red);
+  if (threadIdx.x == 0) {
+    double m0 = 0, m1 = 0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) {
+      m0 = mx[0][w] > m0 ? mx[0][w] : m0;
+      m1 = mx[1][w] > m1 ? mx[1][w] : m1;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) part[8 * blockIdx.x + c] = tot[c];
+    part[8 * blockIdx.x + 6] = m0;
+    part[8 * blockIdx.x + 7] = m1;
+  }
+}
+
+// out = {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev}   (one workgroup, fixed order)
+__global__ void k_finish_pair_stats(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double red[16];
+  __shared__ double mx[2][16];
+  double s[6] = {0, 0, 0, 0, 0, 0}, m0 = 0, m1 = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s[c] += part[8 * i + c];
+    m0 = part[8 * i + 6] > m0 ? part[8 * i + 6] : m0;
+    m1 = part[8 * i + 7] > m1 ? part[8 * i + 7] : m1;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o0 = __shfl_xor(m0, off, 64), o1 = __shfl_xor(m1, off, 64);
+    m0 = o0 > m0 ? o0 : m0;
+    m1 = o1 > m1 ? o1 : m1;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    mx[0][threadIdx.x >> 6] = m0;
+    mx[1][threadIdx.x >> 6] = m1;
+  }
+  double tot[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) tot[c] = block_sum(s[c], red);
+  if (threadIdx.x == 0) {
+    double r0 = 0, r1 = 0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) {
+      r0 = mx[0][w] > r0 ? mx[0][w] : r0;
+      r1 = mx[1][w] > r1 ? mx[1][w] : r1;
+    }
+    out[0] = tot[0];
+    out[1] = tot[1];
+    out[2] = r0;
+    out[3] = r1;
+    out[4] = tot[2];
+    out[5] = tot[3];
+    out[6] = tot[4];
+    out[7] = tot[5];
+  }
+}
+
+template <typename P, typename T>
+int lb_pair_stats(P& pl, const T* g, const T* gp, const T* d, double t, T* y, T* sv, int64_t n, double* out8_dev) {
+  SI_CHECK(g && gp && d && y && sv && out8_dev && n > 0, SPECINV_EINVAL, "bad arguments");
+  const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
+  SI_TRY(pl.lb_part.reserve((size_t)4 * 4 * 1024 * sizeof(double)));
+  double* part = pl.lb_part.template as<double>() + 2 * 4 * 1024;       // slots 2-3 of 4
+  hipLaunchKernelGGL((k_lbfgs_pair_stats<T>), dim3(nb), dim3(256), 0, pl.stream, g, gp, d, (T)t, y, sv, n, part);
+  SI_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_finish_pair_stats, dim3(1), dim3(256), 0, pl.stream, part, nb, out8_dev);
+  SI_HIP(hipGetLastError());
+  return SPECINV_OK;
+}
+
 // Results go to the host (`out_host`: the call synchronises) or to device memory (`out_dev`: nothing waits; the partial
 // sums then live in a scratch of their own, `pl.lb_part`, slot `part_slot`, so that back-to-back passes do not share one).
 template <typename P, typename T>

@@ -190,31 +190,34 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     umid[i] = xmid * (amid > 0.0f ? fast_rcp(amid) : 0.0f);
   }
   OBJ_STAMP(2);
+  // operand blocks of the forward contraction: a ring of kRing blocks in flight per wave (a mel filterbank leaves a wave
+  // fewer blocks than that: all of them are requested here, before the barrier, and land while the other waves finish)
+  constexpr int kRing = 8;
+  const int n_blk = a.tab[ObjTab::BEGIN + KQ];
+  const int* blk_mg = a.tab + ObjTab::mel_group(KQ);
+  const int* blk_fg = a.tab + ObjTab::bin_group(KQ, n_blk);
+  const int fe0 = a.tab[ObjTab::FWD + wib], fe1 = a.tab[ObjTab::FWD + wib + 1];
+  f32x4 av[kRing];
+#pragma unroll
+  for (int i = 0; i < kRing; ++i) av[i] = a.melA[(long long)min(fe0 + i, n_blk - 1) * 64 + lane];
   __syncthreads();
   OBJ_STAMP(3);
 
   // ---- 2. forward contraction mm[m, n] = sum_f Mel[m, f] |S|[f, n]: the waves split the list of non-zero blocks -------
-  const int n_blk = a.tab[ObjTab::BEGIN + KQ];
-  const int* blk_mg = a.tab + ObjTab::mel_group(KQ);
-  const int* blk_fg = a.tab + ObjTab::bin_group(KQ, n_blk);
   {
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int e0 = a.tab[ObjTab::FWD + wib], e1 = a.tab[ObjTab::FWD + wib + 1];
-    f32x4 av[4];                                            // ring of operand blocks in flight (L2 latency >> 4 MFMAs)
+    for (int e = fe0; e < fe1; e += kRing) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) av[i] = a.melA[(long long)min(e0 + i, n_blk - 1) * 64 + lane];
-    for (int e = e0; e < e1; e += 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (e + i < e1) {
+      for (int i = 0; i < kRing; ++i) {
+        if (e + i < fe1) {
           const int fg = blk_fg[e + i], mg = blk_mg[e + i];
           float bv[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) bv[j] = tile[(16 * fg + 4 * j + (lane >> 4)) * RS + (lane & 15)];
           const f32x4 cur = av[i];
-          av[i] = a.melA[(long long)min(e + i + 4, n_blk - 1) * 64 + lane];
+          if (e + i + kRing < fe1) av[i] = a.melA[(long long)(e + i + kRing) * 64 + lane];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             if (mg == mt) {
@@ -229,6 +232,11 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
 #pragma unroll
       for (int r = 0; r < 4; ++r) uni[((wib * MT + mt) * 4 + r) * 64 + lane] = acc[mt][r];
   }
+  // the backward contraction's blocks are requested now: they land during the reduction
+  const int bg0 = a.tab[ObjTab::BWD + wib], bg1 = a.tab[ObjTab::BWD + wib + 1];
+  const int be0 = a.tab[ObjTab::BEGIN + bg0], be1 = a.tab[ObjTab::BEGIN + bg1];
+#pragma unroll
+  for (int i = 0; i < kRing; ++i) av[i] = a.melB[(long long)min(be0 + i, n_blk - 1) * 64 + lane];
   OBJ_STAMP(4);
   __syncthreads();
   OBJ_STAMP(5);
@@ -267,10 +275,8 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
 
   // ---- 4. backward contraction dA[f, n] = sum_m Mel[m, f] dM[m, n]: the waves split the bin groups ----------------------
   {
-    const int g0 = a.tab[ObjTab::BWD + wib], g1 = a.tab[ObjTab::BWD + wib + 1];
-    const int e0 = a.tab[ObjTab::BEGIN + g0], e1 = a.tab[ObjTab::BEGIN + g1];
     f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    int g = g0;
+    int g = bg0;
     auto flush = [&](int upto) {                            // bin groups [g, upto) are complete (groups without a block: zeros)
       for (; g < upto; ++g) {
 #pragma unroll
@@ -278,26 +284,23 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
         c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
     };
-    f32x4 av[4];
+    for (int e = be0; e < be1; e += kRing) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) av[i] = a.melB[(long long)min(e0 + i, n_blk - 1) * 64 + lane];
-    for (int e = e0; e < e1; e += 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (e + i < e1) {
+      for (int i = 0; i < kRing; ++i) {
+        if (e + i < be1) {
           const int fg = blk_fg[e + i], mg = blk_mg[e + i];
           flush(fg);
           float bv[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) bv[j] = dmt[(16 * mg + 4 * j + (lane >> 4)) * RS + (lane & 15)];
           const f32x4 cur = av[i];
-          av[i] = a.melB[(long long)min(e + i + 4, n_blk - 1) * 64 + lane];
+          if (e + i + kRing < be1) av[i] = a.melB[(long long)(e + i + kRing) * 64 + lane];
 #pragma unroll
           for (int j = 0; j < 4; ++j) c = mfma_16x16x4(cur[j], bv[j], c);
         }
       }
     }
-    flush(g1);
+    flush(bg1);
   }
   OBJ_STAMP(7);
   __syncthreads();

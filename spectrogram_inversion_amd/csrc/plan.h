@@ -79,6 +79,8 @@ struct PlanBase {
   virtual int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out,
                          double* out_dev = nullptr) = 0;
   virtual int lbfgs_stats(const void* g, const void* d, int64_t n, double* out, double* out_dev = nullptr) = 0;
+  virtual int lbfgs_pair_stats(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n,
+                               double* out8_dev) = 0;
   virtual int read_doubles(const double* src_dev, int n, double* out_host) = 0;
 
   // _training_loop (methods.py:153-190) driving `iterate`

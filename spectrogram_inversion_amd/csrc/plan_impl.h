@@ -711,6 +711,11 @@ struct PlanT final : PlanBase {
   int lbfgs_stats(const void* g, const void* d, int64_t n, double* out, double* out_dev) override {
     return lb_stats(*this, static_cast<const T*>(g), static_cast<const T*>(d), n, out, out_dev);
   }
+  int lbfgs_pair_stats(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n,
+                       double* out8_dev) override {
+    return lb_pair_stats(*this, static_cast<const T*>(g), static_cast<const T*>(gp), static_cast<const T*>(d), t,
+                         static_cast<T*>(y), static_cast<T*>(sv), n, out8_dev);
+  }
   int read_doubles(const double* src_dev, int n, double* out_host) override {
     SI_CHECK(src_dev && out_host && n > 0, SPECINV_EINVAL, "bad arguments");
     SI_HIP(hipMemcpyAsync(out_host, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));

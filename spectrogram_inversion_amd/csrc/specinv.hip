@@ -413,6 +413,12 @@ int specinv_lbfgs_stats_dev(specinv_plan* plan, const void* g, const void* d, in
   SI_CHECK(out_dev, SPECINV_EINVAL, "out_dev is NULL");
   return plan->impl->lbfgs_stats(g, d, n, nullptr, out_dev);
 }
+int specinv_lbfgs_pair_stats_dev(specinv_plan* plan, const void* g, const void* g_prev, const void* d, double t,
+                                 void* y_out, void* s_out, int64_t n, double* out_dev) {
+  ENTER(plan);
+  SI_CHECK(out_dev, SPECINV_EINVAL, "out_dev is NULL");
+  return plan->impl->lbfgs_pair_stats(g, g_prev, d, t, y_out, s_out, n, out_dev);
+}
 int specinv_read_doubles(specinv_plan* plan, const double* src_dev, int n, double* out_host) {
   ENTER(plan);
   return plan->impl->read_doubles(src_dev, n, out_host);

@@ -76,6 +76,10 @@ class HipVecOps:
     def pair_into(self, g, g_prev, d, t, board, slot):
         return self.plan.lbfgs_pair_dev(g, g_prev, d, t, board.data_ptr() + 8 * slot)
 
+    def pair_stats_into(self, g, g_prev, d, t, board, slot):
+        """`stats_into` (4 values) followed by `pair_into` (4 values) in one pass over the vectors"""
+        return self.plan.lbfgs_pair_stats_dev(g, g_prev, d, t, board.data_ptr() + 8 * slot)
+
     def multi_dot_into(self, g, vecs, board, slot):
         self.plan.vec_multi_dot_dev(g, vecs, board.data_ptr() + 8 * slot)
 
@@ -281,10 +285,15 @@ class LBFGS:
             self._board = ops.board(9 + 2 * self.history_size)
         bd = self._board
         g = ops.eval_into(fg, x, bd, 0)
-        ops.stats_into(g, d if have_prev else g, bd, 1)
         y = s = None
-        if have_prev:
-            y, s = ops.pair_into(g, self.prev_grad, d, t, bd, 5)
+        if not have_prev:
+            ops.stats_into(g, g, bd, 1)
+        else:
+            if hasattr(ops, "pair_stats_into"):
+                y, s = ops.pair_stats_into(g, self.prev_grad, d, t, bd, 1)
+            else:
+                ops.stats_into(g, d, bd, 1)
+                y, s = ops.pair_into(g, self.prev_grad, d, t, bd, 5)
             if m:
                 ops.multi_dot_into(g, self.ss + self.ys, bd, 9)
         v = ops.read(bd, 9 + 2 * m if have_prev else 5)

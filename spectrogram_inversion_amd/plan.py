@@ -494,6 +494,14 @@ class Plan:
                                                    s.data_ptr(), g.numel(), out_ptr))
         return y, s
 
+    def lbfgs_pair_stats_dev(self, g, g_prev, d, t, out_ptr: int):
+        """Pair and statistics in one pass: {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev} to device memory."""
+        self._sync_stream()
+        y, s = torch.empty_like(g), torch.empty_like(g)
+        _lib.check(self.lib.specinv_lbfgs_pair_stats_dev(self._h, g.data_ptr(), g_prev.data_ptr(), d.data_ptr(), float(t),
+                                                         y.data_ptr(), s.data_ptr(), g.numel(), out_ptr))
+        return y, s
+
     def lbfgs_stats_dev(self, g, d, out_ptr: int):
         """{g.d, sum|g|, max|g|, max|d|} to device memory."""
         self._sync_stream()
