@@ -1030,11 +1030,14 @@ template <typename P>
 int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, double* loss, float* grad, bool* used,
                        double* loss_dev = nullptr) {
   *used = false;
-  if (pl.tf_kind != SPECINV_TF_LOGMEL || pl.tf_obj_mt == 0 || pl.force_generic) return SPECINV_OK;
+  const bool mag = pl.tf_kind == SPECINV_TF_MAG;
+  if (pl.force_generic || !pl.cfg.onesided || !pl.fast.xform_ok || (pl.fast.xform_R != 8 && pl.fast.xform_R != 16)) return SPECINV_OK;
+  if (!mag && (pl.tf_kind != SPECINV_TF_LOGMEL || pl.tf_obj_mt == 0)) return SPECINV_OK;
   if (const char* e = getenv("SPECINV_DISABLE_FUSED_OBJECTIVE")) {
     if (e[0] == '1') return SPECINV_OK;
   }
-  const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), B = pl.B(), pad = pl.pad, R = pl.fast.xform_R, MT = pl.tf_obj_mt;
+  const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), B = pl.B(), pad = pl.pad, R = pl.fast.xform_R;
+  const int MT = mag ? 3 : pl.tf_obj_mt;
   if (hop > N || hop < 2 || pad >= len) return SPECINV_OK;
   if ((long long)(T - 1) * hop + N != len + 2LL * pad) return SPECINV_OK;       // the frames must cover the padded signal exactly
   const int nch = (T + fast::kObjTile - 1) / fast::kObjTile;
@@ -1044,7 +1047,7 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   SI_TRY(pl.fast.hop_inv_tail.reserve((size_t)n_tiles * std::max(1, keep) * sizeof(float) + 16));
   SI_TRY(pl.fast.hop_inv_margins.reserve((size_t)B * 2 * std::max(1, pad) * sizeof(float)));
   SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_tiles, 3 * 1024) * sizeof(double)));
-  const double numel = (double)B * T * pl.tf_mels;
+  const double numel = (double)B * T * (mag ? pl.n_freq : pl.tf_mels);
   fast::ObjArgs a{};
   a.x = x;
   a.grad = grad;
@@ -1073,8 +1076,14 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     fn = (const void*)fast::k_objective_logmel<RR, MM>;            \
     lds = fast::ObjGeo<RR, MM>::lds_bytes();                       \
   }
-  SPECINV_OBJ_CASE(16, 3) SPECINV_OBJ_CASE(16, 4) SPECINV_OBJ_CASE(16, 5) SPECINV_OBJ_CASE(16, 8)
-  SPECINV_OBJ_CASE(8, 3) SPECINV_OBJ_CASE(8, 4) SPECINV_OBJ_CASE(8, 5) SPECINV_OBJ_CASE(8, 8)
+  if (mag) {
+    if (R == 16) fn = (const void*)fast::k_objective_logmel<16, 3, true>;
+    else fn = (const void*)fast::k_objective_logmel<8, 3, true>;
+    lds = R == 16 ? fast::ObjGeo<16, 3>::lds_bytes() : fast::ObjGeo<8, 3>::lds_bytes();
+  } else {
+    SPECINV_OBJ_CASE(16, 3) SPECINV_OBJ_CASE(16, 4) SPECINV_OBJ_CASE(16, 5) SPECINV_OBJ_CASE(16, 8)
+    SPECINV_OBJ_CASE(8, 3) SPECINV_OBJ_CASE(8, 4) SPECINV_OBJ_CASE(8, 5) SPECINV_OBJ_CASE(8, 8)
+  }
 #undef SPECINV_OBJ_CASE
   if (fn == nullptr || lds > 160 * 1024) return SPECINV_OK;
   SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -93,7 +93,10 @@ struct ObjGeo {
   }
 };
 
-template <int R, int MT>
+// MAG: the magnitude objective mean((|STFT(x)| - target)^2) (`MagSTFT`, the reference's test / demo transform,
+// test/test_lbfgs.py:17-18, main.py:21-43): the same kernel without the contractions - dA = 2/numel (|S| - T) is formed
+// element by element on the |S| tile (MT only sizes the shared scratch then).
+template <int R, int MT, bool MAG = false>
 __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs a) {
   using G = Geo<R>;
   using OG = ObjGeo<R, MT>;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int q = wib + kObjWaves * i, m = 16 * (q >> 2) + 4 * (lane >> 4) + (q & 3), n = lane & 15;
-    tgt[i] = (q < 4 * MT && m < a.n_mels && n < nfr) ? a.target[((long long)b * a.n_mels + m) * a.T + t0 + n] : 0.0f;
+    tgt[i] = (!MAG && q < 4 * MT && m < a.n_mels && n < nfr) ? a.target[((long long)b * a.n_mels + m) * a.T + t0 + n] : 0.0f;
   }
   for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
   for (int i = threadIdx.x; i < (FP - F) * RS; i += blockDim.x) tile[F * RS + i] = 0.0f;   // rows the zero-padded filterbank meets
@@ -190,19 +193,46 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     umid[i] = xmid * (amid > 0.0f ? fast_rcp(amid) : 0.0f);
   }
   OBJ_STAMP(2);
-  // operand blocks of the forward contraction: a ring of kRing blocks in flight per wave (a mel filterbank leaves a wave
-  // fewer blocks than that: all of them are requested here, before the barrier, and land while the other waves finish)
   constexpr int kRing = 8;
-  const int n_blk = a.tab[ObjTab::BEGIN + KQ];
-  const int* blk_mg = a.tab + ObjTab::mel_group(KQ);
-  const int* blk_fg = a.tab + ObjTab::bin_group(KQ, n_blk);
-  const int fe0 = a.tab[ObjTab::FWD + wib], fe1 = a.tab[ObjTab::FWD + wib + 1];
+  int n_blk = 1, fe0 = 0, fe1 = 0;
+  const int* blk_mg = nullptr;
+  const int* blk_fg = nullptr;
   f32x4 av[kRing];
+  if constexpr (!MAG) {
+    // operand blocks of the forward contraction: a ring of kRing blocks in flight per wave (a mel filterbank leaves a wave
+    // fewer blocks than that: all of them are requested here, before the barrier, and land while the other waves finish)
+    n_blk = a.tab[ObjTab::BEGIN + KQ];
+    blk_mg = a.tab + ObjTab::mel_group(KQ);
+    blk_fg = a.tab + ObjTab::bin_group(KQ, n_blk);
+    fe0 = a.tab[ObjTab::FWD + wib];
+    fe1 = a.tab[ObjTab::FWD + wib + 1];
 #pragma unroll
-  for (int i = 0; i < kRing; ++i) av[i] = a.melA[(long long)min(fe0 + i, n_blk - 1) * 64 + lane];
+    for (int i = 0; i < kRing; ++i) av[i] = a.melA[(long long)min(fe0 + i, n_blk - 1) * 64 + lane];
+  }
   __syncthreads();
   OBJ_STAMP(3);
 
+  if constexpr (MAG) {
+    // ---- 2'-4'. dA = 2/numel (|S| - T) on the tile, squared error; the target is read in the caller's (B, F, T) layout,
+    // 16 consecutive frames (64 bytes) per bin
+    double s2 = 0.0;
+    for (int e = threadIdx.x; e < F * kObjTile; e += blockDim.x) {
+      const int f = e >> 4, n = e & 15;
+      if (n < nfr) {
+        const float d = tile[f * RS + n] - a.target[((long long)b * F + f) * a.T + t0 + n];
+        s2 += (double)d * (double)d;
+        tile[f * RS + n] = a.dscale * d;
+      }
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) lsum[wib] = s2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < kObjWaves; ++w) tot += lsum[w];
+      a.partials[blockIdx.x] = tot;
+    }
+  } else {
   // ---- 2. forward contraction mm[m, n] = sum_f Mel[m, f] |S|[f, n]: the waves split the list of non-zero blocks -------
   {
     f32x4 acc[MT];
@@ -301,6 +331,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       }
     }
     flush(bg1);
+  }
   }
   OBJ_STAMP(7);
   __syncthreads();

@@ -338,3 +338,38 @@ def test_one_launch_objective_with_a_dense_matrix(monkeypatch, n_mels):
             continue
         assert abs(loss - lo) < 1e-5 * abs(lo), (loss, lo)
         assert rel_l2(N(grad), go) < 1e-5, rel_l2(N(grad), go)
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch,kw", [
+    (2048, 512, 40, 2, {}), (2048, 333, 37, 2, dict(pad_mode="constant")), (1024, 256, 50, 3, dict(normalized=True)),
+    (1024, 128, 64, 2, dict(pad_mode="circular")), (2048, 1024, 20, 1, dict(center=False)), (1024, 300, 33, 2, dict(pad_mode="replicate")),
+])
+def test_one_launch_magnitude_objective(monkeypatch, n_fft, hop, frames, batch, kw):
+    """mean((|STFT(x)| - target)^2) - `MagSTFT`, the transform of the reference's own test and demo (test/test_lbfgs.py:17-18,
+    main.py:21-43) - on the one-launch kernel (the log-mel kernel without the contractions) against the kernel chain and
+    the float64 oracle."""
+    rng = np.random.default_rng(n_fft + hop)
+    center = kw.get("center", True)
+    length = (frames - 1) * hop + (0 if center else n_fft)
+    w = hann(n_fft)
+    xs = (0.1 * rng.standard_normal((batch, length))).astype(np.float32)
+    x0 = (0.05 * rng.standard_normal((batch, length))).astype(np.float32)
+    out = {}
+    for mode in ("fused", "chain"):
+        monkeypatch.setenv("SPECINV_DISABLE_FUSED_OBJECTIVE", "1" if mode == "chain" else "0")
+        monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1" if mode == "fused" else "0")
+        tr = MagSTFT(n_fft, hop_length=hop, window=torch.from_numpy(w), **kw)
+        target = tr(T(xs))
+        _, fg = tr.bind(T(x0), target)
+        loss, grad = fg(T(x0))
+        loss2, grad2 = fg(T(x0))
+        assert loss == loss2 and torch.equal(grad, grad2)
+        out[mode] = (loss, N(grad))
+    (lf, gf), (lc, gc) = out["fused"], out["chain"]
+    assert abs(lf - lc) < 2e-6 * abs(lc), (lf, lc)
+    assert rel_l2(gf, gc) < 3e-6, rel_l2(gf, gc)
+    a = oracle.args_helper(n_fft // 2 + 1, np.float64, hop_length=hop, window=w.astype(np.float64), **kw)
+    ref = MagStft(a)
+    lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
+    assert abs(lf - lo) < 1e-5 * abs(lo), (lf, lo)
+    assert rel_l2(gf, go) < 1e-5, rel_l2(gf, go)
