@@ -1039,7 +1039,6 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), B = pl.B(), pad = pl.pad, R = pl.fast.xform_R;
   const int MT = mag ? 3 : pl.tf_obj_mt;
   if (hop > N || hop < 2 || pad >= len) return SPECINV_OK;
-  if ((long long)(T - 1) * hop + N != len + 2LL * pad) return SPECINV_OK;       // the frames must cover the padded signal exactly
   const int nch = (T + fast::kObjTile - 1) / fast::kObjTile;
   if (nch > 1 && T / nch < (N - 1) / hop + 1) return SPECINV_OK;                // a seam must not reach a tile's own tail
   const int keep = N - hop;

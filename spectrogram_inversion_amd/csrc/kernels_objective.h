@@ -440,6 +440,11 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       }
     }
   }
+  if (last) {
+    // samples beyond the last frame (a signal a little longer than (T - 1) hop + n_fft - 2 pad: torch.stft drops the
+    // remainder) take no part in the objective: zero gradient
+    for (long long nn = n0 + span_len + threadIdx.x; nn < a.len; nn += blockDim.x) go[nn] = 0.0f;
+  }
   OBJ_STAMP(12);
 }
 

@@ -303,14 +303,40 @@ def test_one_launch_objective_falls_back_where_it_does_not_fit(monkeypatch):
     monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "0")
     loss, g = fg(x)
     assert loss > 0 and torch.isfinite(g).all()
-    # 7 samples beyond the last frame: they get a zero gradient from the chain, the one-launch kernel is not used
-    fb = si.mel_filterbank(22050, 1024, 40)
-    x = 0.1 * torch.randn(2, 30 * 256 + 7, device=dev())
-    tr = LogMelSTFT(T(fb), 1024, hop_length=256, window=torch.from_numpy(hann(1024)))
-    _, fg = tr.bind(x, tr(x + 0.01))
+    # float64 stays on the chain as well
+    x64 = 0.1 * torch.randn(2, 30 * 256, device=dev(), dtype=torch.float64)
+    fb = si.mel_filterbank(22050, 1024, 40).astype(np.float64)
+    tr = LogMelSTFT(T(fb), 1024, hop_length=256, window=torch.from_numpy(hann(1024, np.float64)))
+    _, fg = tr.bind(x64, tr(x64 + 0.01))
     monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
     with pytest.raises(NotImplementedError, match="one-launch objective"):
-        fg(x)
+        fg(x64)
+
+
+@pytest.mark.parametrize("center", [True, False])
+def test_one_launch_objective_signal_longer_than_its_frames(monkeypatch, center):
+    """torch.stft drops what is left of the signal after the last whole hop (the reference's demo signal, main.py:16-43,
+    has such a remainder).  Centred: the remainder is still inside the last frames, only padded positions stay uncovered;
+    not centred: the last samples take no part in the objective and get a zero gradient.  Against the float64 oracle."""
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    rng = np.random.default_rng(3)
+    n_fft, hop, frames = 1024, 128, 41
+    length = (frames - 1) * hop + (0 if center else n_fft) + 97
+    w = hann(n_fft)
+    xs = (0.1 * rng.standard_normal((2, length))).astype(np.float32)
+    x0 = (0.05 * rng.standard_normal((2, length))).astype(np.float32)
+    a = oracle.args_helper(n_fft // 2 + 1, np.float64, hop_length=hop, window=w.astype(np.float64), center=center)
+    fb = si.mel_filterbank(22050, n_fft, 40)
+    kw = dict(hop_length=hop, window=torch.from_numpy(w), center=center)
+    for tr, ref in ((MagSTFT(n_fft, **kw), MagStft(a)), (LogMelSTFT(T(fb), n_fft, **kw), LogMelStft(a, fb.astype(np.float64)))):
+        target = tr(T(xs))
+        assert target.shape[-1] == frames
+        _, fg = tr.bind(T(x0), target)
+        loss, grad = fg(T(x0))
+        lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
+        assert abs(loss - lo) < 1e-5 * abs(lo) and rel_l2(N(grad), go) < 1e-5
+        if not center:
+            assert not N(grad)[:, -97:].any() and not go[:, -97:].any()
 
 
 @pytest.mark.parametrize("n_mels", [80, 33])
