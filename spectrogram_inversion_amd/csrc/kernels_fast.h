@@ -1401,6 +1401,105 @@ __global__ void k_user_mag_to_pairs(const float* __restrict__ in, float* __restr
   }
 }
 
+// phase_init (methods.py:572-615) for the fused path: the starting spectrum and the target magnitude written straight in
+// conjugate-pair order (what k_phase_init + k_user_spec_to_pairs + k_user_mag_to_pairs produce in three passes and one
+// (B, F, T) complex round trip).  One workgroup per (item, pair row j): its 128 spectrogram rows - bins 64 j + l and
+// M - (64 j + l) - are scanned over time exactly like k_phase_init does it (a wave per row, lanes = 64 consecutive time
+// steps, float64 wave scan with each partial sum rounded to float32, the same operation order), 64 time steps at a time;
+// the 128 x 64 block is transposed through LDS and leaves as 64 records of 1 KiB.  The bin M/2 rides with the last pair row.
+template <int R>
+__global__ __launch_bounds__(1024) void k_phase_init_pairs(const float* __restrict__ mag, v4f* __restrict__ P, v2f* __restrict__ Pmid,
+                                                          float* __restrict__ mpairs, float* __restrict__ mmid,
+                                                          double* __restrict__ partials, int T, int hop) {
+  using G = Geo<R>;
+  constexpr int M = G::M, F = M + 1, H = G::H, NFFT = G::N, LD = 129, WAVES = 16, RPW = 128 / WAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* ct = reinterpret_cast<v2f*>(smem);                   // [64 time steps][LD] complex values, column = row slot
+  float* mt = reinterpret_cast<float*>(ct + 64 * LD);       // [64][LD] magnitudes
+  __shared__ double red[16];
+  __shared__ double carry_s[WAVES][RPW + 1];                // running phase of every row (the row loop is not unrolled)
+  const int b = blockIdx.x / H, j = blockIdx.x - b * H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* base = mag + (long long)b * F * T;
+  const float two_pi = 6.283185307179586476925286766559f;
+  const bool has_mid = j == H - 1 && wave == 0;
+  double* carry = carry_s[wave];
+  if (lane <= RPW) carry[lane] = 0.0;
+  double s2 = 0.0;
+
+  // one row, 64 time steps: returns the complex value and the magnitude of (f, t0 + lane)
+  auto row_step = [&](int f, int t, double* cr, v2f& val, float& m0) {
+    float cur[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      const int g = f + d - 2;
+      cur[d] = (t < T && g >= 0 && g < F) ? base[(long long)g * T + t] : 0.0f;
+    }
+    float om = 0.0f;
+    m0 = cur[2];
+    if (t < T) {
+      float w;
+      // scatter order :607-609: own bin, else the k+1 write of a peak below, else the k-1 write of a peak above
+      if (peak_omega_vals<float>(cur[1], cur[2], cur[3], f, F, two_pi, (float)NFFT, (float)hop, w)) om = w;
+      else if (peak_omega_vals<float>(cur[0], cur[1], cur[2], f - 1, F, two_pi, (float)NFFT, (float)hop, w)) om = w;
+      else if (peak_omega_vals<float>(cur[2], cur[3], cur[4], f + 1, F, two_pi, (float)NFFT, (float)hop, w)) om = w;
+    }
+    double v = (double)om;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    v += *cr;                                               // (wave-private LDS slot: in-order within the wave)
+    if (lane == 63) *cr = v;
+    const float phi = (float)v;                              // :611
+    double sn, cs;
+    sincos((double)phi, &sn, &cs);                           // :612
+    val = v2f{m0 * (float)cs, m0 * (float)sn};               // :614
+  };
+
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+#pragma unroll 1
+    for (int i = 0; i < RPW; ++i) {
+      const int s = wave * RPW + i;                          // row slot: 0..63 bins 64 j + s, 64..127 bins M - (64 j + s - 64)
+      const int f = s < 64 ? 64 * j + s : M - (64 * j + s - 64);
+      v2f val;
+      float m0;
+      row_step(f, t, carry + i, val, m0);
+      ct[lane * LD + s] = val;
+      mt[lane * LD + s] = m0;
+      if (t < T) s2 += (double)m0 * (double)m0;
+    }
+    if (has_mid) {                                           // bin M/2: time-major arrays, written as they come
+      v2f val;
+      float m0;
+      row_step(M / 2, t, carry + RPW, val, m0);
+      if (t < T) {
+        Pmid[(long long)b * T + t] = val;
+        mmid[(long long)b * T + t] = m0;
+        s2 += (double)m0 * (double)m0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 64 / WAVES; ++q) {
+      const int tl = wave * (64 / WAVES) + q, tt = t0 + tl;
+      if (tt < T) {
+        const long long fr = (long long)b * T + tt;
+        const v2f a = ct[tl * LD + lane], bb = ct[tl * LD + 64 + lane];
+        P[(fr * H + j) * 64 + lane] = v4f{a.x, a.y, bb.x, bb.y};
+        // target record c = j / 2 holds (m[k_2c], m[M - k_2c], m[k_2c+1], m[M - k_2c+1]): this row fills one half of it
+        *reinterpret_cast<v2f*>(mpairs + ((fr * (H / 2) + (j >> 1)) * 64 + lane) * 4 + (j & 1) * 2) =
+            v2f{mt[tl * LD + lane], mt[tl * LD + 64 + lane]};
+      }
+    }
+    __syncthreads();
+  }
+  const double tot = block_sum(s2, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
 }  // namespace fast
 }  // namespace specinv
 
@@ -1686,6 +1785,7 @@ struct FastState<float> {
   }
 
   // `spec_user` (B, F, T) complex and `mag_user` (B, F, T) are the caller's / phase_init's arrays
+  // spec_user == nullptr: the starting spectrum is phase_init(mag_user), produced in pair order by k_phase_init_pairs
   template <int RR, typename P>
   int begin_t(P& pl, int md, const v2f* spec_user, const float* mag_user, double* sum_m2_out) {
     using G = fast::Geo<RR>;
@@ -1711,7 +1811,26 @@ struct FastState<float> {
     SI_TRY(mmid.reserve(nf * sizeof(float)));
     SI_TRY(inv_env.reserve(pl.length * sizeof(float)));
     cur = 0;
-    {
+    if (spec_user == nullptr) {
+      const int nwg = pl.B() * G::H;
+      SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nwg, 3 * 1024) * sizeof(double)));
+      const size_t lds = (size_t)64 * 129 * (sizeof(v2f) + sizeof(float));
+      const void* fn = (const void*)fast::k_phase_init_pairs<RR>;
+      SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const float* mg = mag_user;
+      v4f* pp = Pb[0].template as<v4f>();
+      v2f* pm = Pmid[0].template as<v2f>();
+      float* mp = mpairs.template as<float>();
+      float* mm = mmid.template as<float>();
+      double* part = pl.partials.template as<double>();
+      int Tn = pl.Tn(), hp = hop;
+      void* kargs[] = {&mg, &pp, &pm, &mp, &mm, &part, &Tn, &hp};
+      SI_HIP(hipLaunchKernel(fn, dim3(nwg), dim3(1024), kargs, lds, pl.stream));
+      hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), (int64_t)nwg, 1,
+                         pl.sums.template as<double>() + 4);
+      SI_HIP(hipGetLastError());
+      SI_HIP(hipMemcpyAsync(sum_m2_out, pl.sums.template as<double>() + 4, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+    } else {
       const dim3 grid((pl.Tn() + 31) / 32, (pl.n_freq + 31) / 32, pl.B()), blk(32, 8);
       hipLaunchKernelGGL((fast::k_user_spec_to_pairs<RR>), grid, blk, 0, pl.stream, spec_user, Pb[0].template as<v2f>(),
                          Pmid[0].template as<v2f>(), pl.Tn());

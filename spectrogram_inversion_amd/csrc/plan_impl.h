@@ -384,6 +384,12 @@ struct PlanT final : PlanBase {
     const int64_t ns = nspec();
     count = (double)ns;
     const C* start_user = static_cast<const C*>(init_spec);
+    if constexpr (std::is_same<T, float>::value) {
+      // fused kernels, magnitude input: phase_init writes the pair layout itself (methods.py:106 without the (B, F, T)
+      // complex round trip and the two layout passes)
+      if (!init_spec && fast_path() && !fast.semi && (fast.R == 8 || fast.R == 16) && !getenv("SPECINV_DISABLE_INIT_PAIRS"))
+        return fast.begin(*this, fast_mode, nullptr, magp, &sum_m2);
+    }
     if (!init_spec) {
       SI_TRY(tmp_spec.reserve(ns * sizeof(C)));
       SI_TRY(phase_init(magp, tmp_spec.p));                       // methods.py:106

@@ -446,3 +446,35 @@ def test_tuned_copy_equals_template(monkeypatch, n_fft, batch, frames, method):
         assert torch.equal(torch.view_as_real(ua), torch.view_as_real(ub))
     # (the sums are per-wave partial sums added in wave order: a different wave count adds them in a different order)
     np.testing.assert_allclose(sa, sb, rtol=1e-12)
+
+
+@pytest.mark.parametrize("n_fft,batch,frames", [(1024, 3, 70), (2048, 2, 130), (2048, 5, 64), (1024, 2, 200)])
+@pytest.mark.parametrize("method", ["gla", "admm"])
+def test_phase_init_in_pair_order_equals_the_three_pass_form(monkeypatch, n_fft, batch, frames, method):
+    """Magnitude input on the fused kernels: `k_phase_init_pairs` writes the starting spectrum and the target in pair order
+    itself; against phase_init + the two layout passes (SPECINV_DISABLE_INIT_PAIRS=1): starting spectrum, initial
+    waveform, evaluation sums and the state after a few iterations bit for bit; against the oracle's phase_init to 4 ulp."""
+    hop = n_fft // 4
+    rng = np.random.default_rng(n_fft + frames)
+    mag_np = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    mag = torch.from_numpy(mag_np).to(dev())
+    w = torch.from_numpy(hann(n_fft))
+    out = []
+    for disable in (None, "1"):
+        if disable:
+            monkeypatch.setenv("SPECINV_DISABLE_INIT_PAIRS", disable)
+        p = Plan(args_helper(mag, hop_length=hop, window=w), batch, frames, torch.float32, dev())
+        assert p.launch_geometry["kernel"] == "k_fused4"
+        (p.gla_init if method == "gla" else p.admm_init)(None, mag, 0.3)
+        c0, x0 = p.state_spec(0), p.wave()
+        s = p.iterate(3, eval_last=True)
+        out.append((c0, x0, p.wave(), p.state_spec(0), s))
+        del p
+    for a, b in zip(out[0][:4], out[1][:4]):
+        ta = torch.view_as_real(a) if a.is_complex() else a
+        tb = torch.view_as_real(b) if b.is_complex() else b
+        assert torch.equal(ta, tb)
+    np.testing.assert_allclose(out[0][4], out[1][4], rtol=1e-12)       # (sum of m^2: another order of partial sums)
+    ref = oracle.phase_init(mag_np, hop_length=hop, window=hann(n_fft))
+    err = np.abs(N(out[0][0]) - ref).max()
+    assert err <= 4 * np.finfo(np.float32).eps * np.abs(ref).max(), err
