@@ -54,13 +54,14 @@ def hann(n):
 
 def algorithmic_bytes_per_unit(method, hop, n_freq, coef):
     """SURVEY 8d, one frame through one iteration / evaluation, fp32.  griffin_lim: x read+write 8*hop, target 4F,
-    pre_spec read+write 16F (8*hop + 4F when alpha == 0); ADMM: X, U read+write 32F + target 4F; L_BFGS objective:
+    pre_spec read+write 16F (8*hop + 4F when alpha == 0); ADMM: Y = X + U read+write 16F + target 4F (SURVEY counted X
+    and U separately, 32F: methods.py:467-468 only read their sum, DESIGN 3.1 - the smaller figure is used); L_BFGS objective:
     x read + gradient write 8*hop, target 4*n_mels; RTISI_LA: target read 4F + committed frame 4*hop per frame
     (state lives in LDS: the figure is not what bounds that kernel)."""
     if method == "griffin_lim":
         return 8 * hop + (20 if coef != 0 else 4) * n_freq
     if method == "ADMM":
-        return 8 * hop + 36 * n_freq
+        return 8 * hop + 20 * n_freq
     if method == "L_BFGS":
         return 8 * hop + 4 * N_MELS
     return 4 * n_freq + 4 * hop

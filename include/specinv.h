@@ -101,6 +101,12 @@ int64_t specinv_plan_device_bytes(const specinv_plan* plan);
 int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]);
 /* 0: allow the fast path when the configuration supports it (default); 1: force the generic kernels. */
 int specinv_plan_force_generic(specinv_plan* plan, int on);
+/* ADMM on the float32 fast paths carries only Y = X + U between iterations: methods.py:467-468 read the two as
+ * U + X, i.e. the Y that :475 has just rounded, so the iterates are bit-identical and the state traffic halves.
+ * 1: the last iteration of every specinv_admm_iterate call (and specinv_admm_init) also leaves X and U behind for
+ * specinv_get_state_spec; 0 (default): it does not, and asking for them is SPECINV_ESTATE.  Call before
+ * specinv_admm_init.  (The generic kernels keep X and U anyway.) */
+int specinv_plan_keep_state(specinv_plan* plan, int on);
 
 /* ---- building blocks ------------------------------------------------------------------ */
 /* torch.stft(x, n_fft, **processed_args) as called at methods.py:241.  x (B, L_in) -> spec
@@ -137,7 +143,8 @@ int specinv_admm_run(specinv_plan* plan, int max_iter, int eva_iter, double tol,
 
 /* current waveform estimate status_dict['x'] (B, L) of the running GLA / ADMM state */
 int specinv_get_wave(specinv_plan* plan, void* x_out);
-/* current pre_spec (GLA) or X (ADMM) as (B, F, T) complex - for state-parity tests */
+/* running state as (B, F, T) complex: which = 0 pre_spec (GLA) or X (ADMM), 1 U (ADMM), 2 Y = X + U (ADMM, always
+ * available; X and U need specinv_plan_keep_state) - for state-parity tests */
 int specinv_get_state_spec(specinv_plan* plan, int which, void* spec_out);
 
 /* ---- differentiating griffin_lim w.r.t. the spectrogram (the reference's outputs are autograd-differentiable:

@@ -505,14 +505,14 @@ struct FastArgs {
   float* x_out;
   const float* xtail_in;   // [B][nchunks][3*HOP]: what chunk c's last three frames add to the first three
   float* xtail_out;        //                       hop-blocks of chunk c+1 (already times 1/envelope)
-  const v4f* P_in;     // GLA: pre_spec pairs ; ADMM: X pairs      [B*T][H][64] x (Re k, Im k, Re M-k, Im M-k)
+  const v4f* P_in;     // GLA: pre_spec pairs ; ADMM: Y = X + U    [B*T][H][64] x (Re k, Im k, Re M-k, Im M-k)
   v4f* P_out;
   const v2f* Pmid_in;  // bin M/2                                   [B*T]
   v2f* Pmid_out;
-  const v4f* U_in;     // ADMM only
-  v4f* U_out;
-  const v2f* Umid_in;
-  v2f* Umid_out;
+  v4f* X_out;          // ADMM, optional (nullptr: not wanted): X and U of this iteration, for specinv_get_state_spec.
+  v4f* U_out;          // The recursion itself only needs their sum: methods.py:467-468 read X and U as U + X, which is
+  v2f* Xmid_out;       // the Y = x_ + u that :475 has just rounded (float addition commutes), so carrying Y alone is
+  v2f* Umid_out;       // bit-identical and halves the state traffic (16 F instead of 32 F bytes per frame and iteration)
   const v4f* m_pairs;  // target magnitude                          [B*T][H/2][64] x (k_2c, M-k_2c, k_2c+1, M-k_2c+1)
   const float* m_mid;  //                                           [B*T]
   const float* window;   // N
@@ -543,7 +543,7 @@ __device__ __forceinline__ float env_apply(float v, float e) { return v * e; }
 // Frequency-domain update of one bin.  `r` is the STFT bin, `p`/`u` the stored state, `m` the target.
 // Returns the bin to synthesise from (already multiplied by isc); writes the new state.
 template <int MODE, bool EVAL>
-__device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const FastArgs& a, bool live, double& sd,
+__device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, v2f& xs, float m, const FastArgs& a, bool live, double& sd,
                                           double& so) {
   if (EVAL) {
     const float o = fast_abs(r);
@@ -565,10 +565,10 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const 
     return v2f{(s.x * m) * inv, (s.y * m) * inv};
 #endif
   } else {
-    // methods.py:467-475
-    const v2f y = p + u;
+    // methods.py:467-475 with p = Y of the previous iteration (= fl(X + U), the first operation of :468)
+    const v2f y = p;
     const v2f z = v2f{fmaf(a.coef, y.x, r.x) * a.inv1p, fmaf(a.coef, y.y, r.y) * a.inv1p};
-    const v2f un = (u + p) - z;
+    const v2f un = y - z;
     v2f xn = z - un;
 #if SPECINV_IEEE
     const float den = fast_abs(xn) + 1e-16f;
@@ -577,9 +577,10 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, float m, const 
     const float inv = fast_rcp(fast_abs(xn) + 1e-16f);
     xn = v2f{(xn.x * m) * inv, (xn.y * m) * inv};
 #endif
-    p = xn;
+    xs = xn;
     u = un;
-    return (xn + un) * a.inv_scale;
+    p = xn + un;
+    return p * a.inv_scale;
   }
 }
 
@@ -779,19 +780,14 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
     const v4f* pin_ = a.P_in + fl_ * (H * 64);                                             \
     const v4f* min_ = a.m_pairs + fl_ * (H / 2 * 64);                                      \
     _Pragma("unroll") for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin_[j * 64u + ulane]); \
-    if (MODE == MODE_ADMM) {                                                               \
-      const v4f* uin_ = a.U_in + fl_ * (H * 64);                                           \
-      _Pragma("unroll") for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin_[j * 64u + ulane]); \
-    }                                                                                      \
     _Pragma("unroll") for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]); \
     if (lane == 0) {                                                                       \
       pmid = a.Pmid_in[fl_];                                                               \
       mmid = a.m_mid[fl_];                                                                 \
-      if (MODE == MODE_ADMM) umid = a.Umid_in[fl_];                                        \
     }                                                                                      \
   } while (0)
 #if SPECINV_PLATE == 2
-  v4f pp[H], uu[H], mm[H / 2];
+  v4f pp[H], mm[H / 2];
   v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
   float mmid = 0.0f;
   SPECINV_STATE_LOADS4((long long)b * a.T + t_start);
@@ -806,9 +802,9 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
     constexpr bool live = true;
     const long long fi = (long long)b * a.T + t;
     v4f* pout = a.P_out + fi * (H * 64);
-    v4f* uout = MODE == MODE_ADMM ? a.U_out + fi * (H * 64) : nullptr;
+    const bool keep_xu = MODE == MODE_ADMM && a.U_out != nullptr;   // (uniform: a kernel argument)
 #if SPECINV_PLATE != 2
-    v4f pp[H], uu[H], mm[H / 2];
+    v4f pp[H], mm[H / 2];
     v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
     float mmid = 0.0f;
 #endif
@@ -888,18 +884,17 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
       v2f xk = (e2 + tw) * half_scale;
       v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};   // conj(...)
       v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
-      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
-      if (MODE == MODE_ADMM) {
-        uk = v2f{uu[j].x, uu[j].y};
-        um = v2f{uu[j].z, uu[j].w};
-      }
+      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f}, sk = v2f{0.0f, 0.0f}, sm = v2f{0.0f, 0.0f};
       const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
       const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
-      v2f ak = update_bin<MODE, EVAL>(xk, pk, uk, mk, a, live, sd, so);
-      v2f am = update_bin<MODE, EVAL>(xm, pm, um, mq, a, live, sd, so);
+      v2f ak = update_bin<MODE, EVAL>(xk, pk, uk, sk, mk, a, live, sd, so);
+      v2f am = update_bin<MODE, EVAL>(xm, pm, um, sm, mq, a, live, sd, so);
       if (live) {
         st_stream(&pout[j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
-        if (MODE == MODE_ADMM) st_stream(&uout[j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+        if (keep_xu) {
+          st_stream(&a.X_out[fi * (H * 64) + j * 64u + ulane], v4f{sk.x, sk.y, sm.x, sm.y});
+          st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+        }
       }
       if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
         ak.y = 0.0f;
@@ -915,10 +910,14 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
     {
       v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
       const bool live0 = live && lane == 0;
-      const v2f am = update_bin<MODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
+      v2f smid = v2f{0.0f, 0.0f};
+      const v2f am = update_bin<MODE, EVAL>(xmid, pmid, umid, smid, mmid, a, live0, sd, so);
       if (live0) {
         a.Pmid_out[fi] = pmid;
-        if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
+        if (keep_xu) {
+          a.Xmid_out[fi] = smid;
+          a.Umid_out[fi] = umid;
+        }
       }
       zmid = am * v2f{2.0f, -2.0f};
     }
@@ -1063,15 +1062,10 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
     const v4f* pin_ = a.P_in + fl_ * (H * 64);                                             \
     const v4f* min_ = a.m_pairs + fl_ * (H / 2 * 64);                                      \
     _Pragma("unroll") for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin_[j * 64u + ulane]); \
-    if (MODE == MODE_ADMM) {                                                               \
-      const v4f* uin_ = a.U_in + fl_ * (H * 64);                                           \
-      _Pragma("unroll") for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin_[j * 64u + ulane]); \
-    }                                                                                      \
     _Pragma("unroll") for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]); \
     if (lane == 0) {                                                                       \
       pmid = a.Pmid_in[fl_];                                                               \
       mmid = a.m_mid[fl_];                                                                 \
-      if (MODE == MODE_ADMM) umid = a.Umid_in[fl_];                                        \
     }                                                                                      \
   } while (0)
 
@@ -1084,8 +1078,8 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
     constexpr bool live = true;
     const long long fi = (long long)b * a.T + t;
     v4f* pout = a.P_out + fi * (H * 64);
-    v4f* uout = MODE == MODE_ADMM ? a.U_out + fi * (H * 64) : nullptr;
-    v4f pp[H], uu[H], mm[H / 2];
+    const bool keep_xu = MODE == MODE_ADMM && a.U_out != nullptr;   // (uniform: a kernel argument)
+    v4f pp[H], mm[H / 2];
     v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
     float mmid = 0.0f;
 #if SPECINV_PRIO
@@ -1140,18 +1134,17 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
       v2f xk = (e2 + tw) * half_scale;
       v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};   // conj(...)
       v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
-      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
-      if (MODE == MODE_ADMM) {
-        uk = v2f{uu[j].x, uu[j].y};
-        um = v2f{uu[j].z, uu[j].w};
-      }
+      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f}, sk = v2f{0.0f, 0.0f}, sm = v2f{0.0f, 0.0f};
       const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
       const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
-      v2f ak = update_bin<MODE, EVAL>(xk, pk, uk, mk, a, live, sd, so);
-      v2f am = update_bin<MODE, EVAL>(xm, pm, um, mq, a, live, sd, so);
+      v2f ak = update_bin<MODE, EVAL>(xk, pk, uk, sk, mk, a, live, sd, so);
+      v2f am = update_bin<MODE, EVAL>(xm, pm, um, sm, mq, a, live, sd, so);
       if (live) {
         st_stream(&pout[j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
-        if (MODE == MODE_ADMM) st_stream(&uout[j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+        if (keep_xu) {
+          st_stream(&a.X_out[fi * (H * 64) + j * 64u + ulane], v4f{sk.x, sk.y, sm.x, sm.y});
+          st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+        }
       }
       if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
         ak.y = 0.0f;
@@ -1167,10 +1160,14 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
     {
       v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
       const bool live0 = live && lane == 0;
-      const v2f am = update_bin<MODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
+      v2f smid = v2f{0.0f, 0.0f};
+      const v2f am = update_bin<MODE, EVAL>(xmid, pmid, umid, smid, mmid, a, live0, sd, so);
       if (live0) {
         a.Pmid_out[fi] = pmid;
-        if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
+        if (keep_xu) {
+          a.Xmid_out[fi] = smid;
+          a.Umid_out[fi] = umid;
+        }
       }
       zmid = am * v2f{2.0f, -2.0f};
     }
@@ -1619,6 +1616,7 @@ struct FastState {
   bool semi = false;
   bool hopk = false;
   bool xform_ok = false;
+  bool keep_state = false;
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
   void geometry(int out[4]) const { out[0] = out[1] = out[2] = out[3] = 0; }
@@ -1663,7 +1661,36 @@ struct FastState<float> {
   int chunk = 32, nchunks = 0, n_waves = 0, n_partials = 0;
   int cur = 0;   // index of the buffers holding the current state
   int mode = fast::MODE_GLA;
-  FastBuf xb[2], xtail[2], Pb[2], Pmid[2], Ub[2], Umid[2], mpairs, mmid, inv_env, scratch;
+  FastBuf xb[2], xtail[2], Pb[2], Pmid[2], mpairs, mmid, inv_env, scratch;
+  // ADMM carries Y = X + U in Pb (FastArgs).  X and U themselves are only written when the caller has asked for them
+  // (specinv_plan_keep_state), by the last iteration of every iterate() call.
+  bool keep_state = false, xu_valid = false;
+  FastBuf Xb, Xmid, Ub, Umid;
+
+  // the optional X / U outputs of an ADMM iteration (`last`: the last iteration of an iterate() call)
+  template <typename P>
+  int want_xu(P& pl, fast::FastArgs& a, bool last) {
+    if (mode != fast::MODE_ADMM) return SPECINV_OK;
+    xu_valid = false;
+    if (!keep_state || !last) return SPECINV_OK;
+    SI_TRY(reserve_xu(pl));
+    a.X_out = Xb.template as<v4f>();
+    a.U_out = Ub.template as<v4f>();
+    a.Xmid_out = Xmid.template as<v2f>();
+    a.Umid_out = Umid.template as<v2f>();
+    xu_valid = true;
+    return SPECINV_OK;
+  }
+  template <typename P>
+  int reserve_xu(P& pl) {
+    const long long nf = (long long)pl.B() * pl.Tn();
+    const size_t pbytes = (size_t)nf * (R / 2) * 64 * sizeof(v4f);
+    SI_TRY(Xb.reserve(pbytes));
+    SI_TRY(Ub.reserve(pbytes));
+    SI_TRY(Xmid.reserve(nf * sizeof(v2f)));
+    SI_TRY(Umid.reserve(nf * sizeof(v2f)));
+    return SPECINV_OK;
+  }
 
   int setup(const specinv_stft_cfg& cfg, const std::vector<float>&, int64_t length, int pad) {
     supported = false;
@@ -1801,10 +1828,6 @@ struct FastState<float> {
       if (i == 1 && state_in_place) continue;      // the spectral state is updated in place
       SI_TRY(Pb[i].reserve(pbytes));
       SI_TRY(Pmid[i].reserve(nf * sizeof(v2f)));
-      if (md == fast::MODE_ADMM) {
-        SI_TRY(Ub[i].reserve(pbytes));
-        SI_TRY(Umid[i].reserve(nf * sizeof(v2f)));
-      }
     }
     if (semi && !hopk) SI_TRY(pl.frames_needed());
     SI_TRY(mpairs.reserve((size_t)nf * (G::H / 2) * 64 * sizeof(v4f)));
@@ -1845,9 +1868,14 @@ struct FastState<float> {
       SI_HIP(hipGetLastError());
       SI_HIP(hipMemcpyAsync(sum_m2_out, pl.sums.template as<double>() + 4, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
     }
-    if (md == fast::MODE_ADMM) {
-      SI_HIP(hipMemsetAsync(Ub[0].p, 0, pbytes, pl.stream));
-      SI_HIP(hipMemsetAsync(Umid[0].p, 0, nf * sizeof(v2f), pl.stream));
+    xu_valid = false;
+    if (md == fast::MODE_ADMM && keep_state) {      // methods.py:447-449: X = the start spectrum, U = 0 (Y = X is already in Pb)
+      SI_TRY(reserve_xu(pl));
+      SI_HIP(hipMemcpyAsync(Xb.p, Pb[0].p, pbytes, hipMemcpyDeviceToDevice, pl.stream));
+      SI_HIP(hipMemcpyAsync(Xmid.p, Pmid[0].p, nf * sizeof(v2f), hipMemcpyDeviceToDevice, pl.stream));
+      SI_HIP(hipMemsetAsync(Ub.p, 0, pbytes, pl.stream));
+      SI_HIP(hipMemsetAsync(Umid.p, 0, nf * sizeof(v2f), pl.stream));
+      xu_valid = true;
     }
     if (hopk) {
       hipLaunchKernelGGL(fast::k_reciprocal, dim3((unsigned)ceil_div(pl.length, 256)), dim3(256), 0, pl.stream,
@@ -2034,15 +2062,14 @@ struct FastState<float> {
   }
 
   template <int RR, int MODE, bool EVAL, typename P>
-  int launch_semi(P& pl) {
+  int launch_semi(P& pl, bool last = false) {
     using G = fast::Geo<RR>;
     fast::SemiArgs s{};
     fast::FastArgs& a = s.f;
     a.x_in = xb[0].template as<float>();
     a.P_out = Pb[0].template as<v4f>();
     a.Pmid_out = Pmid[0].template as<v2f>();
-    a.U_out = Ub[0].template as<v4f>();
-    a.Umid_out = Umid[0].template as<v2f>();
+    if (MODE == fast::MODE_ADMM) SI_TRY(want_xu(pl, a, last));
     a.m_pairs = mpairs.template as<v4f>();
     a.m_mid = mmid.template as<float>();
     a.window = pl.window.template as<float>();
@@ -2067,7 +2094,7 @@ struct FastState<float> {
 
   // one iteration (or the initial ISTFT) of k_hop: reads x from xb[cur], writes xb[cur ^ 1], then mends the chunk seams
   template <int RR, int MODE, bool EVAL, typename P>
-  int launch_hop(P& pl) {
+  int launch_hop(P& pl, bool last = false) {
     using G = fast::Geo<RR>;
     const int wgw = 8, hop = pl.cfg.hop_length, keep = pl.N() - hop;
     const int nx = MODE == fast::MODE_INIT ? 0 : (cur ^ 1);
@@ -2077,8 +2104,7 @@ struct FastState<float> {
     a.x_out = xb[nx].template as<float>();
     a.P_out = Pb[0].template as<v4f>();
     a.Pmid_out = Pmid[0].template as<v2f>();
-    a.U_out = Ub[0].template as<v4f>();
-    a.Umid_out = Umid[0].template as<v2f>();
+    if (MODE == fast::MODE_ADMM) SI_TRY(want_xu(pl, a, last));
     a.m_pairs = mpairs.template as<v4f>();
     a.m_mid = mmid.template as<float>();
     a.window = pl.window.template as<float>();
@@ -2115,19 +2141,19 @@ struct FastState<float> {
   int iterate_semi(P& pl, int n_iter, bool eval_last) {
     SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2, 3 * 1024) * sizeof(double)));
     for (int i = 0; i < n_iter; ++i) {
-      const bool ev = eval_last && i == n_iter - 1;
+      const bool last = i == n_iter - 1, ev = eval_last && last;
       int rc = SPECINV_OK;
       if (hopk) {
         SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
           if (mode == fast::MODE_GLA) rc = ev ? launch_hop<RR, fast::MODE_GLA, true>(pl) : launch_hop<RR, fast::MODE_GLA, false>(pl);
-          else rc = ev ? launch_hop<RR, fast::MODE_ADMM, true>(pl) : launch_hop<RR, fast::MODE_ADMM, false>(pl);
+          else rc = ev ? launch_hop<RR, fast::MODE_ADMM, true>(pl, last) : launch_hop<RR, fast::MODE_ADMM, false>(pl, last);
         });
         SI_TRY(rc);
         continue;
       }
       SPECINV_R_SWITCH(R, if (mode == fast::MODE_GLA) rc = ev ? launch_semi<RR, fast::MODE_GLA, true>(pl)
                                                                : launch_semi<RR, fast::MODE_GLA, false>(pl);
-                       else rc = ev ? launch_semi<RR, fast::MODE_ADMM, true>(pl) : launch_semi<RR, fast::MODE_ADMM, false>(pl));
+                       else rc = ev ? launch_semi<RR, fast::MODE_ADMM, true>(pl, last) : launch_semi<RR, fast::MODE_ADMM, false>(pl, last));
       SI_TRY(rc);
     }
     n_partials = n_waves;
@@ -2152,10 +2178,7 @@ struct FastState<float> {
       a.P_out = Pb[pn].template as<v4f>();
       a.Pmid_in = Pmid[ps].template as<v2f>();
       a.Pmid_out = Pmid[pn].template as<v2f>();
-      a.U_in = Ub[ps].template as<v4f>();
-      a.U_out = Ub[pn].template as<v4f>();
-      a.Umid_in = Umid[ps].template as<v2f>();
-      a.Umid_out = Umid[pn].template as<v2f>();
+      SI_TRY(want_xu(pl, a, i == n_iter - 1));
       a.m_pairs = mpairs.template as<v4f>();
       a.m_mid = mmid.template as<float>();
       a.window = pl.window.template as<float>();
@@ -2206,8 +2229,11 @@ struct FastState<float> {
     const long long nf = (long long)pl.B() * pl.Tn();
     SI_TRY(scratch.reserve((size_t)nf * pl.n_freq * sizeof(v2f)));
     const int ps = (semi || state_in_place) ? 0 : cur;
-    const FastBuf& src = which == 0 ? Pb[ps] : Ub[ps];
-    const FastBuf& mid = which == 0 ? Pmid[ps] : Umid[ps];
+    const bool admm = mode == fast::MODE_ADMM;
+    SI_CHECK(!admm || which == 2 || xu_valid, SPECINV_ESTATE,
+             "ADMM carries Y = X + U; call specinv_plan_keep_state(plan, 1) before iterating to read X and U (which = 2 reads Y)");
+    const FastBuf& src = (!admm || which == 2) ? Pb[ps] : which == 0 ? Xb : Ub;
+    const FastBuf& mid = (!admm || which == 2) ? Pmid[ps] : which == 0 ? Xmid : Umid;
     SPECINV_R_SWITCH(R, const long long np = nf * fast::Geo<RR>::H * 64;
                      hipLaunchKernelGGL((fast::k_pairs_to_spec<RR>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
                                         src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf));

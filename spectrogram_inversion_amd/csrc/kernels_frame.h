@@ -177,18 +177,14 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
   const float half_scale = 0.5f * a.fwd_scale;
-  v4f pp[H], uu[H], mm[H / 2];
+  v4f pp[H], mm[H / 2];
+  const bool keep_xu = MODE == MODE_ADMM && a.U_out != nullptr;   // (uniform: a kernel argument)
   v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
   float mmid = 0.0f;
   {
     v4f* pin = a.P_out + fi * (H * 64);
 #pragma unroll
     for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin[j * 64u + ulane]);
-    if (MODE == MODE_ADMM) {
-      v4f* uin = a.U_out + fi * (H * 64);
-#pragma unroll
-      for (int j = 0; j < H; ++j) uu[j] = ld_stream(&uin[j * 64u + ulane]);
-    }
     if (MODE != MODE_INIT) {
       const v4f* min = a.m_pairs + fi * (H / 2 * 64);
 #pragma unroll
@@ -197,7 +193,6 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
     if (lane == 0) {
       pmid = a.Pmid_out[fi];
       if (MODE != MODE_INIT) mmid = a.m_mid[fi];
-      if (MODE == MODE_ADMM) umid = a.Umid_out[fi];
     }
   }
   v2f rc[H];
@@ -228,17 +223,16 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
       const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
       const v2f xk = (e2 + tw) * half_scale;
       const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
-      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f};
-      if (MODE == MODE_ADMM) {
-        uk = v2f{uu[j].x, uu[j].y};
-        um = v2f{uu[j].z, uu[j].w};
-      }
+      v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f}, sk = v2f{0.0f, 0.0f}, sm = v2f{0.0f, 0.0f};
       const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
       const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
-      ak = update_bin<UMODE, EVAL>(xk, pk, uk, mk, a, true, sd, so);
-      am = update_bin<UMODE, EVAL>(xm, pm, um, mq, a, true, sd, so);
+      ak = update_bin<UMODE, EVAL>(xk, pk, uk, sk, mk, a, true, sd, so);
+      am = update_bin<UMODE, EVAL>(xm, pm, um, sm, mq, a, true, sd, so);
       st_stream(&a.P_out[fi * (H * 64) + j * 64u + ulane], v4f{pk.x, pk.y, pm.x, pm.y});
-      if (MODE == MODE_ADMM) st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+      if (keep_xu) {
+        st_stream(&a.X_out[fi * (H * 64) + j * 64u + ulane], v4f{sk.x, sk.y, sm.x, sm.y});
+        st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
+      }
     } else {
       ak = pk * a.inv_scale;
       am = pm * a.inv_scale;
@@ -256,10 +250,14 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
   if (MODE != MODE_INIT) {
     const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
     const bool live0 = lane == 0;
-    const v2f am = update_bin<UMODE, EVAL>(xmid, pmid, umid, mmid, a, live0, sd, so);
+    v2f smid = v2f{0.0f, 0.0f};
+    const v2f am = update_bin<UMODE, EVAL>(xmid, pmid, umid, smid, mmid, a, live0, sd, so);
     if (live0) {
       a.Pmid_out[fi] = pmid;
-      if (MODE == MODE_ADMM) a.Umid_out[fi] = umid;
+      if (keep_xu) {
+        a.Xmid_out[fi] = smid;
+        a.Umid_out[fi] = umid;
+      }
     }
     zmid = am * v2f{2.0f, -2.0f};
   } else {

@@ -384,6 +384,7 @@ struct PlanT final : PlanBase {
     const int64_t ns = nspec();
     count = (double)ns;
     const C* start_user = static_cast<const C*>(init_spec);
+    fast.keep_state = keep_state;
     if constexpr (std::is_same<T, float>::value) {
       // fused kernels, magnitude input: phase_init writes the pair layout itself (methods.py:106 without the (B, F, T)
       // complex round trip and the two layout passes)
@@ -451,6 +452,7 @@ struct PlanT final : PlanBase {
     SI_CHECK(n_iter >= 0, SPECINV_EINVAL, "n_iter < 0");
     if (n_iter == 0) return SPECINV_OK;
     if (fast_path()) {
+      fast.keep_state = keep_state;
       SI_TRY(fast.iterate(*this, n_iter, eval_last));
     } else {
       SI_TRY(frames_needed());
@@ -532,8 +534,16 @@ struct PlanT final : PlanBase {
 
   int get_state_spec(int which, void* spec_out) override {
     SI_CHECK(method != Method::None, SPECINV_ESTATE, "no running state");
-    SI_CHECK(spec_out && (which == 0 || (which == 1 && method == Method::Admm)), SPECINV_EINVAL, "bad arguments");
+    SI_CHECK(spec_out && (which == 0 || ((which == 1 || which == 2) && method == Method::Admm)), SPECINV_EINVAL, "bad arguments");
     if (fast_path()) return fast.get_state_spec(*this, which, static_cast<C*>(spec_out));
+    if (which == 2) {                                   // Y = X + U (what the next iteration reads, methods.py:467-468)
+      SI_TRY(tmp_spec.reserve(nspec() * sizeof(C)));
+      SI_HIP(hipMemcpyAsync(tmp_spec.p, specA.p, nspec() * sizeof(C), hipMemcpyDeviceToDevice, stream));
+      hipLaunchKernelGGL((k_axpy<T>), dim3((unsigned)ceil_div(2 * nspec(), 256)), dim3(256), 0, stream, (T)1,
+                         reinterpret_cast<const T*>(specB.as<C>()), reinterpret_cast<T*>(tmp_spec.as<C>()), 2 * nspec());
+      SI_HIP(hipGetLastError());
+      return transpose<C>(tmp_spec.as<C>(), static_cast<C*>(spec_out), Tn(), n_freq);
+    }
     return transpose<C>(which == 0 ? specA.as<C>() : specB.as<C>(), static_cast<C*>(spec_out), Tn(), n_freq);
   }
 

@@ -192,6 +192,11 @@ int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = g[i];
   return SPECINV_OK;
 }
+int specinv_plan_keep_state(specinv_plan* plan, int on) {
+  PLAN_OR_FAIL(plan);
+  plan->impl->keep_state = on != 0;
+  return SPECINV_OK;
+}
 int specinv_plan_force_generic(specinv_plan* plan, int on) {
   PLAN_OR_FAIL(plan);
   SI_CHECK(plan->impl->method == Method::None, SPECINV_ESTATE, "cannot switch paths while a method is running");

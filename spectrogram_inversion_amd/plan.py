@@ -173,6 +173,10 @@ class Plan:
     def force_generic(self, on=True):
         _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))
 
+    def keep_state(self, on=True):
+        """ADMM: make X and U readable through `state_spec` (the fast paths carry only Y = X + U otherwise)."""
+        _lib.check(self.lib.specinv_plan_keep_state(self._h, int(on)))
+
     # -- building blocks ------------------------------------------------------------------
     def stft(self, x: torch.Tensor) -> torch.Tensor:
         self._sync_stream()

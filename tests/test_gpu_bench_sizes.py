@@ -96,6 +96,7 @@ def test_c4_shard_geometry_vs_oracle_and_float64():
     w = hann(n_fft)
     items = [0, 15, 31]
     c0 = p32.phase_init(mag)
+    p32.keep_state()          # (X and U are written by the last iteration of every iterate() call only)
     p32.admm_init(c0, None, rho)
     # waveforms after 1, 2 and 5 iterations against the oracle: rho = 0.1 amplifies rounding ~10x per iteration in the
     # reference itself - the tolerances of the g4 fixture test

@@ -122,6 +122,7 @@ def test_fast_admm(n_fft, hop, frames, batch, rho):
     ref, st = oracle.admm(init, max_iter=3, rho=rho, tol=0, hop_length=hop, window=w, return_state=True)
     plan = make_plan(n_fft, hop, frames, batch)
     assert plan.fast_path
+    plan.keep_state()
     plan.admm_init(T(init), None, rho)
     plan.iterate(3)
     tol = 3e-4 if rho == 0.1 else 5e-5          # rho=0.1 amplifies rounding ~10x per iteration
@@ -295,6 +296,7 @@ def test_fused_other_overlaps_admm_and_paths_agree(n_fft, hop, frames, batch):
     assert (fused.path, frame.path, gen.path) == ("fused", "frame", "generic")
     waves = []
     for p in (fused, frame, gen):
+        p.keep_state()
         p.admm_init(T(init), None, 1.0)
         p.iterate(2)
         s = p.iterate(1, eval_last=True)
@@ -302,6 +304,7 @@ def test_fused_other_overlaps_admm_and_paths_agree(n_fft, hop, frames, batch):
         assert rel_l2(waves[-1][0], ref.reshape(batch, -1)) < 5e-5
         assert rel_l2(N(p.state_spec(0)), st["X"]) < 5e-5
         assert rel_l2(N(p.state_spec(1)), st["U"]) < 1e-3
+        assert torch.equal(torch.view_as_real(p.state_spec(2)), torch.view_as_real(p.state_spec(0) + p.state_spec(1)))
     for other in waves[1:]:
         np.testing.assert_allclose(waves[0][1], other[1], rtol=2e-5)
 
@@ -433,6 +436,7 @@ def test_tuned_copy_equals_template(monkeypatch, n_fft, batch, frames, method):
         assert geo["kernel"] == ("k_fused" if template == "1" else "k_fused4"), geo
         if template == "0" and batch * frames >= 65536:
             assert geo["waves_per_workgroup"] == 8 and geo["waves"] == 2048, geo
+        p.keep_state()
         (p.gla_init if method == "gla" else p.admm_init)(None, mag, 0.3)
         p.iterate(2)
         s = p.iterate(2, eval_last=True)
@@ -465,6 +469,7 @@ def test_phase_init_in_pair_order_equals_the_three_pass_form(monkeypatch, n_fft,
             monkeypatch.setenv("SPECINV_DISABLE_INIT_PAIRS", disable)
         p = Plan(args_helper(mag, hop_length=hop, window=w), batch, frames, torch.float32, dev())
         assert p.launch_geometry["kernel"] == "k_fused4"
+        p.keep_state()
         (p.gla_init if method == "gla" else p.admm_init)(None, mag, 0.3)
         c0, x0 = p.state_spec(0), p.wave()
         s = p.iterate(3, eval_last=True)
@@ -478,3 +483,52 @@ def test_phase_init_in_pair_order_equals_the_three_pass_form(monkeypatch, n_fft,
     ref = oracle.phase_init(mag_np, hop_length=hop, window=hann(n_fft))
     err = np.abs(N(out[0][0]) - ref).max()
     assert err <= 4 * np.finfo(np.float32).eps * np.abs(ref).max(), err
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch,env", [
+    (1024, 256, 512, 16, {}),                                   # k_fused4
+    (2048, 1024, 96, 70, {}),                                   # k_fused<R, 2>
+    (1024, 256, 300, 24, {"SPECINV_DISABLE_FUSED": "1"}),       # k_semi
+    (1024, 200, 256, 40, {"SPECINV_SMALL_FRAMES": "0"}),        # k_hop
+])
+def test_admm_carries_y_only(monkeypatch, n_fft, hop, frames, batch, env):
+    """ADMM on the fast paths keeps Y = X + U between iterations (methods.py:467-468 read X and U as U + X, the Y that
+    :475 has just rounded).  A plan that also writes X and U (keep_state) and one that does not produce the same
+    waveform and the same Y bit for bit; Y equals fl(X + U) of the kept state bit for bit; the oracle agrees with all three;
+    without keep_state X and U are refused, not invented."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(n_fft + hop)
+    mag_np = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01
+    mag = torch.from_numpy(mag_np).to(dev())
+    w = hann(n_fft)
+    init = oracle.phase_init(mag_np[:2], hop_length=hop, window=w)
+    ref, st = oracle.admm(init, max_iter=4, rho=0.5, tol=0, hop_length=hop, window=w, return_state=True)
+    out = []
+    for keep in (False, True):
+        p = Plan(args_helper(mag, hop_length=hop, window=torch.from_numpy(w)), batch, frames, torch.float32, dev())
+        assert p.fast_path
+        c0 = p.phase_init(mag)
+        if keep:
+            p.keep_state()
+        p.admm_init(c0, None, 0.5)
+        if keep:
+            assert torch.equal(torch.view_as_real(p.state_spec(0)), torch.view_as_real(c0))
+            assert float(p.state_spec(1).abs().max()) == 0.0
+        p.iterate(3)
+        p.iterate(1)
+        if keep:
+            X, U = p.state_spec(0), p.state_spec(1)
+        else:
+            with pytest.raises(RuntimeError, match="keep_state"):
+                p.state_spec(0)
+            with pytest.raises(RuntimeError, match="keep_state"):
+                p.state_spec(1)
+        out.append((p.wave(), p.state_spec(2)))
+        del p
+    (xa, ya), (xb, yb) = out
+    assert torch.equal(xa, xb)
+    assert torch.equal(torch.view_as_real(ya), torch.view_as_real(yb))
+    assert torch.equal(torch.view_as_real(X + U), torch.view_as_real(yb))
+    assert rel_l2(N(xb[:2]), ref.reshape(2, -1)) < 5e-5
+    assert rel_l2(N(X[:2]), st["X"]) < 5e-5 and rel_l2(N(U[:2]), st["U"]) < 1e-3

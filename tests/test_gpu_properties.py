@@ -68,6 +68,7 @@ def test_admm_full_frame_size_fast_vs_float64():
     f32, f64 = plan(n_fft, hop, frames, batch), plan(n_fft, hop, frames, batch, torch.float64)
     assert f32.fast_path and not f64.fast_path
     init = f32.phase_init(mag)
+    f32.keep_state()
     f32.admm_init(init, None, 1.0)
     f64.admm_init(init.to(torch.complex128), None, 1.0)
     f32.iterate(3)

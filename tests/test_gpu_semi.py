@@ -74,6 +74,7 @@ def test_semi_admm_matches_oracle(n_fft, hop, frames, batch, extra, rho):
     ref, st = oracle.admm(init, max_iter=3, rho=rho, tol=0, hop_length=hop, window=w, return_state=True)
     plan = make_plan(n_fft, hop, frames, batch)
     assert plan.path == "frame"
+    plan.keep_state()
     plan.admm_init(T(init), None, rho)
     plan.iterate(3)
     tol = 3e-4 if rho == 0.1 else 5e-5
@@ -178,6 +179,7 @@ def test_chunked_frame_kernel(n_fft, hop, frames, batch, extra, method, chunked_
 
     def run():
         plan = make_plan(n_fft, hop, frames, batch, **dict(extra))
+        plan.keep_state()
         (plan.gla_init if gla else plan.admm_init)(T(init), None, 0.3 if gla else 0.2)
         done, evals = plan.run(n_it, 3, 0.0, "sc")
         return plan, N(plan.wave()), evals
@@ -254,6 +256,7 @@ def test_chunked_frame_kernel_random_shapes(seed, chunked_kernel, monkeypatch):
 
     def run():
         plan = make_plan(n_fft, hop, frames, batch, window=w, center=center, pad_mode=pad_mode)
+        plan.keep_state()
         (plan.gla_init if method == "gla" else plan.admm_init)(None, mag, 0.3 if method == "gla" else 0.5)
         done, evals = plan.run(3, 3, 0.0, "sc")
         return plan.path_code, N(plan.wave()), N(plan.state_spec(0)), evals[0][1]

@@ -14,7 +14,7 @@ DOMINANT = {
     "C5": ["specinv::fast::k_objective_logmel<16, 5, false>", "specinv::k_lincomb<float>", "specinv::k_lbfgs_pair_stats<float>",
            "specinv::k_axpy<float>"],
 }
-ALGO = {"C2": 64 * 1024 * 24596, "C4": 32 * 2048 * 20516, "C3": None, "C5": 16 * 1024 * 4416}
+ALGO = {"C2": 64 * 1024 * 24596, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 4416}
 out = os.path.join(ROOT, "profiles")
 traffic_path = os.path.join(out, "traffic.json")
 try:
