@@ -97,15 +97,20 @@ int specinv_plan_fast_path(const specinv_plan* plan);
 int64_t specinv_plan_device_bytes(const specinv_plan* plan);
 /* Launch geometry of the iteration kernel (diagnostics; the tests assert that the benchmark's geometry is the one they
  * cover): out = { waves per workgroup, chunks of frames per item, waves per launch, kernel }, kernel: 0 generic
- * k_iter_pair, 1 k_fused4 (hop = n_fft/4 at n_fft 1024 / 2048), 2 k_fused<R, OV>, 3 k_semi, 4 k_hop. */
+ * k_iter_pair, 1 k_fused4 (hop = n_fft/4 at n_fft 1024 / 2048), 2 k_fused<R, OV>, 3 k_semi, 4 k_hop, 5 k_fused4_td (Griffin-Lim
+ * at hop = n_fft/4, known once specinv_gla_init has run). */
 int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]);
 /* 0: allow the fast path when the configuration supports it (default); 1: force the generic kernels. */
 int specinv_plan_force_generic(specinv_plan* plan, int on);
-/* ADMM on the float32 fast paths carries only Y = X + U between iterations: methods.py:467-468 read the two as
- * U + X, i.e. the Y that :475 has just rounded, so the iterates are bit-identical and the state traffic halves.
- * 1: the last iteration of every specinv_admm_iterate call (and specinv_admm_init) also leaves X and U behind for
- * specinv_get_state_spec; 0 (default): it does not, and asking for them is SPECINV_ESTATE.  Call before
- * specinv_admm_init.  (The generic kernels keep X and U anyway.) */
+/* The float32 fast paths do not carry the reference's spectral state as such.
+ * ADMM keeps only Y = X + U between iterations: methods.py:467-468 read the two as U + X, i.e. the Y that :475 has just
+ * rounded, so the iterates are bit-identical and the state traffic halves.  Griffin-Lim at hop = n_fft/4 (n_fft 1024 /
+ * 2048) keeps its momentum as the signal z_t = x_t - lr z_{t-1} (pre_t = STFT(z_t) + (-lr)^t c0 by linearity of the STFT):
+ * pre_spec is never formed.
+ * 1: ADMM - the last iteration of every specinv_admm_iterate call (and specinv_admm_init) also leaves X and U behind for
+ * specinv_get_state_spec; Griffin-Lim - the iteration runs on pre_spec itself (the spectral-state kernel).
+ * 0 (default): asking for X / U / pre_spec after an iteration is SPECINV_ESTATE.  Call before specinv_*_init.
+ * (The generic kernels, the frame kernels and the other hops keep pre_spec / can always produce X and U.) */
 int specinv_plan_keep_state(specinv_plan* plan, int on);
 
 /* ---- building blocks ------------------------------------------------------------------ */

@@ -520,6 +520,9 @@ struct FastArgs {
   double* partials;      // [n_waves][2]
   int T, nchunks, n_waves, pad_mode;
   long long L;
+  const float* x2_in;   // k_fused4_td: x_t (x_in / x_out carry z there)
+  float* x2_out;
+  float tds;            //              (-lr)^t
   float coef;       // lr (GLA) or rho (ADMM)
   float inv1p;      // 1/(1+rho)
   float fwd_scale;  // 1 or N^-1/2
@@ -986,6 +989,271 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
     for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[i], envp[64u * i + ulane]);
   } else {
     // what this chunk's last three frames contribute to the next chunk's first three hop-blocks
+    v2f* tl = reinterpret_cast<v2f*>(a.xtail_out + ((long long)b * a.nchunks + c) * 3 * HOP);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + (long long)(t_end + q - 2) * HOP);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
+    }
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0) {
+      a.partials[2 * (long long)w] = d;
+      a.partials[2 * (long long)w + 1] = o;
+    }
+  }
+}
+
+// ---- Griffin-Lim with the momentum carried in the time domain (hop = n_fft/4, n_fft 1024 / 2048) -------------------------
+// methods.py:243-244 keep pre_t = STFT(x_t) - lr * pre_{t-1}, a (B, F, T) complex array read and written every iteration
+// (16 F of the 8 hop + 20 F bytes a frame-iteration moves).  The STFT (padding included) is linear, so
+//     pre_t = STFT(z_t) + (-lr)^t * c0,     z_t = x_t - lr * z_{t-1},  z_0 = 0,
+// with c0 the starting spectrum: the recursion can run on the (B, L) signal z instead.  This kernel transforms z_t's
+// frames (one forward FFT, as before), adds the geometrically vanishing c0 term while it is above 2^-30 (EARLY: c0 is read,
+// never written), projects, synthesises x_{t+1} and writes z_{t+1} = x_{t+1} - lr * z_t next to it: the hop-block of z_t that
+// an output block needs is the oldest block of the frame just analysed, still in registers.  Per frame-iteration: 4 hop (z in)
+// + 4 F (target) + 8 hop (z, x out) instead of 8 hop + 20 F bytes; the same arithmetic up to the rounding of where the linear
+// combination is taken (time domain here, frequency domain in the reference).  The evaluating variant transforms x_t's frames
+// as well (|STFT(x_t)| is what the metric wants, methods.py:242).
+//   a.x_in / a.x_out  : z_t / z_{t+1}          a.x2_in / a.x2_out : x_t (EVAL only) / x_{t+1}
+//   a.xtail_in / _out : chunk seams, shared by x and z (the - lr * z_t term goes to the block's owner)
+//   a.P_in, a.Pmid_in : c0 pairs (EARLY)        a.tds : (-lr)^t
+template <int R>
+__device__ __forceinline__ void td_split(v2f zk, v2f zm, v2f wk, float half_scale, v2f& xk, v2f& xm) {
+  const v2f e2 = add_conj(zk, zm);
+  const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));            // W * (-i (Zk - conj Zm))
+  xk = (e2 + tw) * half_scale;
+  xm = (e2 - tw) * v2f{half_scale, -half_scale};
+}
+
+template <int R, bool EARLY, bool EVAL>
+__global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
+  using G = Geo<R>;
+  constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);   // W_M^(l*k1)
+  }
+  __syncthreads();
+
+  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  if (w >= a.n_waves) return;
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  const int t_begin = chunk_begin(c, a.T, a.nchunks);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  const float* zrow = a.x_in + (long long)b * a.L;
+  const float* tailrow = a.xtail_in + (long long)b * a.nchunks * 3 * HOP;
+  float* zorow = a.x_out + (long long)b * a.L;
+  float* xorow = a.x2_out + (long long)b * a.L;
+  const float half_scale = 0.5f * a.fwd_scale;
+  const float nlr = -a.coef;
+
+  v2f acc[3 * QU];
+#pragma unroll
+  for (int i = 0; i < 3 * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
+  double sd = 0.0, so = 0.0;
+  TwRegs<R> twr;
+#pragma unroll
+  for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = lds_tw1[(k1 - 1) * 64 + lane];
+
+  // samples of z_t: three hop-blocks carried from frame to frame plus the new one, fetched one frame ahead
+  v2f xq[3][QU], xn[QU];
+  load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin, lane, a.pad_mode, xq[0]);
+  load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + 1, lane, a.pad_mode, xq[1]);
+  load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + 2, lane, a.pad_mode, xq[2]);
+  load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + 3, lane, a.pad_mode, xn);
+
+  for (int t = t_begin; t < t_end; ++t) {
+    asm volatile("" ::: "memory");     // (window / twiddle reads stay inside the loop: hoisted they pin ~80 VGPRs)
+    v2f wn = k.wn;
+    asm volatile("" : "+v"(wn));
+    const long long fi = (long long)b * a.T + t;
+    v4f mm[H / 2];
+    v4f pp[EARLY ? H : 1];
+    v2f pmid = v2f{0.0f, 0.0f};
+    float mmid = 0.0f;
+    __builtin_amdgcn_s_setprio(1);
+    {
+      const v4f* min_ = a.m_pairs + fi * (H / 2 * 64);
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]);
+      if (EARLY) {
+        const v4f* pin_ = a.P_in + fi * (H * 64);
+#pragma unroll
+        for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin_[j * 64u + ulane]);
+      }
+      if (lane == 0) {
+        mmid = a.m_mid[fi];
+        if (EARLY) pmid = a.Pmid_in[fi];
+      }
+    }
+
+    v2f z[R];
+    if (EVAL) {
+      // |STFT(x_t)| against the target (methods.py:242): x_t's frame, transformed and dropped
+      const float* xrow = a.x2_in + (long long)b * a.L;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        v2f q[QU];
+        load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, a.pad_mode, q);
+#pragma unroll
+        for (int i = 0; i < QU; ++i) z[qq * QU + i] = q[i] * lds_win[64 * (qq * QU + i) + lane];
+      }
+      fft_forward_t<R>(z, k, twr, tr);
+      v2f rc[H];
+#pragma unroll
+      for (int m = H; m < R; ++m) {
+        const v2f got = shfl2(z[m], k.partner);
+        const v2f own = z[(m + 1) % R];
+        rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+      }
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+        v2f xk, xm;
+        td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, xk, xm);
+        const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+        const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+        const float ok = fast_abs(xk), om = fast_abs(xm);
+        const double dk = (double)ok - (double)mk, dm = (double)om - (double)mq;
+        sd += dk * dk + dm * dm;
+        so += (double)ok * (double)ok + (double)om * (double)om;
+      }
+      if (lane == 0) {
+        const float o = fast_abs(z[H] * v2f{a.fwd_scale, -a.fwd_scale});
+        const double d = (double)o - (double)mmid;
+        sd += d * d;
+        so += (double)o * (double)o;
+      }
+    }
+
+    // ---- analysis of z_t's frame; its oldest hop-block is the one this frame's output block needs
+    v2f zold[QU];
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+      zold[i] = xq[0][i];
+      z[i] = xq[0][i] * lds_win[64 * i + lane];
+      z[QU + i] = xq[1][i] * lds_win[64 * (QU + i) + lane];
+      z[2 * QU + i] = xq[2][i] * lds_win[64 * (2 * QU + i) + lane];
+      z[3 * QU + i] = xn[i] * lds_win[64 * (3 * QU + i) + lane];
+      xq[0][i] = xq[1][i];
+      xq[1][i] = xq[2][i];
+      xq[2][i] = xn[i];
+    }
+    if (t + 1 < t_end) load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 4, lane, a.pad_mode, xn);
+    __builtin_amdgcn_s_setprio(0);
+
+    fft_forward_t<R>(z, k, twr, tr);
+
+    v2f rc[H];
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];              // lane 0 is its own partner, shifted by one register
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+
+    // ---- per pair: split -> (+ c0 term) -> projection -> fold back
+    v2f back[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+      v2f sk, sm;
+      td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
+      if (EARLY) {
+        sk = v2f{fmaf(a.tds, pp[j].x, sk.x), fmaf(a.tds, pp[j].y, sk.y)};
+        sm = v2f{fmaf(a.tds, pp[j].z, sm.x), fmaf(a.tds, pp[j].w, sm.y)};
+      }
+      const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+      const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+#if SPECINV_IEEE
+      const float dk = fast_abs(sk) + 1e-16f, dq = fast_abs(sm) + 1e-16f;
+      v2f ak = v2f{__fdiv_rn(sk.x * mk, dk) * a.inv_scale, __fdiv_rn(sk.y * mk, dk) * a.inv_scale};
+      v2f am = v2f{__fdiv_rn(sm.x * mq, dq) * a.inv_scale, __fdiv_rn(sm.y * mq, dq) * a.inv_scale};
+#else
+      const float ik = fast_rcp(fast_abs(sk) + 1e-16f) * a.inv_scale, iq = fast_rcp(fast_abs(sm) + 1e-16f) * a.inv_scale;
+      v2f ak = v2f{(sk.x * mk) * ik, (sk.y * mk) * ik};
+      v2f am = v2f{(sm.x * mq) * iq, (sm.y * mq) * iq};
+#endif
+      if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    v2f zmid;
+    {
+      v2f smid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
+      if (EARLY) smid = v2f{fmaf(a.tds, pmid.x, smid.x), fmaf(a.tds, pmid.y, smid.y)};
+#if SPECINV_IEEE
+      const float dn = fast_abs(smid) + 1e-16f;
+      const v2f am = v2f{__fdiv_rn(smid.x * mmid, dn) * a.inv_scale, __fdiv_rn(smid.y * mmid, dn) * a.inv_scale};
+#else
+      const float inv = fast_rcp(fast_abs(smid) + 1e-16f) * a.inv_scale;
+      const v2f am = v2f{(smid.x * mmid) * inv, (smid.y * mmid) * inv};
+#endif
+      zmid = am * v2f{2.0f, -2.0f};
+    }
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+
+    fft_inverse_t<R>(z, k, twr, tr);
+
+    // ---- synthesis window, register overlap-add, one finished hop-block of x_{t+1} and of z_{t+1} out
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    if (t >= 2) {
+      const long long o0 = (long long)(t - 2) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
+      v2f* xo = reinterpret_cast<v2f*>(xorow + o0);
+      v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) {
+        const v2f xv = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
+        xo[64u * i + ulane] = xv;
+        zo[64u * i + ulane] = v2f{fmaf(nlr, zold[i].x, xv.x), fmaf(nlr, zold[i].y, xv.y)};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+      acc[i] = acc[QU + i] + z[QU + i];
+      acc[QU + i] = acc[2 * QU + i] + z[2 * QU + i];
+      acc[2 * QU + i] = z[3 * QU + i];
+    }
+  }
+  if (t_end == a.T) {
+    // the chunk that holds the last frame also finishes hop-block T (frames T-3 .. T-1); xq[0] is z_t's block T by now
+    const long long o0 = (long long)(a.T - 2) * HOP;
+    const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
+    v2f* xo = reinterpret_cast<v2f*>(xorow + o0);
+    v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+      const v2f xv = env_apply(acc[i], envp[64u * i + ulane]);
+      xo[64u * i + ulane] = xv;
+      zo[64u * i + ulane] = v2f{fmaf(nlr, xq[0][i].x, xv.x), fmaf(nlr, xq[0][i].y, xv.y)};
+    }
+  } else {
+    // what this chunk's last three frames contribute to the next chunk's first three hop-blocks (of x and of z alike)
     v2f* tl = reinterpret_cast<v2f*>(a.xtail_out + ((long long)b * a.nchunks + c) * 3 * HOP);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -1666,6 +1934,10 @@ struct FastState<float> {
   // (specinv_plan_keep_state), by the last iteration of every iterate() call.
   bool keep_state = false, xu_valid = false;
   FastBuf Xb, Xmid, Ub, Umid;
+  // Griffin-Lim on k_fused4_td: the momentum state is the signal z (zb), Pb keeps the starting spectrum c0
+  bool td = false;
+  int td_t = 0;          // closure calls so far (z_1 = x_1: the first call reads x itself)
+  FastBuf zb[2];
 
   // the optional X / U outputs of an ADMM iteration (`last`: the last iteration of an iterate() call)
   template <typename P>
@@ -1818,6 +2090,15 @@ struct FastState<float> {
     using G = fast::Geo<RR>;
     const int hop = pl.cfg.hop_length;
     mode = md;
+    td = md == fast::MODE_GLA && !semi && OV == 4 && (RR == 8 || RR == 16) && !use_template && !keep_state;
+    if (const char* e = getenv("SPECINV_DISABLE_TD")) {      // tests: the spectral-state kernel
+      if (e[0] == '1') td = false;
+    }
+    td_t = 0;
+    if (td) {
+      SI_TRY(zb[0].reserve((size_t)pl.B() * pl.length * sizeof(float)));
+      SI_TRY(zb[1].reserve((size_t)pl.B() * pl.length * sizeof(float)));
+    }
     const long long nf = (long long)pl.B() * pl.Tn();
     const size_t pbytes = (size_t)nf * G::H * 64 * sizeof(v4f);
     const size_t tail_bytes = (size_t)pl.B() * nchunks * (OV > 0 ? OV - 1 : 0) * hop * sizeof(float);
@@ -2024,14 +2305,14 @@ struct FastState<float> {
     if ((R == 8 || R == 16) && OV == 4 && !use_template) return n_waves >= 2048 ? SPECINV_WGW : 4;
     return 4;
   }
-  // {waves per workgroup, chunks per item, waves, kernel: 1 k_fused4, 2 k_fused<R, OV>, 3 k_semi, 4 k_hop}
+  // {waves per workgroup, chunks per item, waves, kernel: 1 k_fused4, 2 k_fused<R, OV>, 3 k_semi, 4 k_hop, 5 k_fused4_td}
   void geometry(int out[4]) const {
     if (semi) {
       out[0] = hopk ? 8 : 4;
       out[3] = hopk ? 4 : 3;
     } else {
       out[0] = fused_wgw();
-      out[3] = ((R == 8 || R == 16) && OV == 4 && !use_template) ? 1 : 2;
+      out[3] = ((R == 8 || R == 16) && OV == 4 && !use_template) ? (td ? 5 : 1) : 2;
     }
     out[1] = nchunks;
     out[2] = n_waves;
@@ -2054,6 +2335,27 @@ struct FastState<float> {
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     const int wgw = fused_wgw();
     const size_t lds_used = G::lds_bytes(wgw);
+    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
+    fast::FastArgs args = a;
+    void* kargs[] = {&args};
+    SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds_used, pl.stream));
+    return SPECINV_OK;
+  }
+
+  template <typename P>
+  int launch_td(P& pl, const fast::FastArgs& a, bool early, bool ev) {
+    const void* fn = nullptr;
+    size_t lds_used = 0;
+    const int wgw = fused_wgw();
+    if (R == 16) {
+      fn = early ? (ev ? (const void*)fast::k_fused4_td<16, true, true> : (const void*)fast::k_fused4_td<16, true, false>)
+                 : (ev ? (const void*)fast::k_fused4_td<16, false, true> : (const void*)fast::k_fused4_td<16, false, false>);
+      lds_used = fast::Geo<16>::lds_bytes(wgw);
+    } else {
+      fn = early ? (ev ? (const void*)fast::k_fused4_td<8, true, true> : (const void*)fast::k_fused4_td<8, true, false>)
+                 : (ev ? (const void*)fast::k_fused4_td<8, false, true> : (const void*)fast::k_fused4_td<8, false, false>);
+      lds_used = fast::Geo<8>::lds_bytes(wgw);
+    }
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
     fast::FastArgs args = a;
     void* kargs[] = {&args};
@@ -2193,6 +2495,21 @@ struct FastState<float> {
       a.inv1p = 1.0f / (float)(1.0 + (double)pl.coef);
       a.fwd_scale = pl.fc.fwd_scale;
       a.inv_scale = pl.fc.inv_scale;
+      if (td) {
+        ++td_t;
+        const double tds = std::pow(-(double)pl.coef, (double)td_t);
+        const bool early = std::fabs(tds) >= 9.3132257461547852e-10;       // 2^-30: below float32 resolution of |pre|
+        a.x_in = td_t == 1 ? xb[cur].template as<float>() : zb[cur].template as<float>();
+        a.x_out = zb[nx].template as<float>();
+        a.x2_in = xb[cur].template as<float>();
+        a.x2_out = xb[nx].template as<float>();
+        a.P_in = Pb[0].template as<v4f>();
+        a.Pmid_in = Pmid[0].template as<v2f>();
+        a.tds = (float)tds;
+        SI_TRY(launch_td(pl, a, early, ev));
+        cur = nx;
+        continue;
+      }
       int rc = SPECINV_OK;
       SPECINV_R_SWITCH(R, if (mode == fast::MODE_GLA) rc = ev ? launch<RR, fast::MODE_GLA, true>(pl, a)
                                                                : launch<RR, fast::MODE_GLA, false>(pl, a);
@@ -2230,6 +2547,9 @@ struct FastState<float> {
     SI_TRY(scratch.reserve((size_t)nf * pl.n_freq * sizeof(v2f)));
     const int ps = (semi || state_in_place) ? 0 : cur;
     const bool admm = mode == fast::MODE_ADMM;
+    SI_CHECK(admm || !td || td_t == 0, SPECINV_ESTATE,
+             "Griffin-Lim carries its momentum as a signal on this path (pre_spec is never formed); call "
+             "specinv_plan_keep_state(plan, 1) before specinv_gla_init to iterate on pre_spec itself");
     SI_CHECK(!admm || which == 2 || xu_valid, SPECINV_ESTATE,
              "ADMM carries Y = X + U; call specinv_plan_keep_state(plan, 1) before iterating to read X and U (which = 2 reads Y)");
     const FastBuf& src = (!admm || which == 2) ? Pb[ps] : which == 0 ? Xb : Ub;

@@ -167,14 +167,16 @@ class Plan:
         """Diagnostics: how the iteration kernel is launched (`specinv_plan_launch_geometry`)."""
         out = (C.c_int32 * 4)()
         _lib.check(self.lib.specinv_plan_launch_geometry(self._h, out))
-        kernel = ("k_iter_pair", "k_fused4", "k_fused", "k_semi", "k_hop")[out[3]]
+        kernel = ("k_iter_pair", "k_fused4", "k_fused", "k_semi", "k_hop", "k_fused4_td")[out[3]]
         return {"waves_per_workgroup": out[0], "chunks": out[1], "waves": out[2], "kernel": kernel}
 
     def force_generic(self, on=True):
         _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))
 
     def keep_state(self, on=True):
-        """ADMM: make X and U readable through `state_spec` (the fast paths carry only Y = X + U otherwise)."""
+        """Make the reference's spectral state readable through `state_spec`: X and U of ADMM (the fast paths carry only
+        Y = X + U otherwise), pre_spec of griffin_lim (the hop = n_fft/4 kernel carries its momentum as a signal otherwise).
+        Call before `admm_init` / `gla_init`."""
         _lib.check(self.lib.specinv_plan_keep_state(self._h, int(on)))
 
     # -- building blocks ------------------------------------------------------------------

@@ -557,14 +557,13 @@ def g13_wave_level_shapes():
     save("g13_wave_level_shapes", **out)
 
 
-def g14_wellcond():
+def g14_wellcond(name="g14_wellcond", n_fft=512, hop=128, frames=40, seed=140):
     """A well-conditioned 100-iteration case: the magnitudes ARE the STFT of a signal (chirps + harmonics + a noise
     floor) and the starting phase is the true phase perturbed by 0.5 rad rms, so the iterates stay close to a consistent
     spectrogram and no bin with a sizeable target passes through zero - unlike g2's random (inconsistent) magnitudes,
     where one such event decorrelates a neighbourhood.  Griffin-Lim after 100 iterations, alpha 0 / 0.3 / 0.99, float32
     and float64: the strict waveform gate min(1e-4, 6 x float32-vs-float64 noise) applies to every kernel path."""
-    rng = np.random.default_rng(140)
-    n_fft, hop, frames = 512, 128, 40
+    rng = np.random.default_rng(seed)
     n = (frames - 1) * hop
     tt = np.arange(n) / 16000.0
     x = np.stack([
@@ -585,14 +584,20 @@ def g14_wellcond():
         out[f"wave_a{alpha}"] = y.numpy()
         out[f"wave64_a{alpha}"] = y64.numpy()
         e = float((y.double() - y64).norm() / y64.norm())
-        print(f"  g14 alpha {alpha}: float32 vs float64 after 100 it {e:.2e}")
-    save("g14_wellcond", **out)
+        print(f"  {name} alpha {alpha}: float32 vs float64 after 100 it {e:.2e}")
+    save(name, **out)
+
+
+def g15_wellcond_1024():
+    """g14's construction at n_fft 1024 / hop 256 (60 frames): the shape class of the hop = n_fft/4 kernels (k_fused4 and
+    k_fused4_td, which carries the momentum as a signal), 100 iterations, strict gate."""
+    g14_wellcond("g15_wellcond_1024", n_fft=1024, hop=256, frames=60, seed=150)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     table = dict(g0=g0_stft, g1=g1_phase_init, g2=g2_gla, g3=g3_sweep, g4=g4_admm, g5=g5_rtisi,
                  g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd, g11=g11_autograd_admm, g12=g12_autograd_rtisi, g13=g13_wave_level_shapes,
-                 g14=g14_wellcond)
+                 g14=g14_wellcond, g15=g15_wellcond_1024)
     for w in which:
         table[w]()

@@ -71,11 +71,12 @@ def test_gla_waveforms(alpha, it):
         np.testing.assert_allclose(got[:, 1], tr[:, 1], rtol=2e-4)
 
 
+@pytest.mark.parametrize("fixture", ["g14_wellcond", "g15_wellcond_1024"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
-def test_gla_wellconditioned_100_iterations(alpha):
-    """g14: consistent magnitudes, perturbed true phase - 100 iterations stay well-conditioned (the reference's own
+def test_gla_wellconditioned_100_iterations(alpha, fixture):
+    """g14 / g15: consistent magnitudes, perturbed true phase - 100 iterations stay well-conditioned (the reference's own
     float32-vs-float64 distance is 1e-6), so the waveform gate is the strict one."""
-    g = load_golden("g14_wellcond")
+    g = load_golden(fixture)
     y = oracle.griffin_lim(g["init"], max_iter=100, alpha=alpha, tol=0, eva_iter=10, hop_length=int(g["hop"]), window=g["window"])
     ref, ref64 = g[f"wave_a{alpha}"], g[f"wave64_a{alpha}"]
     noise = rel_l2(ref, ref64)
