@@ -72,19 +72,61 @@ using v4f = float __attribute__((ext_vector_type(4)));
 
 enum { MODE_GLA = 0, MODE_ADMM = 1 };
 
-__device__ __forceinline__ v2f cmul(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// complex products with a literal constant operand: four scalar operations with inline literals
+__device__ __forceinline__ v2f cmul_k(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ v2f cmulc_k(v2f a, v2f b) { return v2f{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+// ... with both operands in registers: TWO packed operations - the VOP3P source modifiers broadcast a.x / a.y over both
+// halves, pick b's halves crosswise and negate one product (the compiler emits 2 v_mul + 2 v_fma for the scalar form; the
+// wave-level kernels are bound by the instructions a wave can issue, a packed one counts once)
+#ifndef SPECINV_ASM_CMUL
+#define SPECINV_ASM_CMUL 1
+#endif
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+#if SPECINV_ASM_CMUL
+  v2f t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                 // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+  return d;                                                                                               // (- a.y b.y, + a.y b.x)
+#else
+  return cmul_k(a, b);
+#endif
+}
 // a * conj(b)
-__device__ __forceinline__ v2f cmulc(v2f a, v2f b) { return v2f{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+__device__ __forceinline__ v2f cmulc(v2f a, v2f b) {
+#if SPECINV_ASM_CMUL
+  v2f t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));    // (a.x b.x, - a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t)); // (+ a.y b.y, + a.y b.x)
+  return d;
+#else
+  return cmulc_k(a, b);
+#endif
+}
 __device__ __forceinline__ v2f cconj(v2f a) { return v2f{a.x, -a.y}; }
 __device__ __forceinline__ v2f mul_i(v2f a) { return v2f{-a.y, a.x}; }    // a * (+i)
 __device__ __forceinline__ v2f mul_mi(v2f a) { return v2f{a.y, -a.x}; }   // a * (-i)
+template <bool PK>
+__device__ __forceinline__ v2f cmul_p(v2f a, v2f b) { return PK ? cmul(a, b) : cmul_k(a, b); }
+template <bool PK>
+__device__ __forceinline__ v2f cmulc_p(v2f a, v2f b) { return PK ? cmulc(a, b) : cmulc_k(a, b); }
+// (-i w) * d = (w.y d.x + w.x d.y, w.y d.y - w.x d.x) without forming -i w
+__device__ __forceinline__ v2f cmul_mi(v2f w, v2f d) {
+#if SPECINV_ASM_CMUL
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(w), "v"(d));                              // (w.y d.x, w.y d.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(d), "v"(t));
+  return r;                                                                                                              // (+ w.x d.y, - w.x d.x)
+#else
+  return cmul_k(v2f{w.y, -w.x}, d);
+#endif
+}
 template <bool INV>
 __device__ __forceinline__ v2f rot(v2f a) { return INV ? mul_i(a) : mul_mi(a); }
 // exp(-+ i*theta) from (cos, sin): forward uses (c, -s), inverse (c, +s)
 template <bool INV>
 __device__ __forceinline__ v2f twc(float c, float s) { return v2f{c, INV ? s : -s}; }
 template <bool INV>
-__device__ __forceinline__ v2f dirmul(v2f a, v2f w) { return INV ? cmulc(a, w) : cmul(a, w); }
+__device__ __forceinline__ v2f dirmul(v2f a, v2f w) { return INV ? cmulc_k(a, w) : cmul_k(a, w); }   // (literal twiddles)
 
 __device__ __forceinline__ v2f shfl_xor2(v2f a, int mask) {
   return v2f{__shfl_xor(a.x, mask, 64), __shfl_xor(a.y, mask, 64)};
@@ -391,9 +433,12 @@ struct TwRegs {
   __device__ __forceinline__ v2f operator()(int k1) const { return w[k1 - 1]; }
 };
 
-template <int R, typename TW>
+// PK: complex products as two packed operations (cmul) or four scalar ones (cmul_k).  Packed wins wherever two waves share a
+// SIMD (C2 -6 %, C4 -5 %); a lone wave per SIMD (k_rtisi_fast) has nobody to cover the packed pair's dependent latency and
+// measured 12 % slower with it, so that kernel asks for the scalar form.
+template <int R, bool PK = true, typename TW>
 __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr);
-template <int R, typename TW>
+template <int R, bool PK = true, typename TW>
 __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr);
 
 template <int R>
@@ -407,12 +452,12 @@ __device__ __forceinline__ void fft_inverse(v2f (&z)[R], const LaneConst<R>& k, 
   fft_inverse_t<R>(z, k, TwLds{tw1, k.lane}, tr);
 }
 
-template <int R, typename TW>
+template <int R, bool PK, typename TW>
 __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr) {
   using G = Geo<R>;
   Dft<R, false>::run(z);
 #pragma unroll
-  for (int k1 = 1; k1 < R; ++k1) z[k1] = cmul(z[k1], tw(k1));
+  for (int k1 = 1; k1 < R; ++k1) z[k1] = cmul_p<PK>(z[k1], tw(k1));
   // cross-lane radix-C over v = lane / R; afterwards lane position v holds frequency digit k.kv
   if (G::C == 2) {
 #pragma unroll
@@ -426,8 +471,8 @@ __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k
     const float s3 = (k.lane & 8) ? -1.0f : 1.0f, s2 = (k.lane & 4) ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      z[i] = cmul(z[i], k.stage[0]);
-      z[i] = cmul(xlane_bf2(z[i], 8, s3), k.stage[1]);
+      z[i] = cmul_p<PK>(z[i], k.stage[0]);
+      z[i] = cmul_p<PK>(xlane_bf2(z[i], 8, s3), k.stage[1]);
       z[i] = xlane_bf2(z[i], 4, s2);
     }
   } else {
@@ -438,13 +483,13 @@ __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k
     const float sg = upper ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      z[i] = cmul(z[i], k.stage[0]);
+      z[i] = cmul_p<PK>(z[i], k.stage[0]);
       const v2f p = shfl_xor2(z[i], R);
       z[i] = v2f{fmaf(z[i].x, sg, p.x), fmaf(z[i].y, sg, p.y)};   // lower: a + p ; upper: p - a
     }
   }
 #pragma unroll
-  for (int i = 0; i < R; ++i) z[i] = cmul(z[i], k.post);
+  for (int i = 0; i < R; ++i) z[i] = cmul_p<PK>(z[i], k.post);
   // transpose n2 <-> k1 inside each group of R lanes (wave-private LDS, no barrier)
 #pragma unroll
   for (int i = 0; i < R; ++i) tr[k.tr_a + i * (R + 1)] = z[i];
@@ -454,14 +499,14 @@ __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k
 }
 
 // inverse (unnormalised): in z[j] = bin lane + 64j; out z[u] = time sample 64u + lane
-template <int R, typename TW>
+template <int R, bool PK, typename TW>
 __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr) {
   using G = Geo<R>;
   Dft<R, true>::run(z);
 #pragma unroll
   for (int i = 0; i < R; ++i) tr[k.tr_b + i] = z[i];
 #pragma unroll
-  for (int i = 0; i < R; ++i) z[i] = cmulc(tr[k.tr_a + i * (R + 1)], k.post);
+  for (int i = 0; i < R; ++i) z[i] = cmulc_p<PK>(tr[k.tr_a + i * (R + 1)], k.post);
   if (G::C == 2) {
 #pragma unroll
     for (int g = 0; g < R; g += 2) xlane_dft2(z[g], z[g + 1]);
@@ -472,8 +517,8 @@ __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k
     const float s3 = (k.lane & 8) ? -1.0f : 1.0f, s2 = (k.lane & 4) ? -1.0f : 1.0f;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      z[i] = cmulc(xlane_bf2(z[i], 4, s2), k.stage[1]);
-      z[i] = cmulc(xlane_bf2(z[i], 8, s3), k.stage[0]);
+      z[i] = cmulc_p<PK>(xlane_bf2(z[i], 4, s2), k.stage[1]);
+      z[i] = cmulc_p<PK>(xlane_bf2(z[i], 8, s3), k.stage[0]);
     }
 #pragma unroll
     for (int g = 0; g < R; g += 4) xlane_dft4<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
@@ -484,13 +529,13 @@ __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k
     for (int i = 0; i < R; ++i) {
       const v2f p = shfl_xor2(z[i], R);
       z[i] = v2f{fmaf(z[i].x, sg, p.x), fmaf(z[i].y, sg, p.y)};
-      z[i] = cmulc(z[i], k.stage[0]);
+      z[i] = cmulc_p<PK>(z[i], k.stage[0]);
     }
 #pragma unroll
     for (int g = 0; g < R; g += 4) xlane_dft4<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
   }
 #pragma unroll
-  for (int k1 = 1; k1 < R; ++k1) z[k1] = cmulc(z[k1], tw(k1));
+  for (int k1 = 1; k1 < R; ++k1) z[k1] = cmulc_p<PK>(z[k1], tw(k1));
   Dft<R, true>::run(z);
 }
 
@@ -523,6 +568,7 @@ struct FastArgs {
   const float* x2_in;   // k_fused4_td: x_t (x_in / x_out carry z there)
   float* x2_out;
   float tds;            //              (-lr)^t
+  unsigned long long* stamps;   // SPECINV_TD_STAMPS builds only: [n_waves][8]
   float coef;       // lr (GLA) or rho (ADMM)
   float inv1p;      // 1/(1+rho)
   float fwd_scale;  // 1 or N^-1/2
@@ -879,11 +925,11 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       // W_N^(lane + 64 j) = W_N^lane * W_{2R}^j
-      const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = add_conj(zk, zm);
       const v2f dd = sub_conj(zk, zm);
-      const v2f tw = cmul(mul_mi(wk), dd);                 // W * (-i (Zk - conj Zm))
+      const v2f tw = cmul_mi(wk, dd);                 // W * (-i (Zk - conj Zm))
       v2f xk = (e2 + tw) * half_scale;
       v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};   // conj(...)
       v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
@@ -1020,16 +1066,31 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
 //   a.x_in / a.x_out  : z_t / z_{t+1}          a.x2_in / a.x2_out : x_t (EVAL only) / x_{t+1}
 //   a.xtail_in / _out : chunk seams, shared by x and z (the - lr * z_t term goes to the block's owner)
 //   a.P_in, a.Pmid_in : c0 pairs (EARLY)        a.tds : (-lr)^t
+#ifndef SPECINV_TD_STAMPS          // diagnostic build: per-phase s_memtime sums of every wave of k_fused4_td (tools/td_stamps.py)
+#define SPECINV_TD_STAMPS 0
+#endif
+#if SPECINV_TD_STAMPS
+#define TD_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_sum[i] += now_ - stamp_prev; stamp_prev = now_; } while (0)
+#else
+#define TD_STAMP(i) do { } while (0)
+#endif
+
 template <int R>
 __device__ __forceinline__ void td_split(v2f zk, v2f zm, v2f wk, float half_scale, v2f& xk, v2f& xm) {
   const v2f e2 = add_conj(zk, zm);
-  const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));            // W * (-i (Zk - conj Zm))
+  const v2f tw = cmul_mi(wk, sub_conj(zk, zm));            // W * (-i (Zk - conj Zm))
   xk = (e2 + tw) * half_scale;
   xm = (e2 - tw) * v2f{half_scale, -half_scale};
 }
 
 template <int R, bool EARLY, bool EVAL>
-__global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
+#ifndef SPECINV_TD_MINWAVES
+#define SPECINV_TD_MINWAVES 2
+#endif
+#ifndef SPECINV_TD_ABLATE          // timing-only builds (wrong results): 1 target from frame 0 (L2-resident), 2 no output stores,
+#define SPECINV_TD_ABLATE 0        // 4 z samples from the first hop-blocks (L2-resident)
+#endif
+__global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused4_td(FastArgs a) {
   using G = Geo<R>;
   constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1075,7 +1136,12 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
   load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + 2, lane, a.pad_mode, xq[2]);
   load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + 3, lane, a.pad_mode, xn);
 
+#if SPECINV_TD_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = t_begin; t < t_end; ++t) {
+    TD_STAMP(5);                       // (loop overhead / nothing on the first pass)
     asm volatile("" ::: "memory");     // (window / twiddle reads stay inside the loop: hoisted they pin ~80 VGPRs)
     v2f wn = k.wn;
     asm volatile("" : "+v"(wn));
@@ -1086,7 +1152,7 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
     float mmid = 0.0f;
     __builtin_amdgcn_s_setprio(1);
     {
-      const v4f* min_ = a.m_pairs + fi * (H / 2 * 64);
+      const v4f* min_ = a.m_pairs + ((SPECINV_TD_ABLATE & 1) ? (long long)(fi & 255) : fi) * (H / 2 * 64);
 #pragma unroll
       for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]);
       if (EARLY) {
@@ -1121,7 +1187,7 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < H; ++j) {
-        const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+        const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
         v2f xk, xm;
         td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, xk, xm);
         const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
@@ -1152,10 +1218,13 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
       xq[1][i] = xq[2][i];
       xq[2][i] = xn[i];
     }
-    if (t + 1 < t_end) load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t + 4, lane, a.pad_mode, xn);
+    if (t + 1 < t_end)
+      load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, (SPECINV_TD_ABLATE & 4) ? 8 + (t & 3) : t + 4, lane, a.pad_mode, xn);
     __builtin_amdgcn_s_setprio(0);
+    TD_STAMP(0);
 
     fft_forward_t<R>(z, k, twr, tr);
+    TD_STAMP(1);
 
     v2f rc[H];
 #pragma unroll
@@ -1169,7 +1238,7 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
     v2f back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
       v2f sk, sm;
       td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
       if (EARLY) {
@@ -1215,8 +1284,10 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
       const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
       z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
     }
+    TD_STAMP(2);
 
     fft_inverse_t<R>(z, k, twr, tr);
+    TD_STAMP(3);
 
     // ---- synthesis window, register overlap-add, one finished hop-block of x_{t+1} and of z_{t+1} out
 #pragma unroll
@@ -1229,8 +1300,11 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
 #pragma unroll
       for (int i = 0; i < QU; ++i) {
         const v2f xv = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
-        xo[64u * i + ulane] = xv;
-        zo[64u * i + ulane] = v2f{fmaf(nlr, zold[i].x, xv.x), fmaf(nlr, zold[i].y, xv.y)};
+        const v2f zv = v2f{fmaf(nlr, zold[i].x, xv.x), fmaf(nlr, zold[i].y, xv.y)};
+        if (!(SPECINV_TD_ABLATE & 2) || zv.x == 1.2345e30f) {
+          xo[64u * i + ulane] = xv;
+          zo[64u * i + ulane] = zv;
+        }
       }
     }
 #pragma unroll
@@ -1239,7 +1313,15 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, 2) void k_fused4_td(FastArgs a) {
       acc[QU + i] = acc[2 * QU + i] + z[2 * QU + i];
       acc[2 * QU + i] = z[3 * QU + i];
     }
+    TD_STAMP(4);
   }
+#if SPECINV_TD_STAMPS
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.stamps[(long long)w * 8 + i] = stamp_sum[i];
+    a.stamps[(long long)w * 8 + 6] = (unsigned long long)(t_end - t_begin);
+  }
+#endif
   if (t_end == a.T) {
     // the chunk that holds the last frame also finishes hop-block T (frames T-3 .. T-1); xq[0] is z_t's block T by now
     const long long o0 = (long long)(a.T - 2) * HOP;
@@ -1394,11 +1476,11 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(F
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       // W_N^(lane + 64 j) = W_N^lane * W_{2R}^j
-      const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = add_conj(zk, zm);
       const v2f dd = sub_conj(zk, zm);
-      const v2f tw = cmul(mul_mi(wk), dd);                 // W * (-i (Zk - conj Zm))
+      const v2f tw = cmul_mi(wk, dd);                 // W * (-i (Zk - conj Zm))
       v2f xk = (e2 + tw) * half_scale;
       v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};   // conj(...)
       v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
@@ -1547,7 +1629,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
     v2f z[R], back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? wn : cmul(wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
       v2f ak = v2f{pp[j].x, pp[j].y} * a.inv_scale, am = v2f{pp[j].z, pp[j].w} * a.inv_scale;
       if (j == 0 && lane == 0) {
         ak.y = 0.0f;
@@ -2358,8 +2440,32 @@ struct FastState<float> {
     }
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
     fast::FastArgs args = a;
+#if SPECINV_TD_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) SI_HIP(hipMalloc(&d_stamps, (size_t)n_waves * 8 * sizeof(unsigned long long)));
+    args.stamps = d_stamps;
+#endif
     void* kargs[] = {&args};
     SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds_used, pl.stream));
+#if SPECINV_TD_STAMPS
+    if (td_t == 40 || td_t == 5) {
+      std::vector<unsigned long long> h((size_t)n_waves * 8);
+      SI_HIP(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      const char* names[6] = {"loads + window + slide", "forward FFT", "split / project / fold", "inverse FFT", "window + out + OLA", "loop"};
+      double tot[6] = {0}, frames = 0;
+      for (int wv = 0; wv < n_waves; ++wv) {
+        for (int i = 0; i < 6; ++i) tot[i] += (double)h[(size_t)wv * 8 + i];
+        frames += (double)h[(size_t)wv * 8 + 6];
+      }
+      fprintf(stderr, "k_fused4_td<%d, early=%d, eval=%d> iteration %d: cycles per frame (s_memtime, mean over %d waves)\n", R, (int)early, (int)ev, td_t, n_waves);
+      double all = 0;
+      for (int i = 0; i < 6; ++i) {
+        fprintf(stderr, "  %-24s %8.0f\n", names[i], tot[i] / frames);
+        all += tot[i] / frames;
+      }
+      fprintf(stderr, "  %-24s %8.0f\n", "frame", all);
+    }
+#endif
     return SPECINV_OK;
   }
 

@@ -92,10 +92,10 @@ __global__ __launch_bounds__(256) void k_fast_stft(FastXformArgs a) {
     const float hs = 0.5f * a.scale;
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = add_conj(zk, zm);
-      const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
+      const v2f tw = cmul_mi(wk, sub_conj(zk, zm));
       const int kk = lane + 64 * j;
       out[kk] = (e2 + tw) * hs;
       out[M - kk] = (e2 - tw) * v2f{hs, -hs};
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_fast_inverse_frames(FastXformArgs a) {
     v2f z[R], back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
       const int kk = lane + 64 * j;
       v2f ak = in[kk] * a.scale, am = in[M - kk] * a.scale;
       if (j == 0 && lane == 0) {
@@ -214,13 +214,13 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
   v2f back[H];
 #pragma unroll
   for (int j = 0; j < H; ++j) {
-    const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+    const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
     v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
     v2f ak, am;
     if (MODE != MODE_INIT) {
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = add_conj(zk, zm);
-      const v2f tw = cmul(mul_mi(wk), sub_conj(zk, zm));
+      const v2f tw = cmul_mi(wk, sub_conj(zk, zm));
       const v2f xk = (e2 + tw) * half_scale;
       const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
       v2f uk = v2f{0.0f, 0.0f}, um = v2f{0.0f, 0.0f}, sk = v2f{0.0f, 0.0f}, sm = v2f{0.0f, 0.0f};
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512, 1) void k_hop_inverse(HopInvArgs a) {
     v2f z[R], back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
       const int kk = lane + 64 * j;
       v2f ak = in[kk] * a.scale, am = in[M - kk] * a.scale;
       if (j == 0 && lane == 0) {

@@ -115,10 +115,10 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     for (int j = 0; j < H; ++j) {
       const v4f mm = mp[(j / 2) * 64u + ulane];
       const float mk = (j & 1) ? mm.z : mm.x, mq = (j & 1) ? mm.w : mm.y;
-      const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
       const v2f ak = v2f{mk * a.inv_scale, 0.0f}, am = v2f{mq * a.inv_scale, 0.0f};
       const v2f e2i = add_conj(ak, am);
-      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      const v2f o2i = cmulc_k(sub_conj(ak, am), wk);
       z[j] = add_i(e2i, o2i);
       back[j] = conj_sub_i(e2i, o2i);
     }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         for (int u = 0; u < R; ++u) z[u] = z[u] * win[64 * u + lane];
       }
 
-      fft_forward_t<R>(z, k, twr, tr);
+      fft_forward_t<R, false>(z, k, twr, tr);
 
       v2f rc[H];
 #pragma unroll
@@ -239,11 +239,11 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
       v2f back[H];
 #pragma unroll
       for (int j = 0; j < H; ++j) {
-        const v2f wk = j == 0 ? k.wn : cmul(k.wn, w64(j * (32 / R)));
+        const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
         const v2f zk = z[j], zm = rc[R - 1 - j - H];
         const v2f e2 = add_conj(zk, zm);
         const v2f dd = sub_conj(zk, zm);
-        const v2f tw = cmul(mul_mi(wk), dd);
+        const v2f tw = cmul_k(mul_mi(wk), dd);
         const v2f xk = (e2 + tw) * half_scale;
         const v2f xm = (e2 - tw) * v2f{half_scale, -half_scale};
         const v4f p = pre[j];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
           am.y = 0.0f;
         }
         const v2f e2i = add_conj(ak, am);
-        const v2f o2i = cmulc(sub_conj(ak, am), wk);
+        const v2f o2i = cmulc_k(sub_conj(ak, am), wk);
         z[j] = add_i(e2i, o2i);
         back[j] = conj_sub_i(e2i, o2i);
       }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
         z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
       }
-      fft_inverse_t<R>(z, k, twr, tr);
+      fft_inverse_t<R, false>(z, k, twr, tr);
 
       if (q == 0 && i >= la && it == a.max_iter - 1) {   // commit look-ahead slot 0 (methods.py:401-404)
         const v2f* w = reinterpret_cast<const v2f*>(a.window);
