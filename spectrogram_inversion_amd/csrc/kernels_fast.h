@@ -105,6 +105,60 @@ __device__ __forceinline__ v2f cmulc(v2f a, v2f b) {
 __device__ __forceinline__ v2f cconj(v2f a) { return v2f{a.x, -a.y}; }
 __device__ __forceinline__ v2f mul_i(v2f a) { return v2f{-a.y, a.x}; }    // a * (+i)
 __device__ __forceinline__ v2f mul_mi(v2f a) { return v2f{a.y, -a.x}; }   // a * (-i)
+// four products a_i <- a_i * b_i (CONJ: a_i * conj(b_i)) in one block: the four multiplies first, then the four dependent
+// multiply-adds, so that no instruction waits for the one issued just before it (the compiler has no latency model for inline
+// assembly and would leave each pair back to back)
+template <bool CONJ>
+__device__ __forceinline__ void cmul_x4(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f b0, v2f b1, v2f b2, v2f b3) {
+#if SPECINV_ASM_CMUL
+  v2f t0, t1, t2, t3;
+  if (!CONJ) {
+    asm("v_pk_mul_f32 %4, %0, %8 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %5, %1, %9 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %6, %2, %10 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %7, %3, %11 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %0, %8, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %1, %9, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %2, %2, %10, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %3, %3, %11, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+  } else {
+    asm("v_pk_mul_f32 %4, %0, %8 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %5, %1, %9 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %6, %2, %10 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %7, %3, %11 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %0, %8, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %1, %9, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %2, %10, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %3, %3, %11, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+  }
+#else
+  a0 = CONJ ? cmulc_k(a0, b0) : cmul_k(a0, b0);
+  a1 = CONJ ? cmulc_k(a1, b1) : cmul_k(a1, b1);
+  a2 = CONJ ? cmulc_k(a2, b2) : cmul_k(a2, b2);
+  a3 = CONJ ? cmulc_k(a3, b3) : cmul_k(a3, b3);
+#endif
+}
+// z[i] <- z[i] * w(i) for i = FIRST .. R-1 (R a multiple of 4, FIRST 0 or 1)
+template <int R, bool PK, bool CONJ, int FIRST, typename W>
+__device__ __forceinline__ void cmul_all(v2f (&z)[R], const W& w) {
+  if (PK) {
+#pragma unroll
+    for (int i = FIRST; i < 4; ++i) z[i] = CONJ ? cmulc(z[i], w(i)) : cmul(z[i], w(i));
+#pragma unroll
+    for (int g = 4; g < R; g += 4) cmul_x4<CONJ>(z[g], z[g + 1], z[g + 2], z[g + 3], w(g), w(g + 1), w(g + 2), w(g + 3));
+  } else {
+#pragma unroll
+    for (int i = FIRST; i < R; ++i) z[i] = CONJ ? cmulc_k(z[i], w(i)) : cmul_k(z[i], w(i));
+  }
+}
+struct SameW {
+  v2f w;
+  __device__ __forceinline__ v2f operator()(int) const { return w; }
+};
 template <bool PK>
 __device__ __forceinline__ v2f cmul_p(v2f a, v2f b) { return PK ? cmul(a, b) : cmul_k(a, b); }
 template <bool PK>
@@ -456,8 +510,7 @@ template <int R, bool PK, typename TW>
 __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr) {
   using G = Geo<R>;
   Dft<R, false>::run(z);
-#pragma unroll
-  for (int k1 = 1; k1 < R; ++k1) z[k1] = cmul_p<PK>(z[k1], tw(k1));
+  cmul_all<R, PK, false, 1>(z, tw);
   // cross-lane radix-C over v = lane / R; afterwards lane position v holds frequency digit k.kv
   if (G::C == 2) {
 #pragma unroll
@@ -488,8 +541,7 @@ __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k
       z[i] = v2f{fmaf(z[i].x, sg, p.x), fmaf(z[i].y, sg, p.y)};   // lower: a + p ; upper: p - a
     }
   }
-#pragma unroll
-  for (int i = 0; i < R; ++i) z[i] = cmul_p<PK>(z[i], k.post);
+  cmul_all<R, PK, false, 0>(z, SameW{k.post});
   // transpose n2 <-> k1 inside each group of R lanes (wave-private LDS, no barrier)
 #pragma unroll
   for (int i = 0; i < R; ++i) tr[k.tr_a + i * (R + 1)] = z[i];
@@ -506,7 +558,8 @@ __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k
 #pragma unroll
   for (int i = 0; i < R; ++i) tr[k.tr_b + i] = z[i];
 #pragma unroll
-  for (int i = 0; i < R; ++i) z[i] = cmulc_p<PK>(tr[k.tr_a + i * (R + 1)], k.post);
+  for (int i = 0; i < R; ++i) z[i] = tr[k.tr_a + i * (R + 1)];
+  cmul_all<R, PK, true, 0>(z, SameW{k.post});
   if (G::C == 2) {
 #pragma unroll
     for (int g = 0; g < R; g += 2) xlane_dft2(z[g], z[g + 1]);
@@ -534,8 +587,7 @@ __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k
 #pragma unroll
     for (int g = 0; g < R; g += 4) xlane_dft4<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
   }
-#pragma unroll
-  for (int k1 = 1; k1 < R; ++k1) z[k1] = cmulc_p<PK>(z[k1], tw(k1));
+  cmul_all<R, PK, true, 1>(z, tw);
   Dft<R, true>::run(z);
 }
 

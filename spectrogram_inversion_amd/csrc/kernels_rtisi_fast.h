@@ -16,6 +16,10 @@
 #pragma once
 #include "kernels_fast.h"
 
+#ifndef SPECINV_RTISI_PK      // complex products of the step loop's FFTs: 0 scalar (default: a lone wave per SIMD, see fft_forward_t), 1 packed
+#define SPECINV_RTISI_PK 0
+#endif
+
 namespace specinv {
 namespace fast {
 
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         for (int u = 0; u < R; ++u) z[u] = z[u] * win[64 * u + lane];
       }
 
-      fft_forward_t<R, false>(z, k, twr, tr);
+      fft_forward_t<R, SPECINV_RTISI_PK != 0>(z, k, twr, tr);
 
       v2f rc[H];
 #pragma unroll
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
         z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
       }
-      fft_inverse_t<R, false>(z, k, twr, tr);
+      fft_inverse_t<R, SPECINV_RTISI_PK != 0>(z, k, twr, tr);
 
       if (q == 0 && i >= la && it == a.max_iter - 1) {   // commit look-ahead slot 0 (methods.py:401-404)
         const v2f* w = reinterpret_cast<const v2f*>(a.window);
