@@ -1127,6 +1127,12 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
 #define TD_STAMP(i) do { } while (0)
 #endif
 
+template <bool FIRST, typename A, typename B>
+__device__ __forceinline__ const auto& td_pick(const A& a, const B& b) {
+  if constexpr (FIRST) return a;
+  else return b;
+}
+
 template <int R>
 __device__ __forceinline__ void td_split(v2f zk, v2f zm, v2f wk, float half_scale, v2f& xk, v2f& xm) {
   const v2f e2 = add_conj(zk, zm);
@@ -1142,7 +1148,7 @@ template <int R, bool EARLY, bool EVAL>
 #ifndef SPECINV_TD_ABLATE          // timing-only builds (wrong results): 1 target from frame 0 (L2-resident), 2 no output stores,
 #define SPECINV_TD_ABLATE 0        // 4 z samples from the first hop-blocks (L2-resident)
 #endif
-__global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused4_td(FastArgs a) {
+__global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused4_td(FastArgs a) {
   using G = Geo<R>;
   constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1177,9 +1183,16 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused
 #pragma unroll
   for (int i = 0; i < 3 * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
   double sd = 0.0, so = 0.0;
-  TwRegs<R> twr;
+  // pass-1 twiddles in registers - except in the variant that holds c0 and evaluates (one launch in ten of the first few
+  // iterations), which has no room for them at n_fft 2048 and reads the LDS table instead
+  constexpr bool TWLDS = (EARLY && EVAL && R >= 16) || SPECINV_TD_MINWAVES == 3;
+  TwRegs<TWLDS ? 2 : R> twr_regs;
+  if (!TWLDS) {
 #pragma unroll
-  for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = lds_tw1[(k1 - 1) * 64 + lane];
+    for (int k1 = 1; k1 < R; ++k1) twr_regs.w[(TWLDS ? 1 : k1) - 1] = lds_tw1[(k1 - 1) * 64 + lane];
+  }
+  const TwLds twr_lds{lds_tw1, lane};
+  const auto& twr = td_pick<TWLDS>(twr_lds, twr_regs);
 
   // samples of z_t: three hop-blocks carried from frame to frame plus the new one, fetched one frame ahead
   v2f xq[3][QU], xn[QU];
@@ -1207,16 +1220,18 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused
       const v4f* min_ = a.m_pairs + ((SPECINV_TD_ABLATE & 1) ? (long long)(fi & 255) : fi) * (H / 2 * 64);
 #pragma unroll
       for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]);
-      if (EARLY) {
-        const v4f* pin_ = a.P_in + fi * (H * 64);
-#pragma unroll
-        for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin_[j * 64u + ulane]);
-      }
       if (lane == 0) {
         mmid = a.m_mid[fi];
         if (EARLY) pmid = a.Pmid_in[fi];
       }
     }
+#define SPECINV_TD_C0_LOADS()                                                              \
+    if (EARLY) {                                                                           \
+      const v4f* pin_ = a.P_in + fi * (H * 64);                                            \
+      _Pragma("unroll") for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin_[j * 64u + ulane]); \
+    }
+    if (!EVAL) SPECINV_TD_C0_LOADS();      // (in flight during the forward FFT; the evaluating variant has no registers for
+                                           // them before its first transform is done)
 
     v2f z[R];
     if (EVAL) {
@@ -1237,6 +1252,9 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused
         const v2f own = z[(m + 1) % R];
         rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
       }
+      // a frame's 2 H + 1 terms per lane are summed in float32 (relative error 1e-7: the metric is compared to 1e-5), the
+      // frames in float64 - this kernel is bound by its vector instructions, float64 ones cost several each
+      float fd = 0.0f, fo = 0.0f;
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
@@ -1245,17 +1263,23 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused
         const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
         const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
         const float ok = fast_abs(xk), om = fast_abs(xm);
-        const double dk = (double)ok - (double)mk, dm = (double)om - (double)mq;
-        sd += dk * dk + dm * dm;
-        so += (double)ok * (double)ok + (double)om * (double)om;
+        const float dk = ok - mk, dm = om - mq;
+        fd = fmaf(dk, dk, fmaf(dm, dm, fd));
+        fo = fmaf(ok, ok, fmaf(om, om, fo));
       }
       if (lane == 0) {
         const float o = fast_abs(z[H] * v2f{a.fwd_scale, -a.fwd_scale});
-        const double d = (double)o - (double)mmid;
-        sd += d * d;
-        so += (double)o * (double)o;
+        const float d = o - mmid;
+        fd = fmaf(d, d, fd);
+        fo = fmaf(o, o, fo);
       }
+      sd += (double)fd;
+      so += (double)fo;
+      asm volatile("" ::: "memory");       // (keeps the scheduler from hoisting the loads into the transform above)
+      __builtin_amdgcn_sched_barrier(0);
+      SPECINV_TD_C0_LOADS();
     }
+#undef SPECINV_TD_C0_LOADS
 
     // ---- analysis of z_t's frame; its oldest hop-block is the one this frame's output block needs
     v2f zold[QU];
@@ -2190,7 +2214,8 @@ struct FastState<float> {
     // one round) instead of 32 chunks (3072 waves, two rounds).  A chunk boundary costs OV - 1 split hop-blocks, and the
     // reflected edge samples must not fall on split blocks (first / last chunk long enough): chunks of >= 8 (16) frames.
     const int floor_ch = OV == 8 ? 16 : 8;
-    const long long slots = 1024LL * (R >= 32 ? 1 : R <= 4 ? 3 : 2);
+    long long slots = 1024LL * (R >= 32 ? 1 : R <= 4 ? 3 : 2);
+    if (const char* e = getenv("SPECINV_FUSED_SLOTS")) slots = atoll(e);      // (experiments: wave slots of the chip)
     int best_nch = 1;
     double best_cost = 1e300;
     for (int nch = 1; nch <= std::max(1, cfg.n_frames / floor_ch); ++nch) {
@@ -2436,6 +2461,7 @@ struct FastState<float> {
   // waves per workgroup of the fused iteration kernel: k_fused4 takes 8-wave workgroups (one per CU) once every wave
   // slot is filled; fewer waves than slots: smaller workgroups reach more CUs
   int fused_wgw() const {
+    if (const char* e = getenv("SPECINV_FUSED_WGW")) return atoi(e);           // (experiments)
     if ((R == 8 || R == 16) && OV == 4 && !use_template) return n_waves >= 2048 ? SPECINV_WGW : 4;
     return 4;
   }

@@ -26,15 +26,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     print(json.dumps(best))
     sys.exit(0)
 n_fft = sys.argv[1]
-libs = [os.path.join(ROOT, "spectrogram_inversion_amd", "libspecinv.so")] + [os.path.abspath(v) for v in sys.argv[2:]]
+libs = [os.path.join(ROOT, "spectrogram_inversion_amd", "libspecinv.so")] + sys.argv[2:]      # "lib.so" or "lib.so:ENV=V,ENV=V"
 res = {l: [] for l in libs}
 for rnd in range(3):
     for l in libs:
-        env = dict(os.environ, SPECINV_LIB=l)
+        path, _, extra = l.partition(":")
+        env = dict(os.environ, SPECINV_LIB=os.path.abspath(path))
+        for kv in filter(None, extra.split(",")):
+            env[kv.split("=")[0]] = kv.split("=")[1]
         out = subprocess.run([sys.executable, __file__, "--child", n_fft], env=env, capture_output=True, text=True)
         try:
             res[l].append(float(out.stdout.strip().splitlines()[-1]))
         except Exception:
             print(out.stderr[-500:])
 for l in libs:
-    print(f"{os.path.basename(l):28s} " + " ".join(f"{v:.4f}" for v in res[l]), flush=True)
+    print(f"{os.path.basename(l):60s} " + " ".join(f"{v:.4f}" for v in res[l]), flush=True)
