@@ -110,7 +110,7 @@ int specinv_plan_force_generic(specinv_plan* plan, int on);
  * 1: ADMM - the last iteration of every specinv_admm_iterate call (and specinv_admm_init) also leaves X and U behind for
  * specinv_get_state_spec; Griffin-Lim - the iteration runs on pre_spec itself (the spectral-state kernel).
  * 0 (default): asking for X / U / pre_spec after an iteration is SPECINV_ESTATE.  Call before specinv_*_init.
- * (The generic kernels, the frame kernels and the other hops keep pre_spec / can always produce X and U.) */
+ * (The generic kernels keep X and U anyway; every Griffin-Lim kernel other than k_fused4_td keeps pre_spec.) */
 int specinv_plan_keep_state(specinv_plan* plan, int on);
 
 /* ---- building blocks ------------------------------------------------------------------ */

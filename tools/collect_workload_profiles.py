@@ -8,7 +8,8 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 DOMINANT = {
-    "C2": ["specinv::fast::k_fused4<16, 0, false>", "specinv::fast::k_fused4<16, 0, true>", "specinv::fast::k_phase_init_pairs<16>"],
+    "C2": ["specinv::fast::k_fused4_td<16, false, false>", "specinv::fast::k_fused4_td<16, true, false>",
+           "specinv::fast::k_fused4_td<16, false, true>", "specinv::fast::k_phase_init_pairs<16>"],
     "C4": ["specinv::fast::k_fused4<8, 1, false>", "specinv::fast::k_fused4<8, 1, true>"],
     "C3": ["specinv::fast::k_rtisi_fast<16, 256, 4>"],
     "C5": ["specinv::fast::k_objective_logmel<16, 5, false>", "specinv::k_lincomb<float>", "specinv::k_lbfgs_pair_stats<float>",
