@@ -1012,6 +1012,94 @@ inline int obj_mel_tiles(int n_mels) {
   return mt <= 3 ? 3 : mt <= 4 ? 4 : mt <= 5 ? 5 : mt <= 8 ? 8 : 0;
 }
 
+// What follows k_objective_logmel, in ONE launch (three small kernels before: ~8 us of a 0.16 ms evaluation):
+//   * chunk seams: grad[n] += the previous tile's tail over the first n_fft - hop samples of tiles 1.. (k_hop_tails_raw),
+//   * fold of the padded margins onto the signal (k_grad_fold_margins with `margins` given),
+//   * loss = scale * sum(partials), summed like k_finish_scaled by the last block.
+// A margin sample that also lies in a seam region is finished by its margin thread (own + tail first, then the fold: the order
+// of the separate launches); the seam threads leave those samples alone, so no two threads touch the same sample.
+__global__ void k_objective_epilogue(float* __restrict__ grad, const float* __restrict__ xtail, const float* __restrict__ margins,
+                                     const double* __restrict__ part, double* __restrict__ slot, int T, int nchunks, int n_fft, int hop,
+                                     int keep, int pad, int pad_mode, int64_t len, int64_t rows, int64_t n_tail, int64_t n_margin,
+                                     int n_part, double scale) {
+  const int64_t tail_blocks = (n_tail + 255) / 256, margin_blocks = (n_margin + 255) / 256;
+  const bool fold = pad > 0 && pad_mode != SPECINV_PAD_CONSTANT;
+  const int64_t covered = (int64_t)(T - 1) * hop + n_fft;                // padded positions that receive any frame
+  if ((int64_t)blockIdx.x < tail_blocks) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // (b, c - 1, j)
+    if (i >= n_tail) return;
+    const int j = (int)(i % keep);
+    const int c = (int)((i / keep) % (nchunks - 1)) + 1;
+    const int64_t b = i / ((int64_t)keep * (nchunks - 1));
+    const int64_t n = (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+    if (n < 0 || n >= len) return;
+    if (fold && (n <= pad || n >= len - 1 - pad)) return;                 // finished by the margin thread of this sample
+    grad[b * len + n] += xtail[(b * nchunks + (c - 1)) * keep + j];
+    return;
+  }
+  if ((int64_t)blockIdx.x < tail_blocks + margin_blocks) {
+    const int64_t per_row = 2 * ((int64_t)pad + 1);
+    const int64_t i = ((int64_t)blockIdx.x - tail_blocks) * 256 + threadIdx.x;
+    if (i >= n_margin) return;
+    const int64_t bi = i / per_row, j = i - bi * per_row;
+    int64_t n;
+    if (j <= pad) {
+      n = j;                                            // left stretch 0 .. pad
+      if (n >= len) return;
+    } else {
+      n = len - 1 - pad + (j - pad - 1);                // right stretch len-1-pad .. len-1
+      if (n <= pad || n >= len) return;                 // (short signals: already covered by the left stretch)
+    }
+    const float* mg = margins + bi * 2 * pad;
+    auto at = [&](int64_t np) -> float {                // gradient w.r.t. padded sample np
+      if (np < 0 || np >= covered) return 0.0f;
+      if (np < pad) return mg[np];
+      const int64_t r = np - pad - len;
+      return (r >= 0 && r < pad) ? mg[pad + r] : 0.0f;
+    };
+    float g = 0;
+    switch (pad_mode) {
+      case SPECINV_PAD_REFLECT:
+        if (n >= 1 && n <= pad) g += at(pad - n);
+        if (n <= len - 2 && n >= len - 1 - pad) g += at(pad + len + (len - 2 - n));
+        break;
+      case SPECINV_PAD_REPLICATE:
+        if (n == 0)
+          for (int64_t q = 0; q < pad; ++q) g += at(q);
+        if (n == len - 1)
+          for (int64_t q = 0; q < pad; ++q) g += at(pad + len + q);
+        break;
+      case SPECINV_PAD_CIRCULAR:
+        if (n >= len - pad) g += at(n - (len - pad));
+        if (n < pad) g += at(pad + len + n);
+        break;
+      default:
+        break;
+    }
+    float v = grad[bi * len + n];
+    if (keep > 0 && nchunks > 1) {
+      // the seam this sample may lie in: the first n_fft - hop padded positions of the tile that holds frame (n + pad) / hop
+      // (at most one seam: tiles are longer than a frame)
+      int64_t f0 = (n + pad) / hop;
+      if (f0 > T - 1) f0 = T - 1;
+      int c = (int)(((f0 + 1) * nchunks - 1) / T);      // largest c with c * T / nchunks <= f0, up to rounding: corrected below
+      while (c + 1 < nchunks && fast::hop_chunk_begin(c + 1, T, nchunks) <= f0) ++c;
+      while (c > 0 && fast::hop_chunk_begin(c, T, nchunks) > f0) --c;
+      if (c >= 1) {
+        const int64_t j0 = n + pad - (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop;
+        if (j0 >= 0 && j0 < keep) v += xtail[(bi * nchunks + (c - 1)) * keep + j0];
+      }
+    }
+    grad[bi * len + n] = v + g;
+    return;
+  }
+  __shared__ double red[16];
+  double sacc = 0;
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) sacc += part[i];
+  const double t = block_sum(sacc, red);
+  if (threadIdx.x == 0) *slot = scale * t;
+}
+
 // loss = sum(partials) / numel, to the host (synchronises) or to a device scalar (nothing waits)
 template <typename P>
 int tf_finish_loss(P& pl, int64_t n_part, double numel, double* loss_host, double* loss_dev) {
@@ -1113,15 +1201,22 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     }
   }
 #endif
-  if (nch > 1 && keep > 0) {
-    const long long total = (long long)B * (nch - 1) * keep;
-    hipLaunchKernelGGL(fast::k_hop_tails_raw, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, grad,
-                       (const float*)a.xtail, T, nch, hop, keep, pad, (long long)len, total);
+  *used = true;
+  {
+    const bool fold = pad > 0 && pl.cfg.pad_mode != SPECINV_PAD_CONSTANT;
+    const int64_t n_tail = (nch > 1 && keep > 0) ? (int64_t)B * (nch - 1) * keep : 0;
+    const int64_t n_margin = fold ? (int64_t)B * 2 * (pad + 1) : 0;
+    const int64_t blocks = ceil_div(n_tail, 256) + ceil_div(n_margin, 256) + 1;
+    double* slot = loss_dev ? loss_dev : pl.sums.template as<double>();
+    hipLaunchKernelGGL(k_objective_epilogue, dim3((unsigned)blocks), dim3(256), 0, pl.stream, grad, (const float*)a.xtail,
+                       (const float*)a.margins, (const double*)pl.partials.template as<double>(), slot, T, nch, N, hop, keep,
+                       pad, pl.cfg.pad_mode, (int64_t)len, (int64_t)B, n_tail, n_margin, (int)n_tiles, 1.0 / numel);
     SI_HIP(hipGetLastError());
   }
-  SI_TRY(pl.launch_grad_fold(nullptr, grad, len, a.margins));
-  *used = true;
-  return tf_finish_loss(pl, n_tiles, numel, loss, loss_dev);
+  if (loss_dev) return SPECINV_OK;
+  SI_HIP(hipMemcpyAsync(loss, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+  SI_HIP(si_stream_wait_short(pl.stream));
+  return SPECINV_OK;
 }
 
 template <typename P, typename T>
