@@ -222,6 +222,10 @@ int specinv_vec_multi_dot(specinv_plan* plan, const void* g, const void* const* 
                           double* out_host);
 int specinv_vec_lincomb(specinv_plan* plan, const void* const* vecs_host, const double* coef_host, int k, int64_t n,
                         void* out);
+/* The same, and the step x += t * out in the same pass (torch.optim.LBFGS.step: "p.add_(d, alpha=t)" right after the
+ * direction): out is rounded first, x then takes fma(t, out, x) - what a separate specinv_vec_axpy would compute. */
+int specinv_vec_lincomb_step(specinv_plan* plan, const void* const* vecs_host, const double* coef_host, int k, int64_t n,
+                             void* out, double t, void* x);
 /* The whole L-BFGS two-loop recursion d = -H g on the device (torch.optim.LBFGS.step's "compute the approximate
  * inverse Hessian multiplied by the gradient"): s_list_host / y_list_host are HOST arrays of m device pointers
  * (old_stps / old_dirs, oldest first), rho_host[m] = 1 / (y_i . s_i).  All 2m dot products stay on the device

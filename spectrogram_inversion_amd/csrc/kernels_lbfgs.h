@@ -456,8 +456,10 @@ __global__ void k_multi_finish(const double* __restrict__ part, int nb, double* 
 
 // out[e] = (accumulate ? out[e] : 0) + sum_j c_j * v_j[e], summed in float64 in the order of j, rounded once; one
 // 16-byte piece per thread (the trailing n % W elements by the last thread)
+// With `xs` given the same pass also takes the step xs += t * out (the rounded direction: what k_axpy would read back).
 template <typename T>
-__global__ __launch_bounds__(256) void k_lincomb(MultiVecArgs<T> a, int accumulate, T* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(256) void k_lincomb(MultiVecArgs<T> a, int accumulate, T* __restrict__ out, int64_t n,
+                                                 T t = T(0), T* __restrict__ xs = nullptr) {
   constexpr int W = 16 / sizeof(T);
   typedef T VT __attribute__((ext_vector_type(W)));
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -477,11 +479,18 @@ __global__ __launch_bounds__(256) void k_lincomb(MultiVecArgs<T> a, int accumula
 #pragma unroll
     for (int c = 0; c < W; ++c) r[c] = (T)s[c];
     reinterpret_cast<VT*>(out)[i] = r;
+    if (xs != nullptr) {
+      VT xv = reinterpret_cast<const VT*>(xs)[i];
+#pragma unroll
+      for (int c = 0; c < W; ++c) xv[c] = fma(t, r[c], xv[c]);
+      reinterpret_cast<VT*>(xs)[i] = xv;
+    }
   } else if (i == nv) {
     for (int64_t e = nv * W; e < n; ++e) {
       double s = accumulate ? (double)out[e] : 0.0;
       for (int j = 0; j < a.k; ++j) s += a.c[j] * (double)a.v[j][e];
       out[e] = (T)s;
+      if (xs != nullptr) xs[e] = fma(t, (T)s, xs[e]);
     }
   }
 }
@@ -513,9 +522,10 @@ int lb_multi_dot(P& pl, const T* g, const void* const* vecs, int k, int64_t n, d
 }
 
 template <typename P, typename T>
-int lb_lincomb(P& pl, const void* const* vecs, const double* coef, int k, int64_t n, T* out) {
+int lb_lincomb(P& pl, const void* const* vecs, const double* coef, int k, int64_t n, T* out, double t = 0.0, T* xs = nullptr) {
   SI_CHECK(vecs && coef && out && k > 0 && n > 0, SPECINV_EINVAL, "bad arguments");
   SI_CHECK(((uintptr_t)out & 15) == 0, SPECINV_EINVAL, "out is not 16-byte aligned");
+  SI_CHECK(xs == nullptr || ((uintptr_t)xs & 15) == 0, SPECINV_EINVAL, "x is not 16-byte aligned");
   for (int j0 = 0; j0 < k; j0 += kMultiVec) {
     MultiVecArgs<T> a{};
     a.k = std::min(kMultiVec, k - j0);
@@ -526,7 +536,9 @@ int lb_lincomb(P& pl, const void* const* vecs, const double* coef, int k, int64_
       a.c[j] = coef[j0 + j];
     }
     const int64_t pieces = n / (16 / (int64_t)sizeof(T)) + 1;      // + the thread that takes the trailing elements
-    hipLaunchKernelGGL((k_lincomb<T>), dim3((unsigned)ceil_div(pieces, 256)), dim3(256), 0, pl.stream, a, j0 > 0 ? 1 : 0, out, n);
+    const bool last = j0 + kMultiVec >= k;                         // the step rides on the launch that completes the sum
+    hipLaunchKernelGGL((k_lincomb<T>), dim3((unsigned)ceil_div(pieces, 256)), dim3(256), 0, pl.stream, a, j0 > 0 ? 1 : 0, out, n,
+                       (T)t, last ? xs : nullptr);
     SI_HIP(hipGetLastError());
   }
   return SPECINV_OK;

@@ -77,6 +77,7 @@ struct PlanBase {
                               int m, double h_diag, void* d_out, int64_t n) = 0;
   virtual int vec_multi_dot(const void* g, const void* const* vecs, int k, int64_t n, double* out, double* out_dev = nullptr) = 0;
   virtual int vec_lincomb(const void* const* vecs, const double* coef, int k, int64_t n, void* out) = 0;
+  virtual int vec_lincomb_step(const void* const* vecs, const double* coef, int k, int64_t n, void* out, double t, void* x) = 0;
   virtual int lbfgs_pair(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n, double* out,
                          double* out_dev = nullptr) = 0;
   virtual int lbfgs_stats(const void* g, const void* d, int64_t n, double* out, double* out_dev = nullptr) = 0;

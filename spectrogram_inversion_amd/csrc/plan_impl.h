@@ -716,6 +716,10 @@ struct PlanT final : PlanBase {
   int vec_multi_dot(const void* g, const void* const* vecs, int k, int64_t n, double* out, double* out_dev) override {
     return lb_multi_dot(*this, static_cast<const T*>(g), vecs, k, n, out, out_dev);
   }
+  int vec_lincomb_step(const void* const* vecs, const double* coef, int k, int64_t n, void* out, double t, void* xs) override {
+    SI_CHECK(xs != nullptr, SPECINV_EINVAL, "null pointer");
+    return lb_lincomb(*this, vecs, coef, k, n, static_cast<T*>(out), t, static_cast<T*>(xs));
+  }
   int vec_lincomb(const void* const* vecs, const double* coef, int k, int64_t n, void* out) override {
     return lb_lincomb(*this, vecs, coef, k, n, static_cast<T*>(out));
   }

@@ -384,6 +384,11 @@ int specinv_vec_lincomb(specinv_plan* plan, const void* const* vecs_host, const 
   ENTER(plan);
   return plan->impl->vec_lincomb(vecs_host, coef_host, k, n, out);
 }
+int specinv_vec_lincomb_step(specinv_plan* plan, const void* const* vecs_host, const double* coef_host, int k, int64_t n,
+                             void* out, double t, void* x) {
+  ENTER(plan);
+  return plan->impl->vec_lincomb_step(vecs_host, coef_host, k, n, out, t, x);
+}
 
 int specinv_lbfgs_direction(specinv_plan* plan, const void* g, const void* const* s_list_host,
                             const void* const* y_list_host, const double* rho_host, int m, double h_diag, void* d_out,

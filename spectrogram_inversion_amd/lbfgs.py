@@ -50,6 +50,13 @@ class HipVecOps:
     def lincomb(self, vecs, coefs):
         return self.plan.vec_lincomb(vecs, coefs)
 
+    def lincomb_step(self, vecs, coefs, t, x):
+        if x.data_ptr() % 16 != 0 or not x.is_contiguous():      # (a view at an odd offset: two passes)
+            d = self.plan.vec_lincomb(vecs, coefs)
+            self.axpy(t, d, x)
+            return d
+        return self.plan.vec_lincomb_step(vecs, coefs, t, x)
+
     def pair(self, g, g_prev, d, t):
         return self.plan.lbfgs_pair(g, g_prev, d, t)
 
@@ -347,10 +354,14 @@ class LBFGS:
             self.prev_grad = g
             self.prev_loss = loss
             t = min(1.0, 1.0 / b["g_abssum"]) * self.lr if self.total_iters == 1 else self.lr
-            d = ops.scaled(-1.0, g) if vecs is None else ops.lincomb(vecs, coefs)
             if gtd > -self.tol_change:
+                d = ops.scaled(-1.0, g) if vecs is None else ops.lincomb(vecs, coefs)
                 break
-            ops.axpy(t, d, x)
+            if hasattr(ops, "lincomb_step"):                   # direction and step in one pass over the vectors
+                d = ops.lincomb_step([g] if vecs is None else vecs, [-1.0] if vecs is None else coefs, t, x)
+            else:
+                d = ops.scaled(-1.0, g) if vecs is None else ops.lincomb(vecs, coefs)
+                ops.axpy(t, d, x)
             ls_evals = 0
             opt = False
             if n_iter != self.max_iter:

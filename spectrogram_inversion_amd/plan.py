@@ -459,6 +459,18 @@ class Plan:
         _lib.check(self.lib.specinv_vec_lincomb(self._h, vp, cf, k, out.numel(), out.data_ptr()))
         return out
 
+    def vec_lincomb_step(self, vecs, coefs, t, x):
+        """d = sum_j coefs[j] * vecs[j] and x += t * d in one pass; returns d."""
+        self._sync_stream()
+        assert x.is_contiguous() and x.data_ptr() % 16 == 0
+        k = len(vecs)
+        out = torch.empty_like(vecs[0])
+        vecs = [v if v.data_ptr() % 16 == 0 else v.clone() for v in vecs]
+        vp = (C.c_void_p * k)(*[v.data_ptr() for v in vecs])
+        cf = (C.c_double * k)(*[float(c) for c in coefs])
+        _lib.check(self.lib.specinv_vec_lincomb_step(self._h, vp, cf, k, out.numel(), out.data_ptr(), float(t), x.data_ptr()))
+        return out
+
     def lbfgs_pair(self, g, g_prev, d, t):
         """y = g - g_prev, s = t*d in one pass; returns (y, s, y.s, y.y)."""
         self._sync_stream()

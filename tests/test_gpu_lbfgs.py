@@ -399,3 +399,52 @@ def test_one_launch_magnitude_objective(monkeypatch, n_fft, hop, frames, batch, 
     lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
     assert abs(lf - lo) < 1e-5 * abs(lo), (lf, lo)
     assert rel_l2(gf, go) < 1e-5, rel_l2(gf, go)
+
+
+@pytest.mark.parametrize("n", [1000, 100003, 2048 * 1024 + 5, 8388608])
+def test_pair_statistics_pass(n):
+    """`k_lbfgs_pair_stats`: y, s and the eight scalars of an L-BFGS iteration in one pass over g, g_prev, d (+ a one-workgroup
+    reduction of the per-block sums in block order).  Against float64 NumPy, against the separate pair pass, and 50 launches in a
+    row bit for bit.  (Letting the last workgroup to finish do that reduction - no second launch - was tried: the agent-scope
+    release / acquire it needs costs 25 us per launch in L2 write-backs, against the 7 us of the second kernel.)"""
+    ops = HipVecOps(torch.float32, dev())
+    rng = np.random.default_rng(n)
+    g, gp, d = (T(rng.standard_normal(n).astype(np.float32)) for _ in range(3))
+    t = 0.37
+    board = torch.zeros(16, dtype=torch.float64, device=dev())
+    first = None
+    for rep in range(50):
+        y, s = ops.plan.lbfgs_pair_stats_dev(g, gp, d, t, board.data_ptr())
+        vals = np.array(ops.plan.read_doubles(board.data_ptr(), 8))
+        if first is None:
+            first = (vals, y.clone(), s.clone())
+        else:
+            assert np.array_equal(vals, first[0]), rep
+    assert torch.equal(y, first[1]) and torch.equal(s, first[2])
+    g64, gp64, d64 = (N(v).astype(np.float64) for v in (g, gp, d))
+    y64, s64 = N(y).astype(np.float64), N(s).astype(np.float64)
+    want = [g64 @ d64, np.abs(g64).sum(), np.abs(g64).max(), np.abs(d64).max(), y64 @ s64, y64 @ y64, g64 @ g64, g64 @ gp64]
+    np.testing.assert_allclose(first[0], want, rtol=1e-12, atol=1e-9)
+    y2, s2, ys, yy = ops.pair(g, gp, d, t)
+    assert torch.equal(y, y2) and torch.equal(s, s2)
+    np.testing.assert_allclose([ys, yy], first[0][4:6], rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("k,n", [(1, 1003), (5, 100003), (70, 50000)])
+def test_direction_and_step_in_one_pass(k, n, dtype):
+    """`specinv_vec_lincomb_step`: d = sum c_j v_j and x += t d in the pass that completes the sum (more than 64 vectors: the last
+    launch): the same d and the same x, bit for bit, as `lincomb` followed by `axpy`."""
+    ops = HipVecOps(dtype, dev())
+    rng = np.random.default_rng(k + n)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    tv = [T(rng.standard_normal(n).astype(npdt)) for _ in range(k)]
+    coef = rng.standard_normal(k)
+    x0 = T(rng.standard_normal(n).astype(npdt))
+    t = 0.8125
+    d_ref = ops.lincomb(tv, coef)
+    x_ref = x0.clone()
+    ops.axpy(t, d_ref, x_ref)
+    x = x0.clone()
+    d = ops.lincomb_step(tv, coef, t, x)
+    assert torch.equal(d, d_ref) and torch.equal(x, x_ref)
