@@ -44,14 +44,15 @@ def bench_mag(batch, n_freq, frames, seed=1234):
 
 
 # ---- C2: griffin_lim B=64 n_fft=2048 hop=512 T=1024 alpha=0.3 (the headline) ------------------------------------------
-def test_c2_headline_geometry_vs_oracle_and_float64():
+@pytest.mark.parametrize("kernel", ["k_fused4_td", "k_fused4"])
+def test_c2_headline_geometry_vs_oracle_and_float64(kernel):
+    """`k_fused4_td` is what `bench.py` runs (momentum carried as a signal); `k_fused4` iterates on pre_spec itself (what a caller
+    gets after `keep_state`).  Both on the headline geometry.  30 iterations at alpha = 0.3 take `k_fused4_td` through its early
+    launches (c0 term, 15 iterations), the late ones and both evaluating variants (iterations 10 and 30)."""
     n_fft, hop, frames, batch, alpha = 2048, 512, 1024, 64, 0.3
     mag_np = bench_mag(batch, n_fft // 2 + 1, frames)
     mag = torch.from_numpy(mag_np).to(DEV)
     p32 = make_plan(n_fft, hop, frames, batch)
-    geo = p32.launch_geometry
-    # the geometry of the headline number: one 8-wave workgroup per CU, 2048 waves of 32 frames
-    assert geo == {"waves_per_workgroup": 8, "chunks": 32, "waves": 2048, "kernel": "k_fused4"}, geo
     w = hann(n_fft)
     items = [0, 31, 63]
     # phase_init at full size: the three items against the oracle (<= 4 ulp of the magnitude, like g1)
@@ -59,9 +60,14 @@ def test_c2_headline_geometry_vs_oracle_and_float64():
     c0_ref = oracle.phase_init(mag_np[items], hop_length=hop, window=w)
     err = np.abs(N(c0[items]) - c0_ref).max()
     assert err <= 4 * np.finfo(np.float32).eps * np.abs(c0_ref).max(), err
-    # 10 iterations from the same starting spectrum: waveform rel-L2 <= 1e-4 (the north-star bar)
+    p32.keep_state(kernel == "k_fused4")
     p32.gla_init(c0, None, alpha)
-    p32.iterate(10)
+    # the geometry of the headline number: one 8-wave workgroup per CU, 2048 waves of 32 frames
+    geo = p32.launch_geometry
+    assert geo == {"waves_per_workgroup": 8, "chunks": 32, "waves": 2048, "kernel": kernel}, geo
+    # 10 iterations from the same starting spectrum: waveform rel-L2 <= 1e-4 (the north-star bar)
+    p32.iterate(9)
+    s32_10 = p32.iterate(1, eval_last=True)
     y10 = N(p32.wave()[items])
     ref = oracle.griffin_lim(N(c0[items]), max_iter=10, alpha=alpha, tol=0, hop_length=hop, window=w)
     for k, it in enumerate(items):
@@ -74,15 +80,18 @@ def test_c2_headline_geometry_vs_oracle_and_float64():
     p64 = make_plan(n_fft, hop, frames, batch, torch.float64)
     assert p64.path == "generic"
     p64.gla_init(c0.to(torch.complex128), None, alpha)
-    s64 = p64.iterate(30, eval_last=True)
+    s64_10 = p64.iterate(10, eval_last=True)
+    s64 = p64.iterate(20, eval_last=True)
     y64 = N(p64.wave())
     assert abs(sc_lin(s32) - sc_lin(s64)) < 1e-5, (sc_lin(s32), sc_lin(s64))
+    assert abs(sc_lin(s32_10) - sc_lin(s64_10)) < 1e-5, (sc_lin(s32_10), sc_lin(s64_10))
     for b in range(batch):
         seg = segment_errors(y32[b], y64[b], hop)
         assert np.median(seg) < 1e-4, (b, np.median(seg))
         assert rel_l2(y32[b], y64[b]) < 2e-3, (b, rel_l2(y32[b], y64[b]))
-    # the evaluating launch (EVAL instantiation, 8-wave geometry too): its sums against the float64 run
+    # the evaluating launches (8-wave geometry too): their sums against the float64 run
     np.testing.assert_allclose(s32[:3], s64[:3], rtol=2e-5)
+    np.testing.assert_allclose(s32_10[:3], s64_10[:3], rtol=2e-5)
 
 
 # ---- C4 shard: ADMM B=32 n_fft=1024 hop=256 T=2048 rho=0.1 ------------------------------------------------------------
