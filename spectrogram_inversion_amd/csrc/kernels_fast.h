@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(F
   }
 }
 
-// ---- Griffin-Lim with the momentum carried in the time domain (hop = n_fft/4, n_fft 1024 / 2048) -------------------------
+// ---- Griffin-Lim with the momentum carried in the time domain (every fused shape: hop = n_fft/2, /4, /8) ---------------------
 // methods.py:243-244 keep pre_t = STFT(x_t) - lr * pre_{t-1}, a (B, F, T) complex array read and written every iteration
 // (16 F of the 8 hop + 20 F bytes a frame-iteration moves).  The STFT (padding included) is linear, so
 //     pre_t = STFT(z_t) + (-lr)^t * c0,     z_t = x_t - lr * z_{t-1},  z_0 = 0,
@@ -1141,16 +1141,26 @@ __device__ __forceinline__ void td_split(v2f zk, v2f zm, v2f wk, float half_scal
   xm = (e2 - tw) * v2f{half_scale, -half_scale};
 }
 
-template <int R, bool EARLY, bool EVAL>
+// one hop-block of the sample window (the tuned n_fft/4 copy of the loader where it applies)
+template <int R, int OV>
+__device__ __forceinline__ void td_load_block(const float* __restrict__ xrow, const float* __restrict__ tailrow, long long L,
+                                              int T, int c, int t_begin, int t_end, int j, int lane, int pad_mode,
+                                              v2f (&q)[R / OV]) {
+  if constexpr (OV == 4) load_block4<R>(xrow, tailrow, L, T, c, t_begin, t_end, j, lane, pad_mode, q);
+  else load_block<R, OV>(xrow, tailrow, L, T, c, t_begin, t_end, j, lane, pad_mode, q);
+}
+
 #ifndef SPECINV_TD_MINWAVES
 #define SPECINV_TD_MINWAVES 2
 #endif
 #ifndef SPECINV_TD_ABLATE          // timing-only builds (wrong results): 1 target from frame 0 (L2-resident), 2 no output stores,
 #define SPECINV_TD_ABLATE 0        // 4 z samples from the first hop-blocks (L2-resident)
 #endif
-__global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused4_td(FastArgs a) {
+template <int R, int OV, bool EARLY, bool EVAL>
+__device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   using G = Geo<R>;
-  constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
+  using O = Ovl<R, OV>;
+  constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v2f* lds_win = reinterpret_cast<v2f*>(smem);
   v2f* lds_tw1 = lds_win + M;
@@ -1173,15 +1183,15 @@ __global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, 
   const int t_begin = chunk_begin(c, a.T, a.nchunks);
   const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
   const float* zrow = a.x_in + (long long)b * a.L;
-  const float* tailrow = a.xtail_in + (long long)b * a.nchunks * 3 * HOP;
+  const float* tailrow = a.xtail_in + (long long)b * a.nchunks * NB * HOP;
   float* zorow = a.x_out + (long long)b * a.L;
   float* xorow = a.x2_out + (long long)b * a.L;
   const float half_scale = 0.5f * a.fwd_scale;
   const float nlr = -a.coef;
 
-  v2f acc[3 * QU];
+  v2f acc[NB * QU];
 #pragma unroll
-  for (int i = 0; i < 3 * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
+  for (int i = 0; i < NB * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
   double sd = 0.0, so = 0.0;
   // pass-1 twiddles in registers - except in the variant that holds c0 and evaluates (one launch in ten of the first few
   // iterations), which has no room for them at n_fft 2048 and reads the LDS table instead
@@ -1195,11 +1205,11 @@ __global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, 
   const auto& twr = td_pick<TWLDS>(twr_lds, twr_regs);
 
   // samples of z_t: three hop-blocks carried from frame to frame plus the new one, fetched one frame ahead
-  v2f xq[3][QU], xn[QU];
-  load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin, lane, a.pad_mode, xq[0]);
-  load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + 1, lane, a.pad_mode, xq[1]);
-  load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + 2, lane, a.pad_mode, xq[2]);
-  load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + 3, lane, a.pad_mode, xn);
+  v2f xq[NB][QU], xn[QU];
+#pragma unroll
+  for (int q = 0; q < NB; ++q)
+    td_load_block<R, OV>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + q, lane, a.pad_mode, xq[q]);
+  td_load_block<R, OV>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + NB, lane, a.pad_mode, xn);
 
 #if SPECINV_TD_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1238,9 +1248,9 @@ __global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, 
       // |STFT(x_t)| against the target (methods.py:242): x_t's frame, transformed and dropped
       const float* xrow = a.x2_in + (long long)b * a.L;
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
+      for (int qq = 0; qq < OV; ++qq) {
         v2f q[QU];
-        load_block4<R>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, a.pad_mode, q);
+        td_load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, a.pad_mode, q);
 #pragma unroll
         for (int i = 0; i < QU; ++i) z[qq * QU + i] = q[i] * lds_win[64 * (qq * QU + i) + lane];
       }
@@ -1286,16 +1296,15 @@ __global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, 
 #pragma unroll
     for (int i = 0; i < QU; ++i) {
       zold[i] = xq[0][i];
-      z[i] = xq[0][i] * lds_win[64 * i + lane];
-      z[QU + i] = xq[1][i] * lds_win[64 * (QU + i) + lane];
-      z[2 * QU + i] = xq[2][i] * lds_win[64 * (2 * QU + i) + lane];
-      z[3 * QU + i] = xn[i] * lds_win[64 * (3 * QU + i) + lane];
-      xq[0][i] = xq[1][i];
-      xq[1][i] = xq[2][i];
-      xq[2][i] = xn[i];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) z[q * QU + i] = xq[q][i] * lds_win[64 * (q * QU + i) + lane];
+      z[NB * QU + i] = xn[i] * lds_win[64 * (NB * QU + i) + lane];
+#pragma unroll
+      for (int q = 0; q + 1 < NB; ++q) xq[q][i] = xq[q + 1][i];
+      xq[NB - 1][i] = xn[i];
     }
     if (t + 1 < t_end)
-      load_block4<R>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, (SPECINV_TD_ABLATE & 4) ? 8 + (t & 3) : t + 4, lane, a.pad_mode, xn);
+      td_load_block<R, OV>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, (SPECINV_TD_ABLATE & 4) ? 8 + (t & 3) : t + OV, lane, a.pad_mode, xn);
     __builtin_amdgcn_s_setprio(0);
     TD_STAMP(0);
 
@@ -1368,8 +1377,8 @@ __global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, 
     // ---- synthesis window, register overlap-add, one finished hop-block of x_{t+1} and of z_{t+1} out
 #pragma unroll
     for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
-    if (t >= 2) {
-      const long long o0 = (long long)(t - 2) * HOP;
+    if (t >= PB) {
+      const long long o0 = (long long)(t - PB) * HOP;
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
       v2f* xo = reinterpret_cast<v2f*>(xorow + o0);
       v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
@@ -1385,9 +1394,9 @@ __global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, 
     }
 #pragma unroll
     for (int i = 0; i < QU; ++i) {
-      acc[i] = acc[QU + i] + z[QU + i];
-      acc[QU + i] = acc[2 * QU + i] + z[2 * QU + i];
-      acc[2 * QU + i] = z[3 * QU + i];
+#pragma unroll
+      for (int q = 0; q + 1 < NB; ++q) acc[q * QU + i] = acc[(q + 1) * QU + i] + z[(q + 1) * QU + i];
+      acc[(NB - 1) * QU + i] = z[NB * QU + i];
     }
     TD_STAMP(4);
   }
@@ -1399,23 +1408,27 @@ __global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, 
   }
 #endif
   if (t_end == a.T) {
-    // the chunk that holds the last frame also finishes hop-block T (frames T-3 .. T-1); xq[0] is z_t's block T by now
-    const long long o0 = (long long)(a.T - 2) * HOP;
-    const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
-    v2f* xo = reinterpret_cast<v2f*>(xorow + o0);
-    v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
+    // the chunk that holds the last frame also finishes hop-blocks T .. T + PB - 2 (the frames that reach them are done);
+    // xq[q] is z_t's block T + q by now
 #pragma unroll
-    for (int i = 0; i < QU; ++i) {
-      const v2f xv = env_apply(acc[i], envp[64u * i + ulane]);
-      xo[64u * i + ulane] = xv;
-      zo[64u * i + ulane] = v2f{fmaf(nlr, xq[0][i].x, xv.x), fmaf(nlr, xq[0][i].y, xv.y)};
+    for (int q = 0; q < PB - 1; ++q) {
+      const long long o0 = (long long)(a.T + q - PB) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
+      v2f* xo = reinterpret_cast<v2f*>(xorow + o0);
+      v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) {
+        const v2f xv = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
+        xo[64u * i + ulane] = xv;
+        zo[64u * i + ulane] = v2f{fmaf(nlr, xq[q][i].x, xv.x), fmaf(nlr, xq[q][i].y, xv.y)};
+      }
     }
   } else {
-    // what this chunk's last three frames contribute to the next chunk's first three hop-blocks (of x and of z alike)
-    v2f* tl = reinterpret_cast<v2f*>(a.xtail_out + ((long long)b * a.nchunks + c) * 3 * HOP);
+    // what this chunk's last NB frames contribute to the next chunk's first NB hop-blocks (of x and of z alike)
+    v2f* tl = reinterpret_cast<v2f*>(a.xtail_out + ((long long)b * a.nchunks + c) * NB * HOP);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + (long long)(t_end + q - 2) * HOP);
+    for (int q = 0; q < NB; ++q) {
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + (long long)(t_end + q - PB) * HOP);
 #pragma unroll
       for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
     }
@@ -1427,6 +1440,17 @@ __global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, 
       a.partials[2 * (long long)w + 1] = o;
     }
   }
+}
+
+// the headline shapes (hop = n_fft/4 at n_fft 1024 / 2048) launch 8-wave workgroups, one per CU, like k_fused4
+template <int R, bool EARLY, bool EVAL>
+__global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused4_td(FastArgs a) {
+  fused_td_body<R, 4, EARLY, EVAL>(a);
+}
+// every other fused shape: 4-wave workgroups like k_fused<R, OV>
+template <int R, int OV, bool EARLY, bool EVAL>
+__global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_td(FastArgs a) {
+  fused_td_body<R, OV, EARLY, EVAL>(a);
 }
 
 template <int R, int OV, int MODE, bool EVAL>
@@ -2249,7 +2273,9 @@ struct FastState<float> {
     using G = fast::Geo<RR>;
     const int hop = pl.cfg.hop_length;
     mode = md;
-    td = md == fast::MODE_GLA && !semi && OV == 4 && (RR == 8 || RR == 16) && !use_template && !keep_state;
+    // (n_fft 4096 runs one wave per SIMD: its vector latency, not the state traffic, is what bounds it there - the signal form
+    // measured 0.360 against 0.340 ms per iteration and is not used)
+    td = md == fast::MODE_GLA && !semi && !use_template && !keep_state && RR <= 16;
     if (const char* e = getenv("SPECINV_DISABLE_TD")) {      // tests: the spectral-state kernel
       if (e[0] == '1') td = false;
     }
@@ -2465,14 +2491,14 @@ struct FastState<float> {
     if ((R == 8 || R == 16) && OV == 4 && !use_template) return n_waves >= 2048 ? SPECINV_WGW : 4;
     return 4;
   }
-  // {waves per workgroup, chunks per item, waves, kernel: 1 k_fused4, 2 k_fused<R, OV>, 3 k_semi, 4 k_hop, 5 k_fused4_td}
+  // {waves per workgroup, chunks per item, waves, kernel: 1 k_fused4, 2 k_fused<R, OV>, 3 k_semi, 4 k_hop, 5 k_fused_td<R, 4> at n_fft 1024 / 2048, 6 k_fused_td<R, OV> otherwise}
   void geometry(int out[4]) const {
     if (semi) {
       out[0] = hopk ? 8 : 4;
       out[3] = hopk ? 4 : 3;
     } else {
       out[0] = fused_wgw();
-      out[3] = ((R == 8 || R == 16) && OV == 4 && !use_template) ? (td ? 5 : 1) : 2;
+      out[3] = ((R == 8 || R == 16) && OV == 4 && !use_template) ? (td ? 5 : 1) : (td ? 6 : 2);
     }
     out[1] = nchunks;
     out[2] = n_waves;
@@ -2502,20 +2528,27 @@ struct FastState<float> {
     return SPECINV_OK;
   }
 
+  template <int RR, int OVV>
+  static const void* td_kernel(bool early, bool ev) {
+    return early ? (ev ? (const void*)fast::k_fused_td<RR, OVV, true, true> : (const void*)fast::k_fused_td<RR, OVV, true, false>)
+                 : (ev ? (const void*)fast::k_fused_td<RR, OVV, false, true> : (const void*)fast::k_fused_td<RR, OVV, false, false>);
+  }
+  template <int RR>
+  static const void* td_kernel4(bool early, bool ev) {
+    return early ? (ev ? (const void*)fast::k_fused4_td<RR, true, true> : (const void*)fast::k_fused4_td<RR, true, false>)
+                 : (ev ? (const void*)fast::k_fused4_td<RR, false, true> : (const void*)fast::k_fused4_td<RR, false, false>);
+  }
   template <typename P>
   int launch_td(P& pl, const fast::FastArgs& a, bool early, bool ev) {
     const void* fn = nullptr;
     size_t lds_used = 0;
     const int wgw = fused_wgw();
-    if (R == 16) {
-      fn = early ? (ev ? (const void*)fast::k_fused4_td<16, true, true> : (const void*)fast::k_fused4_td<16, true, false>)
-                 : (ev ? (const void*)fast::k_fused4_td<16, false, true> : (const void*)fast::k_fused4_td<16, false, false>);
-      lds_used = fast::Geo<16>::lds_bytes(wgw);
-    } else {
-      fn = early ? (ev ? (const void*)fast::k_fused4_td<8, true, true> : (const void*)fast::k_fused4_td<8, true, false>)
-                 : (ev ? (const void*)fast::k_fused4_td<8, false, true> : (const void*)fast::k_fused4_td<8, false, false>);
-      lds_used = fast::Geo<8>::lds_bytes(wgw);
-    }
+    SPECINV_R_SWITCH(R, lds_used = fast::Geo<RR>::lds_bytes(wgw);
+                     if constexpr (RR % 8 == 0) { if (OV == 8) fn = td_kernel<RR, 8>(early, ev); }
+                     if constexpr (RR == 8 || RR == 16) { if (OV == 4) fn = td_kernel4<RR>(early, ev); }
+                     else { if (OV == 4) fn = td_kernel<RR, 4>(early, ev); }
+                     if (OV == 2) fn = td_kernel<RR, 2>(early, ev));
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
     fast::FastArgs args = a;
 #if SPECINV_TD_STAMPS

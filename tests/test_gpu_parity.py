@@ -119,13 +119,14 @@ def test_gla_waveforms(alpha, it):
     assert abs(sc_y - sc_ref) < 1e-5, (sc_y, sc_ref)
 
 
-@pytest.mark.parametrize("path", ["default", "fused", "frame_lds", "generic", "float64"])
+@pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "generic", "float64"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
     """g14 (consistent magnitudes of a real signal, true phase perturbed by 0.5 rad): 100 iterations held to the STRICT
     gate min(1e-4, 6 x the reference's float32-vs-float64 noise) - no segment statistics - on every kernel path: the
-    frame kernel (default for a problem this small), the fused chunk-walking kernel, the chunked frame kernel with the
-    overlap-add in LDS, the generic kernels, and float64.  (g2's random magnitudes are inconsistent: there a near-zero
+    frame kernel (default for a problem this small), the fused chunk-walking kernel with the momentum carried as a signal
+    (`k_fused_td<4, 4>`) and on pre_spec itself (`k_fused<4, 4>`), the chunked frame kernel with the overlap-add in LDS, the
+    generic kernels, and float64.  (g2's random magnitudes are inconsistent: there a near-zero
     bin can decorrelate a neighbourhood between ANY two float32 runs, see test_gla_waveforms.)"""
     from spectrogram_inversion_amd.plan import Plan, clear_plan_cache
     g = load_golden("g14_wellcond")
@@ -134,7 +135,7 @@ def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
     gate = min(1e-4, max(6 * noise, 3e-6))
     init = T(g["init"])
     hop, w = int(g["hop"]), torch.from_numpy(g["window"])
-    if path in ("fused", "frame_lds"):
+    if path in ("fused", "fused_prespec", "frame_lds"):
         monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")
     if path == "frame_lds":
         monkeypatch.setenv("SPECINV_DISABLE_FUSED", "1")
@@ -143,9 +144,11 @@ def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
     p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], w.dtype, dev())
     if path == "generic":
         p.force_generic(True)
-    want = {"default": "k_semi", "fused": "k_fused", "frame_lds": "k_hop", "generic": "k_iter_pair", "float64": "k_iter_pair"}[path]
-    assert p.launch_geometry["kernel"] == want, p.launch_geometry
+    want = {"default": "k_semi", "fused": "k_fused_td", "fused_prespec": "k_fused", "frame_lds": "k_hop", "generic": "k_iter_pair",
+            "float64": "k_iter_pair"}[path]
+    p.keep_state(path == "fused_prespec")
     p.gla_init(init, None, alpha)
+    assert p.launch_geometry["kernel"] == want, p.launch_geometry
     done, _ = p.run(100, 10, 0.0, "sc")
     y = N(p.wave())
     if path == "float64":
