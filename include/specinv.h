@@ -257,6 +257,11 @@ int specinv_lbfgs_pair_stats_dev(specinv_plan* plan, const void* g, const void* 
                                  void* y_out, void* s_out, int64_t n, double* out_dev);
 /* n doubles from device memory to the host, after everything enqueued on the plan's stream so far */
 int specinv_read_doubles(specinv_plan* plan, const double* src_dev, int n, double* out_host);
+/* A board of n doubles in pinned host memory that the device writes directly (pass *dev_out + slot to the *_dev entry points):
+ * the scalars of an iteration land in host memory without a copy kernel; specinv_stream_wait (everything enqueued on the
+ * plan's stream so far has finished) makes *host_out readable.  The board lives as long as the plan. */
+int specinv_board_alloc(specinv_plan* plan, int n, double** host_out, double** dev_out);
+int specinv_stream_wait(specinv_plan* plan);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,8 @@ SIGNATURES = {
     "specinv_lbfgs_direction": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(_P), _DP, C.c_int, _D, _P, _I64]),
     "specinv_vec_multi_dot": (C.c_int, [_P, _P, C.POINTER(_P), C.c_int, _I64, _DP]),
     "specinv_vec_lincomb": (C.c_int, [_P, C.POINTER(_P), _DP, C.c_int, _I64, _P]),
+    "specinv_board_alloc": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P)]),
+    "specinv_stream_wait": (C.c_int, [_P]),
     "specinv_vec_lincomb_step": (C.c_int, [_P, C.POINTER(_P), _DP, C.c_int, _I64, _P, C.c_double, _P]),
     "specinv_transform_loss_grad_dev": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
     "specinv_vec_multi_dot_dev": (C.c_int, [_P, _P, C.POINTER(_P), C.c_int, _I64, _P]),

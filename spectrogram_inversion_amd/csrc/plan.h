@@ -84,6 +84,8 @@ struct PlanBase {
   virtual int lbfgs_pair_stats(const void* g, const void* gp, const void* d, double t, void* y, void* sv, int64_t n,
                                double* out8_dev) = 0;
   virtual int read_doubles(const double* src_dev, int n, double* out_host) = 0;
+  virtual int board_alloc(int n, double** host_out, double** dev_out) = 0;
+  virtual int stream_wait() = 0;
 
   // _training_loop (methods.py:153-190) driving `iterate`
   int run_loop(int max_iter, int eva_iter, double tol, int metric, specinv_eval* evals, int* n_evals,

@@ -3,6 +3,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <type_traits>
 #include <vector>
 
@@ -739,6 +740,33 @@ struct PlanT final : PlanBase {
   int read_doubles(const double* src_dev, int n, double* out_host) override {
     SI_CHECK(src_dev && out_host && n > 0, SPECINV_EINVAL, "bad arguments");
     SI_HIP(hipMemcpyAsync(out_host, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    SI_HIP(si_stream_wait_short(stream));
+    return SPECINV_OK;
+  }
+  // pinned, device-mapped host memory for the scalar results of an optimiser iteration
+  struct HostBoard {
+    void* p = nullptr;
+    HostBoard() = default;
+    HostBoard(const HostBoard&) = delete;
+    HostBoard& operator=(const HostBoard&) = delete;
+    ~HostBoard() {
+      if (p) (void)hipHostFree(p);
+    }
+  };
+  std::vector<std::unique_ptr<HostBoard>> boards;
+  int board_alloc(int n, double** host_out, double** dev_out) override {
+    SI_CHECK(n > 0 && host_out && dev_out, SPECINV_EINVAL, "bad arguments");
+    std::unique_ptr<HostBoard> b(new HostBoard());
+    SI_HIP(hipHostMalloc(&b->p, (size_t)n * sizeof(double), hipHostMallocMapped));
+    std::memset(b->p, 0, (size_t)n * sizeof(double));
+    void* dp = nullptr;
+    SI_HIP(hipHostGetDevicePointer(&dp, b->p, 0));
+    *host_out = static_cast<double*>(b->p);
+    *dev_out = static_cast<double*>(dp);
+    boards.push_back(std::move(b));
+    return SPECINV_OK;
+  }
+  int stream_wait() override {
     SI_HIP(si_stream_wait_short(stream));
     return SPECINV_OK;
   }

@@ -433,5 +433,13 @@ int specinv_read_doubles(specinv_plan* plan, const double* src_dev, int n, doubl
   ENTER(plan);
   return plan->impl->read_doubles(src_dev, n, out_host);
 }
+int specinv_board_alloc(specinv_plan* plan, int n, double** host_out, double** dev_out) {
+  ENTER(plan);
+  return plan->impl->board_alloc(n, host_out, dev_out);
+}
+int specinv_stream_wait(specinv_plan* plan) {
+  ENTER(plan);
+  return plan->impl->stream_wait();
+}
 
 }  // extern "C"

@@ -20,6 +20,27 @@ import torch
 from .plan import StftArgs, get_plan
 
 
+class _HostBoard:
+    """`specinv_board_alloc`: doubles in pinned host memory, mapped into the device's address space."""
+
+    def __init__(self, plan, n):
+        self.plan, self.n = plan, n                        # (the plan owns the memory: keep it alive)
+        self.host, self.dev = plan.board_alloc(n)
+
+    def data_ptr(self):
+        return self.dev
+
+    def numel(self):
+        return self.n
+
+    def put(self, slot, value):
+        self.host[slot] = value
+
+    def read(self, n):
+        self.plan.stream_wait()
+        return self.host[:n]
+
+
 class HipVecOps:
     """Vector primitives on the HIP device (libspecinv vec_* entry points)."""
 
@@ -67,14 +88,15 @@ class HipVecOps:
     packed = True
 
     def board(self, n):
-        return torch.zeros(n, dtype=torch.float64, device=self.plan.device)
+        """scalar results of an iteration: pinned host memory written by the kernels themselves (no copy on the way back)"""
+        return _HostBoard(self.plan, n)
 
     def eval_into(self, fg, x, board, slot):
         """gradient of the objective at x; the loss goes to board[slot]"""
         if hasattr(fg, "dev"):
             return fg.dev(x, board.data_ptr() + 8 * slot)
         loss, g = fg(x)                                    # a generic callable: its loss is already on the host
-        board[slot:slot + 1].fill_(float(loss))
+        board.put(slot, float(loss))
         return g
 
     def stats_into(self, g, d, board, slot):
@@ -91,7 +113,7 @@ class HipVecOps:
         self.plan.vec_multi_dot_dev(g, vecs, board.data_ptr() + 8 * slot)
 
     def read(self, board, n):
-        return self.plan.read_doubles(board.data_ptr(), n)
+        return board.read(n)
 
 
 def _cubic_step(xa, fa, ga, xb, fb, gb, bounds=None):

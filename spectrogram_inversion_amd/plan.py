@@ -525,6 +525,16 @@ class Plan:
         self._sync_stream()
         _lib.check(self.lib.specinv_lbfgs_stats_dev(self._h, g.data_ptr(), d.data_ptr(), g.numel(), out_ptr))
 
+    def board_alloc(self, n: int):
+        """n doubles of pinned host memory the device writes directly: (host ctypes array, device address)."""
+        hp, dp = C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.specinv_board_alloc(self._h, int(n), C.byref(hp), C.byref(dp)))
+        return (C.c_double * n).from_address(hp.value), dp.value
+
+    def stream_wait(self):
+        self._sync_stream()
+        _lib.check(self.lib.specinv_stream_wait(self._h))
+
     def read_doubles(self, ptr: int, n: int):
         self._sync_stream()
         out = (C.c_double * n)()

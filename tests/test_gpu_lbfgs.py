@@ -448,3 +448,22 @@ def test_direction_and_step_in_one_pass(k, n, dtype):
     x = x0.clone()
     d = ops.lincomb_step(tv, coef, t, x)
     assert torch.equal(d, d_ref) and torch.equal(x, x_ref)
+
+
+def test_host_board_receives_device_results():
+    """`specinv_board_alloc`: the scalar results of the optimiser passes are written by the kernels into pinned host memory;
+    `specinv_stream_wait` makes them readable - the same values as through a device buffer and `specinv_read_doubles`."""
+    ops = HipVecOps(torch.float32, dev())
+    rng = np.random.default_rng(3)
+    n = 300007
+    g, gp, d = (T(rng.standard_normal(n).astype(np.float32)) for _ in range(3))
+    hb = ops.board(16)
+    db = torch.zeros(16, dtype=torch.float64, device=dev())
+    for rep in range(20):
+        t = 0.1 + 0.05 * rep
+        ops.plan.lbfgs_pair_stats_dev(g, gp, d, t, hb.data_ptr() + 8)         # slots 1..8
+        ops.plan.lbfgs_pair_stats_dev(g, gp, d, t, db.data_ptr() + 8)
+        hb.put(0, float(rep))
+        got = ops.read(hb, 9)
+        want = ops.plan.read_doubles(db.data_ptr(), 9)
+        assert got[0] == float(rep) and list(got[1:]) == list(want[1:]), rep
