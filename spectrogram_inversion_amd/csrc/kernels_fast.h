@@ -813,7 +813,10 @@ __device__ __forceinline__ void load_block4(const float* __restrict__ xrow, cons
 }
 
 template <int R, int MODE, bool EVAL>
-__global__ __launch_bounds__(64 * SPECINV_WGW, SPECINV_MINWAVES) void k_fused4(FastArgs a) {
+#ifndef SPECINV_R8_W3        // n_fft 1024 at hop 256: three waves per SIMD (12-wave workgroups, 3072 wave slots).  The plain launches fit
+#define SPECINV_R8_W3 1      // 168 registers (ADMM 2 spilled, the evaluating variants 8-31); measured against two waves per SIMD:
+#endif                       // C4 34.3 -> 32.3 ms per step, Griffin-Lim 1024 / 256 0.135 -> 0.127 ms per iteration
+__global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW, (SPECINV_R8_W3 && R == 8) ? 3 : SPECINV_MINWAVES) void k_fused4(FastArgs a) {
   using G = Geo<R>;
   constexpr int H = G::H, QU = G::QU, M = G::M, HOP = G::HOP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1444,7 +1447,8 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 
 // the headline shapes (hop = n_fft/4 at n_fft 1024 / 2048) launch 8-wave workgroups, one per CU, like k_fused4
 template <int R, bool EARLY, bool EVAL>
-__global__ __launch_bounds__(SPECINV_TD_MINWAVES == 3 ? 768 : 64 * SPECINV_WGW, SPECINV_TD_MINWAVES) void k_fused4_td(FastArgs a) {
+__global__ __launch_bounds__((SPECINV_TD_MINWAVES == 3 || (SPECINV_R8_W3 && R == 8)) ? 768 : 64 * SPECINV_WGW,
+                            (SPECINV_R8_W3 && R == 8) ? 3 : SPECINV_TD_MINWAVES) void k_fused4_td(FastArgs a) {
   fused_td_body<R, 4, EARLY, EVAL>(a);
 }
 // every other fused shape: 4-wave workgroups like k_fused<R, OV>
@@ -2239,6 +2243,7 @@ struct FastState<float> {
     // reflected edge samples must not fall on split blocks (first / last chunk long enough): chunks of >= 8 (16) frames.
     const int floor_ch = OV == 8 ? 16 : 8;
     long long slots = 1024LL * (R >= 32 ? 1 : R <= 4 ? 3 : 2);
+    if (SPECINV_R8_W3 && R == 8 && OV == 4) slots = 3072;
     if (const char* e = getenv("SPECINV_FUSED_SLOTS")) slots = atoll(e);      // (experiments: wave slots of the chip)
     int best_nch = 1;
     double best_cost = 1e300;
@@ -2488,6 +2493,7 @@ struct FastState<float> {
   // slot is filled; fewer waves than slots: smaller workgroups reach more CUs
   int fused_wgw() const {
     if (const char* e = getenv("SPECINV_FUSED_WGW")) return atoi(e);           // (experiments)
+    if (SPECINV_R8_W3 && R == 8 && OV == 4 && !use_template && n_waves >= 3072) return 12;
     if ((R == 8 || R == 16) && OV == 4 && !use_template) return n_waves >= 2048 ? SPECINV_WGW : 4;
     return 4;
   }

@@ -1,7 +1,8 @@
 """Every BASELINE.json configuration at the size `bench.py` runs it, on the launch geometry `bench.py` gets.
 
-The wave-level kernels pick their geometry from the problem size (8-wave workgroups of `k_fused4` once the launch
-fills every wave slot: 2048 waves, i.e. BASELINE C2 at B = 64 and the C4 shard at B = 32), so small-shape tests do
+The wave-level kernels pick their geometry from the problem size (8-wave workgroups of `k_fused4` / `k_fused4_td` once the launch
+fills every wave slot: 2048 waves at n_fft 2048, i.e. BASELINE C2 at B = 64; 12-wave workgroups and 3072 waves at n_fft 1024, the C4
+shard at B = 32), so small-shape tests do
 not run the code the benchmark runs.  These do, against (a) the CPU oracle on a few whole items - batch items are
 independent (torch_specinv/methods.py:237-250, :458-483, :363-404), three of them are seconds on the CPU - and
 (b) the float64 generic kernels on the whole batch.  Needs an MI355X: `-m gpu`."""
@@ -101,7 +102,7 @@ def test_c4_shard_geometry_vs_oracle_and_float64():
     mag = torch.from_numpy(mag_np).to(DEV)
     p32 = make_plan(n_fft, hop, frames, batch)
     geo = p32.launch_geometry
-    assert geo == {"waves_per_workgroup": 8, "chunks": 64, "waves": 2048, "kernel": "k_fused4"}, geo
+    assert geo == {"waves_per_workgroup": 12, "chunks": 96, "waves": 3072, "kernel": "k_fused4"}, geo
     w = hann(n_fft)
     items = [0, 15, 31]
     c0 = p32.phase_init(mag)

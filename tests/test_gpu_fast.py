@@ -448,7 +448,7 @@ def test_tuned_copy_equals_template(monkeypatch, n_fft, batch, frames, method):
         geo = p.launch_geometry
         assert geo["kernel"] == ("k_fused" if template == "1" else "k_fused4"), geo
         if template == "0" and batch * frames >= 65536:
-            assert geo["waves_per_workgroup"] == 8 and geo["waves"] == 2048, geo
+            assert (geo["waves_per_workgroup"], geo["waves"]) == ((8, 2048) if n_fft == 2048 else (12, 3072)), geo
         p.keep_state()
         (p.gla_init if method == "gla" else p.admm_init)(None, mag, 0.3)
         p.iterate(2)
@@ -572,7 +572,7 @@ def test_time_domain_momentum_against_spectral_state(n_fft, batch, frames, ov, a
         geo = p.launch_geometry
         assert geo["kernel"] == (("k_fused4" if keep else "k_fused4_td") if tuned else ("k_fused" if keep else "k_fused_td")), geo
         if batch * frames >= 65536:
-            assert geo["waves_per_workgroup"] == 8 and geo["waves"] == 2048, geo
+            assert (geo["waves_per_workgroup"], geo["waves"]) == ((8, 2048) if n_fft == 2048 else (12, 3072)), geo
         sums = [p.iterate(3, eval_last=True)]
         p.iterate(11)
         sums += [p.iterate(1, eval_last=True), p.iterate(1, eval_last=True), p.iterate(1, eval_last=True)]    # 15, 16, 17
