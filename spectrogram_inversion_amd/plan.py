@@ -574,6 +574,7 @@ def get_plan(args: StftArgs, batch: int, n_frames: int, dtype: torch.dtype, devi
         cache[key] = plan
     else:
         cache.move_to_end(key)
+        plan.keep_state(False)                 # (a per-run request: the next user of a cached plan gets the default kernels)
     trim_plan_cache()
     return plan
 
