@@ -98,20 +98,19 @@ int64_t specinv_plan_device_bytes(const specinv_plan* plan);
 /* Launch geometry of the iteration kernel (diagnostics; the tests assert that the benchmark's geometry is the one they
  * cover): out = { waves per workgroup, chunks of frames per item, waves per launch, kernel }, kernel: 0 generic
  * k_iter_pair, 1 k_fused4 (hop = n_fft/4 at n_fft 1024 / 2048), 2 k_fused<R, OV>, 3 k_semi, 4 k_hop, 5 k_fused4_td and
- * 6 k_fused_td<R, OV> (Griffin-Lim on the fused shapes with the momentum carried as a signal; known once specinv_gla_init
- * has run). */
+ * 6 k_fused_td<R, OV>, 7 k_hop_td (Griffin-Lim with the momentum carried as a signal; known once specinv_gla_init has run). */
 int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]);
 /* 0: allow the fast path when the configuration supports it (default); 1: force the generic kernels. */
 int specinv_plan_force_generic(specinv_plan* plan, int on);
 /* The float32 fast paths do not carry the reference's spectral state as such.
  * ADMM keeps only Y = X + U between iterations: methods.py:467-468 read the two as U + X, i.e. the Y that :475 has just
- * rounded, so the iterates are bit-identical and the state traffic halves.  Griffin-Lim on the fused shapes (hop = n_fft/2, /4, /8) keeps
- * its momentum as the signal z_t = x_t - lr z_{t-1} (pre_t = STFT(z_t) + (-lr)^t c0 by linearity of the STFT):
+ * rounded, so the iterates are bit-identical and the state traffic halves.  Griffin-Lim on the fused shapes (hop = n_fft/2, /4, /8) and on the chunked
+ * frame kernel keeps its momentum as the signal z_t = x_t - lr z_{t-1} (pre_t = STFT(z_t) + (-lr)^t c0 by linearity of the STFT):
  * pre_spec is never formed.
  * 1: ADMM - the last iteration of every specinv_admm_iterate call (and specinv_admm_init) also leaves X and U behind for
  * specinv_get_state_spec; Griffin-Lim - the iteration runs on pre_spec itself (the spectral-state kernel).
  * 0 (default): asking for X / U / pre_spec after an iteration is SPECINV_ESTATE.  Call before specinv_*_init.
- * (The generic kernels keep X and U anyway; the frame and generic Griffin-Lim kernels keep pre_spec.) */
+ * (The generic kernels keep X and U anyway; the frame-at-a-time and generic Griffin-Lim kernels keep pre_spec.) */
 int specinv_plan_keep_state(specinv_plan* plan, int on);
 
 /* ---- building blocks ------------------------------------------------------------------ */

@@ -2280,7 +2280,11 @@ struct FastState<float> {
     mode = md;
     // (n_fft 4096 runs one wave per SIMD: its vector latency, not the state traffic, is what bounds it there - the signal form
     // measured 0.360 against 0.340 ms per iteration and is not used)
-    td = md == fast::MODE_GLA && !semi && !use_template && !keep_state && RR <= 16;
+    td = md == fast::MODE_GLA && (!semi || hopk) && !use_template && !keep_state && RR <= 16;
+    // k_hop_td writes two signals and re-reads z_t where k_hop writes one: its sample-at-a-time emission loop grows with the hop
+    // and overtakes the saved state traffic (measured, late iterations, 32 768+ frames: n_fft 2048 hop 333 0.179 vs 0.192 ms, hop 600
+    // 0.212 vs 0.201; n_fft 1024 hop 400 0.197 vs 0.225; n_fft 512 hop 100 0.173 vs 0.200, hop 200 0.235 vs 0.221)
+    if (hopk && hop > (RR == 4 ? 128 : RR == 8 ? 448 : 416)) td = false;
     if (const char* e = getenv("SPECINV_DISABLE_TD")) {      // tests: the spectral-state kernel
       if (e[0] == '1') td = false;
     }
@@ -2501,7 +2505,7 @@ struct FastState<float> {
   void geometry(int out[4]) const {
     if (semi) {
       out[0] = hopk ? 8 : 4;
-      out[3] = hopk ? 4 : 3;
+      out[3] = hopk ? (td ? 7 : 4) : 3;
     } else {
       out[0] = fused_wgw();
       out[3] = ((R == 8 || R == 16) && OV == 4 && !use_template) ? (td ? 5 : 1) : (td ? 6 : 2);
@@ -2662,6 +2666,58 @@ struct FastState<float> {
     return SPECINV_OK;
   }
 
+  // the same for Griffin-Lim with the momentum carried as a signal: z from zb[cur] (the first closure call: x itself) to
+  // zb[cur ^ 1], x to xb[cur ^ 1]
+  template <int RR, typename P>
+  int launch_hop_td(P& pl, bool ev) {
+    using G = fast::Geo<RR>;
+    const int wgw = 8, hop = pl.cfg.hop_length, keep = pl.N() - hop;
+    const int nx = cur ^ 1;
+    ++td_t;
+    const double tds = std::pow(-(double)pl.coef, (double)td_t);
+    const bool early = std::fabs(tds) >= 9.3132257461547852e-10;       // 2^-30, as in iterate()
+    fast::HopArgs s{};
+    fast::FastArgs& a = s.f;
+    a.x_in = td_t == 1 ? xb[cur].template as<float>() : zb[cur].template as<float>();
+    a.x_out = zb[nx].template as<float>();
+    a.x2_in = xb[cur].template as<float>();
+    a.x2_out = xb[nx].template as<float>();
+    a.P_in = Pb[0].template as<v4f>();
+    a.Pmid_in = Pmid[0].template as<v2f>();
+    a.tds = (float)tds;
+    a.m_pairs = mpairs.template as<v4f>();
+    a.m_mid = mmid.template as<float>();
+    a.window = pl.window.template as<float>();
+    a.partials = pl.partials.template as<double>();
+    a.T = pl.Tn();
+    a.nchunks = nchunks;
+    a.n_waves = n_waves;
+    a.pad_mode = pl.cfg.pad_mode;
+    a.L = pl.length;
+    a.coef = pl.coef;
+    a.fwd_scale = pl.fc.fwd_scale;
+    a.inv_scale = pl.fc.inv_scale;
+    s.env = inv_env.template as<float>();
+    s.xtail = xtail[0].template as<float>();
+    s.hop = hop;
+    s.pad = pl.pad;
+    const size_t lds = G::lds_bytes(wgw) + (size_t)wgw * G::N * sizeof(float);
+    const void* fn = early ? (ev ? (const void*)fast::k_hop_td<RR, true, true> : (const void*)fast::k_hop_td<RR, true, false>)
+                           : (ev ? (const void*)fast::k_hop_td<RR, false, true> : (const void*)fast::k_hop_td<RR, false, false>);
+    SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* kargs[] = {&s};
+    SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds, pl.stream));
+    if (nchunks > 1 && keep > 0) {
+      const long long total = (long long)pl.B() * (nchunks - 1) * keep;
+      hipLaunchKernelGGL(fast::k_hop_tails_td, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, a.x2_out, a.x_out,
+                         a.x_in, (const float*)s.xtail, s.env, a.coef, pl.Tn(), nchunks, hop, keep, pl.pad, (long long)pl.length,
+                         total);
+      SI_HIP(hipGetLastError());
+    }
+    cur = nx;
+    return SPECINV_OK;
+  }
+
   template <typename P>
   int iterate_semi(P& pl, int n_iter, bool eval_last) {
     SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2, 3 * 1024) * sizeof(double)));
@@ -2670,7 +2726,8 @@ struct FastState<float> {
       int rc = SPECINV_OK;
       if (hopk) {
         SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
-          if (mode == fast::MODE_GLA) rc = ev ? launch_hop<RR, fast::MODE_GLA, true>(pl) : launch_hop<RR, fast::MODE_GLA, false>(pl);
+          if (td) rc = launch_hop_td<RR>(pl, ev);
+          else if (mode == fast::MODE_GLA) rc = ev ? launch_hop<RR, fast::MODE_GLA, true>(pl) : launch_hop<RR, fast::MODE_GLA, false>(pl);
           else rc = ev ? launch_hop<RR, fast::MODE_ADMM, true>(pl, last) : launch_hop<RR, fast::MODE_ADMM, false>(pl, last);
         });
         SI_TRY(rc);

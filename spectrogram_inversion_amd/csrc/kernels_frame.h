@@ -425,6 +425,267 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
   }
 }
 
+// ---- k_hop with Griffin-Lim's momentum carried as a signal (kernels_fast.h: fused_td_body has the derivation) ---------------
+// pre_t = STFT(z_t) + (-lr)^t c0, z_{t+1} = x_{t+1} - lr z_t.  The wave transforms z_t's frames (a.x_in), an evaluating launch
+// x_t's as well (a.x2_in); the samples that become final after a frame go out as x_{t+1} (a.x2_out) and z_{t+1} (a.x_out), z_t's
+// value at those positions re-read from L2.  Seam samples (first n_fft - hop of a later chunk) leave the kernel as undivided
+// partial sums of x, as in k_hop; k_hop_tails_td finishes x and z there.
+template <int R, bool EARLY, bool EVAL>
+__device__ __forceinline__ void semi_frame_td(const FastArgs& a, long long fi, const LaneConst<R>& k, const v2f* lds_win,
+                                              const v2f* lds_tw1, v2f* tr, v2f (&z)[R], const v2f (&xf)[EVAL ? R : 1],
+                                              double& sd, double& so) {
+  using G = Geo<R>;
+  constexpr int H = G::H;
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const float half_scale = 0.5f * a.fwd_scale;
+  v4f mm[H / 2];
+  float mmid = 0.0f;
+  v2f pmid = v2f{0.0f, 0.0f};
+  {
+    const v4f* min = a.m_pairs + fi * (H / 2 * 64);
+#pragma unroll
+    for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min[j * 64u + ulane]);
+    if (lane == 0) {
+      mmid = a.m_mid[fi];
+      if (EARLY) pmid = a.Pmid_in[fi];
+    }
+  }
+  if (EVAL) {
+    // |STFT(x_t)| against the target (methods.py:242)
+    v2f y[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) y[u] = xf[u] * lds_win[64 * u + lane];
+    fft_forward<R>(y, k, lds_tw1, tr);
+    v2f rc[H];
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(y[m], k.partner);
+      const v2f own = y[(m + 1) % R];
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+    float fd = 0.0f, fo = 0.0f;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+      v2f xk, xm;
+      td_split<R>(y[j], rc[R - 1 - j - H], wk, half_scale, xk, xm);
+      const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+      const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+      const float ok = fast_abs(xk), om = fast_abs(xm);
+      const float dk = ok - mk, dm = om - mq;
+      fd = fmaf(dk, dk, fmaf(dm, dm, fd));
+      fo = fmaf(ok, ok, fmaf(om, om, fo));
+    }
+    if (lane == 0) {
+      const float o = fast_abs(y[H] * v2f{a.fwd_scale, -a.fwd_scale});
+      const float d = o - mmid;
+      fd = fmaf(d, d, fd);
+      fo = fmaf(o, o, fo);
+    }
+    sd += (double)fd;
+    so += (double)fo;
+  }
+  v4f pp[EARLY ? H : 1];
+  if (EARLY) {
+    const v4f* pin = a.P_in + fi * (H * 64);
+#pragma unroll
+    for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin[j * 64u + ulane]);
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+  fft_forward<R>(z, k, lds_tw1, tr);
+  v2f rc[H];
+#pragma unroll
+  for (int m = H; m < R; ++m) {
+    const v2f got = shfl2(z[m], k.partner);
+    const v2f own = z[(m + 1) % R];
+    rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+  }
+  v2f back[H];
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+    v2f sk, sm;
+    td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
+    if (EARLY) {
+      sk = v2f{fmaf(a.tds, pp[j].x, sk.x), fmaf(a.tds, pp[j].y, sk.y)};
+      sm = v2f{fmaf(a.tds, pp[j].z, sm.x), fmaf(a.tds, pp[j].w, sm.y)};
+    }
+    const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+    const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+#if SPECINV_IEEE
+    const float dk = fast_abs(sk) + 1e-16f, dq = fast_abs(sm) + 1e-16f;
+    v2f ak = v2f{__fdiv_rn(sk.x * mk, dk) * a.inv_scale, __fdiv_rn(sk.y * mk, dk) * a.inv_scale};
+    v2f am = v2f{__fdiv_rn(sm.x * mq, dq) * a.inv_scale, __fdiv_rn(sm.y * mq, dq) * a.inv_scale};
+#else
+    const float ik = fast_rcp(fast_abs(sk) + 1e-16f) * a.inv_scale, iq = fast_rcp(fast_abs(sm) + 1e-16f) * a.inv_scale;
+    v2f ak = v2f{(sk.x * mk) * ik, (sk.y * mk) * ik};
+    v2f am = v2f{(sm.x * mq) * iq, (sm.y * mq) * iq};
+#endif
+    if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+      ak.y = 0.0f;
+      am.y = 0.0f;
+    }
+    const v2f e2i = add_conj(ak, am);
+    const v2f o2i = cmulc(sub_conj(ak, am), wk);
+    z[j] = add_i(e2i, o2i);
+    back[j] = conj_sub_i(e2i, o2i);
+  }
+  v2f zmid;
+  {
+    v2f smid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
+    if (EARLY) smid = v2f{fmaf(a.tds, pmid.x, smid.x), fmaf(a.tds, pmid.y, smid.y)};
+#if SPECINV_IEEE
+    const float dn = fast_abs(smid) + 1e-16f;
+    const v2f am = v2f{__fdiv_rn(smid.x * mmid, dn) * a.inv_scale, __fdiv_rn(smid.y * mmid, dn) * a.inv_scale};
+#else
+    const float inv = fast_rcp(fast_abs(smid) + 1e-16f) * a.inv_scale;
+    const v2f am = v2f{(smid.x * mmid) * inv, (smid.y * mmid) * inv};
+#endif
+    zmid = am * v2f{2.0f, -2.0f};
+  }
+#pragma unroll
+  for (int m = H; m < R; ++m) {
+    const v2f got = shfl2(back[R - 1 - m], k.partner);
+    const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+    z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+  }
+  fft_inverse<R>(z, k, lds_tw1, tr);
+}
+
+template <int R, bool EARLY, bool EVAL>
+__global__ __launch_bounds__(512, 1) void k_hop_td(HopArgs s) {
+  using G = Geo<R>;
+  constexpr int M = G::M, N = G::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const FastArgs& a = s.f;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwib = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  float* ring = reinterpret_cast<float*>(lds_tw1 + (R - 1) * 64 + nwib * G::TR) + wib * N;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * nwib + wib);
+  double sd = 0.0, so = 0.0;
+  if (w < a.n_waves) {
+    const int b = w / a.nchunks, c = w - b * a.nchunks;
+    const int t0 = hop_chunk_begin(c, a.T, a.nchunks), t1 = hop_chunk_begin(c + 1, a.T, a.nchunks);
+    const int hop = s.hop, keep = N - hop;
+    const float* env = s.env;
+    const float nlr = -a.coef;
+    const float* zrow = a.x_in + (long long)b * a.L;
+    const float* xrow = a.x2_in + (long long)b * a.L;
+    float* zo = a.x_out + (long long)b * a.L;
+    float* xo = a.x2_out + (long long)b * a.L;
+#pragma unroll
+    for (int u = 0; u < R; ++u) reinterpret_cast<v2f*>(ring)[64 * u + lane] = v2f{0.0f, 0.0f};
+    const long long raw_end = c > 0 ? (long long)t0 * hop + keep : -1;
+    int slot0 = (int)(((long long)t0 * hop) % N);
+    v2f zn[R];
+    load_frame_raw<R>(zrow, a.L, (long long)t0 * hop - s.pad, lane, a.pad_mode, zn);
+    for (int t = t0; t < t1; ++t) {
+      const long long fi = (long long)b * a.T + t;
+      v2f z[R], xf[EVAL ? R : 1];
+#pragma unroll
+      for (int u = 0; u < R; ++u) z[u] = zn[u];
+      if constexpr (EVAL) load_frame_raw<R>(xrow, a.L, (long long)t * hop - s.pad, lane, a.pad_mode, xf);
+      if (t + 1 < t1) load_frame_raw<R>(zrow, a.L, (long long)(t + 1) * hop - s.pad, lane, a.pad_mode, zn);
+      semi_frame_td<R, EARLY, EVAL>(a, fi, k, lds_win, lds_tw1, tr, z, xf, sd, so);
+      if ((slot0 & 1) == 0) {                              // register pairs stay aligned in the ring
+        v2f* r2 = reinterpret_cast<v2f*>(ring);
+        const int h0 = slot0 >> 1;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          int i = h0 + 64 * u + lane;
+          if (i >= M) i -= M;
+          r2[i] = r2[i] + z[u] * lds_win[64 * u + lane];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const v2f v = z[u] * lds_win[64 * u + lane];
+          int i = slot0 + 128 * u + 2 * lane;
+          if (i >= N) i -= N;
+          const int i1 = i + 1 == N ? 0 : i + 1;
+          ring[i] += v.x;
+          ring[i1] += v.y;
+        }
+      }
+      // the hop samples no later frame reaches: x_{t+1} and z_{t+1} = x_{t+1} - lr z_t
+      const long long p0 = (long long)t * hop;
+      for (int j = lane; j < hop; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        const float v = ring[i];
+        ring[i] = 0.0f;
+        const long long p = p0 + j, n = p - s.pad;
+        if (n >= 0 && n < a.L) {
+          if (p < raw_end) {
+            xo[n] = v;                                     // undivided partial sum: k_hop_tails_td finishes x and z
+          } else {
+            const float xv = env_apply(v, env[n]);
+            xo[n] = xv;
+            zo[n] = fmaf(nlr, zrow[n], xv);
+          }
+        }
+      }
+      slot0 += hop;
+      if (slot0 >= N) slot0 -= N;
+    }
+    const long long p0 = (long long)t1 * hop;
+    if (c == a.nchunks - 1) {
+      for (int j = lane; j < keep; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        const long long p = p0 + j, n = p - s.pad;
+        if (n >= 0 && n < a.L) {
+          if (p < raw_end) {
+            xo[n] = ring[i];
+          } else {
+            const float xv = env_apply(ring[i], env[n]);
+            xo[n] = xv;
+            zo[n] = fmaf(nlr, zrow[n], xv);
+          }
+        }
+      }
+    } else {
+      float* tl = s.xtail + ((long long)b * a.nchunks + c) * keep;
+      for (int j = lane; j < keep; j += 64) {
+        int i = slot0 + j;
+        if (i >= N) i -= N;
+        tl[j] = ring[i];
+      }
+    }
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0 && w < a.n_waves) {
+      a.partials[2 * w] = d;
+      a.partials[2 * w + 1] = o;
+    }
+  }
+}
+
+// x[n] = (own partial sum + the previous chunk's tail) * (1 / envelope), z_out[n] = x[n] - lr z_in[n] over the seam samples
+__global__ void k_hop_tails_td(float* __restrict__ x, float* __restrict__ z_out, const float* __restrict__ z_in,
+                               const float* __restrict__ xtail, const float* __restrict__ env, float lr, int T, int nchunks,
+                               int hop, int keep, int pad, long long L, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
+  if (i >= total) return;
+  const int j = (int)(i % keep);
+  const int c = (int)((i / keep) % (nchunks - 1)) + 1;
+  const long long b = i / ((long long)keep * (nchunks - 1));
+  const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+  if (n < 0 || n >= L) return;
+  const float xv = env_apply(x[b * L + n] + xtail[(b * nchunks + (c - 1)) * keep + j], env[n]);
+  x[b * L + n] = xv;
+  z_out[b * L + n] = fmaf(-lr, z_in[b * L + n], xv);
+}
+
 // ---- adjoint of the STFT without the frame round trip: inverse frames + plain overlap-add over the padded signal --------
 // k_fast_inverse_frames' body in k_hop's chunk / ring structure (no envelope): samples inside the signal go to `out`
 // (B, len), the `pad` samples on either side of it to `margins` (B, 2, pad) for the fold of the padding, chunk seams

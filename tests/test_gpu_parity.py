@@ -119,7 +119,7 @@ def test_gla_waveforms(alpha, it):
     assert abs(sc_y - sc_ref) < 1e-5, (sc_y, sc_ref)
 
 
-@pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "generic", "float64"])
+@pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "frame_lds_prespec", "generic", "float64"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
     """g14 (consistent magnitudes of a real signal, true phase perturbed by 0.5 rad): 100 iterations held to the STRICT
@@ -135,18 +135,18 @@ def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
     gate = min(1e-4, max(6 * noise, 3e-6))
     init = T(g["init"])
     hop, w = int(g["hop"]), torch.from_numpy(g["window"])
-    if path in ("fused", "fused_prespec", "frame_lds"):
+    if path in ("fused", "fused_prespec", "frame_lds", "frame_lds_prespec"):
         monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")
-    if path == "frame_lds":
+    if path in ("frame_lds", "frame_lds_prespec"):
         monkeypatch.setenv("SPECINV_DISABLE_FUSED", "1")
     if path == "float64":
         init, w = init.to(torch.complex128), w.double()
     p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], w.dtype, dev())
     if path == "generic":
         p.force_generic(True)
-    want = {"default": "k_semi", "fused": "k_fused_td", "fused_prespec": "k_fused", "frame_lds": "k_hop", "generic": "k_iter_pair",
-            "float64": "k_iter_pair"}[path]
-    p.keep_state(path == "fused_prespec")
+    want = {"default": "k_semi", "fused": "k_fused_td", "fused_prespec": "k_fused", "frame_lds": "k_hop_td", "frame_lds_prespec": "k_hop",
+            "generic": "k_iter_pair", "float64": "k_iter_pair"}[path]
+    p.keep_state(path.endswith("_prespec"))
     p.gla_init(init, None, alpha)
     assert p.launch_geometry["kernel"] == want, p.launch_geometry
     done, _ = p.run(100, 10, 0.0, "sc")
@@ -157,7 +157,7 @@ def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
         assert rel_l2(y, ref) < gate, (path, rel_l2(y, ref), rel_l2(y, ref64), noise)
 
 
-@pytest.mark.parametrize("kernel", ["k_fused4_td", "k_fused4", "k_fused", "k_hop", "k_iter_pair"])
+@pytest.mark.parametrize("kernel", ["k_fused4_td", "k_fused4", "k_fused", "k_hop_td", "k_hop", "k_iter_pair"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 def test_gla_wellconditioned_hop_quarter_100_iterations(alpha, kernel, monkeypatch):
     """g15 (g14's construction at n_fft 1024 / hop 256, the shape class of the headline): 100 iterations of the reference in
@@ -175,12 +175,12 @@ def test_gla_wellconditioned_hop_quarter_100_iterations(alpha, kernel, monkeypat
     monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")
     if kernel == "k_fused":
         monkeypatch.setenv("SPECINV_FUSED_TEMPLATE", "1")
-    if kernel == "k_hop":
+    if kernel in ("k_hop", "k_hop_td"):
         monkeypatch.setenv("SPECINV_DISABLE_FUSED", "1")
     p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], w.dtype, dev())
     if kernel == "k_iter_pair":
         p.force_generic(True)
-    p.keep_state(kernel != "k_fused4_td")
+    p.keep_state(kernel not in ("k_fused4_td", "k_hop_td"))
     p.gla_init(init, None, alpha)
     assert p.launch_geometry["kernel"] == kernel, p.launch_geometry
     done, evals = p.run(100, 10, 0.0, "sc")

@@ -177,15 +177,31 @@ def test_chunked_frame_kernel(n_fft, hop, frames, batch, extra, method, chunked_
         ref, st = oracle.admm(init, max_iter=n_it, rho=0.2, tol=0, eva_iter=3, hop_length=hop, window=w, trace=trace,
                               return_state=True, **okw)
 
-    def run():
+    def run(keep=True):
         plan = make_plan(n_fft, hop, frames, batch, **dict(extra))
-        plan.keep_state()
+        plan.keep_state(keep)
         (plan.gla_init if gla else plan.admm_init)(T(init), None, 0.3 if gla else 0.2)
         done, evals = plan.run(n_it, 3, 0.0, "sc")
         return plan, N(plan.wave()), evals
 
+    if gla:
+        # the default for Griffin-Lim: the same chunk walk with the momentum carried as a signal (k_hop_td) - waveform and
+        # evaluated metric against the oracle; pre_spec is only formed by the kernel below
+        plan_td, y_td, evals_td = run(keep=False)
+        # (large hops stay on k_hop: the signal form's emission loop costs more there than the state traffic it saves)
+        td_expected = hop <= {512: 128, 1024: 448, 2048: 416}[n_fft]
+        assert plan_td.launch_geometry["kernel"] == ("k_hop_td" if td_expected else "k_hop"), plan_td.launch_geometry
+        ref_td = ref.reshape(y_td.shape)
+        assert np.array_equal(np.isfinite(y_td), np.isfinite(ref_td))
+        ok_td = np.isfinite(ref_td)
+        assert rel_l2(y_td[ok_td], ref_td[ok_td]) < 1e-4, rel_l2(y_td[ok_td], ref_td[ok_td])
+        got_td = sc_linear(np.array([m for _, m, _ in evals_td]))
+        want_td = sc_linear(np.array([m for _, m, _ in trace]))
+        assert np.array_equal(np.isnan(got_td), np.isnan(want_td))
+        assert np.nan_to_num(np.abs(got_td - want_td)).max() < 1e-5
     plan, y, evals = run()
     assert plan.path == "frame" and plan.path_code == 3
+    assert plan.launch_geometry["kernel"] == "k_hop"
     ref = ref.reshape(y.shape)
     assert np.array_equal(np.isfinite(y), np.isfinite(ref))
     ok = np.isfinite(ref)
@@ -254,15 +270,23 @@ def test_chunked_frame_kernel_random_shapes(seed, chunked_kernel, monkeypatch):
         pytest.skip("torch.stft itself refuses this padding")
     mag = T(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.02)
 
-    def run():
+    def run(keep=True):
         plan = make_plan(n_fft, hop, frames, batch, window=w, center=center, pad_mode=pad_mode)
-        plan.keep_state()
+        plan.keep_state(keep)
         (plan.gla_init if method == "gla" else plan.admm_init)(None, mag, 0.3 if method == "gla" else 0.5)
         done, evals = plan.run(3, 3, 0.0, "sc")
-        return plan.path_code, N(plan.wave()), N(plan.state_spec(0)), evals[0][1]
+        return plan.path_code, N(plan.wave()), (N(plan.state_spec(0)) if keep else None), evals[0][1]
 
     code, y, st, m = run()
     assert code == 3
+    if method == "gla":
+        # the default kernel (momentum carried as a signal where the hop is small enough): same iterates up to where the linear
+        # combination is rounded
+        code_td, y_td, _, m_td = run(keep=False)
+        assert code_td == 3 and np.array_equal(np.isfinite(y), np.isfinite(y_td))
+        okt = np.isfinite(y)
+        assert rel_l2(y_td[okt], y[okt]) < 2e-5, (rel_l2(y_td[okt], y[okt]), n_fft, hop, frames, batch, center, pad_mode)
+        assert abs(m_td - m) < 1e-3 * max(1.0, abs(m))
     monkeypatch.setenv("SPECINV_DISABLE_HOP", "1")
     code2, y2, st2, m2 = run()
     assert code2 == 2
