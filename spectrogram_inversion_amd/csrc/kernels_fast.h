@@ -2281,10 +2281,15 @@ struct FastState<float> {
     // (n_fft 4096 runs one wave per SIMD: its vector latency, not the state traffic, is what bounds it there - the signal form
     // measured 0.360 against 0.340 ms per iteration and is not used)
     td = md == fast::MODE_GLA && (!semi || hopk) && !use_template && !keep_state && RR <= 16;
-    // k_hop_td writes two signals and re-reads z_t where k_hop writes one: its sample-at-a-time emission loop grows with the hop
-    // and overtakes the saved state traffic (measured, late iterations, 32 768+ frames: n_fft 2048 hop 333 0.179 vs 0.192 ms, hop 600
-    // 0.212 vs 0.201; n_fft 1024 hop 400 0.197 vs 0.225; n_fft 512 hop 100 0.173 vs 0.200, hop 200 0.235 vs 0.221)
-    if (hopk && hop > (RR == 4 ? 128 : RR == 8 ? 448 : 416)) td = false;
+    // k_hop_td writes two signals and re-reads z_t where k_hop writes one: at large hops its emission loop overtakes the saved state
+    // traffic.  Measured crossovers (late iterations, 65 536 frames, tools/r02_hop_td2.sh), emission two samples at a time (even hop,
+    // padding and length) / one at a time: n_fft 2048: wins up to hop 768 (0.350 vs 0.367 ms), loses at 1000 / wins at 333, loses at
+    // 601; n_fft 1024: wins everywhere measured (hop 800: 0.195 vs 0.240) / wins at 301; n_fft 512: wins at 300, loses at 400 / wins
+    // at 100, loses at 201
+    const bool emit_pairs = ((hop | pl.pad) & 1) == 0 && (pl.length & 1) == 0;
+    int hop_td_max = emit_pairs ? (RR == 4 ? 320 : RR == 8 ? 1024 : 800) : (RR == 4 ? 128 : RR == 8 ? 448 : 416);
+    if (const char* e = getenv("SPECINV_HOP_TD_MAX")) hop_td_max = atoi(e);          // (experiments)
+    if (hopk && hop > hop_td_max) td = false;
     if (const char* e = getenv("SPECINV_DISABLE_TD")) {      // tests: the spectral-state kernel
       if (e[0] == '1') td = false;
     }

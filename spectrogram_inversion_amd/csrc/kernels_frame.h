@@ -351,6 +351,8 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
     // padded-signal position p <-> ring slot p mod N; samples below `raw_end` of a later chunk stay undivided
     const long long raw_end = c > 0 ? (long long)t0 * hop + keep : -1;
     int slot0 = (int)(((long long)t0 * hop) % N);          // ring slot of the frame's first sample
+    // even hop, padding and length: ring slots, signal positions and row starts of the emitted samples are all even
+    const bool pairs = ((hop | s.pad) & 1) == 0 && (a.L & 1) == 0;
     // the samples of frame t + 1 are requested before frame t is transformed (they come from L2 / HBM with a latency
     // that two waves per SIMD do not hide)
     constexpr bool PRE = MODE != MODE_INIT;
@@ -385,15 +387,28 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
           ring[i1] += v.y;
         }
       }
-      // the hop samples no later frame reaches
+      // the hop samples no later frame reaches (two at a time when every index involved is even)
       const long long p0 = (long long)t * hop;
-      for (int j = lane; j < hop; j += 64) {
-        int i = slot0 + j;
-        if (i >= N) i -= N;
-        const float v = ring[i];
-        ring[i] = 0.0f;
-        const long long p = p0 + j, n = p - s.pad;
-        if (n >= 0 && n < a.L) xo[n] = p < raw_end ? v : env_apply(v, env[n]);
+      if (pairs) {
+        for (int j = 2 * lane; j < hop; j += 128) {
+          int i = slot0 + j;
+          if (i >= N) i -= N;
+          v2f* rp = reinterpret_cast<v2f*>(ring + i);
+          const v2f v = *rp;
+          *rp = v2f{0.0f, 0.0f};
+          const long long p = p0 + j, n = p - s.pad;
+          if (n >= 0 && n < a.L)
+            *reinterpret_cast<v2f*>(xo + n) = p < raw_end ? v : env_apply(v, *reinterpret_cast<const v2f*>(env + n));
+        }
+      } else {
+        for (int j = lane; j < hop; j += 64) {
+          int i = slot0 + j;
+          if (i >= N) i -= N;
+          const float v = ring[i];
+          ring[i] = 0.0f;
+          const long long p = p0 + j, n = p - s.pad;
+          if (n >= 0 && n < a.L) xo[n] = p < raw_end ? v : env_apply(v, env[n]);
+        }
       }
       slot0 += hop;
       if (slot0 >= N) slot0 -= N;
@@ -585,6 +600,7 @@ __global__ __launch_bounds__(512, 1) void k_hop_td(HopArgs s) {
     for (int u = 0; u < R; ++u) reinterpret_cast<v2f*>(ring)[64 * u + lane] = v2f{0.0f, 0.0f};
     const long long raw_end = c > 0 ? (long long)t0 * hop + keep : -1;
     int slot0 = (int)(((long long)t0 * hop) % N);
+    const bool pairs = ((hop | s.pad) & 1) == 0 && (a.L & 1) == 0;     // (as in k_hop)
     v2f zn[R];
     load_frame_raw<R>(zrow, a.L, (long long)t0 * hop - s.pad, lane, a.pad_mode, zn);
     for (int t = t0; t < t1; ++t) {
@@ -617,19 +633,40 @@ __global__ __launch_bounds__(512, 1) void k_hop_td(HopArgs s) {
       }
       // the hop samples no later frame reaches: x_{t+1} and z_{t+1} = x_{t+1} - lr z_t
       const long long p0 = (long long)t * hop;
-      for (int j = lane; j < hop; j += 64) {
-        int i = slot0 + j;
-        if (i >= N) i -= N;
-        const float v = ring[i];
-        ring[i] = 0.0f;
-        const long long p = p0 + j, n = p - s.pad;
-        if (n >= 0 && n < a.L) {
-          if (p < raw_end) {
-            xo[n] = v;                                     // undivided partial sum: k_hop_tails_td finishes x and z
-          } else {
-            const float xv = env_apply(v, env[n]);
-            xo[n] = xv;
-            zo[n] = fmaf(nlr, zrow[n], xv);
+      if (pairs) {
+        for (int j = 2 * lane; j < hop; j += 128) {
+          int i = slot0 + j;
+          if (i >= N) i -= N;
+          v2f* rp = reinterpret_cast<v2f*>(ring + i);
+          const v2f v = *rp;
+          *rp = v2f{0.0f, 0.0f};
+          const long long p = p0 + j, n = p - s.pad;
+          if (n >= 0 && n < a.L) {
+            if (p < raw_end) {
+              *reinterpret_cast<v2f*>(xo + n) = v;         // undivided partial sums: k_hop_tails_td finishes x and z
+            } else {
+              const v2f xv = env_apply(v, *reinterpret_cast<const v2f*>(env + n));
+              const v2f zv = *reinterpret_cast<const v2f*>(zrow + n);
+              *reinterpret_cast<v2f*>(xo + n) = xv;
+              *reinterpret_cast<v2f*>(zo + n) = v2f{fmaf(nlr, zv.x, xv.x), fmaf(nlr, zv.y, xv.y)};
+            }
+          }
+        }
+      } else {
+        for (int j = lane; j < hop; j += 64) {
+          int i = slot0 + j;
+          if (i >= N) i -= N;
+          const float v = ring[i];
+          ring[i] = 0.0f;
+          const long long p = p0 + j, n = p - s.pad;
+          if (n >= 0 && n < a.L) {
+            if (p < raw_end) {
+              xo[n] = v;                                   // undivided partial sum: k_hop_tails_td finishes x and z
+            } else {
+              const float xv = env_apply(v, env[n]);
+              xo[n] = xv;
+              zo[n] = fmaf(nlr, zrow[n], xv);
+            }
           }
         }
       }

@@ -189,7 +189,9 @@ def test_chunked_frame_kernel(n_fft, hop, frames, batch, extra, method, chunked_
         # evaluated metric against the oracle; pre_spec is only formed by the kernel below
         plan_td, y_td, evals_td = run(keep=False)
         # (large hops stay on k_hop: the signal form's emission loop costs more there than the state traffic it saves)
-        td_expected = hop <= {512: 128, 1024: 448, 2048: 416}[n_fft]
+        pad_, len_ = (n_fft // 2 if okw.get("center", True) else 0), plan_td.length
+        pairs = hop % 2 == 0 and pad_ % 2 == 0 and len_ % 2 == 0
+        td_expected = hop <= ({512: 320, 1024: 1024, 2048: 800} if pairs else {512: 128, 1024: 448, 2048: 416})[n_fft]
         assert plan_td.launch_geometry["kernel"] == ("k_hop_td" if td_expected else "k_hop"), plan_td.launch_geometry
         ref_td = ref.reshape(y_td.shape)
         assert np.array_equal(np.isfinite(y_td), np.isfinite(ref_td))
