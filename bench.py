@@ -238,7 +238,8 @@ def main():
                        "k_fused4_td": f"specinv::fast::k_fused4_td<{n_fft // 128}> (momentum carried as a signal; late, early "
                                       f"(+c0) and evaluating launches averaged)",
                        "k_fused": f"specinv::fast::k_fused<{n_fft // 128}, {n_fft // hop}>", "k_semi": "k_semi+k_ola_f4",
-                       "k_hop": "k_hop", "k_iter_pair": "k_iter_pair+k_ola"}[g["kernel"]]
+                       "k_fused_td": f"specinv::fast::k_fused_td<{n_fft // 128}, {n_fft // hop}>", "k_hop": "k_hop",
+                       "k_hop_td": "k_hop_td", "k_iter_pair": "k_iter_pair+k_ola"}[g["kernel"]]
         launches_per_step = iters
         length = plan.length
     elif method == "RTISI_LA":
@@ -381,7 +382,7 @@ def main():
                          "kernel": kernel, "launch_ms": launch_ms, "launches_timed": n_launch,
                          "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_unit": unit_bytes},
         }
-        if method == "griffin_lim" and geo.get("kernel") == "k_fused4_td":
+        if method == "griffin_lim" and geo.get("kernel") in ("k_fused4_td", "k_fused_td"):
             # z in 4h, target 4F, z and x out 8h; the first iterations also read the starting spectrum (8F)
             moved = 12 * hop + 4 * n_freq
             out["roofline"]["moved_bytes_per_unit"] = moved
