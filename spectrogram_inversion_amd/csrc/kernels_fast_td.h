@@ -1,0 +1,355 @@
+// Griffin-Lim on the fused shapes with the momentum carried as a signal: fused_td_body and its two launch forms (k_fused4_td for the
+// headline shapes, k_fused_td<R, OV> for every other overlap).  Included by kernels_fast.h inside namespace specinv::fast, after the
+// wave-level FFT, the block loaders (load_block, load_block4) and FastArgs; the host side is FastState<float>::launch_td there.
+#pragma once
+
+// ---- Griffin-Lim with the momentum carried in the time domain (every fused shape: hop = n_fft/2, /4, /8) ---------------------
+// methods.py:243-244 keep pre_t = STFT(x_t) - lr * pre_{t-1}, a (B, F, T) complex array read and written every iteration
+// (16 F of the 8 hop + 20 F bytes a frame-iteration moves).  The STFT (padding included) is linear, so
+//     pre_t = STFT(z_t) + (-lr)^t * c0,     z_t = x_t - lr * z_{t-1},  z_0 = 0,
+// with c0 the starting spectrum: the recursion can run on the (B, L) signal z instead.  This kernel transforms z_t's
+// frames (one forward FFT, as before), adds the geometrically vanishing c0 term while it is above 2^-30 (EARLY: c0 is read,
+// never written), projects, synthesises x_{t+1} and writes z_{t+1} = x_{t+1} - lr * z_t next to it: the hop-block of z_t that
+// an output block needs is the oldest block of the frame just analysed, still in registers.  Per frame-iteration: 4 hop (z in)
+// + 4 F (target) + 8 hop (z, x out) instead of 8 hop + 20 F bytes; the same arithmetic up to the rounding of where the linear
+// combination is taken (time domain here, frequency domain in the reference).  The evaluating variant transforms x_t's frames
+// as well (|STFT(x_t)| is what the metric wants, methods.py:242).
+//   a.x_in / a.x_out  : z_t / z_{t+1}          a.x2_in / a.x2_out : x_t (EVAL only) / x_{t+1}
+//   a.xtail_in / _out : chunk seams, shared by x and z (the - lr * z_t term goes to the block's owner)
+//   a.P_in, a.Pmid_in : c0 pairs (EARLY)        a.tds : (-lr)^t
+#ifndef SPECINV_TD_STAMPS          // diagnostic build: per-phase s_memtime sums of every wave of k_fused4_td (tools/td_stamps.py)
+#define SPECINV_TD_STAMPS 0
+#endif
+#if SPECINV_TD_STAMPS
+#define TD_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_sum[i] += now_ - stamp_prev; stamp_prev = now_; } while (0)
+#else
+#define TD_STAMP(i) do { } while (0)
+#endif
+
+template <bool FIRST, typename A, typename B>
+__device__ __forceinline__ const auto& td_pick(const A& a, const B& b) {
+  if constexpr (FIRST) return a;
+  else return b;
+}
+
+template <int R>
+__device__ __forceinline__ void td_split(v2f zk, v2f zm, v2f wk, float half_scale, v2f& xk, v2f& xm) {
+  const v2f e2 = add_conj(zk, zm);
+  const v2f tw = cmul_mi(wk, sub_conj(zk, zm));            // W * (-i (Zk - conj Zm))
+  xk = (e2 + tw) * half_scale;
+  xm = (e2 - tw) * v2f{half_scale, -half_scale};
+}
+
+// one hop-block of the sample window (the tuned n_fft/4 copy of the loader where it applies)
+template <int R, int OV>
+__device__ __forceinline__ void td_load_block(const float* __restrict__ xrow, const float* __restrict__ tailrow, long long L,
+                                              int T, int c, int t_begin, int t_end, int j, int lane, int pad_mode,
+                                              v2f (&q)[R / OV]) {
+  if constexpr (OV == 4) load_block4<R>(xrow, tailrow, L, T, c, t_begin, t_end, j, lane, pad_mode, q);
+  else load_block<R, OV>(xrow, tailrow, L, T, c, t_begin, t_end, j, lane, pad_mode, q);
+}
+
+#ifndef SPECINV_TD_MINWAVES
+#define SPECINV_TD_MINWAVES 2
+#endif
+#ifndef SPECINV_TD_ABLATE          // timing-only builds (wrong results): 1 target from frame 0 (L2-resident), 2 no output stores,
+#define SPECINV_TD_ABLATE 0        // 4 z samples from the first hop-blocks (L2-resident)
+#endif
+template <int R, int OV, bool EARLY, bool EVAL>
+__device__ __forceinline__ void fused_td_body(const FastArgs& a) {
+  using G = Geo<R>;
+  using O = Ovl<R, OV>;
+  constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);   // W_M^(l*k1)
+  }
+  __syncthreads();
+
+  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  if (w >= a.n_waves) return;
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  const int t_begin = chunk_begin(c, a.T, a.nchunks);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  const float* zrow = a.x_in + (long long)b * a.L;
+  const float* tailrow = a.xtail_in + (long long)b * a.nchunks * NB * HOP;
+  float* zorow = a.x_out + (long long)b * a.L;
+  float* xorow = a.x2_out + (long long)b * a.L;
+  const float half_scale = 0.5f * a.fwd_scale;
+  const float nlr = -a.coef;
+
+  v2f acc[NB * QU];
+#pragma unroll
+  for (int i = 0; i < NB * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
+  double sd = 0.0, so = 0.0;
+  // pass-1 twiddles in registers - except in the variant that holds c0 and evaluates (one launch in ten of the first few
+  // iterations), which has no room for them at n_fft 2048 and reads the LDS table instead
+  constexpr bool TWLDS = (EARLY && EVAL && R >= 16) || SPECINV_TD_MINWAVES == 3;
+  TwRegs<TWLDS ? 2 : R> twr_regs;
+  if (!TWLDS) {
+#pragma unroll
+    for (int k1 = 1; k1 < R; ++k1) twr_regs.w[(TWLDS ? 1 : k1) - 1] = lds_tw1[(k1 - 1) * 64 + lane];
+  }
+  const TwLds twr_lds{lds_tw1, lane};
+  const auto& twr = td_pick<TWLDS>(twr_lds, twr_regs);
+
+  // samples of z_t: three hop-blocks carried from frame to frame plus the new one, fetched one frame ahead
+  v2f xq[NB][QU], xn[QU];
+#pragma unroll
+  for (int q = 0; q < NB; ++q)
+    td_load_block<R, OV>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + q, lane, a.pad_mode, xq[q]);
+  td_load_block<R, OV>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + NB, lane, a.pad_mode, xn);
+
+#if SPECINV_TD_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
+  for (int t = t_begin; t < t_end; ++t) {
+    TD_STAMP(5);                       // (loop overhead / nothing on the first pass)
+    asm volatile("" ::: "memory");     // (window / twiddle reads stay inside the loop: hoisted they pin ~80 VGPRs)
+    v2f wn = k.wn;
+    asm volatile("" : "+v"(wn));
+    const long long fi = (long long)b * a.T + t;
+    v4f mm[H / 2];
+    v4f pp[EARLY ? H : 1];
+    v2f pmid = v2f{0.0f, 0.0f};
+    float mmid = 0.0f;
+    __builtin_amdgcn_s_setprio(1);
+    {
+      const v4f* min_ = a.m_pairs + ((SPECINV_TD_ABLATE & 1) ? (long long)(fi & 255) : fi) * (H / 2 * 64);
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]);
+      if (lane == 0) {
+        mmid = a.m_mid[fi];
+        if (EARLY) pmid = a.Pmid_in[fi];
+      }
+    }
+#define SPECINV_TD_C0_LOADS()                                                              \
+    if (EARLY) {                                                                           \
+      const v4f* pin_ = a.P_in + fi * (H * 64);                                            \
+      _Pragma("unroll") for (int j = 0; j < H; ++j) pp[j] = ld_stream(&pin_[j * 64u + ulane]); \
+    }
+    if (!EVAL) SPECINV_TD_C0_LOADS();      // (in flight during the forward FFT; the evaluating variant has no registers for
+                                           // them before its first transform is done)
+
+    v2f z[R];
+    if (EVAL) {
+      // |STFT(x_t)| against the target (methods.py:242): x_t's frame, transformed and dropped
+      const float* xrow = a.x2_in + (long long)b * a.L;
+#pragma unroll
+      for (int qq = 0; qq < OV; ++qq) {
+        v2f q[QU];
+        td_load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + qq, lane, a.pad_mode, q);
+#pragma unroll
+        for (int i = 0; i < QU; ++i) z[qq * QU + i] = q[i] * lds_win[64 * (qq * QU + i) + lane];
+      }
+      fft_forward_t<R>(z, k, twr, tr);
+      v2f rc[H];
+#pragma unroll
+      for (int m = H; m < R; ++m) {
+        const v2f got = shfl2(z[m], k.partner);
+        const v2f own = z[(m + 1) % R];
+        rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+      }
+      // a frame's 2 H + 1 terms per lane are summed in float32 (relative error 1e-7: the metric is compared to 1e-5), the
+      // frames in float64 - this kernel is bound by its vector instructions, float64 ones cost several each
+      float fd = 0.0f, fo = 0.0f;
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
+        v2f xk, xm;
+        td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, xk, xm);
+        const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+        const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+        const float ok = fast_abs(xk), om = fast_abs(xm);
+        const float dk = ok - mk, dm = om - mq;
+        fd = fmaf(dk, dk, fmaf(dm, dm, fd));
+        fo = fmaf(ok, ok, fmaf(om, om, fo));
+      }
+      if (lane == 0) {
+        const float o = fast_abs(z[H] * v2f{a.fwd_scale, -a.fwd_scale});
+        const float d = o - mmid;
+        fd = fmaf(d, d, fd);
+        fo = fmaf(o, o, fo);
+      }
+      sd += (double)fd;
+      so += (double)fo;
+      asm volatile("" ::: "memory");       // (keeps the scheduler from hoisting the loads into the transform above)
+      __builtin_amdgcn_sched_barrier(0);
+      SPECINV_TD_C0_LOADS();
+    }
+#undef SPECINV_TD_C0_LOADS
+
+    // ---- analysis of z_t's frame; its oldest hop-block is the one this frame's output block needs
+    v2f zold[QU];
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+      zold[i] = xq[0][i];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) z[q * QU + i] = xq[q][i] * lds_win[64 * (q * QU + i) + lane];
+      z[NB * QU + i] = xn[i] * lds_win[64 * (NB * QU + i) + lane];
+#pragma unroll
+      for (int q = 0; q + 1 < NB; ++q) xq[q][i] = xq[q + 1][i];
+      xq[NB - 1][i] = xn[i];
+    }
+    if (t + 1 < t_end)
+      td_load_block<R, OV>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, (SPECINV_TD_ABLATE & 4) ? 8 + (t & 3) : t + OV, lane, a.pad_mode, xn);
+    __builtin_amdgcn_s_setprio(0);
+    TD_STAMP(0);
+
+    fft_forward_t<R>(z, k, twr, tr);
+    TD_STAMP(1);
+
+    v2f rc[H];
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];              // lane 0 is its own partner, shifted by one register
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+
+    // ---- per pair: split -> (+ c0 term) -> projection -> fold back
+    v2f back[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
+      v2f sk, sm;
+      td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
+      if (EARLY) {
+        sk = v2f{fmaf(a.tds, pp[j].x, sk.x), fmaf(a.tds, pp[j].y, sk.y)};
+        sm = v2f{fmaf(a.tds, pp[j].z, sm.x), fmaf(a.tds, pp[j].w, sm.y)};
+      }
+      const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+      const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+#if SPECINV_IEEE
+      const float dk = fast_abs(sk) + 1e-16f, dq = fast_abs(sm) + 1e-16f;
+      v2f ak = v2f{__fdiv_rn(sk.x * mk, dk) * a.inv_scale, __fdiv_rn(sk.y * mk, dk) * a.inv_scale};
+      v2f am = v2f{__fdiv_rn(sm.x * mq, dq) * a.inv_scale, __fdiv_rn(sm.y * mq, dq) * a.inv_scale};
+#else
+      const float ik = fast_rcp(fast_abs(sk) + 1e-16f) * a.inv_scale, iq = fast_rcp(fast_abs(sm) + 1e-16f) * a.inv_scale;
+      v2f ak = v2f{(sk.x * mk) * ik, (sk.y * mk) * ik};
+      v2f am = v2f{(sm.x * mq) * iq, (sm.y * mq) * iq};
+#endif
+      if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+    v2f zmid;
+    {
+      v2f smid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
+      if (EARLY) smid = v2f{fmaf(a.tds, pmid.x, smid.x), fmaf(a.tds, pmid.y, smid.y)};
+#if SPECINV_IEEE
+      const float dn = fast_abs(smid) + 1e-16f;
+      const v2f am = v2f{__fdiv_rn(smid.x * mmid, dn) * a.inv_scale, __fdiv_rn(smid.y * mmid, dn) * a.inv_scale};
+#else
+      const float inv = fast_rcp(fast_abs(smid) + 1e-16f) * a.inv_scale;
+      const v2f am = v2f{(smid.x * mmid) * inv, (smid.y * mmid) * inv};
+#endif
+      zmid = am * v2f{2.0f, -2.0f};
+    }
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(back[R - 1 - m], k.partner);
+      const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
+      z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
+    }
+    TD_STAMP(2);
+
+    fft_inverse_t<R>(z, k, twr, tr);
+    TD_STAMP(3);
+
+    // ---- synthesis window, register overlap-add, one finished hop-block of x_{t+1} and of z_{t+1} out
+#pragma unroll
+    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    if (t >= PB) {
+      const long long o0 = (long long)(t - PB) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
+      v2f* xo = reinterpret_cast<v2f*>(xorow + o0);
+      v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) {
+        const v2f xv = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
+        const v2f zv = v2f{fmaf(nlr, zold[i].x, xv.x), fmaf(nlr, zold[i].y, xv.y)};
+        if (!(SPECINV_TD_ABLATE & 2) || zv.x == 1.2345e30f) {
+          xo[64u * i + ulane] = xv;
+          zo[64u * i + ulane] = zv;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+#pragma unroll
+      for (int q = 0; q + 1 < NB; ++q) acc[q * QU + i] = acc[(q + 1) * QU + i] + z[(q + 1) * QU + i];
+      acc[(NB - 1) * QU + i] = z[NB * QU + i];
+    }
+    TD_STAMP(4);
+  }
+#if SPECINV_TD_STAMPS
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.stamps[(long long)w * 8 + i] = stamp_sum[i];
+    a.stamps[(long long)w * 8 + 6] = (unsigned long long)(t_end - t_begin);
+  }
+#endif
+  if (t_end == a.T) {
+    // the chunk that holds the last frame also finishes hop-blocks T .. T + PB - 2 (the frames that reach them are done);
+    // xq[q] is z_t's block T + q by now
+#pragma unroll
+    for (int q = 0; q < PB - 1; ++q) {
+      const long long o0 = (long long)(a.T + q - PB) * HOP;
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);
+      v2f* xo = reinterpret_cast<v2f*>(xorow + o0);
+      v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) {
+        const v2f xv = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
+        xo[64u * i + ulane] = xv;
+        zo[64u * i + ulane] = v2f{fmaf(nlr, xq[q][i].x, xv.x), fmaf(nlr, xq[q][i].y, xv.y)};
+      }
+    }
+  } else {
+    // what this chunk's last NB frames contribute to the next chunk's first NB hop-blocks (of x and of z alike)
+    v2f* tl = reinterpret_cast<v2f*>(a.xtail_out + ((long long)b * a.nchunks + c) * NB * HOP);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + (long long)(t_end + q - PB) * HOP);
+#pragma unroll
+      for (int i = 0; i < QU; ++i) tl[(q * QU + i) * 64u + ulane] = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
+    }
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0) {
+      a.partials[2 * (long long)w] = d;
+      a.partials[2 * (long long)w + 1] = o;
+    }
+  }
+}
+
+// the headline shapes (hop = n_fft/4 at n_fft 1024 / 2048) launch 8-wave workgroups, one per CU, like k_fused4
+template <int R, bool EARLY, bool EVAL>
+__global__ __launch_bounds__((SPECINV_TD_MINWAVES == 3 || (SPECINV_R8_W3 && R == 8)) ? 768 : 64 * SPECINV_WGW,
+                            (SPECINV_R8_W3 && R == 8) ? 3 : SPECINV_TD_MINWAVES) void k_fused4_td(FastArgs a) {
+  fused_td_body<R, 4, EARLY, EVAL>(a);
+}
+// every other fused shape: 4-wave workgroups like k_fused<R, OV>
+template <int R, int OV, bool EARLY, bool EVAL>
+__global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_td(FastArgs a) {
+  fused_td_body<R, OV, EARLY, EVAL>(a);
+}
+

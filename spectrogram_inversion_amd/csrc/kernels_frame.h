@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
   }
 }
 
-// ---- k_hop with Griffin-Lim's momentum carried as a signal (kernels_fast.h: fused_td_body has the derivation) ---------------
+// ---- k_hop with Griffin-Lim's momentum carried as a signal (kernels_fast_td.h has the derivation) ---------------
 // pre_t = STFT(z_t) + (-lr)^t c0, z_{t+1} = x_{t+1} - lr z_t.  The wave transforms z_t's frames (a.x_in), an evaluating launch
 // x_t's as well (a.x2_in); the samples that become final after a frame go out as x_{t+1} (a.x2_out) and z_{t+1} (a.x_out), z_t's
 // value at those positions re-read from L2.  Seam samples (first n_fft - hop of a later chunk) leave the kernel as undivided
