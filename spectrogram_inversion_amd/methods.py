@@ -31,6 +31,22 @@ def _format_spec(spec):
     return spec.unsqueeze(0) if spec.dim() == 2 else spec
 
 
+_HALF = {torch.float16: torch.float32, torch.complex32: torch.complex64}
+
+
+def _widen(spec, stft_kwargs):
+    """float16 / complex32 spectrograms (methods.py:52-53 names them) are inverted in float32 and the result is rounded back to
+    float16: the kernels are float32 / float64.  (The reference would compute in half precision itself - where torch.stft can -
+    so its result is the noisier of the two.)  Returns (spec, stft_kwargs, dtype to cast the result to or None)."""
+    if spec.dtype not in _HALF:
+        return spec, stft_kwargs, None
+    kw = dict(stft_kwargs)
+    w = kw.get("window")
+    if isinstance(w, torch.Tensor) and w.dtype == torch.float16:
+        kw["window"] = w.float()
+    return spec.to(_HALF[spec.dtype]), kw, torch.float16
+
+
 def _finish(x, spec, out_device):
     """methods.py:267-270: squeeze unless the input was exactly (1, F, T)."""
     trim_plan_cache()
@@ -101,7 +117,9 @@ def griffin_lim(spec, max_iter=200, tol=1e-6, alpha=0.99, verbose=True, eva_iter
     `torch.stft` arguments the spectrogram was computed with.  Returns (L,) / (B, L).
     """
     assert alpha >= 0
-    return _iterative("gla", spec, alpha, max_iter, tol, verbose, eva_iter, metric, stft_kwargs)
+    spec, stft_kwargs, half = _widen(spec, stft_kwargs)
+    y = _iterative("gla", spec, alpha, max_iter, tol, verbose, eva_iter, metric, stft_kwargs)
+    return y.to(half) if half else y
 
 
 def ADMM(spec, max_iter=1000, tol=1e-6, rho=0.1, verbose=1, eva_iter=10, metric="sc", **stft_kwargs):
@@ -110,7 +128,9 @@ def ADMM(spec, max_iter=1000, tol=1e-6, rho=0.1, verbose=1, eva_iter=10, metric=
     assert max_iter > 0
     assert tol >= 0
     assert isinstance(metric, str) and metric.upper() in _lib.METRICS
-    return _iterative("admm", spec, rho, max_iter, tol, verbose, eva_iter, metric, stft_kwargs)
+    spec, stft_kwargs, half = _widen(spec, stft_kwargs)
+    y = _iterative("admm", spec, rho, max_iter, tol, verbose, eva_iter, metric, stft_kwargs)
+    return y.to(half) if half else y
 
 
 _STFT_KWARGS = tuple(p for p in inspect.signature(torch.stft).parameters if p not in ("input", "n_fft"))
@@ -127,6 +147,7 @@ def RTISI_LA(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, alpha=0.
     assert max_iter > 0
     assert alpha >= 0
     assert not spec.is_complex()
+    spec, stft_kwargs, half = _widen(spec, stft_kwargs)
     spec3 = _format_spec(spec)
     args = args_helper(spec3, **stft_kwargs)
     if not asymmetric_window:
@@ -146,7 +167,8 @@ def RTISI_LA(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, alpha=0.
     else:
         plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
         x = plan.rtisi(spec3, look_ahead, asymmetric_window, max_iter, alpha)
-    return _finish(x, spec, spec.device)
+    x = _finish(x, spec, spec.device)
+    return x.to(half) if half else x
 
 
 def _rtisi_with_progress(spec3, look_ahead, asymmetric_window, max_iter, alpha, stft_kwargs):
@@ -169,13 +191,15 @@ def phase_init(spec, **stft_kwargs):
     r"""Single-pass phase initialisation (reference: methods.py:572-615).  Returns a complex
     tensor of the input's shape."""
     assert not spec.is_complex()
+    spec, stft_kwargs, half = _widen(spec, stft_kwargs)
     shape = spec.shape
     spec3 = spec.unsqueeze(0) if spec.dim() == 2 else spec
     assert spec3.dim() == 3
     args = args_helper(spec3, **stft_kwargs)
     device = require_gpu(spec3.device)
     plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
-    return plan.phase_init(spec3).view(shape).to(spec.device)
+    out = plan.phase_init(spec3).view(shape).to(spec.device)
+    return out.to(torch.complex32) if half else out
 
 
 def L_BFGS(spec, transform_fn, samples=None, init_x0=None, outer_max_iter=1000, tol=1e-6, verbose=1, eva_iter=10,

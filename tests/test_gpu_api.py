@@ -413,3 +413,27 @@ def test_two_transforms_on_one_stft_shape_do_not_interfere():
             loss, g = fg(x)
             assert loss < 1e-12 and g.shape == x.shape
     assert refs[0].shape[1] == 513 and refs[1].shape[1] == 40 and refs[2].shape[1] == 64
+
+
+def test_half_precision_spectrograms_are_inverted_in_float32():
+    """methods.py:52-53 names float16 / complex32 inputs.  The kernels are float32 / float64: a half spectrogram is inverted in
+    float32 and the waveform rounded back to float16 - the same samples as inverting `spec.float()` and rounding."""
+    import spectrogram_inversion_amd as si
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2)
+    mag = torch.from_numpy(rng.random((2, 257, 40), dtype=np.float32)).to(dev).half()
+    w = torch.hann_window(512)
+    kw = dict(hop_length=128, window=w)
+    for fn, extra in ((si.griffin_lim, dict(max_iter=8, alpha=0.5, tol=0, verbose=False)),
+                      (si.ADMM, dict(max_iter=6, rho=0.5, tol=0, verbose=False)),
+                      (si.RTISI_LA, dict(look_ahead=2, max_iter=3, verbose=False))):
+        y16 = fn(mag, **extra, **kw)
+        y32 = fn(mag.float(), **extra, **kw)
+        assert y16.dtype == torch.float16 and y16.shape == y32.shape
+        assert torch.equal(y16, y32.half())
+    c16 = si.phase_init(mag, hop_length=128, window=w.half())
+    c32 = si.phase_init(mag.float(), hop_length=128, window=w)
+    assert c16.dtype == torch.complex32
+    assert torch.equal(torch.view_as_real(c16), torch.view_as_real(c32.to(torch.complex32)))
+    y = si.griffin_lim(c16, max_iter=4, alpha=0.3, tol=0, verbose=False, **kw)      # complex32 warm start
+    assert y.dtype == torch.float16 and torch.isfinite(y.float()).all()
