@@ -813,7 +813,7 @@ __device__ __forceinline__ void load_block4(const float* __restrict__ xrow, cons
 }
 
 template <int R, int MODE, bool EVAL>
-#ifndef SPECINV_R8_W3        // n_fft 1024 at hop 256: three waves per SIMD (12-wave workgroups, 3072 wave slots).  The plain launches fit
+#ifndef SPECINV_R8_W3        // n_fft 1024: three waves per SIMD (3072 wave slots; 12-wave workgroups at hop 256).  The plain launches fit
 #define SPECINV_R8_W3 1      // 168 registers (ADMM 2 spilled, the evaluating variants 8-31); measured against two waves per SIMD:
 #endif                       // C4 34.3 -> 32.3 ms per step, Griffin-Lim 1024 / 256 0.135 -> 0.127 ms per iteration
 __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW, (SPECINV_R8_W3 && R == 8) ? 3 : SPECINV_MINWAVES) void k_fused4(FastArgs a) {
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
 #include "kernels_fast_td.h"   // k_fused4_td / k_fused_td: the same iteration with the momentum carried as a signal
 
 template <int R, int OV, int MODE, bool EVAL>
-__global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused(FastArgs a) {
+__global__ __launch_bounds__(256, R >= 32 ? 1 : (SPECINV_R8_W3 && R == 8) ? 3 : SPECINV_MINWAVES) void k_fused(FastArgs a) {
   using G = Geo<R>;
   using O = Ovl<R, OV>;
   constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
@@ -1895,7 +1895,7 @@ struct FastState<float> {
     // reflected edge samples must not fall on split blocks (first / last chunk long enough): chunks of >= 8 (16) frames.
     const int floor_ch = OV == 8 ? 16 : 8;
     long long slots = 1024LL * (R >= 32 ? 1 : R <= 4 ? 3 : 2);
-    if (SPECINV_R8_W3 && R == 8 && OV == 4) slots = 3072;
+    if (SPECINV_R8_W3 && R == 8) slots = 3072;
     if (const char* e = getenv("SPECINV_FUSED_SLOTS")) slots = atoll(e);      // (experiments: wave slots of the chip)
     int best_nch = 1;
     double best_cost = 1e300;

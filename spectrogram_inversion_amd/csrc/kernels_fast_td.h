@@ -349,7 +349,7 @@ __global__ __launch_bounds__((SPECINV_TD_MINWAVES == 3 || (SPECINV_R8_W3 && R ==
 }
 // every other fused shape: 4-wave workgroups like k_fused<R, OV>
 template <int R, int OV, bool EARLY, bool EVAL>
-__global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_td(FastArgs a) {
+__global__ __launch_bounds__(256, R >= 32 ? 1 : (SPECINV_R8_W3 && R == 8) ? 3 : SPECINV_MINWAVES) void k_fused_td(FastArgs a) {
   fused_td_body<R, OV, EARLY, EVAL>(a);
 }
 
