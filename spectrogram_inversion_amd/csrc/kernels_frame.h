@@ -314,6 +314,9 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
 // chunk lack what the earlier chunk's last frames add: the later chunk stores its own partial sums undivided, the
 // earlier one leaves the rest of its ring in `xtail`, and k_hop_tails adds the two and divides (a few MB per
 // iteration).  x ping-pongs between two buffers, the spectral state is updated in place.
+#ifndef SPECINV_HOP_R8_W2     // k_hop at n_fft 1024: 128 registers (2 - 13 spilled), so that two 8-wave workgroups fit a CU like the host's
+#define SPECINV_HOP_R8_W2 1     // 4096 wave slots assume: ADMM 1024 / 160 0.191 -> 0.182 ms, 1024 / 300 0.197 -> 0.184 (k_hop_td fits as it is and
+#endif                          // measured 5 % slower under the same bound)
 struct HopArgs {
   FastArgs f;              // x_in, x_out, P_out (in place), U_out, m_pairs, ..., nchunks, n_waves, L, T, pad_mode, partials
   const float* env;        // (L) reciprocal of the overlap-add envelope
@@ -324,7 +327,7 @@ struct HopArgs {
 __host__ __device__ inline int hop_chunk_begin(int c, int T, int nchunks) { return (int)((long long)c * T / nchunks); }
 
 template <int R, int MODE, bool EVAL>
-__global__ __launch_bounds__(512, 1) void k_hop(HopArgs s) {
+__global__ __launch_bounds__(512, (SPECINV_HOP_R8_W2 && R == 8) ? 4 : 1) void k_hop(HopArgs s) {
   using G = Geo<R>;
   constexpr int M = G::M, N = G::N;
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+V=$GRAFT_REPO_ROOT/spectrogram_inversion_amd/variants/libspecinv_hopw2.so
+for cfg in "1024 160 2048 32 gla" "1024 300 2048 32 gla" "1024 600 2048 32 gla" "1024 160 2048 32 admm" "1024 300 2048 32 admm"; do
+  set -- $cfg
+  for lib in "" "$V"; do
+    echo -n "n_fft $1 hop $2 T $3 B $4 $5 ${lib:+hopw2}: "; SPECINV_LIB=$lib python tools/bench_iter.py --n-fft $1 --hop $2 --frames $3 --batch $4 --method $5 2>/dev/null | tail -1 | cut -c22-100
+  done
+done
