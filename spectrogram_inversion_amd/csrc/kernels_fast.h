@@ -2155,6 +2155,9 @@ struct FastState<float> {
   int fused_wgw() const {
     if (const char* e = getenv("SPECINV_FUSED_WGW")) return atoi(e);           // (experiments)
     if (SPECINV_R8_W3 && R == 8 && OV == 4 && !use_template && n_waves >= 3072) return 12;
+    // (the signal-form kernel at n_fft 2048 measured 2 % faster with two 4-wave workgroups per CU than with one 8-wave one:
+    // C2 25.8 vs 26.3 ms per step on one box, three runs each - the opposite of k_fused4)
+    if (td && R == 16 && OV == 4) return 4;
     if ((R == 8 || R == 16) && OV == 4 && !use_template) return n_waves >= 2048 ? SPECINV_WGW : 4;
     return 4;
   }
