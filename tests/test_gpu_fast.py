@@ -601,3 +601,45 @@ def test_time_domain_momentum_against_spectral_state(n_fft, batch, frames, ov, a
     e_td, e_sp = segment_errors(ya[:nb], y64, hop), segment_errors(yb[:nb], y64, hop)
     assert np.median(e_td) < 1.5 * np.median(e_sp) + 1e-7, (np.median(e_td), np.median(e_sp))
     assert np.quantile(e_td, 0.9) < 2 * np.quantile(e_sp, 0.9) + 1e-6, (np.quantile(e_td, 0.9), np.quantile(e_sp, 0.9))
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch", [(2048, 512, 80, 3), (1024, 256, 130, 2), (1024, 128, 90, 2), (1024, 200, 120, 3)])
+def test_signal_form_state_does_not_leak_between_runs(n_fft, hop, frames, batch):
+    """One plan, many runs: the signal-form kernels keep an iteration counter, two signal buffers and (early on) read the starting
+    spectrum - re-initialising with another alpha, running ADMM in between, splitting the iterations over several calls or
+    reading the waveform in the middle must not change a run: bit-identical to the same run on a fresh plan."""
+    rng = np.random.default_rng(n_fft + hop)
+    mag = torch.from_numpy(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.01).to(dev())
+    w = torch.from_numpy(hann(n_fft))
+
+    def fresh():
+        return Plan(args_helper(mag, hop_length=hop, window=w), batch, frames, torch.float32, dev())
+
+    p = fresh()
+    p.gla_init(None, mag, 0.3)
+    assert p.launch_geometry["kernel"].endswith("_td"), p.launch_geometry
+    s_ref = p.iterate(20, eval_last=True)
+    w_ref = p.wave().clone()
+    del p
+    p = fresh()
+    p.gla_init(None, mag, 0.99)
+    p.iterate(5)
+    p.gla_init(None, mag, 0.3)                     # a new run on a used plan
+    p.iterate(3)
+    _ = p.wave()                                   # reading the waveform in the middle
+    p.iterate(9)
+    p.iterate(7)
+    s = p.iterate(1, eval_last=True)               # ... and an evaluation as a call of its own
+    assert torch.equal(p.wave(), w_ref)
+    np.testing.assert_allclose(s, s_ref, rtol=1e-6)          # (evaluating launch of a one-iteration call: same sums)
+    p.admm_init(None, mag, 0.5)
+    p.iterate(4)
+    p.keep_state(True)
+    p.gla_init(None, mag, 0.3)                     # pre_spec itself this time
+    assert not p.launch_geometry["kernel"].endswith("_td")
+    p.iterate(20)
+    assert rel_l2(N(p.wave()), N(w_ref)) < 1e-4
+    p.keep_state(False)
+    p.gla_init(None, mag, 0.3)
+    p.iterate(20)
+    assert torch.equal(p.wave(), w_ref)
