@@ -160,8 +160,8 @@ def sc_lin_f64(x_item, mag_item, hop, window, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
     ap.add_argument("--asym", action="store_true", help="C3: asymmetric_window=True")
