@@ -383,14 +383,15 @@ def main():
                          "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_unit": unit_bytes},
         }
         if method == "griffin_lim" and geo.get("kernel") in ("k_fused4_td", "k_fused_td"):
-            # z in 4h, target 4F, z and x out 8h; the first iterations also read the starting spectrum (8F)
-            moved = 12 * hop + 4 * n_freq
+            # z in 4h, target 4F, z out 4h; x out (+4h) only by the launch before an evaluation and the last of a call; the first
+            # iterations also read the starting spectrum (8F)
+            moved = 8 * hop + 4 * n_freq
             out["roofline"]["moved_bytes_per_unit"] = moved
             out["roofline"]["moved_frac"] = moved * batch * frames / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["note"] = (
                 "achieved / frac price the reference algorithm's bytes (SURVEY 8d: 8 hop + 20 F per frame-iteration, pre_spec "
                 "read and written) as the contract asks; this kernel carries the momentum as a (B, L) signal instead "
-                "(pre_t = STFT(z_t) + (-lr)^t c0, DESIGN 3.1) and moves 12 hop + 4 F - see traffic / moved_frac - so it is no "
+                "(pre_t = STFT(z_t) + (-lr)^t c0, DESIGN 3.1) and moves 8 hop + 4 F - see traffic / moved_frac - so it is no "
                 "longer HBM-bound: the FFTs' vector issue rate bounds it")
         if method == "RTISI_LA":
             steps_dep = (frames + LOOK_AHEAD) * iters

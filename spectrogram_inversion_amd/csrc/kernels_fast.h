@@ -2329,7 +2329,7 @@ struct FastState<float> {
   // the same for Griffin-Lim with the momentum carried as a signal: z from zb[cur] (the first closure call: x itself) to
   // zb[cur ^ 1], x to xb[cur ^ 1]
   template <int RR, typename P>
-  int launch_hop_td(P& pl, bool ev) {
+  int launch_hop_td(P& pl, bool ev, bool need_x) {
     using G = fast::Geo<RR>;
     const int wgw = 8, hop = pl.cfg.hop_length, keep = pl.N() - hop;
     const int nx = cur ^ 1;
@@ -2361,6 +2361,7 @@ struct FastState<float> {
     s.xtail = xtail[0].template as<float>();
     s.hop = hop;
     s.pad = pl.pad;
+    s.write_x = need_x ? 1 : 0;
     const size_t lds = G::lds_bytes(wgw) + (size_t)wgw * G::N * sizeof(float);
     const void* fn = early ? (ev ? (const void*)fast::k_hop_td<RR, true, true> : (const void*)fast::k_hop_td<RR, true, false>)
                            : (ev ? (const void*)fast::k_hop_td<RR, false, true> : (const void*)fast::k_hop_td<RR, false, false>);
@@ -2386,7 +2387,7 @@ struct FastState<float> {
       int rc = SPECINV_OK;
       if (hopk) {
         SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {
-          if (td) rc = launch_hop_td<RR>(pl, ev);
+          if (td) rc = launch_hop_td<RR>(pl, ev, last || (eval_last && i == n_iter - 2));
           else if (mode == fast::MODE_GLA) rc = ev ? launch_hop<RR, fast::MODE_GLA, true>(pl) : launch_hop<RR, fast::MODE_GLA, false>(pl);
           else rc = ev ? launch_hop<RR, fast::MODE_ADMM, true>(pl, last) : launch_hop<RR, fast::MODE_ADMM, false>(pl, last);
         });
@@ -2442,7 +2443,9 @@ struct FastState<float> {
         a.x_in = td_t == 1 ? xb[cur].template as<float>() : zb[cur].template as<float>();
         a.x_out = zb[nx].template as<float>();
         a.x2_in = xb[cur].template as<float>();
-        a.x2_out = xb[nx].template as<float>();
+        // x_{t+1} has a reader only after the last iteration of a call (get_wave, the next call) and before an evaluating launch
+        const bool need_x = i == n_iter - 1 || (eval_last && i == n_iter - 2);
+        a.x2_out = need_x ? xb[nx].template as<float>() : nullptr;
         a.P_in = Pb[0].template as<v4f>();
         a.Pmid_in = Pmid[0].template as<v2f>();
         a.tds = (float)tds;

@@ -14,7 +14,7 @@
 // + 4 F (target) + 8 hop (z, x out) instead of 8 hop + 20 F bytes; the same arithmetic up to the rounding of where the linear
 // combination is taken (time domain here, frequency domain in the reference).  The evaluating variant transforms x_t's frames
 // as well (|STFT(x_t)| is what the metric wants, methods.py:242).
-//   a.x_in / a.x_out  : z_t / z_{t+1}          a.x2_in / a.x2_out : x_t (EVAL only) / x_{t+1}
+//   a.x_in / a.x_out  : z_t / z_{t+1}          a.x2_in / a.x2_out : x_t (EVAL only) / x_{t+1} (nullptr: not wanted)
 //   a.xtail_in / _out : chunk seams, shared by x and z (the - lr * z_t term goes to the block's owner)
 //   a.P_in, a.Pmid_in : c0 pairs (EARLY)        a.tds : (-lr)^t
 #ifndef SPECINV_TD_STAMPS          // diagnostic build: per-phase s_memtime sums of every wave of k_fused4_td (tools/td_stamps.py)
@@ -84,6 +84,9 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   const float* zrow = a.x_in + (long long)b * a.L;
   const float* tailrow = a.xtail_in + (long long)b * a.nchunks * NB * HOP;
   float* zorow = a.x_out + (long long)b * a.L;
+  // x_{t+1} is only written when somebody will read it (a.x2_out given): the launch before an evaluating one and the last one of
+  // a call; the recursion itself runs on z
+  const bool write_x = a.x2_out != nullptr;
   float* xorow = a.x2_out + (long long)b * a.L;
   const float half_scale = 0.5f * a.fwd_scale;
   const float nlr = -a.coef;
@@ -286,7 +289,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
         const v2f xv = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
         const v2f zv = v2f{fmaf(nlr, zold[i].x, xv.x), fmaf(nlr, zold[i].y, xv.y)};
         if (!(SPECINV_TD_ABLATE & 2) || zv.x == 1.2345e30f) {
-          xo[64u * i + ulane] = xv;
+          if (write_x) xo[64u * i + ulane] = xv;
           zo[64u * i + ulane] = zv;
         }
       }
@@ -318,7 +321,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 #pragma unroll
       for (int i = 0; i < QU; ++i) {
         const v2f xv = env_apply(acc[q * QU + i], envp[64u * i + ulane]);
-        xo[64u * i + ulane] = xv;
+        if (write_x) xo[64u * i + ulane] = xv;
         zo[64u * i + ulane] = v2f{fmaf(nlr, xq[q][i].x, xv.x), fmaf(nlr, xq[q][i].y, xv.y)};
       }
     }

@@ -162,6 +162,7 @@ struct SemiArgs {
   float* frames;           // (B*T, N)
   long long n_frames_total;
   int hop, pad;
+  int write_x;             // k_hop_td: 0 = x_{t+1} has no reader (only the seam samples, which the tails kernel needs, are stored)
 };
 
 // One frame of the frame kernels: state in, (samples -> spectrum -> update) unless MODE_INIT, state out, inverse
@@ -322,6 +323,7 @@ struct HopArgs {
   const float* env;        // (L) reciprocal of the overlap-add envelope
   float* xtail;            // (B, nchunks, n_fft - hop)
   int hop, pad;
+  int write_x;             // k_hop_td: 0 = x_{t+1} has no reader (only the seam samples, which the tails kernel needs, are stored)
 };
 
 __host__ __device__ inline int hop_chunk_begin(int c, int T, int nchunks) { return (int)((long long)c * T / nchunks); }
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(512, 1) void k_hop_td(HopArgs s) {
             } else {
               const v2f xv = env_apply(v, *reinterpret_cast<const v2f*>(env + n));
               const v2f zv = *reinterpret_cast<const v2f*>(zrow + n);
-              *reinterpret_cast<v2f*>(xo + n) = xv;
+              if (s.write_x) *reinterpret_cast<v2f*>(xo + n) = xv;
               *reinterpret_cast<v2f*>(zo + n) = v2f{fmaf(nlr, zv.x, xv.x), fmaf(nlr, zv.y, xv.y)};
             }
           }
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(512, 1) void k_hop_td(HopArgs s) {
               xo[n] = v;                                   // undivided partial sum: k_hop_tails_td finishes x and z
             } else {
               const float xv = env_apply(v, env[n]);
-              xo[n] = xv;
+              if (s.write_x) xo[n] = xv;
               zo[n] = fmaf(nlr, zrow[n], xv);
             }
           }
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(512, 1) void k_hop_td(HopArgs s) {
             xo[n] = ring[i];
           } else {
             const float xv = env_apply(ring[i], env[n]);
-            xo[n] = xv;
+            if (s.write_x) xo[n] = xv;
             zo[n] = fmaf(nlr, zrow[n], xv);
           }
         }
