@@ -113,6 +113,16 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
     td_load_block<R, OV>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + q, lane, a.pad_mode, xq[q]);
   td_load_block<R, OV>(zrow, tailrow, a.L, a.T, c, t_begin, t_end, t_begin + NB, lane, a.pad_mode, xn);
 
+  // The overlap-add envelope is periodic in the hop wherever all n_fft / hop frames that cover a sample exist (hop-blocks NB .. T-1:
+  // the same summands in the same order, plan_impl.h): one block of its reciprocal is kept in registers instead of being loaded for
+  // every frame (the evaluating variant has no registers to spare and keeps loading)
+  constexpr bool ENVREG = !EVAL;
+  v2f envc[ENVREG ? QU : 1];
+  if (ENVREG) {
+    const v2f* e0 = reinterpret_cast<const v2f*>(a.inv_env + (long long)(NB - PB) * HOP);
+#pragma unroll
+    for (int i = 0; i < QU; ++i) envc[i] = e0[64u * i + ulane];
+  }
 #if SPECINV_TD_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
@@ -286,7 +296,8 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
 #pragma unroll
       for (int i = 0; i < QU; ++i) {
-        const v2f xv = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
+        const v2f ev = (ENVREG && t >= NB) ? envc[ENVREG ? i : 0] : envp[64u * i + ulane];
+        const v2f xv = env_apply(acc[i] + z[i], ev);
         const v2f zv = v2f{fmaf(nlr, zold[i].x, xv.x), fmaf(nlr, zold[i].y, xv.y)};
         if (!(SPECINV_TD_ABLATE & 2) || zv.x == 1.2345e30f) {
           if (write_x) xo[64u * i + ulane] = xv;
