@@ -813,6 +813,9 @@ __device__ __forceinline__ void load_block4(const float* __restrict__ xrow, cons
 }
 
 template <int R, int MODE, bool EVAL>
+#ifndef SPECINV_K4_ENVREG
+#define SPECINV_K4_ENVREG 1
+#endif
 #ifndef SPECINV_R8_W3        // n_fft 1024: three waves per SIMD (3072 wave slots; 12-wave workgroups at hop 256).  The plain launches fit
 #define SPECINV_R8_W3 1      // 168 registers (ADMM 2 spilled, the evaluating variants 8-31); measured against two waves per SIMD:
 #endif                       // C4 34.3 -> 32.3 ms per step, Griffin-Lim 1024 / 256 0.135 -> 0.127 ms per iteration
@@ -852,6 +855,13 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
 #pragma unroll
   for (int i = 0; i < 3 * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
   double sd = 0.0, so = 0.0;
+  // one block of the envelope reciprocal, periodic in the hop from hop-block 3 on (kernels_fast_td.h), kept in registers
+  v2f envc[SPECINV_K4_ENVREG ? QU : 1];
+  if (SPECINV_K4_ENVREG) {
+    const v2f* e0 = reinterpret_cast<const v2f*>(a.inv_env + (long long)HOP);
+#pragma unroll
+    for (int i = 0; i < QU; ++i) envc[i] = e0[64u * i + ulane];
+  }
 #if SPECINV_TW_REGS
   TwRegs<R> twr;
 #pragma unroll
@@ -1069,7 +1079,8 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
 #pragma unroll
-      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[i] + z[i], envp[64u * i + ulane]);
+      for (int i = 0; i < QU; ++i)
+        outp[64u * i + ulane] = env_apply(acc[i] + z[i], (SPECINV_K4_ENVREG && t >= 3) ? envc[SPECINV_K4_ENVREG ? i : 0] : envp[64u * i + ulane]);
     }
 #if SPECINV_PRIO & 4
     __builtin_amdgcn_s_setprio(0);
