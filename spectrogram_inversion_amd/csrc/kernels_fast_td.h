@@ -1,7 +1,11 @@
 // Griffin-Lim on the fused shapes with the momentum carried as a signal: fused_td_body and its two launch forms (k_fused4_td for the
-// headline shapes, k_fused_td<R, OV> for every other overlap).  Included by kernels_fast.h inside namespace specinv::fast, after the
-// wave-level FFT, the block loaders (load_block, load_block4) and FastArgs; the host side is FastState<float>::launch_td there.
+// headline shapes, k_fused_td<R, OV> for every other overlap).  Built on fast_core.h (the wave-level FFT, the block loaders load_block /
+// load_block4, FastArgs); compiled in tu_td_*.hip; the host side is FastState<float>::launch_td (fast_state.h).
 #pragma once
+#include "fast_core.h"
+
+namespace specinv {
+namespace fast {
 
 // ---- Griffin-Lim with the momentum carried in the time domain (every fused shape: hop = n_fft/2, /4, /8) ---------------------
 // methods.py:243-244 keep pre_t = STFT(x_t) - lr * pre_{t-1}, a (B, F, T) complex array read and written every iteration
@@ -32,13 +36,6 @@ __device__ __forceinline__ const auto& td_pick(const A& a, const B& b) {
   else return b;
 }
 
-template <int R>
-__device__ __forceinline__ void td_split(v2f zk, v2f zm, v2f wk, float half_scale, v2f& xk, v2f& xm) {
-  const v2f e2 = add_conj(zk, zm);
-  const v2f tw = cmul_mi(wk, sub_conj(zk, zm));            // W * (-i (Zk - conj Zm))
-  xk = (e2 + tw) * half_scale;
-  xm = (e2 - tw) * v2f{half_scale, -half_scale};
-}
 
 // one hop-block of the sample window (the tuned n_fft/4 copy of the loader where it applies)
 template <int R, int OV>
@@ -367,3 +364,5 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : (SPECINV_R8_W3 && R == 8) ? 3 : 
   fused_td_body<R, OV, EARLY, EVAL>(a);
 }
 
+}  // namespace fast
+}  // namespace specinv

@@ -1,65 +1,17 @@
-// Frame kernels on the wave-level FFT of kernels_fast.h (float32, one-sided, n_fft 512 ... 4096, ANY hop / centring /
+// Frame kernels on the wave-level FFT of fast_core.h (float32, one-sided, n_fft 512 ... 4096, ANY hop / centring /
 // pad mode): the stand-alone transforms (k_fast_stft, k_fast_inverse_frames), one iteration a frame at a time
 // (k_semi + the gather overlap-add of kernels_generic.h), the same over chunks of frames with the overlap-add in an LDS
 // ring (k_hop + k_hop_tails), and the adjoint of the analysis in that structure (k_hop_inverse + k_hop_tails_raw).
-// Included by kernels_fast.h after the FFT / update primitives; the host side is FastState<float> there.
+// Built on fast_core.h; compiled in tu_frame_*.hip; the host side is FastState<float> (fast_state.h).
 #pragma once
+#include "fast_core.h"
 
 namespace specinv {
 namespace fast {
 
 // ---- stand-alone transforms on the wave-level FFT (any hop; used by specinv_stft and the L_BFGS objective) ----
-// windowed frame starting at signal index `start` (may reach into the reflect padding) -> registers
-template <int R>
-__device__ __forceinline__ void load_frame_raw(const float* __restrict__ xrow, long long len, long long start, int lane,
-                                               int pad_mode, v2f (&z)[R]) {
-  constexpr int N = Geo<R>::N;
-  if (start >= 0 && start + N <= len && (start & 1) == 0) {
-    const v2f* src = reinterpret_cast<const v2f*>(xrow + start);
-#pragma unroll
-    for (int u = 0; u < R; ++u) z[u] = src[64u * u + (unsigned)lane];
-  } else if (start >= 0 && start + N <= len) {   // inside the signal at an odd offset: two 4-byte loads per register
-    const float* src = xrow + start;
-#pragma unroll
-    for (int u = 0; u < R; ++u) z[u] = v2f{src[128u * u + 2u * (unsigned)lane], src[128u * u + 2u * (unsigned)lane + 1u]};
-  } else {
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      const long long n0 = pad_index(start + 128 * u + 2 * lane, len, pad_mode);
-      const long long n1 = pad_index(start + 128 * u + 2 * lane + 1, len, pad_mode);
-      z[u] = v2f{n0 < 0 ? 0.0f : xrow[n0], n1 < 0 ? 0.0f : xrow[n1]};
-    }
-  }
-}
 
-template <int R>
-__device__ __forceinline__ void load_frame_regs(const float* __restrict__ xrow, long long len, long long start, int lane,
-                                                int pad_mode, const v2f* __restrict__ lds_win, v2f (&z)[R]) {
-  load_frame_raw<R>(xrow, len, start, lane, pad_mode, z);
-#pragma unroll
-  for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
-}
 
-struct FastXformArgs {
-  const float* x;        // (B, len)
-  v2f* spec;             // (B*T, F) frame-major, natural bin order
-  float* frames;         // (B*T, N)
-  const float* window;
-  long long len, n_frames_total;
-  int T, hop, pad, pad_mode;
-  float scale;
-};
-
-template <int R>
-__device__ __forceinline__ void xform_tables(const float* __restrict__ window, v2f* lds_win, v2f* lds_tw1) {
-  constexpr int M = Geo<R>::M;
-  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{window[2 * i], window[2 * i + 1]};
-  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
-    const int k1 = i / 64 + 1, l = i & 63;
-    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
-  }
-  __syncthreads();
-}
 
 // torch.stft (center, reflect, onesided): one wave per frame, spectrum written in natural bin order
 // (register j of lane l is bin l + 64 j: every store instruction covers 64 consecutive bins)
@@ -156,14 +108,6 @@ __global__ __launch_bounds__(256) void k_fast_inverse_frames(FastXformArgs a) {
 // straight from x, any hop, any pad mode) and writes the windowed synthesis frame to `frames`; k_ola then does the
 // overlap-add / envelope division.  Costs one frame round trip (8 N bytes per frame) more than k_fused; used when
 // hop != n_fft/4 or centre = False.  MODE_INIT synthesises the stored spectrum as it is (the initial ISTFT).
-constexpr int MODE_INIT = 2;
-struct SemiArgs {
-  FastArgs f;              // x_in, P_in (updated in place), U_in, m_pairs, ..., L, T, pad_mode, coef, scales, partials
-  float* frames;           // (B*T, N)
-  long long n_frames_total;
-  int hop, pad;
-  int write_x;             // k_hop_td: 0 = x_{t+1} has no reader (only the seam samples, which the tails kernel needs, are stored)
-};
 
 // One frame of the frame kernels: state in, (samples -> spectrum -> update) unless MODE_INIT, state out, inverse
 // transform.  On return z holds the synthesis frame before its window (register u <-> samples 128u + 2 lane, +1).
@@ -315,18 +259,6 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
 // chunk lack what the earlier chunk's last frames add: the later chunk stores its own partial sums undivided, the
 // earlier one leaves the rest of its ring in `xtail`, and k_hop_tails adds the two and divides (a few MB per
 // iteration).  x ping-pongs between two buffers, the spectral state is updated in place.
-#ifndef SPECINV_HOP_R8_W2     // k_hop at n_fft 1024: 128 registers (2 - 13 spilled), so that two 8-wave workgroups fit a CU like the host's
-#define SPECINV_HOP_R8_W2 1     // 4096 wave slots assume: ADMM 1024 / 160 0.191 -> 0.182 ms, 1024 / 300 0.197 -> 0.184 (k_hop_td fits as it is and
-#endif                          // measured 5 % slower under the same bound)
-struct HopArgs {
-  FastArgs f;              // x_in, x_out, P_out (in place), U_out, m_pairs, ..., nchunks, n_waves, L, T, pad_mode, partials
-  const float* env;        // (L) reciprocal of the overlap-add envelope
-  float* xtail;            // (B, nchunks, n_fft - hop)
-  int hop, pad;
-  int write_x;             // k_hop_td: 0 = x_{t+1} has no reader (only the seam samples, which the tails kernel needs, are stored)
-};
-
-__host__ __device__ inline int hop_chunk_begin(int c, int T, int nchunks) { return (int)((long long)c * T / nchunks); }
 
 template <int R, int MODE, bool EVAL>
 __global__ __launch_bounds__(512, (SPECINV_HOP_R8_W2 && R == 8) ? 4 : 1) void k_hop(HopArgs s) {
@@ -712,36 +644,11 @@ __global__ __launch_bounds__(512, 1) void k_hop_td(HopArgs s) {
   }
 }
 
-// x[n] = (own partial sum + the previous chunk's tail) * (1 / envelope), z_out[n] = x[n] - lr z_in[n] over the seam samples
-__global__ void k_hop_tails_td(float* __restrict__ x, float* __restrict__ z_out, const float* __restrict__ z_in,
-                               const float* __restrict__ xtail, const float* __restrict__ env, float lr, int T, int nchunks,
-                               int hop, int keep, int pad, long long L, long long total) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
-  if (i >= total) return;
-  const int j = (int)(i % keep);
-  const int c = (int)((i / keep) % (nchunks - 1)) + 1;
-  const long long b = i / ((long long)keep * (nchunks - 1));
-  const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
-  if (n < 0 || n >= L) return;
-  const float xv = env_apply(x[b * L + n] + xtail[(b * nchunks + (c - 1)) * keep + j], env[n]);
-  x[b * L + n] = xv;
-  z_out[b * L + n] = fmaf(-lr, z_in[b * L + n], xv);
-}
 
 // ---- adjoint of the STFT without the frame round trip: inverse frames + plain overlap-add over the padded signal --------
 // k_fast_inverse_frames' body in k_hop's chunk / ring structure (no envelope): samples inside the signal go to `out`
 // (B, len), the `pad` samples on either side of it to `margins` (B, 2, pad) for the fold of the padding, chunk seams
 // through `xtail` + k_hop_tails_raw.
-struct HopInvArgs {
-  const v2f* spec;         // (B*T, F) frame-major, natural bin order
-  float* out;              // (B, len)
-  float* margins;          // (B, 2, pad)
-  float* xtail;            // (B, nchunks, n_fft - hop)
-  const float* window;
-  long long len;
-  int T, nchunks, n_waves, hop, pad;
-  float scale;
-};
 
 template <int R>
 __global__ __launch_bounds__(512, 1) void k_hop_inverse(HopInvArgs a) {
@@ -848,33 +755,7 @@ __global__ __launch_bounds__(512, 1) void k_hop_inverse(HopInvArgs a) {
   }
 }
 
-// out[n] += the previous chunk's tail over the first n_fft - hop samples of chunks 1.. (all inside the signal: a chunk
-// is at least (n_fft - 1) / hop + 1 frames long)
-__global__ void k_hop_tails_raw(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, int hop, int keep,
-                                int pad, long long L, long long total) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
-  if (i >= total) return;
-  const int j = (int)(i % keep);
-  const int c = (int)((i / keep) % (nchunks - 1)) + 1;
-  const long long b = i / ((long long)keep * (nchunks - 1));
-  const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
-  if (n < 0 || n >= L) return;
-  x[b * L + n] += xtail[(b * nchunks + (c - 1)) * keep + j];
-}
 
-// x[n] = (own partial sum + the previous chunk's tail) * (1 / envelope) over the first n_fft - hop samples of chunks 1..
-__global__ void k_hop_tails(float* __restrict__ x, const float* __restrict__ xtail, const float* __restrict__ env, int T,
-                            int nchunks, int hop, int keep, int pad, long long L, long long total) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
-  if (i >= total) return;
-  const int j = (int)(i % keep);
-  const int c = (int)((i / keep) % (nchunks - 1)) + 1;
-  const long long b = i / ((long long)keep * (nchunks - 1));
-  const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
-  if (n < 0 || n >= L) return;
-  float* px = x + b * L + n;
-  *px = env_apply(*px + xtail[(b * nchunks + (c - 1)) * keep + j], env[n]);
-}
 
 }  // namespace fast
 }  // namespace specinv

@@ -5,7 +5,7 @@
 // handled by a direct small DFT), updated in the frequency domain, transformed back and
 // written out windowed; a second kernel overlap-adds the frames (gather form, so the sum
 // order is fixed and the result is bitwise reproducible) and divides by the envelope.
-// This is the coverage path; the measured path for the headline shapes is kernels_fast.h.
+// This is the coverage path; the measured path for the headline shapes is kernels_fast_td.h / kernels_fused.h on fast_core.h.
 #pragma once
 #include "common.h"
 
@@ -314,7 +314,7 @@ __global__ void k_ola(const T* __restrict__ frames, const T* __restrict__ env, T
 // four consecutive samples per thread (float, hop / n_fft / pad / length all multiples of 4): the four samples
 // share their frame range and sit contiguously in every frame, so each term is one 16-byte load.  Same sums in
 // the same order as k_ola.
-__global__ void k_ola_f4(const float* __restrict__ frames, const float* __restrict__ env, float* __restrict__ x, int n_fft,
+static __global__ void k_ola_f4(const float* __restrict__ frames, const float* __restrict__ env, float* __restrict__ x, int n_fft,
                          int hop, int pad, int n_frames, int64_t length, int64_t total4, int use_env) {
   using f4 = float __attribute__((ext_vector_type(4)));
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -507,7 +507,7 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
 
 // ---- deterministic reductions ----------------------------------------------------------------
 // sums[k] = sum_i partials[n_comp*i + k] for k < n_comp; single workgroup, fixed order.
-__global__ void k_finish_partials(const double* __restrict__ partials, int64_t n, int n_comp,
+static __global__ void k_finish_partials(const double* __restrict__ partials, int64_t n, int n_comp,
                                   double* __restrict__ sums) {
   __shared__ double red[16];
   for (int k = 0; k < n_comp; ++k) {

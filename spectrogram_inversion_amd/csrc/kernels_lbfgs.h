@@ -14,8 +14,8 @@
 
 #include "common.h"
 #include "kernels_generic.h"
-#include "kernels_fast.h"
-#include "kernels_objective.h"
+#include "fast_state.h"
+#include "objective_args.h"
 
 namespace specinv {
 
@@ -58,7 +58,7 @@ __global__ void k_abs_partials(const T* __restrict__ a, int64_t n, double* __res
 }
 
 // out[0] = max_i part[2i], out[1] = sum_i part[2i+1]
-__global__ void k_finish_absmax(const double* __restrict__ part, int n, double* __restrict__ out) {
+static __global__ void k_finish_absmax(const double* __restrict__ part, int n, double* __restrict__ out) {
   __shared__ double red[16];
   double s = 0, m = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -160,7 +160,7 @@ __global__ void k_lbfgs_stats(const T* __restrict__ g, const T* __restrict__ d, 
 }
 
 // out[0..1] = sums of part[4i], part[4i+1]; out[2..3] = maxima of part[4i+2], part[4i+3]   (one workgroup, fixed order)
-__global__ void k_finish_stats(const double* __restrict__ part, int n, double* __restrict__ out) {
+static __global__ void k_finish_stats(const double* __restrict__ part, int n, double* __restrict__ out) {
   __shared__ double red[16];
   __shared__ double mx[2][16];
   double a = 0, b = 0, m0 = 0, m1 = 0;
@@ -245,7 +245,7 @@ __global__ void k_lbfgs_pair_stats(const T* __restrict__ g, const T* __restrict_
 }
 
 // out = {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev}   (one workgroup, fixed order)
-__global__ void k_finish_pair_stats(const double* __restrict__ part, int n, double* __restrict__ out) {
+static __global__ void k_finish_pair_stats(const double* __restrict__ part, int n, double* __restrict__ out) {
   __shared__ double red[16];
   __shared__ double mx[2][16];
   double s[6] = {0, 0, 0, 0, 0, 0}, m0 = 0, m1 = 0;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_multi_dot(const T* __restrict__ g, Mult
 }
 
 // out[j] = sum_b part[j * nb + b]
-__global__ void k_multi_finish(const double* __restrict__ part, int nb, double* __restrict__ out) {
+static __global__ void k_multi_finish(const double* __restrict__ part, int nb, double* __restrict__ out) {
   __shared__ double red[16];
   const int j = blockIdx.x;
   double s = 0;
@@ -546,7 +546,7 @@ int lb_lincomb(P& pl, const void* const* vecs, const double* coef, int k, int64_
 
 // ---- two-loop recursion with device-resident scalars -----------------------------------------------------
 // slot = scale * sum(partials)      (al_i = rho_i * (s_i . q))
-__global__ void k_finish_scaled(const double* __restrict__ part, int n, double scale, double* __restrict__ slot) {
+static __global__ void k_finish_scaled(const double* __restrict__ part, int n, double scale, double* __restrict__ slot) {
   __shared__ double red[16];
   double s = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
@@ -604,7 +604,7 @@ __device__ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return __bui
 
 // mm[bt, m] = sum_f Mel[m, f] * |S[bt, f]|  ->  V = log1p(mm).   S: (BT, F) complex, Mel: (n_mels, F).
 // grid (ceil(BT/32), ceil(n_mels/32)), one wave per block.  Float32 only.
-__global__ __launch_bounds__(64) void k_mel_forward_mfma(const cplx<float>* __restrict__ spec, const float* __restrict__ mel,
+static __global__ __launch_bounds__(64) void k_mel_forward_mfma(const cplx<float>* __restrict__ spec, const float* __restrict__ mel,
                                                          float* __restrict__ mm_out, int64_t BT, int F, int n_mels) {
   __shared__ float sa[32][33];   // Mel tile  [m][k]
   __shared__ float sb[32][33];   // |S| tile  [bt][k]
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void k_mel_forward_splitk(const cplx<float>* _
 }
 
 // mel (n_mels, F) -> tiled[ks][k][m] with m padded to mw and k to 32 * ksteps (zeros)
-__global__ void k_mel_tile(const float* __restrict__ mel, float* __restrict__ tiled, int F, int n_mels, int mw, int64_t total) {
+static __global__ void k_mel_tile(const float* __restrict__ mel, float* __restrict__ tiled, int F, int n_mels, int mw, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int m = i % mw;
@@ -729,7 +729,7 @@ __global__ void k_mel_tile(const float* __restrict__ mel, float* __restrict__ ti
 
 // dA[bt, f] = sum_m dM[bt, m] * Mel[m, f] ; G[bt, f] = dA * S/|S| * (interior ? 1/2 : 1)   (in place over S)
 // grid (ceil(BT/32), ceil(F/32)), one wave per block.
-__global__ __launch_bounds__(64) void k_mel_backward_mfma(cplx<float>* __restrict__ spec, const float* __restrict__ mel,
+static __global__ __launch_bounds__(64) void k_mel_backward_mfma(cplx<float>* __restrict__ spec, const float* __restrict__ mel,
                                                           const float* __restrict__ dM, int64_t BT, int F, int n_mels,
                                                           int n_fft, int onesided) {
   __shared__ float sa[32][33];   // dM tile  [bt][m]
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void k_mel_backward_tiles(cplx<float>* __restr
 }
 
 // mel (n_mels, F) -> tiled_t[ft][m][f] with m padded to mw and f to 32 * ftiles (zeros)
-__global__ void k_mel_tile_t(const float* __restrict__ mel, float* __restrict__ tiled, int F, int n_mels, int mw, int64_t total) {
+static __global__ void k_mel_tile_t(const float* __restrict__ mel, float* __restrict__ tiled, int F, int n_mels, int mw, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int fl = i & 31;
@@ -1030,7 +1030,7 @@ inline int obj_mel_tiles(int n_mels) {
 //   * loss = scale * sum(partials), summed like k_finish_scaled by the last block.
 // A margin sample that also lies in a seam region is finished by its margin thread (own + tail first, then the fold: the order
 // of the separate launches); the seam threads leave those samples alone, so no two threads touch the same sample.
-__global__ void k_objective_epilogue(float* __restrict__ grad, const float* __restrict__ xtail, const float* __restrict__ margins,
+static __global__ void k_objective_epilogue(float* __restrict__ grad, const float* __restrict__ xtail, const float* __restrict__ margins,
                                      const double* __restrict__ part, double* __restrict__ slot, int T, int nchunks, int n_fft, int hop,
                                      int keep, int pad, int pad_mode, int64_t len, int64_t rows, int64_t n_tail, int64_t n_margin,
                                      int n_part, double scale) {

@@ -4,7 +4,7 @@
 //     loss = mean((log1p(Mel |STFT(x)|) - target)^2)   and   d loss / d x
 //
 // One 8-wave workgroup owns a tile of up to 16 consecutive frames of one batch item; the spectrum never leaves the chip.
-//   1. each wave transforms two frames with the wave-level FFT of kernels_fast.h, writes |S| into an LDS tile
+//   1. each wave transforms two frames with the wave-level FFT of fast_core.h, writes |S| into an LDS tile
 //      [bin][frame] and keeps the unit phases S/|S| in registers;
 //   2. forward mel contraction on the matrix cores (v_mfma_f32_16x16x4_f32: exact float32, an fmaf chain): the eight
 //      waves split the 1025 bins (K), partial accumulators are added through LDS in a fixed order;
@@ -23,80 +23,27 @@
 // (obj_build_blocks): adding 0 * x changes nothing, so the result is bit for bit that of the dense contraction, and a mel
 // filterbank - triangles around the diagonal - keeps ~1/3 of its blocks.  A dense matrix keeps all of them.
 #pragma once
+#include "objective_args.h"
 
 namespace specinv {
 namespace fast {
 
-using f32x4 = float __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-#ifndef SPECINV_OBJ_STAMPS        // diagnostic build: s_memtime at the phase boundaries of wave 0 of every workgroup
-#define SPECINV_OBJ_STAMPS 0      // (tools/obj_stamps.py; the shipped kernel executes no stamp)
-#endif
 #if SPECINV_OBJ_STAMPS
 #define OBJ_STAMP(i) do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define OBJ_STAMP(i) do { } while (0)
 #endif
 
-constexpr int kObjWaves = 8;      // waves per workgroup
-constexpr int kObjTile = 16;      // frames per tile (the N of the MFMA), two per wave
-constexpr int kObjRow = 17;       // LDS row stride of the [bin][frame] tiles (odd: column reads are conflict-free)
-
-struct ObjArgs {
-  const float* x;          // (B, len)
-  float* grad;             // (B, len)
-  float* margins;          // (B, 2, pad): gradient w.r.t. the padded samples either side of the signal
-  float* xtail;            // (B, nchunks, n_fft - hop)
-  const float* target;     // (B, n_mels, T), the caller's layout
-  const f32x4* melA;       // forward operand blocks  [E][64] x 4 k-steps: A[i = mel row][k = bin]
-  const f32x4* melB;       // backward operand blocks [E][64] x 4 k-steps: A[i = bin][k = mel row]
-  const int* tab;          // block list, see ObjTab
-  const float* window;
-  double* partials;        // [B * nchunks] squared-error sums
-  long long len;
-  int T, nchunks, hop, pad, pad_mode, n_mels;
-  float fwd_scale;
-  float dscale;            // 2 / numel
-  unsigned hop_magic;      // ceil(2^32 / hop) (hop > 1), for the division-free frame lookup of the overlap-add
-#if SPECINV_OBJ_STAMPS
-  unsigned long long* stamps;   // [tiles][16]
-#endif
-};
-
-// Layout of the block table (ints): the non-zero blocks are sorted by bin group, then mel group.
-//   [0 .. 8]            forward: wave w takes blocks [tab[w], tab[w+1])
-//   [9 .. 17]           backward: wave w takes bin groups [tab[9+w], tab[9+w+1])  (balanced by block count)
-//   [18 .. 18+KQ]       first block of bin group g (KQ + 1 entries)
-//   [19+KQ .. +E)       mel group of block e
-//   [19+KQ+E .. +E)     bin group of block e
-struct ObjTab {
-  static constexpr int FWD = 0, BWD = 9, BEGIN = 18;
-  static constexpr int mel_group(int KQ) { return 19 + KQ; }
-  static constexpr int bin_group(int KQ, int E) { return 19 + KQ + E; }
-};
-
-template <int R, int MT>
-struct ObjGeo {
-  using G = Geo<R>;
-  static constexpr int F = G::M + 1;
-  static constexpr int KQ = (F + 15) / 16;            // groups of 16 bins
-  static constexpr int FP = 16 * KQ;                  // rows of the |S| / dA tile
-  static constexpr int UNI_TR = kObjWaves * G::TR * 2;            // floats: FFT transpose scratch of the waves
-  static constexpr int UNI_RED = kObjWaves * MT * 4 * 64;         // floats: partial accumulators of the forward contraction
-  static constexpr int UNI = UNI_TR > UNI_RED ? UNI_TR : UNI_RED;
-  static constexpr size_t lds_bytes() {
-    return sizeof(v2f) * G::M + sizeof(float) * ((size_t)FP * kObjRow + 16 * MT * kObjRow + UNI);
-  }
-};
 
 // MAG: the magnitude objective mean((|STFT(x)| - target)^2) (`MagSTFT`, the reference's test / demo transform,
 // test/test_lbfgs.py:17-18, main.py:21-43): the same kernel without the contractions - dA = 2/numel (|S| - T) is formed
 // element by element on the |S| tile (MT only sizes the shared scratch then).
-template <int R, int MT, bool MAG = false>
+template <int R, int MT, bool MAG>
 __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs a) {
   using G = Geo<R>;
   using OG = ObjGeo<R, MT>;
@@ -448,60 +395,6 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   OBJ_STAMP(12);
 }
 
-// Host side: cut the filterbank (n_mels x F, row-major, host copy) into 16 x 16 blocks, keep the non-zero ones in
-// operand order and build the block table (ObjTab).
-inline void obj_build_blocks(const float* mel, int F, int n_mels, int MT, std::vector<float>& A, std::vector<float>& B,
-                             std::vector<int>& tab) {
-  const int KQ = (F + 15) / 16;
-  std::vector<int> begin(KQ + 1, 0), mgs, fgs;
-  for (int fg = 0; fg < KQ; ++fg) {
-    begin[fg] = (int)mgs.size();
-    for (int mg = 0; mg < MT; ++mg) {
-      bool any = false;
-      for (int m = 16 * mg; m < std::min(n_mels, 16 * mg + 16) && !any; ++m)
-        for (int f = 16 * fg; f < std::min(F, 16 * fg + 16); ++f)
-          if (mel[(size_t)m * F + f] != 0.0f) {
-            any = true;
-            break;
-          }
-      if (any) {
-        mgs.push_back(mg);
-        fgs.push_back(fg);
-      }
-    }
-  }
-  if (mgs.empty()) {                       // an all-zero filterbank still needs one (zero) block to point the loads at
-    mgs.push_back(0);
-    fgs.push_back(0);
-    for (int fg = 1; fg <= KQ; ++fg) begin[fg] = 1;
-  }
-  const int E = (int)mgs.size();
-  begin[KQ] = E;
-  auto at = [&](int m, int f) { return (m < n_mels && f < F) ? mel[(size_t)m * F + f] : 0.0f; };
-  A.assign((size_t)E * 256, 0.0f);
-  B.assign((size_t)E * 256, 0.0f);
-  for (int e = 0; e < E; ++e)
-    for (int lane = 0; lane < 64; ++lane)
-      for (int j = 0; j < 4; ++j) {
-        // forward: A[i = mel row = lane & 15][k = bin = 4 j + (lane >> 4)]; backward: A[i = bin][k = mel row]
-        A[((size_t)e * 64 + lane) * 4 + j] = at(16 * mgs[e] + (lane & 15), 16 * fgs[e] + 4 * j + (lane >> 4));
-        B[((size_t)e * 64 + lane) * 4 + j] = at(16 * mgs[e] + 4 * j + (lane >> 4), 16 * fgs[e] + (lane & 15));
-      }
-  tab.assign(ObjTab::bin_group(KQ, E) + E, 0);
-  for (int w = 0; w <= kObjWaves; ++w) tab[ObjTab::FWD + w] = (int)((long long)E * w / kObjWaves);
-  for (int w = 0; w <= kObjWaves; ++w) {   // first bin group that starts at or after block E w / 8
-    const int want = (int)((long long)E * w / kObjWaves);
-    int g = 0;
-    while (g < KQ && begin[g] < want) ++g;
-    tab[ObjTab::BWD + w] = w == kObjWaves ? KQ : g;
-  }
-  tab[ObjTab::BWD] = 0;
-  for (int g = 0; g <= KQ; ++g) tab[ObjTab::BEGIN + g] = begin[g];
-  for (int e = 0; e < E; ++e) {
-    tab[ObjTab::mel_group(KQ) + e] = mgs[e];
-    tab[ObjTab::bin_group(KQ, E) + e] = fgs[e];
-  }
-}
 
 }  // namespace fast
 }  // namespace specinv

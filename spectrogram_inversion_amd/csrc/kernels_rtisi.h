@@ -14,7 +14,7 @@
 
 #include "common.h"
 #include "kernels_generic.h"
-#include "kernels_rtisi_fast.h"
+#include "rtisi_fast_host.h"
 
 namespace specinv {
 

@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "kernels_adjoint.h"
-#include "kernels_fast.h"
+#include "fast_state.h"
 #include "kernels_generic.h"
 #include "kernels_lbfgs.h"
 #include "kernels_rtisi.h"

@@ -1,0 +1,26 @@
+// k_fused<32, OV> and the fused initial ISTFT at n_fft 4096.
+// Explicit instantiations: the host side (fast_state.h / rtisi_fast_host.h / kernels_lbfgs.h) takes these kernels' addresses from
+// the declarations in fast_core.h / rtisi_fast_host.h / objective_args.h; a kernel missing here is an undefined symbol at link time.
+#include "kernels_fused.h"
+
+namespace specinv {
+namespace fast {
+
+template __global__ void k_fused<32, 8, MODE_GLA, false>(FastArgs);
+template __global__ void k_fused<32, 8, MODE_GLA, true>(FastArgs);
+template __global__ void k_fused<32, 8, MODE_ADMM, false>(FastArgs);
+template __global__ void k_fused<32, 8, MODE_ADMM, true>(FastArgs);
+template __global__ void k_fused_istft<32, 8>(FastArgs);
+template __global__ void k_fused<32, 4, MODE_GLA, false>(FastArgs);
+template __global__ void k_fused<32, 4, MODE_GLA, true>(FastArgs);
+template __global__ void k_fused<32, 4, MODE_ADMM, false>(FastArgs);
+template __global__ void k_fused<32, 4, MODE_ADMM, true>(FastArgs);
+template __global__ void k_fused_istft<32, 4>(FastArgs);
+template __global__ void k_fused<32, 2, MODE_GLA, false>(FastArgs);
+template __global__ void k_fused<32, 2, MODE_GLA, true>(FastArgs);
+template __global__ void k_fused<32, 2, MODE_ADMM, false>(FastArgs);
+template __global__ void k_fused<32, 2, MODE_ADMM, true>(FastArgs);
+template __global__ void k_fused_istft<32, 2>(FastArgs);
+
+}  // namespace fast
+}  // namespace specinv

@@ -1,0 +1,19 @@
+// k_fused_td<R, OV>: the signal-form Griffin-Lim kernel at the other overlaps, n_fft 2048 (n_fft 4096 stays on the spectral state: one wave per SIMD there).
+// Explicit instantiations: the host side (fast_state.h / rtisi_fast_host.h / kernels_lbfgs.h) takes these kernels' addresses from
+// the declarations in fast_core.h / rtisi_fast_host.h / objective_args.h; a kernel missing here is an undefined symbol at link time.
+#include "kernels_fast_td.h"
+
+namespace specinv {
+namespace fast {
+
+template __global__ void k_fused_td<16, 8, false, false>(FastArgs);
+template __global__ void k_fused_td<16, 8, false, true>(FastArgs);
+template __global__ void k_fused_td<16, 8, true, false>(FastArgs);
+template __global__ void k_fused_td<16, 8, true, true>(FastArgs);
+template __global__ void k_fused_td<16, 2, false, false>(FastArgs);
+template __global__ void k_fused_td<16, 2, false, true>(FastArgs);
+template __global__ void k_fused_td<16, 2, true, false>(FastArgs);
+template __global__ void k_fused_td<16, 2, true, true>(FastArgs);
+
+}  // namespace fast
+}  // namespace specinv

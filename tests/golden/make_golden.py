@@ -594,10 +594,56 @@ def g15_wellcond_1024():
     g14_wellcond("g15_wellcond_1024", n_fft=1024, hop=256, frames=60, seed=150)
 
 
+def g16_headline_2048():
+    """The headline instantiation (n_fft 2048 / hop 512: k_fused4_td<16>, k_fused4<16>, k_hop<16>) against the reference itself.
+    (a) g14's well-conditioned construction at 2048 / 512, 2 items x 64 frames, 100 iterations, alpha 0 / 0.3 / 0.99, float32 and
+    float64 (strict waveform gate).  (b) BASELINE configs[1] exactly as bench.py runs it on rank 0 - magnitudes
+    default_rng(1234).random((64, 1025, 1024), float32), periodic Hann, 100 iterations, alpha 0.3, eva_iter 10, tol 0 - through the
+    unmodified reference: the ten (SC dB, loss) evaluations of the WHOLE batch, the final waveforms of items 0 and 63, and a float64
+    run of those two items (its trace, and the reference's own float32-vs-float64 error per hop segment as the noise yardstick)."""
+    import time
+    g14_wellcond("g16a_wellcond_2048", n_fft=2048, hop=512, frames=64, seed=160)
+    n_fft, hop, frames, batch = 2048, 512, 1024, 64
+    rng = np.random.default_rng(1234)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    win = hann(n_fft)
+    kw = dict(hop_length=hop, window=t(win))
+    t0 = time.time()
+    y = M.griffin_lim(t(mag), max_iter=100, alpha=0.3, tol=0, verbose=True, eva_iter=10, metric="sc", **kw)
+    trace = trace_of(_Bar.last, "sc")
+    print(f"  reference C2 (B=64, float32): {time.time() - t0:.0f} s, trace {trace[:, 0]}")
+    assert trace.shape == (10, 2) and y.shape == (batch, (frames - 1) * hop)
+    items = [0, 63]
+    pair = np.ascontiguousarray(mag[items])
+    y2 = M.griffin_lim(t(pair), max_iter=100, alpha=0.3, tol=0, verbose=True, eva_iter=10, metric="sc", **kw)
+    trace_pair = trace_of(_Bar.last, "sc")
+    same = [bool(torch.equal(y2[i], y[it])) for i, it in enumerate(items)]
+    print(f"  items {items} alone (B=2) equal their rows of the B=64 run bit for bit: {same}")
+    # float64 run of the two items from the float32 phase_init (the reference's float64 phase_init would start elsewhere)
+    init = M.phase_init(t(pair), **kw)
+    y64 = M.griffin_lim(init.to(torch.complex128), max_iter=100, alpha=0.3, tol=0, verbose=True, eva_iter=10, metric="sc",
+                        hop_length=hop, window=t(win.astype(np.float64)))
+    trace64_pair = trace_of(_Bar.last, "sc")
+    out = {"window": win, "hop": np.array(hop), "items": np.array(items), "seed": np.array(1234),
+           "mag_checksum": np.array([float(mag.astype(np.float64).sum()), float(mag[0, 5, 7]), float(mag[63, 1024, 1023])]),
+           "trace": trace, "trace_pair": trace_pair, "trace64_pair": trace64_pair,
+           "rows_equal_pair_run": np.array(same)}
+    for i, it in enumerate(items):
+        a, b = y[it].double().numpy(), y64[i].numpy()
+        seg = np.linalg.norm((a - b).reshape(-1, hop), axis=1) / (np.linalg.norm(b.reshape(-1, hop), axis=1) + 1e-30)
+        out[f"wave_{it}"] = y[it].numpy()
+        out[f"segerr_{it}"] = seg.astype(np.float32)
+        out[f"segnorm64_{it}"] = np.linalg.norm(b.reshape(-1, hop), axis=1).astype(np.float32)
+        out[f"noise_{it}"] = np.array(np.linalg.norm(a - b) / np.linalg.norm(b))
+        print(f"  item {it}: float32 vs float64 rel-L2 {float(out[f'noise_{it}']):.2e}, median segment {np.median(seg):.2e}, "
+              f"segments above 1e-3: {(seg > 1e-3).mean():.3f}")
+    save("g16b_c2_headline", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     table = dict(g0=g0_stft, g1=g1_phase_init, g2=g2_gla, g3=g3_sweep, g4=g4_admm, g5=g5_rtisi,
                  g6=g6_lbfgs, g7=g7_metrics, g8=g8_f64, g9=g9_lbfgs_rosen, g10=g10_autograd, g11=g11_autograd_admm, g12=g12_autograd_rtisi, g13=g13_wave_level_shapes,
-                 g14=g14_wellcond, g15=g15_wellcond_1024)
+                 g14=g14_wellcond, g15=g15_wellcond_1024, g16=g16_headline_2048)
     for w in which:
         table[w]()

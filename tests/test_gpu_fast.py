@@ -1,4 +1,4 @@
-"""The fused wave-per-frame kernels (kernels_fast.h) against the oracle and against the generic
+"""The fused wave-per-frame kernels (fast_core.h, kernels_fused.h, kernels_fast_td.h) against the oracle and against the generic
 kernels, through the C ABI.  Needs an MI355X: `-m gpu`."""
 import os
 
@@ -432,7 +432,7 @@ def test_gradient_with_the_overlap_add_on_chip(pad_mode, n_fft, hop, frames, cen
 @pytest.mark.parametrize("n_fft,batch,frames", [(1024, 3, 70), (2048, 2, 50), (2048, 64, 1024), (1024, 32, 2048)])
 @pytest.mark.parametrize("method", ["gla", "admm"])
 def test_tuned_copy_equals_template(monkeypatch, n_fft, batch, frames, method):
-    """`k_fused4<R>` (kernels_fast.h) is a hand-tuned copy of `k_fused<R, 4>`: whatever is fixed in one must be fixed in
+    """`k_fused4<R>` (kernels_fused.h) is a hand-tuned copy of `k_fused<R, 4>`: whatever is fixed in one must be fixed in
     the other.  SPECINV_FUSED_TEMPLATE=1 makes a plan run the template where the copy would run; waveform, spectral state
     and evaluation sums must agree bit for bit, plain and evaluating launches, small launches (4-wave workgroups) and the
     benchmark geometries (8-wave workgroups of the copy: C2 at B = 64, the C4 shard at B = 32)."""
