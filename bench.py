@@ -53,18 +53,29 @@ def hann(n):
 
 
 def algorithmic_bytes_per_unit(method, hop, n_freq, coef):
-    """SURVEY 8d, one frame through one iteration / evaluation, fp32.  griffin_lim: x read+write 8*hop, target 4F,
-    pre_spec read+write 16F (8*hop + 4F when alpha == 0); ADMM: Y = X + U read+write 16F + target 4F (SURVEY counted X
-    and U separately, 32F: methods.py:467-468 only read their sum, DESIGN 3.1 - the smaller figure is used); L_BFGS objective:
-    x read + gradient write 8*hop, target 4*n_mels; RTISI_LA: target read 4F + committed frame 4*hop per frame
-    (state lives in LDS: the figure is not what bounds that kernel)."""
+    """SURVEY 8d, one frame through one iteration / evaluation of the REFERENCE ALGORITHM, fp32 - the figure `roofline.achieved`
+    and `roofline.frac` price (the contract).  griffin_lim: x read+write 8*hop, target 4F, pre_spec read+write 16F (8*hop + 4F
+    when alpha == 0); ADMM: X and U read+write 32F + target 4F; L_BFGS objective: x read + gradient write 8*hop, target
+    4*n_mels; RTISI_LA: target read 4F + committed frame 4*hop per frame (state lives in LDS: not what bounds that kernel)."""
     if method == "griffin_lim":
         return 8 * hop + (20 if coef != 0 else 4) * n_freq
     if method == "ADMM":
-        return 8 * hop + 20 * n_freq
+        return 8 * hop + 36 * n_freq
     if method == "L_BFGS":
         return 8 * hop + 4 * N_MELS
     return 4 * n_freq + 4 * hop
+
+
+def restated_bytes_per_unit(method, hop, n_freq, kernel):
+    """What the shipped kernel has to move after the reformulations of DESIGN 3.1 (None: the reference algorithm's bytes).
+    Griffin-Lim with the momentum carried as a (B, L) signal: z in 4h, target 4F, z out 4h (x out only when somebody reads it;
+    the first iterations also read the starting spectrum) instead of 8h + 20F; ADMM on Y = X + U alone: 8h + 20F instead of
+    8h + 36F (methods.py:467-468 only ever read X + U)."""
+    if method == "griffin_lim" and kernel in ("k_fused4_td", "k_fused_td", "k_hop_td"):
+        return 8 * hop + 4 * n_freq
+    if method == "ADMM":
+        return 8 * hop + 20 * n_freq
+    return None
 
 
 def _timed_oracle(run, units_per_iter, budget_s, first=2, cap=400):
@@ -106,11 +117,15 @@ def cpu_baseline(method, n_fft, hop, frames, coef, budget_s=15.0):
                               f"workers={cores})"}
         if method == "RTISI_LA":
             b, t, its = 2, 12, 25
-            mag = rng.random((b, n_freq, t), dtype=np.float32)
-            t0 = time.perf_counter()
-            oracle.rtisi_la(mag, look_ahead=LOOK_AHEAD, asymmetric_window=False, max_iter=its, alpha=coef,
-                            hop_length=hop, window=w)
-            dt = time.perf_counter() - t0
+            while True:                                                                # at least ~2 s of work (frame-serial)
+                mag = rng.random((b, n_freq, t), dtype=np.float32)
+                t0 = time.perf_counter()
+                oracle.rtisi_la(mag, look_ahead=LOOK_AHEAD, asymmetric_window=False, max_iter=its, alpha=coef,
+                                hop_length=hop, window=w)
+                dt = time.perf_counter() - t0
+                if dt >= 2.0 or t >= frames:
+                    break
+                t = min(frames, max(2 * t, int(t * 3.0 / max(dt, 1e-3))))
             return {"value": its * b * t / dt, "unit": "iterations*frames/s", "cores": 1, "kind": "port",
                     "sample": f"oracle.rtisi_la batch={b} n_fft={n_fft} hop={hop} n_frames={t} look_ahead={LOOK_AHEAD} "
                               f"{its} iterations ({dt:.1f} s, frame-serial NumPy loop)"}
@@ -135,15 +150,16 @@ def cpu_baseline(method, n_fft, hop, frames, coef, budget_s=15.0):
         stftlib.WORKERS = 1
 
 
-def load_traffic(key):
-    """HBM bytes per launch of the dominant kernel: a STORED figure from the committed PMC summary (profiles/traffic.json,
-    tools/pmc_summary.py), not measured in this run - PMC passes need rocprofv3 around the process."""
+def load_traffic():
+    """Stored counter figures of the dominant kernels: profiles/traffic.json (tools/collect_workload_profiles.py from the
+    committed rocprofv3 --pmc summaries) - HBM bytes per launch, VALU issue share, LDS conflict share - and the hash of the
+    kernel sources they were measured on.  Not measured in this run: PMC passes need rocprofv3 around the process."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get(key)
+            return json.load(fh)
     except (OSError, ValueError):
-        return None
+        return {}
 
 
 def sc_lin_f64(x_item, mag_item, hop, window, dev):
@@ -165,7 +181,11 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
     ap.add_argument("--asym", action="store_true", help="C3: asymmetric_window=True")
-    ap.add_argument("--outer", type=int, default=2, help="C5: optimizer.step calls per bench step")
+    ap.add_argument("--outer", type=int, default=50, help="C5: optimizer.step calls per bench step (BASELINE configs[4]: maxiter=50)")
+    ap.add_argument("--c5-variant", default="baseline", choices=["baseline", "main", "wolfe"],
+                    help="C5 optimiser options: torch.optim.LBFGS defaults (BASELINE); the reference demo's (main.py:43: max_iter 50, "
+                         "history 10); defaults + line_search_fn='strong_wolfe' (steps long enough for the curvature pairs to pass "
+                         "y.s > 1e-10, so the memory fills to history_size = 100 and the recursion's vector passes carry weight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
@@ -222,9 +242,10 @@ def main():
             init(None, mag, coef)                           # phase_init + initial ISTFT
             e0, e1 = ev(), ev()
             e0.record()                                     # HIP events on the stream the kernels are launched on
-            done, _ = plan.run(iters, 10, 0.0, "sc")        # evaluation every 10, sums stay on the device
+            done, evals = plan.run(iters, 10, 0.0, "sc")    # evaluation every 10, sums stay on the device
             e1.record()
             assert done == iters
+            state["evals"] = evals
             events.append((e0, e1, iters))
             finish_step(plan.wave())
         units_per_step = iters * batch * frames
@@ -296,11 +317,15 @@ def main():
 
         from spectrogram_inversion_amd.lbfgs import LBFGS
 
+        opt_kw = {"baseline": {}, "main": dict(max_iter=50, history_size=10),
+                  "wolfe": dict(line_search_fn="strong_wolfe")}[args.c5_variant]
+
         def step():
             x = x_init.clone()
-            opt = LBFGS(x, device=dev)                       # torch.optim.LBFGS defaults: max_iter 20, history 100, lr 1
+            opt = LBFGS(x, device=dev, **opt_kw)             # torch.optim.LBFGS defaults: max_iter 20, history 100, lr 1
             for _ in range(args.outer):
                 opt.step(fg)
+            state["opt"] = opt
             finish_step(x)
         units_per_step = None                               # closure evaluations are counted
         unit = "evaluations*frames/s"
@@ -358,8 +383,8 @@ def main():
                     f"tol=0 eva_iter=10",
             "RTISI_LA": f"RTISI_LA batch={batch}/GPU n_fft={n_fft} hop={hop} n_frames={frames} look_ahead={LOOK_AHEAD} "
                         f"maxiter={iters} alpha={coef} asymmetric_window={args.asym} hann",
-            "L_BFGS": f"L_BFGS log-mel-{N_MELS} batch={batch} n_fft={n_fft} hop={hop} n_frames={frames} {args.outer} "
-                      f"optimizer.step x 20 closure evaluations, history 100, lr 1",
+            "L_BFGS": f"L_BFGS log-mel-{N_MELS} batch={batch} n_fft={n_fft} hop={hop} n_frames={frames} maxiter={args.outer} "
+                      f"(optimizer.step calls) x LBFGS({'defaults: max_iter 20, history 100, lr 1' if not locals().get('opt_kw') else opt_kw})",
         }[method]
         out = {
             "metric": "Griffin-Lim iterations*frames/sec at n_fft=2048 hop=512" if args.workload == "C2"
@@ -384,24 +409,49 @@ def main():
                                 "ADMM": "phase_init + ISTFT + iterations + gather",
                                 "RTISI_LA": "persistent RTISI-LA launch + overlap-add + gather",
                                 "L_BFGS": "optimizer.step calls (objective evaluations + two-loop recursion)"}[method]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_traffic(args.workload if path != "generic" else args.workload + "_generic"),
-                         "traffic_source": "stored: profiles/traffic.json (rocprofv3 --pmc summary), not measured in this run",
-                         "kernel": kernel, "launch_ms": launch_ms, "launches_timed": n_launch,
-                         "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_unit": unit_bytes},
+            "roofline": None,
         }
-        if method == "griffin_lim" and geo.get("kernel") in ("k_fused4_td", "k_fused_td"):
-            # z in 4h, target 4F, z out 4h; x out (+4h) only by the launch before an evaluation and the last of a call; the first
-            # iterations also read the starting spectrum (8F)
-            moved = 8 * hop + 4 * n_freq
-            out["roofline"]["moved_bytes_per_unit"] = moved
-            out["roofline"]["moved_frac"] = moved * batch * frames / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            out["roofline"]["note"] = (
-                "achieved / frac price the reference algorithm's bytes (SURVEY 8d: 8 hop + 20 F per frame-iteration, pre_spec "
-                "read and written) as the contract asks; this kernel carries the momentum as a (B, L) signal instead "
-                "(pre_t = STFT(z_t) + (-lr)^t c0, DESIGN 3.1) and moves 8 hop + 4 F - see traffic / moved_frac - so it is no "
-                "longer HBM-bound: the FFTs' vector issue rate bounds it")
+        # ---- roofline of the dominant kernel.  `achieved` / `frac` price the REFERENCE ALGORITHM's bytes (the contract);
+        # what the shipped kernel moves and what actually bounds it are reported beside them, so that the line alone tells the story
+        kname = (geo or {}).get("kernel")
+        tr = load_traffic()
+        tkey = args.workload if path != "generic" else args.workload + "_generic"
+        traffic = tr.get(tkey)
+        from spectrogram_inversion_amd.build import sources_hash
+        here = sources_hash()
+        stale = tr.get("csrc_sha1") != here
+        restated = restated_bytes_per_unit(method, hop, n_freq, kname)
+        bound = {"griffin_lim": "valu" if restated else "hbm", "ADMM": "hbm", "RTISI_LA": "latency", "L_BFGS": "valu"}[method]
+        if path == "generic":
+            bound = "valu"
+        roof = {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_source": "stored: profiles/traffic.json (rocprofv3 --pmc summary), not measured in this run",
+                "traffic_stale": bool(stale), "traffic_csrc_sha1": tr.get("csrc_sha1"), "csrc_sha1": here,
+                "kernel": kernel, "launch_ms": launch_ms, "launches_timed": n_launch,
+                "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_unit": unit_bytes,
+                "bytes_convention": "SURVEY 8d: the reference algorithm's bytes per frame-iteration"}
+        if traffic:
+            # HBM bytes the counters saw per launch / launch time / peak: the PHYSICAL HBM fraction
+            roof["hbm_physical_frac"] = traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if tr.get(tkey + "_valu_issue_frac") is not None:
+            roof["valu_issue_frac"] = tr[tkey + "_valu_issue_frac"]      # share of the chip's VALU issue slots in use (PMC)
+        if tr.get(tkey + "_lds_conflict_frac") is not None:
+            roof["lds_conflict_frac"] = tr[tkey + "_lds_conflict_frac"]
+        if restated:
+            roof["restated_bytes_per_unit"] = restated
+            roof["restated_frac"] = restated * batch * frames / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if method == "griffin_lim" and restated:
+            roof["note"] = (
+                "frac prices the reference algorithm's 8 hop + 20 F bytes per frame-iteration (pre_spec read and written); this "
+                "kernel carries the momentum as a (B, L) signal (pre_t = STFT(z_t) + (-lr)^t c0, DESIGN 3.1) and moves "
+                "8 hop + 4 F (restated_frac; hbm_physical_frac from the counters), so it is bound by the vector issue rate of "
+                "its two FFTs per frame (valu_issue_frac), not by HBM")
+        if method == "ADMM":
+            roof["note"] = ("frac prices SURVEY's 8 hop + 36 F (X and U read and written); the kernel carries Y = X + U alone "
+                            "(methods.py:467-468 only read the sum, bit-identical): 8 hop + 20 F, restated_frac - the figure to "
+                            "compare with hbm_physical_frac")
+        out["roofline"] = roof
         if method == "RTISI_LA":
             steps_dep = (frames + LOOK_AHEAD) * iters
             out["roofline"]["note"] = ("serial-latency-bound (dependent inner steps; state in LDS / registers): the HBM "
@@ -409,6 +459,13 @@ def main():
             out["roofline"]["dependent_steps_per_s"] = steps_dep / (launch_ms * 1e-3)
         if method == "L_BFGS":
             out["roofline"]["evaluations_timed"] = counters["evals"]
+            opt = state["opt"]
+            out["config"]["lbfgs"] = {"variant": args.c5_variant, "outer_steps": args.outer, "inner_iterations": opt.total_iters,
+                                      "evaluations": opt.func_evals, "pairs_accepted": int(opt.pairs_accepted),
+                                      "pairs_rejected": int(opt.pairs_rejected), "history_len": opt.history_len,
+                                      "history_size": opt.history_size}
+            roof["note"] = ("compute-bound (SURVEY 8d): two FFTs per frame on the vector units + two mel contractions on the "
+                            "matrix cores; frac is the HBM fraction of its 8 hop + 4 n_mels bytes, reported as the contract asks")
         if not args.no_check:
             out["check"] = check(method, x, locals())
         if world == 1 and not args.no_cpu_baseline:
@@ -437,7 +494,7 @@ def check(method, x, env):
         lm, _ = fg_raw((xr - eps * d).contiguous())
         fd, gd = (lp - lm) / (2 * eps), float((g.double() * d.double()).sum())
         ok = abs(loss - mse) <= 1e-5 * abs(mse) and abs(fd - gd) <= 2e-2 * abs(gd)
-        return {"what": "objective loss vs mse(forward, target); central difference vs g.d", "loss": loss, "mse": mse,
+        return {"what": "self-check (tripwire, not parity evidence): objective loss vs mse(forward, target); central difference vs g.d", "loss": loss, "mse": mse,
                 "directional_fd": fd, "directional_g": gd, "ok": bool(ok)}
     mag = env["mag"]
     from spectrogram_inversion_amd.plan import Plan, args_helper
@@ -449,7 +506,7 @@ def check(method, x, env):
         xg = pg.rtisi(mag[:1], LOOK_AHEAD, env["args"].asym, iters, coef)
         scg, _ = sc_lin_f64(xg[0], mag[0], hop, window, dev)
         tol = 2e-3
-        return {"what": "SC_lin of item 0 (float64 evaluation) vs the generic RTISI-LA kernel", "sc_lin": sc32,
+        return {"what": "self-check (tripwire, not parity evidence): SC_lin of item 0 (float64 evaluation) vs the generic RTISI-LA kernel", "sc_lin": sc32,
                 "sc_lin_ref": scg, "abs_diff": abs(sc32 - scg), "tol": tol, "ok": bool(abs(sc32 - scg) <= tol)}
     # float64 re-run of item 0 from the float32 phase_init
     a32 = args_helper(mag[:1], hop_length=hop, window=window)
@@ -463,8 +520,35 @@ def check(method, x, env):
     x64 = p64.wave()
     sc64, _ = sc_lin_f64(x64[0], mag[0], hop, window, dev)
     tol = 1e-5 if method == "griffin_lim" else 3e-3      # ADMM at rho = 0.1 is chaotic w.r.t. rounding
-    return {"what": "SC_lin of item 0 (float64 evaluation) vs a float64 re-run of the same iterations", "sc_lin": sc32,
-            "sc_lin_ref": sc64, "abs_diff": abs(sc32 - sc64), "tol": tol, "ok": bool(abs(sc32 - sc64) <= tol)}
+    out = {"what": "self-check (a tripwire, not parity evidence - parity is tests/ against the reference's fixtures): SC_lin of "
+                   "item 0 (float64 evaluation) vs a float64 re-run of the same iterations on this library's generic kernels",
+           "sc_lin": sc32, "sc_lin_ref": sc64, "abs_diff": abs(sc32 - sc64), "tol": tol, "ok": bool(abs(sc32 - sc64) <= tol)}
+    ref = reference_trace_check(env)
+    if ref is not None:
+        out["reference"] = ref
+        out["ok"] = bool(out["ok"] and ref["ok"])
+    return out
+
+
+def reference_trace_check(env):
+    """C2 on rank 0's input is exactly what tests/golden/g16b_c2_headline.npz holds the UNMODIFIED REFERENCE's run of
+    (torch_specinv/methods.py:193-270, B = 64, 100 iterations, alpha 0.3, eva_iter 10; tests/golden/make_golden.py:g16): the ten
+    whole-batch evaluations of the last timed step against the reference's, |dSC_lin| <= 1e-5 (the north-star bar)."""
+    args, state = env["args"], env["state"]
+    if args.workload != "C2" or env["batch"] != 64 or env["rank"] != 0 or args.generic or "evals" not in state:
+        return None
+    path = os.path.join(ROOT, "tests", "golden", "g16b_c2_headline.npz")
+    if not os.path.exists(path):
+        return None
+    want = np.load(path)["trace"]
+    got = np.array([[m, l] for _, m, l in state["evals"]])
+    if got.shape != want.shape:
+        return None
+    d = np.abs(10.0 ** (got[:, 0] / 20.0) - 10.0 ** (want[:, 0] / 20.0))
+    return {"what": "the ten whole-batch evaluations of the last step vs the unmodified reference's run of this configuration and "
+                    "input (tests/golden/g16b_c2_headline.npz): max |dSC_lin|",
+            "max_abs_dsc_lin": float(d.max()), "sc_db_final": float(got[-1, 0]), "sc_db_final_reference": float(want[-1, 0]),
+            "tol": 1e-5, "ok": bool(d.max() <= 1e-5)}
 
 
 if __name__ == "__main__":

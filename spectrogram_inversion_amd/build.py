@@ -47,6 +47,18 @@ def sources():
     return srcs, hdrs
 
 
+def sources_hash() -> str:
+    """sha1 over the kernel sources (csrc/*.hip, csrc/*.h, include/specinv.h): what a stored profile figure was measured on
+    (profiles/traffic.json records it; bench.py flags figures taken on other sources as stale)."""
+    h = hashlib.sha1()
+    srcs, hdrs = sources()
+    for p in sorted(srcs + hdrs):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -149,6 +161,9 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
 
 
 if __name__ == "__main__":
+    if "--hash" in sys.argv:
+        print(sources_hash())
+        sys.exit(0)
     j = None
     if "-j" in sys.argv:
         j = int(sys.argv[sys.argv.index("-j") + 1])

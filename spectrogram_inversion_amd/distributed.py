@@ -46,13 +46,25 @@ class PendingGather:
         return self._out
 
 
+def _host_staged(group, device) -> bool:
+    """True when the group's backend cannot move device tensors itself (gloo with a GPU tensor): the payload is
+    then staged through host memory.  RCCL ("nccl") groups exchange device buffers directly over xGMI."""
+    return device.type == "cuda" and str(dist.get_backend(group)).lower() == "gloo"
+
+
 def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None, async_op: bool = False):
     """Gather (B_r, L) blocks of possibly different B_r to `dst`.  Returns the concatenated
     (sum B_r, L) tensor on `dst`, None elsewhere.  `sizes` (the per-rank batch sizes) may be
     passed when known, e.g. equal shards, to skip the size exchange.  With `async_op=True` (equal
-    shards only) a `PendingGather` is returned instead and the transfer overlaps later work."""
+    shards only) a `PendingGather` is returned instead and the transfer overlaps later work.
+    `dst` is a rank OF `group` (like the `rank` it is compared with); the collectives get it as `group_dst`."""
     if not dist.is_initialized():
         return PendingGather(None, x_local, None) if async_op else x_local
+    if _host_staged(group, x_local.device):
+        assert not async_op, "asynchronous gathers need a backend that moves device buffers (nccl)"
+        dev = x_local.device
+        out = gather_waveforms(x_local.cpu(), dst=dst, group=group, sizes=sizes)
+        return None if out is None else out.to(dev)
     # (a one-rank group still goes through the collective: the same code path at every world size)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -68,8 +80,8 @@ def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None
         out = list(big.split(sizes[0], 0)) if rank == dst else None
         src = x_local.contiguous()
         if async_op:
-            return PendingGather(dist.gather(src, out, dst=dst, group=group, async_op=True), big, src)
-        dist.gather(src, out, dst=dst, group=group)
+            return PendingGather(dist.gather(src, out, group_dst=dst, group=group, async_op=True), big, src)
+        dist.gather(src, out, group_dst=dst, group=group)
         return big
     assert not async_op, "async gather needs equal shards"
     # ragged batch: point-to-point to the root
@@ -80,10 +92,10 @@ def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None
                 parts.append(x_local)
             else:
                 buf = x_local.new_empty((sizes[r],) + tuple(x_local.shape[1:]))
-                dist.recv(buf, src=r, group=group)
+                dist.recv(buf, group_src=r, group=group)
                 parts.append(buf)
         return torch.cat(parts, 0)
-    dist.send(x_local.contiguous(), dst=dst, group=group)
+    dist.send(x_local.contiguous(), group_dst=dst, group=group)
     return None
 
 
@@ -103,10 +115,12 @@ def run_loop_global(plan, max_iter, eva_iter=10, tol=0.0, metric="sc", callback=
             plan.iterate(max_iter - done)
             done = max_iter
             break
-        s = torch.tensor(plan.iterate(until, eval_last=True), dtype=torch.float64, device=plan.device)
+        s = plan.iterate(until, eval_last=True)          # this rank's four sums (host floats)
         if dist.is_initialized():
+            where = torch.device("cpu") if _host_staged(group, plan.device) else plan.device
+            s = torch.tensor(s, dtype=torch.float64, device=where)
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
-        s = s.tolist()
+            s = s.tolist()
         done += until
         m, loss = _from_sums(name, s), s[0] / s[3]
         evals.append((done - 1, m, loss))
@@ -143,6 +157,8 @@ def _sharded(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, dst, g
     assert eva_iter > 0 and max_iter > 0 and tol >= 0
     assert isinstance(metric, str) and metric.upper() in _lib.METRICS
     assert spec.dim() == 3, "sharded inversion takes a (B, F, T) batch"
+    from .methods import _widen
+    spec, stft_kwargs, narrow = _widen(spec, stft_kwargs)     # float16 / complex32 spectrograms are inverted in float32
     world, rank = _world(group)
     if spec_is_local:
         local = spec
@@ -183,7 +199,10 @@ def _sharded(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, dst, g
                 pbar.update(eva_iter)
                 return 0
             done, evals = run_loop_global(plan, max_iter, eva_iter, tol, metric, callback=cb, group=group)
-    x = gather_waveforms(plan.wave(), dst=dst, group=group)
+    x = plan.wave()
+    if narrow is not None:
+        x = x.to(narrow)
+    x = gather_waveforms(x, dst=dst, group=group)
     return x, done, evals
 
 
@@ -218,6 +237,7 @@ def RTISI_LA_sharded(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, 
     world, rank = _world(group)
     local = spec
     if not spec_is_local:
+        assert spec.shape[0] >= world, "fewer items than ranks"     # (an empty shard would leave the others waiting in the gather)
         lo, hi = shard_bounds(spec.shape[0], world, rank)
         local = spec[lo:hi]
     from .plan import require_gpu

@@ -88,8 +88,15 @@ class HipVecOps:
     packed = True
 
     def board(self, n):
-        """scalar results of an iteration: pinned host memory written by the kernels themselves (no copy on the way back)"""
-        return _HostBoard(self.plan, n)
+        """scalar results of an iteration: pinned host memory written by the kernels themselves (no copy on the way back).
+        ONE board per plan, shared by every optimiser that runs on it (the plan - cached by `get_plan` - owns the pinned
+        memory until it is destroyed, so a board per `LBFGS` object would pin another region on every `L_BFGS` call): an
+        iteration writes and reads its slots within one `_batch` call, and a plan serves one thread at a time."""
+        cached = getattr(self.plan, "_lbfgs_board", None)
+        if cached is None or cached.numel() < n:
+            cached = _HostBoard(self.plan, max(n, 9 + 2 * 100))      # (room for torch.optim.LBFGS's default history)
+            self.plan._lbfgs_board = cached
+        return cached
 
     def eval_into(self, fg, x, board, slot):
         """gradient of the objective at x; the loss goes to board[slot]"""
@@ -149,6 +156,8 @@ class LBFGS:
         self.ops = vec_ops if vec_ops is not None else HipVecOps(x.dtype, x.device if device is None else device)
         self.total_iters = 0
         self.func_evals = 0
+        self.pairs_accepted = 0                # curvature pairs that passed `y.s > 1e-10` ...
+        self.pairs_rejected = 0                # ... and those that did not (the memory stays as it was)
         self.d = None
         self.t = None
         # the recursion on Gram matrices (two passes over the memory) needs the one-pass vector kernels
@@ -157,6 +166,11 @@ class LBFGS:
         self.prev_grad = None
         self.prev_loss = None
         self._board = None
+
+    @property
+    def history_len(self):
+        """curvature pairs in the memory (<= history_size)"""
+        return len(self.ss)
 
     # ---- pieces -----------------------------------------------------------------------------
     def _forget(self):
@@ -356,6 +370,8 @@ class LBFGS:
                 vecs, coefs = None, None
             else:
                 sg, yg = b["sg"], b["yg"]
+                self.pairs_accepted += b["ys"] > 1e-10
+                self.pairs_rejected += not b["ys"] > 1e-10
                 if b["ys"] > 1e-10:
                     if len(self.ys) == self.history_size:
                         self._drop_oldest()
@@ -432,6 +448,8 @@ class LBFGS:
                     ops.axpy(-1.0, self.prev_grad, y)
                     s = ops.scaled(t, d)
                     ys, yy = ops.dot(y, s), None
+                self.pairs_accepted += ys > 1e-10
+                self.pairs_rejected += not ys > 1e-10
                 if ys > 1e-10:
                     if len(self.ys) == self.history_size:
                         self._drop_oldest()

@@ -196,3 +196,36 @@ def _async_worker(rank, world, port):
 def test_async_gather_overlaps_and_completes():
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_async_worker, args=(2, port), nprocs=2, join=True)
+
+
+def _subgroup_worker(rank, world, port):
+    _init(rank, world, port)
+    from spectrogram_inversion_amd.distributed import gather_waveforms, griffin_lim_sharded
+    g = dist.new_group([1, 2])                          # a group that does not start at global rank 0
+    if rank in (1, 2):
+        gr = dist.get_rank(g)                           # 0 / 1 inside the group
+        # `dst` is a group rank: group rank 0 = global rank 1 receives (equal shards: dist.gather; ragged: send / recv)
+        z = gather_waveforms(torch.full((2, 3), float(rank)), dst=0, group=g)
+        r = gather_waveforms(torch.full((1 + gr, 3), float(rank)), dst=1, group=g)
+        if gr == 0:
+            assert z.shape == (4, 3) and z[:2].eq(1).all() and z[2:].eq(2).all()
+            assert r is None
+        else:
+            assert z is None
+            assert r.shape == (3, 3) and r[:1].eq(1).all() and r[1:].eq(2).all()
+        # the one-call entry point on the sub-group: shards by group rank, result on the group's `dst`
+        rng = np.random.default_rng(5)
+        mag = torch.from_numpy(rng.random((3, 129, 12), dtype=np.float32))
+        x, done, _ = griffin_lim_sharded(mag, max_iter=4, tol=1e-30, alpha=0.3, verbose=False, eva_iter=2, dst=1, group=g,
+                                         return_info=True, _plan_factory=_factory, hop_length=64,
+                                         window=torch.from_numpy(_hann(256)))
+        assert done == 4 and ((x is not None and x.shape[0] == 3) if gr == 1 else x is None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sub_group_that_does_not_start_at_rank_zero():
+    """`dst` and the rank it is compared with are both ranks of `group` (the collectives get `group_dst` / `group_src`)."""
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_subgroup_worker, args=(3, port), nprocs=3, join=True)

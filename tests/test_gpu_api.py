@@ -1,5 +1,7 @@
 """Drop-in API behaviour on the device: shapes, devices, dtypes, progress reporting, early stop, path selection
 for configurations around the edges of the fused kernels.  Needs an MI355X: `-m gpu`."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -270,6 +272,8 @@ def test_plans_release_their_device_memory():
     """Creating, running and dropping plans over and over leaves the device's free memory where it started (the
     library allocates with hipMalloc, outside torch's caching allocator)."""
     import gc
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("reads the whole device's free memory: meaningless while other xdist workers allocate on it")
     rng = np.random.default_rng(34)
     w = torch.from_numpy(hann(2048))
     mag = torch.from_numpy(rng.random((8, 1025, 256), dtype=np.float32)).to(DEV)
@@ -335,9 +339,12 @@ def test_phase_init_accepts_a_complex_window():
     assert out.dtype == torch.complex64 and torch.equal(torch.view_as_real(out), torch.view_as_real(ref))
 
 
-def test_rtisi_progress_bar_path_gives_the_same_samples(capsys):
-    """`verbose` feeds the frames in blocks through the resumable kernel and advances a bar of frames + look_ahead
-    steps (methods.py:362,400): the same samples bit for bit as the one-launch run, on both RTISI kernels."""
+@pytest.mark.parametrize("mode", ["blocks", "end"])
+def test_rtisi_progress_bar_path_gives_the_same_samples(capsys, monkeypatch, mode):
+    """`verbose` on a terminal (here: SPECINV_RTISI_PROGRESS=blocks) feeds the frames in blocks through the resumable kernel and
+    advances a bar of frames + look_ahead steps (methods.py:362,400); without a terminal the bar is completed after the one
+    persistent launch.  The same samples bit for bit as the quiet run either way, on both RTISI kernels."""
+    monkeypatch.setenv("SPECINV_RTISI_PROGRESS", mode)
     rng = np.random.default_rng(41)
     for n_fft, hop, frames in ((1024, 256, 70), (400, 100, 45)):
         mag = torch.from_numpy(rng.random((2, n_fft // 2 + 1, frames), dtype=np.float32)).to(DEV)

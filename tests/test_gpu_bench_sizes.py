@@ -95,6 +95,43 @@ def test_c2_headline_geometry_vs_oracle_and_float64(kernel):
     np.testing.assert_allclose(s32_10[:3], s64_10[:3], rtol=2e-5)
 
 
+@pytest.mark.parametrize("kernel", ["k_fused4_td", "k_fused4"])
+def test_c2_headline_100_iterations_vs_the_reference_run(kernel):
+    """g16b: BASELINE configs[1] end to end against the UNMODIFIED REFERENCE's own run of it (torch_specinv/methods.py:193-270 on
+    bench.py's rank-0 input, B = 64, 100 iterations, alpha 0.3, eva_iter 10): the ten whole-batch evaluations within 1e-5 of the
+    reference's (linear spectral convergence - the north-star bar), and the final waveforms of items 0 and 63 as close to the
+    reference's float32 waveforms as those are to the reference's own float64 run, hop segment by hop segment (random magnitudes
+    are inconsistent: isolated near-zero bins decorrelate a neighbourhood in any two float32 implementations).  On the launch
+    geometry of the headline number; from the magnitudes (phase_init in pair order), exactly what `bench.py` times."""
+    from _util import load_golden, sc_linear
+    g = load_golden("g16b_c2_headline")
+    n_fft, hop, frames, batch, alpha = 2048, 512, 1024, 64, 0.3
+    mag_np = bench_mag(batch, n_fft // 2 + 1, frames, int(g["seed"]))
+    chk = g["mag_checksum"]
+    assert float(mag_np.astype(np.float64).sum()) == chk[0] and float(mag_np[63, 1024, 1023]) == chk[2]
+    mag = torch.from_numpy(mag_np).to(DEV)
+    p = make_plan(n_fft, hop, frames, batch)
+    p.keep_state(kernel == "k_fused4")
+    p.gla_init(None, mag, alpha)
+    geo = p.launch_geometry
+    assert geo == {"waves_per_workgroup": 4 if kernel == "k_fused4_td" else 8, "chunks": 32, "waves": 2048, "kernel": kernel}, geo
+    done, evals = p.run(100, 10, 0.0, "sc")
+    assert done == 100 and len(evals) == 10
+    got = np.array([[m, l] for _, m, l in evals])
+    want = g["trace"]
+    d_sc = np.abs(sc_linear(got[:, 0]) - sc_linear(want[:, 0]))
+    assert d_sc.max() < 1e-5, d_sc
+    np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=2e-4)
+    y = N(p.wave())
+    for it in (int(i) for i in g["items"]):
+        ref = g[f"wave_{it}"].astype(np.float64)
+        seg = np.linalg.norm((y[it] - ref).reshape(-1, hop), axis=1) / np.maximum(g[f"segnorm64_{it}"], 1e-30)
+        own = g[f"segerr_{it}"]
+        assert np.median(seg) < 4 * np.median(own) + 1e-6, (it, np.median(seg), np.median(own))
+        assert np.quantile(seg, 0.9) < 6 * np.quantile(own, 0.9) + 1e-5, (it, np.quantile(seg, 0.9), np.quantile(own, 0.9))
+        assert rel_l2(y[it], ref) < max(10 * float(g[f"noise_{it}"]), 1e-4), (it, rel_l2(y[it], ref), float(g[f"noise_{it}"]))
+
+
 # ---- C4 shard: ADMM B=32 n_fft=1024 hop=256 T=2048 rho=0.1 ------------------------------------------------------------
 def test_c4_shard_geometry_vs_oracle_and_float64():
     n_fft, hop, frames, batch, rho = 1024, 256, 2048, 32, 0.1

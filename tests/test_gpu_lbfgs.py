@@ -467,3 +467,15 @@ def test_host_board_receives_device_results():
         got = ops.read(hb, 9)
         want = ops.plan.read_doubles(db.data_ptr(), 9)
         assert got[0] == float(rep) and list(got[1:]) == list(want[1:]), rep
+
+
+def test_one_pinned_board_per_plan():
+    """Every optimiser on a device / dtype shares the plan `get_plan` caches, and with it ONE pinned result board: a service that
+    calls `L_BFGS` in a loop must not pin another host region per call (the plan frees its boards only when it is destroyed)."""
+    from spectrogram_inversion_amd.lbfgs import LBFGS
+    x = torch.zeros(4096, device=DEV)
+    a, b = LBFGS(x), LBFGS(x.clone(), history_size=7)
+    assert a.ops.plan is b.ops.plan
+    assert a.ops.board(23) is b.ops.board(9 + 2 * 100)
+    big = a.ops.board(1000)                                  # grows once, then serves everybody
+    assert big.numel() >= 1000 and b.ops.board(50) is big

@@ -195,6 +195,41 @@ def test_gla_wellconditioned_hop_quarter_100_iterations(alpha, kernel, monkeypat
     assert np.abs(got - want).max() < 1e-5, np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("kernel", ["k_fused4_td", "k_fused4", "k_hop_td", "k_hop"])
+@pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
+def test_gla_wellconditioned_2048_100_iterations(alpha, kernel, monkeypatch):
+    """g16a: g14's construction at n_fft 2048 / hop 512 - the HEADLINE instantiation (`k_fused4_td<16>`, what BASELINE C2 runs) and
+    the other kernels that serve the shape, against 100 iterations of the unmodified reference (torch_specinv/methods.py:237-250) in
+    float32, STRICT gate min(1e-4, 6 x the reference's own float32-vs-float64 noise).  run(100, 10) takes the signal-form kernel
+    through all four variants: with alpha 0.3 the c0 term is added for 15 iterations (early; early + evaluating at iteration 10),
+    with 0.99 for 30, with 0 never; from then on the late launch - 77 of C2's 100 - and late + evaluating."""
+    from spectrogram_inversion_amd.plan import Plan
+    g = load_golden("g16a_wellcond_2048")
+    ref, ref64 = g[f"wave_a{alpha}"], g[f"wave64_a{alpha}"]
+    noise = rel_l2(ref, ref64)
+    gate = min(1e-4, max(6 * noise, 3e-6))
+    init = T(g["init"])
+    hop, w = int(g["hop"]), torch.from_numpy(g["window"])
+    assert (init.shape[1], hop) == (1025, 512)
+    monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")
+    if kernel in ("k_hop", "k_hop_td"):
+        monkeypatch.setenv("SPECINV_DISABLE_FUSED", "1")
+    p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], w.dtype, dev())
+    p.keep_state(kernel not in ("k_fused4_td", "k_hop_td"))
+    p.gla_init(init, None, alpha)
+    assert p.launch_geometry["kernel"] == kernel, p.launch_geometry
+    done, evals = p.run(100, 10, 0.0, "sc")
+    assert done == 100 and len(evals) == 10
+    y = N(p.wave())
+    assert rel_l2(y, ref) < gate, (kernel, rel_l2(y, ref), rel_l2(y, ref64), noise)
+    trace = []
+    oracle.griffin_lim(g["init"].astype(np.complex128), max_iter=100, alpha=alpha, tol=0, eva_iter=10, hop_length=hop,
+                       window=g["window"].astype(np.float64), trace=trace)
+    got = sc_linear(np.array([m for _, m, _ in evals]))
+    want = sc_linear(np.array([m for _, m, _ in trace]))
+    assert np.abs(got - want).max() < 1e-5, np.abs(got - want).max()
+
+
 def test_gla_trace_and_spectral_convergence():
     g = load_golden("g2_gla")
     kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))

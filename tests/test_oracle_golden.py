@@ -71,10 +71,10 @@ def test_gla_waveforms(alpha, it):
         np.testing.assert_allclose(got[:, 1], tr[:, 1], rtol=2e-4)
 
 
-@pytest.mark.parametrize("fixture", ["g14_wellcond", "g15_wellcond_1024"])
+@pytest.mark.parametrize("fixture", ["g14_wellcond", "g15_wellcond_1024", "g16a_wellcond_2048"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 def test_gla_wellconditioned_100_iterations(alpha, fixture):
-    """g14 / g15: consistent magnitudes, perturbed true phase - 100 iterations stay well-conditioned (the reference's own
+    """g14 / g15 / g16a (n_fft 512 / 1024 / 2048): consistent magnitudes, perturbed true phase - 100 iterations stay well-conditioned (the reference's own
     float32-vs-float64 distance is 1e-6), so the waveform gate is the strict one."""
     g = load_golden(fixture)
     y = oracle.griffin_lim(g["init"], max_iter=100, alpha=alpha, tol=0, eva_iter=10, hop_length=int(g["hop"]), window=g["window"])
@@ -82,6 +82,35 @@ def test_gla_wellconditioned_100_iterations(alpha, fixture):
     noise = rel_l2(ref, ref64)
     assert noise < 3e-6, noise
     assert rel_l2(y, ref) < min(1e-4, max(6 * noise, 3e-6)), (rel_l2(y, ref), noise)
+
+
+def test_c2_headline_items_against_the_reference_run():
+    """g16b: BASELINE configs[1] through the unmodified reference (B = 64, n_fft 2048, hop 512, 1024 frames, 100 iterations,
+    alpha 0.3, magnitudes default_rng(1234) like bench.py's rank 0).  The oracle inverts items 0 and 63 (batch items are
+    independent: the fixture records that the reference's B = 2 run of them equals their rows of the B = 64 run bit for bit):
+    the per-pair metric trace within 1e-5 (linear SC) of the reference's float32 trace of the same pair, and the waveforms as close
+    to the reference's float32 result as that is to its own float64 run, hop segment by hop segment."""
+    g = load_golden("g16b_c2_headline")
+    assert bool(g["rows_equal_pair_run"].all())
+    items = [int(i) for i in g["items"]]
+    mag = np.random.default_rng(int(g["seed"])).random((64, 1025, 1024), dtype=np.float32)
+    chk = g["mag_checksum"]
+    assert float(mag.astype(np.float64).sum()) == chk[0] and float(mag[0, 5, 7]) == chk[1] and float(mag[63, 1024, 1023]) == chk[2]
+    hop, win = int(g["hop"]), g["window"]
+    trace = []
+    y = oracle.griffin_lim(np.ascontiguousarray(mag[items]), max_iter=100, alpha=0.3, tol=0, eva_iter=10, hop_length=hop, window=win,
+                           trace=trace)
+    got = np.array([[m, l] for _, m, l in trace])
+    want = g["trace_pair"]
+    assert np.abs(sc_linear(got[:, 0]) - sc_linear(want[:, 0])).max() < 1e-5, np.abs(sc_linear(got[:, 0]) - sc_linear(want[:, 0])).max()
+    np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=2e-4)
+    for k, it in enumerate(items):
+        ref = g[f"wave_{it}"].astype(np.float64)
+        seg = np.linalg.norm((y[k] - ref).reshape(-1, hop), axis=1) / np.maximum(g[f"segnorm64_{it}"], 1e-30)
+        own = g[f"segerr_{it}"]                         # the reference's float32 vs its float64, same segments
+        assert np.median(seg) < 4 * np.median(own) + 1e-6, (it, np.median(seg), np.median(own))
+        assert np.quantile(seg, 0.9) < 6 * np.quantile(own, 0.9) + 1e-5, (it, np.quantile(seg, 0.9), np.quantile(own, 0.9))
+        assert rel_l2(y[k], ref) < max(10 * float(g[f"noise_{it}"]), 1e-4), (it, rel_l2(y[k], ref), float(g[f"noise_{it}"]))
 
 
 @pytest.mark.parametrize("metric", ["snr", "ser"])

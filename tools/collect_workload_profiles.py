@@ -64,6 +64,12 @@ for W, kernels in DOMINANT.items():
             wc = c["SQ_WAVE_CYCLES"]["mean_per_launch"]
             entry["wave_cycle_shares"] = {k: c[k]["mean_per_launch"] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
                                                                                    "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS") if k in c}
+        if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
+            # share of the chip's VALU issue slots in use: SQ_ACTIVE_INST_VALU counts 4-cycle quanta over all SIMDs (1024),
+            # GRBM_GUI_ACTIVE the busy cycles summed over the 8 XCDs
+            entry["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4 / (c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 * 1024)
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE", {}).get("mean_per_launch"):
+            entry["lds_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / c["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"]
         summary["kernels"][kern] = entry
     json.dump(summary, open(os.path.join(out, f"{tag}_{W}_pmc.json"), "w"), indent=1)
     first = summary["kernels"].get(kernels[0], {})
@@ -71,8 +77,18 @@ for W, kernels in DOMINANT.items():
         traffic[W] = first["hbm_bytes_per_launch"]
         traffic[f"_{W}_note"] = (f"{kernels[0]}: (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/{tag}_{W}_pmc.json"
                                  + (f"; algorithmic {ALGO[W]} B" if ALGO[W] else ""))
+    for key in ("valu_issue_frac", "lds_conflict_frac"):
+        if key in first:
+            traffic[f"{W}_{key}"] = first[key]
+    if "wave_cycle_shares" in first and "SQ_ACTIVE_INST_VALU" in first["wave_cycle_shares"]:
+        traffic[f"{W}_valu_share_of_wave_life"] = first["wave_cycle_shares"]["SQ_ACTIVE_INST_VALU"]
     kt = first.get("kernel_trace", {})
     print(W, kernels[0], "steady %.1f us" % kt.get("steady_mean_us", float("nan")),
           "traffic %.4g B" % first.get("hbm_bytes_per_launch", float("nan")),
           ("= %.3f x algorithmic" % (first["hbm_bytes_per_launch"] / ALGO[W])) if ALGO[W] and "hbm_bytes_per_launch" in first else "")
+sha = newest(f"gpurun_out/{tag}_csrc_sha1.txt")
+if sha:
+    traffic["csrc_sha1"] = open(sha).read().strip()
+    traffic["_csrc_sha1_note"] = (f"sha1 of the kernel sources the {tag} profiles were taken on (python -m spectrogram_inversion_amd.build "
+                                  "--hash); bench.py prints traffic_stale when the tree it runs differs")
 json.dump(traffic, open(traffic_path, "w"), indent=1)

@@ -6,6 +6,7 @@ WL=${@:-C2 C4 C3 C5}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+python3 -m spectrogram_inversion_amd.build --hash > gpurun_out/${TAG}_csrc_sha1.txt   # the sources the profiled library was built from
 for W in $WL; do
   CMD="python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-check"
   P=gpurun_out/${TAG}_${W}
