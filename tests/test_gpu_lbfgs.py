@@ -473,7 +473,7 @@ def test_one_pinned_board_per_plan():
     """Every optimiser on a device / dtype shares the plan `get_plan` caches, and with it ONE pinned result board: a service that
     calls `L_BFGS` in a loop must not pin another host region per call (the plan frees its boards only when it is destroyed)."""
     from spectrogram_inversion_amd.lbfgs import LBFGS
-    x = torch.zeros(4096, device=DEV)
+    x = torch.zeros(4096, device=dev())
     a, b = LBFGS(x), LBFGS(x.clone(), history_size=7)
     assert a.ops.plan is b.ops.plan
     assert a.ops.board(23) is b.ops.board(9 + 2 * 100)
