@@ -361,6 +361,27 @@ struct Dft<32, INV> {
   }
 };
 
+// The transpose scratch of one wave: a 64 x R matrix (rows of R + 1 elements) written in layout A - lane (v, n2) holds row
+// kv(v) * R + i, column n2 for register i - and read back in layout B - lane l holds row l, column i - by the forward transform,
+// the other way round by the inverse.  The 64 / R groups of R rows (one per frequency digit kv) start at kv * R * (R + 1) +
+// tr_pad<R>(kv).  With the odd row stride alone, n_fft 2048 (R = 16) is free of LDS bank conflicts, but at R = 8 / R = 4 the
+// groups a 32-lane read group (16-lane write group) touches in layout A fall on the same banks: 2-way conflicts on every layout-A
+// access (PMC, C4: SQ_LDS_BANK_CONFLICT 14 % of SQ_LDS_IDX_ACTIVE).  The pads below make the group bases distinct mod 32
+// elements for the lanes of a ds_read_b64 group and mod 16 for a ds_write_b64 group in BOTH layouts (banking rules:
+// MI355X_MICROARCH.md, LDS; found by exhaustive search over the residues, smallest total size).
+template <int R>
+__host__ __device__ constexpr int tr_pad(int kv) {
+  if (R == 8) {
+    constexpr int p[8] = {0, 0, 8, 24, 24, 40, 48, 48};
+    return p[kv];
+  }
+  if (R == 4) {
+    constexpr int p[16] = {0, 0, 0, 16, 20, 20, 36, 36, 40, 56, 56, 56, 76, 76, 76, 76};
+    return p[kv];
+  }
+  return 0;
+}
+
 template <int R>
 struct Geo {
   static constexpr int C = 64 / R;       // cross-lane radix
@@ -371,7 +392,7 @@ struct Geo {
   static constexpr int H = R / 2;        // conjugate pairs per lane
   static constexpr int QU = R / 4;       // registers per hop-block quarter
   static constexpr int HOP = N / 4;
-  static constexpr int TR = 64 * (R + 1);  // transpose scratch per wave (complex elements)
+  static constexpr int TR = 64 * (R + 1) + tr_pad<R>(64 / R - 1);  // transpose scratch per wave (complex elements)
   static constexpr size_t lds_bytes(int waves) { return sizeof(v2f) * (size_t)(M + (R - 1) * 64 + waves * TR); }
 };
 
@@ -393,8 +414,8 @@ struct LaneConst {
   v2f post;                // W_64^(n2*kv)
   v2f stage[2];            // twiddles between the cross-lane radix-4 and radix-2 steps (C == 8: one, C == 16: two)
   v2f wn;                  // W_N^lane
-  int tr_a;                // transpose address for layout A: (kv*R + reg)*(R+1) + n2  -> base + reg*(R+1)
-  int tr_b;                // layout B: lane*(R+1) + reg
+  int tr_a;                // transpose address for layout A: (kv*R + reg)*(R+1) + tr_pad(kv) + n2  -> base + reg*(R+1)
+  int tr_b;                // layout B: lane*(R+1) + tr_pad(lane / R) + reg
 };
 
 __device__ __forceinline__ v2f unit(float turns_times_2) {  // exp(-i*pi*x)
@@ -431,8 +452,8 @@ __device__ __forceinline__ LaneConst<R> lane_consts() {
   k.partner = (64 - k.lane) & 63;
   k.post = unit(2.0f * (float)(k.n2 * k.kv) / 64.0f);
   k.wn = unit(2.0f * (float)k.lane / (float)G::N);
-  k.tr_a = (k.kv * R) * (R + 1) + k.n2;
-  k.tr_b = k.lane * (R + 1);
+  k.tr_a = (k.kv * R) * (R + 1) + tr_pad<R>(k.kv) + k.n2;
+  k.tr_b = k.lane * (R + 1) + tr_pad<R>(k.lane / R);
   return k;
 }
 

@@ -14,7 +14,7 @@
 //     barriers per iteration, no global memory traffic except the once-per-frame target load and commit.
 // Step latency drops from ~115 us (generic k_rtisi) to a few us.
 #pragma once
-#include "rtisi_fast_host.h"
+#include "rtisi_fast_args.h"
 
 #ifndef SPECINV_RTISI_PK      // complex products of the step loop's FFTs: 0 scalar (default: a lone wave per SIMD, see fft_forward_t), 1 packed
 #define SPECINV_RTISI_PK 0

@@ -9,6 +9,7 @@ mkdir -p gpurun_out
 python3 -m spectrogram_inversion_amd.build --hash > gpurun_out/${TAG}_csrc_sha1.txt   # the sources the profiled library was built from
 for W in $WL; do
   CMD="python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-check"
+  if [ $W = C5 ]; then CMD="$CMD --outer 2"; fi        # (two optimizer.step calls: the per-dispatch counter files of 50 would not fit gpurun_out)
   P=gpurun_out/${TAG}_${W}
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${P}_kt -- $CMD > ${P}_kt.log 2>&1
   timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d ${P}_pmc_fetch -- $CMD > ${P}_pmc_fetch.log 2>&1
