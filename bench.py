@@ -540,15 +540,22 @@ def reference_trace_check(env):
     path = os.path.join(ROOT, "tests", "golden", "g16b_c2_headline.npz")
     if not os.path.exists(path):
         return None
-    want = np.load(path)["trace"]
+    g = np.load(path)
+    want, sc_ref = g["trace"], g["sc_db_from_loss"]
     got = np.array([[m, l] for _, m, l in state["evals"]])
     if got.shape != want.shape:
         return None
-    d = np.abs(10.0 ** (got[:, 0] / 20.0) - 10.0 ** (want[:, 0] / 20.0))
+    # The reference's loss column (F.mse_loss) is good to 1e-7; its SC column is not (torch's float32 `norm` over 6.7e7 elements is
+    # 4e-3 off for ||target|| alone), so the spectral convergence is compared with what the reference's loss and the exact
+    # ||target|| imply (tests/golden/make_golden.py:g16)
+    d = np.abs(10.0 ** (got[:, 0] / 20.0) - 10.0 ** (sc_ref / 20.0))
+    dl = np.abs(got[:, 1] / want[:, 1] - 1.0)
     return {"what": "the ten whole-batch evaluations of the last step vs the unmodified reference's run of this configuration and "
-                    "input (tests/golden/g16b_c2_headline.npz): max |dSC_lin|",
-            "max_abs_dsc_lin": float(d.max()), "sc_db_final": float(got[-1, 0]), "sc_db_final_reference": float(want[-1, 0]),
-            "tol": 1e-5, "ok": bool(d.max() <= 1e-5)}
+                    "input (tests/golden/g16b_c2_headline.npz): loss (F.mse_loss) relative difference, and |dSC_lin| against the "
+                    "spectral convergence the reference's loss implies (its own SC column carries a 1.5e-3 float32-norm error)",
+            "max_rel_dloss": float(dl.max()), "max_abs_dsc_lin": float(d.max()), "sc_db_final": float(got[-1, 0]),
+            "sc_db_final_reference_from_loss": float(sc_ref[-1]), "sc_db_final_reference_reported": float(want[-1, 0]),
+            "tol": 1e-5, "ok": bool(d.max() <= 1e-5 and dl.max() <= 1e-5)}
 
 
 if __name__ == "__main__":

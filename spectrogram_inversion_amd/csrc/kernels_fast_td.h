@@ -49,6 +49,9 @@ __device__ __forceinline__ void td_load_block(const float* __restrict__ xrow, co
 #ifndef SPECINV_TD_MINWAVES
 #define SPECINV_TD_MINWAVES 2
 #endif
+#ifndef SPECINV_TD_ENVREG          // 1: one block of the (hop-periodic) envelope reciprocal stays in registers (8 at n_fft 2048)
+#define SPECINV_TD_ENVREG 1
+#endif
 #ifndef SPECINV_TD_ABLATE          // timing-only builds (wrong results): 1 target from frame 0 (L2-resident), 2 no output stores,
 #define SPECINV_TD_ABLATE 0        // 4 z samples from the first hop-blocks (L2-resident)
 #endif
@@ -113,7 +116,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   // The overlap-add envelope is periodic in the hop wherever all n_fft / hop frames that cover a sample exist (hop-blocks NB .. T-1:
   // the same summands in the same order, plan_impl.h): one block of its reciprocal is kept in registers instead of being loaded for
   // every frame (the evaluating variant has no registers to spare and keeps loading)
-  constexpr bool ENVREG = !EVAL;
+  constexpr bool ENVREG = !EVAL && SPECINV_TD_ENVREG;
   v2f envc[ENVREG ? QU : 1];
   if (ENVREG) {
     const v2f* e0 = reinterpret_cast<const v2f*>(a.inv_env + (long long)(NB - PB) * HOP);

@@ -98,8 +98,9 @@ def test_c2_headline_geometry_vs_oracle_and_float64(kernel):
 @pytest.mark.parametrize("kernel", ["k_fused4_td", "k_fused4"])
 def test_c2_headline_100_iterations_vs_the_reference_run(kernel):
     """g16b: BASELINE configs[1] end to end against the UNMODIFIED REFERENCE's own run of it (torch_specinv/methods.py:193-270 on
-    bench.py's rank-0 input, B = 64, 100 iterations, alpha 0.3, eva_iter 10): the ten whole-batch evaluations within 1e-5 of the
-    reference's (linear spectral convergence - the north-star bar), and the final waveforms of items 0 and 63 as close to the
+    bench.py's rank-0 input, B = 64, 100 iterations, alpha 0.3, eva_iter 10): the ten whole-batch evaluations - loss within 1e-5
+    (relative) of the reference's, linear spectral convergence within 1e-5 (the north-star bar) of the value the reference's loss
+    implies - and the final waveforms of items 0 and 63 as close to the
     reference's float32 waveforms as those are to the reference's own float64 run, hop segment by hop segment (random magnitudes
     are inconsistent: isolated near-zero bins decorrelate a neighbourhood in any two float32 implementations).  On the launch
     geometry of the headline number; from the magnitudes (phase_init in pair order), exactly what `bench.py` times."""
@@ -119,9 +120,15 @@ def test_c2_headline_100_iterations_vs_the_reference_run(kernel):
     assert done == 100 and len(evals) == 10
     got = np.array([[m, l] for _, m, l in evals])
     want = g["trace"]
-    d_sc = np.abs(sc_linear(got[:, 0]) - sc_linear(want[:, 0]))
+    # the loss column (F.mse_loss, methods.py:182) to 1e-5 relative; the spectral convergence against what follows from that loss
+    # and the exact ||target|| - the reference's own SC column is computed with torch's float32 `norm` over 6.7e7 elements
+    # (metrics.py:14), which is 4e-3 off for ||target|| alone at this size (fixture: target_norm_torch_f32 vs target_norm_exact),
+    # so that column can only be held to 2e-3
+    np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=1e-5)
+    d_sc = np.abs(sc_linear(got[:, 0]) - sc_linear(g["sc_db_from_loss"]))
     assert d_sc.max() < 1e-5, d_sc
-    np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=2e-4)
+    assert abs(float(g["target_norm_torch_f32"]) / float(g["target_norm_exact"]) - 1) > 1e-3      # (the artefact is real)
+    assert np.abs(sc_linear(got[:, 0]) - sc_linear(want[:, 0])).max() < 2e-3
     y = N(p.wave())
     for it in (int(i) for i in g["items"]):
         ref = g[f"wave_{it}"].astype(np.float64)
