@@ -302,6 +302,9 @@ def main():
                 a, b, n = events.pop(0)
                 folded["ms"] += a.elapsed_time(b)
                 folded["n"] += n
+            if os.environ.get("SPECINV_BENCH_NO_EVENTS"):   # (experiments: what the event pairs themselves cost)
+                counters["evals"] += 1
+                return call()
             e0, e1 = ev(), ev()
             e0.record()                                     # HIP events on the stream the objective is launched on
             out = call()
@@ -314,6 +317,9 @@ def main():
             return timed_eval(lambda: fg_raw(v))
 
         fg.dev = lambda v, loss_ptr: timed_eval(lambda: fg_raw.dev(v, loss_ptr))   # loss left on the device: no sync per evaluation
+        # the device-resident optimiser (csrc/lbfgs_dev.h) enqueues a whole optimizer.step from C++: it times its own objective
+        # launches with HIP events on the launch stream (LBFGS.time_objective) and counts the evaluations the device executed
+        fg.device_objective = fg_raw.device_objective
 
         from spectrogram_inversion_amd.lbfgs import LBFGS
 
@@ -323,9 +329,14 @@ def main():
         def step():
             x = x_init.clone()
             opt = LBFGS(x, device=dev, **opt_kw)             # torch.optim.LBFGS defaults: max_iter 20, history 100, lr 1
+            opt.time_objective = not os.environ.get("SPECINV_BENCH_NO_EVENTS")
             for _ in range(args.outer):
                 opt.step(fg)
             state["opt"] = opt
+            if opt.objective_launches:                       # evaluations the device-resident optimiser ran and timed itself
+                folded["ms"] += opt.objective_ms
+                folded["n"] += opt.objective_launches
+                counters["evals"] += opt.objective_launches
             finish_step(x)
         units_per_step = None                               # closure evaluations are counted
         unit = "evaluations*frames/s"
@@ -463,7 +474,9 @@ def main():
             out["config"]["lbfgs"] = {"variant": args.c5_variant, "outer_steps": args.outer, "inner_iterations": opt.total_iters,
                                       "evaluations": opt.func_evals, "pairs_accepted": int(opt.pairs_accepted),
                                       "pairs_rejected": int(opt.pairs_rejected), "history_len": opt.history_len,
-                                      "history_size": opt.history_size}
+                                      "history_size": opt.history_size,
+                                      "decisions": "on the device, one host synchronisation per optimizer.step" if opt._dev
+                                                   else "on the host, one synchronisation per inner iteration"}
             roof["note"] = ("compute-bound (SURVEY 8d): two FFTs per frame on the vector units + two mel contractions on the "
                             "matrix cores; frac is the HBM fraction of its 8 hop + 4 n_mels bytes, reported as the contract asks")
         if not args.no_check:

@@ -262,6 +262,34 @@ int specinv_read_doubles(specinv_plan* plan, const double* src_dev, int n, doubl
 int specinv_board_alloc(specinv_plan* plan, int n, double** host_out, double** dev_out);
 int specinv_stream_wait(specinv_plan* plan);
 
+/* ---- L-BFGS with the decisions on the device (float32, the one-launch objective of specinv_transform_setup) --------------
+ * Replaces the inner loop of torch.optim.LBFGS.step as torch_specinv/methods.py:553 drives it (no line search): one call
+ * enqueues a whole optimizer.step - for each inner iteration the objective, the curvature pair and its statistics, the products
+ * with the memory, a one-wave decision kernel (tolerance tests, y.s > 1e-10, memory ring, two-loop recursion on Gram matrices,
+ * step length) and direction + step - and synchronises ONCE, at the end; after a break the rest of the enqueued step runs as
+ * no-ops.  The optimiser's state (memory, d, t, previous gradient / loss, counters) lives on the device between steps.
+ * Options carry torch.optim.LBFGS's names; max_eval <= 0 means max_iter * 5 / 4.  history_size <= 120.
+ * SPECINV_EUNSUPPORTED when the plan's transform is not served by the one-launch objective (the caller then runs the
+ * host-driven loop on the *_dev entry points above). */
+typedef struct specinv_lbfgs_opts {
+  double lr, tolerance_grad, tolerance_change;
+  int32_t max_iter, max_eval, history_size;
+  int32_t time_objective;  /* != 0: bracket every objective evaluation with HIP events (benchmarks: specinv_lbfgs_info.objective_ms) */
+} specinv_lbfgs_opts;
+typedef struct specinv_lbfgs_info {
+  double first_loss;      /* what optimizer.step returns: the loss at the entry evaluation */
+  double loss, t;
+  int32_t total_iters, func_evals, n_iter, history_len, pairs_accepted, pairs_rejected;
+  int32_t objective_launches;  /* evaluations this step executed ... */
+  double objective_ms;         /* ... and their summed duration (objective + epilogue launch), when time_objective was set */
+} specinv_lbfgs_info;
+/* `n` = elements of the parameter (batch * length); *handle_out identifies the optimiser within the plan */
+int specinv_lbfgs_dev_create(specinv_plan* plan, int64_t n, const specinv_lbfgs_opts* opts, int32_t* handle_out);
+/* one optimizer.step on x (batch, length), updated in place; target as in specinv_transform_loss_grad */
+int specinv_lbfgs_dev_step(specinv_plan* plan, int32_t handle, void* x, int64_t length, const void* target,
+                           specinv_lbfgs_info* info_out);
+int specinv_lbfgs_dev_destroy(specinv_plan* plan, int32_t handle);
+
 #ifdef __cplusplus
 }
 #endif

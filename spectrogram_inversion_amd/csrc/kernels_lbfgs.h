@@ -1033,7 +1033,11 @@ inline int obj_mel_tiles(int n_mels) {
 static __global__ void k_objective_epilogue(float* __restrict__ grad, const float* __restrict__ xtail, const float* __restrict__ margins,
                                      const double* __restrict__ part, double* __restrict__ slot, int T, int nchunks, int n_fft, int hop,
                                      int keep, int pad, int pad_mode, int64_t len, int64_t rows, int64_t n_tail, int64_t n_margin,
-                                     int n_part, double scale) {
+                                     int n_part, double scale, fast::ObjCtl ctl) {
+  if (ctl.do_eval != nullptr) {                  // device-resident optimiser: gate and gradient ping-pong (lbfgs_dev.h)
+    if (*ctl.do_eval == 0) return;
+    if ((*ctl.cur ^ 1) != 0) grad = ctl.grad_alt;
+  }
   const int64_t tail_blocks = (n_tail + 255) / 256, margin_blocks = (n_margin + 255) / 256;
   const bool fold = pad > 0 && pad_mode != SPECINV_PAD_CONSTANT;
   const int64_t covered = (int64_t)(T - 1) * hop + n_fft;                // padded positions that receive any frame
@@ -1128,7 +1132,7 @@ int tf_finish_loss(P& pl, int64_t n_part, double numel, double* loss_host, doubl
 // `*used` stays false when the configuration is not covered: the caller then runs the kernel chain.
 template <typename P>
 int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, double* loss, float* grad, bool* used,
-                       double* loss_dev = nullptr) {
+                       double* loss_dev = nullptr, const fast::ObjCtl* ctl = nullptr) {
   *used = false;
   const bool mag = pl.tf_kind == SPECINV_TF_MAG;
   if (pl.force_generic || !pl.cfg.onesided || !pl.fast.xform_ok || (pl.fast.xform_R != 8 && pl.fast.xform_R != 16)) return SPECINV_OK;
@@ -1168,6 +1172,11 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   a.fwd_scale = pl.fc.fwd_scale;
   a.dscale = (float)(2.0 / numel);
   a.hop_magic = (unsigned)(((1ull << 32) + hop - 1) / hop);
+  if (ctl) {
+    a.ctl_eval = ctl->do_eval;
+    a.ctl_cur = ctl->cur;
+    a.grad_alt = ctl->grad_alt;
+  }
   const void* fn = nullptr;
   size_t lds = 0;
 #define SPECINV_OBJ_CASE(RR, MM)                                   \
@@ -1222,7 +1231,8 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     double* slot = loss_dev ? loss_dev : pl.sums.template as<double>();
     hipLaunchKernelGGL(k_objective_epilogue, dim3((unsigned)blocks), dim3(256), 0, pl.stream, grad, (const float*)a.xtail,
                        (const float*)a.margins, (const double*)pl.partials.template as<double>(), slot, T, nch, N, hop, keep,
-                       pad, pl.cfg.pad_mode, (int64_t)len, (int64_t)B, n_tail, n_margin, (int)n_tiles, 1.0 / numel);
+                       pad, pl.cfg.pad_mode, (int64_t)len, (int64_t)B, n_tail, n_margin, (int)n_tiles, 1.0 / numel,
+                       ctl ? *ctl : fast::ObjCtl{});
     SI_HIP(hipGetLastError());
   }
   if (loss_dev) return SPECINV_OK;

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   float* dmt = tile + FP * RS;
   float* uni = dmt + 16 * MT * RS;
   __shared__ double lsum[kObjWaves];
+  if (a.ctl_eval != nullptr && *a.ctl_eval == 0) return;     // (the optimiser has stopped: the rest of its enqueued step is no-ops)
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   v2f* tr = reinterpret_cast<v2f*>(uni) + wib * G::TR;
   const LaneConst<R> k = lane_consts<R>();
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   const long long p0 = (long long)t0 * a.hop;
   const int owned = nfr * a.hop, keep = N - a.hop;
   const bool last = c == a.nchunks - 1;
-  float* go = a.grad + (long long)b * a.len;
+  float* go = ((a.ctl_cur != nullptr && (*a.ctl_cur ^ 1) != 0) ? a.grad_alt : a.grad) + (long long)b * a.len;
   float* mgn = a.margins + (long long)b * 2 * a.pad;
   float* tl = a.xtail + ((long long)b * a.nchunks + c) * keep;
   const long long n0 = p0 - a.pad;                          // signal index of span[0]

@@ -34,9 +34,20 @@ struct ObjArgs {
   float fwd_scale;
   float dscale;            // 2 / numel
   unsigned hop_magic;      // ceil(2^32 / hop) (hop > 1), for the division-free frame lookup of the overlap-add
+  // device-resident optimiser (lbfgs_dev.h): run only if *ctl_eval != 0; the gradient goes to (*ctl_cur ^ 1 ? grad_alt : grad)
+  const int* ctl_eval;
+  const int* ctl_cur;
+  float* grad_alt;
 #if SPECINV_OBJ_STAMPS
   unsigned long long* stamps;   // [tiles][16]
 #endif
+};
+
+// what lbfgs_dev.h hands to the objective: the gate and the gradient ping-pong of the optimiser's state record
+struct ObjCtl {
+  const int* do_eval;
+  const int* cur;
+  float* grad_alt;
 };
 
 // Layout of the block table (ints): the non-zero blocks are sorted by bin group, then mel group.

@@ -86,6 +86,9 @@ struct PlanBase {
   virtual int read_doubles(const double* src_dev, int n, double* out_host) = 0;
   virtual int board_alloc(int n, double** host_out, double** dev_out) = 0;
   virtual int stream_wait() = 0;
+  virtual int lbfgs_dev_create(int64_t n, const specinv_lbfgs_opts* opts, int32_t* handle_out) = 0;
+  virtual int lbfgs_dev_step(int32_t handle, void* x, int64_t len, const void* target, specinv_lbfgs_info* info) = 0;
+  virtual int lbfgs_dev_destroy(int32_t handle) = 0;
 
   // _training_loop (methods.py:153-190) driving `iterate`
   int run_loop(int max_iter, int eva_iter, double tol, int metric, specinv_eval* evals, int* n_evals,

@@ -11,6 +11,7 @@
 #include "fast_state.h"
 #include "kernels_generic.h"
 #include "kernels_lbfgs.h"
+#include "lbfgs_dev.h"
 #include "kernels_rtisi.h"
 #include "plan.h"
 
@@ -768,6 +769,41 @@ struct PlanT final : PlanBase {
   }
   int stream_wait() override {
     SI_HIP(si_stream_wait_short(stream));
+    return SPECINV_OK;
+  }
+
+  // the device-resident optimiser (lbfgs_dev.h): float32 on the one-launch objective
+  std::vector<std::unique_ptr<LbfgsDev<float>>> lbfgs_devs;
+  std::vector<std::unique_ptr<FastBuf>> lbd_pool;     // parameter-sized vectors of optimisers that are gone, for the next one
+  int lbfgs_dev_create(int64_t n, const specinv_lbfgs_opts* opts, int32_t* handle_out) override {
+    SI_CHECK(opts && handle_out, SPECINV_EINVAL, "null pointer");
+    if constexpr (std::is_same<T, float>::value) {
+      SI_CHECK(tf_kind >= 0, SPECINV_ESTATE, "specinv_transform_setup has not been called");
+      std::unique_ptr<LbfgsDev<float>> L(new LbfgsDev<float>());
+      SI_TRY(lbd_create(*this, *L, n, *opts));
+      size_t slot = 0;
+      while (slot < lbfgs_devs.size() && lbfgs_devs[slot]) ++slot;
+      if (slot == lbfgs_devs.size()) lbfgs_devs.emplace_back();
+      lbfgs_devs[slot] = std::move(L);
+      *handle_out = (int32_t)slot;
+      return SPECINV_OK;
+    } else {
+      return fail(SPECINV_EUNSUPPORTED, "the device-resident optimiser is float32 only");
+    }
+  }
+  int lbfgs_dev_step(int32_t handle, void* xs, int64_t len, const void* target, specinv_lbfgs_info* info) override {
+    if constexpr (std::is_same<T, float>::value) {
+      SI_CHECK(handle >= 0 && (size_t)handle < lbfgs_devs.size() && lbfgs_devs[handle], SPECINV_EINVAL, "bad optimiser handle");
+      return lbd_step(*this, *lbfgs_devs[handle], static_cast<float*>(xs), len, static_cast<const float*>(target), info);
+    } else {
+      return fail(SPECINV_EUNSUPPORTED, "the device-resident optimiser is float32 only");
+    }
+  }
+  int lbfgs_dev_destroy(int32_t handle) override {
+    SI_CHECK(handle >= 0 && (size_t)handle < lbfgs_devs.size() && lbfgs_devs[handle], SPECINV_EINVAL, "bad optimiser handle");
+    SI_HIP(hipStreamSynchronize(stream));
+    for (auto& b : lbfgs_devs[handle]->vecs) lbd_pool.push_back(std::move(b));
+    lbfgs_devs[handle].reset();
     return SPECINV_OK;
   }
 };

@@ -441,5 +441,18 @@ int specinv_stream_wait(specinv_plan* plan) {
   ENTER(plan);
   return plan->impl->stream_wait();
 }
+int specinv_lbfgs_dev_create(specinv_plan* plan, int64_t n, const specinv_lbfgs_opts* opts, int32_t* handle_out) {
+  ENTER(plan);
+  return plan->impl->lbfgs_dev_create(n, opts, handle_out);
+}
+int specinv_lbfgs_dev_step(specinv_plan* plan, int32_t handle, void* x, int64_t length, const void* target,
+                           specinv_lbfgs_info* info_out) {
+  ENTER(plan);
+  return plan->impl->lbfgs_dev_step(handle, x, length, target, info_out);
+}
+int specinv_lbfgs_dev_destroy(specinv_plan* plan, int32_t handle) {
+  ENTER(plan);
+  return plan->impl->lbfgs_dev_destroy(handle);
+}
 
 }  // extern "C"

@@ -166,11 +166,15 @@ class LBFGS:
         self.prev_grad = None
         self.prev_loss = None
         self._board = None
+        self._dev = None                       # device-resident optimiser: None undecided, False not taken, else its handle
+        self._dev_history = 0
+        self.time_objective = False            # benchmarks: HIP events around every objective evaluation of the device path
+        self.objective_ms, self.objective_launches = 0.0, 0
 
     @property
     def history_len(self):
         """curvature pairs in the memory (<= history_size)"""
-        return len(self.ss)
+        return self._dev_history if self._dev else len(self.ss)
 
     # ---- pieces -----------------------------------------------------------------------------
     def _forget(self):
@@ -418,8 +422,61 @@ class LBFGS:
         self.d, self.t = d, t
         return first_loss
 
+    # ---- one optimizer.step with the decisions on the device: one host synchronisation per STEP -------------------
+    def _device_ok(self, fg):
+        """The device-resident optimiser (csrc/lbfgs_dev.h) serves float32 parameters on the one-launch objective, no line
+        search, history_size <= 120.  Decided at the first step; an optimiser never changes paths afterwards (its state
+        lives where its path keeps it)."""
+        if self._dev is not None:
+            return self._dev is not False
+        self._dev = False
+        obj = getattr(fg, "device_objective", None)
+        if obj is None or self.line_search is not None or not self.gram or os.environ.get("SPECINV_LBFGS_DEVICE", "1") == "0":
+            return False
+        plan, target, shape = obj
+        x = self.x
+        if self.total_iters != 0 or x.dtype != torch.float32 or not x.is_contiguous() or x.data_ptr() % 16 != 0 or \
+                x.numel() != shape[0] * shape[1] or not 1 <= self.history_size <= 120:
+            return False
+        from . import _lib
+        try:
+            handle = plan.lbfgs_dev_create(x.numel(), self.lr, self.max_iter, self.max_eval, self.tol_grad, self.tol_change,
+                                           self.history_size, self.time_objective)
+        except (_lib.SpecinvError, NotImplementedError):
+            return False
+        self._dev = (plan, handle, target, shape)
+        return True
+
+    def _step_device(self, fg):
+        from . import _lib
+        plan, handle, target, shape = self._dev
+        try:
+            info = plan.lbfgs_dev_step(handle, self.x.view(shape), target)
+        except NotImplementedError:
+            if self.total_iters != 0:
+                raise
+            plan.lbfgs_dev_destroy(handle)              # a configuration the one-launch objective does not cover: host-driven loop
+            self._dev = False
+            return self.step(fg)
+        self.total_iters, self.func_evals = info.total_iters, info.func_evals
+        self.pairs_accepted, self.pairs_rejected = info.pairs_accepted, info.pairs_rejected
+        self._dev_history, self.t, self.prev_loss = info.history_len, info.t, info.loss
+        self.objective_ms += info.objective_ms
+        self.objective_launches += info.objective_launches
+        return info.first_loss
+
+    def __del__(self):
+        dev = getattr(self, "_dev", None)
+        if dev:
+            try:
+                dev[0].lbfgs_dev_destroy(dev[1])
+            except Exception:                           # (interpreter shutdown: the plan may be gone already)
+                pass
+
     # ---- one optimizer.step ------------------------------------------------------------------
     def step(self, fg):
+        if self._device_ok(fg):
+            return self._step_device(fg)
         if self.line_search is None and self.gram and getattr(self.ops, "packed", False) and \
                 os.environ.get("SPECINV_LBFGS_PACKED", "1") != "0":
             return self._step_packed(fg)

@@ -525,6 +525,29 @@ class Plan:
         self._sync_stream()
         _lib.check(self.lib.specinv_lbfgs_stats_dev(self._h, g.data_ptr(), d.data_ptr(), g.numel(), out_ptr))
 
+    # ---- the device-resident optimiser (csrc/lbfgs_dev.h) --------------------------------------------------------------
+    def lbfgs_dev_create(self, n: int, lr, max_iter, max_eval, tolerance_grad, tolerance_change, history_size,
+                         time_objective=False) -> int:
+        self._sync_stream()
+        o = _lib.LbfgsOpts(float(lr), float(tolerance_grad), float(tolerance_change), int(max_iter),
+                           int(max_eval) if max_eval is not None else 0, int(history_size), 1 if time_objective else 0)
+        h = C.c_int32(-1)
+        _lib.check(self.lib.specinv_lbfgs_dev_create(self._h, int(n), C.byref(o), C.byref(h)))
+        return h.value
+
+    def lbfgs_dev_step(self, handle: int, x: torch.Tensor, target: torch.Tensor):
+        """One optimizer.step on x (in place), everything enqueued, one synchronisation.  Returns the info record."""
+        self._sync_stream()
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.device == self.device
+        target = self._in(target, self.dtype, (self.batch, self.n_out, self.n_frames))
+        info = _lib.LbfgsInfo()
+        _lib.check(self.lib.specinv_lbfgs_dev_step(self._h, handle, x.data_ptr(), x.shape[-1], target.data_ptr(), C.byref(info)))
+        return info
+
+    def lbfgs_dev_destroy(self, handle: int):
+        if self._h:
+            _lib.check(self.lib.specinv_lbfgs_dev_destroy(self._h, handle))
+
     def board_alloc(self, n: int):
         """n doubles of pinned host memory the device writes directly: (host ctypes array, device address)."""
         hp, dp = C.c_void_p(), C.c_void_p()

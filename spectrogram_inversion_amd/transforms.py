@@ -80,6 +80,8 @@ class DeviceTransform:
             return plan.transform_loss_grad_dev(v.reshape(x2.shape), tgt, loss_ptr).reshape(v.shape)
 
         fg.dev = fg_dev
+        # what the device-resident optimiser needs (lbfgs.py:_step_device): the plan that owns the objective, and its target
+        fg.device_objective = (plan, tgt, tuple(x2.shape))
         return fwd, fg
 
 

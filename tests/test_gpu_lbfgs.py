@@ -479,3 +479,87 @@ def test_one_pinned_board_per_plan():
     assert a.ops.board(23) is b.ops.board(9 + 2 * 100)
     big = a.ops.board(1000)                                  # grows once, then serves everybody
     assert big.numel() >= 1000 and b.ops.board(50) is big
+
+
+# ---- the device-resident optimiser (csrc/lbfgs_dev.h): decisions in k_lbd_decide, one host synchronisation per step ----------
+def _device_problem(kind, seed=7):
+    rng = np.random.default_rng(seed)
+    if kind == "logmel":
+        n_fft, hop, frames, batch = 2048, 512, 24, 2
+        tr = LogMelSTFT(torch.from_numpy(si.mel_filterbank(22050, n_fft, 80)).to(dev()), n_fft, hop_length=hop,
+                        window=torch.from_numpy(hann(n_fft)))
+    else:
+        n_fft, hop, frames, batch = 1024, 256, 30, 3
+        tr = MagSTFT(n_fft, hop_length=hop, window=torch.from_numpy(hann(n_fft)))
+    length = (frames - 1) * hop
+    xs = torch.from_numpy((0.1 * rng.standard_normal((batch, length))).astype(np.float32)).to(dev())
+    x0 = torch.from_numpy((1e-2 * rng.standard_normal((batch, length))).astype(np.float32)).to(dev())
+    return tr, tr(xs), x0
+
+
+def _run_steps(monkeypatch, device_path, tr, target, x0, steps, **kw):
+    monkeypatch.setenv("SPECINV_LBFGS_DEVICE", "1" if device_path else "0")
+    x = x0.clone()
+    _, fg = tr.bind(x, target)
+    opt = LBFGS(x, device=dev(), **kw)
+    losses, snaps = [], []
+    for _ in range(steps):
+        losses.append(opt.step(fg))
+        snaps.append((x.clone(), opt.total_iters, opt.func_evals, int(opt.pairs_accepted), int(opt.pairs_rejected), opt.history_len))
+    assert bool(opt._dev) == device_path
+    return losses, snaps
+
+
+@pytest.mark.parametrize("kind,kw,steps", [
+    ("logmel", dict(), 3),                                       # torch.optim.LBFGS defaults: max_iter 20, history 100
+    ("logmel", dict(max_iter=12, history_size=3), 4),            # the memory ring wraps (drop-oldest on the device)
+    ("mag", dict(max_iter=10), 3),
+    ("mag", dict(max_iter=50, history_size=10), 2),              # the reference demo's options (main.py:43)
+    ("mag", dict(max_iter=20, tolerance_change=1e-4), 3),        # a tolerance that breaks steps early: the rest is no-ops
+    ("logmel", dict(max_iter=6, max_eval=4), 3),                 # max_eval ends the inner loop
+])
+def test_device_resident_optimiser_retraces_the_host_driven_loop(monkeypatch, kind, kw, steps):
+    """One `optimizer.step` enqueued as a whole with the decisions of torch.optim.LBFGS.step taken by `k_lbd_decide` on the
+    device (curvature guard, memory ring, Gram recursion, tolerance tests) against the same step driven from the host with one
+    read-back per inner iteration (`_step_packed`, itself retraced against torch.optim.LBFGS in test_host_logic.py and on the g6 /
+    g9 fixtures): the same counters after every step, the same losses and iterates up to the order of the float64 sums."""
+    tr, target, x0 = _device_problem(kind)
+    la, sa = _run_steps(monkeypatch, False, tr, target, x0, steps, **kw)
+    lb, sb = _run_steps(monkeypatch, True, tr, target, x0, steps, **kw)
+    for i, (a, b) in enumerate(zip(sa, sb)):
+        assert a[1:] == b[1:], (i, a[1:], b[1:])                  # total_iters, func_evals, accepted, rejected, history
+        # (bit-identical while the memory is short; with dozens of pairs the float64 sums of the recursion are taken in another
+        # order - wave reductions against numpy's dot - and the last digits of a nearly converged iterate move)
+        tol = 1e-6 if a[5] <= 20 else 2e-3
+        assert rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()) < tol, (i, rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()))
+    np.testing.assert_allclose(lb, la, rtol=1e-4)
+    assert sa[-1][3] > 0                                          # (pairs were accepted: the memory path ran)
+
+
+def test_device_resident_optimiser_at_the_optimum_and_reuse(monkeypatch):
+    """At a stationary point max|g| <= tolerance_grad ends the step at its entry evaluation (nothing moves, one evaluation);
+    two optimisers on one plan keep their states apart; a dropped optimiser frees its state (its parameter-sized vectors go back to
+    the plan's pool for the next optimiser)."""
+    monkeypatch.setenv("SPECINV_LBFGS_DEVICE", "1")
+    tr, target, x0 = _device_problem("mag")
+    xs = torch.from_numpy((0.1 * np.random.default_rng(7).standard_normal(tuple(x0.shape))).astype(np.float32)).to(dev())
+    x = xs.clone()
+    _, fg = tr.bind(x, tr(xs))
+    opt = LBFGS(x, device=dev(), tolerance_grad=1e-3)
+    loss = opt.step(fg)
+    assert opt._dev and loss < 1e-10 and opt.func_evals == 1 and opt.total_iters == 0 and torch.equal(x, xs)
+    a, b = x0.clone(), x0.clone()
+    _, fga = tr.bind(a, target)
+    _, fgb = tr.bind(b, target)
+    oa, ob = LBFGS(a, device=dev(), max_iter=5), LBFGS(b, device=dev(), max_iter=5)
+    for _ in range(3):
+        oa.step(fga)
+    for _ in range(3):
+        ob.step(fgb)
+    assert oa._dev and ob._dev and oa._dev[1] != ob._dev[1] and torch.equal(a, b)
+    plan = oa._dev[0]
+    before = plan.device_bytes
+    del oa, ob, opt
+    import gc
+    gc.collect()
+    assert plan.device_bytes < before
