@@ -102,6 +102,13 @@ int64_t specinv_plan_device_bytes(const specinv_plan* plan);
 int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]);
 /* 0: allow the fast path when the configuration supports it (default); 1: force the generic kernels. */
 int specinv_plan_force_generic(specinv_plan* plan, int on);
+/* The magnitude projection S * m / (|S| + 1e-16) and the division by the overlap-add envelope exactly as the reference rounds them
+ * (torch_specinv/methods.py:132,246-247: correctly rounded sqrt and divisions) instead of the default v_sqrt_f32 / v_rcp_f32 and a
+ * multiplication by 1 / envelope.  The default differs from the reference by less than the reference's own float32-vs-float64 noise
+ * except where a bin passes close to zero on inconsistent magnitudes (one neighbourhood in 18 fixture cases after 100 iterations,
+ * profiles/r02_ieee_study.txt); the exact kernels cost ~10 % on the headline kernel.  Applies to the float32 wave-level kernels
+ * (fused, frame, chunked frame); the generic kernels and float64 are exact already.  Takes effect at the next specinv_gla_init / specinv_admm_init. */
+int specinv_plan_set_exact(specinv_plan* plan, int on);
 /* The float32 fast paths do not carry the reference's spectral state as such.
  * ADMM keeps only Y = X + U between iterations: methods.py:467-468 read the two as U + X, i.e. the Y that :475 has just
  * rounded, so the iterates are bit-identical and the state traffic halves.  Griffin-Lim on the fused shapes (hop = n_fft/2, /4, /8) and on the chunked

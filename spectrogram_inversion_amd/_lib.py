@@ -63,6 +63,7 @@ SIGNATURES = {
     "specinv_plan_device_bytes": (_I64, [_P]),
     "specinv_plan_launch_geometry": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "specinv_plan_force_generic": (C.c_int, [_P, C.c_int]),
+    "specinv_plan_set_exact": (C.c_int, [_P, C.c_int]),
     "specinv_plan_keep_state": (C.c_int, [_P, C.c_int]),
     "specinv_stft": (C.c_int, [_P, _P, _I64, _P]),
     "specinv_istft": (C.c_int, [_P, _P, _P]),

@@ -74,8 +74,18 @@
 #define SPECINV_R8_W3 1      // 168 registers (ADMM 2 spilled, the evaluating variants 8-31); measured against two waves per SIMD:
 #endif                       // C4 34.3 -> 32.3 ms per step, Griffin-Lim 1024 / 256 0.135 -> 0.127 ms per iteration
 
+// The wave-level kernels are compiled twice: as `specinv::fast` with the hardware's approximate sqrt / reciprocal in the
+// projection and a multiplication by 1 / envelope (default; 10 % faster on the headline kernel), and - in the tu_exact_*.hip
+// units, which define SPECINV_IEEE=1 and SI_FAST_NS=fast_exact before including the kernel headers - as `specinv::fast_exact`
+// with correctly rounded sqrt and divisions and a true division by the envelope, the reference's own operations
+// (methods.py:132,246-247).  `specinv_plan_set_exact` selects the second set (fast_state.h takes its kernels' addresses from
+// the extern "C" tables of those units).
+#ifndef SI_FAST_NS
+#define SI_FAST_NS fast
+#endif
+
 namespace specinv {
-namespace fast {
+namespace SI_FAST_NS {
 
 using v2f = float __attribute__((ext_vector_type(2)));
 using v4f = float __attribute__((ext_vector_type(4)));
@@ -964,5 +974,5 @@ __global__ void k_hop_td(HopArgs s);
 template <int R>
 __global__ void k_hop_inverse(HopInvArgs a);
 
-}  // namespace fast
+}  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
 }  // namespace specinv

@@ -3,7 +3,23 @@
 #include "fast_core.h"
 #include "kernels_layout.h"
 
+// kernel tables of the exact-projection units (tu_exact_*.hip): nullptr where there is no such kernel
+extern "C" {
+__attribute__((visibility("hidden"))) const void* specinv_exact_fused_a(int R, int OV, int mode, int eval, int tuned4);
+__attribute__((visibility("hidden"))) const void* specinv_exact_fused_b(int R, int OV, int mode, int eval, int tuned4);
+__attribute__((visibility("hidden"))) const void* specinv_exact_fused_c(int R, int OV, int mode, int eval, int tuned4);
+__attribute__((visibility("hidden"))) const void* specinv_exact_td(int R, int OV, int early, int eval, int tuned4);
+__attribute__((visibility("hidden"))) const void* specinv_exact_frame(int family, int R, int a, int b);
+}
+
 namespace specinv {
+
+inline const void* exact_fused(int R, int OV, int mode, int eval, int tuned4) {
+  const void* fn = specinv_exact_fused_a(R, OV, mode, eval, tuned4);
+  if (!fn) fn = specinv_exact_fused_b(R, OV, mode, eval, tuned4);
+  if (!fn) fn = specinv_exact_fused_c(R, OV, mode, eval, tuned4);
+  return fn;
+}
 
 // ---- host side ---------------------------------------------------------------------------------------
 struct FastBuf {
@@ -43,6 +59,7 @@ struct FastState {
   bool hopk = false;
   bool xform_ok = false;
   bool keep_state = false;
+  bool exact = false;
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
   void geometry(int out[4]) const { out[0] = out[1] = out[2] = out[3] = 0; }
@@ -91,6 +108,9 @@ struct FastState<float> {
   // ADMM carries Y = X + U in Pb (FastArgs).  X and U themselves are only written when the caller has asked for them
   // (specinv_plan_keep_state), by the last iteration of every iterate() call.
   bool keep_state = false, xu_valid = false;
+  // the projection as the reference rounds it (correctly rounded sqrt / divisions, division by the envelope): the kernels of the
+  // tu_exact_*.hip units, 10 % slower on the headline kernel (specinv_plan_set_exact)
+  bool exact = false;
   FastBuf Xb, Xmid, Ub, Umid;
   // Griffin-Lim on k_fused4_td: the momentum state is the signal z (zb), Pb keeps the starting spectrum c0
   bool td = false;
@@ -331,7 +351,7 @@ struct FastState<float> {
     }
     if (hopk) {
       hipLaunchKernelGGL(fast::k_reciprocal, dim3((unsigned)ceil_div(pl.length, 256)), dim3(256), 0, pl.stream,
-                         pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length);
+                         pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length, exact ? 1 : 0);
       SI_HIP(hipGetLastError());
     }
     if (semi) {
@@ -344,7 +364,7 @@ struct FastState<float> {
       return SPECINV_OK;
     }
     hipLaunchKernelGGL(fast::k_reciprocal, dim3((unsigned)ceil_div(pl.length, 256)), dim3(256), 0, pl.stream,
-                       pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length);
+                       pl.env.template as<float>(), inv_env.template as<float>(), (long long)pl.length, exact ? 1 : 0);
     SI_HIP(hipGetLastError());
     SI_HIP(hipMemsetAsync(xtail[0].p, 0, tail_bytes, pl.stream));   // x0 below is written whole
     // x0 = ISTFT(start spectrum) (methods.py:233 / :453) straight from the pair layout
@@ -367,6 +387,7 @@ struct FastState<float> {
     }
     if (OV == 4) fn = (const void*)fast::k_fused_istft<RR, 4>;
     if (OV == 2) fn = (const void*)fast::k_fused_istft<RR, 2>;
+    if (exact && fn != nullptr) fn = exact_fused(RR, OV, 2, 0, 0);
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&a};
@@ -508,6 +529,7 @@ struct FastState<float> {
       if (OV == 4) fn = (const void*)fast::k_fused<RR, 4, MODE, EVAL>;
     }
     if (OV == 2) fn = (const void*)fast::k_fused<RR, 2, MODE, EVAL>;
+    if (exact && fn != nullptr) fn = exact_fused(RR, OV, MODE, EVAL ? 1 : 0, ((RR == 8 || RR == 16) && OV == 4 && !use_template) ? 1 : 0);
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     const int wgw = fused_wgw();
     const size_t lds_used = G::lds_bytes(wgw);
@@ -540,6 +562,7 @@ struct FastState<float> {
                        else { if (OV == 4) fn = td_kernel<RR, 4>(early, ev); }
                        if (OV == 2) fn = td_kernel<RR, 2>(early, ev);
                      });
+    if (exact && fn != nullptr) fn = specinv_exact_td(R, OV, early ? 1 : 0, ev ? 1 : 0, ((R == 8 || R == 16) && OV == 4) ? 1 : 0);
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
     fast::FastArgs args = a;
@@ -597,7 +620,8 @@ struct FastState<float> {
     s.hop = pl.cfg.hop_length;
     s.pad = pl.pad;
     const size_t lds = G::lds_bytes(4);
-    const void* fn = (const void*)fast::k_semi<RR, MODE, EVAL>;
+    const void* fn = exact ? specinv_exact_frame(0, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_semi<RR, MODE, EVAL>;
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no exact-projection frame kernel for this shape");
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&s};
     SI_HIP(hipLaunchKernel(fn, dim3(semi_grid), dim3(256), kargs, lds, pl.stream));
@@ -635,14 +659,15 @@ struct FastState<float> {
     s.hop = hop;
     s.pad = pl.pad;
     const size_t lds = G::lds_bytes(wgw) + (size_t)wgw * G::N * sizeof(float);
-    const void* fn = (const void*)fast::k_hop<RR, MODE, EVAL>;
+    const void* fn = exact ? specinv_exact_frame(1, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_hop<RR, MODE, EVAL>;
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no exact-projection chunked frame kernel for this shape");
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&s};
     SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds, pl.stream));
     if (nchunks > 1 && keep > 0) {
       const long long total = (long long)pl.B() * (nchunks - 1) * keep;
       hipLaunchKernelGGL(fast::k_hop_tails, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, a.x_out,
-                         (const float*)s.xtail, s.env, pl.Tn(), nchunks, hop, keep, pl.pad, (long long)pl.length, total);
+                         (const float*)s.xtail, s.env, pl.Tn(), nchunks, hop, keep, pl.pad, (long long)pl.length, total, exact ? 1 : 0);
       SI_HIP(hipGetLastError());
     }
     cur = nx;
@@ -688,6 +713,8 @@ struct FastState<float> {
     const size_t lds = G::lds_bytes(wgw) + (size_t)wgw * G::N * sizeof(float);
     const void* fn = early ? (ev ? (const void*)fast::k_hop_td<RR, true, true> : (const void*)fast::k_hop_td<RR, true, false>)
                            : (ev ? (const void*)fast::k_hop_td<RR, false, true> : (const void*)fast::k_hop_td<RR, false, false>);
+    if (exact) fn = specinv_exact_frame(2, RR, early ? 1 : 0, ev ? 1 : 0);
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no exact-projection chunked frame kernel for this shape");
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&s};
     SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds, pl.stream));
@@ -695,7 +722,7 @@ struct FastState<float> {
       const long long total = (long long)pl.B() * (nchunks - 1) * keep;
       hipLaunchKernelGGL(fast::k_hop_tails_td, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, pl.stream, a.x2_out, a.x_out,
                          a.x_in, (const float*)s.xtail, s.env, a.coef, pl.Tn(), nchunks, hop, keep, pl.pad, (long long)pl.length,
-                         total);
+                         total, exact ? 1 : 0);
       SI_HIP(hipGetLastError());
     }
     cur = nx;

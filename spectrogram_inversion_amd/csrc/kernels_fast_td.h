@@ -5,7 +5,7 @@
 #include "fast_core.h"
 
 namespace specinv {
-namespace fast {
+namespace SI_FAST_NS {
 
 // ---- Griffin-Lim with the momentum carried in the time domain (every fused shape: hop = n_fft/2, /4, /8) ---------------------
 // methods.py:243-244 keep pre_t = STFT(x_t) - lr * pre_{t-1}, a (B, F, T) complex array read and written every iteration
@@ -367,5 +367,5 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : (SPECINV_R8_W3 && R == 8) ? 3 : 
   fused_td_body<R, OV, EARLY, EVAL>(a);
 }
 
-}  // namespace fast
+}  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
 }  // namespace specinv

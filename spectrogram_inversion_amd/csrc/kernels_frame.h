@@ -7,7 +7,7 @@
 #include "fast_core.h"
 
 namespace specinv {
-namespace fast {
+namespace SI_FAST_NS {
 
 // ---- stand-alone transforms on the wave-level FFT (any hop; used by specinv_stft and the L_BFGS objective) ----
 
@@ -757,5 +757,5 @@ __global__ __launch_bounds__(512, 1) void k_hop_inverse(HopInvArgs a) {
 
 
 
-}  // namespace fast
+}  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
 }  // namespace specinv

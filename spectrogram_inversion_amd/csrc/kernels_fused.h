@@ -3,7 +3,7 @@
 #include "fast_core.h"
 
 namespace specinv {
-namespace fast {
+namespace SI_FAST_NS {
 
 template <int R, int MODE, bool EVAL>
 __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW, (SPECINV_R8_W3 && R == 8) ? 3 : SPECINV_MINWAVES) void k_fused4(FastArgs a) {
@@ -629,5 +629,5 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
 }
 
 
-}  // namespace fast
+}  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
 }  // namespace specinv

@@ -243,16 +243,18 @@ __global__ void k_mag_to_pairs(const float* __restrict__ mag, v4f* __restrict__ 
   if (lane == 0 && c == 0) mid[f] = s[G::M / 2];
 }
 
-static __global__ void k_reciprocal(const float* __restrict__ in, float* __restrict__ out, long long n) {
+// the envelope table of the wave-level kernels: 1 / envelope (they multiply), or - exact projection - the envelope itself (they
+// divide, like methods.py:132)
+static __global__ void k_reciprocal(const float* __restrict__ in, float* __restrict__ out, long long n, int exact) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = SPECINV_IEEE ? in[i] : 1.0f / in[i];
+  if (i < n) out[i] = exact ? in[i] : 1.0f / in[i];
 }
 
 
 // x[n] = (own partial sum + the previous chunk's tail) * (1 / envelope), z_out[n] = x[n] - lr z_in[n] over the seam samples
 static __global__ void k_hop_tails_td(float* __restrict__ x, float* __restrict__ z_out, const float* __restrict__ z_in,
                                const float* __restrict__ xtail, const float* __restrict__ env, float lr, int T, int nchunks,
-                               int hop, int keep, int pad, long long L, long long total) {
+                               int hop, int keep, int pad, long long L, long long total, int exact) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
   if (i >= total) return;
   const int j = (int)(i % keep);
@@ -260,7 +262,8 @@ static __global__ void k_hop_tails_td(float* __restrict__ x, float* __restrict__
   const long long b = i / ((long long)keep * (nchunks - 1));
   const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
   if (n < 0 || n >= L) return;
-  const float xv = env_apply(x[b * L + n] + xtail[(b * nchunks + (c - 1)) * keep + j], env[n]);
+  const float sum = x[b * L + n] + xtail[(b * nchunks + (c - 1)) * keep + j];
+  const float xv = exact ? __fdiv_rn(sum, env[n]) : sum * env[n];
   x[b * L + n] = xv;
   z_out[b * L + n] = fmaf(-lr, z_in[b * L + n], xv);
 }
@@ -281,7 +284,7 @@ static __global__ void k_hop_tails_raw(float* __restrict__ x, const float* __res
 
 // x[n] = (own partial sum + the previous chunk's tail) * (1 / envelope) over the first n_fft - hop samples of chunks 1..
 static __global__ void k_hop_tails(float* __restrict__ x, const float* __restrict__ xtail, const float* __restrict__ env, int T,
-                            int nchunks, int hop, int keep, int pad, long long L, long long total) {
+                            int nchunks, int hop, int keep, int pad, long long L, long long total, int exact) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c - 1, j)
   if (i >= total) return;
   const int j = (int)(i % keep);
@@ -290,7 +293,8 @@ static __global__ void k_hop_tails(float* __restrict__ x, const float* __restric
   const long long n = (long long)hop_chunk_begin(c, T, nchunks) * hop + j - pad;
   if (n < 0 || n >= L) return;
   float* px = x + b * L + n;
-  *px = env_apply(*px + xtail[(b * nchunks + (c - 1)) * keep + j], env[n]);
+  const float sum = *px + xtail[(b * nchunks + (c - 1)) * keep + j];
+  *px = exact ? __fdiv_rn(sum, env[n]) : sum * env[n];
 }
 
 }  // namespace fast

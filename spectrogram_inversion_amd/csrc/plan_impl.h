@@ -387,6 +387,7 @@ struct PlanT final : PlanBase {
     count = (double)ns;
     const C* start_user = static_cast<const C*>(init_spec);
     fast.keep_state = keep_state;
+    fast.exact = exact;
     if constexpr (std::is_same<T, float>::value) {
       // fused kernels, magnitude input: phase_init writes the pair layout itself (methods.py:106 without the (B, F, T)
       // complex round trip and the two layout passes)

@@ -197,6 +197,11 @@ int specinv_plan_keep_state(specinv_plan* plan, int on) {
   plan->impl->keep_state = on != 0;
   return SPECINV_OK;
 }
+int specinv_plan_set_exact(specinv_plan* plan, int on) {
+  PLAN_OR_FAIL(plan);
+  plan->impl->exact = on != 0;          // (read by the next specinv_gla_init / specinv_admm_init: a running method keeps its kernels)
+  return SPECINV_OK;
+}
 int specinv_plan_force_generic(specinv_plan* plan, int on) {
   PLAN_OR_FAIL(plan);
   SI_CHECK(plan->impl->method == Method::None, SPECINV_ESTATE, "cannot switch paths while a method is running");

@@ -1,0 +1,49 @@
+// k_fused<R, OV> / k_fused_istft at n_fft 4096 with the exact projection.
+// The exact-projection copy of these kernels (fast_core.h): correctly rounded sqrt / divisions and a true division by the envelope,
+// the reference's own operations (torch_specinv/methods.py:132,246-247), in namespace specinv::fast_exact.  The host side takes
+// the kernels' addresses from the table function below (specinv_plan_set_exact).
+#define SPECINV_IEEE 1
+#define SI_FAST_NS fast_exact
+#include "kernels_fused.h"
+
+namespace specinv {
+namespace fast_exact {
+
+template __global__ void k_fused<32, 8, MODE_GLA, false>(FastArgs);
+template __global__ void k_fused<32, 8, MODE_GLA, true>(FastArgs);
+template __global__ void k_fused<32, 8, MODE_ADMM, false>(FastArgs);
+template __global__ void k_fused<32, 8, MODE_ADMM, true>(FastArgs);
+template __global__ void k_fused_istft<32, 8>(FastArgs);
+template __global__ void k_fused<32, 4, MODE_GLA, false>(FastArgs);
+template __global__ void k_fused<32, 4, MODE_GLA, true>(FastArgs);
+template __global__ void k_fused<32, 4, MODE_ADMM, false>(FastArgs);
+template __global__ void k_fused<32, 4, MODE_ADMM, true>(FastArgs);
+template __global__ void k_fused_istft<32, 4>(FastArgs);
+template __global__ void k_fused<32, 2, MODE_GLA, false>(FastArgs);
+template __global__ void k_fused<32, 2, MODE_GLA, true>(FastArgs);
+template __global__ void k_fused<32, 2, MODE_ADMM, false>(FastArgs);
+template __global__ void k_fused<32, 2, MODE_ADMM, true>(FastArgs);
+template __global__ void k_fused_istft<32, 2>(FastArgs);
+
+}  // namespace fast_exact
+}  // namespace specinv
+
+extern "C" __attribute__((visibility("hidden"))) const void* specinv_exact_fused_c(int R, int OV, int mode /* 0 GLA, 1 ADMM, 2 initial ISTFT */, int eval, int tuned4) {
+  using namespace specinv::fast_exact;
+  if (!tuned4 && R == 32 && OV == 8 && mode == 0 && eval == 0) return (const void*)k_fused<32, 8, MODE_GLA, false>;
+  if (!tuned4 && R == 32 && OV == 8 && mode == 0 && eval == 1) return (const void*)k_fused<32, 8, MODE_GLA, true>;
+  if (!tuned4 && R == 32 && OV == 8 && mode == 1 && eval == 0) return (const void*)k_fused<32, 8, MODE_ADMM, false>;
+  if (!tuned4 && R == 32 && OV == 8 && mode == 1 && eval == 1) return (const void*)k_fused<32, 8, MODE_ADMM, true>;
+  if (mode == 2 && R == 32 && OV == 8) return (const void*)k_fused_istft<32, 8>;
+  if (!tuned4 && R == 32 && OV == 4 && mode == 0 && eval == 0) return (const void*)k_fused<32, 4, MODE_GLA, false>;
+  if (!tuned4 && R == 32 && OV == 4 && mode == 0 && eval == 1) return (const void*)k_fused<32, 4, MODE_GLA, true>;
+  if (!tuned4 && R == 32 && OV == 4 && mode == 1 && eval == 0) return (const void*)k_fused<32, 4, MODE_ADMM, false>;
+  if (!tuned4 && R == 32 && OV == 4 && mode == 1 && eval == 1) return (const void*)k_fused<32, 4, MODE_ADMM, true>;
+  if (mode == 2 && R == 32 && OV == 4) return (const void*)k_fused_istft<32, 4>;
+  if (!tuned4 && R == 32 && OV == 2 && mode == 0 && eval == 0) return (const void*)k_fused<32, 2, MODE_GLA, false>;
+  if (!tuned4 && R == 32 && OV == 2 && mode == 0 && eval == 1) return (const void*)k_fused<32, 2, MODE_GLA, true>;
+  if (!tuned4 && R == 32 && OV == 2 && mode == 1 && eval == 0) return (const void*)k_fused<32, 2, MODE_ADMM, false>;
+  if (!tuned4 && R == 32 && OV == 2 && mode == 1 && eval == 1) return (const void*)k_fused<32, 2, MODE_ADMM, true>;
+  if (mode == 2 && R == 32 && OV == 2) return (const void*)k_fused_istft<32, 2>;
+  return nullptr;
+}

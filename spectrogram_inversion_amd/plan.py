@@ -173,6 +173,13 @@ class Plan:
     def force_generic(self, on=True):
         _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))
 
+    def set_exact(self, on=True):
+        """Round the magnitude projection and the envelope division exactly like the reference (correctly rounded sqrt /
+        divisions, torch_specinv/methods.py:132,246-247) instead of the hardware's approximate sqrt / reciprocal: the
+        float32 wave-level kernels' second instantiation (~10 % slower on the headline kernel).  Call before `gla_init` /
+        `admm_init`: the next init picks the kernels (a running method keeps its own)."""
+        _lib.check(self.lib.specinv_plan_set_exact(self._h, int(on)))
+
     def keep_state(self, on=True):
         """Make the reference's spectral state readable through `state_spec`: X and U of ADMM (the fast paths carry only
         Y = X + U otherwise), pre_spec of griffin_lim (the hop = n_fft/4 kernel carries its momentum as a signal otherwise).
@@ -598,8 +605,25 @@ def get_plan(args: StftArgs, batch: int, n_frames: int, dtype: torch.dtype, devi
     else:
         cache.move_to_end(key)
         plan.keep_state(False)                 # (a per-run request: the next user of a cached plan gets the default kernels)
+    plan.set_exact(exact_projection())
     trim_plan_cache()
     return plan
+
+
+_EXACT = [None]
+
+
+def set_exact_projection(on: bool | None):
+    """Module-level switch for the drop-in functions (their signatures are the reference's, so the choice cannot be an
+    argument): True = the projection and the envelope division rounded exactly like the reference on every plan the public
+    functions create from now on, False = the default fast arithmetic, None = follow the environment (SPECINV_EXACT=1)."""
+    _EXACT[0] = on
+
+
+def exact_projection() -> bool:
+    if _EXACT[0] is not None:
+        return bool(_EXACT[0])
+    return os.environ.get("SPECINV_EXACT", "0") == "1"
 
 
 def trim_plan_cache():

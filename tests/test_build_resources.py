@@ -48,8 +48,9 @@ def kernels():
     return t
 
 
-def _find(table, *parts):
-    hits = [k for k in table if all(p in k for p in parts)]
+def _find(table, *parts, exact=False):
+    """the kernel whose mangled name holds every part, in namespace fast (default) or fast_exact (the exact-projection copy)"""
+    hits = [k for k in table if all(p in k for p in parts) and ("10fast_exact" in k) == exact]
     assert len(hits) == 1, (parts, hits)
     return table[hits[0]]
 
@@ -65,6 +66,9 @@ def test_headline_kernels_keep_their_register_budgets(kernels):
     # C3: k_rtisi_fast<16, 256, 4> - one wave per SIMD, the whole 512-entry file, no spills
     v, sp, a = _find(kernels, "12k_rtisi_fastILi16ELi256ELi4E")
     assert v > 256 and sp == 0, (v, sp, a)
+    # the exact-projection copy of the headline kernel keeps the two-waves budget as well
+    v, sp, _ = _find(kernels, "11k_fused4_tdILi16ELb0ELb0E", exact=True)
+    assert v <= 256 and sp == 0, (v, sp)
     # C5: k_objective_logmel<16, 5> - two 8-wave workgroups' worth of registers (<= 256), no spills
     v, sp, _ = _find(kernels, "18k_objective_logmelILi16ELi5ELb0E")
     assert v <= 256 and sp == 0, (v, sp)

@@ -119,6 +119,76 @@ def test_gla_waveforms(alpha, it):
     assert abs(sc_y - sc_ref) < 1e-5, (sc_y, sc_ref)
 
 
+# which (alpha, path) cases of g2 at 100 iterations hold the STRICT gate with the exact projection.  g2's magnitudes are random
+# (inconsistent), so an isolated near-zero bin can still part two float32 runs - the exact arithmetic removes the library's share
+# of that (profiles/r02_ieee_study.txt: 17 of 18 cases; the one left is such an event in the reference's own float32 run).
+EXACT_STRICT_XFAIL = set()
+
+
+@pytest.mark.parametrize("path", ["frame", "fused", "fused_prespec"])
+@pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
+@pytest.mark.parametrize("it", [10, 100])
+def test_gla_waveforms_exact_projection(alpha, it, path, monkeypatch):
+    """`specinv_plan_set_exact` / `set_exact_projection(True)`: the magnitude projection and the envelope division rounded like the
+    reference's own operations (correctly rounded sqrt and divisions, torch_specinv/methods.py:132,246-247) on the float32
+    wave-level kernels - the frame kernel (default for a problem this small), the signal-form fused kernel and the fused kernel on
+    pre_spec.  The g2 waveforms after 10 and 100 iterations against the reference to the STRICT gate min(1e-4, 6 x its own
+    float32-vs-float64 noise), where the default arithmetic needs the segment statistics of `test_gla_waveforms`."""
+    from spectrogram_inversion_amd.plan import Plan
+    g = load_golden("g2_gla")
+    hop, w = int(g["hop"]), torch.from_numpy(g["window"])
+    key = f"a{alpha}_it{it}"
+    ref, ref64 = g["wave_" + key], g["wave64_" + key]
+    noise = rel_l2(ref, ref64)
+    gate = min(1e-4, max(6 * noise, 3e-6))
+    init = T(g["init"])
+    if path != "frame":
+        monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")
+    p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], torch.float32, dev())
+    p.set_exact(True)
+    p.keep_state(path == "fused_prespec")
+    p.gla_init(init, None, alpha)
+    want = {"frame": "k_semi", "fused": "k_fused_td", "fused_prespec": "k_fused"}[path]
+    assert p.launch_geometry["kernel"] == want, p.launch_geometry
+    p.run(it, 10, 0.0, "sc")
+    y = N(p.wave())
+    err = rel_l2(y, ref)
+    if (alpha, it, path) in EXACT_STRICT_XFAIL:
+        seg = segment_errors(y, ref, hop)
+        assert np.quantile(seg, 0.75) < gate and seg.max() < 3e-2, (err, np.quantile(seg, 0.75), seg.max())
+        return
+    assert err < gate, (alpha, it, path, err, rel_l2(y, ref64), noise)
+
+
+def test_exact_projection_switch_of_the_drop_in_functions(monkeypatch):
+    """The module-level switch (the drop-in signatures are the reference's): `set_exact_projection(True)` / SPECINV_EXACT=1 make
+    `griffin_lim` / `ADMM` take the exact kernels - the result equals a plan run with `set_exact`, and differs from the default
+    arithmetic's in the last bits only."""
+    from spectrogram_inversion_amd.plan import Plan, clear_plan_cache
+    g = load_golden("g2_gla")
+    kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
+    init = T(g["init"])
+    fast = N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw))
+    try:
+        si.set_exact_projection(True)
+        exact = N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw))
+        exact_admm = N(si.ADMM(init, max_iter=3, rho=1.0, tol=0, verbose=False, **kw))
+    finally:
+        si.set_exact_projection(None)
+    monkeypatch.setenv("SPECINV_EXACT", "1")
+    assert np.array_equal(N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw)), exact)
+    monkeypatch.delenv("SPECINV_EXACT")
+    assert np.array_equal(N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw)), fast)
+    p = Plan(args_helper(init, **kw), init.shape[0], init.shape[2], torch.float32, dev())
+    p.set_exact(True)
+    p.gla_init(init, None, 0.3)
+    p.iterate(10)
+    assert np.array_equal(N(p.wave()), exact)
+    assert not np.array_equal(exact, fast) and rel_l2(exact, fast) < 1e-5
+    ref = oracle.admm(g["init"], max_iter=3, rho=1.0, tol=0, hop_length=int(g["hop"]), window=g["window"])
+    assert rel_l2(exact_admm, ref) < 1e-5
+
+
 @pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "frame_lds_prespec", "generic", "float64"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
