@@ -281,14 +281,16 @@ int specinv_stream_wait(specinv_plan* plan);
 typedef struct specinv_lbfgs_opts {
   double lr, tolerance_grad, tolerance_change;
   int32_t max_iter, max_eval, history_size;
-  int32_t time_objective;  /* != 0: bracket every objective evaluation with HIP events (benchmarks: specinv_lbfgs_info.objective_ms) */
+  int32_t time_objective;  /* k > 0: bracket every k-th objective evaluation of a step with HIP events (benchmarks:
+                              specinv_lbfgs_info.objective_ms / objective_timed; an event pair costs ~10 us of the timeline) */
 } specinv_lbfgs_opts;
 typedef struct specinv_lbfgs_info {
   double first_loss;      /* what optimizer.step returns: the loss at the entry evaluation */
   double loss, t;
   int32_t total_iters, func_evals, n_iter, history_len, pairs_accepted, pairs_rejected;
-  int32_t objective_launches;  /* evaluations this step executed ... */
-  double objective_ms;         /* ... and their summed duration (objective + epilogue launch), when time_objective was set */
+  int32_t objective_launches;  /* evaluations this step executed, ... */
+  int32_t objective_timed;     /* ... how many of them were bracketed with events (time_objective) ... */
+  double objective_ms;         /* ... and the summed duration of those (objective + epilogue launch) */
 } specinv_lbfgs_info;
 /* `n` = elements of the parameter (batch * length); *handle_out identifies the optimiser within the plan */
 int specinv_lbfgs_dev_create(specinv_plan* plan, int64_t n, const specinv_lbfgs_opts* opts, int32_t* handle_out);

@@ -39,7 +39,7 @@ class LbfgsInfo(C.Structure):
     _fields_ = [("first_loss", C.c_double), ("loss", C.c_double), ("t", C.c_double),
                 ("total_iters", C.c_int32), ("func_evals", C.c_int32), ("n_iter", C.c_int32), ("history_len", C.c_int32),
                 ("pairs_accepted", C.c_int32), ("pairs_rejected", C.c_int32), ("objective_launches", C.c_int32),
-                ("objective_ms", C.c_double)]
+                ("objective_timed", C.c_int32), ("objective_ms", C.c_double)]
 
 
 EVAL_CB = C.CFUNCTYPE(C.c_int, C.POINTER(Eval), C.c_void_p)

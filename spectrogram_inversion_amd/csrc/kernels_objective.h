@@ -146,6 +146,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   const int* blk_mg = nullptr;
   const int* blk_fg = nullptr;
   f32x4 av[kRing];
+  int dsc_fg = 0, dsc_mg = 0;
   if constexpr (!MAG) {
     // operand blocks of the forward contraction: a ring of kRing blocks in flight per wave (a mel filterbank leaves a wave
     // fewer blocks than that: all of them are requested here, before the barrier, and land while the other waves finish)
@@ -156,6 +157,11 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     fe1 = a.tab[ObjTab::FWD + wib + 1];
 #pragma unroll
     for (int i = 0; i < kRing; ++i) av[i] = a.melA[(long long)min(fe0 + i, n_blk - 1) * 64 + lane];
+    // ... and so do the blocks' descriptors (bin group, mel group): lane i of a descriptor register holds block e + i of the
+    // ring pass, read back with v_readlane - a scalar load from the table per block would sit, unprefetched, in front of every
+    // block's LDS reads (~300 cycles each, nine blocks per wave)
+    dsc_fg = blk_fg[min(fe0 + (lane & (kRing - 1)), n_blk - 1)];
+    dsc_mg = blk_mg[min(fe0 + (lane & (kRing - 1)), n_blk - 1)];
   }
   __syncthreads();
   OBJ_STAMP(3);
@@ -187,10 +193,15 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     for (int e = fe0; e < fe1; e += kRing) {
+      const int cfg = dsc_fg, cmg = dsc_mg;
+      if (e + kRing < fe1) {                        // the next pass's descriptors, a pass ahead
+        dsc_fg = blk_fg[min(e + kRing + (lane & (kRing - 1)), n_blk - 1)];
+        dsc_mg = blk_mg[min(e + kRing + (lane & (kRing - 1)), n_blk - 1)];
+      }
 #pragma unroll
       for (int i = 0; i < kRing; ++i) {
         if (e + i < fe1) {
-          const int fg = blk_fg[e + i], mg = blk_mg[e + i];
+          const int fg = __builtin_amdgcn_readlane(cfg, i), mg = __builtin_amdgcn_readlane(cmg, i);
           float bv[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) bv[j] = tile[(16 * fg + 4 * j + (lane >> 4)) * RS + (lane & 15)];
@@ -215,6 +226,8 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   const int be0 = a.tab[ObjTab::BEGIN + bg0], be1 = a.tab[ObjTab::BEGIN + bg1];
 #pragma unroll
   for (int i = 0; i < kRing; ++i) av[i] = a.melB[(long long)min(be0 + i, n_blk - 1) * 64 + lane];
+  dsc_fg = blk_fg[min(be0 + (lane & (kRing - 1)), n_blk - 1)];
+  dsc_mg = blk_mg[min(be0 + (lane & (kRing - 1)), n_blk - 1)];
   OBJ_STAMP(4);
   __syncthreads();
   OBJ_STAMP(5);
@@ -263,10 +276,15 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       }
     };
     for (int e = be0; e < be1; e += kRing) {
+      const int cfg = dsc_fg, cmg = dsc_mg;
+      if (e + kRing < be1) {
+        dsc_fg = blk_fg[min(e + kRing + (lane & (kRing - 1)), n_blk - 1)];
+        dsc_mg = blk_mg[min(e + kRing + (lane & (kRing - 1)), n_blk - 1)];
+      }
 #pragma unroll
       for (int i = 0; i < kRing; ++i) {
         if (e + i < be1) {
-          const int fg = blk_fg[e + i], mg = blk_mg[e + i];
+          const int fg = __builtin_amdgcn_readlane(cfg, i), mg = __builtin_amdgcn_readlane(cmg, i);
           flush(fg);
           float bv[4];
 #pragma unroll

@@ -168,8 +168,8 @@ class LBFGS:
         self._board = None
         self._dev = None                       # device-resident optimiser: None undecided, False not taken, else its handle
         self._dev_history = 0
-        self.time_objective = False            # benchmarks: HIP events around every objective evaluation of the device path
-        self.objective_ms, self.objective_launches = 0.0, 0
+        self.time_objective = 0                # benchmarks: HIP events around every k-th objective evaluation of the device path
+        self.objective_ms, self.objective_timed, self.objective_launches = 0.0, 0, 0
 
     @property
     def history_len(self):
@@ -462,6 +462,7 @@ class LBFGS:
         self.pairs_accepted, self.pairs_rejected = info.pairs_accepted, info.pairs_rejected
         self._dev_history, self.t, self.prev_loss = info.history_len, info.t, info.loss
         self.objective_ms += info.objective_ms
+        self.objective_timed += info.objective_timed
         self.objective_launches += info.objective_launches
         return info.first_loss
 

@@ -537,7 +537,7 @@ class Plan:
                          time_objective=False) -> int:
         self._sync_stream()
         o = _lib.LbfgsOpts(float(lr), float(tolerance_grad), float(tolerance_change), int(max_iter),
-                           int(max_eval) if max_eval is not None else 0, int(history_size), 1 if time_objective else 0)
+                           int(max_eval) if max_eval is not None else 0, int(history_size), int(time_objective))
         h = C.c_int32(-1)
         _lib.check(self.lib.specinv_lbfgs_dev_create(self._h, int(n), C.byref(o), C.byref(h)))
         return h.value
