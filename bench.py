@@ -449,6 +449,9 @@ def main():
             roof["hbm_physical_frac"] = traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if tr.get(tkey + "_valu_issue_frac") is not None:
             roof["valu_issue_frac"] = tr[tkey + "_valu_issue_frac"]      # share of the chip's VALU issue slots in use (PMC)
+        if tr.get(tkey + "_valu_share_of_wave_life") is not None:
+            # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of one wave; times the waves per SIMD = the share of a SIMD's issue slots in use
+            roof["valu_share_of_wave_life"] = tr[tkey + "_valu_share_of_wave_life"]
         if tr.get(tkey + "_lds_conflict_frac") is not None:
             roof["lds_conflict_frac"] = tr[tkey + "_lds_conflict_frac"]
         if restated:

@@ -12,8 +12,8 @@ DOMINANT = {
            "specinv::fast::k_fused4_td<16, false, true>", "specinv::fast::k_phase_init_pairs<16>"],
     "C4": ["specinv::fast::k_fused4<8, 1, false>", "specinv::fast::k_fused4<8, 1, true>"],
     "C3": ["specinv::fast::k_rtisi_fast<16, 256, 4>"],
-    "C5": ["specinv::fast::k_objective_logmel<16, 5, false>", "specinv::k_lincomb<float>", "specinv::k_lbfgs_pair_stats<float>",
-           "specinv::k_axpy<float>"],
+    "C5": ["specinv::fast::k_objective_logmel<16, 5, false>", "specinv::k_lbd_pair_stats<float>", "specinv::k_lbd_lincomb_step<float>",
+           "specinv::k_lbd_decide<float>", "specinv::k_objective_epilogue", "specinv::k_lbd_multi_dot<float>"],
 }
 ALGO = {"C2": 64 * 1024 * 24596, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 4416}
 out = os.path.join(ROOT, "profiles")
