@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: argument normalisation, shape rules, error behaviour, metric
 formulas, the L-BFGS control flow (with a torch-CPU vector backend supplied by the test), mel filterbank."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -8,7 +9,7 @@ import torch
 
 import oracle
 import spectrogram_inversion_amd as si
-from _util import hann, load_golden, sweep_kwargs
+from _util import ROOT, hann, load_golden, sweep_kwargs
 from spectrogram_inversion_amd.lbfgs import LBFGS
 from spectrogram_inversion_amd.metrics import _from_sums
 from spectrogram_inversion_amd.plan import args_helper, require_gpu
@@ -295,3 +296,45 @@ def test_mel_filterbank_options():
     lim = si.mel_filterbank(16000, 512, 20, fmin=300.0, fmax=4000.0)
     hz = np.linspace(0, 8000, 257)
     assert lim[:, hz < 290].sum() == 0 and lim[:, hz > 4010].sum() == 0
+
+
+def test_exact_projection_switch_and_progress_mode(monkeypatch):
+    """The module-level switches of round 3 (no GPU involved): `set_exact_projection` overrides SPECINV_EXACT, None follows it;
+    RTISI_LA's live progress bar is only taken when somebody can watch it (a terminal) or on request."""
+    from spectrogram_inversion_amd import plan as P, methods as M
+    monkeypatch.delenv("SPECINV_EXACT", raising=False)
+    P.set_exact_projection(None)
+    assert P.exact_projection() is False
+    monkeypatch.setenv("SPECINV_EXACT", "1")
+    assert P.exact_projection() is True
+    P.set_exact_projection(False)
+    assert P.exact_projection() is False
+    P.set_exact_projection(True)
+    monkeypatch.setenv("SPECINV_EXACT", "0")
+    assert P.exact_projection() is True
+    P.set_exact_projection(None)
+    assert P.exact_projection() is False
+    monkeypatch.setenv("SPECINV_RTISI_PROGRESS", "blocks")
+    assert M._live_progress() is True
+    monkeypatch.setenv("SPECINV_RTISI_PROGRESS", "end")
+    assert M._live_progress() is False
+    monkeypatch.delenv("SPECINV_RTISI_PROGRESS")
+    assert M._live_progress() is False                      # (pytest captures stderr: not a terminal)
+
+
+def test_bench_byte_conventions():
+    """bench.py prices `roofline.frac` with SURVEY 8d's bytes of the reference algorithm and reports the bytes the shipped kernels
+    have to move beside it: the figures BASELINE.md quotes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.algorithmic_bytes_per_unit("griffin_lim", 512, 1025, 0.3) == 24596          # C2
+    assert bench.algorithmic_bytes_per_unit("griffin_lim", 256, 513, 0.0) == 4100            # C1
+    assert bench.algorithmic_bytes_per_unit("ADMM", 256, 513, 0.1) == 20516                  # C4
+    assert bench.algorithmic_bytes_per_unit("L_BFGS", 512, 1025, None) == 4416               # C5
+    assert bench.restated_bytes_per_unit("griffin_lim", 512, 1025, "k_fused4_td") == 8196
+    assert bench.restated_bytes_per_unit("griffin_lim", 512, 1025, "k_fused4") is None
+    assert bench.restated_bytes_per_unit("ADMM", 256, 513, "k_fused4") == 12308
+    from spectrogram_inversion_amd.build import sources_hash
+    assert len(sources_hash()) == 16 and sources_hash() == sources_hash()
