@@ -182,10 +182,13 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
     ap.add_argument("--asym", action="store_true", help="C3: asymmetric_window=True")
     ap.add_argument("--outer", type=int, default=50, help="C5: optimizer.step calls per bench step (BASELINE configs[4]: maxiter=50)")
-    ap.add_argument("--c5-variant", default="baseline", choices=["baseline", "main", "wolfe"],
+    ap.add_argument("--c5-variant", default="baseline", choices=["baseline", "main", "wolfe", "memory"],
                     help="C5 optimiser options: torch.optim.LBFGS defaults (BASELINE); the reference demo's (main.py:43: max_iter 50, "
                          "history 10); defaults + line_search_fn='strong_wolfe' (steps long enough for the curvature pairs to pass "
-                         "y.s > 1e-10, so the memory fills to history_size = 100 and the recursion's vector passes carry weight)")
+                         "y.s > 1e-10; its default tolerances end most steps after one iteration on this input); 'memory': strong "
+                         "Wolfe with both tolerances at 0, so that every step runs its 20 iterations, the memory fills to "
+                         "history_size = 100 and the recursion's passes over 200 vectors (k_multi_dot, k_lincomb) carry weight - use "
+                         "--outer 8 or more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
@@ -324,7 +327,8 @@ def main():
         from spectrogram_inversion_amd.lbfgs import LBFGS
 
         opt_kw = {"baseline": {}, "main": dict(max_iter=50, history_size=10),
-                  "wolfe": dict(line_search_fn="strong_wolfe")}[args.c5_variant]
+                  "wolfe": dict(line_search_fn="strong_wolfe"),
+                  "memory": dict(line_search_fn="strong_wolfe", tolerance_grad=0.0, tolerance_change=0.0)}[args.c5_variant]
 
         def step():
             x = x_init.clone()
