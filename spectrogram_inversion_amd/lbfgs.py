@@ -450,6 +450,11 @@ class LBFGS:
     def _step_device(self, fg):
         from . import _lib
         plan, handle, target, shape = self._dev
+        obj = getattr(fg, "device_objective", None)     # the closure of THIS step: same objective kernel, possibly another target
+        if obj is None or obj[0] is not plan or tuple(obj[2]) != tuple(shape):
+            raise RuntimeError("this optimiser's state lives on the device with the objective it was first stepped with; "
+                               "use a new LBFGS for another transform / shape (SPECINV_LBFGS_DEVICE=0 keeps the state on the host)")
+        target = obj[1]
         try:
             info = plan.lbfgs_dev_step(handle, self.x.view(shape), target)
         except NotImplementedError:
