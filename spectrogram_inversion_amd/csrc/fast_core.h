@@ -103,10 +103,11 @@ __device__ __forceinline__ v2f cmulc_k(v2f a, v2f b) { return v2f{a.x * b.x + a.
 #endif
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) {
 #if SPECINV_ASM_CMUL
-  v2f t, d;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                 // (a.x b.x, a.x b.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
-  return d;                                                                                               // (- a.y b.y, + a.y b.x)
+  v2f t, d;   // (one asm statement: between two the compiler puts an s_nop, which costs an issue slot)
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                         // (a.x b.x, a.x b.y)
+      "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                       // (- a.y b.y, + a.y b.x)
+      : "=v"(d), "=&v"(t) : "v"(a), "v"(b));
+  return d;
 #else
   return cmul_k(a, b);
 #endif
@@ -115,8 +116,9 @@ __device__ __forceinline__ v2f cmul(v2f a, v2f b) {
 __device__ __forceinline__ v2f cmulc(v2f a, v2f b) {
 #if SPECINV_ASM_CMUL
   v2f t, d;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));    // (a.x b.x, - a.x b.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t)); // (+ a.y b.y, + a.y b.x)
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"                             // (a.x b.x, - a.x b.y)
+      "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"                                      // (+ a.y b.y, + a.y b.x)
+      : "=v"(d), "=&v"(t) : "v"(a), "v"(b));
   return d;
 #else
   return cmulc_k(a, b);
@@ -187,9 +189,10 @@ __device__ __forceinline__ v2f cmulc_p(v2f a, v2f b) { return PK ? cmulc(a, b) :
 __device__ __forceinline__ v2f cmul_mi(v2f w, v2f d) {
 #if SPECINV_ASM_CMUL
   v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(w), "v"(d));                              // (w.y d.x, w.y d.y)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(d), "v"(t));
-  return r;                                                                                                              // (+ w.x d.y, - w.x d.x)
+  asm("v_pk_mul_f32 %1, %2, %3 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                         // (w.y d.x, w.y d.y)
+      "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"                       // (+ w.x d.y, - w.x d.x)
+      : "=v"(r), "=&v"(t) : "v"(w), "v"(d));
+  return r;
 #else
   return cmul_k(v2f{w.y, -w.x}, d);
 #endif
@@ -201,6 +204,71 @@ template <bool INV>
 __device__ __forceinline__ v2f twc(float c, float s) { return v2f{c, INV ? s : -s}; }
 template <bool INV>
 __device__ __forceinline__ v2f dirmul(v2f a, v2f w) { return INV ? cmulc_k(a, w) : cmul_k(a, w); }   // (literal twiddles)
+// a * w (INV: a * conj(w)) with a compile-time constant w: the constant sits in a scalar register pair and the product is TWO
+// packed operations like cmul (VOP3P takes no literal, but one scalar source) instead of the four scalar ones with inline
+// literals; the in-register DFTs' fixed twiddles and the W_64^j steps of the real-FFT split are 43 such products per frame
+// and iteration at n_fft 2048 (86 of ~1240 vector instructions)
+#ifndef SPECINV_PKCONST
+#define SPECINV_PKCONST 1
+#endif
+template <bool INV>
+__device__ __forceinline__ v2f cmul_sk(v2f a, v2f w) {
+  v2f t, d;
+  if (!INV) {
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=v"(d), "=&v"(t) : "v"(a), "s"(w));
+  } else {
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=v"(d), "=&v"(t) : "v"(a), "s"(w));
+  }
+  return d;
+}
+// four of them in one block: the four multiplies first, then the four dependent multiply-adds (cmul_x4)
+template <bool INV>
+__device__ __forceinline__ void cmul_sk_x4(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f w0, v2f w1, v2f w2, v2f w3) {
+  v2f t0, t1, t2, t3;
+  if (!INV) {
+    asm("v_pk_mul_f32 %4, %0, %8 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %5, %1, %9 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %6, %2, %10 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %7, %3, %11 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %0, %8, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %1, %9, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %2, %2, %10, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %3, %3, %11, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "s"(w0), "s"(w1), "s"(w2), "s"(w3));
+  } else {
+    asm("v_pk_mul_f32 %4, %0, %8 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %5, %1, %9 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %6, %2, %10 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %7, %3, %11 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %0, %8, %4 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %1, %9, %5 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %2, %10, %6 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %3, %3, %11, %7 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "s"(w0), "s"(w1), "s"(w2), "s"(w3));
+  }
+}
+template <bool INV, bool PK>
+__device__ __forceinline__ void dirmul_x4(v2f& a0, v2f& a1, v2f& a2, v2f& a3, v2f w0, v2f w1, v2f w2, v2f w3) {
+  if (PK && SPECINV_PKCONST) {
+    cmul_sk_x4<INV>(a0, a1, a2, a3, w0, w1, w2, w3);
+  } else {
+    a0 = dirmul<INV>(a0, w0);
+    a1 = dirmul<INV>(a1, w1);
+    a2 = dirmul<INV>(a2, w2);
+    a3 = dirmul<INV>(a3, w3);
+  }
+}
+template <bool INV, bool PK>
+__device__ __forceinline__ v2f dirmul_p(v2f a, v2f w) {
+  if (PK && SPECINV_PKCONST) return cmul_sk<INV>(a, w);
+  return dirmul<INV>(a, w);
+}
 
 __device__ __forceinline__ v2f shfl_xor2(v2f a, int mask) {
   return v2f{__shfl_xor(a.x, mask, 64), __shfl_xor(a.y, mask, 64)};
@@ -270,16 +338,16 @@ __device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
   a3 = INV ? sub_i(t1, d) : add_i(t1, d);
 }
 
-template <int R, bool INV>
+template <int R, bool INV, bool PK = true>
 struct Dft;
 
-template <bool INV>
-struct Dft<4, INV> {
+template <bool INV, bool PK>
+struct Dft<4, INV, PK> {
   static __device__ __forceinline__ void run(v2f (&a)[4]) { dft4<INV>(a[0], a[1], a[2], a[3]); }
 };
 
-template <bool INV>
-struct Dft<8, INV> {
+template <bool INV, bool PK>
+struct Dft<8, INV, PK> {
   static __device__ __forceinline__ void run(v2f (&a)[8]) {
     constexpr float h = 0.70710678118654752440f;
     // n = 4*n1 + n0: radix-2 over n1, twiddle W8^(n0*k1), radix-4 over n0
@@ -289,9 +357,9 @@ struct Dft<8, INV> {
       a[n0] = s;
       a[n0 + 4] = d;
     }
-    a[5] = dirmul<INV>(a[5], v2f{h, -h});
+    a[5] = dirmul_p<INV, PK>(a[5], v2f{h, -h});
     a[6] = rot<INV>(a[6]);
-    a[7] = dirmul<INV>(a[7], v2f{-h, -h});
+    a[7] = dirmul_p<INV, PK>(a[7], v2f{-h, -h});
     dft4<INV>(a[0], a[1], a[2], a[3]);
     dft4<INV>(a[4], a[5], a[6], a[7]);
     // a[k0 + 4*k1] = X[k1 + 2*k0]
@@ -306,22 +374,17 @@ struct Dft<8, INV> {
   }
 };
 
-template <bool INV>
-struct Dft<16, INV> {
+template <bool INV, bool PK>
+struct Dft<16, INV, PK> {
   static __device__ __forceinline__ void run(v2f (&a)[16]) {
     constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
     // n = 4*n1 + n0: radix-4 over n1 (in place -> slot n0 + 4*k1), twiddle W16^(n0*k1), radix-4 over n0
 #pragma unroll
     for (int n0 = 0; n0 < 4; ++n0) dft4<INV>(a[n0], a[n0 + 4], a[n0 + 8], a[n0 + 12]);
-    a[5] = dirmul<INV>(a[5], v2f{c1, -s1});    // W16^1
-    a[6] = dirmul<INV>(a[6], v2f{h, -h});      // W16^2
-    a[7] = dirmul<INV>(a[7], v2f{s1, -c1});    // W16^3
-    a[9] = dirmul<INV>(a[9], v2f{h, -h});      // W16^2
-    a[10] = rot<INV>(a[10]);                   // W16^4
-    a[11] = dirmul<INV>(a[11], v2f{-h, -h});   // W16^6
-    a[13] = dirmul<INV>(a[13], v2f{s1, -c1});  // W16^3
-    a[14] = dirmul<INV>(a[14], v2f{-h, -h});   // W16^6
-    a[15] = dirmul<INV>(a[15], v2f{-c1, s1});  // W16^9
+    //      W16^1, W16^2, W16^3, W16^2 ; W16^6, W16^3, W16^6, W16^9 ; W16^4
+    dirmul_x4<INV, PK>(a[5], a[6], a[7], a[9], v2f{c1, -s1}, v2f{h, -h}, v2f{s1, -c1}, v2f{h, -h});
+    dirmul_x4<INV, PK>(a[11], a[13], a[14], a[15], v2f{-h, -h}, v2f{s1, -c1}, v2f{-h, -h}, v2f{-c1, s1});
+    a[10] = rot<INV>(a[10]);
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
     // a[k0 + 4*k1] = X[k1 + 4*k0]
@@ -341,8 +404,8 @@ __device__ __forceinline__ v2f w32(int e) {
   return v2f{tab[e][0], tab[e][1]};
 }
 
-template <bool INV>
-struct Dft<32, INV> {
+template <bool INV, bool PK>
+struct Dft<32, INV, PK> {
   static __device__ __forceinline__ void run(v2f (&a)[32]) {
     // n = 8*n1 + n0: radix-4 over n1 (in place -> slot n0 + 8*k1), twiddle W32^(n0*k1), radix-8 over n0
 #pragma unroll
@@ -353,7 +416,7 @@ struct Dft<32, INV> {
       for (int n0 = 1; n0 < 8; ++n0) {
         const int e = n0 * k1;
         if (e == 8) a[n0 + 8 * k1] = rot<INV>(a[n0 + 8 * k1]);
-        else a[n0 + 8 * k1] = dirmul<INV>(a[n0 + 8 * k1], w32(e));
+        else a[n0 + 8 * k1] = dirmul_p<INV, PK>(a[n0 + 8 * k1], w32(e));
       }
     v2f o[32];
 #pragma unroll
@@ -361,7 +424,7 @@ struct Dft<32, INV> {
       v2f t[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) t[i] = a[8 * k1 + i];
-      Dft<8, INV>::run(t);
+      Dft<8, INV, PK>::run(t);
       // t[k0] = X[k1 + 4*k0]
 #pragma unroll
       for (int k0 = 0; k0 < 8; ++k0) o[k1 + 4 * k0] = t[k0];
@@ -531,9 +594,11 @@ struct TwRegs {
 // PK: complex products as two packed operations (cmul) or four scalar ones (cmul_k).  Packed wins wherever two waves share a
 // SIMD (C2 -6 %, C4 -5 %); a lone wave per SIMD (k_rtisi_fast) has nobody to cover the packed pair's dependent latency and
 // measured 12 % slower with it, so that kernel asks for the scalar form.
-template <int R, bool PK = true, typename TW>
+// PKC: the in-register DFTs' constant twiddles as packed products with a scalar-register operand (cmul_sk) or as four scalar
+// operations with literals (k_rtisi_fast keeps the scalar form throughout).
+template <int R, bool PK = true, bool PKC = PK, typename TW>
 __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr);
-template <int R, bool PK = true, typename TW>
+template <int R, bool PK = true, bool PKC = PK, typename TW>
 __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr);
 
 template <int R>
@@ -547,10 +612,10 @@ __device__ __forceinline__ void fft_inverse(v2f (&z)[R], const LaneConst<R>& k, 
   fft_inverse_t<R>(z, k, TwLds{tw1, k.lane}, tr);
 }
 
-template <int R, bool PK, typename TW>
+template <int R, bool PK, bool PKC, typename TW>
 __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr) {
   using G = Geo<R>;
-  Dft<R, false>::run(z);
+  Dft<R, false, PKC>::run(z);
   cmul_all<R, PK, false, 1>(z, tw);
   // cross-lane radix-C over v = lane / R; afterwards lane position v holds frequency digit k.kv
   if (G::C == 2) {
@@ -588,14 +653,14 @@ __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k
   for (int i = 0; i < R; ++i) tr[k.tr_a + i * (R + 1)] = z[i];
 #pragma unroll
   for (int i = 0; i < R; ++i) z[i] = tr[k.tr_b + i];
-  Dft<R, false>::run(z);
+  Dft<R, false, PKC>::run(z);
 }
 
 // inverse (unnormalised): in z[j] = bin lane + 64j; out z[u] = time sample 64u + lane
-template <int R, bool PK, typename TW>
+template <int R, bool PK, bool PKC, typename TW>
 __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k, const TW& tw, v2f* __restrict__ tr) {
   using G = Geo<R>;
-  Dft<R, true>::run(z);
+  Dft<R, true, PKC>::run(z);
 #pragma unroll
   for (int i = 0; i < R; ++i) tr[k.tr_b + i] = z[i];
 #pragma unroll
@@ -629,7 +694,7 @@ __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k
     for (int g = 0; g < R; g += 4) xlane_dft4<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
   }
   cmul_all<R, PK, true, 1>(z, tw);
-  Dft<R, true>::run(z);
+  Dft<R, true, PKC>::run(z);
 }
 
 // W_64^j = exp(-2 pi i j / 64), j < 16: the per-pair step of the real-FFT twiddle W_N^(lane + 64 j)
@@ -682,6 +747,15 @@ __device__ __forceinline__ v2f env_apply(v2f v, v2f e) { return v * e; }
 __device__ __forceinline__ float env_apply(float v, float e) { return v * e; }
 #endif
 
+// The projection's factor m / (|s| + 1e-16) (methods.py:246-247) on the default (approximate) path: m * rsq(|s|^2 + 1e-32) -
+// one transcendental instruction instead of two (they cost two issue slots each) and no addition.  v_rsq_f32 is good to 1 ulp like
+// v_sqrt_f32 and v_rcp_f32 each; the guard term only matters below |s| ~ 1e-9, where both forms tend to m * 1e16, and s = 0 gives
+// 0 either way.  The exact-projection build (SPECINV_IEEE) keeps the reference's operations.
+#ifndef SPECINV_RSQ
+#define SPECINV_RSQ 1
+#endif
+__device__ __forceinline__ float proj_rsq(v2f s) { return __builtin_amdgcn_rsqf(fmaf(s.y, s.y, fmaf(s.x, s.x, 1e-32f))); }
+
 // Frequency-domain update of one bin.  `r` is the STFT bin, `p`/`u` the stored state, `m` the target.
 // Returns the bin to synthesise from (already multiplied by isc); writes the new state.
 template <int MODE, bool EVAL>
@@ -702,6 +776,8 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, v2f& xs, float 
 #if SPECINV_IEEE
     const float den = fast_abs(s) + 1e-16f;
     return v2f{__fdiv_rn(s.x * m, den) * a.inv_scale, __fdiv_rn(s.y * m, den) * a.inv_scale};
+#elif SPECINV_RSQ
+    return s * ((m * proj_rsq(s)) * a.inv_scale);
 #else
     const float inv = fast_rcp(fast_abs(s) + 1e-16f) * a.inv_scale;
     return v2f{(s.x * m) * inv, (s.y * m) * inv};
@@ -715,6 +791,11 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, v2f& xs, float 
 #if SPECINV_IEEE
     const float den = fast_abs(xn) + 1e-16f;
     xn = v2f{__fdiv_rn(xn.x * m, den), __fdiv_rn(xn.y * m, den)};
+#elif SPECINV_RSQ
+    {
+#pragma clang fp contract(off)   // X is rounded before Y = X + U is formed (:473-475): no multiply-add across the two
+      xn = xn * (m * proj_rsq(xn));
+    }
 #else
     const float inv = fast_rcp(fast_abs(xn) + 1e-16f);
     xn = v2f{(xn.x * m) * inv, (xn.y * m) * inv};
@@ -860,6 +941,32 @@ __device__ __forceinline__ void td_split(v2f zk, v2f zm, v2f wk, float half_scal
   const v2f tw = cmul_mi(wk, sub_conj(zk, zm));            // W * (-i (Zk - conj Zm))
   xk = (e2 + tw) * half_scale;
   xm = (e2 - tw) * v2f{half_scale, -half_scale};
+}
+// ... left unscaled (2 / fwd_scale times the STFT bins): for a launch whose projection is the only reader of the bins - it
+// divides by their magnitude, so the scale cancels
+template <int R>
+__device__ __forceinline__ void td_split_raw(v2f zk, v2f zm, v2f wk, v2f& xk, v2f& xm) {
+  const v2f e2 = add_conj(zk, zm);
+  const v2f tw = cmul_mi(wk, sub_conj(zk, zm));
+  xk = e2 + tw;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(xm) : "v"(e2), "v"(tw));   // conj(e2 - tw)
+}
+// W_N^(lane + 64 j) = W_N^lane * W_{2R}^j: the real-FFT twiddle of pair j from the lane's own W_N^lane
+template <int R, bool PK = true>
+__device__ __forceinline__ v2f pair_twiddle(v2f wn, int j) {
+  if (j == 0) return wn;
+  return (PK && SPECINV_PKCONST) ? cmul_sk<false>(wn, w64(j * (32 / R))) : cmul_k(wn, w64(j * (32 / R)));
+}
+// s * p.x and s * p.y: ONE packed multiplication each (the scalar factor is picked from a register pair by op_sel)
+__device__ __forceinline__ v2f scale_lo(v2f s, v2f p) {
+  v2f d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(s), "v"(p));
+  return d;
+}
+__device__ __forceinline__ v2f scale_hi(v2f s, v2f p) {
+  v2f d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(s), "v"(p));
+  return d;
 }
 
 // ---- whole frames from the signal (the frame kernels and the one-launch objective)

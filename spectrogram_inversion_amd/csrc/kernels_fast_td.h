@@ -179,7 +179,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       float fd = 0.0f, fo = 0.0f;
 #pragma unroll
       for (int j = 0; j < H; ++j) {
-        const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
+        const v2f wk = pair_twiddle<R>(wn, j);
         v2f xk, xm;
         td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, xk, xm);
         const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
@@ -235,9 +235,13 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
     v2f back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(wn, j);
       v2f sk, sm;
-      td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
+      if (EARLY || SPECINV_IEEE || !SPECINV_RSQ) {
+        td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
+      } else {
+        td_split_raw<R>(z[j], rc[R - 1 - j - H], wk, sk, sm);   // (the late launches: nothing but the projection reads the bins)
+      }
       if (EARLY) {
         sk = v2f{fmaf(a.tds, pp[j].x, sk.x), fmaf(a.tds, pp[j].y, sk.y)};
         sm = v2f{fmaf(a.tds, pp[j].z, sm.x), fmaf(a.tds, pp[j].w, sm.y)};
@@ -248,6 +252,12 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       const float dk = fast_abs(sk) + 1e-16f, dq = fast_abs(sm) + 1e-16f;
       v2f ak = v2f{__fdiv_rn(sk.x * mk, dk) * a.inv_scale, __fdiv_rn(sk.y * mk, dk) * a.inv_scale};
       v2f am = v2f{__fdiv_rn(sm.x * mq, dq) * a.inv_scale, __fdiv_rn(sm.y * mq, dq) * a.inv_scale};
+#elif SPECINV_RSQ
+      // the projection's factors (proj_rsq, fast_core.h) of the pair's two bins, formed and applied as packed operations
+      const v2f inv = v2f{proj_rsq(sk), proj_rsq(sm)};
+      const v2f mi = (v2f{mk, mq} * inv) * a.inv_scale;
+      v2f ak = scale_lo(sk, mi);
+      v2f am = scale_hi(sm, mi);
 #else
       const float ik = fast_rcp(fast_abs(sk) + 1e-16f) * a.inv_scale, iq = fast_rcp(fast_abs(sm) + 1e-16f) * a.inv_scale;
       v2f ak = v2f{(sk.x * mk) * ik, (sk.y * mk) * ik};
@@ -269,6 +279,8 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 #if SPECINV_IEEE
       const float dn = fast_abs(smid) + 1e-16f;
       const v2f am = v2f{__fdiv_rn(smid.x * mmid, dn) * a.inv_scale, __fdiv_rn(smid.y * mmid, dn) * a.inv_scale};
+#elif SPECINV_RSQ
+      const v2f am = smid * ((mmid * proj_rsq(smid)) * a.inv_scale);
 #else
       const float inv = fast_rcp(fast_abs(smid) + 1e-16f) * a.inv_scale;
       const v2f am = v2f{(smid.x * mmid) * inv, (smid.y * mmid) * inv};
@@ -294,10 +306,26 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
       v2f* xo = reinterpret_cast<v2f*>(xorow + o0);
       v2f* zo = reinterpret_cast<v2f*>(zorow + o0);
+      // The envelope block: the register copy wherever it is valid.  The first frames of an item load theirs - in an arm of
+      // its own that also waits for it (the empty asm reads the registers): left to a select per value the compiler puts each
+      // load behind a branch and an unconditional s_waitcnt vmcnt(0) after the join, which on gfx950 also waits for the stores
+      // just issued - three store round trips per frame in the steady state.
+      v2f ev[QU];
+      if (!ENVREG) {
+#pragma unroll
+        for (int i = 0; i < QU; ++i) ev[i] = envp[64u * i + ulane];
+      } else if (t >= NB) {
+#pragma unroll
+        for (int i = 0; i < QU; ++i) ev[i] = envc[ENVREG ? i : 0];
+      } else {
+#pragma unroll
+        for (int i = 0; i < QU; ++i) ev[i] = envp[64u * i + ulane];
+#pragma unroll
+        for (int i = 0; i < QU; ++i) asm volatile("" : "+v"(ev[i]));
+      }
 #pragma unroll
       for (int i = 0; i < QU; ++i) {
-        const v2f ev = (ENVREG && t >= NB) ? envc[ENVREG ? i : 0] : envp[64u * i + ulane];
-        const v2f xv = env_apply(acc[i] + z[i], ev);
+        const v2f xv = env_apply(acc[i] + z[i], ev[i]);
         const v2f zv = v2f{fmaf(nlr, zold[i].x, xv.x), fmaf(nlr, zold[i].y, xv.y)};
         if (!(SPECINV_TD_ABLATE & 2) || zv.x == 1.2345e30f) {
           if (write_x) xo[64u * i + ulane] = xv;

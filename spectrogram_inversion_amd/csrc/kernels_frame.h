@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_fast_stft(FastXformArgs a) {
     const float hs = 0.5f * a.scale;
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(k.wn, j);
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = add_conj(zk, zm);
       const v2f tw = cmul_mi(wk, sub_conj(zk, zm));
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_fast_inverse_frames(FastXformArgs a) {
     v2f z[R], back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(k.wn, j);
       const int kk = lane + 64 * j;
       v2f ak = in[kk] * a.scale, am = in[M - kk] * a.scale;
       if (j == 0 && lane == 0) {
@@ -159,7 +159,7 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
   v2f back[H];
 #pragma unroll
   for (int j = 0; j < H; ++j) {
-    const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+    const v2f wk = pair_twiddle<R>(k.wn, j);
     v2f pk = v2f{pp[j].x, pp[j].y}, pm = v2f{pp[j].z, pp[j].w};
     v2f ak, am;
     if (MODE != MODE_INIT) {
@@ -419,7 +419,7 @@ __device__ __forceinline__ void semi_frame_td(const FastArgs& a, long long fi, c
     float fd = 0.0f, fo = 0.0f;
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(k.wn, j);
       v2f xk, xm;
       td_split<R>(y[j], rc[R - 1 - j - H], wk, half_scale, xk, xm);
       const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void semi_frame_td(const FastArgs& a, long long fi, c
   v2f back[H];
 #pragma unroll
   for (int j = 0; j < H; ++j) {
-    const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+    const v2f wk = pair_twiddle<R>(k.wn, j);
     v2f sk, sm;
     td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
     if (EARLY) {
@@ -470,6 +470,10 @@ __device__ __forceinline__ void semi_frame_td(const FastArgs& a, long long fi, c
     const float dk = fast_abs(sk) + 1e-16f, dq = fast_abs(sm) + 1e-16f;
     v2f ak = v2f{__fdiv_rn(sk.x * mk, dk) * a.inv_scale, __fdiv_rn(sk.y * mk, dk) * a.inv_scale};
     v2f am = v2f{__fdiv_rn(sm.x * mq, dq) * a.inv_scale, __fdiv_rn(sm.y * mq, dq) * a.inv_scale};
+#elif SPECINV_RSQ
+    const v2f mi = (v2f{mk, mq} * v2f{proj_rsq(sk), proj_rsq(sm)}) * a.inv_scale;
+    v2f ak = scale_lo(sk, mi);
+    v2f am = scale_hi(sm, mi);
 #else
     const float ik = fast_rcp(fast_abs(sk) + 1e-16f) * a.inv_scale, iq = fast_rcp(fast_abs(sm) + 1e-16f) * a.inv_scale;
     v2f ak = v2f{(sk.x * mk) * ik, (sk.y * mk) * ik};
@@ -491,6 +495,8 @@ __device__ __forceinline__ void semi_frame_td(const FastArgs& a, long long fi, c
 #if SPECINV_IEEE
     const float dn = fast_abs(smid) + 1e-16f;
     const v2f am = v2f{__fdiv_rn(smid.x * mmid, dn) * a.inv_scale, __fdiv_rn(smid.y * mmid, dn) * a.inv_scale};
+#elif SPECINV_RSQ
+    const v2f am = smid * ((mmid * proj_rsq(smid)) * a.inv_scale);
 #else
     const float inv = fast_rcp(fast_abs(smid) + 1e-16f) * a.inv_scale;
     const v2f am = v2f{(smid.x * mmid) * inv, (smid.y * mmid) * inv};
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(512, 1) void k_hop_inverse(HopInvArgs a) {
     v2f z[R], back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(k.wn, j);
       const int kk = lane + 64 * j;
       v2f ak = in[kk] * a.scale, am = in[M - kk] * a.scale;
       if (j == 0 && lane == 0) {

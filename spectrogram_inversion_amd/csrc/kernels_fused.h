@@ -177,7 +177,7 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       // W_N^(lane + 64 j) = W_N^lane * W_{2R}^j
-      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(wn, j);
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = add_conj(zk, zm);
       const v2f dd = sub_conj(zk, zm);
@@ -265,9 +265,23 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
       const long long o0 = (long long)(t - 2) * HOP;
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
+      // (the envelope block: register copy, or - first frames of an item - loaded and waited for in an arm of its own; see
+      // fused_td_body, kernels_fast_td.h)
+      v2f ev[QU];
+      if (!SPECINV_K4_ENVREG) {
 #pragma unroll
-      for (int i = 0; i < QU; ++i)
-        outp[64u * i + ulane] = env_apply(acc[i] + z[i], (SPECINV_K4_ENVREG && t >= 3) ? envc[SPECINV_K4_ENVREG ? i : 0] : envp[64u * i + ulane]);
+        for (int i = 0; i < QU; ++i) ev[i] = envp[64u * i + ulane];
+      } else if (t >= 3) {
+#pragma unroll
+        for (int i = 0; i < QU; ++i) ev[i] = envc[SPECINV_K4_ENVREG ? i : 0];
+      } else {
+#pragma unroll
+        for (int i = 0; i < QU; ++i) ev[i] = envp[64u * i + ulane];
+#pragma unroll
+        for (int i = 0; i < QU; ++i) asm volatile("" : "+v"(ev[i]));
+      }
+#pragma unroll
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[i] + z[i], ev[i]);
     }
 #if SPECINV_PRIO & 4
     __builtin_amdgcn_s_setprio(0);
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : (SPECINV_R8_W3 && R == 8) ? 3 : 
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       // W_N^(lane + 64 j) = W_N^lane * W_{2R}^j
-      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(wn, j);
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = add_conj(zk, zm);
       const v2f dd = sub_conj(zk, zm);
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
     v2f z[R], back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? wn : cmul_k(wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(wn, j);
       v2f ak = v2f{pp[j].x, pp[j].y} * a.inv_scale, am = v2f{pp[j].z, pp[j].w} * a.inv_scale;
       if (j == 0 && lane == 0) {
         ak.y = 0.0f;

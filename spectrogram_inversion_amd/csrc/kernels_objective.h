@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(k.wn, j);
       const v2f zk = z[j], zm = rc[R - 1 - j - H];
       const v2f e2 = add_conj(zk, zm);
       const v2f tw = cmul_mi(wk, sub_conj(zk, zm));
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     v2f z[R], back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = j == 0 ? k.wn : cmul_k(k.wn, w64(j * (32 / R)));
+      const v2f wk = pair_twiddle<R>(k.wn, j);
       const int kk = lane + 64 * j;
       // interior bins of the one-sided spectrum count half (their mirror images carry the other half); bins 0 and M do not
       const float hw = (kk == 0 ? 1.0f : 0.5f) * a.fwd_scale;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
       const v2f l0 = (m == H) ? zmid : back[(R - m) % H];
       z[m] = v2f{lane == 0 ? l0.x : got.x, lane == 0 ? l0.y : got.y};
     }
-    fft_inverse<R>(z, k, lds_tw1, tr);
+    fft_inverse_t<R, true, false>(z, k, TwLds{lds_tw1, k.lane}, tr);   // (constant twiddles in the scalar form, like the step loop)
     v2f* dst = ring + (size_t)(nslots - 1) * M;
 #pragma unroll
     for (int u = 0; u < R; ++u) dst[64 * u + lane] = z[u] * lds_wsyn[64 * u + lane];
