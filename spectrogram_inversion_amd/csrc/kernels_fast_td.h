@@ -73,7 +73,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   }
   __syncthreads();
 
-  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wib);   // (scalar: the frame loop and its padding tests branch on the scalar unit; left to the compiler the work-group size may arrive in a vector register and make all of it per-lane)
   if (w >= a.n_waves) return;
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
   }
   __syncthreads();
 
-  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wib);   // (scalar: the frame loop and its padding tests branch on the scalar unit; left to the compiler the work-group size may arrive in a vector register and make all of it per-lane)
   if (w >= a.n_waves) return;
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : (SPECINV_R8_W3 && R == 8) ? 3 : 
   }
   __syncthreads();
 
-  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wib);   // (scalar: the frame loop and its padding tests branch on the scalar unit; left to the compiler the work-group size may arrive in a vector register and make all of it per-lane)
   if (w >= a.n_waves) return;
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
     lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
   }
   __syncthreads();
-  const int w = blockIdx.x * (blockDim.x >> 6) + wib;
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wib);   // (scalar: the frame loop and its padding tests branch on the scalar unit; left to the compiler the work-group size may arrive in a vector register and make all of it per-lane)
   if (w >= a.n_waves) return;
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
