@@ -94,10 +94,65 @@ struct eps16<double> {
   static constexpr double value = 1e-16;
 };
 
+// sin and cos of a phase (methods.py:612, exp(1j * phi)) in float64, for rounding to the phase's own type.
+// A float32 phase (up to ~1.5e6 rad at 1024 frames, far more on long signals) does not need the library's general float64 sincos -
+// its argument reduction alone is several hundred instructions at the float64 rate, and phase_init was bound by it: quadrant
+// k = rint(phi * 2/pi), remainder r = phi - k * pi/2 by two fused multiply-adds on a two-term pi/2 (each rounds the exact
+// difference once: |error| < 1e-16 + k * 1e-33), then the float64 kernels' polynomials on |r| <= pi/4 (the classic fdlibm minimax
+// coefficients, 2^-58): the float64 results are good to ~1e-16, rounded to float32 they equal the library's except where the
+// exact value sits within 1e-16 of a rounding boundary.  Phases beyond 1e9 rad (and NaN / inf) take the library path.
+__device__ inline void sincos_phase(double phi, double* sn, double* cs) { sincos(phi, sn, cs); }
+__device__ inline void sincos_phase(float phi_f, double* sn, double* cs) {
+  const double phi = (double)phi_f;
+  if (!(fabs(phi) < 1.0e9)) {
+    sincos(phi, sn, cs);
+    return;
+  }
+  const double k = rint(phi * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632679489655800e+00, phi);
+  r = fma(-k, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double s = fma(r * z, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)k & 3;               // (|k| < 2^30: the conversion is exact, two's complement gives k mod 4)
+  const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 // wave-wide (64 lanes) sum in double
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// inclusive prefix sum over the 64 lanes in double: shifts inside the rows of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3
+// and lane 31 into the upper half - data-parallel-primitive moves on the vector unit (two per step) instead of the twelve
+// ds_bpermute round trips of a shuffle ladder
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_scan_inclusive(double v) {
+  v += dpp_move_f64<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_move_f64<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_move_f64<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_move_f64<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_move_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_move_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
   return v;
 }
 

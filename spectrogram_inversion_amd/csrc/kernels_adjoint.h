@@ -165,17 +165,13 @@ __global__ void k_phase_init_adjoint_rows(const T* __restrict__ mag, const cplx<
       else if (peak_omega_adj<T>(col, Tn, f + 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
     }
     double v = (double)om;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double u = __shfl_up(v, off, 64);
-      if (lane >= off) v += u;
-    }
+    v = wave_scan_inclusive(v);
     v += carry;
     carry = __shfl(v, 63, 64);
     if (t < Tn) {
       const T phi = (T)v;
       double s, c;
-      sincos((double)phi, &s, &c);
+      sincos_phase(phi, &s, &c);
       const cplx<T> g = gC[roff + t];
       const T m0 = base[(int64_t)f * Tn + t];
       gm[roff + t] += (T)c * g.x + (T)s * g.y;
@@ -188,11 +184,7 @@ __global__ void k_phase_init_adjoint_rows(const T* __restrict__ mag, const cplx<
   for (int ch = nchunk - 1; ch >= 0; --ch) {
     const int t = ch * 64 + (63 - lane);                       // lane 0 holds the latest time of the chunk
     double v = t < Tn ? (double)gomega[roff + t] : 0.0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double u = __shfl_up(v, off, 64);
-      if (lane >= off) v += u;
-    }
+    v = wave_scan_inclusive(v);
     v += rc;
     rc = __shfl(v, 63, 64);
     if (t < Tn) gomega[roff + t] = (T)v;

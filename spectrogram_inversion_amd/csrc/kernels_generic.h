@@ -575,15 +575,23 @@ __device__ inline bool peak_omega(const T* __restrict__ col, int64_t fstride, in
   return true;
 }
 
-// peak test and omega from the three magnitudes around bin g (same operation order as peak_omega)
+// omega of bin f after the scatter of :607-609 - its own peak, else the k+1 write of a peak below, else the k-1 write of a peak
+// above (later statements overwrite earlier ones), else 0 - from the five magnitudes f-2 .. f+2 of one time step.  The three
+// peak tests are comparisons; the two divisions of :604-605 run ONCE, on the operands of whichever peak won (the same
+// operations on the same values as peak_omega: bit-identical), instead of once per candidate.
 template <typename T>
-__device__ inline bool peak_omega_vals(T a, T bb, T r, int g, int F, T two_pi, T n_fft, T hop, T& w) {
+__device__ inline T scatter_omega(const T (&cur)[5], int f, int F, T two_pi, T n_fft, T hop) {
 #pragma clang fp contract(off)
-  if (g < 1 || g > F - 2) return false;
-  if (!(bb > r && bb > a)) return false;                // :597
+  const bool own = f >= 1 && f <= F - 2 && cur[2] > cur[3] && cur[2] > cur[1];             // :597 at g = f
+  const bool below = f - 1 >= 1 && f - 1 <= F - 2 && cur[1] > cur[2] && cur[1] > cur[0];   //      at g = f - 1
+  const bool above = f + 1 >= 1 && f + 1 <= F - 2 && cur[3] > cur[4] && cur[3] > cur[2];   //      at g = f + 1
+  const int g = own ? f : below ? f - 1 : f + 1;
+  const T a = own ? cur[1] : below ? cur[0] : cur[2];
+  const T bb = own ? cur[2] : below ? cur[1] : cur[3];
+  const T r = own ? cur[3] : below ? cur[2] : cur[4];
   const T p = T(0.5) * (a - r) / (a - T(2) * bb + r);   // :604
-  w = two_pi * (T(g) + p) / n_fft * hop;                // :605
-  return true;
+  const T w = two_pi * (T(g) + p) / n_fft * hop;        // :605
+  return (own || below || above) ? w : T(0);
 }
 
 template <typename T>
@@ -612,26 +620,15 @@ __global__ void k_phase_init(const T* __restrict__ mag, cplx<T>* __restrict__ ou
     fetch(t + 64, nxt);
     T om = 0;
     const T m0 = cur[2];
-    if (t < Tn) {
-      T w;
-      // scatter order :607-609: own bin, else the k+1 write of a peak below, else the k-1
-      // write of a peak above (later statements overwrite earlier ones)
-      if (peak_omega_vals<T>(cur[1], cur[2], cur[3], f, F, two_pi, T(n_fft), T(hop), w)) om = w;
-      else if (peak_omega_vals<T>(cur[0], cur[1], cur[2], f - 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
-      else if (peak_omega_vals<T>(cur[2], cur[3], cur[4], f + 1, F, two_pi, T(n_fft), T(hop), w)) om = w;
-    }
+    if (t < Tn) om = scatter_omega<T>(cur, f, F, two_pi, T(n_fft), T(hop));
     double v = (double)om;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double u = __shfl_up(v, off, 64);
-      if (lane >= off) v += u;
-    }
+    v = wave_scan_inclusive(v);
     v += carry;
     carry = __shfl(v, 63, 64);
     if (t < Tn) {
       const T phi = (T)v;                                  // :611
       double s, cs;
-      sincos((double)phi, &s, &cs);                        // :612
+      sincos_phase(phi, &s, &cs);                          // :612
       orow[t] = mk<T>(m0 * (T)cs, m0 * (T)s);              // :614
     }
 #pragma unroll

@@ -113,24 +113,14 @@ __global__ __launch_bounds__(1024) void k_phase_init_pairs(const float* __restri
     }
     float om = 0.0f;
     m0 = cur[2];
-    if (t < T) {
-      float w;
-      // scatter order :607-609: own bin, else the k+1 write of a peak below, else the k-1 write of a peak above
-      if (peak_omega_vals<float>(cur[1], cur[2], cur[3], f, F, two_pi, (float)NFFT, (float)hop, w)) om = w;
-      else if (peak_omega_vals<float>(cur[0], cur[1], cur[2], f - 1, F, two_pi, (float)NFFT, (float)hop, w)) om = w;
-      else if (peak_omega_vals<float>(cur[2], cur[3], cur[4], f + 1, F, two_pi, (float)NFFT, (float)hop, w)) om = w;
-    }
+    if (t < T) om = scatter_omega<float>(cur, f, F, two_pi, (float)NFFT, (float)hop);   // (:597-609)
     double v = (double)om;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double u = __shfl_up(v, off, 64);
-      if (lane >= off) v += u;
-    }
+    v = wave_scan_inclusive(v);
     v += *cr;                                               // (wave-private LDS slot: in-order within the wave)
     if (lane == 63) *cr = v;
     const float phi = (float)v;                              // :611
     double sn, cs;
-    sincos((double)phi, &sn, &cs);                           // :612
+    sincos_phase(phi, &sn, &cs);                             // :612
     val = v2f{m0 * (float)cs, m0 * (float)sn};               // :614
   };
 
