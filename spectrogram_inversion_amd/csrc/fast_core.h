@@ -485,6 +485,8 @@ template <int R>
 struct LaneConst {
   int lane, n2, v, kv, partner;
   v2f post;                // W_64^(n2*kv)
+  v2f postq[3];            // C == 4 (n_fft 2048): W_64^(n2*s), s = 1, 2, 3 - the lane holds all four frequency digits there (fft_forward_t)
+  int tr_q;                // ... and its transpose address in that arrangement: (0, 2, 1, 3)[lane / 16] * (R + 1) + n2
   v2f stage[2];            // twiddles between the cross-lane radix-4 and radix-2 steps (C == 8: one, C == 16: two)
   v2f wn;                  // W_N^lane
   int tr_a;                // transpose address for layout A: (kv*R + reg)*(R+1) + tr_pad(kv) + n2  -> base + reg*(R+1)
@@ -524,6 +526,9 @@ __device__ __forceinline__ LaneConst<R> lane_consts() {
   }
   k.partner = (64 - k.lane) & 63;
   k.post = unit(2.0f * (float)(k.n2 * k.kv) / 64.0f);
+#pragma unroll
+  for (int sgt = 1; sgt < 4; ++sgt) k.postq[sgt - 1] = unit(2.0f * (float)(k.n2 * sgt) / 64.0f);
+  k.tr_q = (((k.v & 1) << 1) | ((k.v >> 1) & 1)) * (R + 1) + k.n2;   // row q ends up owning register g + (0, 2, 1, 3)[q] (swap32 then swap16)
   k.wn = unit(2.0f * (float)k.lane / (float)G::N);
   k.tr_a = (k.kv * R) * (R + 1) + tr_pad<R>(k.kv) + k.n2;
   k.tr_b = k.lane * (R + 1) + tr_pad<R>(k.lane / R);
@@ -561,6 +566,32 @@ __device__ __forceinline__ void xlane_dft4(v2f& A, v2f& B, v2f& C, v2f& D) {
   swap32(A, B);
   swap32(C, D);
 }
+
+// The two halves of xlane_dft4 for transforms that meet the wave's transpose scratch on one side (n_fft 2048, C == 4): after the
+// swaps each 16-lane row owns ONE of the four registers, all four of its row values - in (A, C, B, D) - and after the in-lane
+// radix-4 all four of its frequency digits.  The forward transform writes them to the scratch from there (every register has its
+// own constant address, the lane its own base) instead of swapping them back into rows first, the inverse reads them from the
+// scratch in that arrangement instead of swapping them in: 32 of the 64 lane swaps of a transform go, and the digit-0 quarter
+// of the post-twiddles (a multiplication by one) with them.  The same butterflies on the same values.
+template <bool INV>
+__device__ __forceinline__ void xlane_dft4_in(v2f& A, v2f& B, v2f& C, v2f& D) {
+  swap32(A, B);
+  swap32(C, D);
+  swap16(A, C);
+  swap16(B, D);
+  dft4<INV>(A, C, B, D);   // digit s = 0..3 of the register this row owns sits in (A, C, B, D)
+}
+template <bool INV>
+__device__ __forceinline__ void xlane_dft4_out(v2f& A, v2f& B, v2f& C, v2f& D) {
+  dft4<INV>(A, C, B, D);   // in: row value q = 0..3 of the register this row owns in (A, C, B, D)
+  swap16(A, C);
+  swap16(B, D);
+  swap32(A, B);
+  swap32(C, D);
+}
+#ifndef SPECINV_XLANE_HALF
+#define SPECINV_XLANE_HALF 1
+#endif
 
 // DFT over lane bit 5 of two registers at once: after the first swap the low half of the wave holds both halves
 // of A (in A, B) and the high half both halves of B
@@ -621,6 +652,28 @@ __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k
   if (G::C == 2) {
 #pragma unroll
     for (int g = 0; g < R; g += 2) xlane_dft2(z[g], z[g + 1]);
+  } else if (G::C == 4 && SPECINV_XLANE_HALF) {
+    // slot (A, C, B, D) = (z[g], z[g+2], z[g+1], z[g+3]) holds digit s = 0..3 of the register g + q' this row owns
+    // (q' = (0, 2, 1, 3)[lane / 16]): post-twiddle W_64^(n2 s), scratch row s R + g + q'
+#pragma unroll
+    for (int g = 0; g < R; g += 4) xlane_dft4_in<false>(z[g], z[g + 1], z[g + 2], z[g + 3]);
+#pragma unroll
+    for (int g = 0; g < R; g += 4) {
+      z[g + 2] = cmul_p<PK>(z[g + 2], k.postq[0]);
+      z[g + 1] = cmul_p<PK>(z[g + 1], k.postq[1]);
+      z[g + 3] = cmul_p<PK>(z[g + 3], k.postq[2]);
+    }
+#pragma unroll
+    for (int g = 0; g < R; g += 4) {
+      tr[k.tr_q + (0 * R + g) * (R + 1)] = z[g];
+      tr[k.tr_q + (1 * R + g) * (R + 1)] = z[g + 2];
+      tr[k.tr_q + (2 * R + g) * (R + 1)] = z[g + 1];
+      tr[k.tr_q + (3 * R + g) * (R + 1)] = z[g + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) z[i] = tr[k.tr_b + i];
+    Dft<R, false, PKC>::run(z);
+    return;
   } else if (G::C == 4) {
 #pragma unroll
     for (int g = 0; g < R; g += 4) xlane_dft4<false>(z[g], z[g + 1], z[g + 2], z[g + 3]);
@@ -663,6 +716,27 @@ __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k
   Dft<R, true, PKC>::run(z);
 #pragma unroll
   for (int i = 0; i < R; ++i) tr[k.tr_b + i] = z[i];
+  if (G::C == 4 && SPECINV_XLANE_HALF) {
+    // (the mirror image of the forward transform's short cut: the row that owns register g + lane / 16 reads its four row values)
+#pragma unroll
+    for (int g = 0; g < R; g += 4) {
+      z[g] = tr[k.tr_q + (0 * R + g) * (R + 1)];
+      z[g + 2] = tr[k.tr_q + (1 * R + g) * (R + 1)];
+      z[g + 1] = tr[k.tr_q + (2 * R + g) * (R + 1)];
+      z[g + 3] = tr[k.tr_q + (3 * R + g) * (R + 1)];
+    }
+#pragma unroll
+    for (int g = 0; g < R; g += 4) {
+      z[g + 2] = cmulc_p<PK>(z[g + 2], k.postq[0]);
+      z[g + 1] = cmulc_p<PK>(z[g + 1], k.postq[1]);
+      z[g + 3] = cmulc_p<PK>(z[g + 3], k.postq[2]);
+    }
+#pragma unroll
+    for (int g = 0; g < R; g += 4) xlane_dft4_out<true>(z[g], z[g + 1], z[g + 2], z[g + 3]);
+    cmul_all<R, PK, true, 1>(z, tw);
+    Dft<R, true, PKC>::run(z);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < R; ++i) z[i] = tr[k.tr_a + i * (R + 1)];
   cmul_all<R, PK, true, 0>(z, SameW{k.post});

@@ -95,9 +95,9 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 #pragma unroll
   for (int i = 0; i < NB * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
   double sd = 0.0, so = 0.0;
-  // pass-1 twiddles in registers - except in the variant that holds c0 and evaluates (one launch in ten of the first few
-  // iterations), which has no room for them at n_fft 2048 and reads the LDS table instead
-  constexpr bool TWLDS = (EARLY && EVAL && R >= 16) || SPECINV_TD_MINWAVES == 3;
+  // pass-1 twiddles in registers - except in the evaluating variants (one launch in ten), which have no room for them at
+  // n_fft 2048 and read the LDS table instead (measured: the same step time, no spills in the late one)
+  constexpr bool TWLDS = (EVAL && R >= 16) || SPECINV_TD_MINWAVES == 3;
   TwRegs<TWLDS ? 2 : R> twr_regs;
   if (!TWLDS) {
 #pragma unroll
