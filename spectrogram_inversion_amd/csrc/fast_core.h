@@ -467,6 +467,7 @@ struct Geo {
   static constexpr int HOP = N / 4;
   static constexpr int TR = 64 * (R + 1) + tr_pad<R>(64 / R - 1);  // transpose scratch per wave (complex elements)
   static constexpr size_t lds_bytes(int waves) { return sizeof(v2f) * (size_t)(M + (R - 1) * 64 + waves * TR); }
+  static constexpr size_t lds_bytes_td(int waves) { return lds_bytes(waves) + sizeof(v2f) * (size_t)M; }   // + the scaled synthesis window
 };
 
 // overlap geometry of the fused kernels: hop = N / OV, OV in {2, 4, 8}

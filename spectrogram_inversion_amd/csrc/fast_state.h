@@ -556,7 +556,7 @@ struct FastState<float> {
     size_t lds_used = 0;
     const int wgw = fused_wgw();
     SPECINV_R_SWITCH(R, if constexpr (RR <= 16) {                      // (n_fft 4096 never takes the signal form: begin_t)
-                       lds_used = fast::Geo<RR>::lds_bytes(wgw);
+                       lds_used = fast::Geo<RR>::lds_bytes_td(wgw);
                        if constexpr (RR % 8 == 0) { if (OV == 8) fn = td_kernel<RR, 8>(early, ev); }
                        if constexpr (RR == 8 || RR == 16) { if (OV == 4) fn = td_kernel4<RR>(early, ev); }
                        else { if (OV == 4) fn = td_kernel<RR, 4>(early, ev); }

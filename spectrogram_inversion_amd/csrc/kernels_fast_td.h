@@ -46,6 +46,9 @@ __device__ __forceinline__ void td_load_block(const float* __restrict__ xrow, co
   else load_block<R, OV>(xrow, tailrow, L, T, c, t_begin, t_end, j, lane, pad_mode, q);
 }
 
+#ifndef SPECINV_TD_WKREG
+#define SPECINV_TD_WKREG 1
+#endif
 #ifndef SPECINV_TD_MINWAVES
 #define SPECINV_TD_MINWAVES 2
 #endif
@@ -61,12 +64,21 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   using O = Ovl<R, OV>;
   constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // The synthesis window carries the inverse transform's scale (a second table): one multiplication less per bin pair in the
+  // projection; 1 / n_fft is a power of two, so nothing changes in the result (normalized=True: one rounding moves).  The
+  // exact-projection build keeps the reference's order of operations.
+  constexpr bool WSCALE = !SPECINV_IEEE && SPECINV_RSQ;
   v2f* lds_win = reinterpret_cast<v2f*>(smem);
-  v2f* lds_tw1 = lds_win + M;
+  v2f* lds_wins = WSCALE ? lds_win + M : lds_win;
+  v2f* lds_tw1 = lds_win + 2 * M;      // (the host reserves both tables for every build: Geo::lds_bytes_td)
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
 
-  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    const v2f wv = v2f{a.window[2 * i], a.window[2 * i + 1]};
+    lds_win[i] = wv;
+    if (WSCALE) lds_wins[i] = wv * a.inv_scale;
+  }
   for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
     const int k1 = i / 64 + 1, l = i & 63;
     lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);   // W_M^(l*k1)
@@ -127,6 +139,14 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
+  // the real-FFT twiddles of the pairs, W_N^(lane + 64 j): the plain launches have the registers to keep all of them (two waves
+  // per SIMD leave 256 each), the others rebuild them from W_N^lane every frame
+  constexpr bool WKREG = !EARLY && !EVAL && SPECINV_TD_MINWAVES == 2 && SPECINV_TD_WKREG;
+  v2f wkr[WKREG ? H : 1];
+  if (WKREG) {
+#pragma unroll
+    for (int j = 0; j < H; ++j) wkr[j] = pair_twiddle<R>(k.wn, j);
+  }
   for (int t = t_begin; t < t_end; ++t) {
     TD_STAMP(5);                       // (loop overhead / nothing on the first pass)
     asm volatile("" ::: "memory");     // (window / twiddle reads stay inside the loop: hoisted they pin ~80 VGPRs)
@@ -235,7 +255,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
     v2f back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
-      const v2f wk = pair_twiddle<R>(wn, j);
+      const v2f wk = WKREG ? wkr[WKREG ? j : 0] : pair_twiddle<R>(wn, j);
       v2f sk, sm;
       if (EARLY || SPECINV_IEEE || !SPECINV_RSQ) {
         td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
@@ -255,7 +275,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 #elif SPECINV_RSQ
       // the projection's factors (proj_rsq, fast_core.h) of the pair's two bins, formed and applied as packed operations
       const v2f inv = v2f{proj_rsq(sk), proj_rsq(sm)};
-      const v2f mi = (v2f{mk, mq} * inv) * a.inv_scale;
+      const v2f mi = v2f{mk, mq} * inv;                       // (the inverse scale rides on the synthesis window)
       v2f ak = scale_lo(sk, mi);
       v2f am = scale_hi(sm, mi);
 #else
@@ -280,7 +300,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       const float dn = fast_abs(smid) + 1e-16f;
       const v2f am = v2f{__fdiv_rn(smid.x * mmid, dn) * a.inv_scale, __fdiv_rn(smid.y * mmid, dn) * a.inv_scale};
 #elif SPECINV_RSQ
-      const v2f am = smid * ((mmid * proj_rsq(smid)) * a.inv_scale);
+      const v2f am = smid * (mmid * proj_rsq(smid));
 #else
       const float inv = fast_rcp(fast_abs(smid) + 1e-16f) * a.inv_scale;
       const v2f am = v2f{(smid.x * mmid) * inv, (smid.y * mmid) * inv};
@@ -300,7 +320,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 
     // ---- synthesis window, register overlap-add, one finished hop-block of x_{t+1} and of z_{t+1} out
 #pragma unroll
-    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_win[64 * u + lane];
+    for (int u = 0; u < R; ++u) z[u] = z[u] * lds_wins[64 * u + lane];
     if (t >= PB) {
       const long long o0 = (long long)(t - PB) * HOP;
       const v2f* envp = reinterpret_cast<const v2f*>(a.inv_env + o0);   // uniform
