@@ -573,7 +573,8 @@ __device__ __forceinline__ void xlane_dft4(v2f& A, v2f& B, v2f& C, v2f& D) {
 // radix-4 all four of its frequency digits.  The forward transform writes them to the scratch from there (every register has its
 // own constant address, the lane its own base) instead of swapping them back into rows first, the inverse reads them from the
 // scratch in that arrangement instead of swapping them in: 32 of the 64 lane swaps of a transform go, and the digit-0 quarter
-// of the post-twiddles (a multiplication by one) with them.  The same butterflies on the same values.
+// of the post-twiddles (a multiplication by one) with them.  The same butterflies on the same values.  Taken with the packed
+// products (PK): k_rtisi_fast - a lone wave per SIMD, scalar products - measured 2.6 % slower with it (C3 126.1 vs 122.9 ms).
 template <bool INV>
 __device__ __forceinline__ void xlane_dft4_in(v2f& A, v2f& B, v2f& C, v2f& D) {
   swap32(A, B);
@@ -653,7 +654,7 @@ __device__ __forceinline__ void fft_forward_t(v2f (&z)[R], const LaneConst<R>& k
   if (G::C == 2) {
 #pragma unroll
     for (int g = 0; g < R; g += 2) xlane_dft2(z[g], z[g + 1]);
-  } else if (G::C == 4 && SPECINV_XLANE_HALF) {
+  } else if (G::C == 4 && SPECINV_XLANE_HALF && PK) {
     // slot (A, C, B, D) = (z[g], z[g+2], z[g+1], z[g+3]) holds digit s = 0..3 of the register g + q' this row owns
     // (q' = (0, 2, 1, 3)[lane / 16]): post-twiddle W_64^(n2 s), scratch row s R + g + q'
 #pragma unroll
@@ -717,7 +718,7 @@ __device__ __forceinline__ void fft_inverse_t(v2f (&z)[R], const LaneConst<R>& k
   Dft<R, true, PKC>::run(z);
 #pragma unroll
   for (int i = 0; i < R; ++i) tr[k.tr_b + i] = z[i];
-  if (G::C == 4 && SPECINV_XLANE_HALF) {
+  if (G::C == 4 && SPECINV_XLANE_HALF && PK) {
     // (the mirror image of the forward transform's short cut: the row that owns register g + lane / 16 reads its four row values)
 #pragma unroll
     for (int g = 0; g < R; g += 4) {
