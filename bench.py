@@ -201,12 +201,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # SPECINV_BENCH_BACKEND=gloo (development only): rehearse the N > 1 code path of this script - sharding, barrier, gather,
+    # max over ranks - with several ranks on the ONE GPU of a test box (a device cannot host two ranks of an RCCL communicator);
+    # the gather is then staged through host memory, so the line it prints is not a measurement
+    backend = os.environ.get("SPECINV_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import spectrogram_inversion_amd as si
     from spectrogram_inversion_amd.distributed import gather_waveforms
@@ -231,7 +240,11 @@ def main():
             # overlap it - every gather is completed (`result()`) inside the timed region
             if pending:
                 pending.pop().result()
-            pending.append(gather_waveforms(x, dst=0, sizes=[batch] * world, async_op=True))
+            if backend == "nccl":
+                pending.append(gather_waveforms(x, dst=0, sizes=[batch] * world, async_op=True))
+            else:                                            # (rehearsal: a blocking gather through host memory)
+                done = gather_waveforms(x, dst=0, sizes=[batch] * world)
+                pending.append(type("Done", (), {"result": staticmethod(lambda done=done: done)})())
         state["x"] = x
 
     if method in ("griffin_lim", "ADMM"):

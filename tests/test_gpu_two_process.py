@@ -95,3 +95,31 @@ def test_two_processes_on_one_device_match_the_whole_batch_run(tmp_path):
     assert np.array_equal(got["r"], r.cpu().numpy())
     f = si.griffin_lim(mag, max_iter=7, tol=0.0, alpha=0.3, verbose=False, eva_iter=3, **kw)
     assert np.array_equal(got["f"], f.cpu().numpy())
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workload,extra", [("C1", []), ("C5", ["--outer", "2"])])
+def test_bench_world_size_two_rehearsal(workload, extra):
+    """bench.py's N > 1 code path - launched the way the driver launches it (torch.distributed.run, one rank per process) -
+    with both ranks on cuda:0 and a gloo group (`SPECINV_BENCH_BACKEND=gloo`: a device cannot host two RCCL ranks): the
+    shards, the barrier + max-over-ranks timing, the gather to rank 0 and the one JSON line with whole-job units.  The rate it
+    prints is not a measurement; that the 8-GPU launch cannot die on a code path nobody has run is the point."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SPECINV_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", workload, "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]              # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    if workload == "C1":
+        assert d["config"]["global_batch"] == 2 and d["check"]["ok"]
+    else:
+        assert d["config"]["parallelism"].startswith("replicas x2")
