@@ -1019,9 +1019,12 @@ __global__ void k_grad_fold_margins(const T* __restrict__ frames, T* __restrict_
 
 // ---- host side ------------------------------------------------------------------------------------------------
 // 16-row mel tiles the one-launch objective is instantiated for (0: not covered)
-inline int obj_mel_tiles(int n_mels) {
+// (n_fft 1024 takes NINE tiles for 81 ... 128 bands, the last one empty: k_objective_logmel<8, 8> is the one instantiation the
+// register allocator loses - 256 registers and 978 spilled, 0.204 ms per evaluation at B16 x T1024 where <8, 5> takes 0.113 -
+// while <8, 7>, <8, 9> and <8, 10> allocate 180 ... 193 and spill nothing)
+inline int obj_mel_tiles(int n_mels, int R) {
   const int mt = (n_mels + 15) / 16;
-  return mt <= 3 ? 3 : mt <= 4 ? 4 : mt <= 5 ? 5 : mt <= 8 ? 8 : 0;
+  return mt <= 3 ? 3 : mt <= 4 ? 4 : mt <= 5 ? 5 : mt <= 8 ? (R == 8 ? 9 : 8) : 0;
 }
 
 // What follows k_objective_logmel, in ONE launch (three small kernels before: ~8 us of a 0.16 ms evaluation):
@@ -1190,7 +1193,7 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     lds = R == 16 ? fast::ObjGeo<16, 3>::lds_bytes() : fast::ObjGeo<8, 3>::lds_bytes();
   } else {
     SPECINV_OBJ_CASE(16, 3) SPECINV_OBJ_CASE(16, 4) SPECINV_OBJ_CASE(16, 5) SPECINV_OBJ_CASE(16, 8)
-    SPECINV_OBJ_CASE(8, 3) SPECINV_OBJ_CASE(8, 4) SPECINV_OBJ_CASE(8, 5) SPECINV_OBJ_CASE(8, 8)
+    SPECINV_OBJ_CASE(8, 3) SPECINV_OBJ_CASE(8, 4) SPECINV_OBJ_CASE(8, 5) SPECINV_OBJ_CASE(8, 9)
   }
 #undef SPECINV_OBJ_CASE
   if (fn == nullptr || lds > 160 * 1024) return SPECINV_OK;
@@ -1267,7 +1270,7 @@ int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
       }
       // operand tiles of the one-launch objective (kernels_objective.h): one-sided spectra on the wave-level FFT
       pl.tf_obj_mt = 0;
-      const int mt16 = obj_mel_tiles(n_mels);
+      const int mt16 = obj_mel_tiles(n_mels, pl.fast.xform_R);
       if (mt16 > 0 && pl.cfg.onesided && pl.fast.xform_ok && (pl.fast.xform_R == 8 || pl.fast.xform_R == 16)) {
         std::vector<float> h_mel((size_t)n_mels * pl.n_freq), hA, hB;
         std::vector<int> h_tab;

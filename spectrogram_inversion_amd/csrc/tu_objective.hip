@@ -9,7 +9,7 @@ namespace fast {
 template __global__ void k_objective_logmel<8, 3, false>(ObjArgs);
 template __global__ void k_objective_logmel<8, 4, false>(ObjArgs);
 template __global__ void k_objective_logmel<8, 5, false>(ObjArgs);
-template __global__ void k_objective_logmel<8, 8, false>(ObjArgs);
+template __global__ void k_objective_logmel<8, 9, false>(ObjArgs);
 template __global__ void k_objective_logmel<16, 3, false>(ObjArgs);
 template __global__ void k_objective_logmel<16, 4, false>(ObjArgs);
 template __global__ void k_objective_logmel<16, 5, false>(ObjArgs);

@@ -74,6 +74,14 @@ def test_headline_kernels_keep_their_register_budgets(kernels):
     assert v <= 256 and sp == 0, (v, sp)
 
 
+def test_no_shipped_wave_level_kernel_spills_heavily(kernels):
+    """k_objective_logmel<8, 8> compiled to 256 registers + 978 spilled and ran 1.8 x slower than its neighbours <8, 7> / <8, 9> for
+    a whole round before anybody looked: no kernel of the wave-level family may spill more than a hundred registers (the known
+    heavy ones: the early evaluating launch, k_rtisi_fast with 512-sample hops at look-ahead 8)."""
+    bad = {k: v for k, v in kernels.items() if ("4fast" in k or "10fast_exact" in k) and v[1] > 140}
+    assert not bad, bad
+
+
 def test_no_wave_level_kernel_is_capped_at_the_default_bounds(kernels):
     """A wave-level kernel compiled without its launch bounds gets the 1024-thread default: exactly 128 registers plus a large
     spill.  None of them may look like that."""

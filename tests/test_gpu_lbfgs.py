@@ -254,7 +254,9 @@ def test_gram_direction_follows_the_two_loop_recursion(history):
     (2048, 333, 48, 2, 40, {}),                                   # odd hop: scalar overlap-add
     (2048, 1500, 20, 2, 80, {}),                                  # hardly any overlap
     (1024, 256, 50, 3, 40, {}),
-    (1024, 128, 64, 2, 128, {}),                                  # 8 mel tiles, hop = n_fft/8 (tiles of exactly 16 frames)
+    (1024, 128, 64, 2, 128, {}),                                  # 8 mel tiles (+ an empty ninth at n_fft 1024), hop = n_fft/8
+    (1024, 256, 30, 2, 100, {}),                                  # 7 mel tiles, the last one partial, on the nine-tile kernel
+    (2048, 512, 24, 2, 128, {}),                                  # 8 mel tiles at n_fft 2048
     (1024, 256, 40, 2, 20, dict(normalized=True)),                # padded mel tile, ortho scaling
     (2048, 512, 20, 2, 80, dict(center=False)),                   # no padding: signal of (T-1) hop + n_fft samples
 ])
