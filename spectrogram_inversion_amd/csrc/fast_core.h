@@ -802,6 +802,7 @@ struct FastArgs {
   const float* x2_in;   // k_fused4_td: x_t (x_in / x_out carry z there)
   float* x2_out;
   float tds;            //              (-lr)^t
+  int skew;             // chunk_begin's skew (0: even chunks)
   unsigned long long* stamps;   // SPECINV_TD_STAMPS builds only: [n_waves][8]
   float coef;       // lr (GLA) or rho (ADMM)
   float inv1p;      // 1/(1+rho)
@@ -898,9 +899,12 @@ __device__ __forceinline__ long long pad_index(long long n, long long L, int pad
   }
 }
 
-// Frames [chunk_begin(c), chunk_begin(c+1)) belong to wave-chunk c; sizes differ by at most one frame.
-__device__ __host__ __forceinline__ int chunk_begin(int c, int T, int nchunks) {
-  return (int)(((unsigned)c * (unsigned)T) / (unsigned)nchunks);   // c * T < 2^32 for any plan that fits in memory
+// Frames [chunk_begin(c), chunk_begin(c+1)) belong to wave-chunk c; sizes differ by at most one frame - unless the plan skews
+// them: `skew` frames move from every odd chunk to the even chunk before it (FastState::skew: the waves of a launch that exactly
+// fills two wave slots per SIMD do not run at the same speed, kernels_fast_td.h).
+__device__ __host__ __forceinline__ int chunk_begin(int c, int T, int nchunks, int skew = 0) {
+  const int even = (int)(((unsigned)c * (unsigned)T) / (unsigned)nchunks);   // c * T < 2^32 for any plan that fits in memory
+  return even + ((c & 1) ? skew : 0);
 }
 
 // One hop-block (N/4 samples, padded-signal block index j) of row `xrow` in the register layout

@@ -1,5 +1,6 @@
 // Host side of the wave-level kernels: FastState<float> picks the kernel, sizes the launch and owns the device state.
 #pragma once
+#include <algorithm>
 #include "fast_core.h"
 #include "kernels_layout.h"
 
@@ -102,6 +103,7 @@ struct FastState<float> {
   bool state_in_place = true;
   bool use_template = false;   // tests: run k_fused<R, 4> where the tuned copy k_fused4<R> would run (SPECINV_FUSED_TEMPLATE=1)
   int chunk = 32, nchunks = 0, n_waves = 0, n_partials = 0;
+  int skew = 0;        // frames every odd chunk cedes to the even chunk before it (chunk_begin; set per Griffin-Lim run in begin_t)
   int cur = 0;   // index of the buffers holding the current state
   int mode = fast::MODE_GLA;
   FastBuf xb[2], xtail[2], Pb[2], Pmid[2], mpairs, mmid, inv_env, scratch;
@@ -286,6 +288,20 @@ struct FastState<float> {
       if (e[0] == '1') td = false;
     }
     td_t = 0;
+    // Skewed chunks.  Two waves share a SIMD and the arbiter serves the OLDER one first whenever both have an instruction ready:
+    // at BASELINE C2 the wave in hardware slot 0 ran 0.132 frames per kilotick against its neighbour's 0.077 and finished after
+    // 69 % of the launch (237 k against 337 k ticks on every one of the 1024 SIMDs, tools/td_waves.py); the neighbour ran the last
+    // third alone at 0.143 - a SIMD with two waves does 0.209.  Chunks of 42 and 22 frames instead of 32 and 32 let both finish
+    // together (measured: 0.172-0.176 -> 0.166 ms per late launch; 8 / 12 / 14 frames of skew 0.168 / 0.169 / 0.172).  Only for
+    // the launch shape this was measured on - the signal-form kernel at two waves per SIMD with exactly as many waves as the
+    // chip has slots for them (BASELINE C2 per GPU: 2048).  SPECINV_TD_SKEW overrides (experiments; 0 switches it off).
+    // Also tried: s_setprio by frame parity or by time slice so that the two waves take turns (-2...3 %, no better with the skew).
+    skew = 0;
+    if (td && !semi && RR == 16 && OV == 4 && n_waves == 2048 && (nchunks & 1) == 0 && pl.Tn() / nchunks >= 24) skew = 10;
+    if (const char* e = getenv("SPECINV_TD_SKEW")) {
+      const int v = atoi(e);
+      if (v == 0 || (td && !semi && (nchunks & 1) == 0 && (n_waves & 1) == 0 && pl.Tn() / nchunks - v >= 8)) skew = v;
+    }
     if (td) {
       SI_TRY(zb[0].reserve((size_t)pl.B() * pl.length * sizeof(float)));
       SI_TRY(zb[1].reserve((size_t)pl.B() * pl.length * sizeof(float)));
@@ -376,6 +392,7 @@ struct FastState<float> {
     a.inv_env = inv_env.template as<float>();
     a.T = pl.Tn();
     a.nchunks = nchunks;
+    a.skew = skew;
     a.n_waves = n_waves;
     a.L = pl.length;
     a.fwd_scale = pl.fc.fwd_scale;
@@ -568,14 +585,14 @@ struct FastState<float> {
     fast::FastArgs args = a;
 #if SPECINV_TD_STAMPS
     static unsigned long long* d_stamps = nullptr;
-    if (!d_stamps) SI_HIP(hipMalloc(&d_stamps, (size_t)n_waves * 8 * sizeof(unsigned long long)));
+    if (!d_stamps) SI_HIP(hipMalloc(&d_stamps, (size_t)n_waves * 11 * sizeof(unsigned long long)));
     args.stamps = d_stamps;
 #endif
     void* kargs[] = {&args};
     SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds_used, pl.stream));
 #if SPECINV_TD_STAMPS
     if (td_t == 40 || td_t == 5) {
-      std::vector<unsigned long long> h((size_t)n_waves * 8);
+      std::vector<unsigned long long> h((size_t)n_waves * 11);
       SI_HIP(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       const char* names[6] = {"loads + window + slide", "forward FFT", "split / project / fold", "inverse FFT", "window + out + OLA", "loop"};
       double tot[6] = {0}, frames = 0;
@@ -590,6 +607,32 @@ struct FastState<float> {
         all += tot[i] / frames;
       }
       fprintf(stderr, "  %-24s %8.0f\n", "frame", all);
+      // how evenly the waves finish: every wave walks the same number of frames, a launch lasts as long as its slowest wave
+      std::vector<double> per_wave((size_t)n_waves);
+      for (int wv = 0; wv < n_waves; ++wv) {
+        double t = 0;
+        for (int i = 0; i < 6; ++i) t += (double)h[(size_t)wv * 8 + i];
+        per_wave[(size_t)wv] = t;
+      }
+      std::sort(per_wave.begin(), per_wave.end());
+      double mean = 0;
+      for (double v : per_wave) mean += v / n_waves;
+      if (const char* dump = getenv("SPECINV_TD_STAMP_DUMP")) {     // wave, xcc, hw_id, begin, end, frames: one line per wave
+        FILE* f = fopen(dump, td_t == 5 ? "w" : "a");
+        if (f) {
+          unsigned long long t0 = ~0ull;
+          for (int wv = 0; wv < n_waves; ++wv) t0 = std::min(t0, h[(size_t)n_waves * 8 + 2 * (size_t)wv + 1]);
+          for (int wv = 0; wv < n_waves; ++wv) {
+            const unsigned long long id = h[(size_t)n_waves * 8 + 2 * (size_t)wv];
+            fprintf(f, "%d %d %u %u %llu %llu %llu\n", td_t, wv, (unsigned)(id >> 32), (unsigned)id,
+                    h[(size_t)n_waves * 8 + 2 * (size_t)wv + 1] - t0, h[(size_t)n_waves * 10 + (size_t)wv] - t0, h[(size_t)wv * 8 + 6]);
+          }
+          fclose(f);
+        }
+      }
+      fprintf(stderr, "  per-wave total: min %.0f  p10 %.0f  median %.0f  mean %.0f  p90 %.0f  p99 %.0f  max %.0f  (max / mean %.3f)\n",
+              per_wave.front(), per_wave[(size_t)(0.1 * n_waves)], per_wave[(size_t)(0.5 * n_waves)], mean,
+              per_wave[(size_t)(0.9 * n_waves)], per_wave[(size_t)(0.99 * n_waves)], per_wave.back(), per_wave.back() / mean);
     }
 #endif
     return SPECINV_OK;
@@ -779,6 +822,7 @@ struct FastState<float> {
       a.partials = pl.partials.template as<double>();
       a.T = pl.Tn();
         a.nchunks = nchunks;
+      a.skew = skew;
       a.n_waves = n_waves;
       a.pad_mode = pl.cfg.pad_mode;
       a.L = pl.length;
@@ -828,7 +872,8 @@ struct FastState<float> {
       const float* tl = xtail[cur].template as<float>();
       int Tn = pl.Tn(), nc = nchunks;
       long long Ln = (long long)pl.length, tot = total;
-      void* kargs[] = {&xo, &tl, &Tn, &nc, &Ln, &tot};
+      int sk = skew;
+      void* kargs[] = {&xo, &tl, &Tn, &nc, &Ln, &tot, &sk};
       SI_HIP(hipLaunchKernel(fn, dim3((unsigned)ceil_div(total, 256)), dim3(256), kargs, 0, pl.stream));
     }
     return SPECINV_OK;

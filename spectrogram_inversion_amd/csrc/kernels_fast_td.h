@@ -85,14 +85,26 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   }
   __syncthreads();
 
-  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wib);   // (scalar: the frame loop and its padding tests branch on the scalar unit; left to the compiler the work-group size may arrive in a vector register and make all of it per-lane)
+  int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wib);   // (scalar: the frame loop and its padding tests branch on the scalar unit; left to the compiler the work-group size may arrive in a vector register and make all of it per-lane)
   if (w >= a.n_waves) return;
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
-  const int b = w / a.nchunks, c = w - b * a.nchunks;
-  const int t_begin = chunk_begin(c, a.T, a.nchunks);
-  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  // Even chunks: wave w walks chunk w mod nchunks of item w / nchunks.  Skewed chunks (a launch of exactly two waves per SIMD):
+  // the dispatcher hands every CU its first workgroup before any gets a second, so the first half of the waves sit in hardware
+  // slot 0 of their SIMDs (1024 of 1024 in every dump of tools/td_waves.py) - the older wave, which the arbiter serves first: it
+  // runs 1.7 x as fast as its neighbour while both are there - and take the even (longer) chunks, the second half the odd ones.
+  // (Drawing the chunk by the slot actually occupied, with two atomic counters, balanced the waves to 4 % - and cost more in
+  // 1024 same-address atomics per counter than it won.  A launch placed differently is merely less balanced.)
+  int b = w / a.nchunks, c = w - b * a.nchunks;
+  if (a.skew != 0) {
+    const int half = a.n_waves >> 1, second = w >= half ? 1 : 0, wl = w - second * half, pairs = a.nchunks >> 1;
+    b = wl / pairs;
+    c = 2 * (wl - b * pairs) + second;
+    w = b * a.nchunks + c;      // (the index of the chunk walked: partial sums and stamps go by it)
+  }
+  const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
   const float* zrow = a.x_in + (long long)b * a.L;
   const float* tailrow = a.xtail_in + (long long)b * a.nchunks * NB * HOP;
   float* zorow = a.x_out + (long long)b * a.L;
@@ -138,6 +150,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 #if SPECINV_TD_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long stamp_begin = stamp_prev;
 #endif
   // the real-FFT twiddles of the pairs, W_N^(lane + 64 j): the plain launches have the registers to keep all of them (two waves
   // per SIMD leave 256 each), the others rebuild them from W_N^lane every frame
@@ -366,6 +379,13 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) a.stamps[(long long)w * 8 + i] = stamp_sum[i];
     a.stamps[(long long)w * 8 + 6] = (unsigned long long)(t_end - t_begin);
+    // where and when the wave ran: HW_ID (wave / SIMD / CU / SH / SE) with the XCC id above it, begin and end in the low / high
+    // halves of one word (differences to the launch's earliest begin fit 32 bits)
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    a.stamps[(long long)a.n_waves * 8 + 2 * (long long)w] = ((unsigned long long)xcc << 32) | hw;
+    a.stamps[(long long)a.n_waves * 8 + 2 * (long long)w + 1] = stamp_begin;
+    a.stamps[(long long)a.n_waves * 10 + (long long)w] = __builtin_amdgcn_s_memtime();
   }
 #endif
   if (t_end == a.T) {

@@ -30,8 +30,8 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
   const int b = w / a.nchunks, c = w - b * a.nchunks;
-  const int t_begin = chunk_begin(c, a.T, a.nchunks);
-  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
   const int t_start = t_begin;   // no halo: the previous chunk's share of the first three hop-blocks comes via xtail
   const float* xrow = a.x_in + (long long)b * a.L;
   const float* tailrow = a.xtail_in + (long long)b * a.nchunks * 3 * HOP;
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : (SPECINV_R8_W3 && R == 8) ? 3 : 
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
   const int b = w / a.nchunks, c = w - b * a.nchunks;
-  const int t_begin = chunk_begin(c, a.T, a.nchunks);
-  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
   const int t_start = t_begin;   // no halo: the previous chunk's share of the first NB hop-blocks comes via xtail
   const float* xrow = a.x_in + (long long)b * a.L;
   const float* tailrow = a.xtail_in + (long long)b * a.nchunks * NB * HOP;
@@ -573,8 +573,8 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
   const int b = w / a.nchunks, c = w - b * a.nchunks;
-  const int t_begin = chunk_begin(c, a.T, a.nchunks);
-  const int t_end = chunk_begin(c + 1, a.T, a.nchunks);
+  const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew);
+  const int t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
   const int t_start = max(0, t_begin - NB);      // one-off kernel: recompute the NB-frame halo, write whole blocks
   float* orow = a.x_out + (long long)b * a.L;
   v2f acc[NB * QU];

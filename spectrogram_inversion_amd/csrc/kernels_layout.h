@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void k_phase_init_pairs(const float* __restri
 // x += the tail partial sums (final waveform for get_wave)
 template <int R, int OV>
 __global__ void k_add_tails(float* __restrict__ x, const float* __restrict__ xtail, int T, int nchunks, long long L,
-                            long long total) {
+                            long long total, int skew) {
   constexpr int HOP = Ovl<R, OV>::HOP, NB = Ovl<R, OV>::NB, PB = Ovl<R, OV>::PB;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c, q, sample) over tails
   if (i >= total) return;
@@ -178,7 +178,7 @@ __global__ void k_add_tails(float* __restrict__ x, const float* __restrict__ xta
   const int c = (i / (NB * HOP)) % nchunks;
   const long long b = i / ((long long)NB * HOP * nchunks);
   if (c >= nchunks - 1) return;                       // the last chunk has no successor
-  const int blk = chunk_begin(c + 1, T, nchunks) + q; // padded-signal hop-block
+  const int blk = chunk_begin(c + 1, T, nchunks, skew) + q; // padded-signal hop-block
   // register layout of a block: element (reg i2, lane l, comp e) <-> sample 128*i2 + 2*l + e
   const int i2 = smp / 128, rem = smp % 128;
   x[b * L + (long long)(blk - PB) * HOP + smp] += xtail[((b * nchunks + c) * NB + q) * HOP + (i2 * 64 + rem / 2) * 2 + (rem & 1)];

@@ -643,3 +643,34 @@ def test_signal_form_state_does_not_leak_between_runs(n_fft, hop, frames, batch)
     p.gla_init(None, mag, 0.3)
     p.iterate(20)
     assert torch.equal(p.wave(), w_ref)
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,batch,chunk,skew", [(2048, 512, 128, 2, 16, 3), (2048, 512, 96, 3, 24, 5),
+                                                                (1024, 256, 200, 2, 25, 4)])
+def test_skewed_chunks_against_even_chunks_and_oracle(monkeypatch, n_fft, hop, frames, batch, chunk, skew):
+    """`chunk_begin`'s skew (every odd chunk cedes frames to the even chunk before it, the first half of the waves walk the even
+    chunks: what BASELINE C2's launch shape runs with, FastState::begin_t) only moves the seams: the iterates equal those of the
+    even chunks up to the order of the seam sums, and both match the oracle.  Momentum, evaluation and the early (+c0)
+    launches included."""
+    rng = np.random.default_rng(n_fft + skew)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)
+    w = hann(n_fft)
+    init = oracle.phase_init(mag, hop_length=hop, window=w)
+    trace = []
+    ref = oracle.griffin_lim(init, max_iter=12, alpha=0.3, tol=0, eva_iter=4, hop_length=hop, window=w, trace=trace)
+    out = []
+    for sk in (0, skew):
+        monkeypatch.setenv("SPECINV_TD_SKEW", str(sk))
+        plan = make_plan(n_fft, hop, frames, batch, chunk=chunk)
+        plan.gla_init(T(init), None, 0.3)
+        geo = plan.launch_geometry
+        assert geo["kernel"] in ("k_fused4_td", "k_fused_td") and geo["chunks"] % 2 == 0, geo
+        done, evals = plan.run(12, 4, 0.0, "sc")
+        y = N(plan.wave())
+        assert rel_l2(y, ref.reshape(y.shape)) < 1e-4
+        assert np.abs(sc_linear(np.array([m for _, m, _ in evals])) - sc_linear(np.array([m for _, m, _ in trace]))).max() < 1e-5
+        out.append((y, np.array([m for _, m, _ in evals])))
+        del plan
+    assert rel_l2(out[0][0], out[1][0]) < 2e-5
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-5)
+    assert not np.array_equal(out[0][0], out[1][0])          # (the seams did move: the switch is live)
