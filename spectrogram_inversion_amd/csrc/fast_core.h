@@ -902,9 +902,12 @@ __device__ __forceinline__ long long pad_index(long long n, long long L, int pad
 // Frames [chunk_begin(c), chunk_begin(c+1)) belong to wave-chunk c; sizes differ by at most one frame - unless the plan skews
 // them: `skew` frames move from every odd chunk to the even chunk before it (FastState::skew: the waves of a launch that exactly
 // fills two wave slots per SIMD do not run at the same speed, kernels_fast_td.h).
+// Three waves per SIMD (k_fused4<8>): skew = 0x10000 | s1 << 8 | s2 moves the begin of chunks 3q + 1 / 3q + 2 by s1 / s2 frames.
 __device__ __host__ __forceinline__ int chunk_begin(int c, int T, int nchunks, int skew = 0) {
   const int even = (int)(((unsigned)c * (unsigned)T) / (unsigned)nchunks);   // c * T < 2^32 for any plan that fits in memory
-  return even + ((c & 1) ? skew : 0);
+  if (skew < 0x10000) return even + ((c & 1) ? skew : 0);
+  const int r = c % 3;
+  return even + (r == 1 ? ((skew >> 8) & 0xff) : r == 2 ? (skew & 0xff) : 0);
 }
 
 // One hop-block (N/4 samples, padded-signal block index j) of row `xrow` in the register layout

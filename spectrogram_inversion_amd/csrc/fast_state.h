@@ -90,6 +90,11 @@ struct FastState {
     default: { constexpr int RR = 32; __VA_ARGS__; } break; \
   }
 
+#ifndef SPECINV_K4_SKEW1            // begin shifts of the second / third chunk of a triple (frames) at BASELINE C4's launch shape
+#define SPECINV_K4_SKEW1 4          // (C4 step, two runs each: "0,0" 30.38 / 30.38 ms, "3,4" 30.29 / 30.26, "4,6" 29.93 / 29.97, "5,8" 30.49 / 30.20,
+#define SPECINV_K4_SKEW2 6          //  "6,9" 30.27 / 30.21, "6,11" 30.78 / 30.68, "8,12" 30.40 / 30.34: the kernel sits on the memory system, the balance buys 1.4 %)
+#endif
+
 template <>
 struct FastState<float> {
   using v2f = fast::v2f;
@@ -298,6 +303,17 @@ struct FastState<float> {
     // Also tried: s_setprio by frame parity or by time slice so that the two waves take turns (-2...3 %, no better with the skew).
     skew = 0;
     if (td && !semi && RR == 16 && OV == 4 && n_waves == 2048 && (nchunks & 1) == 0 && pl.Tn() / nchunks >= 24) skew = 10;
+    // ... and the spectral-state kernel at three waves per SIMD (12-wave workgroups, the hardware slot is the wave's index in the
+    // workgroup / 4, kernels_fused.h): chunk triples, the oldest wave the longest.  BASELINE C4's shard: 3072 waves.
+    if (!td && !semi && RR == 8 && OV == 4 && !use_template && fused_wgw() == 12 && n_waves == 3072 && nchunks % 3 == 0 &&
+        pl.Tn() / nchunks >= 16)
+      skew = 0x10000 | (SPECINV_K4_SKEW1 << 8) | SPECINV_K4_SKEW2;
+    if (const char* e = getenv("SPECINV_K4_SKEW")) {          // "s1,s2" (experiments; "0,0" switches it off)
+      int s1 = 0, s2 = 0;
+      if (sscanf(e, "%d,%d", &s1, &s2) == 2 && !td && !semi && fused_wgw() == 12 && nchunks % 3 == 0 && n_waves % 12 == 0 && s1 >= 0 && s2 >= 0 &&
+          s1 < 200 && s2 < 200 && pl.Tn() / nchunks - s2 >= 8 && pl.Tn() / nchunks + s2 - s1 >= 8)
+        skew = (s1 | s2) ? (0x10000 | (s1 << 8) | s2) : 0;
+    }
     if (const char* e = getenv("SPECINV_TD_SKEW")) {
       const int v = atoi(e);
       if (v == 0 || (td && !semi && (nchunks & 1) == 0 && (n_waves & 1) == 0 && pl.Tn() / nchunks - v >= 8)) skew = v;
@@ -552,8 +568,30 @@ struct FastState<float> {
     const size_t lds_used = G::lds_bytes(wgw);
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
     fast::FastArgs args = a;
+#if SPECINV_K4_STAMPS      // diagnostic build (-DSPECINV_K4_STAMPS=1): the 20th launch's waves to $SPECINV_K4_STAMP_DUMP, tools/td_waves.py format
+    static unsigned long long* d_k4 = nullptr;
+    static int k4_launches = 0;
+    if (!d_k4) SI_HIP(hipMalloc(&d_k4, (size_t)n_waves * 4 * sizeof(unsigned long long)));
+    args.stamps = d_k4;
+#endif
     void* kargs[] = {&args};
     SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds_used, pl.stream));
+#if SPECINV_K4_STAMPS
+    if (++k4_launches == 20) {
+      if (const char* dump = getenv("SPECINV_K4_STAMP_DUMP")) {
+        std::vector<unsigned long long> h((size_t)n_waves * 4);
+        SI_HIP(hipMemcpy(h.data(), d_k4, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int wv = 0; wv < n_waves; ++wv) t0 = std::min(t0, h[4 * (size_t)wv + 1]);
+        if (FILE* f = fopen(dump, "w")) {
+          for (int wv = 0; wv < n_waves; ++wv)
+            fprintf(f, "40 %d %u %u %llu %llu %llu\n", wv, (unsigned)(h[4 * (size_t)wv] >> 32), (unsigned)h[4 * (size_t)wv],
+                    h[4 * (size_t)wv + 1] - t0, h[4 * (size_t)wv + 2] - t0, h[4 * (size_t)wv + 3]);
+          fclose(f);
+        }
+      }
+    }
+#endif
     return SPECINV_OK;
   }
 

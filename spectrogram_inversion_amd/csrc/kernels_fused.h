@@ -2,6 +2,10 @@
 #pragma once
 #include "fast_core.h"
 
+#ifndef SPECINV_K4_STAMPS
+#define SPECINV_K4_STAMPS 0
+#endif
+
 namespace specinv {
 namespace SI_FAST_NS {
 
@@ -26,10 +30,22 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
 
   const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wib);   // (scalar: the frame loop and its padding tests branch on the scalar unit; left to the compiler the work-group size may arrive in a vector register and make all of it per-lane)
   if (w >= a.n_waves) return;
+#if SPECINV_K4_STAMPS
+  const unsigned long long k4_begin = __builtin_amdgcn_s_memtime();
+#endif
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
-  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  // Even chunks: wave w walks chunk w mod nchunks of item w / nchunks.  With three waves per SIMD (12-wave workgroups, one per
+  // CU) the hardware slot of a wave is its index in the workgroup / 4, and the arbiter serves the oldest wave first: at BASELINE
+  // C4 the slot-0 waves finished after 193 k ticks, slot 1 after 226 k, slot 2 after 271 k (1024 each).  The plan then skews the
+  // chunks in threes (chunk_begin) and the three waves of a SIMD walk one triple: the oldest the longest.
+  int b = w / a.nchunks, c = w - b * a.nchunks;
+  if (a.skew >= 0x10000) {
+    const int cg = 3 * ((int)blockIdx.x * 4 + (wib & 3)) + (wib >> 2);
+    b = cg / a.nchunks;
+    c = cg - b * a.nchunks;
+  }
   const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew);
   const int t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
   const int t_start = t_begin;   // no halo: the previous chunk's share of the first three hop-blocks comes via xtail
@@ -317,6 +333,16 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
       a.partials[2 * (long long)w + 1] = o;
     }
   }
+#if SPECINV_K4_STAMPS   // diagnostic build: where and when the wave ran (tools/td_waves.py reads the dump)
+  if (lane == 0 && a.stamps != nullptr) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+    a.stamps[4 * (long long)w] = ((unsigned long long)xcc << 32) | hw;
+    a.stamps[4 * (long long)w + 1] = k4_begin;
+    a.stamps[4 * (long long)w + 2] = __builtin_amdgcn_s_memtime();
+    a.stamps[4 * (long long)w + 3] = (unsigned long long)(t_end - t_begin);
+  }
+#endif
 }
 
 template <int R, int OV, int MODE, bool EVAL>

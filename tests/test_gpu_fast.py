@@ -442,6 +442,7 @@ def test_tuned_copy_equals_template(monkeypatch, n_fft, batch, frames, method):
     mag = torch.from_numpy(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32)).to(DEV)
     w = torch.from_numpy(hann(n_fft))
     out = []
+    monkeypatch.setenv("SPECINV_K4_SKEW", "0,0")   # (the copy's chunk triples at the C4 shape are not in the template: even chunks for both)
     for template in ("0", "1"):
         monkeypatch.setenv("SPECINV_FUSED_TEMPLATE", template)
         p = Plan(args_helper(mag, hop_length=hop, window=w), batch, frames, torch.float32, DEV)
@@ -674,3 +675,34 @@ def test_skewed_chunks_against_even_chunks_and_oracle(monkeypatch, n_fft, hop, f
     assert rel_l2(out[0][0], out[1][0]) < 2e-5
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-5)
     assert not np.array_equal(out[0][0], out[1][0])          # (the seams did move: the switch is live)
+
+
+@pytest.mark.parametrize("method", ["admm", "gla"])
+def test_chunk_triples_of_the_three_wave_kernel(monkeypatch, method):
+    """BASELINE C4's launch shape (3072 waves of k_fused4<8>: three per SIMD) walks chunk triples of unequal length - the oldest
+    wave of a SIMD the longest (FastState::begin_t, kernels_fused.h).  Against even chunks: the same iterates up to the order of
+    the seam sums, after a few iterations (ADMM is chaotic beyond that)."""
+    n_fft, hop, frames, batch = 1024, 256, 2048, 32
+    rng = np.random.default_rng(44)
+    mag = T(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32))
+    out = []
+    for env in ("0,0", None):
+        if env is None:
+            monkeypatch.delenv("SPECINV_K4_SKEW", raising=False)
+        else:
+            monkeypatch.setenv("SPECINV_K4_SKEW", env)
+        plan = make_plan(n_fft, hop, frames, batch)
+        if method == "admm":
+            plan.admm_init(None, mag, 0.1)
+        else:
+            plan.keep_state(True)
+            plan.gla_init(None, mag, 0.3)
+        geo = plan.launch_geometry
+        assert geo["kernel"] == "k_fused4" and geo["waves"] == 3072 and geo["waves_per_workgroup"] == 12, geo
+        sums = plan.iterate(3, eval_last=True)
+        out.append((N(plan.wave()), np.array(sums)))
+        del plan
+    assert np.isfinite(out[0][0]).all()
+    assert rel_l2(out[0][0], out[1][0]) < 2e-5, rel_l2(out[0][0], out[1][0])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-5)
+    assert not np.array_equal(out[0][0], out[1][0])          # (the triples are live)
