@@ -157,6 +157,10 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(target + ".tmp", target)
+    if key != "default":
+        # a tuning variant's objects are not kept (12 MB each): the whole tree, csrc/build included, travels to the GPU box
+        import shutil
+        shutil.rmtree(objdir, ignore_errors=True)
     return target
 
 
