@@ -296,13 +296,15 @@ struct FastState<float> {
     // Skewed chunks.  Two waves share a SIMD and the arbiter serves the OLDER one first whenever both have an instruction ready:
     // at BASELINE C2 the wave in hardware slot 0 ran 0.132 frames per kilotick against its neighbour's 0.077 and finished after
     // 69 % of the launch (237 k against 337 k ticks on every one of the 1024 SIMDs, tools/td_waves.py); the neighbour ran the last
-    // third alone at 0.143 - a SIMD with two waves does 0.209.  Chunks of 42 and 22 frames instead of 32 and 32 let both finish
-    // together (measured: 0.172-0.176 -> 0.166 ms per late launch; 8 / 12 / 14 frames of skew 0.168 / 0.169 / 0.172).  Only for
+    // third alone at 0.143 - a SIMD with two waves does 0.209.  Chunks of 40 and 24 frames instead of 32 and 32 let both finish
+    // nearly together (late launch 0.172-0.176 -> 0.166-0.168 ms at 8 ... 10 frames of skew, 0.169 / 0.172 at 12 / 14; the
+    // evaluating launches and the initial ISTFT like less of it: whole C2 step 20.54 / 20.18 / 20.12 / 20.14 / 20.41 ms at
+    // 0 / 6 / 8 / 10 / 12, tools/log/r03_skewstep.sh).  Only for
     // the launch shape this was measured on - the signal-form kernel at two waves per SIMD with exactly as many waves as the
     // chip has slots for them (BASELINE C2 per GPU: 2048).  SPECINV_TD_SKEW overrides (experiments; 0 switches it off).
     // Also tried: s_setprio by frame parity or by time slice so that the two waves take turns (-2...3 %, no better with the skew).
     skew = 0;
-    if (td && !semi && RR == 16 && OV == 4 && n_waves == 2048 && (nchunks & 1) == 0 && pl.Tn() / nchunks >= 24) skew = 10;
+    if (td && !semi && RR == 16 && OV == 4 && n_waves == 2048 && (nchunks & 1) == 0 && pl.Tn() / nchunks >= 24) skew = 8;
     // ... and the spectral-state kernel at three waves per SIMD (12-wave workgroups, the hardware slot is the wave's index in the
     // workgroup / 4, kernels_fused.h): chunk triples, the oldest wave the longest.  BASELINE C4's shard: 3072 waves.
     if (!td && !semi && RR == 8 && OV == 4 && !use_template && fused_wgw() == 12 && n_waves == 3072 && nchunks % 3 == 0 &&
