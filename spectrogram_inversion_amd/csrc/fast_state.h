@@ -305,14 +305,15 @@ struct FastState<float> {
     // Also tried: s_setprio by frame parity or by time slice so that the two waves take turns (-2...3 %, no better with the skew).
     skew = 0;
     if (td && !semi && RR == 16 && OV == 4 && n_waves == 2048 && (nchunks & 1) == 0 && pl.Tn() / nchunks >= 24) skew = 8;
-    // ... and the spectral-state kernel at three waves per SIMD (12-wave workgroups, the hardware slot is the wave's index in the
-    // workgroup / 4, kernels_fused.h): chunk triples, the oldest wave the longest.  BASELINE C4's shard: 3072 waves.
-    if (!td && !semi && RR == 8 && OV == 4 && !use_template && fused_wgw() == 12 && n_waves == 3072 && nchunks % 3 == 0 &&
+    // ... and the n_fft 1024 kernels (spectral state or signal form) at three waves per SIMD (12-wave workgroups, the hardware slot
+    // is the wave's index in the workgroup / 4, kernels_fused.h): chunk triples, the oldest wave the longest.  BASELINE C4's
+    // shard: 3072 waves.
+    if (!semi && RR == 8 && OV == 4 && !use_template && fused_wgw() == 12 && n_waves == 3072 && nchunks % 3 == 0 &&
         pl.Tn() / nchunks >= 16)
       skew = 0x10000 | (SPECINV_K4_SKEW1 << 8) | SPECINV_K4_SKEW2;
     if (const char* e = getenv("SPECINV_K4_SKEW")) {          // "s1,s2" (experiments; "0,0" switches it off)
       int s1 = 0, s2 = 0;
-      if (sscanf(e, "%d,%d", &s1, &s2) == 2 && !td && !semi && fused_wgw() == 12 && nchunks % 3 == 0 && n_waves % 12 == 0 && s1 >= 0 && s2 >= 0 &&
+      if (sscanf(e, "%d,%d", &s1, &s2) == 2 && !semi && fused_wgw() == 12 && nchunks % 3 == 0 && n_waves % 12 == 0 && s1 >= 0 && s2 >= 0 &&
           s1 < 200 && s2 < 200 && pl.Tn() / nchunks - s2 >= 8 && pl.Tn() / nchunks + s2 - s1 >= 8)
         skew = (s1 | s2) ? (0x10000 | (s1 << 8) | s2) : 0;
     }

@@ -97,7 +97,12 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   // (Drawing the chunk by the slot actually occupied, with two atomic counters, balanced the waves to 4 % - and cost more in
   // 1024 same-address atomics per counter than it won.  A launch placed differently is merely less balanced.)
   int b = w / a.nchunks, c = w - b * a.nchunks;
-  if (a.skew != 0) {
+  if (a.skew >= 0x10000) {       // three waves per SIMD, 12-wave workgroups: the chunk triples of k_fused4 (kernels_fused.h)
+    const int cg = 3 * ((int)blockIdx.x * 4 + (wib & 3)) + (wib >> 2);
+    b = cg / a.nchunks;
+    c = cg - b * a.nchunks;
+    w = cg;
+  } else if (a.skew != 0) {
     const int half = a.n_waves >> 1, second = w >= half ? 1 : 0, wl = w - second * half, pairs = a.nchunks >> 1;
     b = wl / pairs;
     c = 2 * (wl - b * pairs) + second;

@@ -677,7 +677,7 @@ def test_skewed_chunks_against_even_chunks_and_oracle(monkeypatch, n_fft, hop, f
     assert not np.array_equal(out[0][0], out[1][0])          # (the seams did move: the switch is live)
 
 
-@pytest.mark.parametrize("method", ["admm", "gla"])
+@pytest.mark.parametrize("method", ["admm", "gla", "gla_td"])
 def test_chunk_triples_of_the_three_wave_kernel(monkeypatch, method):
     """BASELINE C4's launch shape (3072 waves of k_fused4<8>: three per SIMD) walks chunk triples of unequal length - the oldest
     wave of a SIMD the longest (FastState::begin_t, kernels_fused.h).  Against even chunks: the same iterates up to the order of
@@ -695,10 +695,11 @@ def test_chunk_triples_of_the_three_wave_kernel(monkeypatch, method):
         if method == "admm":
             plan.admm_init(None, mag, 0.1)
         else:
-            plan.keep_state(True)
+            plan.keep_state(method == "gla")                    # (gla_td: the signal-form kernel, same triples)
             plan.gla_init(None, mag, 0.3)
         geo = plan.launch_geometry
-        assert geo["kernel"] == "k_fused4" and geo["waves"] == 3072 and geo["waves_per_workgroup"] == 12, geo
+        assert geo["kernel"] == ("k_fused4_td" if method == "gla_td" else "k_fused4"), geo
+        assert geo["waves"] == 3072 and geo["waves_per_workgroup"] == 12, geo
         sums = plan.iterate(3, eval_last=True)
         out.append((N(plan.wave()), np.array(sums)))
         del plan
