@@ -598,7 +598,12 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
-  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  int b = w / a.nchunks, c = w - b * a.nchunks;
+  if (a.skew != 0 && a.skew < 0x10000) {         // skewed chunk pairs: the first half of the waves the long ones (fused_td_body)
+    const int half = a.n_waves >> 1, second = w >= half ? 1 : 0, wl = w - second * half, pairs = a.nchunks >> 1;
+    b = wl / pairs;
+    c = 2 * (wl - b * pairs) + second;
+  }
   const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew);
   const int t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
   const int t_start = max(0, t_begin - NB);      // one-off kernel: recompute the NB-frame halo, write whole blocks
