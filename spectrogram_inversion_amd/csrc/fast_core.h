@@ -1151,6 +1151,15 @@ template <int R, bool EARLY, bool EVAL>
 __global__ void k_fused4_td(FastArgs a);
 template <int R, int OV, bool EARLY, bool EVAL>
 __global__ void k_fused_td(FastArgs a);
+#ifndef SPECINV_EVAL_PIECES          // k_eval_td at BASELINE C2 (rocprofv3): 1 piece / 2 waves per SIMD 0.133 ms, 2 / 3 0.122, 4 / 4 with LDS
+#define SPECINV_EVAL_PIECES 2        // twiddles 0.141 (0.129 at 1 piece) - the fused evaluating variant spends 0.16 on the same work
+#endif
+#ifndef SPECINV_EVAL_WAVES
+#define SPECINV_EVAL_WAVES 3
+#endif
+constexpr int kEvalPieces = SPECINV_EVAL_PIECES;     // pieces of a chunk per wave of k_eval_td (kernels_fast_td.h: kEvalSub)
+template <int R, int OV>
+__global__ __launch_bounds__(256, SPECINV_EVAL_WAVES) void k_eval_td(FastArgs a);   // (bounds on the declaration too: see rtisi_fast_args.h)
 template <int R>
 __global__ void k_fast_stft(FastXformArgs a);
 template <int R>

@@ -840,7 +840,8 @@ struct FastState<float> {
   template <typename P>
   int iterate(P& pl, int n_iter, bool eval_last) {
     if (semi) return iterate_semi(pl, n_iter, eval_last);
-    SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2, 3 * 1024) * sizeof(double)));
+    SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves * 2 * fast::kEvalPieces, 3 * 1024) * sizeof(double)));
+    int eval_pieces = 1;
     for (int i = 0; i < n_iter; ++i) {
       const bool ev = eval_last && i == n_iter - 1;
       const int nx = cur ^ 1;
@@ -884,6 +885,22 @@ struct FastState<float> {
         a.P_in = Pb[0].template as<v4f>();
         a.Pmid_in = Pmid[0].template as<v2f>();
         a.tds = (float)tds;
+        // an evaluating iteration on the headline shapes: the plain kernel, then the evaluation of x_t as a kernel of its own
+        // (kernels_fast_td.h: k_eval_td; SPECINV_EVAL_KERNEL=0: the fused evaluating variant)
+        const char* eval_env = ev ? getenv("SPECINV_EVAL_KERNEL") : nullptr;
+        const bool eval_kernel = !(eval_env && eval_env[0] == '0');
+        if (ev && eval_kernel && !exact && OV == 4 && (R == 8 || R == 16)) {
+          SI_TRY(launch_td(pl, a, early, false));
+          const void* fn = R == 16 ? (const void*)fast::k_eval_td<16, 4> : (const void*)fast::k_eval_td<8, 4>;
+          const size_t lds_used = R == 16 ? fast::Geo<16>::lds_bytes(4) : fast::Geo<8>::lds_bytes(4);
+          SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
+          fast::FastArgs args = a;
+          void* kargs[] = {&args};
+          SI_HIP(hipLaunchKernel(fn, dim3((n_waves * fast::kEvalPieces + 3) / 4), dim3(256), kargs, lds_used, pl.stream));
+          eval_pieces = fast::kEvalPieces;
+          cur = nx;
+          continue;
+        }
         SI_TRY(launch_td(pl, a, early, ev));
         cur = nx;
         continue;
@@ -895,7 +912,7 @@ struct FastState<float> {
       SI_TRY(rc);
       cur = nx;
     }
-    n_partials = n_waves;
+    n_partials = n_waves * eval_pieces;
     return SPECINV_OK;
   }
 

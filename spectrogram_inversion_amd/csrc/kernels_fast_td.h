@@ -440,5 +440,118 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : (SPECINV_R8_W3 && R == 8) ? 3 : 
   fused_td_body<R, OV, EARLY, EVAL>(a);
 }
 
+// ---- the evaluation of x_t as a kernel of its own ----------------------------------------------------------------------------
+// |STFT(x_t)| against the target (methods.py:180-182, 242) does not depend on iteration t's update, which reads z_t.  Inside
+// the iteration kernel the second transform runs in a 256-register wave, two to a SIMD, its frame loaded block by block through
+// the seam logic four times over: + 0.16 ms per launch at BASELINE C2.  On its own - launched behind the plain iteration kernel
+// on the same stream - it is a forward transform and a sum with the sample window carried from frame to frame like the
+// iteration's: 0.12 ms.  A wave walks one of kEvalSub pieces of a chunk of the iteration's chunking (whose seams the block
+// loader resolves).  Same operations in the same order as the EVAL block of fused_td_body: the same sums, bit for bit.
+#ifndef SPECINV_EVAL_TWREGS
+#define SPECINV_EVAL_TWREGS 1
+#endif
+constexpr int kEvalSub = kEvalPieces;
+template <int R, int OV>
+__global__ __launch_bounds__(256, SPECINV_EVAL_WAVES) void k_eval_td(FastArgs a) {
+  using G = Geo<R>;
+  using O = Ovl<R, OV>;
+  constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
+  for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
+    const int k1 = i / 64 + 1, l = i & 63;
+    lds_tw1[i] = unit(2.0f * (float)((l * k1) % M) / (float)M);
+  }
+  __syncthreads();
+  const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wib);
+  if (w >= a.n_waves * kEvalSub) return;
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  const int cw = w / kEvalSub, sub = w - cw * kEvalSub;
+  const int b = cw / a.nchunks, c = cw - b * a.nchunks;
+  const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew), t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
+  const int s_begin = t_begin + (sub * (t_end - t_begin)) / kEvalSub, s_end = t_begin + ((sub + 1) * (t_end - t_begin)) / kEvalSub;
+  const float* xrow = a.x2_in + (long long)b * a.L;
+  const float* tailrow = a.xtail_in + (long long)b * a.nchunks * NB * HOP;
+  const float half_scale = 0.5f * a.fwd_scale;
+#if SPECINV_EVAL_TWREGS
+  TwRegs<R> twr;
+#pragma unroll
+  for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = lds_tw1[(k1 - 1) * 64 + lane];
+#else
+  const TwLds twr{lds_tw1, lane};
+#endif
+  double sd = 0.0, so = 0.0;
+  v2f xq[NB][QU], xn[QU];
+#pragma unroll
+  for (int q = 0; q < NB; ++q)
+    td_load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, s_begin + q, lane, a.pad_mode, xq[q]);
+  td_load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, s_begin + NB, lane, a.pad_mode, xn);
+  for (int t = s_begin; t < s_end; ++t) {
+    asm volatile("" ::: "memory");
+    v2f wn = k.wn;
+    asm volatile("" : "+v"(wn));
+    const long long fi = (long long)b * a.T + t;
+    v4f mm[H / 2];
+    float mmid = 0.0f;
+    {
+      const v4f* min_ = a.m_pairs + fi * (H / 2 * 64);
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) mm[j] = ld_stream(&min_[j * 64u + ulane]);
+      if (lane == 0) mmid = a.m_mid[fi];
+    }
+    v2f z[R];
+#pragma unroll
+    for (int i = 0; i < QU; ++i) {
+#pragma unroll
+      for (int q = 0; q < NB; ++q) z[q * QU + i] = xq[q][i] * lds_win[64 * (q * QU + i) + lane];
+      z[NB * QU + i] = xn[i] * lds_win[64 * (NB * QU + i) + lane];
+#pragma unroll
+      for (int q = 0; q + 1 < NB; ++q) xq[q][i] = xq[q + 1][i];
+      xq[NB - 1][i] = xn[i];
+    }
+    if (t + 1 < s_end) td_load_block<R, OV>(xrow, tailrow, a.L, a.T, c, t_begin, t_end, t + OV, lane, a.pad_mode, xn);
+    fft_forward_t<R>(z, k, twr, tr);
+    v2f rc[H];
+#pragma unroll
+    for (int m = H; m < R; ++m) {
+      const v2f got = shfl2(z[m], k.partner);
+      const v2f own = z[(m + 1) % R];
+      rc[m - H] = v2f{lane == 0 ? own.x : got.x, lane == 0 ? own.y : got.y};
+    }
+    float fd = 0.0f, fo = 0.0f;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = pair_twiddle<R>(wn, j);
+      v2f xk, xm;
+      td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, xk, xm);
+      const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
+      const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+      const float ok = fast_abs(xk), om = fast_abs(xm);
+      const float dk = ok - mk, dm = om - mq;
+      fd = fmaf(dk, dk, fmaf(dm, dm, fd));
+      fo = fmaf(ok, ok, fmaf(om, om, fo));
+    }
+    if (lane == 0) {
+      const float o = fast_abs(z[H] * v2f{a.fwd_scale, -a.fwd_scale});
+      const float d = o - mmid;
+      fd = fmaf(d, d, fd);
+      fo = fmaf(o, o, fo);
+    }
+    sd += (double)fd;
+    so += (double)fo;
+  }
+  const double d = wave_sum(sd), o = wave_sum(so);
+  if (lane == 0) {
+    a.partials[2 * (long long)w] = d;
+    a.partials[2 * (long long)w + 1] = o;
+  }
+}
+
 }  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
 }  // namespace specinv

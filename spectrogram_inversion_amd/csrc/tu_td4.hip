@@ -14,6 +14,8 @@ template __global__ void k_fused4_td<16, false, false>(FastArgs);
 template __global__ void k_fused4_td<16, false, true>(FastArgs);
 template __global__ void k_fused4_td<16, true, false>(FastArgs);
 template __global__ void k_fused4_td<16, true, true>(FastArgs);
+template __global__ void k_eval_td<8, 4>(FastArgs);
+template __global__ void k_eval_td<16, 4>(FastArgs);
 
 }  // namespace fast
 }  // namespace specinv

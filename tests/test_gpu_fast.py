@@ -707,3 +707,28 @@ def test_chunk_triples_of_the_three_wave_kernel(monkeypatch, method):
     assert rel_l2(out[0][0], out[1][0]) < 2e-5, rel_l2(out[0][0], out[1][0])
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-5)
     assert not np.array_equal(out[0][0], out[1][0])          # (the triples are live)
+
+
+@pytest.mark.parametrize("n_fft,batch,frames", [(2048, 3, 70), (1024, 4, 90), (2048, 64, 1024)])
+def test_evaluation_kernel_equals_the_fused_evaluating_variant(monkeypatch, n_fft, batch, frames):
+    """An evaluating iteration on the headline shapes runs the plain kernel and then `k_eval_td` (x_t's transform and the metric
+    sums as a kernel of its own); `SPECINV_EVAL_KERNEL=0` runs the fused evaluating variant `k_fused4_td<R, *, true>` instead
+    (what the exact-projection build always does).  Same operations in the same order: the same sums and the same iterates bit
+    for bit - early (+c0) and late launches, small launches and the C2 geometry."""
+    hop = n_fft // 4
+    rng = np.random.default_rng(n_fft + batch)
+    mag = T(rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32))
+    out = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("SPECINV_EVAL_KERNEL", env)
+        plan = make_plan(n_fft, hop, frames, batch)
+        plan.gla_init(None, mag, 0.3)
+        assert plan.launch_geometry["kernel"] == "k_fused4_td"
+        sums = [plan.iterate(1, eval_last=True), plan.iterate(3, eval_last=True)]      # early launches
+        plan.iterate(14)
+        sums += [plan.iterate(1, eval_last=True), plan.iterate(2, eval_last=True)]     # late launches
+        out.append((plan.wave(), np.array(sums)))
+        del plan
+    assert torch.equal(out[0][0], out[1][0])
+    # (per-wave partial sums added in wave order: the evaluation kernel has more waves, the totals agree to rounding)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12)
