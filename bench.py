@@ -272,8 +272,8 @@ def main():
         def iteration_kernel():
             g = plan.launch_geometry
             return g, {"k_fused4": f"specinv::fast::k_fused4<{n_fft // 128}, {'GLA' if method == 'griffin_lim' else 'ADMM'}>",
-                       "k_fused4_td": f"specinv::fast::k_fused4_td<{n_fft // 128}> (momentum carried as a signal; late, early "
-                                      f"(+c0) and evaluating launches averaged)",
+                       "k_fused4_td": f"specinv::fast::k_fused4_td<{n_fft // 128}> (momentum carried as a signal; late and early "
+                                      f"(+c0) launches and the evaluation kernel k_eval_td averaged)",
                        "k_fused": f"specinv::fast::k_fused<{n_fft // 128}, {n_fft // hop}>", "k_semi": "k_semi+k_ola_f4",
                        "k_fused_td": f"specinv::fast::k_fused_td<{n_fft // 128}, {n_fft // hop}>", "k_hop": "k_hop",
                        "k_hop_td": "k_hop_td", "k_iter_pair": "k_iter_pair+k_ola"}[g["kernel"]]
