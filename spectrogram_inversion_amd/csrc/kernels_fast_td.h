@@ -118,6 +118,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   const bool write_x = a.x2_out != nullptr;
   float* xorow = a.x2_out + (long long)b * a.L;
   const float half_scale = 0.5f * a.fwd_scale;
+  const float tds_raw = a.tds / half_scale;
   const float nlr = -a.coef;
 
   v2f acc[NB * QU];
@@ -159,7 +160,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 #endif
   // the real-FFT twiddles of the pairs, W_N^(lane + 64 j): the plain launches have the registers to keep all of them (two waves
   // per SIMD leave 256 each), the others rebuild them from W_N^lane every frame
-  constexpr bool WKREG = !EARLY && !EVAL && SPECINV_TD_MINWAVES == 2 && SPECINV_TD_WKREG;
+  constexpr bool WKREG = !EVAL && SPECINV_TD_MINWAVES == 2 && SPECINV_TD_WKREG;
   v2f wkr[WKREG ? H : 1];
   if (WKREG) {
 #pragma unroll
@@ -275,14 +276,21 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
     for (int j = 0; j < H; ++j) {
       const v2f wk = WKREG ? wkr[WKREG ? j : 0] : pair_twiddle<R>(wn, j);
       v2f sk, sm;
-      if (EARLY || SPECINV_IEEE || !SPECINV_RSQ) {
+      if (SPECINV_IEEE || !SPECINV_RSQ) {
         td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
+        if (EARLY) {
+          sk = v2f{fmaf(a.tds, pp[j].x, sk.x), fmaf(a.tds, pp[j].y, sk.y)};
+          sm = v2f{fmaf(a.tds, pp[j].z, sm.x), fmaf(a.tds, pp[j].w, sm.y)};
+        }
       } else {
-        td_split_raw<R>(z[j], rc[R - 1 - j - H], wk, sk, sm);   // (the late launches: nothing but the projection reads the bins)
-      }
-      if (EARLY) {
-        sk = v2f{fmaf(a.tds, pp[j].x, sk.x), fmaf(a.tds, pp[j].y, sk.y)};
-        sm = v2f{fmaf(a.tds, pp[j].z, sm.x), fmaf(a.tds, pp[j].w, sm.y)};
+        // nothing but the projection reads the bins, and it divides by their magnitude: the 1/2 fwd_scale of the split is left
+        // out (late launches) or moved onto the c0 term's factor (early launches: S / s = raw + (tds / s) c0, one packed
+        // multiply-add per bin)
+        td_split_raw<R>(z[j], rc[R - 1 - j - H], wk, sk, sm);
+        if (EARLY) {
+          sk = __builtin_elementwise_fma(v2f{pp[j].x, pp[j].y}, v2f{tds_raw, tds_raw}, sk);
+          sm = __builtin_elementwise_fma(v2f{pp[j].z, pp[j].w}, v2f{tds_raw, tds_raw}, sm);
+        }
       }
       const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
       const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
