@@ -1211,12 +1211,12 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     SI_HIP(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     static int calls = 0;
     if (++calls == 5) {
-      const char* names[12] = {"tables", "twiddle regs", "analysis (2 frames)", "barrier", "forward GEMM", "barrier",
-                               "reduce+log1p+dM", "backward GEMM", "barrier", "synthesis (2 frames)", "barrier", "overlap-add"};
+      const char* names[12] = {"tables + twiddle regs", "analysis (2 frames)", "  wait", "forward GEMM", "  wait", "reduce+log1p+dM",
+                               "backward GEMM", "  wait", "synthesis (2 frames)", "  wait", "frames to LDS", "overlap-add"};
       double tot[13] = {0};
       for (int64_t t = 0; t < n_tiles; ++t)
         for (int i = 1; i <= 12; ++i) tot[i] += (double)(h[t * 16 + i] - h[t * 16 + i - 1]);
-      fprintf(stderr, "k_objective_logmel phase cycles (s_memtime, 100 MHz ticks x clock ratio; mean over %lld tiles, wave 0):\n", (long long)n_tiles);
+      fprintf(stderr, "k_objective_logmel phase cycles (s_memtime; mean over %lld tiles, wave %d of the workgroup; 'wait' = at the barrier):\n", (long long)n_tiles, SPECINV_OBJ_STAMP_WAVE);
       for (int i = 1; i <= 11; ++i) fprintf(stderr, "  %-22s %9.0f\n", names[i - 1], tot[i] / n_tiles);
       fprintf(stderr, "  %-22s %9.0f\n", "write-out", tot[12] / n_tiles);
       double all = 0;

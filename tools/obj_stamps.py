@@ -4,7 +4,7 @@ wave 0 of every workgroup; the fifth evaluation prints the table to stderr)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "spectrogram_inversion_amd", "variants", "libspecinv_stamps.so")
+lib = os.environ.get("SPECINV_STAMP_LIB") or os.path.join(ROOT, "spectrogram_inversion_amd", "variants", "libspecinv_stamps.so")
 if not os.path.exists(lib):
     raise SystemExit(f"build it first: build_lib(extra_flags=['-DSPECINV_OBJ_STAMPS=1'], out='{lib}')")
 os.environ["SPECINV_LIB"] = lib
