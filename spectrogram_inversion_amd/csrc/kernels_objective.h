@@ -34,9 +34,6 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 }
 
 #if SPECINV_OBJ_STAMPS
-#ifndef SPECINV_OBJ_STAMP_WAVE      // which wave of the workgroup stamps (0 .. 7)
-#define SPECINV_OBJ_STAMP_WAVE 0
-#endif
 #define OBJ_STAMP(i) do { if (threadIdx.x == 64 * SPECINV_OBJ_STAMP_WAVE) a.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define OBJ_STAMP(i) do { } while (0)

@@ -10,8 +10,11 @@ namespace fast {
 
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
-#ifndef SPECINV_OBJ_STAMPS        // diagnostic build: s_memtime at the phase boundaries of wave 0 of every workgroup
+#ifndef SPECINV_OBJ_STAMPS        // diagnostic build: s_memtime at the phase boundaries of one wave of every workgroup
 #define SPECINV_OBJ_STAMPS 0      // (tools/obj_stamps.py; the shipped kernel executes no stamp)
+#endif
+#ifndef SPECINV_OBJ_STAMP_WAVE    // ... which wave (0 .. 7; 0 - 3 are the older waves of their SIMDs, 4 - 7 the younger ones)
+#define SPECINV_OBJ_STAMP_WAVE 0
 #endif
 
 constexpr int kObjWaves = 8;      // waves per workgroup
