@@ -90,6 +90,9 @@ struct FastState {
     default: { constexpr int RR = 32; __VA_ARGS__; } break; \
   }
 
+#ifndef SPECINV_TD_SKEW_DEFAULT
+#define SPECINV_TD_SKEW_DEFAULT 8
+#endif
 #ifndef SPECINV_K4_SKEW1            // begin shifts of the second / third chunk of a triple (frames) at BASELINE C4's launch shape
 #define SPECINV_K4_SKEW1 4          // (C4 step, two runs each: "0,0" 30.38 / 30.38 ms, "3,4" 30.29 / 30.26, "4,6" 29.93 / 29.97, "5,8" 30.49 / 30.20,
 #define SPECINV_K4_SKEW2 6          //  "6,9" 30.27 / 30.21, "6,11" 30.78 / 30.68, "8,12" 30.40 / 30.34: the kernel sits on the memory system, the balance buys 1.4 %)
@@ -299,12 +302,13 @@ struct FastState<float> {
     // third alone at 0.143 - a SIMD with two waves does 0.209.  Chunks of 40 and 24 frames instead of 32 and 32 let both finish
     // nearly together (late launch 0.172-0.176 -> 0.166-0.168 ms at 8 ... 10 frames of skew, 0.169 / 0.172 at 12 / 14; the
     // evaluating launches and the initial ISTFT like less of it: whole C2 step 20.54 / 20.18 / 20.12 / 20.14 / 20.41 ms at
-    // 0 / 6 / 8 / 10 / 12, tools/log/r03_skewstep.sh).  Only for
+    // 0 / 6 / 8 / 10 / 12, tools/log/r03_skewstep.sh; the other overlaps of n_fft 2048 gain 3.5 % (hop 256) and 2 % (hop 1024)
+    // at the same 8, tools/log/r03_skew_ov.sh).  Only for
     // the launch shape this was measured on - the signal-form kernel at two waves per SIMD with exactly as many waves as the
     // chip has slots for them (BASELINE C2 per GPU: 2048).  SPECINV_TD_SKEW overrides (experiments; 0 switches it off).
     // Also tried: s_setprio by frame parity or by time slice so that the two waves take turns (-2...3 %, no better with the skew).
     skew = 0;
-    if (td && !semi && RR == 16 && OV == 4 && n_waves == 2048 && (nchunks & 1) == 0 && pl.Tn() / nchunks >= 24) skew = 8;
+    if (td && !semi && RR == 16 && n_waves == 2048 && (nchunks & 1) == 0 && pl.Tn() / nchunks >= 24) skew = SPECINV_TD_SKEW_DEFAULT;
     // ... and the n_fft 1024 kernels (spectral state or signal form) at three waves per SIMD (12-wave workgroups, the hardware slot
     // is the wave's index in the workgroup / 4, kernels_fused.h): chunk triples, the oldest wave the longest.  BASELINE C4's
     // shard: 3072 waves.

@@ -647,7 +647,8 @@ def test_signal_form_state_does_not_leak_between_runs(n_fft, hop, frames, batch)
 
 
 @pytest.mark.parametrize("n_fft,hop,frames,batch,chunk,skew", [(2048, 512, 128, 2, 16, 3), (2048, 512, 96, 3, 24, 5),
-                                                                (1024, 256, 200, 2, 25, 4)])
+                                                                (1024, 256, 200, 2, 25, 4), (2048, 256, 192, 2, 24, 6),
+                                                                (2048, 1024, 120, 3, 20, 5)])
 def test_skewed_chunks_against_even_chunks_and_oracle(monkeypatch, n_fft, hop, frames, batch, chunk, skew):
     """`chunk_begin`'s skew (every odd chunk cedes frames to the even chunk before it, the first half of the waves walk the even
     chunks: what BASELINE C2's launch shape runs with, FastState::begin_t) only moves the seams: the iterates equal those of the
