@@ -91,7 +91,7 @@ struct FastState {
   }
 
 #ifndef SPECINV_TD_SKEW_DEFAULT
-#define SPECINV_TD_SKEW_DEFAULT 8
+#define SPECINV_TD_SKEW_DEFAULT 10
 #endif
 #ifndef SPECINV_K4_SKEW1            // begin shifts of the second / third chunk of a triple (frames) at BASELINE C4's launch shape
 #define SPECINV_K4_SKEW1 4          // (C4 step, two runs each: "0,0" 30.38 / 30.38 ms, "3,4" 30.29 / 30.26, "4,6" 29.93 / 29.97, "5,8" 30.49 / 30.20,
@@ -538,7 +538,10 @@ struct FastState<float> {
     if (SPECINV_R8_W3 && R == 8 && OV == 4 && !use_template && n_waves >= 3072) return 12;
     // (the signal-form kernel at n_fft 2048 measured 2 % faster with two 4-wave workgroups per CU than with one 8-wave one:
     // C2 25.8 vs 26.3 ms per step on one box, three runs each - the opposite of k_fused4)
-    if (td && R == 16 && OV == 4) return 4;
+    // ... except when the chunks are skewed (begin_t): one 8-wave workgroup per CU makes the hardware slot of a wave its index in
+    // the workgroup / 4, whatever else runs on the chip - the 4-wave form has to infer it from the dispatch order (measured with
+    // the skew: 19.89-20.09 against 20.02-20.16 ms per C2 step, tools/log/r03_wgw8.sh)
+    if (td && R == 16 && OV == 4) return (skew != 0 && skew < 0x10000) ? 8 : 4;
     if ((R == 8 || R == 16) && OV == 4 && !use_template) return n_waves >= 2048 ? SPECINV_WGW : 4;
     return 4;
   }

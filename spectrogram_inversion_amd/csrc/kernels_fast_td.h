@@ -86,7 +86,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   __syncthreads();
 
   int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wib);   // (scalar: the frame loop and its padding tests branch on the scalar unit; left to the compiler the work-group size may arrive in a vector register and make all of it per-lane)
-  if (w >= a.n_waves) return;
+  if (a.skew == 0 && w >= a.n_waves) return;     // (skewed chunks: the test follows the mapping, which permutes inside a workgroup)
   const LaneConst<R> k = lane_consts<R>();
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
@@ -102,12 +102,20 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
     b = cg / a.nchunks;
     c = cg - b * a.nchunks;
     w = cg;
+  } else if (a.skew != 0 && (blockDim.x >> 6) == 8) {
+    // 8-wave workgroups, one per CU: the two waves of a SIMD are waves i and i + 4 of one workgroup, dispatched in that order -
+    // the hardware slot is the wave's index in the workgroup / 4 whatever else runs on the chip
+    const int cg = 2 * ((int)blockIdx.x * 4 + (wib & 3)) + (wib >> 2);
+    b = cg / a.nchunks;
+    c = cg - b * a.nchunks;
+    w = cg;
   } else if (a.skew != 0) {
     const int half = a.n_waves >> 1, second = w >= half ? 1 : 0, wl = w - second * half, pairs = a.nchunks >> 1;
     b = wl / pairs;
     c = 2 * (wl - b * pairs) + second;
     w = b * a.nchunks + c;      // (the index of the chunk walked: partial sums and stamps go by it)
   }
+  if (a.skew != 0 && w >= a.n_waves) return;
   const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew);
   const int t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
   const float* zrow = a.x_in + (long long)b * a.L;

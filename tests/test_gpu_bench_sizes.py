@@ -65,7 +65,7 @@ def test_c2_headline_geometry_vs_oracle_and_float64(kernel):
     p32.gla_init(c0, None, alpha)
     # the geometry of the headline number: 2048 waves of 32 frames, two 4-wave workgroups per CU (one 8-wave one for k_fused4)
     geo = p32.launch_geometry
-    assert geo == {"waves_per_workgroup": 4 if kernel == "k_fused4_td" else 8, "chunks": 32, "waves": 2048, "kernel": kernel}, geo
+    assert geo == {"waves_per_workgroup": 8, "chunks": 32, "waves": 2048, "kernel": kernel}, geo
     # 10 iterations from the same starting spectrum: waveform rel-L2 <= 1e-4 (the north-star bar)
     p32.iterate(9)
     s32_10 = p32.iterate(1, eval_last=True)
@@ -115,7 +115,7 @@ def test_c2_headline_100_iterations_vs_the_reference_run(kernel):
     p.keep_state(kernel == "k_fused4")
     p.gla_init(None, mag, alpha)
     geo = p.launch_geometry
-    assert geo == {"waves_per_workgroup": 4 if kernel == "k_fused4_td" else 8, "chunks": 32, "waves": 2048, "kernel": kernel}, geo
+    assert geo == {"waves_per_workgroup": 8, "chunks": 32, "waves": 2048, "kernel": kernel}, geo
     done, evals = p.run(100, 10, 0.0, "sc")
     assert done == 100 and len(evals) == 10
     got = np.array([[m, l] for _, m, l in evals])

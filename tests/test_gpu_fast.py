@@ -573,7 +573,7 @@ def test_time_domain_momentum_against_spectral_state(n_fft, batch, frames, ov, a
         geo = p.launch_geometry
         assert geo["kernel"] == (("k_fused4" if keep else "k_fused4_td") if tuned else ("k_fused" if keep else "k_fused_td")), geo
         if batch * frames >= 65536:
-            assert (geo["waves_per_workgroup"], geo["waves"]) == (((8 if keep else 4), 2048) if n_fft == 2048 else (12, 3072)), geo
+            assert (geo["waves_per_workgroup"], geo["waves"]) == ((8, 2048) if n_fft == 2048 else (12, 3072)), geo
         sums = [p.iterate(3, eval_last=True)]
         p.iterate(11)
         sums += [p.iterate(1, eval_last=True), p.iterate(1, eval_last=True), p.iterate(1, eval_last=True)]    # 15, 16, 17
