@@ -299,7 +299,7 @@ struct FastState<float> {
     // Skewed chunks.  Two waves share a SIMD and the arbiter serves the OLDER one first whenever both have an instruction ready:
     // at BASELINE C2 the wave in hardware slot 0 ran 0.132 frames per kilotick against its neighbour's 0.077 and finished after
     // 69 % of the launch (237 k against 337 k ticks on every one of the 1024 SIMDs, tools/td_waves.py); the neighbour ran the last
-    // third alone at 0.143 - a SIMD with two waves does 0.209.  Chunks of 40 and 24 frames instead of 32 and 32 let both finish
+    // third alone at 0.143 - a SIMD with two waves does 0.209.  Chunks of 42 and 22 frames instead of 32 and 32 let both finish
     // nearly together (late launch 0.172-0.176 -> 0.166-0.168 ms at 8 ... 10 frames of skew, 0.169 / 0.172 at 12 / 14; the
     // evaluating launches and the initial ISTFT like less of it: whole C2 step 20.54 / 20.18 / 20.12 / 20.14 / 20.41 ms at
     // 0 / 6 / 8 / 10 / 12, tools/log/r03_skewstep.sh; the other overlaps of n_fft 2048 gain 3.5 % (hop 256) and 2 % (hop 1024)

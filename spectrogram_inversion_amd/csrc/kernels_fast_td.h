@@ -91,11 +91,13 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   const int lane = k.lane;
   const unsigned ulane = (unsigned)lane;
   // Even chunks: wave w walks chunk w mod nchunks of item w / nchunks.  Skewed chunks (a launch of exactly two waves per SIMD):
-  // the dispatcher hands every CU its first workgroup before any gets a second, so the first half of the waves sit in hardware
-  // slot 0 of their SIMDs (1024 of 1024 in every dump of tools/td_waves.py) - the older wave, which the arbiter serves first: it
-  // runs 1.7 x as fast as its neighbour while both are there - and take the even (longer) chunks, the second half the odd ones.
-  // (Drawing the chunk by the slot actually occupied, with two atomic counters, balanced the waves to 4 % - and cost more in
-  // 1024 same-address atomics per counter than it won.  A launch placed differently is merely less balanced.)
+  // the older wave of a SIMD, which the arbiter serves first - it runs 1.7 x as fast as its neighbour while both are there -
+  // takes the even (longer) chunk of a pair, the younger the odd one.  In 8-wave workgroups (the headline shape) the role is the
+  // wave's index in the workgroup / 4.  In 4-wave workgroups (the other overlaps) it is inferred from the dispatch order: the
+  // dispatcher hands every CU its first workgroup before any gets a second, so the first half of the waves are the older ones
+  // (1024 of 1024 in every dump of tools/td_waves.py; a launch placed differently is merely less balanced).  (Drawing the chunk
+  // by the slot actually occupied, with two atomic counters, balanced the waves to 4 % - and cost more in 1024 same-address
+  // atomics per counter than it won.)
   int b = w / a.nchunks, c = w - b * a.nchunks;
   if (a.skew >= 0x10000) {       // three waves per SIMD, 12-wave workgroups: the chunk triples of k_fused4 (kernels_fused.h)
     const int cg = 3 * ((int)blockIdx.x * 4 + (wib & 3)) + (wib >> 2);
