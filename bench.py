@@ -16,17 +16,33 @@ Other workloads (`--workload`), same JSON contract:
       closure evaluations each (whole batch = one optimisation problem: replicas only for N > 1)
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8                       # spawns its own 8 ranks (torch.distributed.run) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1 [--workload C4]
 
-Rank 0 prints ONE JSON line (see the driver contract) with `roofline` (dominant-kernel achieved HBM GB/s from HIP
-events on the launch stream), `check` (an independent re-evaluation of the result outside the timed region) and
-`cpu_baseline` (the NumPy oracle timed on the host cores on a bounded sample of the same workload; N=1, rank 0).
+Rank 0 prints ONE JSON line (the driver contract).  Beside the contract's keys:
+  roofline       the dominant kernel against the resource that BINDS it (`bound`): "valu" -> share of the chip's vector issue
+                 slots in use, "hbm" -> HBM bytes the counters saw / launch time / 8 TB/s, "latency" -> (RTISI-LA) vector issue
+                 share, reported with the dependent-step rate.  Launch time: HIP events on the launch stream inside the timed
+                 region.  Counters: rocprofv3 --pmc passes over a child process of THIS run (N = 1; `--no-pmc` or a failed pass
+                 falls back to profiles/traffic.json and says so).  `roofline.hbm` always carries the HBM view (counter
+                 bytes and the bytes the kernel must move), `roofline.reference_bytes_equiv` SURVEY 8d's bytes of the
+                 REFERENCE ALGORITHM over the same launch time (a speed-up over that algorithm: may exceed the peak).
+  value_incl_h2d the same step with the target magnitudes staged from pinned host memory each step (SURVEY 8d "report both")
+  extra.workloads short C4 / C3 / C5 legs run in the same process after the timed region (default C2 run at N = 1 only)
+  cpu_baseline   the NumPy oracle timed on the host cores on a bounded sample of the same workload (N = 1, rank 0)
+  check          an independent re-evaluation of the result outside the timed region
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -45,7 +61,28 @@ WORKLOADS = {
     "C5": ("L_BFGS", 16, 2048, 512, 1024, 20, None),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 N_MELS, SR, LOOK_AHEAD = 80, 22050, 3
+
+# The dominant kernel of each workload at its BASELINE shape, as rocprofv3 names it (substring of Kernel_Name), and what binds it.
+# tools/collect_workload_profiles.py reads the same table.
+DOMINANT = {
+    "C2": ("specinv::fast::k_fused4_td<16, false, false>", "valu"),
+    "C4": ("specinv::fast::k_fused4<8, 1, false>", "hbm"),
+    "C3": ("specinv::fast::k_rtisi_fast<16, 256, 4>", "latency"),
+    "C5": ("specinv::fast::k_objective_logmel<16, 5, false>", "valu"),
+    "C1": ("specinv::fast::k_semi<8", "latency"),
+}
+PMC_PASSES = (
+    ("fetch", ["FETCH_SIZE"]),
+    ("write", ["WRITE_SIZE"]),
+    ("sq", ["SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_ANY",
+            "GRBM_GUI_ACTIVE"]),
+)
+VALU_FORMULA = ("valu_issue_frac = SQ_ACTIVE_INST_VALU * 4 / (GRBM_GUI_ACTIVE / 8 * 1024): SQ_ACTIVE_INST_VALU counts quad-cycles "
+                "summed over the 1024 SIMDs, GRBM_GUI_ACTIVE busy cycles summed over the 8 XCDs (means per launch of the kernel)")
+HBM_FORMULA = ("traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 B per launch (gfx950: FETCH_SIZE tallies a 16-B-per-lane streaming "
+               "read at half its bytes, MI355X_MICROARCH.md HBM section; separate --pmc passes); frac = traffic / launch time / 8 TB/s")
 
 
 def hann(n):
@@ -53,10 +90,10 @@ def hann(n):
 
 
 def algorithmic_bytes_per_unit(method, hop, n_freq, coef):
-    """SURVEY 8d, one frame through one iteration / evaluation of the REFERENCE ALGORITHM, fp32 - the figure `roofline.achieved`
-    and `roofline.frac` price (the contract).  griffin_lim: x read+write 8*hop, target 4F, pre_spec read+write 16F (8*hop + 4F
-    when alpha == 0); ADMM: X and U read+write 32F + target 4F; L_BFGS objective: x read + gradient write 8*hop, target
-    4*n_mels; RTISI_LA: target read 4F + committed frame 4*hop per frame (state lives in LDS: not what bounds that kernel)."""
+    """SURVEY 8d, one frame through one iteration / evaluation of the REFERENCE ALGORITHM, fp32 (`roofline.reference_bytes_equiv`).
+    griffin_lim: x read+write 8*hop, target 4F, pre_spec read+write 16F (8*hop + 4F when alpha == 0); ADMM: X and U read+write
+    32F + target 4F; L_BFGS objective: x read + gradient write 8*hop, target 4*n_mels; RTISI_LA: target read 4F + committed frame
+    4*hop per frame (state lives in LDS: not what bounds that kernel)."""
     if method == "griffin_lim":
         return 8 * hop + (20 if coef != 0 else 4) * n_freq
     if method == "ADMM":
@@ -67,7 +104,7 @@ def algorithmic_bytes_per_unit(method, hop, n_freq, coef):
 
 
 def restated_bytes_per_unit(method, hop, n_freq, kernel):
-    """What the shipped kernel has to move after the reformulations of DESIGN 3.1 (None: the reference algorithm's bytes).
+    """What the shipped kernel has to move after the reformulations of DESIGN 3.2 / 3.3 (None: the reference algorithm's bytes).
     Griffin-Lim with the momentum carried as a (B, L) signal: z in 4h, target 4F, z out 4h (x out only when somebody reads it;
     the first iterations also read the starting spectrum) instead of 8h + 20F; ADMM on Y = X + U alone: 8h + 20F instead of
     8h + 36F (methods.py:467-468 only ever read X + U)."""
@@ -78,6 +115,8 @@ def restated_bytes_per_unit(method, hop, n_freq, kernel):
     return None
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle; the only place this file touches oracle/)
 def _timed_oracle(run, units_per_iter, budget_s, first=2, cap=400):
     iters = first
     while True:
@@ -150,10 +189,11 @@ def cpu_baseline(method, n_fft, hop, frames, coef, budget_s=15.0):
         stftlib.WORKERS = 1
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Counters
 def load_traffic():
     """Stored counter figures of the dominant kernels: profiles/traffic.json (tools/collect_workload_profiles.py from the
-    committed rocprofv3 --pmc summaries) - HBM bytes per launch, VALU issue share, LDS conflict share - and the hash of the
-    kernel sources they were measured on.  Not measured in this run: PMC passes need rocprofv3 around the process."""
+    committed rocprofv3 --pmc summaries) and the hash of the kernel sources they were measured on: the fall-back of `live_pmc`."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
@@ -162,6 +202,89 @@ def load_traffic():
         return {}
 
 
+def summarise_counters(c):
+    """Derived figures of one kernel from its mean counter values per launch (`c`: {counter: mean})."""
+    out = {"counters": c}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        out["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+    if c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c:
+        out["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * N_SIMD)
+    if c.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_VALU" in c:
+        out["valu_share_of_wave_life"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in c:
+        out["lds_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    return out
+
+
+def under_profiler():
+    env = os.environ
+    return any(k.startswith("ROCPROF") or k.startswith("ROCPROFILER") for k in env) or "rocprofiler" in env.get("LD_PRELOAD", "")
+
+
+def live_pmc(workloads, timeout_s=150, keep=None):
+    """rocprofv3 --pmc passes (counters only: no trace domain beside them) around a CHILD process that runs one step of each of
+    `workloads` on this GPU - started as a child (`subprocess`), never an exec of this process, which has initialised the GPU.
+    One pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+    Returns {workload: summarise_counters(...)} for the dominant kernel of each, {} on any failure.  `keep`: directory to
+    copy the raw per-dispatch CSVs to (tools/profile_workloads.sh)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or under_profiler():
+        return {}, "rocprofv3 not available (or this process is itself profiled)"
+    tmp = tempfile.mkdtemp(prefix="specinv_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    env.pop("SPECINV_BENCH_BACKEND", None)
+    means = {w: {} for w in workloads}
+    t0 = time.perf_counter()
+    try:
+        for tag, counters in PMC_PASSES:
+            out_dir = os.path.join(tmp, tag)
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", out_dir, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", ",".join(workloads)]
+            r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}, f"pass {tag}: rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"
+            agg = {w: {} for w in workloads}
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        for w in workloads:
+                            if DOMINANT[w][0] in row["Kernel_Name"]:
+                                agg[w].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                if keep:
+                    os.makedirs(keep, exist_ok=True)
+                    shutil.copy(f, os.path.join(keep, f"pmc_{tag}_counter_collection.csv"))
+            for w in workloads:
+                for k, v in agg[w].items():
+                    means[w][k] = sum(v) / len(v)
+                    means[w].setdefault("_launches", {})[k] = len(v)
+        out = {}
+        for w in workloads:
+            n = means[w].pop("_launches", {})
+            if means[w]:
+                out[w] = summarise_counters(means[w])
+                out[w]["launches_counted"] = min(n.values()) if n else 0
+        return out, f"measured in this run: {len(PMC_PASSES)} rocprofv3 --pmc passes over a child process ({time.perf_counter() - t0:.0f} s)"
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return {}, f"{type(e).__name__}: {e}"[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def stored_pmc(workload, generic=False):
+    tr = load_traffic()
+    key = workload + ("_generic" if generic else "")
+    out = {}
+    if tr.get(key) is not None:
+        out["hbm_bytes_per_launch"] = tr[key]
+    for k in ("valu_issue_frac", "valu_share_of_wave_life", "lds_conflict_frac"):
+        if tr.get(f"{key}_{k}") is not None:
+            out[k] = tr[f"{key}_{k}"]
+    from spectrogram_inversion_amd.build import sources_hash
+    return out, tr.get("csrc_sha1"), tr.get("csrc_sha1") != sources_hash()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 def sc_lin_f64(x_item, mag_item, hop, window, dev):
     """||  |STFT(x)| - m || / || m ||  of one item, evaluated by the float64 generic kernels."""
     from spectrogram_inversion_amd.plan import Plan, args_helper
@@ -173,143 +296,115 @@ def sc_lin_f64(x_item, mag_item, hop, window, dev):
     return out, p
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
-    ap.add_argument("--asym", action="store_true", help="C3: asymmetric_window=True")
-    ap.add_argument("--outer", type=int, default=50, help="C5: optimizer.step calls per bench step (BASELINE configs[4]: maxiter=50)")
-    ap.add_argument("--c5-variant", default="baseline", choices=["baseline", "main", "wolfe", "memory"],
-                    help="C5 optimiser options: torch.optim.LBFGS defaults (BASELINE); the reference demo's (main.py:43: max_iter 50, "
-                         "history 10); defaults + line_search_fn='strong_wolfe' (steps long enough for the curvature pairs to pass "
-                         "y.s > 1e-10; its default tolerances end most steps after one iteration on this input); 'memory': strong "
-                         "Wolfe with both tolerances at 0, so that every step runs its 20 iterations, the memory fills to "
-                         "history_size = 100 and the recursion's passes over 200 vectors (k_multi_dot, k_lincomb) carry weight - use "
-                         "--outer 8 or more")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
-    args = ap.parse_args()
+def ev():
+    return torch.cuda.Event(enable_timing=True)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    # SPECINV_BENCH_BACKEND=gloo (development only): rehearse the N > 1 code path of this script - sharding, barrier, gather,
-    # max over ranks - with several ranks on the ONE GPU of a test box (a device cannot host two ranks of an RCCL communicator);
-    # the gather is then staged through host memory, so the line it prints is not a measurement
-    backend = os.environ.get("SPECINV_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+
+class Leg:
+    """One workload set up on this rank's GPU: `step()` runs one complete inversion; HIP events on the launch stream bracket
+    the dominant kernel's launches."""
+
+    def __init__(self, workload, o, rank, world, dev, backend):
+        import spectrogram_inversion_amd as si
+        from spectrogram_inversion_amd.plan import args_helper, get_plan
+        self.workload, self.o, self.rank, self.world, self.dev, self.backend = workload, o, rank, world, dev, backend
+        self.method, self.batch, self.n_fft, self.hop, self.frames, self.iters, self.coef = WORKLOADS[workload]
+        if o.batch:
+            self.batch = o.batch
+        self.n_freq = self.n_fft // 2 + 1
+        rng = np.random.default_rng(1234 + rank)
+        self.window = torch.from_numpy(hann(self.n_fft))
+        self.events, self.pending, self.state = [], [], {}
+        self.folded = {"ms": 0.0, "n": 0}
+        self.counters = {"evals": 0}
+        self.gather_wait_s = 0.0
+        self.plan = self.mag = None
+        m = self.method
+        if m != "L_BFGS":
+            mag_np = rng.random((self.batch, self.n_freq, self.frames), dtype=np.float32)
+            self.mag = torch.from_numpy(mag_np).to(dev)
+            self.plan = get_plan(args_helper(self.mag, hop_length=self.hop, window=self.window), self.batch, self.frames,
+                                 torch.float32, dev)
+            if o.generic:
+                self.plan.force_generic(True)
+            self.length = self.plan.length
+            self.unit = "iterations*frames/s"
+            self.units_per_step = self.iters * self.batch * self.frames
         else:
-            dist.init_process_group(backend)
+            self.length = (self.frames - 1) * self.hop
+            fb = torch.from_numpy(si.mel_filterbank(SR, self.n_fft, N_MELS)).to(dev)
+            self.tr = si.LogMelSTFT(fb, self.n_fft, hop_length=self.hop, window=self.window)
+            gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+            xs = (0.1 * torch.randn(self.batch, self.length, generator=gen)).to(dev)
+            self.target = self.tr(xs)
+            self.x_init = (1e-6 * torch.randn(self.batch, self.length, generator=gen)).to(dev)
+            self.fwd, self.fg_raw = self.tr.bind(self.x_init, self.target)
+            self.unit = "evaluations*frames/s"
+            self.units_per_step = None                         # closure evaluations are counted
+            self.opt_kw = {"baseline": {}, "main": dict(max_iter=50, history_size=10),
+                           "wolfe": dict(line_search_fn="strong_wolfe"),
+                           "memory": dict(line_search_fn="strong_wolfe", tolerance_grad=0.0, tolerance_change=0.0)}[o.c5_variant]
 
-    import spectrogram_inversion_amd as si
-    from spectrogram_inversion_amd.distributed import gather_waveforms
-    from spectrogram_inversion_amd.plan import args_helper, get_plan
-
-    method, batch, n_fft, hop, frames, iters, coef = WORKLOADS[args.workload]
-    if args.batch:
-        batch = args.batch
-    n_freq = n_fft // 2 + 1
-    rng = np.random.default_rng(1234 + rank)
-    window = torch.from_numpy(hann(n_fft))
-    events = []           # (start, stop, launches) of the dominant kernel inside the timed region
-    pending = []
-    state = {}
-
-    def ev():
-        return torch.cuda.Event(enable_timing=True)
-
-    def finish_step(x):
-        if world > 1 and method != "L_BFGS":
-            # RCCL gather of the (B, L) waveforms to rank 0; it runs on RCCL's stream, so the next step's kernels
-            # overlap it - every gather is completed (`result()`) inside the timed region
-            if pending:
-                pending.pop().result()
-            if backend == "nccl":
-                pending.append(gather_waveforms(x, dst=0, sizes=[batch] * world, async_op=True))
+    # -- one step ---------------------------------------------------------------------------------------------------------
+    def finish_step(self, x):
+        if self.world > 1 and self.method != "L_BFGS":
+            # RCCL gather of the (B, L) waveforms to rank 0; it runs on RCCL's stream, so the next step's kernels overlap it -
+            # every gather is completed (`result()`) inside the timed region.  --no-overlap-gather waits for it right away.
+            from spectrogram_inversion_amd.distributed import gather_waveforms
+            t0 = time.perf_counter()
+            if self.pending:
+                self.pending.pop().result()
+            if self.backend == "nccl":
+                h = gather_waveforms(x, dst=0, sizes=[self.batch] * self.world, async_op=True)
+                if self.o.no_overlap_gather:
+                    h.result()
+                    torch.cuda.current_stream().synchronize()
+                self.pending.append(h)
             else:                                            # (rehearsal: a blocking gather through host memory)
-                done = gather_waveforms(x, dst=0, sizes=[batch] * world)
-                pending.append(type("Done", (), {"result": staticmethod(lambda done=done: done)})())
-        state["x"] = x
+                done = gather_waveforms(x, dst=0, sizes=[self.batch] * self.world)
+                self.pending.append(type("Done", (), {"result": staticmethod(lambda done=done: done)})())
+            self.gather_wait_s += time.perf_counter() - t0
+        self.state["x"] = x
 
-    if method in ("griffin_lim", "ADMM"):
-        mag = torch.from_numpy(rng.random((batch, n_freq, frames), dtype=np.float32)).to(dev)
-        plan = get_plan(args_helper(mag, hop_length=hop, window=window), batch, frames, torch.float32, dev)
-        if args.generic:
-            plan.force_generic(True)
-        init = plan.gla_init if method == "griffin_lim" else plan.admm_init
-
-        def step():
-            init(None, mag, coef)                           # phase_init + initial ISTFT
+    def step(self, mag=None):
+        m, plan = self.method, self.plan
+        mag = self.mag if mag is None else mag
+        if m in ("griffin_lim", "ADMM"):
+            (plan.gla_init if m == "griffin_lim" else plan.admm_init)(None, mag, self.coef)   # phase_init + initial ISTFT
             e0, e1 = ev(), ev()
             e0.record()                                     # HIP events on the stream the kernels are launched on
-            done, evals = plan.run(iters, 10, 0.0, "sc")    # evaluation every 10, sums stay on the device
+            done, evals = plan.run(self.iters, 10, 0.0, "sc")    # evaluation every 10, sums stay on the device
             e1.record()
-            assert done == iters
-            state["evals"] = evals
-            events.append((e0, e1, iters))
-            finish_step(plan.wave())
-        units_per_step = iters * batch * frames
-        unit = "iterations*frames/s"
-        path = plan.path
-        geo = kernel = None                                 # known once a step has run (which kernel serves the method)
-
-        def iteration_kernel():
-            g = plan.launch_geometry
-            return g, {"k_fused4": f"specinv::fast::k_fused4<{n_fft // 128}, {'GLA' if method == 'griffin_lim' else 'ADMM'}>",
-                       "k_fused4_td": f"specinv::fast::k_fused4_td<{n_fft // 128}> (momentum carried as a signal; late and early "
-                                      f"(+c0) launches and the evaluation kernel k_eval_td averaged)",
-                       "k_fused": f"specinv::fast::k_fused<{n_fft // 128}, {n_fft // hop}>", "k_semi": "k_semi+k_ola_f4",
-                       "k_fused_td": f"specinv::fast::k_fused_td<{n_fft // 128}, {n_fft // hop}>", "k_hop": "k_hop",
-                       "k_hop_td": "k_hop_td", "k_iter_pair": "k_iter_pair+k_ola"}[g["kernel"]]
-        launches_per_step = iters
-        length = plan.length
-    elif method == "RTISI_LA":
-        mag = torch.from_numpy(rng.random((batch, n_freq, frames), dtype=np.float32)).to(dev)
-        plan = get_plan(args_helper(mag, hop_length=hop, window=window), batch, frames, torch.float32, dev)
-        if args.generic:
-            plan.force_generic(True)
-
-        def step():
+            assert done == self.iters
+            self.state["evals"] = evals
+            self.events.append((e0, e1, self.iters))
+            self.finish_step(plan.wave())
+        elif m == "RTISI_LA":
             e0, e1 = ev(), ev()
             e0.record()
-            x = plan.rtisi(mag, LOOK_AHEAD, args.asym, iters, coef)
+            x = plan.rtisi(mag, LOOK_AHEAD, self.o.asym, self.iters, self.coef)
             e1.record()
-            events.append((e0, e1, 1))
-            finish_step(x)
-        units_per_step = iters * batch * frames
-        unit = "iterations*frames/s"
-        path, geo = plan.path, {"kernel": "k_rtisi_fast" if plan.fast_path else "k_rtisi"}
-        kernel = f"specinv::k_rtisi_fast<{n_fft // 128}>" if plan.fast_path else "specinv::k_rtisi"
-        launches_per_step = 1
-        length = plan.length
-    else:
-        length = (frames - 1) * hop
-        fb = torch.from_numpy(si.mel_filterbank(SR, n_fft, N_MELS)).to(dev)
-        tr = si.LogMelSTFT(fb, n_fft, hop_length=hop, window=window)
-        gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
-        xs = (0.1 * torch.randn(batch, length, generator=gen)).to(dev)
-        target = tr(xs)
-        x_init = (1e-6 * torch.randn(batch, length, generator=gen)).to(dev)
-        fwd, fg_raw = tr.bind(x_init, target)
-        counters = {"evals": 0}
+            self.events.append((e0, e1, 1))
+            self.finish_step(x)
+        else:
+            from spectrogram_inversion_amd.lbfgs import LBFGS
+            x = self.x_init.clone()
+            opt = LBFGS(x, device=self.dev, **self.opt_kw)    # torch.optim.LBFGS defaults: max_iter 20, history 100, lr 1
+            # HIP events around every 8th objective evaluation (on the launch stream, recorded by the library: an event pair costs
+            # ~10 us of the timeline, so bracketing every one of the 1000 evaluations of a step would lower the throughput measured)
+            opt.time_objective = 0 if os.environ.get("SPECINV_BENCH_NO_EVENTS") else 8
+            fg = self._timed_fg()
+            for _ in range(self.o.outer):
+                opt.step(fg)
+            self.state["opt"] = opt
+            if opt.objective_launches:                       # evaluations the device-resident optimiser ran (and timed a sample of)
+                self.folded["ms"] += opt.objective_ms
+                self.folded["n"] += opt.objective_timed
+                self.counters["evals"] += opt.objective_launches
+            self.finish_step(x)
 
-        folded = {"ms": 0.0, "n": 0}
+    def _timed_fg(self):
+        events, folded, counters, fg_raw = self.events, self.folded, self.counters, self.fg_raw
 
         def timed_eval(call):
             # finished event pairs are folded into a running sum as we go: hundreds of live HIP events slow every launch down
@@ -335,190 +430,228 @@ def main():
         fg.dev = lambda v, loss_ptr: timed_eval(lambda: fg_raw.dev(v, loss_ptr))   # loss left on the device: no sync per evaluation
         # the device-resident optimiser (csrc/lbfgs_dev.h) enqueues a whole optimizer.step from C++: it times its own objective
         # launches with HIP events on the launch stream (LBFGS.time_objective) and counts the evaluations the device executed
-        fg.device_objective = fg_raw.device_objective
+        if hasattr(fg_raw, "device_objective"):
+            fg.device_objective = fg_raw.device_objective
+        if hasattr(fg_raw, "device_wolfe"):
+            fg.device_wolfe = fg_raw.device_wolfe
+        return fg
 
-        from spectrogram_inversion_amd.lbfgs import LBFGS
-
-        opt_kw = {"baseline": {}, "main": dict(max_iter=50, history_size=10),
-                  "wolfe": dict(line_search_fn="strong_wolfe"),
-                  "memory": dict(line_search_fn="strong_wolfe", tolerance_grad=0.0, tolerance_change=0.0)}[args.c5_variant]
-
-        def step():
-            x = x_init.clone()
-            opt = LBFGS(x, device=dev, **opt_kw)             # torch.optim.LBFGS defaults: max_iter 20, history 100, lr 1
-            # HIP events around every 8th objective evaluation (on the launch stream, recorded by the library: an event pair costs
-            # ~10 us of the timeline, so bracketing every one of the 1000 evaluations of a step would lower the throughput measured)
-            opt.time_objective = 0 if os.environ.get("SPECINV_BENCH_NO_EVENTS") else 8
-            for _ in range(args.outer):
-                opt.step(fg)
-            state["opt"] = opt
-            if opt.objective_launches:                       # evaluations the device-resident optimiser ran (and timed a sample of)
-                folded["ms"] += opt.objective_ms
-                folded["n"] += opt.objective_timed
-                counters["evals"] += opt.objective_launches
-            finish_step(x)
-        units_per_step = None                               # closure evaluations are counted
-        unit = "evaluations*frames/s"
-        path, geo = "fused", {"kernel": "objective"}
-        kernel = "L-BFGS objective (forward + loss + gradient)"
-        launches_per_step = None
-        plan = None
-
-    def fence():
-        out = pending.pop().result() if pending else None
-        if world > 1:
+    def fence(self):
+        import torch.distributed as dist
+        t0 = time.perf_counter()
+        out = self.pending.pop().result() if self.pending else None
+        self.gather_wait_s += time.perf_counter() - t0
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         return out
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    events.clear()
-    if method == "L_BFGS":
-        counters["evals"] = 0
-        folded["ms"], folded["n"] = 0.0, 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    gathered = fence()
-    elapsed = time.perf_counter() - t0
-    x = gathered if (world > 1 and method != "L_BFGS") else state["x"]
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    if rank == 0:
-        want = (batch * world if method != "L_BFGS" else batch, length)
-        assert tuple(x.shape) == want, (tuple(x.shape), want)
+    # -- the timed region -------------------------------------------------------------------------------------------------
+    def run(self, steps, warmup, step=None):
+        """W untimed steps, then EXACTLY `steps` timed ones between barrier + synchronize on both sides.  Returns the elapsed
+        seconds of this rank and what the last gather delivered."""
+        step = step or self.step
+        for _ in range(warmup):
+            step()
+        self.fence()
+        self.events.clear()
+        self.counters["evals"] = 0
+        self.folded["ms"], self.folded["n"] = 0.0, 0
+        self.gather_wait_s = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        gathered = self.fence()
+        elapsed = time.perf_counter() - t0
+        return elapsed, gathered
 
-    if method in ("griffin_lim", "ADMM"):
-        geo, kernel = iteration_kernel()
-    # dominant kernel: average duration over the timed region from the HIP events (launches back to back on one stream)
-    n_launch = sum(n for _, _, n in events) + (folded["n"] if method == "L_BFGS" else 0)
-    launch_ms = (sum(a.elapsed_time(b) for a, b, _ in events) + (folded["ms"] if method == "L_BFGS" else 0.0)) / max(1, n_launch)
-    unit_bytes = algorithmic_bytes_per_unit(method, hop, n_freq, coef)
-    launch_bytes = unit_bytes * batch * frames
-    achieved = launch_bytes / (launch_ms * 1e-3) / 1e9
+    def units(self, steps):
+        if self.method == "L_BFGS":
+            return self.counters["evals"] * self.batch * self.frames * self.world
+        return steps * self.units_per_step * self.world
 
-    if rank == 0:
-        if method == "L_BFGS":
-            units = counters["evals"] * batch * frames * world
-        else:
-            units = args.steps * units_per_step * world
-        desc = {
-            "griffin_lim": f"griffin_lim batch={batch}/GPU n_fft={n_fft} hop={hop} n_frames={frames} maxiter={iters} "
-                           f"alpha={coef} hann center reflect tol=0 eva_iter=10",
-            "ADMM": f"ADMM batch={batch}/GPU n_fft={n_fft} hop={hop} n_frames={frames} rho={coef} maxiter={iters} hann "
-                    f"tol=0 eva_iter=10",
-            "RTISI_LA": f"RTISI_LA batch={batch}/GPU n_fft={n_fft} hop={hop} n_frames={frames} look_ahead={LOOK_AHEAD} "
-                        f"maxiter={iters} alpha={coef} asymmetric_window={args.asym} hann",
-            "L_BFGS": f"L_BFGS log-mel-{N_MELS} batch={batch} n_fft={n_fft} hop={hop} n_frames={frames} maxiter={args.outer} "
-                      f"(optimizer.step calls) x LBFGS({'defaults: max_iter 20, history 100, lr 1' if not locals().get('opt_kw') else opt_kw})",
-        }[method]
-        out = {
-            "metric": "Griffin-Lim iterations*frames/sec at n_fft=2048 hop=512" if args.workload == "C2"
-                      else f"{method} {unit.split('/')[0]}/sec ({args.workload})",
-            "value": units / elapsed,
-            "unit": unit,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}",
-                       "global_batch": batch * world,
-                       "parallelism": (f"batch-sharded x{world}, RCCL gather" if method != "L_BFGS"
-                                       else f"replicas x{world} (one optimisation problem per GPU)"),
-                       "kernel_path": path, "launch_geometry": geo,
-                       "step": {"griffin_lim": "phase_init + ISTFT + iterations + gather",
-                                "ADMM": "phase_init + ISTFT + iterations + gather",
-                                "RTISI_LA": "persistent RTISI-LA launch + overlap-add + gather",
-                                "L_BFGS": "optimizer.step calls (objective evaluations + two-loop recursion)"}[method]},
-            "roofline": None,
-        }
-        # ---- roofline of the dominant kernel.  `achieved` / `frac` price the REFERENCE ALGORITHM's bytes (the contract);
-        # what the shipped kernel moves and what actually bounds it are reported beside them, so that the line alone tells the story
-        kname = (geo or {}).get("kernel")
-        tr = load_traffic()
-        tkey = args.workload if path != "generic" else args.workload + "_generic"
-        traffic = tr.get(tkey)
+    def freeze(self):
+        """Pin the figures of the timed region that just ended (later legs on this object reuse the event lists)."""
+        self._frozen = None
+        self._frozen = (self.launch_ms(), self.counters["evals"])
+
+    def launch_ms(self):
+        """dominant kernel: average duration over the timed region from the HIP events (launches back to back on one stream)"""
+        if getattr(self, "_frozen", None):
+            return self._frozen[0]
+        n = sum(n for _, _, n in self.events) + self.folded["n"]
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.events) + self.folded["ms"]
+        return ms / max(1, n), n
+
+    def kernel_info(self):
+        m = self.method
+        if m in ("griffin_lim", "ADMM"):
+            g = self.plan.launch_geometry
+            r = self.n_fft // 128
+            name = {"k_fused4": f"specinv::fast::k_fused4<{r}, {'GLA' if m == 'griffin_lim' else 'ADMM'}>",
+                    "k_fused4_td": f"specinv::fast::k_fused4_td<{r}> (momentum carried as a signal; late and early (+c0) launches "
+                                   f"and the evaluation kernel k_eval_td averaged in launch_ms)",
+                    "k_fused": f"specinv::fast::k_fused<{r}, {self.n_fft // self.hop}>", "k_semi": "k_semi+k_ola_f4",
+                    "k_fused_td": f"specinv::fast::k_fused_td<{r}, {self.n_fft // self.hop}>", "k_hop": "k_hop",
+                    "k_hop_td": "k_hop_td", "k_iter_pair": "k_iter_pair+k_ola"}[g["kernel"]]
+            return self.plan.path, g, name
+        if m == "RTISI_LA":
+            fast = self.plan.fast_path
+            return self.plan.path, {"kernel": "k_rtisi_fast" if fast else "k_rtisi"}, \
+                (f"specinv::k_rtisi_fast<{self.n_fft // 128}>" if fast else "specinv::k_rtisi")
+        return "fused", {"kernel": "objective"}, "L-BFGS objective (forward + loss + gradient in one launch)"
+
+    def describe(self):
+        o = self.o
+        return {
+            "griffin_lim": f"griffin_lim batch={self.batch}/GPU n_fft={self.n_fft} hop={self.hop} n_frames={self.frames} "
+                           f"maxiter={self.iters} alpha={self.coef} hann center reflect tol=0 eva_iter=10",
+            "ADMM": f"ADMM batch={self.batch}/GPU n_fft={self.n_fft} hop={self.hop} n_frames={self.frames} rho={self.coef} "
+                    f"maxiter={self.iters} hann tol=0 eva_iter=10",
+            "RTISI_LA": f"RTISI_LA batch={self.batch}/GPU n_fft={self.n_fft} hop={self.hop} n_frames={self.frames} "
+                        f"look_ahead={LOOK_AHEAD} maxiter={self.iters} alpha={self.coef} asymmetric_window={o.asym} hann",
+            "L_BFGS": f"L_BFGS log-mel-{N_MELS} batch={self.batch} n_fft={self.n_fft} hop={self.hop} n_frames={self.frames} "
+                      f"maxiter={o.outer} (optimizer.step calls) x LBFGS("
+                      f"{'defaults: max_iter 20, history 100, lr 1' if not getattr(self, 'opt_kw', None) else self.opt_kw})",
+        }[self.method]
+
+    # -- roofline ---------------------------------------------------------------------------------------------------------
+    def roofline(self, pmc, pmc_source, stale=None, stored_sha=None):
+        """The dominant kernel against the resource that binds it (module docstring)."""
         from spectrogram_inversion_amd.build import sources_hash
-        here = sources_hash()
-        stale = tr.get("csrc_sha1") != here
-        restated = restated_bytes_per_unit(method, hop, n_freq, kname)
-        bound = {"griffin_lim": "valu" if restated else "hbm", "ADMM": "hbm", "RTISI_LA": "latency", "L_BFGS": "valu"}[method]
-        if path == "generic":
-            bound = "valu"
-        roof = {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": "stored: profiles/traffic.json (rocprofv3 --pmc summary), not measured in this run",
-                "traffic_stale": bool(stale), "traffic_csrc_sha1": tr.get("csrc_sha1"), "csrc_sha1": here,
-                "kernel": kernel, "launch_ms": launch_ms, "launches_timed": n_launch,
-                "algorithmic_bytes_per_launch": launch_bytes, "bytes_per_unit": unit_bytes,
-                "bytes_convention": "SURVEY 8d: the reference algorithm's bytes per frame-iteration"}
+        path, geo, kernel = self.kernel_info()
+        launch_ms, n_launch = self.launch_ms()
+        secs = launch_ms * 1e-3
+        kname = (geo or {}).get("kernel")
+        default_shape = self.batch == WORKLOADS[self.workload][1] and not self.o.generic and path != "generic"
+        bound = DOMINANT[self.workload][1] if default_shape else ("valu" if path == "generic" else "hbm")
+        units = self.batch * self.frames
+        ref_unit = algorithmic_bytes_per_unit(self.method, self.hop, self.n_freq, self.coef)
+        must_unit = restated_bytes_per_unit(self.method, self.hop, self.n_freq, kname) or ref_unit
+        pmc = pmc or {}
+        traffic = pmc.get("hbm_bytes_per_launch")
+        vfrac = pmc.get("valu_issue_frac")
+        hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_unit": must_unit, "algorithmic_bytes_per_launch": must_unit * units,
+               "achieved_algorithmic": must_unit * units / secs / 1e9, "frac_algorithmic": must_unit * units / secs / 1e9 / HBM_PEAK_GBS,
+               "what": "bytes this kernel has to move per frame-iteration (DESIGN 3) over the measured launch time; `achieved` / "
+                       "`frac`: the counters' bytes over the same time", "formula": HBM_FORMULA}
         if traffic:
-            # HBM bytes the counters saw per launch / launch time / peak: the PHYSICAL HBM fraction
-            roof["hbm_physical_frac"] = traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if tr.get(tkey + "_valu_issue_frac") is not None:
-            roof["valu_issue_frac"] = tr[tkey + "_valu_issue_frac"]      # share of the chip's VALU issue slots in use (PMC)
-        if tr.get(tkey + "_valu_share_of_wave_life") is not None:
-            # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of one wave; times the waves per SIMD = the share of a SIMD's issue slots in use
-            roof["valu_share_of_wave_life"] = tr[tkey + "_valu_share_of_wave_life"]
-        if tr.get(tkey + "_lds_conflict_frac") is not None:
-            roof["lds_conflict_frac"] = tr[tkey + "_lds_conflict_frac"]
-        if restated:
-            roof["restated_bytes_per_unit"] = restated
-            roof["restated_frac"] = restated * batch * frames / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if method == "griffin_lim" and restated:
-            roof["note"] = (
-                "frac prices the reference algorithm's 8 hop + 20 F bytes per frame-iteration (pre_spec read and written); this "
-                "kernel carries the momentum as a (B, L) signal (pre_t = STFT(z_t) + (-lr)^t c0, DESIGN 3.1) and moves "
-                "8 hop + 4 F (restated_frac; hbm_physical_frac from the counters), so it is bound by the vector issue rate of "
-                "its two FFTs per frame (valu_issue_frac), not by HBM")
-        if method == "ADMM":
-            roof["note"] = ("frac prices SURVEY's 8 hop + 36 F (X and U read and written); the kernel carries Y = X + U alone "
-                            "(methods.py:467-468 only read the sum, bit-identical): 8 hop + 20 F, restated_frac - the figure to "
-                            "compare with hbm_physical_frac")
-        out["roofline"] = roof
-        if method == "RTISI_LA":
-            steps_dep = (frames + LOOK_AHEAD) * iters
-            out["roofline"]["note"] = ("serial-latency-bound (dependent inner steps; state in LDS / registers): the HBM "
-                                       "fraction is not what limits this kernel")
-            out["roofline"]["dependent_steps_per_s"] = steps_dep / (launch_ms * 1e-3)
-        if method == "L_BFGS":
-            out["roofline"]["evaluations_timed"] = counters["evals"]
-            opt = state["opt"]
-            out["config"]["lbfgs"] = {"variant": args.c5_variant, "outer_steps": args.outer, "inner_iterations": opt.total_iters,
-                                      "evaluations": opt.func_evals, "pairs_accepted": int(opt.pairs_accepted),
-                                      "pairs_rejected": int(opt.pairs_rejected), "history_len": opt.history_len,
-                                      "history_size": opt.history_size,
-                                      "decisions": "on the device, one host synchronisation per optimizer.step" if opt._dev
-                                                   else "on the host, one synchronisation per inner iteration"}
-            roof["note"] = ("compute-bound (SURVEY 8d): two FFTs per frame on the vector units + two mel contractions on the "
-                            "matrix cores; frac is the HBM fraction of its 8 hop + 4 n_mels bytes, reported as the contract asks")
-        if not args.no_check:
-            out["check"] = check(method, x, locals())
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(method, n_fft, hop, frames, coef if coef is not None else 0.0)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            hbm["achieved"] = traffic / secs / 1e9
+            hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
+            hbm["traffic_over_algorithmic"] = traffic / (must_unit * units)
+        roof = {"bound": bound, "kernel": kernel, "dominant_kernel_symbol": DOMINANT[self.workload][0] if default_shape else None,
+                "launch_ms": launch_ms, "launches_timed": n_launch, "traffic": traffic, "traffic_source": pmc_source,
+                "csrc_sha1": sources_hash()}
+        if stale is not None:
+            roof["traffic_stale"], roof["traffic_csrc_sha1"] = bool(stale), stored_sha
+        if bound == "hbm":
+            a = hbm.get("achieved", hbm["achieved_algorithmic"])
+            roof.update(achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
+                        frac_is="HBM bytes the counters saw per launch / launch time / 8 TB/s" if traffic else
+                                "no counters in this run: the bytes the kernel has to move / launch time / 8 TB/s")
+        else:
+            # vector issue: achieved = VALU-busy cycles per second over all SIMDs, peak = 1024 SIMDs x the clock the chip held
+            c = pmc.get("counters", {})
+            if vfrac is not None and c.get("GRBM_GUI_ACTIVE"):
+                clock_cycles = c["GRBM_GUI_ACTIVE"] / 8                   # per launch, under the profiler
+                roof.update(achieved=c["SQ_ACTIVE_INST_VALU"] * 4 / clock_cycles, peak=float(N_SIMD),
+                            unit="SIMDs issuing a vector instruction (mean over the launch, of 1024)", frac=vfrac)
+            else:
+                roof.update(achieved=None if vfrac is None else vfrac * N_SIMD, peak=float(N_SIMD),
+                            unit="SIMDs issuing a vector instruction (mean over the launch, of 1024)", frac=vfrac)
+            roof["frac_is"] = VALU_FORMULA
+        roof["hbm"] = hbm
+        for k in ("valu_issue_frac", "valu_share_of_wave_life", "lds_conflict_frac", "launches_counted"):
+            if pmc.get(k) is not None:
+                roof[k] = pmc[k]
+        if pmc.get("counters"):
+            roof["counters_mean_per_launch"] = pmc["counters"]
+        roof["reference_bytes_equiv"] = {
+            "bytes_per_unit": ref_unit, "bytes_per_launch": ref_unit * units, "achieved": ref_unit * units / secs / 1e9, "unit": "GB/s",
+            "over_hbm_peak": ref_unit * units / secs / 1e9 / HBM_PEAK_GBS,
+            "what": "SURVEY 8d's bytes of the REFERENCE ALGORITHM per frame-iteration over this kernel's launch time: a speed-up over "
+                    "that algorithm, not a fraction of anything (the kernel moves fewer bytes: may exceed 1)"}
+        if self.method == "RTISI_LA":
+            roof["dependent_steps_per_s"] = (self.frames + LOOK_AHEAD) * self.iters / secs
+            roof["note"] = ("serial-latency-bound: (T + LA) * max_iter dependent steps per item, one workgroup per item (32 of 256 "
+                            "CUs); frac = the chip's vector issue share, dependent_steps_per_s is the figure to watch")
+        elif self.method == "griffin_lim" and must_unit != ref_unit:
+            roof["note"] = ("the momentum is carried as a (B, L) signal (pre_t = STFT(z_t) + (-lr)^t c0, DESIGN 3.2): the kernel moves "
+                            "8 hop + 4 F bytes per frame-iteration and is bound by the vector issue rate of its two FFTs per frame")
+        elif self.method == "ADMM":
+            roof["note"] = ("the kernel carries Y = X + U alone (methods.py:467-468 only read the sum, bit-identical): 8 hop + 20 F "
+                            "bytes per frame-iteration instead of SURVEY's 8 hop + 36 F")
+        elif self.method == "L_BFGS":
+            roof["note"] = ("two FFTs per frame on the vector units + two mel contractions on the matrix cores (fp32 MFMA), the "
+                            "spectrum never leaves the chip; HBM view in `hbm`")
+            roof["evaluations_timed"] = self._frozen[1] if getattr(self, "_frozen", None) else self.counters["evals"]
+        return roof
+
+    def lbfgs_info(self):
+        opt = self.state["opt"]
+        return {"variant": self.o.c5_variant, "outer_steps": self.o.outer, "inner_iterations": opt.total_iters,
+                "evaluations": opt.func_evals, "pairs_accepted": int(opt.pairs_accepted),
+                "pairs_rejected": int(opt.pairs_rejected), "history_len": opt.history_len, "history_size": opt.history_size,
+                "decisions": "on the device, one host synchronisation per optimizer.step" if opt._dev
+                             else "on the host, one synchronisation per inner iteration"}
+
+    # -- H2D-inclusive step (SURVEY 8d: "excludes plan creation / H2D of inputs - report both") ---------------------------------
+    def h2d_legs(self, steps, warmup):
+        """The step with its input staged from pinned host memory: (a) serial - the copy on the launch stream in front of every
+        step; (b) pipelined - the next step's target copied on a second stream into a second buffer while this step iterates."""
+        if self.method == "L_BFGS":
+            return None
+        host = torch.empty(self.mag.shape, dtype=self.mag.dtype, pin_memory=True)
+        host.copy_(self.mag)
+        bufs = [torch.empty_like(self.mag), torch.empty_like(self.mag)]
+        nbytes = self.mag.numel() * self.mag.element_size()
+
+        def serial():
+            bufs[0].copy_(host, non_blocking=True)
+            self.step(bufs[0])
+        el, _ = self.run(steps, warmup, serial)
+        out = {"bytes_per_step": nbytes,
+               "serial": {"ms_per_step": 1e3 * el / steps, "value": self.units(steps) / el,
+                          "what": "hipMemcpyAsync of the target from pinned host memory on the launch stream, then the step"}}
+        copy_stream = torch.cuda.Stream(self.dev)
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        freed = [torch.cuda.Event(), torch.cuda.Event()]
+        k = {"i": 0}
+
+        def stage(slot):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(freed[slot])
+                bufs[slot].copy_(host, non_blocking=True)
+                ready[slot].record(copy_stream)
+
+        def pipelined():
+            slot = k["i"] & 1
+            k["i"] += 1
+            torch.cuda.current_stream().wait_event(ready[slot])
+            stage(slot ^ 1)                                   # the next step's input, under this step's iterations
+            self.step(bufs[slot])
+            freed[slot].record()
+        for s in (0, 1):
+            freed[s].record()
+        stage(0)
+        el, _ = self.run(steps, warmup, pipelined)
+        torch.cuda.synchronize()
+        out["pipelined"] = {"ms_per_step": 1e3 * el / steps, "value": self.units(steps) / el,
+                            "what": "the next step's target copied on a second HIP stream into a second buffer while this step "
+                                    "iterates (double-buffered)"}
+        return out
 
 
-def check(method, x, env):
+# ---------------------------------------------------------------------------------------------------------------------------
+def check(leg, x):
     """Independent re-evaluation of item 0 of the result, outside the timed region: the spectral convergence of the
     float32 result as the float64 generic kernels measure it, against a complete float64 re-run from the same
     starting spectrum (linear scale; the north-star bar for Griffin-Lim is 1e-5)."""
-    dev, hop, window, iters, coef = env["dev"], env["hop"], env["window"], env["iters"], env["coef"]
+    method, dev, hop, window, iters, coef = leg.method, leg.dev, leg.hop, leg.window, leg.iters, leg.coef
     if method == "L_BFGS":
         # the loss the objective kernel reports against the loss recomputed from its own forward pass by the metric
         # kernel, and the directional derivative of the loss against g . d
-        fwd, fg_raw, x0, target = env["fwd"], env["fg_raw"], env["x_init"], env["target"]
+        fwd, fg_raw, x0, target = leg.fwd, leg.fg_raw, leg.x_init, leg.target
         xr = (x0 + 1e-3 * torch.randn_like(x0)).contiguous()
         loss, g = fg_raw(xr)
         v = fwd(xr)
@@ -529,20 +662,20 @@ def check(method, x, env):
         lm, _ = fg_raw((xr - eps * d).contiguous())
         fd, gd = (lp - lm) / (2 * eps), float((g.double() * d.double()).sum())
         ok = abs(loss - mse) <= 1e-5 * abs(mse) and abs(fd - gd) <= 2e-2 * abs(gd)
-        return {"what": "self-check (tripwire, not parity evidence): objective loss vs mse(forward, target); central difference vs g.d", "loss": loss, "mse": mse,
-                "directional_fd": fd, "directional_g": gd, "ok": bool(ok)}
-    mag = env["mag"]
+        return {"what": "self-check (tripwire, not parity evidence): objective loss vs mse(forward, target); central difference vs g.d",
+                "loss": loss, "mse": mse, "directional_fd": fd, "directional_g": gd, "ok": bool(ok)}
+    mag = leg.mag
     from spectrogram_inversion_amd.plan import Plan, args_helper
     sc32, p64 = sc_lin_f64(x[0], mag[0], hop, window, dev)
     if method == "RTISI_LA":
         a = args_helper(mag[:1], hop_length=hop, window=window)
         pg = Plan(a, 1, mag.shape[2], torch.float32, dev)
         pg.force_generic(True)
-        xg = pg.rtisi(mag[:1], LOOK_AHEAD, env["args"].asym, iters, coef)
+        xg = pg.rtisi(mag[:1], LOOK_AHEAD, leg.o.asym, iters, coef)
         scg, _ = sc_lin_f64(xg[0], mag[0], hop, window, dev)
         tol = 2e-3
-        return {"what": "self-check (tripwire, not parity evidence): SC_lin of item 0 (float64 evaluation) vs the generic RTISI-LA kernel", "sc_lin": sc32,
-                "sc_lin_ref": scg, "abs_diff": abs(sc32 - scg), "tol": tol, "ok": bool(abs(sc32 - scg) <= tol)}
+        return {"what": "self-check (tripwire, not parity evidence): SC_lin of item 0 (float64 evaluation) vs the generic RTISI-LA kernel",
+                "sc_lin": sc32, "sc_lin_ref": scg, "abs_diff": abs(sc32 - scg), "tol": tol, "ok": bool(abs(sc32 - scg) <= tol)}
     # float64 re-run of item 0 from the float32 phase_init
     a32 = args_helper(mag[:1], hop_length=hop, window=window)
     p32 = Plan(a32, 1, mag.shape[2], torch.float32, dev)
@@ -558,26 +691,25 @@ def check(method, x, env):
     out = {"what": "self-check (a tripwire, not parity evidence - parity is tests/ against the reference's fixtures): SC_lin of "
                    "item 0 (float64 evaluation) vs a float64 re-run of the same iterations on this library's generic kernels",
            "sc_lin": sc32, "sc_lin_ref": sc64, "abs_diff": abs(sc32 - sc64), "tol": tol, "ok": bool(abs(sc32 - sc64) <= tol)}
-    ref = reference_trace_check(env)
+    ref = reference_trace_check(leg)
     if ref is not None:
         out["reference"] = ref
         out["ok"] = bool(out["ok"] and ref["ok"])
     return out
 
 
-def reference_trace_check(env):
+def reference_trace_check(leg):
     """C2 on rank 0's input is exactly what tests/golden/g16b_c2_headline.npz holds the UNMODIFIED REFERENCE's run of
     (torch_specinv/methods.py:193-270, B = 64, 100 iterations, alpha 0.3, eva_iter 10; tests/golden/make_golden.py:g16): the ten
     whole-batch evaluations of the last timed step against the reference's, |dSC_lin| <= 1e-5 (the north-star bar)."""
-    args, state = env["args"], env["state"]
-    if args.workload != "C2" or env["batch"] != 64 or env["rank"] != 0 or args.generic or "evals" not in state:
+    if leg.workload != "C2" or leg.batch != 64 or leg.rank != 0 or leg.o.generic or "evals" not in leg.state:
         return None
     path = os.path.join(ROOT, "tests", "golden", "g16b_c2_headline.npz")
     if not os.path.exists(path):
         return None
     g = np.load(path)
     want, sc_ref = g["trace"], g["sc_db_from_loss"]
-    got = np.array([[m, l] for _, m, l in state["evals"]])
+    got = np.array([[m, l] for _, m, l in leg.state["evals"]])
     if got.shape != want.shape:
         return None
     # The reference's loss column (F.mse_loss) is good to 1e-7; its SC column is not (torch's float32 `norm` over 6.7e7 elements is
@@ -591,6 +723,261 @@ def reference_trace_check(env):
             "max_rel_dloss": float(dl.max()), "max_abs_dsc_lin": float(d.max()), "sc_db_final": float(got[-1, 0]),
             "sc_db_final_reference_from_loss": float(sc_ref[-1]), "sc_db_final_reference_reported": float(want[-1, 0]),
             "tol": 1e-5, "ok": bool(d.max() <= 1e-5 and dl.max() <= 1e-5)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+EXTRA_LEGS = (          # (key, workload, steps, warmup, option overrides) - short legs after the headline's timed region
+    ("C4", "C4", 5, 1, {}),
+    ("C3", "C3", 2, 1, {}),
+    ("C5", "C5", 2, 1, {"outer": 50, "c5_variant": "baseline"}),
+    ("C5_wolfe", "C5", 2, 1, {"outer": 50, "c5_variant": "wolfe"}),
+)
+
+
+def leg_options(args, **over):
+    o = argparse.Namespace(**vars(args))
+    o.batch, o.generic = None, False
+    for k, v in over.items():
+        setattr(o, k, v)
+    return o
+
+
+def run_extra(args, dev, pmc_all, pmc_source):
+    from spectrogram_inversion_amd.plan import clear_plan_cache
+    out = {}
+    for key, workload, steps, warmup, over in EXTRA_LEGS:
+        t0 = time.perf_counter()
+        try:
+            leg = Leg(workload, leg_options(args, **over), 0, 1, dev, "nccl")
+            el, _ = leg.run(steps, warmup)
+            leg.freeze()
+            entry = {"workload": f"{workload}: {leg.describe()}", "value": leg.units(steps) / el, "unit": leg.unit, "steps": steps,
+                     "warmup": warmup, "ms_per_step": 1e3 * el / steps}
+            pmc = pmc_all.get(workload)
+            src = pmc_source
+            stale = sha = None
+            if not pmc:
+                pmc, sha, stale = stored_pmc(workload)
+                src = "stored: profiles/traffic.json (rocprofv3 --pmc summary), not measured in this run"
+            roof = leg.roofline(pmc, src, stale, sha)
+            entry["launch_ms"] = roof["launch_ms"]
+            entry["frac"] = roof.get("frac")
+            entry["roofline"] = {k: roof[k] for k in ("bound", "kernel", "frac", "achieved", "peak", "unit", "traffic", "traffic_source",
+                                                       "hbm", "valu_issue_frac", "lds_conflict_frac", "dependent_steps_per_s",
+                                                       "evaluations_timed") if k in roof}
+            if leg.method == "L_BFGS":
+                entry["lbfgs"] = leg.lbfgs_info()
+            if not args.no_check:
+                entry["check"] = check(leg, leg.state["x"])
+            entry["leg_seconds"] = time.perf_counter() - t0
+            out[key] = entry
+            del leg
+        except Exception as e:                                # an extra leg must never take the headline line down with it
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        clear_plan_cache()
+        torch.cuda.empty_cache()
+    return out
+
+
+def pmc_child(workloads):
+    """The process rocprofv3 wraps (`live_pmc`): one warm-up + one counted step of every workload, nothing printed."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ap = build_parser()
+    base = ap.parse_args([])
+    for w in workloads:
+        o = leg_options(base, outer=2) if w == "C5" else leg_options(base)
+        leg = Leg(w, o, 0, 1, dev, "nccl")
+        leg.run(1, 1)
+        del leg
+        from spectrogram_inversion_amd.plan import clear_plan_cache
+        clear_plan_cache()
+    torch.cuda.synchronize()
+
+
+def spawn_ranks(args):
+    """`python3 bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD process - before this
+    process has made any GPU call - and leave with its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
+    ap.add_argument("--asym", action="store_true", help="C3: asymmetric_window=True")
+    ap.add_argument("--outer", type=int, default=50, help="C5: optimizer.step calls per bench step (BASELINE configs[4]: maxiter=50)")
+    ap.add_argument("--c5-variant", default="baseline", choices=["baseline", "main", "wolfe", "memory"],
+                    help="C5 optimiser options: torch.optim.LBFGS defaults (BASELINE); the reference demo's (main.py:43: max_iter 50, "
+                         "history 10); defaults + line_search_fn='strong_wolfe' (steps long enough for the curvature pairs to pass "
+                         "y.s > 1e-10; its default tolerances end most steps after one iteration on this input); 'memory': strong "
+                         "Wolfe with both tolerances at 0, so that every step runs its 20 iterations, the memory fills to "
+                         "history_size = 100 and the recursion's passes over 200 vectors carry weight - use --outer 8 or more")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C4 / C3 / C5 legs that follow the default C2 run")
+    ap.add_argument("--no-pmc", action="store_true", help="no live rocprofv3 --pmc passes: counters from profiles/traffic.json")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the H2D-inclusive legs")
+    ap.add_argument("--no-overlap-gather", action="store_true",
+                    help="N > 1: wait for each step's RCCL gather before the next step starts (default: it overlaps the next step)")
+    ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-dispatch counter CSVs of the live passes in")
+    ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
+    if args.pmc_child:
+        return pmc_child(args.pmc_child.split(","))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # SPECINV_BENCH_BACKEND=gloo (development only): rehearse the N > 1 code path of this script - sharding, barrier, gather,
+    # max over ranks - with several ranks on the ONE GPU of a test box (a device cannot host two ranks of an RCCL communicator);
+    # the gather is then staged through host memory, so the line it prints is not a measurement
+    backend = os.environ.get("SPECINV_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    t_begin = time.perf_counter()
+    leg = Leg(args.workload, args, rank, world, dev, backend)
+    method, batch = leg.method, leg.batch
+    elapsed_local, gathered = leg.run(args.steps, args.warmup)
+    elapsed = elapsed_local
+    x = gathered if (world > 1 and method != "L_BFGS") else leg.state["x"]
+    diag = None
+    if world > 1:
+        where = dev if backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=where)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        # per-rank diagnostics: every rank's own wall time and the host time it spent waiting on gathers; ranks RCCL really saw
+        mine = torch.tensor([elapsed_local, leg.gather_wait_s, 1.0], dtype=torch.float64, device=where)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        # one blocking gather after the timed region, nothing else on the chip: what the exchange itself costs
+        gather_ms = None
+        if method != "L_BFGS":
+            from spectrogram_inversion_amd.distributed import gather_waveforms
+            xl = leg.state["x"]
+            gather_waveforms(xl, dst=0, sizes=[batch] * world)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            gather_waveforms(xl, dst=0, sizes=[batch] * world)
+            torch.cuda.synchronize()
+            gather_ms = 1e3 * (time.perf_counter() - t0)
+        diag = {"per_rank_ms_per_step": [1e3 * float(t[0]) / args.steps for t in every],
+                "per_rank_gather_wait_ms_per_step": [1e3 * float(t[1]) / args.steps for t in every],
+                "ranks_seen": int(sum(float(t[2]) for t in every)), "backend": backend,
+                "gather": "overlapped with the next step (RCCL stream)" if not args.no_overlap_gather else "blocking after each step",
+                "gather_alone_ms_rank0": gather_ms,
+                "gather_bytes_per_rank": None if method == "L_BFGS" else batch * leg.length * 4}
+    if rank == 0:
+        want = (batch * world if method != "L_BFGS" else batch, leg.length)
+        assert tuple(x.shape) == want, (tuple(x.shape), want)
+
+    if rank == 0:
+        path, geo, kernel = leg.kernel_info()
+        out = {
+            "metric": "Griffin-Lim iterations*frames/sec at n_fft=2048 hop=512" if args.workload == "C2"
+                      else f"{method} {leg.unit.split('/')[0]}/sec ({args.workload})",
+            "value": leg.units(args.steps) / elapsed,
+            "unit": leg.unit,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {leg.describe()}",
+                       "global_batch": batch * world,
+                       "parallelism": (f"batch-sharded x{world}, RCCL gather" if method != "L_BFGS"
+                                       else f"replicas x{world} (one optimisation problem per GPU)"),
+                       "kernel_path": path, "launch_geometry": geo,
+                       "step": {"griffin_lim": "phase_init + ISTFT + iterations + gather",
+                                "ADMM": "phase_init + ISTFT + iterations + gather",
+                                "RTISI_LA": "persistent RTISI-LA launch + overlap-add + gather",
+                                "L_BFGS": "optimizer.step calls (objective evaluations + two-loop recursion)"}[method]},
+            "roofline": None,
+        }
+        if diag:
+            out["multi_gpu"] = diag
+        if method == "L_BFGS":
+            out["config"]["lbfgs"] = leg.lbfgs_info()
+        leg.freeze()                       # the launch time belongs to the timed region: later legs reuse the event lists
+        primary_state = dict(leg.state)
+        solo = world == 1 and args.batch is None and not args.generic
+        # ---- counters: live passes over a child process (N = 1), else the stored summary
+        want_extra = solo and args.workload == "C2" and not args.no_extra
+        pmc_all, pmc_source = {}, None
+        if solo and not args.no_pmc and args.workload in DOMINANT:
+            wl = [args.workload] + ([w for w in ("C4", "C3", "C5") if want_extra])
+            pmc_all, pmc_source = live_pmc(wl, keep=args.keep_pmc)
+        pmc, stale, sha = pmc_all.get(args.workload), None, None
+        if not pmc:
+            why = pmc_source
+            pmc, sha, stale = stored_pmc(args.workload, generic=(path == "generic"))
+            pmc_source = "stored: profiles/traffic.json (rocprofv3 --pmc summary), not measured in this run" + \
+                         (f" [live passes: {why}]" if why else "")
+        out["roofline"] = leg.roofline(pmc, pmc_source, stale, sha)
+        if not args.no_check:
+            out["check"] = check(leg, x)
+        # ---- the same step with its input staged over PCIe
+        if world == 1 and not args.no_h2d and method != "L_BFGS":
+            h = leg.h2d_legs(max(3, min(args.steps, 10)), 1)
+            if h:
+                out["value_incl_h2d"] = h["pipelined"]["value"]
+                out["ms_per_step_incl_h2d"] = h["pipelined"]["ms_per_step"]
+                out["h2d"] = h
+        leg.state.update(primary_state)
+        if want_extra:
+            del leg
+            from spectrogram_inversion_amd.plan import clear_plan_cache
+            clear_plan_cache()
+            torch.cuda.empty_cache()
+            out["extra"] = {"workloads": run_extra(args, dev, pmc_all, pmc_source),
+                            "what": "short legs of the other BASELINE workloads, run in this process after the headline's timed "
+                                    "region (same timing rules: warm-up, barrier + synchronize on both sides)"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(method, WORKLOADS[args.workload][2], WORKLOADS[args.workload][3],
+                                               WORKLOADS[args.workload][4],
+                                               WORKLOADS[args.workload][6] if WORKLOADS[args.workload][6] is not None else 0.0)
+        out["bench_seconds"] = time.perf_counter() - t_begin
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
