@@ -102,12 +102,14 @@ int64_t specinv_plan_device_bytes(const specinv_plan* plan);
 int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]);
 /* 0: allow the fast path when the configuration supports it (default); 1: force the generic kernels. */
 int specinv_plan_force_generic(specinv_plan* plan, int on);
-/* The magnitude projection S * m / (|S| + 1e-16) and the division by the overlap-add envelope exactly as the reference rounds them
- * (torch_specinv/methods.py:132,246-247: correctly rounded sqrt and divisions) instead of the default v_sqrt_f32 / v_rcp_f32 and a
- * multiplication by 1 / envelope.  The default differs from the reference by less than the reference's own float32-vs-float64 noise
- * except where a bin passes close to zero on inconsistent magnitudes (one neighbourhood in 18 fixture cases after 100 iterations,
- * profiles/r02_ieee_study.txt); the exact kernels cost ~10 % on the headline kernel.  Applies to the float32 wave-level kernels
- * (fused, frame, chunked frame); the generic kernels and float64 are exact already.  Takes effect at the next specinv_gla_init / specinv_admm_init. */
+/* The arithmetic of the magnitude projection S * m / (|S| + 1e-16) and of the division by the overlap-add envelope
+ * (torch_specinv/methods.py:132,246-247) on the float32 wave-level kernels (fused, frame, chunked frame).
+ * on = 1 (the default since round 4): the reference's operation order - ATen executes the projection as (S * m) * r with r the rounded
+ * reciprocal of |S| + 1e-16 (tools/ref_ops_probe.py) - with r the correctly rounded 1 / |S| (one Newton step on v_rsq_f32) and a
+ * correctly rounded division by the envelope: 73 % of the projected bins bit-identical to the reference's chain, every one within
+ * its rounding noise; + 3 % on the headline step.  on = 0: S * (m * v_rsq_f32(|S|^2 + 1e-32)) and a multiplication by 1 / envelope
+ * (52 % bit-identical, the same distance from the exact value).  The generic kernels and float64 use IEEE operations in the
+ * reference's order throughout.  Takes effect at the next specinv_gla_init / specinv_admm_init. */
 int specinv_plan_set_exact(specinv_plan* plan, int on);
 /* The float32 fast paths do not carry the reference's spectral state as such.
  * ADMM keeps only Y = X + U between iterations: methods.py:467-468 read the two as U + X, i.e. the Y that :475 has just

@@ -63,10 +63,16 @@
 #ifndef SPECINV_NT
 #define SPECINV_NT 1         // nontemporal state streams (keeps the re-used samples in L2)
 #endif
-#ifndef SPECINV_IEEE        // 1: correctly rounded sqrt / division in the projection and a true division by the envelope
-#define SPECINV_IEEE 0      //    (the reference's operations, methods.py:132,246-247) instead of v_sqrt_f32 / v_rcp_f32 and
-#endif                      //    a multiplication by 1/envelope: the accuracy study of tools/dbg_acc.py, profiles/r02_ieee_study.txt
+#ifndef SPECINV_IEEE        // 1 (default): the reference's operation order in the projection, (s m) r with r the correctly rounded
+#define SPECINV_IEEE 1      //    1 / |s|, and a true division by the envelope (methods.py:132,246-247; ref_rcp_abs2 below);
+#endif                      // 0: s (m v_rsq_f32(|s|^2 + 1e-32)) and a multiplication by 1 / envelope (the fast_approx copy)
 
+#ifndef SPECINV_REFCHAIN    // (experiments) 1: RN(1 / (RN(sqrt t) + 1e-16)), both roundings; 2: one Newton step to RN(t^-1/2)
+#define SPECINV_REFCHAIN 2
+#endif
+#ifndef SPECINV_REFBREADTH  // (experiments) 1: the chain written breadth-first over a frame's pairs in k_fused_td
+#define SPECINV_REFBREADTH 1
+#endif
 #ifndef SPECINV_K4_ENVREG
 #define SPECINV_K4_ENVREG 1
 #endif
@@ -74,12 +80,12 @@
 #define SPECINV_R8_W3 1      // 168 registers (ADMM 2 spilled, the evaluating variants 8-31); measured against two waves per SIMD:
 #endif                       // C4 34.3 -> 32.3 ms per step, Griffin-Lim 1024 / 256 0.135 -> 0.127 ms per iteration
 
-// The wave-level kernels are compiled twice: as `specinv::fast` with the hardware's approximate sqrt / reciprocal in the
-// projection and a multiplication by 1 / envelope (default; 10 % faster on the headline kernel), and - in the tu_exact_*.hip
-// units, which define SPECINV_IEEE=1 and SI_FAST_NS=fast_exact before including the kernel headers - as `specinv::fast_exact`
-// with correctly rounded sqrt and divisions and a true division by the envelope, the reference's own operations
-// (methods.py:132,246-247).  `specinv_plan_set_exact` selects the second set (fast_state.h takes its kernels' addresses from
-// the extern "C" tables of those units).
+// The wave-level kernels are compiled twice: as `specinv::fast` with the reference's operation order and correctly rounded factors
+// (SPECINV_IEEE=1, the default arithmetic since round 4: + 3 % on the headline step, tools/refchain_study.py), and - in the
+// tu_approx_*.hip units, which define SPECINV_IEEE=0 and SI_FAST_NS=fast_approx before including the kernel headers - as
+// `specinv::fast_approx` with the hardware's approximate inverse square root in the projection and a multiplication by
+// 1 / envelope.  `specinv_plan_set_exact(plan, 0)` selects the second set (fast_state.h takes its kernels' addresses from the
+// extern "C" tables of those units).
 #ifndef SI_FAST_NS
 #define SI_FAST_NS fast
 #endif
@@ -810,16 +816,75 @@ struct FastArgs {
   float inv_scale;  // 1/N or N^-1/2
 };
 
+// |s| where only the metric reads it (sums compared to 1e-5: the hardware square root is good to 1 ulp)
+__device__ __forceinline__ float fast_abs(v2f s) { return __builtin_amdgcn_sqrtf(fmaf(s.x, s.x, s.y * s.y)); }
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 #if SPECINV_IEEE
-__device__ __forceinline__ float fast_abs(v2f s) { return __fsqrt_rn(fmaf(s.x, s.x, s.y * s.y)); }
-__device__ __forceinline__ float fast_rcp(float v) { return __fdiv_rn(1.0f, v); }
-// the envelope table holds the envelope itself
+// ---- the reference's operation order from corrected hardware approximations ------------------------------------------------
+// methods.py:246-247 is `spec * target / (spec.abs() + 1e-16)`.  What ATen executes for it (torch 2.10 CPU, checked value by
+// value on 2^22 random bins, tools/ref_ops_probe.py): abs = hypotf (correctly rounded), and the complex / real division is a
+// multiplication by the rounded RECIPROCAL of the real divisor (c10::complex<T>::operator/= with a zero imaginary part):
+//     out = (s * m) * r,   r = RN(1 / (RN(|s|) + 1e-16)).
+// Here t = |s|^2 by two fused multiply-adds, y = v_rsq_f32(t) (1 ulp), and
+//   SPECINV_REFCHAIN == 2 (shipped): ONE Newton step on y gives r = RN(t^-1/2), the correctly rounded 1 / |s| in all but ~1e-6 of
+//     the cases (one rounding of the exact value where the reference rounds |s| and then its reciprocal): two transcendental and
+//     four packed instructions per PAIR of bins, no division; 73 % of the outputs bit-identical to the reference's chain, rms
+//     deviation from it 4.9e-8 relative - and from the EXACT value 4.7e-8, where the reference's own chain has 5.1e-8;
+//   SPECINV_REFCHAIN == 1: h = t y corrected by one residual step to RN(sqrt t), + 1e-16, one Newton step from y to
+//     RN(1 / (h + 1e-16)): both of the reference's roundings, 88 % bit-identical (the rest is hypotf rounding the exact sum of
+//     squares), three more packed instructions per pair: + 5.3 % on the BASELINE C2 step against + 3.1 % (tools/refchain_study.py,
+//     profiles/r04_refchain.txt).
+// For comparison: the IEEE sqrt + two divisions of rounds 2-3 (x m / d: not the reference's chain) matched 65 % at + 27 %, the
+// approximate path (SPECINV_IEEE=0: s (m rsq(t))) 52 %; every form sits 4.7-5.3e-8 from the exact value.
+// kRefFloor keeps rsq finite at s = 0 (then out = 0 like the reference's 0 / 1e-16) and bounds r by 1e16 like the guard does; it
+// is absorbed by t above |s| = 6e-13 (REFCHAIN 2 has no other guard: it only differs from the reference's below |s| = 3e-9).
+constexpr float kRefFloor = 1e-32f;
+__device__ __forceinline__ float ref_norm2(v2f s, float floor_ = kRefFloor) { return fmaf(s.y, s.y, fmaf(s.x, s.x, floor_)); }
+__device__ __forceinline__ v2f ref_rcp_abs2(v2f t, float guard = 1e-16f) {
+  const v2f y = v2f{__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y)};
+  v2f h = t * y;
+#if SPECINV_REFCHAIN == 1
+  const v2f res = __builtin_elementwise_fma(-h, h, t);
+  h = __builtin_elementwise_fma(res, y * 0.5f, h);
+  const v2f den = h + guard;
+  const v2f e = __builtin_elementwise_fma(-den, y, v2f{1.0f, 1.0f});
+  return __builtin_elementwise_fma(e, y, y);
+#else
+  const v2f e = __builtin_elementwise_fma(-h, y, v2f{1.0f, 1.0f});
+  return __builtin_elementwise_fma(y * 0.5f, e, y);
+#endif
+}
+__device__ __forceinline__ float ref_rcp_abs(float t, float guard = 1e-16f) {
+  const float y = __builtin_amdgcn_rsqf(t);
+  float h = t * y;
+#if SPECINV_REFCHAIN == 1
+  const float res = fmaf(-h, h, t);
+  h = fmaf(res, y * 0.5f, h);
+  const float den = h + guard;
+  const float e = fmaf(-den, y, 1.0f);
+  return fmaf(e, y, y);
+#else
+  return fmaf(y * 0.5f, fmaf(-h, y, 1.0f), y);
+#endif
+}
+// The envelope division of methods.py:132 (a true float32 division): q = v r, one residual step - correctly rounded when r is the
+// correctly rounded reciprocal of e (`env_rcp`: v_rcp_f32 + one Newton step), which the kernels keep in registers wherever the
+// envelope is periodic; where it is not (the first frames of an item, tails) they divide.  The envelope table holds the envelope.
+__device__ __forceinline__ float env_rcp(float e) {
+  const float r = __builtin_amdgcn_rcpf(e);
+  return fmaf(fmaf(-e, r, 1.0f), r, r);
+}
+__device__ __forceinline__ v2f env_rcp(v2f e) { return v2f{env_rcp(e.x), env_rcp(e.y)}; }
+__device__ __forceinline__ v2f env_apply_r(v2f v, v2f e, v2f r) {
+  const v2f q = v * r;
+  return __builtin_elementwise_fma(__builtin_elementwise_fma(-q, e, v), r, q);
+}
 __device__ __forceinline__ v2f env_apply(v2f v, v2f e) { return v2f{__fdiv_rn(v.x, e.x), __fdiv_rn(v.y, e.y)}; }
 __device__ __forceinline__ float env_apply(float v, float e) { return __fdiv_rn(v, e); }
 #else
-__device__ __forceinline__ float fast_abs(v2f s) { return __builtin_amdgcn_sqrtf(fmaf(s.x, s.x, s.y * s.y)); }
-__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 // the envelope table holds 1 / envelope
+__device__ __forceinline__ v2f env_rcp(v2f e) { return e; }
+__device__ __forceinline__ v2f env_apply_r(v2f v, v2f e, v2f) { return v * e; }
 __device__ __forceinline__ v2f env_apply(v2f v, v2f e) { return v * e; }
 __device__ __forceinline__ float env_apply(float v, float e) { return v * e; }
 #endif
@@ -851,8 +916,7 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, v2f& xs, float 
     const v2f s = v2f{fmaf(-a.coef, p.x, r.x), fmaf(-a.coef, p.y, r.y)};
     p = s;
 #if SPECINV_IEEE
-    const float den = fast_abs(s) + 1e-16f;
-    return v2f{__fdiv_rn(s.x * m, den) * a.inv_scale, __fdiv_rn(s.y * m, den) * a.inv_scale};
+    return ((s * m) * ref_rcp_abs(ref_norm2(s))) * a.inv_scale;
 #elif SPECINV_RSQ
     return s * ((m * proj_rsq(s)) * a.inv_scale);
 #else
@@ -866,8 +930,10 @@ __device__ __forceinline__ v2f update_bin(v2f r, v2f& p, v2f& u, v2f& xs, float 
     const v2f un = y - z;
     v2f xn = z - un;
 #if SPECINV_IEEE
-    const float den = fast_abs(xn) + 1e-16f;
-    xn = v2f{__fdiv_rn(xn.x * m, den), __fdiv_rn(xn.y * m, den)};
+    {
+#pragma clang fp contract(off)   // X is rounded before Y = X + U is formed (:473-475): no multiply-add across the two
+      xn = (xn * m) * ref_rcp_abs(ref_norm2(xn));
+    }
 #elif SPECINV_RSQ
     {
 #pragma clang fp contract(off)   // X is rounded before Y = X + U is formed (:473-475): no multiply-add across the two
@@ -1173,5 +1239,5 @@ __global__ void k_hop_td(HopArgs s);
 template <int R>
 __global__ void k_hop_inverse(HopInvArgs a);
 
-}  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
+}  // namespace SI_FAST_NS (fast, or fast_approx in the approximate-projection units)
 }  // namespace specinv

@@ -4,21 +4,21 @@
 #include "fast_core.h"
 #include "kernels_layout.h"
 
-// kernel tables of the exact-projection units (tu_exact_*.hip): nullptr where there is no such kernel
+// kernel tables of the approximate-projection units (tu_approx_*.hip): nullptr where there is no such kernel
 extern "C" {
-__attribute__((visibility("hidden"))) const void* specinv_exact_fused_a(int R, int OV, int mode, int eval, int tuned4);
-__attribute__((visibility("hidden"))) const void* specinv_exact_fused_b(int R, int OV, int mode, int eval, int tuned4);
-__attribute__((visibility("hidden"))) const void* specinv_exact_fused_c(int R, int OV, int mode, int eval, int tuned4);
-__attribute__((visibility("hidden"))) const void* specinv_exact_td(int R, int OV, int early, int eval, int tuned4);
-__attribute__((visibility("hidden"))) const void* specinv_exact_frame(int family, int R, int a, int b);
+__attribute__((visibility("hidden"))) const void* specinv_approx_fused_a(int R, int OV, int mode, int eval, int tuned4);
+__attribute__((visibility("hidden"))) const void* specinv_approx_fused_b(int R, int OV, int mode, int eval, int tuned4);
+__attribute__((visibility("hidden"))) const void* specinv_approx_fused_c(int R, int OV, int mode, int eval, int tuned4);
+__attribute__((visibility("hidden"))) const void* specinv_approx_td(int R, int OV, int early, int eval, int tuned4);
+__attribute__((visibility("hidden"))) const void* specinv_approx_frame(int family, int R, int a, int b);
 }
 
 namespace specinv {
 
-inline const void* exact_fused(int R, int OV, int mode, int eval, int tuned4) {
-  const void* fn = specinv_exact_fused_a(R, OV, mode, eval, tuned4);
-  if (!fn) fn = specinv_exact_fused_b(R, OV, mode, eval, tuned4);
-  if (!fn) fn = specinv_exact_fused_c(R, OV, mode, eval, tuned4);
+inline const void* approx_fused(int R, int OV, int mode, int eval, int tuned4) {
+  const void* fn = specinv_approx_fused_a(R, OV, mode, eval, tuned4);
+  if (!fn) fn = specinv_approx_fused_b(R, OV, mode, eval, tuned4);
+  if (!fn) fn = specinv_approx_fused_c(R, OV, mode, eval, tuned4);
   return fn;
 }
 
@@ -60,7 +60,7 @@ struct FastState {
   bool hopk = false;
   bool xform_ok = false;
   bool keep_state = false;
-  bool exact = false;
+  bool exact = true;
   int n_partials = 0;
   int setup(const specinv_stft_cfg&, const std::vector<T>&, int64_t, int) { return SPECINV_OK; }
   void geometry(int out[4]) const { out[0] = out[1] = out[2] = out[3] = 0; }
@@ -118,9 +118,10 @@ struct FastState<float> {
   // ADMM carries Y = X + U in Pb (FastArgs).  X and U themselves are only written when the caller has asked for them
   // (specinv_plan_keep_state), by the last iteration of every iterate() call.
   bool keep_state = false, xu_valid = false;
-  // the projection as the reference rounds it (correctly rounded sqrt / divisions, division by the envelope): the kernels of the
-  // tu_exact_*.hip units, 10 % slower on the headline kernel (specinv_plan_set_exact)
-  bool exact = false;
+  // the projection in the reference's operation order with correctly rounded factors and a true division by the envelope (the
+  // default kernels); false: the approximate copies of the tu_approx_*.hip units, 3 % faster on the headline step
+  // (specinv_plan_set_exact)
+  bool exact = true;
   FastBuf Xb, Xmid, Ub, Umid;
   // Griffin-Lim on k_fused4_td: the momentum state is the signal z (zb), Pb keeps the starting spectrum c0
   bool td = false;
@@ -283,6 +284,8 @@ struct FastState<float> {
     // (n_fft 4096 runs one wave per SIMD: its vector latency, not the state traffic, is what bounds it there - the signal form
     // measured 0.360 against 0.340 ms per iteration and is not used)
     td = md == fast::MODE_GLA && (!semi || hopk) && !use_template && !keep_state && RR <= 16;
+    // (the reference-chain build leaves the real-FFT split unscaled, which is exact only for a power-of-two fwd_scale / 2)
+    if (exact && pl.cfg.normalized && !hopk) td = false;
     // k_hop_td writes two signals and re-reads z_t where k_hop writes one: at large hops its emission loop overtakes the saved state
     // traffic.  Measured crossovers (late iterations, 65 536 frames, tools/r02_hop_td2.sh), emission two samples at a time (even hop,
     // padding and length) / one at a time: n_fft 2048: wins up to hop 768 (0.350 vs 0.367 ms), loses at 1000 / wins at 333, loses at
@@ -427,7 +430,7 @@ struct FastState<float> {
     }
     if (OV == 4) fn = (const void*)fast::k_fused_istft<RR, 4>;
     if (OV == 2) fn = (const void*)fast::k_fused_istft<RR, 2>;
-    if (exact && fn != nullptr) fn = exact_fused(RR, OV, 2, 0, 0);
+    if (!exact && fn != nullptr) fn = approx_fused(RR, OV, 2, 0, 0);
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&a};
@@ -572,7 +575,7 @@ struct FastState<float> {
       if (OV == 4) fn = (const void*)fast::k_fused<RR, 4, MODE, EVAL>;
     }
     if (OV == 2) fn = (const void*)fast::k_fused<RR, 2, MODE, EVAL>;
-    if (exact && fn != nullptr) fn = exact_fused(RR, OV, MODE, EVAL ? 1 : 0, ((RR == 8 || RR == 16) && OV == 4 && !use_template) ? 1 : 0);
+    if (!exact && fn != nullptr) fn = approx_fused(RR, OV, MODE, EVAL ? 1 : 0, ((RR == 8 || RR == 16) && OV == 4 && !use_template) ? 1 : 0);
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     const int wgw = fused_wgw();
     const size_t lds_used = G::lds_bytes(wgw);
@@ -627,7 +630,7 @@ struct FastState<float> {
                        else { if (OV == 4) fn = td_kernel<RR, 4>(early, ev); }
                        if (OV == 2) fn = td_kernel<RR, 2>(early, ev);
                      });
-    if (exact && fn != nullptr) fn = specinv_exact_td(R, OV, early ? 1 : 0, ev ? 1 : 0, ((R == 8 || R == 16) && OV == 4) ? 1 : 0);
+    if (!exact && fn != nullptr) fn = specinv_approx_td(R, OV, early ? 1 : 0, ev ? 1 : 0, ((R == 8 || R == 16) && OV == 4) ? 1 : 0);
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no fused kernel for n_fft / hop = %d", OV);
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used));
     fast::FastArgs args = a;
@@ -711,8 +714,8 @@ struct FastState<float> {
     s.hop = pl.cfg.hop_length;
     s.pad = pl.pad;
     const size_t lds = G::lds_bytes(4);
-    const void* fn = exact ? specinv_exact_frame(0, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_semi<RR, MODE, EVAL>;
-    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no exact-projection frame kernel for this shape");
+    const void* fn = !exact ? specinv_approx_frame(0, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_semi<RR, MODE, EVAL>;
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no approximate-projection frame kernel for this shape");
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&s};
     SI_HIP(hipLaunchKernel(fn, dim3(semi_grid), dim3(256), kargs, lds, pl.stream));
@@ -750,8 +753,8 @@ struct FastState<float> {
     s.hop = hop;
     s.pad = pl.pad;
     const size_t lds = G::lds_bytes(wgw) + (size_t)wgw * G::N * sizeof(float);
-    const void* fn = exact ? specinv_exact_frame(1, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_hop<RR, MODE, EVAL>;
-    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no exact-projection chunked frame kernel for this shape");
+    const void* fn = !exact ? specinv_approx_frame(1, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_hop<RR, MODE, EVAL>;
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no approximate-projection chunked frame kernel for this shape");
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&s};
     SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds, pl.stream));
@@ -804,8 +807,8 @@ struct FastState<float> {
     const size_t lds = G::lds_bytes(wgw) + (size_t)wgw * G::N * sizeof(float);
     const void* fn = early ? (ev ? (const void*)fast::k_hop_td<RR, true, true> : (const void*)fast::k_hop_td<RR, true, false>)
                            : (ev ? (const void*)fast::k_hop_td<RR, false, true> : (const void*)fast::k_hop_td<RR, false, false>);
-    if (exact) fn = specinv_exact_frame(2, RR, early ? 1 : 0, ev ? 1 : 0);
-    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no exact-projection chunked frame kernel for this shape");
+    if (!exact) fn = specinv_approx_frame(2, RR, early ? 1 : 0, ev ? 1 : 0);
+    SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no approximate-projection chunked frame kernel for this shape");
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&s};
     SI_HIP(hipLaunchKernel(fn, dim3((n_waves + wgw - 1) / wgw), dim3(64 * wgw), kargs, lds, pl.stream));
@@ -896,7 +899,7 @@ struct FastState<float> {
         // (kernels_fast_td.h: k_eval_td; SPECINV_EVAL_KERNEL=0: the fused evaluating variant)
         const char* eval_env = ev ? getenv("SPECINV_EVAL_KERNEL") : nullptr;
         const bool eval_kernel = !(eval_env && eval_env[0] == '0');
-        if (ev && eval_kernel && !exact && OV == 4 && (R == 8 || R == 16)) {
+        if (ev && eval_kernel && OV == 4 && (R == 8 || R == 16)) {
           SI_TRY(launch_td(pl, a, early, false));
           const void* fn = R == 16 ? (const void*)fast::k_eval_td<16, 4> : (const void*)fast::k_eval_td<8, 4>;
           const size_t lds_used = R == 16 ? fast::Geo<16>::lds_bytes(4) : fast::Geo<8>::lds_bytes(4);

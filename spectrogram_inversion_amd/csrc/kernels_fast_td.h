@@ -65,9 +65,9 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // The synthesis window carries the inverse transform's scale (a second table): one multiplication less per bin pair in the
-  // projection; 1 / n_fft is a power of two, so nothing changes in the result (normalized=True: one rounding moves).  The
-  // exact-projection build keeps the reference's order of operations.
-  constexpr bool WSCALE = !SPECINV_IEEE && SPECINV_RSQ;
+  // projection; 1 / n_fft is a power of two, so nothing changes in the result (normalized=True never takes this kernel when the
+  // reference's operation chain is asked for: FastState::begin_t).
+  constexpr bool WSCALE = SPECINV_IEEE || SPECINV_RSQ;
   v2f* lds_win = reinterpret_cast<v2f*>(smem);
   v2f* lds_wins = WSCALE ? lds_win + M : lds_win;
   v2f* lds_tw1 = lds_win + 2 * M;      // (the host reserves both tables for every build: Geo::lds_bytes_td)
@@ -158,10 +158,14 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
   // every frame (the evaluating variant has no registers to spare and keeps loading)
   constexpr bool ENVREG = !EVAL && SPECINV_TD_ENVREG;
   v2f envc[ENVREG ? QU : 1];
+  v2f envr[(ENVREG && SPECINV_IEEE) ? QU : 1];     // (reference chain: the envelope block and its correctly rounded reciprocal)
   if (ENVREG) {
     const v2f* e0 = reinterpret_cast<const v2f*>(a.inv_env + (long long)(NB - PB) * HOP);
 #pragma unroll
-    for (int i = 0; i < QU; ++i) envc[i] = e0[64u * i + ulane];
+    for (int i = 0; i < QU; ++i) {
+      envc[i] = e0[64u * i + ulane];
+      if (SPECINV_IEEE) envr[SPECINV_IEEE ? i : 0] = env_rcp(envc[i]);
+    }
   }
 #if SPECINV_TD_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -282,11 +286,97 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
 
     // ---- per pair: split -> (+ c0 term) -> projection -> fold back
     v2f back[H];
+#if SPECINV_IEEE && !SPECINV_REFBREADTH
 #pragma unroll
     for (int j = 0; j < H; ++j) {
       const v2f wk = WKREG ? wkr[WKREG ? j : 0] : pair_twiddle<R>(wn, j);
       v2f sk, sm;
-      if (SPECINV_IEEE || !SPECINV_RSQ) {
+      td_split_raw<R>(z[j], rc[R - 1 - j - H], wk, sk, sm);
+      if (EARLY) {
+        sk = __builtin_elementwise_fma(v2f{pp[j].x, pp[j].y}, v2f{tds_raw, tds_raw}, sk);
+        sm = __builtin_elementwise_fma(v2f{pp[j].z, pp[j].w}, v2f{tds_raw, tds_raw}, sm);
+      }
+      const v2f rr = ref_rcp_abs2(v2f{ref_norm2(sk, 4.0f * kRefFloor), ref_norm2(sm, 4.0f * kRefFloor)}, 2e-16f);
+      const v2f mp = (j & 1) ? v2f{mm[j / 2].z, mm[j / 2].w} : v2f{mm[j / 2].x, mm[j / 2].y};
+      v2f ak = scale_lo(scale_lo(sk, mp), rr);
+      v2f am = scale_hi(scale_hi(sm, mp), rr);
+      if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+        ak.y = 0.0f;
+        am.y = 0.0f;
+      }
+      const v2f e2i = add_conj(ak, am);
+      const v2f o2i = cmulc(sub_conj(ak, am), wk);
+      z[j] = add_i(e2i, o2i);
+      back[j] = conj_sub_i(e2i, o2i);
+    }
+#elif SPECINV_IEEE
+    // The reference's operation order (ref_rcp_abs2, fast_core.h), written breadth-first over the frame's H pairs: every step of
+    // the chain of dependent packed operations is issued for all pairs before the next one, so that no instruction waits on the
+    // one just before it (the compiler pads such pairs with s_nop: 44 in the frame loop instead of 106).
+    {
+      v2f sk[H], sm[H], tt[H], yy[H], hh[H];
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const v2f wk = WKREG ? wkr[WKREG ? j : 0] : pair_twiddle<R>(wn, j);
+        td_split_raw<R>(z[j], rc[R - 1 - j - H], wk, sk[j], sm[j]);
+        if (EARLY) {
+          sk[j] = __builtin_elementwise_fma(v2f{pp[j].x, pp[j].y}, v2f{tds_raw, tds_raw}, sk[j]);
+          sm[j] = __builtin_elementwise_fma(v2f{pp[j].z, pp[j].w}, v2f{tds_raw, tds_raw}, sm[j]);
+        }
+        tt[j] = v2f{ref_norm2(sk[j], 4.0f * kRefFloor), ref_norm2(sm[j], 4.0f * kRefFloor)};
+      }
+#pragma unroll
+      for (int j = 0; j < H; ++j) yy[j] = v2f{__builtin_amdgcn_rsqf(tt[j].x), __builtin_amdgcn_rsqf(tt[j].y)};
+#if SPECINV_REFCHAIN == 1
+#pragma unroll
+      for (int j = 0; j < H; ++j) hh[j] = tt[j] * yy[j];
+#pragma unroll
+      for (int j = 0; j < H; ++j) tt[j] = __builtin_elementwise_fma(-hh[j], hh[j], tt[j]);        // residual t - h^2
+#pragma unroll
+      for (int j = 0; j < H; ++j) hh[j] = __builtin_elementwise_fma(tt[j], yy[j] * 0.5f, hh[j]);  // RN(sqrt t)
+#pragma unroll
+      for (int j = 0; j < H; ++j) hh[j] = hh[j] + 2e-16f;                                           // (+ 1e-16 at the true scale)
+#pragma unroll
+      for (int j = 0; j < H; ++j) tt[j] = __builtin_elementwise_fma(-hh[j], yy[j], v2f{1.0f, 1.0f});
+#pragma unroll
+      for (int j = 0; j < H; ++j) yy[j] = __builtin_elementwise_fma(tt[j], yy[j], yy[j]);          // RN(1 / (|s| + 1e-16))
+#else
+      // one Newton step on y ~ t^-1/2: the correctly rounded 1 / |s| in all but ~1e-6 of the cases (ONE rounding of the exact
+      // value where the reference rounds |s| and then its reciprocal); the guard 1e-16 only matters below |s| = 3e-9
+#pragma unroll
+      for (int j = 0; j < H; ++j) hh[j] = tt[j] * yy[j];
+#pragma unroll
+      for (int j = 0; j < H; ++j) tt[j] = __builtin_elementwise_fma(-hh[j], yy[j], v2f{1.0f, 1.0f});
+#pragma unroll
+      for (int j = 0; j < H; ++j) yy[j] = __builtin_elementwise_fma(yy[j] * 0.5f, tt[j], yy[j]);
+#endif
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const v2f mp = (j & 1) ? v2f{mm[j / 2].z, mm[j / 2].w} : v2f{mm[j / 2].x, mm[j / 2].y};
+        sk[j] = scale_lo(sk[j], mp);
+        sm[j] = scale_hi(sm[j], mp);
+      }
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const v2f wk = WKREG ? wkr[WKREG ? j : 0] : pair_twiddle<R>(wn, j);
+        v2f ak = scale_lo(sk[j], yy[j]);
+        v2f am = scale_hi(sm[j], yy[j]);
+        if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
+          ak.y = 0.0f;
+          am.y = 0.0f;
+        }
+        const v2f e2i = add_conj(ak, am);
+        const v2f o2i = cmulc(sub_conj(ak, am), wk);
+        z[j] = add_i(e2i, o2i);
+        back[j] = conj_sub_i(e2i, o2i);
+      }
+    }
+#else
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const v2f wk = WKREG ? wkr[WKREG ? j : 0] : pair_twiddle<R>(wn, j);
+      v2f sk, sm;
+      if (!SPECINV_RSQ) {
         td_split<R>(z[j], rc[R - 1 - j - H], wk, half_scale, sk, sm);
         if (EARLY) {
           sk = v2f{fmaf(a.tds, pp[j].x, sk.x), fmaf(a.tds, pp[j].y, sk.y)};
@@ -295,7 +385,9 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       } else {
         // nothing but the projection reads the bins, and it divides by their magnitude: the 1/2 fwd_scale of the split is left
         // out (late launches) or moved onto the c0 term's factor (early launches: S / s = raw + (tds / s) c0, one packed
-        // multiply-add per bin)
+        // multiply-add per bin).  With the reference's operation chain (SPECINV_IEEE) this is exact, not approximate: the
+        // kernel is only taken for fwd_scale = 1, the factor 2 scales every intermediate result without a rounding, and the
+        // guard / floor constants are doubled / quadrupled with it.
         td_split_raw<R>(z[j], rc[R - 1 - j - H], wk, sk, sm);
         if (EARLY) {
           sk = __builtin_elementwise_fma(v2f{pp[j].x, pp[j].y}, v2f{tds_raw, tds_raw}, sk);
@@ -304,11 +396,7 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       }
       const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
       const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
-#if SPECINV_IEEE
-      const float dk = fast_abs(sk) + 1e-16f, dq = fast_abs(sm) + 1e-16f;
-      v2f ak = v2f{__fdiv_rn(sk.x * mk, dk) * a.inv_scale, __fdiv_rn(sk.y * mk, dk) * a.inv_scale};
-      v2f am = v2f{__fdiv_rn(sm.x * mq, dq) * a.inv_scale, __fdiv_rn(sm.y * mq, dq) * a.inv_scale};
-#elif SPECINV_RSQ
+#if SPECINV_RSQ
       // the projection's factors (proj_rsq, fast_core.h) of the pair's two bins, formed and applied as packed operations
       const v2f inv = v2f{proj_rsq(sk), proj_rsq(sm)};
       const v2f mi = v2f{mk, mq} * inv;                       // (the inverse scale rides on the synthesis window)
@@ -328,13 +416,13 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       z[j] = add_i(e2i, o2i);
       back[j] = conj_sub_i(e2i, o2i);
     }
+#endif
     v2f zmid;
     {
       v2f smid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
       if (EARLY) smid = v2f{fmaf(a.tds, pmid.x, smid.x), fmaf(a.tds, pmid.y, smid.y)};
 #if SPECINV_IEEE
-      const float dn = fast_abs(smid) + 1e-16f;
-      const v2f am = v2f{__fdiv_rn(smid.x * mmid, dn) * a.inv_scale, __fdiv_rn(smid.y * mmid, dn) * a.inv_scale};
+      const v2f am = (smid * mmid) * ref_rcp_abs(ref_norm2(smid));
 #elif SPECINV_RSQ
       const v2f am = smid * (mmid * proj_rsq(smid));
 #else
@@ -366,22 +454,30 @@ __device__ __forceinline__ void fused_td_body(const FastArgs& a) {
       // its own that also waits for it (the empty asm reads the registers): left to a select per value the compiler puts each
       // load behind a branch and an unconditional s_waitcnt vmcnt(0) after the join, which on gfx950 also waits for the stores
       // just issued - three store round trips per frame in the steady state.
-      v2f ev[QU];
+      v2f ev[QU], er[QU];
       if (!ENVREG) {
 #pragma unroll
-        for (int i = 0; i < QU; ++i) ev[i] = envp[64u * i + ulane];
+        for (int i = 0; i < QU; ++i) {
+          ev[i] = envp[64u * i + ulane];
+          er[i] = env_rcp(ev[i]);
+        }
       } else if (t >= NB) {
 #pragma unroll
-        for (int i = 0; i < QU; ++i) ev[i] = envc[ENVREG ? i : 0];
+        for (int i = 0; i < QU; ++i) {
+          ev[i] = envc[ENVREG ? i : 0];
+          er[i] = envr[(ENVREG && SPECINV_IEEE) ? i : 0];
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < QU; ++i) ev[i] = envp[64u * i + ulane];
 #pragma unroll
         for (int i = 0; i < QU; ++i) asm volatile("" : "+v"(ev[i]));
+#pragma unroll
+        for (int i = 0; i < QU; ++i) er[i] = env_rcp(ev[i]);
       }
 #pragma unroll
       for (int i = 0; i < QU; ++i) {
-        const v2f xv = env_apply(acc[i] + z[i], ev[i]);
+        const v2f xv = env_apply_r(acc[i] + z[i], ev[i], er[i]);
         const v2f zv = v2f{fmaf(nlr, zold[i].x, xv.x), fmaf(nlr, zold[i].y, xv.y)};
         if (!(SPECINV_TD_ABLATE & 2) || zv.x == 1.2345e30f) {
           if (write_x) xo[64u * i + ulane] = xv;
@@ -571,5 +667,5 @@ __global__ __launch_bounds__(256, SPECINV_EVAL_WAVES) void k_eval_td(FastArgs a)
   }
 }
 
-}  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
+}  // namespace SI_FAST_NS (fast, or fast_approx in the approximate-projection units)
 }  // namespace specinv

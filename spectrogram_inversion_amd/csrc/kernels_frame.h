@@ -467,9 +467,11 @@ __device__ __forceinline__ void semi_frame_td(const FastArgs& a, long long fi, c
     const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
     const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
 #if SPECINV_IEEE
-    const float dk = fast_abs(sk) + 1e-16f, dq = fast_abs(sm) + 1e-16f;
-    v2f ak = v2f{__fdiv_rn(sk.x * mk, dk) * a.inv_scale, __fdiv_rn(sk.y * mk, dk) * a.inv_scale};
-    v2f am = v2f{__fdiv_rn(sm.x * mq, dq) * a.inv_scale, __fdiv_rn(sm.y * mq, dq) * a.inv_scale};
+    // (s m) r with r the correctly rounded 1 / |s|: the reference's operation order (ref_rcp_abs2, fast_core.h)
+    const v2f rr = ref_rcp_abs2(v2f{ref_norm2(sk), ref_norm2(sm)});
+    const v2f mp = v2f{mk, mq};
+    v2f ak = scale_lo(scale_lo(sk, mp), rr) * a.inv_scale;
+    v2f am = scale_hi(scale_hi(sm, mp), rr) * a.inv_scale;
 #elif SPECINV_RSQ
     const v2f mi = (v2f{mk, mq} * v2f{proj_rsq(sk), proj_rsq(sm)}) * a.inv_scale;
     v2f ak = scale_lo(sk, mi);
@@ -493,8 +495,7 @@ __device__ __forceinline__ void semi_frame_td(const FastArgs& a, long long fi, c
     v2f smid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
     if (EARLY) smid = v2f{fmaf(a.tds, pmid.x, smid.x), fmaf(a.tds, pmid.y, smid.y)};
 #if SPECINV_IEEE
-    const float dn = fast_abs(smid) + 1e-16f;
-    const v2f am = v2f{__fdiv_rn(smid.x * mmid, dn) * a.inv_scale, __fdiv_rn(smid.y * mmid, dn) * a.inv_scale};
+    const v2f am = ((smid * mmid) * ref_rcp_abs(ref_norm2(smid))) * a.inv_scale;
 #elif SPECINV_RSQ
     const v2f am = smid * ((mmid * proj_rsq(smid)) * a.inv_scale);
 #else
@@ -763,5 +764,5 @@ __global__ __launch_bounds__(512, 1) void k_hop_inverse(HopInvArgs a) {
 
 
 
-}  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
+}  // namespace SI_FAST_NS (fast, or fast_approx in the approximate-projection units)
 }  // namespace specinv

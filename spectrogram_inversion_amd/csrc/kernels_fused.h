@@ -60,10 +60,14 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
   double sd = 0.0, so = 0.0;
   // one block of the envelope reciprocal, periodic in the hop from hop-block 3 on (kernels_fast_td.h), kept in registers
   v2f envc[SPECINV_K4_ENVREG ? QU : 1];
+  v2f envr[(SPECINV_K4_ENVREG && SPECINV_IEEE) ? QU : 1];   // (reference chain: the envelope and its correctly rounded reciprocal)
   if (SPECINV_K4_ENVREG) {
     const v2f* e0 = reinterpret_cast<const v2f*>(a.inv_env + (long long)HOP);
 #pragma unroll
-    for (int i = 0; i < QU; ++i) envc[i] = e0[64u * i + ulane];
+    for (int i = 0; i < QU; ++i) {
+      envc[i] = e0[64u * i + ulane];
+      if (SPECINV_IEEE) envr[SPECINV_IEEE ? i : 0] = env_rcp(envc[i]);
+    }
   }
 #if SPECINV_TW_REGS
   TwRegs<R> twr;
@@ -283,21 +287,29 @@ __global__ __launch_bounds__((SPECINV_R8_W3 && R == 8) ? 768 : 64 * SPECINV_WGW,
       v2f* outp = reinterpret_cast<v2f*>(orow + o0);
       // (the envelope block: register copy, or - first frames of an item - loaded and waited for in an arm of its own; see
       // fused_td_body, kernels_fast_td.h)
-      v2f ev[QU];
+      v2f ev[QU], er[QU];
       if (!SPECINV_K4_ENVREG) {
 #pragma unroll
-        for (int i = 0; i < QU; ++i) ev[i] = envp[64u * i + ulane];
+        for (int i = 0; i < QU; ++i) {
+          ev[i] = envp[64u * i + ulane];
+          er[i] = env_rcp(ev[i]);
+        }
       } else if (t >= 3) {
 #pragma unroll
-        for (int i = 0; i < QU; ++i) ev[i] = envc[SPECINV_K4_ENVREG ? i : 0];
+        for (int i = 0; i < QU; ++i) {
+          ev[i] = envc[SPECINV_K4_ENVREG ? i : 0];
+          er[i] = envr[(SPECINV_K4_ENVREG && SPECINV_IEEE) ? i : 0];
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < QU; ++i) ev[i] = envp[64u * i + ulane];
 #pragma unroll
         for (int i = 0; i < QU; ++i) asm volatile("" : "+v"(ev[i]));
+#pragma unroll
+        for (int i = 0; i < QU; ++i) er[i] = env_rcp(ev[i]);
       }
 #pragma unroll
-      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply(acc[i] + z[i], ev[i]);
+      for (int i = 0; i < QU; ++i) outp[64u * i + ulane] = env_apply_r(acc[i] + z[i], ev[i], er[i]);
     }
 #if SPECINV_PRIO & 4
     __builtin_amdgcn_s_setprio(0);
@@ -674,5 +686,5 @@ __global__ __launch_bounds__(256, R >= 32 ? 1 : SPECINV_MINWAVES) void k_fused_i
 }
 
 
-}  // namespace SI_FAST_NS (fast, or fast_exact in the exact-projection units)
+}  // namespace SI_FAST_NS (fast, or fast_approx in the approximate-projection units)
 }  // namespace specinv

@@ -18,7 +18,7 @@ struct PlanBase {
   hipStream_t stream = nullptr;
   Method method = Method::None;
   bool force_generic = false;
-  bool exact = false;        // projection / envelope division rounded like the reference (specinv_plan_set_exact)
+  bool exact = true;         // projection / envelope division in the reference's operation order (specinv_plan_set_exact; 0: approximations)
   bool keep_state = false;   // ADMM: the last iteration of every iterate() also writes X and U (specinv_plan_keep_state)
   int64_t dev_bytes = 0;   // device memory held by the plan's buffers (account_bytes)
 

@@ -1,13 +1,13 @@
-// k_semi / k_hop / k_hop_td with the exact projection.
-// The exact-projection copy of these kernels (fast_core.h): correctly rounded sqrt / divisions and a true division by the envelope,
-// the reference's own operations (torch_specinv/methods.py:132,246-247), in namespace specinv::fast_exact.  The host side takes
-// the kernels' addresses from the table function below (specinv_plan_set_exact).
-#define SPECINV_IEEE 1
-#define SI_FAST_NS fast_exact
+// k_semi / k_hop / k_hop_td with the approximate projection (opt-in).
+// The second copy of these kernels (fast_core.h, SPECINV_IEEE=0): m * v_rsq_f32(|s|^2 + 1e-32) in the projection and a multiplication
+// by 1 / envelope instead of the reference's operation order with correctly rounded factors (the default build), in namespace
+// specinv::fast_approx.  The host side takes the kernels' addresses from the table function below (specinv_plan_set_exact(plan, 0)).
+#define SPECINV_IEEE 0
+#define SI_FAST_NS fast_approx
 #include "kernels_frame.h"
 
 namespace specinv {
-namespace fast_exact {
+namespace fast_approx {
 
 template __global__ void k_semi<4, MODE_GLA, false>(SemiArgs);
 template __global__ void k_semi<4, MODE_GLA, true>(SemiArgs);
@@ -57,11 +57,11 @@ template __global__ void k_hop_td<16, false, true>(HopArgs);
 template __global__ void k_hop_td<16, true, false>(HopArgs);
 template __global__ void k_hop_td<16, true, true>(HopArgs);
 
-}  // namespace fast_exact
+}  // namespace fast_approx
 }  // namespace specinv
 
-extern "C" __attribute__((visibility("hidden"))) const void* specinv_exact_frame(int family /* 0 k_semi, 1 k_hop, 2 k_hop_td */, int R, int a /* mode, or early */, int b /* eval */) {
-  using namespace specinv::fast_exact;
+extern "C" __attribute__((visibility("hidden"))) const void* specinv_approx_frame(int family /* 0 k_semi, 1 k_hop, 2 k_hop_td */, int R, int a /* mode, or early */, int b /* eval */) {
+  using namespace specinv::fast_approx;
   if (family == 0 && R == 4 && a == 0 && b == 0) return (const void*)k_semi<4, MODE_GLA, false>;
   if (family == 0 && R == 4 && a == 0 && b == 1) return (const void*)k_semi<4, MODE_GLA, true>;
   if (family == 0 && R == 4 && a == 1 && b == 0) return (const void*)k_semi<4, MODE_ADMM, false>;

@@ -1,13 +1,13 @@
-// k_fused<R, OV> / k_fused_istft at n_fft 2048 with the exact projection.
-// The exact-projection copy of these kernels (fast_core.h): correctly rounded sqrt / divisions and a true division by the envelope,
-// the reference's own operations (torch_specinv/methods.py:132,246-247), in namespace specinv::fast_exact.  The host side takes
-// the kernels' addresses from the table function below (specinv_plan_set_exact).
-#define SPECINV_IEEE 1
-#define SI_FAST_NS fast_exact
+// k_fused<R, OV> / k_fused_istft at n_fft 2048 with the approximate projection (opt-in).
+// The second copy of these kernels (fast_core.h, SPECINV_IEEE=0): m * v_rsq_f32(|s|^2 + 1e-32) in the projection and a multiplication
+// by 1 / envelope instead of the reference's operation order with correctly rounded factors (the default build), in namespace
+// specinv::fast_approx.  The host side takes the kernels' addresses from the table function below (specinv_plan_set_exact(plan, 0)).
+#define SPECINV_IEEE 0
+#define SI_FAST_NS fast_approx
 #include "kernels_fused.h"
 
 namespace specinv {
-namespace fast_exact {
+namespace fast_approx {
 
 template __global__ void k_fused<16, 8, MODE_GLA, false>(FastArgs);
 template __global__ void k_fused<16, 8, MODE_GLA, true>(FastArgs);
@@ -25,11 +25,11 @@ template __global__ void k_fused<16, 2, MODE_ADMM, false>(FastArgs);
 template __global__ void k_fused<16, 2, MODE_ADMM, true>(FastArgs);
 template __global__ void k_fused_istft<16, 2>(FastArgs);
 
-}  // namespace fast_exact
+}  // namespace fast_approx
 }  // namespace specinv
 
-extern "C" __attribute__((visibility("hidden"))) const void* specinv_exact_fused_b(int R, int OV, int mode /* 0 GLA, 1 ADMM, 2 initial ISTFT */, int eval, int tuned4) {
-  using namespace specinv::fast_exact;
+extern "C" __attribute__((visibility("hidden"))) const void* specinv_approx_fused_b(int R, int OV, int mode /* 0 GLA, 1 ADMM, 2 initial ISTFT */, int eval, int tuned4) {
+  using namespace specinv::fast_approx;
   if (!tuned4 && R == 16 && OV == 8 && mode == 0 && eval == 0) return (const void*)k_fused<16, 8, MODE_GLA, false>;
   if (!tuned4 && R == 16 && OV == 8 && mode == 0 && eval == 1) return (const void*)k_fused<16, 8, MODE_GLA, true>;
   if (!tuned4 && R == 16 && OV == 8 && mode == 1 && eval == 0) return (const void*)k_fused<16, 8, MODE_ADMM, false>;

@@ -174,9 +174,10 @@ class Plan:
         _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))
 
     def set_exact(self, on=True):
-        """Round the magnitude projection and the envelope division exactly like the reference (correctly rounded sqrt /
-        divisions, torch_specinv/methods.py:132,246-247) instead of the hardware's approximate sqrt / reciprocal: the
-        float32 wave-level kernels' second instantiation (~10 % slower on the headline kernel).  Call before `gla_init` /
+        """The arithmetic of the magnitude projection and of the envelope division on the float32 wave-level kernels
+        (torch_specinv/methods.py:132,246-247).  True (the library's default): the reference's operation order, (S m) r with r the
+        correctly rounded 1 / |S|, and a correctly rounded division by the envelope; False: the approximate copies of the kernels
+        (S (m rsq(|S|^2)), multiplication by 1 / envelope; 3 % faster on the headline step).  Call before `gla_init` /
         `admm_init`: the next init picks the kernels (a running method keeps its own)."""
         _lib.check(self.lib.specinv_plan_set_exact(self._h, int(on)))
 
@@ -615,15 +616,16 @@ _EXACT = [None]
 
 def set_exact_projection(on: bool | None):
     """Module-level switch for the drop-in functions (their signatures are the reference's, so the choice cannot be an
-    argument): True = the projection and the envelope division rounded exactly like the reference on every plan the public
-    functions create from now on, False = the default fast arithmetic, None = follow the environment (SPECINV_EXACT=1)."""
+    argument): True = the reference's operation order in the projection and a true envelope division on every plan the public
+    functions create from now on (the default), False = the approximate kernels (3 % faster on the headline step),
+    None = follow the environment (SPECINV_EXACT=0 selects the approximations)."""
     _EXACT[0] = on
 
 
 def exact_projection() -> bool:
     if _EXACT[0] is not None:
         return bool(_EXACT[0])
-    return os.environ.get("SPECINV_EXACT", "0") == "1"
+    return os.environ.get("SPECINV_EXACT", "1") != "0"
 
 
 def trim_plan_cache():

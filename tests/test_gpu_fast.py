@@ -714,7 +714,7 @@ def test_chunk_triples_of_the_three_wave_kernel(monkeypatch, method):
 def test_evaluation_kernel_equals_the_fused_evaluating_variant(monkeypatch, n_fft, batch, frames):
     """An evaluating iteration on the headline shapes runs the plain kernel and then `k_eval_td` (x_t's transform and the metric
     sums as a kernel of its own); `SPECINV_EVAL_KERNEL=0` runs the fused evaluating variant `k_fused4_td<R, *, true>` instead
-    (what the exact-projection build always does).  Same operations in the same order: the same sums and the same iterates bit
+    (what the other overlaps do).  Same operations in the same order: the same sums and the same iterates bit
     for bit - early (+c0) and late launches, small launches and the C2 geometry."""
     hop = n_fft // 4
     rng = np.random.default_rng(n_fft + batch)

@@ -87,9 +87,33 @@ def test_phase_init(i):
 
 
 # ---- G2: griffin_lim ---------------------------------------------------------------------------------
+# g2's magnitudes are random (inconsistent): at 100 iterations of alpha = 0.3 ONE bin parts float32 runs.  Diagnosis
+# (tools/near_zero_event.py, profiles/r04_near_zero_event.txt): at iteration 95 the DC bin of frame 8 of item 0 - a REAL number -
+# passes zero: S = -8.5e-7 in float64 (3.5e-6 of its target magnitude, where the frame's typical ratio is 0.8), +7.6e-8 on the
+# float32 frame kernel.  The projection S m / |S| turns that into -m or +m: a sign flip of one bin, 1.3e-2 of that hop segment at
+# once, 2.6e-3 five iterations later, 4.9e-4 of the whole waveform at iteration 100 (the reference's own float32 and float64 runs
+# happen to fall on the same side).  Which side a kernel lands on is decided by 1e-7 of rounding in its FFT, not by the
+# projection's arithmetic: rounds 2 / 3 / 4 measured the event on the fused kernels with the approximate projection, on the frame
+# kernel with IEEE divisions and with one-rounding reciprocals, on the pre_spec kernel with two-rounding reciprocals
+# (tools/refchain_study.py, profiles/r04_refchain.txt); every other of the 45 strict-gate cases passes on every arithmetic.  The
+# cases listed here keep the segment-distribution form of the gate.
+STRICT_XFAIL = {(0.3, 100, "frame")}
+
+
+def _strict_or_segments(y, ref, gate, hop, key, err):
+    if key in STRICT_XFAIL:
+        seg = segment_errors(y, ref, hop)
+        assert np.quantile(seg, 0.75) < gate and seg.max() < 3e-2, (key, err, np.quantile(seg, 0.75), seg.max())
+    else:
+        assert err < gate, (key, err)
+
+
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 @pytest.mark.parametrize("it", [1, 10, 100])
 def test_gla_waveforms(alpha, it):
+    """The drop-in `griffin_lim` on its default arithmetic (round 4: the reference's operation order in the projection, a true
+    envelope division) against the reference's waveforms: the STRICT gate - rel-L2 <= 1e-4 (north-star bar) and within 6 x the
+    reference's own float32-vs-float64 noise - at 1, 10 and 100 iterations, and the spectral convergence to 1e-5."""
     g = load_golden("g2_gla")
     kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
     key = f"a{alpha}_it{it}"
@@ -97,45 +121,29 @@ def test_gla_waveforms(alpha, it):
     ref, ref64 = g["wave_" + key], g["wave64_" + key]
     noise = rel_l2(ref, ref64)
     assert y.shape == ref.shape
-    # gate: waveform rel-L2 <= 1e-4 (north-star bar), and within a small multiple of the reference's own
-    # float32-vs-float64 noise
     gate = min(1e-4, max(6 * noise, 3e-6))
-    if it < 100:
-        assert rel_l2(y, ref) < gate, (rel_l2(y, ref), noise)
-        return
-    # 100 iterations: a near-zero bin can send any two float32 runs apart around one frame (_util.segment_errors;
-    # tools/dbg_acc.py shows one such event at iteration ~93 of the alpha = 0.3 case for one of two builds that
-    # differ in instruction selection only; seven iterations later it has spread over ~12 of the 78 segments).
-    # Robust form of the same gate: three quarters of the hop-sized segments within it, none worse than a single
-    # flipped bin could make it, and the spectral convergence equal to 1e-5.
-    seg = segment_errors(y, ref, int(g["hop"]))
-    assert np.quantile(seg, 0.75) < gate, (np.quantile(seg, 0.75), noise)
-    assert seg.max() < 3e-2, seg.max()
-    w = g["window"]
-    a = oracle.args_helper(g["init"].shape[1], np.float32, hop_length=int(g["hop"]), window=w)
-    target = np.abs(g["init"])
-    sc_y = np.linalg.norm(np.abs(oracle.stft(y, a)) - target) / np.linalg.norm(target)
-    sc_ref = np.linalg.norm(np.abs(oracle.stft(ref, a)) - target) / np.linalg.norm(target)
-    assert abs(sc_y - sc_ref) < 1e-5, (sc_y, sc_ref)
+    # (a problem this small runs on the frame kernel; its one near-zero event keeps the segment form of the gate)
+    _strict_or_segments(y, ref, gate, int(g["hop"]), (alpha, it, "frame"), rel_l2(y, ref))
+    if it == 100:
+        w = g["window"]
+        a = oracle.args_helper(g["init"].shape[1], np.float32, hop_length=int(g["hop"]), window=w)
+        target = np.abs(g["init"])
+        sc_y = np.linalg.norm(np.abs(oracle.stft(y, a)) - target) / np.linalg.norm(target)
+        sc_ref = np.linalg.norm(np.abs(oracle.stft(ref, a)) - target) / np.linalg.norm(target)
+        assert abs(sc_y - sc_ref) < 1e-5, (sc_y, sc_ref)
 
 
-# which (alpha, path) cases of g2 at 100 iterations hold the STRICT gate with the exact projection.  g2's magnitudes are random
-# (inconsistent), so an isolated near-zero bin can still part two float32 runs - the exact arithmetic removes the library's share
-# of that (profiles/r02_ieee_study.txt: 17 of 18 cases with the IEEE build; measured again in round 3 on the shipped exact kernels:
-# 17 of 18, the one left - the frame kernel at alpha 0.3 / 100 iterations, 4.9e-4 - is such an event: the fused kernels with the same
-# arithmetic pass it, and the case keeps the segment-distribution gate of `test_gla_waveforms`).
-EXACT_STRICT_XFAIL = {(0.3, 100, "frame")}
-
-
+@pytest.mark.parametrize("exact", [True, False])
 @pytest.mark.parametrize("path", ["frame", "fused", "fused_prespec"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 @pytest.mark.parametrize("it", [10, 100])
-def test_gla_waveforms_exact_projection(alpha, it, path, monkeypatch):
-    """`specinv_plan_set_exact` / `set_exact_projection(True)`: the magnitude projection and the envelope division rounded like the
-    reference's own operations (correctly rounded sqrt and divisions, torch_specinv/methods.py:132,246-247) on the float32
-    wave-level kernels - the frame kernel (default for a problem this small), the signal-form fused kernel and the fused kernel on
-    pre_spec.  The g2 waveforms after 10 and 100 iterations against the reference to the STRICT gate min(1e-4, 6 x its own
-    float32-vs-float64 noise), where the default arithmetic needs the segment statistics of `test_gla_waveforms`."""
+def test_gla_waveforms_every_kernel_and_arithmetic(alpha, it, path, exact, monkeypatch):
+    """The g2 waveforms after 10 and 100 iterations on each float32 wave-level kernel - the frame kernel (default for a problem this
+    small), the signal-form fused kernel, the fused kernel on pre_spec - with the default arithmetic (`set_exact(True)`: the
+    reference's operation order, (S m) r with r the correctly rounded 1 / |S|, torch_specinv/methods.py:246-247; a true division by
+    the envelope, :132) and with the approximate copies (`set_exact(False)`).  Exact arithmetic: the STRICT gate
+    min(1e-4, 6 x the reference's float32-vs-float64 noise), the one near-zero event excepted (STRICT_XFAIL).  Approximate
+    arithmetic: the strict gate at 10 iterations, the segment-distribution form at 100."""
     from spectrogram_inversion_amd.plan import Plan
     g = load_golden("g2_gla")
     hop, w = int(g["hop"]), torch.from_numpy(g["window"])
@@ -147,7 +155,7 @@ def test_gla_waveforms_exact_projection(alpha, it, path, monkeypatch):
     if path != "frame":
         monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")
     p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], torch.float32, dev())
-    p.set_exact(True)
+    p.set_exact(exact)
     p.keep_state(path == "fused_prespec")
     p.gla_init(init, None, alpha)
     want = {"frame": "k_semi", "fused": "k_fused_td", "fused_prespec": "k_fused"}[path]
@@ -155,40 +163,43 @@ def test_gla_waveforms_exact_projection(alpha, it, path, monkeypatch):
     p.run(it, 10, 0.0, "sc")
     y = N(p.wave())
     err = rel_l2(y, ref)
-    if (alpha, it, path) in EXACT_STRICT_XFAIL:
+    if exact or it < 100:
+        _strict_or_segments(y, ref, gate, hop, (alpha, it, path), err)
+    else:
         seg = segment_errors(y, ref, hop)
-        assert np.quantile(seg, 0.75) < gate and seg.max() < 3e-2, (err, np.quantile(seg, 0.75), seg.max())
-        return
-    assert err < gate, (alpha, it, path, err, rel_l2(y, ref64), noise)
+        assert np.quantile(seg, 0.75) < gate and seg.max() < 3e-2, (alpha, path, err, np.quantile(seg, 0.75), seg.max())
 
 
 def test_exact_projection_switch_of_the_drop_in_functions(monkeypatch):
-    """The module-level switch (the drop-in signatures are the reference's): `set_exact_projection(True)` / SPECINV_EXACT=1 make
-    `griffin_lim` / `ADMM` take the exact kernels - the result equals a plan run with `set_exact`, and differs from the default
-    arithmetic's in the last bits only."""
+    """The module-level switch (the drop-in signatures are the reference's): the default is the reference's operation order;
+    `set_exact_projection(False)` / SPECINV_EXACT=0 make `griffin_lim` / `ADMM` take the approximate kernels - the result equals a
+    plan run with `set_exact(False)` and differs from the default arithmetic's in the last bits only."""
     from spectrogram_inversion_amd.plan import Plan, clear_plan_cache
     g = load_golden("g2_gla")
     kw = dict(hop_length=int(g["hop"]), window=torch.from_numpy(g["window"]))
     init = T(g["init"])
-    fast = N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw))
+    monkeypatch.delenv("SPECINV_EXACT", raising=False)
+    exact = N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw))
+    exact_admm = N(si.ADMM(init, max_iter=3, rho=1.0, tol=0, verbose=False, **kw))
     try:
-        si.set_exact_projection(True)
-        exact = N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw))
-        exact_admm = N(si.ADMM(init, max_iter=3, rho=1.0, tol=0, verbose=False, **kw))
+        si.set_exact_projection(False)
+        approx = N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw))
+        approx_admm = N(si.ADMM(init, max_iter=3, rho=1.0, tol=0, verbose=False, **kw))
     finally:
         si.set_exact_projection(None)
-    monkeypatch.setenv("SPECINV_EXACT", "1")
-    assert np.array_equal(N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw)), exact)
+    monkeypatch.setenv("SPECINV_EXACT", "0")
+    assert np.array_equal(N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw)), approx)
     monkeypatch.delenv("SPECINV_EXACT")
-    assert np.array_equal(N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw)), fast)
-    p = Plan(args_helper(init, **kw), init.shape[0], init.shape[2], torch.float32, dev())
-    p.set_exact(True)
-    p.gla_init(init, None, 0.3)
-    p.iterate(10)
-    assert np.array_equal(N(p.wave()), exact)
-    assert not np.array_equal(exact, fast) and rel_l2(exact, fast) < 1e-5
+    assert np.array_equal(N(si.griffin_lim(init, max_iter=10, alpha=0.3, tol=0, verbose=False, **kw)), exact)
+    for on, want in ((True, exact), (False, approx)):
+        p = Plan(args_helper(init, **kw), init.shape[0], init.shape[2], torch.float32, dev())
+        p.set_exact(on)
+        p.gla_init(init, None, 0.3)
+        p.iterate(10)
+        assert np.array_equal(N(p.wave()), want)
+    assert not np.array_equal(exact, approx) and rel_l2(exact, approx) < 1e-5
     ref = oracle.admm(g["init"], max_iter=3, rho=1.0, tol=0, hop_length=int(g["hop"]), window=g["window"])
-    assert rel_l2(exact_admm, ref) < 1e-5
+    assert rel_l2(exact_admm, ref) < 1e-5 and rel_l2(approx_admm, ref) < 1e-5
 
 
 @pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "frame_lds_prespec", "generic", "float64"])

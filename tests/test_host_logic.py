@@ -304,16 +304,16 @@ def test_exact_projection_switch_and_progress_mode(monkeypatch):
     from spectrogram_inversion_amd import plan as P, methods as M
     monkeypatch.delenv("SPECINV_EXACT", raising=False)
     P.set_exact_projection(None)
-    assert P.exact_projection() is False
-    monkeypatch.setenv("SPECINV_EXACT", "1")
-    assert P.exact_projection() is True
-    P.set_exact_projection(False)
+    assert P.exact_projection() is True                     # (round 4: the reference's operation order is the default)
+    monkeypatch.setenv("SPECINV_EXACT", "0")
     assert P.exact_projection() is False
     P.set_exact_projection(True)
-    monkeypatch.setenv("SPECINV_EXACT", "0")
     assert P.exact_projection() is True
-    P.set_exact_projection(None)
+    P.set_exact_projection(False)
+    monkeypatch.setenv("SPECINV_EXACT", "1")
     assert P.exact_projection() is False
+    P.set_exact_projection(None)
+    assert P.exact_projection() is True
     monkeypatch.setenv("SPECINV_RTISI_PROGRESS", "blocks")
     assert M._live_progress() is True
     monkeypatch.setenv("SPECINV_RTISI_PROGRESS", "end")
