@@ -830,6 +830,9 @@ def build_parser():
     ap.add_argument("--no-h2d", action="store_true", help="skip the H2D-inclusive legs")
     ap.add_argument("--no-overlap-gather", action="store_true",
                     help="N > 1: wait for each step's RCCL gather before the next step starts (default: it overlaps the next step)")
+    ap.add_argument("--even-chunks", action="store_true",
+                    help="even chunks of frames per wave instead of the skewed ones (DESIGN 3.2 (7)): to try when RCCL's kernels share "
+                         "the chip with an exactly-full iteration launch")
     ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-dispatch counter CSVs of the live passes in")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
@@ -838,6 +841,9 @@ def build_parser():
 
 def main():
     args = build_parser().parse_args()
+    if args.even_chunks:
+        os.environ["SPECINV_TD_SKEW"] = "0"
+        os.environ["SPECINV_K4_SKEW"] = "0,0"
     if args.pmc_child:
         return pmc_child(args.pmc_child.split(","))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -98,20 +98,19 @@ def test_two_processes_on_one_device_match_the_whole_batch_run(tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("workload,extra", [("C1", []), ("C5", ["--outer", "2"])])
+@pytest.mark.parametrize("workload,extra", [("C1", []), ("C1", ["--no-overlap-gather", "--even-chunks"]), ("C5", ["--outer", "2"])])
 def test_bench_world_size_two_rehearsal(workload, extra):
-    """bench.py's N > 1 code path - launched the way the driver launches it (torch.distributed.run, one rank per process) -
-    with both ranks on cuda:0 and a gloo group (`SPECINV_BENCH_BACKEND=gloo`: a device cannot host two RCCL ranks): the
-    shards, the barrier + max-over-ranks timing, the gather to rank 0 and the one JSON line with whole-job units.  The rate it
+    """bench.py's N > 1 code path, started as a user would - plain `python3 bench.py --gpus 2`: with WORLD_SIZE unset the script
+    spawns its own ranks under torch.distributed.run (a child process, before anything has touched the GPU) - with both ranks on
+    cuda:0 and a gloo group (`SPECINV_BENCH_BACKEND=gloo`: a device cannot host two RCCL ranks): the shards, the barrier +
+    max-over-ranks timing, the gather to rank 0, the per-rank diagnostics and the one JSON line with whole-job units.  The rate it
     prints is not a measurement; that the 8-GPU launch cannot die on a code path nobody has run is the point."""
     import json
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, SPECINV_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--workload", workload, "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=800)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -119,7 +118,11 @@ def test_bench_world_size_two_rehearsal(workload, extra):
     assert len(lines) == 1, out.stdout[-2000:]              # rank 0 alone prints
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and len(mg["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in mg["per_rank_ms_per_step"])
     if workload == "C1":
         assert d["config"]["global_batch"] == 2 and d["check"]["ok"]
+        assert mg["gather_alone_ms_rank0"] > 0 and mg["gather_bytes_per_rank"] == 4 * 130816
+        assert mg["gather"].startswith("blocking" if "--no-overlap-gather" in extra else "overlapped")
     else:
         assert d["config"]["parallelism"].startswith("replicas x2")

@@ -338,3 +338,30 @@ def test_bench_byte_conventions():
     assert bench.restated_bytes_per_unit("ADMM", 256, 513, "k_fused4") == 12308
     from spectrogram_inversion_amd.build import sources_hash
     assert len(sources_hash()) == 16 and sources_hash() == sources_hash()
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python3 bench.py --gpus N` with WORLD_SIZE unset starts N ranks under torch.distributed.run as a child process (bench.py:
+    spawn_ranks) - the command line the driver itself uses, rendezvous on 127.0.0.1 - and leaves with its exit code; nothing in
+    the parent touches the GPU before that."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_spawn", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--workload", "C4"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--workload", "C4"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
