@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     tgt[i] = (!MAG && q < 4 * MT && m < a.n_mels && n < nfr) ? a.target[((long long)b * a.n_mels + m) * a.T + t0 + n] : 0.0f;
   }
   for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
-  for (int i = threadIdx.x; i < (FP - F) * RS; i += blockDim.x) tile[F * RS + i] = 0.0f;   // rows the zero-padded filterbank meets
+  for (int i = threadIdx.x; i < (FP - F) * RS; i += blockDim.x) tile[obj_at(F + (i >> 4), i & 15)] = 0.0f;   // rows the zero-padded filterbank meets
   OBJ_STAMP(0);
   {
     v2f* twt = reinterpret_cast<v2f*>(uni);                   // W_M^(l*k1), (R-1) x 64 entries: built once, kept in registers
@@ -108,6 +108,8 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int n = 2 * wib + i;
+    // rows lane + 64 j and M - lane - 64 j of the quad-major tile: lane-constant bases, 1024 floats per j (objective_args.h)
+    const int ak0 = obj_at(lane, n), am0 = obj_at(M - lane, n);
     v2f z[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) z[u] = zin[i][u] * lds_win[64 * u + lane];
@@ -128,16 +130,15 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       const v2f xk = (e2 + tw) * hs;
       const v2f xm = (e2 - tw) * v2f{hs, -hs};
       const float ak = fast_abs(xk), am = fast_abs(xm);
-      const int kk = lane + 64 * j;
-      tile[kk * RS + n] = ak;
-      tile[(M - kk) * RS + n] = am;
+      tile[ak0 + 1024 * j] = ak;
+      tile[am0 - 1024 * j] = am;
       const float ik = ak > 0.0f ? fast_rcp(ak) : 0.0f, im = am > 0.0f ? fast_rcp(am) : 0.0f;
       un[i][j] = xk * ik;                                                      // G = dA * S/|S|, 0 where |S| = 0
       um[i][j] = xm * im;
     }
     const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};                  // bin M/2 (lane 0)
     const float amid = fast_abs(xmid);
-    if (lane == 0) tile[(M / 2) * RS + n] = amid;
+    if (lane == 0) tile[obj_at(M / 2, n)] = amid;
     umid[i] = xmid * (amid > 0.0f ? fast_rcp(amid) : 0.0f);
   }
   OBJ_STAMP(2);
@@ -173,9 +174,9 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     for (int e = threadIdx.x; e < F * kObjTile; e += blockDim.x) {
       const int f = e >> 4, n = e & 15;
       if (n < nfr) {
-        const float d = tile[f * RS + n] - a.target[((long long)b * F + f) * a.T + t0 + n];
+        const float d = tile[obj_at(f, n)] - a.target[((long long)b * F + f) * a.T + t0 + n];
         s2 += (double)d * (double)d;
-        tile[f * RS + n] = a.dscale * d;
+        tile[obj_at(f, n)] = a.dscale * d;
       }
     }
     s2 = wave_sum(s2);
@@ -202,9 +203,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       for (int i = 0; i < kRing; ++i) {
         if (e + i < fe1) {
           const int fg = __builtin_amdgcn_readlane(cfg, i), mg = __builtin_amdgcn_readlane(cmg, i);
-          float bv[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[j] = tile[(16 * fg + 4 * j + (lane >> 4)) * RS + (lane & 15)];
+          const f32x4 bv = reinterpret_cast<const f32x4*>(tile)[obj_quad(4 * fg + (lane >> 4), lane & 15)];
           const f32x4 cur = av[i];
           if (e + i + kRing < fe1) av[i] = a.melA[(long long)(e + i + kRing) * 64 + lane];
 #pragma unroll
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
           s2 += (double)d * (double)d;
           dm = a.dscale * d / (1.0f + v);
         }
-        dmt[m * RS + n] = dm;
+        dmt[obj_at(m, n)] = dm;
       }
     }
     s2 = wave_sum(s2);
@@ -270,8 +269,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     int g = bg0;
     auto flush = [&](int upto) {                            // bin groups [g, upto) are complete (groups without a block: zeros)
       for (; g < upto; ++g) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tile[(16 * g + 4 * (lane >> 4) + r) * RS + (lane & 15)] = c[r];
+        reinterpret_cast<f32x4*>(tile)[obj_quad(4 * g + (lane >> 4), lane & 15)] = c;     // D rows 4 i .. 4 i + 3 of column c: one unit
         c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
     };
@@ -286,9 +284,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
         if (e + i < be1) {
           const int fg = __builtin_amdgcn_readlane(cfg, i), mg = __builtin_amdgcn_readlane(cmg, i);
           flush(fg);
-          float bv[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[j] = dmt[(16 * mg + 4 * j + (lane >> 4)) * RS + (lane & 15)];
+          const f32x4 bv = reinterpret_cast<const f32x4*>(dmt)[obj_quad(4 * mg + (lane >> 4), lane & 15)];
           const f32x4 cur = av[i];
           if (e + i + kRing < be1) av[i] = a.melB[(long long)(e + i + kRing) * 64 + lane];
 #pragma unroll
@@ -308,6 +304,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int n = 2 * wib + i;
+    const int ak0 = obj_at(lane, n), am0 = obj_at(M - lane, n);
     v2f z[R], back[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) {
@@ -315,8 +312,8 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       const int kk = lane + 64 * j;
       // interior bins of the one-sided spectrum count half (their mirror images carry the other half); bins 0 and M do not
       const float hw = (kk == 0 ? 1.0f : 0.5f) * a.fwd_scale;
-      v2f ak = un[i][j] * (tile[kk * RS + n] * hw);
-      v2f am = um[i][j] * (tile[(M - kk) * RS + n] * hw);
+      v2f ak = un[i][j] * (tile[ak0 + 1024 * j] * hw);
+      v2f am = um[i][j] * (tile[am0 - 1024 * j] * hw);
       if (j == 0 && lane == 0) {
         ak.y = 0.0f;
         am.y = 0.0f;
@@ -326,7 +323,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       z[j] = add_i(e2i, o2i);
       back[j] = conj_sub_i(e2i, o2i);
     }
-    const float dmid = tile[(M / 2) * RS + n] * a.fwd_scale;
+    const float dmid = tile[obj_at(M / 2, n)] * a.fwd_scale;
     const v2f zmid = umid[i] * v2f{dmid, -dmid};
 #pragma unroll
     for (int m = H; m < R; ++m) {

@@ -19,7 +19,20 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 
 constexpr int kObjWaves = 8;      // waves per workgroup
 constexpr int kObjTile = 16;      // frames per tile (the N of the MFMA), two per wave
-constexpr int kObjRow = 17;       // LDS row stride of the [bin][frame] tiles (odd: column reads are conflict-free)
+constexpr int kObjRow = 16;       // floats per row of the [bin][frame] tiles; elements sit at obj_at(row, frame)
+
+// The [rows][16 frames] float tiles in LDS are stored QUAD-MAJOR: the four rows of an aligned group of four sit side by side as
+// one 16-byte unit per frame, [row >> 2][frame ^ swizzle][row & 3], with the frame index XOR-ed by the quad's low four bits.
+//   * the matrix cores take their operands and leave their results in exactly these units: v_mfma_f32_16x16x4_f32's lane
+//     (i = lane >> 4, c = lane & 15) supplies B[k][c] of k-step j from row 4 i + j of the 16-row group (obj_build_blocks orders the
+//     filterbank operand to match) - ONE ds_read_b128 per block instead of four ds_read_b32 - and holds D rows 4 i .. 4 i + 3 of
+//     column c: one ds_write_b128.  The 64 lanes cover 64 consecutive units (the XOR permutes them inside a row): no conflict;
+//   * the FFT's lanes - 64 consecutive rows at one frame - write |S| and read dA one float each: lanes 4 q .. 4 q + 3 share a
+//     unit, the XOR spreads the 16 quads over the 16 units of a row of 64 banks: no conflict either.
+// (Round 3 used rows of 17 floats: conflict-free for the FFT's lanes, but the operand read - 4 rows x 16 frames - put six of its
+// 64 lanes on three banks: SQ_LDS_BANK_CONFLICT 14 % of SQ_LDS_IDX_ACTIVE, profiles/r03_C5_pmc.json.)
+__device__ __forceinline__ int obj_quad(int q, int n) { return (q << 4) + (n ^ (q & 15)); }       // in 16-byte units
+__device__ __forceinline__ int obj_at(int f, int n) { return obj_quad(f >> 2, n) * 4 + (f & 3); }   // in floats
 
 struct ObjArgs {
   const float* x;          // (B, len)
@@ -118,9 +131,10 @@ inline void obj_build_blocks(const float* mel, int F, int n_mels, int MT, std::v
   for (int e = 0; e < E; ++e)
     for (int lane = 0; lane < 64; ++lane)
       for (int j = 0; j < 4; ++j) {
-        // forward: A[i = mel row = lane & 15][k = bin = 4 j + (lane >> 4)]; backward: A[i = bin][k = mel row]
-        A[((size_t)e * 64 + lane) * 4 + j] = at(16 * mgs[e] + (lane & 15), 16 * fgs[e] + 4 * j + (lane >> 4));
-        B[((size_t)e * 64 + lane) * 4 + j] = at(16 * mgs[e] + 4 * j + (lane >> 4), 16 * fgs[e] + (lane & 15));
+        // k-step j pairs lane-row i = lane >> 4 with row 4 i + j of the 16-row group: the quad the B operand's lane reads in one piece
+        // (obj_quad).  forward: A[i = mel row = lane & 15][k = bin]; backward: A[i = bin][k = mel row]
+        A[((size_t)e * 64 + lane) * 4 + j] = at(16 * mgs[e] + (lane & 15), 16 * fgs[e] + 4 * (lane >> 4) + j);
+        B[((size_t)e * 64 + lane) * 4 + j] = at(16 * mgs[e] + 4 * (lane >> 4) + j, 16 * fgs[e] + (lane & 15));
       }
   tab.assign(ObjTab::bin_group(KQ, E) + E, 0);
   for (int w = 0; w <= kObjWaves; ++w) tab[ObjTab::FWD + w] = (int)((long long)E * w / kObjWaves);

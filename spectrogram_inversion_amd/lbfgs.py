@@ -422,6 +422,160 @@ class LBFGS:
         self.d, self.t = d, t
         return first_loss
 
+    # ---- one optimizer.step with the strong-Wolfe line search, one host synchronisation per EVALUATION -----------------------
+    def _eval_point(self, fg, x, d):
+        """The objective at x and the statistics a decision needs, enqueued back to back and fetched with ONE read:
+        (g, loss, g.d, sum|g|, max|g|, max|d|).  `d` None: the statistics are taken with d = g."""
+        ops = self.ops
+        if self._board is None or self._board.numel() < 9 + 2 * self.history_size:
+            self._board = ops.board(9 + 2 * self.history_size)
+        bd = self._board
+        g = ops.eval_into(fg, x, bd, 0)
+        ops.stats_into(g, g if d is None else d, bd, 1)
+        v = ops.read(bd, 5)
+        return g, v[0], v[1], v[2], v[3], v[4]
+
+    def _pair_products(self, g, g_prev, d, t):
+        """The curvature pair y = g - g_prev, s = t d with {y.s, y.y, g.g, g.g_prev} and the products of g with the memory:
+        one pass each, ONE read - no evaluation (the line search has produced g already)."""
+        ops, bd, m = self.ops, self._board, len(self.ss)
+        y, s = ops.pair_into(g, g_prev, d, t, bd, 5)
+        if m:
+            ops.multi_dot_into(g, self.ss + self.ys, bd, 9)
+        v = ops.read(bd, 9 + 2 * m)
+        return y, s, v[5], v[6], v[7], v[8], np.asarray(v[9:9 + m], dtype=np.float64), np.asarray(v[9 + m:9 + 2 * m], dtype=np.float64)
+
+    def _wolfe_packed(self, fg, x0, t, d, f0, g0, gtd0, max_ls, c1=1e-4, c2=0.9):
+        """`_wolfe` (torch.optim.lbfgs._strong_wolfe: bracket, cubic interpolation, zoom) with every trial point evaluated by
+        `_eval_point`: the step, the objective, g.d and max|g| enqueued together, one read-back per trial instead of three.
+        Same decisions in the same order on the same values.  Returns (loss, g, t, evaluations, g.d, max|g|) of the accepted point and max|d|."""
+        ops = self.ops
+
+        def phi(step):
+            trial = x0.clone()
+            ops.axpy(step, d, trial)
+            g, f, gd, _, gmax, dmax = self._eval_point(fg, trial, d)
+            return [step, f, g, gd, gmax], dmax
+
+        new, d_norm = phi(t)
+        evals, it = 1, 0
+        prev = [0.0, f0, g0, gtd0, None]
+        done, br = False, None
+        while it < max_ls:
+            if new[1] > f0 + c1 * new[0] * gtd0 or (it > 1 and new[1] >= prev[1]):
+                br = [prev, new]
+                break
+            if abs(new[3]) <= -c2 * gtd0:
+                br, done = [new], True
+                break
+            if new[3] >= 0:
+                br = [prev, new]
+                break
+            nxt = _cubic_step(prev[0], prev[1], prev[3], new[0], new[1], new[3], (new[0] + 0.01 * (new[0] - prev[0]), new[0] * 10))
+            prev = new
+            new, _ = phi(nxt)
+            evals += 1
+            it += 1
+        if it == max_ls:
+            br = [[0.0, f0, g0, gtd0, None], new]
+        stalled = False
+        lo, hi = (0, 1) if br[0][1] <= br[-1][1] else (1, 0)
+        while not done and it < max_ls:
+            if abs(br[1][0] - br[0][0]) * d_norm < 1e-9:         # (_strong_wolfe's own tolerance_change: torch does not forward its)
+                break
+            t = _cubic_step(br[0][0], br[0][1], br[0][3], br[1][0], br[1][1], br[1][3])
+            bmax, bmin = max(br[0][0], br[1][0]), min(br[0][0], br[1][0])
+            margin = 0.1 * (bmax - bmin)
+            if min(bmax - t, t - bmin) < margin:
+                if stalled or t >= bmax or t <= bmin:
+                    t = bmax - margin if abs(t - bmax) < abs(t - bmin) else bmin + margin
+                    stalled = False
+                else:
+                    stalled = True
+            else:
+                stalled = False
+            new, _ = phi(t)
+            evals += 1
+            it += 1
+            if new[1] > f0 + c1 * t * gtd0 or new[1] >= br[lo][1]:
+                br[hi] = new
+                lo, hi = (0, 1) if br[0][1] <= br[1][1] else (1, 0)
+            else:
+                if abs(new[3]) <= -c2 * gtd0:
+                    done = True
+                elif new[3] * (br[hi][0] - br[lo][0]) >= 0:
+                    br[hi] = list(br[lo])
+                br[lo] = new
+        if len(br) == 1:
+            lo = 0
+        best = br[lo]
+        return best[1], best[2], best[0], evals, best[3], best[4], d_norm
+
+    def _step_wolfe_packed(self, fg):
+        """`step` with line_search_fn='strong_wolfe' for an objective that can leave its loss on the device (`fg.dev`): the
+        decisions of torch.optim.LBFGS.step in the same order, taken from ONE packed read-back per evaluation (entry point, every
+        trial of the line search) and one per curvature pair, where the general path below reads three scalars one by one around
+        every evaluation.  The direction is a linear combination of g and the memory with coefficients from the Gram recursion
+        (`_gram_coefficients`); g.d of the new direction follows from the known products, as in `_step_packed`."""
+        ops, x = self.ops, self.x
+        # the entry evaluation; its statistics are taken against the direction of the previous step's last iteration (g . d is
+        # needed for the curvature pair: s_new . g = t (d . g)) or, before the first iteration, against g itself (g . g)
+        g, loss, gd_old, g_abssum, g_absmax, d_norm = self._eval_point(fg, x, self.d if self.total_iters >= 1 else None)
+        first_loss = loss
+        evals = 1
+        self.func_evals += 1
+        if g_absmax <= self.tol_grad:
+            return first_loss
+        d, t = self.d, self.t
+        n_iter = 0
+        while n_iter < self.max_iter:
+            n_iter += 1
+            self.total_iters += 1
+            if self.total_iters == 1:
+                self._forget()
+                d = ops.scaled(-1.0, g)
+                gtd = -gd_old                                  # (the entry statistics were taken with d = g)
+            else:
+                y, s, ys, yy, gg, ggp, sg, yg = self._pair_products(g, self.prev_grad, d, t)
+                self.pairs_accepted += ys > 1e-10
+                self.pairs_rejected += not ys > 1e-10
+                if ys > 1e-10:
+                    if len(self.ys) == self.history_size:
+                        self._drop_oldest()
+                        sg, yg = sg[1:], yg[1:]
+                    self.ys.append(y)
+                    self.ss.append(s)
+                    self.rho.append(1.0 / ys)
+                    self.h_diag = ys / yy
+                    self._pushed = (ys, yy)
+                    sg = np.append(sg, t * gd_old)             # s_new . g = t (d . g)
+                    yg = np.append(yg, gg - ggp)               # y_new . g = g . g - g_prev . g
+                self._gram_append(sg, yg)
+                coefs = self._gram_coefficients(sg, yg)
+                m = len(self.ss)
+                d = ops.lincomb([g] + self.ys + self.ss, coefs)
+                gtd = coefs[0] * gg + float(np.dot(coefs[1:1 + m], yg)) + float(np.dot(coefs[1 + m:], sg))
+            self.prev_grad = g
+            self.prev_loss = loss
+            t = min(1.0, 1.0 / g_abssum) * self.lr if self.total_iters == 1 else self.lr
+            if gtd > -self.tol_change:
+                break
+            loss, g, t, ls_evals, gd_old, ls_gmax, d_norm = self._wolfe_packed(fg, x.clone(), t, d, loss, g, gtd, self.max_eval - evals)
+            ops.axpy(t, d, x)
+            if ls_gmax is not None:                        # (None: the search ended on its starting point - t = 0, g is the gradient
+                g_absmax = ls_gmax                         # it started from, whose max|g| is known)
+            opt = g_absmax <= self.tol_grad
+            evals += ls_evals
+            self.func_evals += ls_evals
+            if n_iter == self.max_iter or evals >= self.max_eval or opt:
+                break
+            if abs(t) * d_norm <= self.tol_change:
+                break
+            if abs(loss - self.prev_loss) < self.tol_change:
+                break
+        self.d, self.t = d, t
+        return first_loss
+
     # ---- one optimizer.step with the decisions on the device: one host synchronisation per STEP -------------------
     def _device_ok(self, fg):
         """The device-resident optimiser (csrc/lbfgs_dev.h) serves float32 parameters on the one-launch objective, no line
@@ -486,6 +640,9 @@ class LBFGS:
         if self.line_search is None and self.gram and getattr(self.ops, "packed", False) and \
                 os.environ.get("SPECINV_LBFGS_PACKED", "1") != "0":
             return self._step_packed(fg)
+        if self.line_search is not None and self.gram and getattr(self.ops, "packed", False) and hasattr(fg, "dev") and \
+                os.environ.get("SPECINV_LBFGS_PACKED", "1") != "0":
+            return self._step_wolfe_packed(fg)
         ops, x = self.ops, self.x
         fused = hasattr(ops, "pair") and hasattr(ops, "stats")     # one pass per group of vector operations
         loss, g = fg(x)

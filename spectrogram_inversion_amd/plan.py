@@ -138,7 +138,10 @@ class Plan:
         _lib.check(self.lib.specinv_plan_set_stream(self._h, C.c_void_p(s.cuda_stream)))
 
     def _in(self, t: torch.Tensor, dtype, shape=None):
-        t = t.detach().to(device=self.device, dtype=dtype).contiguous()
+        # (the optimiser loops call this a few hundred thousand times with tensors that are already in place: skip the three
+        # dispatcher round trips then)
+        if t.dtype != dtype or t.device != self.device or t.requires_grad or not t.is_contiguous():
+            t = t.detach().to(device=self.device, dtype=dtype).contiguous()
         if shape is not None:
             assert tuple(t.shape) == tuple(shape), f"expected shape {tuple(shape)}, got {tuple(t.shape)}"
         return t
