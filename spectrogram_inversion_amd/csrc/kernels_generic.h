@@ -25,6 +25,12 @@ struct FrameCfg {
   int tw_step[kMaxStages];
   const cplx<T>* tw;  // tw[n] = exp(-2 pi i n / n_fft)
   const T* window;    // n_fft
+  // In-place transforms (k_stft, k_iter_pair, k_grad_frames): the kernel has ONE buffer of n_fft complex points in LDS instead of
+  // two; a stage's threads hold their butterflies (IpMB<T, R> each at most) in registers across a barrier between the last read
+  // and the first write.  Twice the workgroups per CU where LDS is what limits them (float64 at n_fft 2048: 2 -> 4), and n_fft up to
+  // 16384 (float32) / 8192 (float64) in 128 KiB.  Radices 2, 3, 4, 5, 7, 8 only (a larger prime factor keeps the two-buffer form).
+  // A compile-time property of the kernel (template parameter IP); these fields only record the plan's choice.
+  int inplace, maxb;
 };
 
 // ---- signal access with torch.stft's centre padding (methods.py:241 -> F.pad) -----------
@@ -198,6 +204,76 @@ __device__ inline void fft_stage_any(const cplx<T>* __restrict__ a, cplx<T>* __r
   }
 }
 
+// One stage of the transform IN PLACE: every butterfly of the stage is read and computed, then - after a barrier - written to the
+// Stockham positions of the same buffer.  Thread `tid` owns butterflies tid, tid + nthr, ... (at most MB of them).
+template <typename T, int R, bool INV, int MB>
+__device__ __forceinline__ void fft_stage_inplace(cplx<T>* __restrict__ a, const FrameCfg<T>& c, int s, int ns, int tid, int nthr) {
+  const int N = c.n_fft, nb = (unsigned)N / (unsigned)R, tws = c.tw_step[s];
+  const unsigned magic = c.ns_magic[s];
+  cplx<T> v[MB][R];
+  int base[MB];
+#pragma unroll
+  for (int it = 0; it < MB; ++it) {
+    const int j = tid + it * nthr;
+    base[it] = -1;
+    if (j < nb) {
+      const int blk = div_magic(j, ns, magic), k = j - blk * ns;
+#pragma unroll
+      for (int q = 0; q < R; ++q) v[it][q] = a[j + q * nb];
+      if (ns > 1) {
+        const int kt = k * tws;
+#pragma unroll
+        for (int q = 1; q < R; ++q) {
+          cplx<T> w = c.tw[kt * q];
+          if (INV) w.y = -w.y;
+          v[it][q] = cmul(v[it][q], w);
+        }
+      }
+      Butterfly<T, R, INV>::run(v[it], c.tw, N);
+      base[it] = blk * ns * R + k;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < MB; ++it) {
+    if (base[it] >= 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[base[it] + r * ns] = v[it][r];
+    }
+  }
+}
+
+// Butterflies a thread may hold across the barrier, by radix: 16 complex values in float32, 8 in float64 (their registers), at
+// most 4.  The host sizes the workgroup so that every stage fits (ip_butterflies_per_thread, plan_impl.h).
+template <typename T, int R>
+struct IpMB {
+  static constexpr int budget = sizeof(T) == 8 ? 8 : 16;
+  static constexpr int value = (R == 5 || R == 7) ? 1 : (budget / R >= 4 ? 4 : (budget / R >= 1 ? budget / R : 1));
+};
+inline int ip_butterflies_per_thread(int radix, bool f64) {          // (the same rule for the host, plan_impl.h)
+  const int budget = f64 ? 8 : 16;
+  if (radix == 5 || radix == 7) return 1;                            // (the odd radices' butterflies carry their own tables)
+  return budget / radix >= 4 ? 4 : (budget / radix >= 1 ? budget / radix : 1);
+}
+
+template <typename T, bool INV>
+__device__ inline void lds_fft_inplace(cplx<T>* a, const FrameCfg<T>& c, int tid, int nthr) {
+  int ns = 1;
+  for (int s = 0; s < c.n_stages; ++s) {
+    const int R = c.radix[s];
+    switch (R) {
+      case 2: fft_stage_inplace<T, 2, INV, IpMB<T, 2>::value>(a, c, s, ns, tid, nthr); break;
+      case 3: fft_stage_inplace<T, 3, INV, IpMB<T, 3>::value>(a, c, s, ns, tid, nthr); break;
+      case 4: fft_stage_inplace<T, 4, INV, IpMB<T, 4>::value>(a, c, s, ns, tid, nthr); break;
+      case 5: fft_stage_inplace<T, 5, INV, IpMB<T, 5>::value>(a, c, s, ns, tid, nthr); break;
+      case 7: fft_stage_inplace<T, 7, INV, IpMB<T, 7>::value>(a, c, s, ns, tid, nthr); break;
+      default: fft_stage_inplace<T, 8, INV, IpMB<T, 8>::value>(a, c, s, ns, tid, nthr); break;
+    }
+    __syncthreads();
+    ns *= R;
+  }
+}
+
 template <typename T, bool INV>
 __device__ inline void lds_fft_dir(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, int tid, int nthr) {
   int ns = 1;
@@ -220,15 +296,22 @@ __device__ inline void lds_fft_dir(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& 
   }
 }
 
-template <typename T>
+// IP: the in-place form (one buffer: b == a, the result stays where the input was) - a compile-time choice, so that a kernel
+// carries the registers of one form only
+template <typename T, bool IP = false>
 __device__ inline void lds_fft(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, bool inverse, int tid = -1,
                                int nthr = 0) {
   if (tid < 0) {
     tid = threadIdx.x;
     nthr = blockDim.x;
   }
-  if (inverse) lds_fft_dir<T, true>(a, b, c, tid, nthr);
-  else lds_fft_dir<T, false>(a, b, c, tid, nthr);
+  if constexpr (IP) {
+    if (inverse) lds_fft_inplace<T, true>(a, c, tid, nthr);
+    else lds_fft_inplace<T, false>(a, c, tid, nthr);
+  } else {
+    if (inverse) lds_fft_dir<T, true>(a, b, c, tid, nthr);
+    else lds_fft_dir<T, false>(a, b, c, tid, nthr);
+  }
 }
 
 // windowed frame t of row `x` -> LDS (imaginary part zero); ends synchronised
@@ -244,7 +327,7 @@ __device__ inline void load_frame(const FrameCfg<T>& c, const T* __restrict__ x,
 }
 
 // LDS bins [0, n_freq) -> real frame (inverse FFT, scale, synthesis window) -> out[n_fft]
-template <typename T>
+template <typename T, bool IP = false>
 __device__ inline void spectrum_to_frame(const FrameCfg<T>& c, cplx<T>* a, cplx<T>* b, T* __restrict__ out,
                                          const T* __restrict__ window) {
   const int N = c.n_fft;
@@ -260,7 +343,7 @@ __device__ inline void spectrum_to_frame(const FrameCfg<T>& c, cplx<T>* a, cplx<
     }
     __syncthreads();
   }
-  lds_fft(a, b, c, true);
+  lds_fft<T, IP>(a, b, c, true);
   for (int n = threadIdx.x; n < N; n += blockDim.x) out[n] = (a[n].x * c.inv_scale) * window[n];
 }
 
@@ -280,14 +363,14 @@ __device__ inline double block_sum(double v, double* red) {
 }
 
 // ---- forward STFT: x (B, length) -> spec (B, T, F) [frame-major internal layout] -----------
-template <typename T>
+template <typename T, bool IP = false>
 __global__ void k_stft(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ spec) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* b = a + c.n_fft;
+  cplx<T>* b = IP ? a : a + c.n_fft;
   const int t = blockIdx.x, bi = blockIdx.y;
   load_frame(c, x + (int64_t)bi * c.length, t, a, c.window);
-  lds_fft(a, b, c, false);
+  lds_fft<T, IP>(a, b, c, false);
   cplx<T>* out = spec + ((int64_t)bi * c.n_frames + t) * c.n_freq;
   for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) out[f] = mk<T>(a[f].x * c.fwd_scale, a[f].y * c.fwd_scale);
 }
@@ -381,14 +464,14 @@ __device__ __forceinline__ cplx<T> update_one(cplx<T> r, cplx<T>* __restrict__ S
   return y;
 }
 
-template <typename T, int MODE, bool EVAL>
+template <typename T, int MODE, bool EVAL, bool IP = false>
 __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ S0, cplx<T>* __restrict__ S1,
                             const T* __restrict__ mag, T coef, T inv1p, T* __restrict__ frames,
                             double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double red[16];
   cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* b = a + c.n_fft;
+  cplx<T>* b = IP ? a : a + c.n_fft;     // (in place: a bin pair (f, N - f) is read and rewritten by one thread)
   const int N = c.n_fft, F = c.n_freq;
   const int t0 = 2 * blockIdx.x, bi = blockIdx.y;
   const T* xr = x + (int64_t)bi * c.length;
@@ -425,7 +508,7 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
       for (int n = threadIdx.x; n < N; n += blockDim.x) a[n].y = T(0);
       __syncthreads();
     }
-    lds_fft(a, b, c, false);
+    lds_fft<T, IP>(a, b, c, false);
     const int64_t base_a = ((int64_t)bi * c.n_frames + ta) * F, base_b = ((int64_t)bi * c.n_frames + tb) * F;
     const bool has_b = tb >= 0;
     if (c.onesided) {
@@ -482,7 +565,7 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
       a = b;
       b = tmp;
     }
-    lds_fft(a, b, c, true);
+    lds_fft<T, IP>(a, b, c, true);
     T* fa = frames + ((int64_t)bi * c.n_frames + ta) * N;
     T* fb = frames + ((int64_t)bi * c.n_frames + tb) * N;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {

@@ -946,16 +946,16 @@ __global__ void k_mel_backward_valu(cplx<T>* __restrict__ spec, const T* __restr
 
 // inverse frames (generic): windowed Hermitian inverse transform of a (B, T, F) spectrum, scale = c.inv_scale.
 // Used by _istft (scale 1/N) and by the STFT adjoint of the L_BFGS gradient (scale = forward scale).
-template <typename T>
+template <typename T, bool IP = false>
 __global__ void k_grad_frames(FrameCfg<T> c, const cplx<T>* __restrict__ g, T* __restrict__ frames) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* b = a + c.n_fft;
+  cplx<T>* b = IP ? a : a + c.n_fft;
   const int t = blockIdx.x, bi = blockIdx.y;
   const cplx<T>* in = g + ((int64_t)bi * c.n_frames + t) * c.n_freq;
   for (int f = threadIdx.x; f < c.n_freq; f += blockDim.x) a[f] = in[f];
   __syncthreads();
-  spectrum_to_frame(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
+  spectrum_to_frame<T, IP>(c, a, b, frames + ((int64_t)bi * c.n_frames + t) * c.n_fft, c.window);
 }
 
 // Fold of the padded margins onto the signal: grad already holds the plain overlap-add of the gradient frames over

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <memory>
 #include <type_traits>
+#include <atomic>
 #include <vector>
 
 #include "kernels_adjoint.h"
@@ -97,7 +98,10 @@ struct PlanT final : PlanBase {
   int tf_obj_mt = 0;                    // its 16-row mel tiles (0: the objective runs as a kernel chain)
   std::vector<T> h_window;
   FrameCfg<T> fc{};
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0;        // LDS of k_stft / k_iter_pair / k_grad_frames (one buffer when use_inplace)
+  size_t lds_bytes2 = 0;       // two buffers (the kernels that keep the two-buffer transform)
+  bool use_inplace = false;
+  int ip_threads = 0, ip_maxb = 0;
   double sum_m2 = 0, count = 0;
   T coef = 0;  // lr (GLA) or rho (ADMM)
   FastState<T> fast;
@@ -172,17 +176,49 @@ struct PlanT final : PlanBase {
     }
     fc.tw = tw.as<C>();
     fc.window = window.as<T>();
-    lds_bytes = 2 * (size_t)n * sizeof(C);
+    fc.inplace = 0;
+    fc.maxb = 0;
+    lds_bytes2 = 2 * (size_t)n * sizeof(C);          // two buffers: every kernel can run (RTISI-LA and the L-BFGS chain need them)
+    // In-place transforms (kernels_generic.h: FrameCfg::inplace) for k_stft / k_iter_pair / k_grad_frames: one buffer - more
+    // workgroups per CU for a latency-bound kernel (measured, tools/bench_generic_r04.py: float64 2048 / 512 0.58 -> 0.44 ms per
+    // iteration, float64 512 two-sided 1.40 -> 1.02, float32 8192 0.64 -> 0.31; float32 at n_fft <= 1024 2 % slower: the extra
+    // barrier per stage with nothing to gain) - and the only form beyond n_fft 8192 (float32) / 4096 (float64).
+    bool ip_ok = true;
+    for (int r : rad) ip_ok = ip_ok && (r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8);
+    // the smallest workgroup (whole waves, 64 ... 1024 threads) whose threads can hold every stage's butterflies
+    ip_threads = 64;
+    ip_maxb = 1;
+    if (ip_ok) {
+      auto fits = [&](int threads) {
+        for (int r : rad)
+          if ((n / r + threads - 1) / threads > ip_butterflies_per_thread(r, sizeof(T) == 8)) return false;
+        return true;
+      };
+      // (at least a thread per butterfly of the widest stage up to 256 threads, like the two-buffer form)
+      int rmin = 8;
+      for (int r : rad) rmin = std::min(rmin, r);
+      while (ip_threads < 256 && ip_threads < n / std::max(2, rmin)) ip_threads *= 2;
+      while (ip_threads < 1024 && !fits(ip_threads)) ip_threads *= 2;
+      ip_ok = fits(ip_threads);
+    }
+    const char* ip_env = getenv("SPECINV_GENERIC_INPLACE");           // (experiments: 0 never, 1 whenever possible)
+    use_inplace = ip_ok && (sizeof(T) == 8 || lds_bytes2 > 16 * 1024 || (ip_env && ip_env[0] == '1')) && !(ip_env && ip_env[0] == '0');
+    lds_bytes = use_inplace ? lds_bytes2 / 2 : lds_bytes2;
     SI_CHECK(lds_bytes <= 160 * 1024 - 256, SPECINV_EUNSUPPORTED,
              "n_fft=%d needs %zu bytes of LDS per frame (limit 160 KiB)", n, lds_bytes);
     if (lds_bytes > 48 * 1024) {
-      const int lim = (int)lds_bytes;
-      SI_HIP(hipFuncSetAttribute((const void*)k_stft<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_iter_pair<T, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_iter_pair<T, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_iter_pair<T, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_iter_pair<T, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      SI_HIP(hipFuncSetAttribute((const void*)k_grad_frames<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      // (the attribute belongs to the kernel, not to the plan: never lower what another plan has asked for)
+      static std::atomic<int> lds_cap{0};
+      int seen = lds_cap.load();
+      while (seen < (int)lds_bytes && !lds_cap.compare_exchange_weak(seen, (int)lds_bytes)) {}
+      const int lim = std::max(seen, (int)lds_bytes);
+      const void* fns[] = {(const void*)k_stft<T, false>, (const void*)k_stft<T, true>, (const void*)k_grad_frames<T, false>,
+                           (const void*)k_grad_frames<T, true>,
+                           (const void*)k_iter_pair<T, 0, false, false>, (const void*)k_iter_pair<T, 0, true, false>,
+                           (const void*)k_iter_pair<T, 1, false, false>, (const void*)k_iter_pair<T, 1, true, false>,
+                           (const void*)k_iter_pair<T, 0, false, true>, (const void*)k_iter_pair<T, 0, true, true>,
+                           (const void*)k_iter_pair<T, 1, false, true>, (const void*)k_iter_pair<T, 1, true, true>};
+      for (const void* fn : fns) SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     }
     SI_TRY(sums.reserve(16 * sizeof(double)));
     SI_TRY(fast.setup(cfg, h_window, length, pad));
@@ -213,9 +249,13 @@ struct PlanT final : PlanBase {
     return SPECINV_OK;
   }
 
+  // `fc` describes the two-buffer transform (what RTISI-LA and the L-BFGS chain run); k_stft / k_iter_pair / k_grad_frames take
+  // the in-place form where the plan chose it
   FrameCfg<T> frame_cfg(int64_t len) const {
     FrameCfg<T> c = fc;
     c.length = len;
+    c.inplace = use_inplace ? 1 : 0;
+    c.maxb = use_inplace ? ip_maxb : 0;
     return c;
   }
 
@@ -271,6 +311,7 @@ struct PlanT final : PlanBase {
   // threads per frame workgroup of the generic kernels: one per butterfly of the widest stage (n_fft / smallest radix),
   // whole waves, at most 256
   int frame_threads() const {
+    if (use_inplace) return ip_threads;
     int rmin = 8;
     for (int i = 0; i < fc.n_stages; ++i) rmin = std::min(rmin, fc.radix[i]);
     const int want = (N() / std::max(2, rmin) + 63) / 64 * 64;
@@ -303,7 +344,8 @@ struct PlanT final : PlanBase {
     FrameCfg<T> c = frame_cfg(len);
     c.pad_mode = pm;
     c.fwd_scale = sc;
-    hipLaunchKernelGGL((k_stft<T>), dim3(Tn(), B()), dim3(frame_threads()), lds_bytes, stream, c, xin, spec_btf);
+    if (use_inplace) hipLaunchKernelGGL((k_stft<T, true>), dim3(Tn(), B()), dim3(frame_threads()), lds_bytes, stream, c, xin, spec_btf);
+    else hipLaunchKernelGGL((k_stft<T, false>), dim3(Tn(), B()), dim3(frame_threads()), lds_bytes, stream, c, xin, spec_btf);
     SI_HIP(hipGetLastError());
     return SPECINV_OK;
   }
@@ -317,7 +359,8 @@ struct PlanT final : PlanBase {
     }
     FrameCfg<T> c = frame_cfg(len);
     c.inv_scale = scale;
-    hipLaunchKernelGGL((k_grad_frames<T>), dim3(Tn(), B()), dim3(frame_threads()), lds_bytes, stream, c, spec_btf, fr);
+    if (use_inplace) hipLaunchKernelGGL((k_grad_frames<T, true>), dim3(Tn(), B()), dim3(frame_threads()), lds_bytes, stream, c, spec_btf, fr);
+    else hipLaunchKernelGGL((k_grad_frames<T, false>), dim3(Tn(), B()), dim3(frame_threads()), lds_bytes, stream, c, spec_btf, fr);
     SI_HIP(hipGetLastError());
     return SPECINV_OK;
   }
@@ -460,23 +503,27 @@ struct PlanT final : PlanBase {
     } else {
       SI_TRY(frames_needed());
       const T inv1p = T(1) / (T)(1.0 + (double)coef);
+      const FrameCfg<T> fci = frame_cfg(length);
       for (int i = 0; i < n_iter; ++i) {
         const bool ev = eval_last && i == n_iter - 1;
         const dim3 grid((Tn() + 1) / 2, B()), blk(frame_threads());   // two frames per complex FFT
-        if (method == Method::Gla) {
-          if (ev)
-            hipLaunchKernelGGL((k_iter_pair<T, 0, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
-                               (C*)nullptr, mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
-          else
-            hipLaunchKernelGGL((k_iter_pair<T, 0, false>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
-                               (C*)nullptr, mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
-        } else {
-          if (ev)
-            hipLaunchKernelGGL((k_iter_pair<T, 1, true>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
-                               specB.as<C>(), mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
-          else
-            hipLaunchKernelGGL((k_iter_pair<T, 1, false>), grid, blk, lds_bytes, stream, fc, x.as<T>(), specA.as<C>(),
-                               specB.as<C>(), mag.as<T>(), coef, inv1p, frames.as<T>(), partials.as<double>());
+        {
+          const void* fn = nullptr;
+          const int mode = method == Method::Gla ? 0 : 1;
+          if (use_inplace) fn = mode == 0 ? (ev ? (const void*)k_iter_pair<T, 0, true, true> : (const void*)k_iter_pair<T, 0, false, true>)
+                                          : (ev ? (const void*)k_iter_pair<T, 1, true, true> : (const void*)k_iter_pair<T, 1, false, true>);
+          else fn = mode == 0 ? (ev ? (const void*)k_iter_pair<T, 0, true, false> : (const void*)k_iter_pair<T, 0, false, false>)
+                              : (ev ? (const void*)k_iter_pair<T, 1, true, false> : (const void*)k_iter_pair<T, 1, false, false>);
+          FrameCfg<T> ca = fci;
+          const T* xa = x.as<T>();
+          C* sa = specA.as<C>();
+          C* sb = mode == 0 ? (C*)nullptr : specB.as<C>();
+          const T* ma = mag.as<T>();
+          T cf = coef, ip = inv1p;
+          T* fra = frames.as<T>();
+          double* pa = partials.as<double>();
+          void* kargs[] = {&ca, &xa, &sa, &sb, &ma, &cf, &ip, &fra, &pa};
+          SI_HIP(hipLaunchKernel(fn, grid, blk, kargs, lds_bytes, stream));
         }
         SI_HIP(hipGetLastError());
         SI_TRY(launch_ola(frames.as<T>(), x.as<T>(), true));

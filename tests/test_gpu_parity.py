@@ -479,13 +479,40 @@ def test_large_prime_factors_vs_oracle(n_fft, hop, frames, onesided, dtype):
     assert rel_l2(y, ref64) < max(10 * tol, 20 * rel_l2(ref, ref64)), (rel_l2(y, ref64), rel_l2(ref, ref64))   # no blow-up
 
 
+@pytest.mark.parametrize("n_fft,dtype,tol", [(16384, np.float32, 2e-5), (8192, np.float64, 1e-10)])
+def test_transforms_beyond_two_lds_buffers(n_fft, dtype, tol):
+    """The reference derives n_fft from the spectrogram with no bound (torch_specinv/methods.py:65-68).  The generic kernels keep a
+    frame pair's transform in LDS: with the in-place form (one buffer of n_fft complex points, kernels_generic.h) 16384 points in
+    float32 and 8192 in float64 - refused until round 3 - run: Griffin-Lim and ADMM against the oracle."""
+    rng = np.random.default_rng(n_fft)
+    hop, frames = n_fft // 4, 6
+    mag = (rng.random((2, n_fft // 2 + 1, frames)) + 0.05).astype(dtype)
+    w = hann(n_fft, dtype)
+    init = oracle.phase_init(mag, hop_length=hop, window=w)        # (a complex start: the transforms are what is under test)
+    # random magnitudes are inconsistent: a few of the 10^5 bins pass close to zero and amplify rounding (the float64 run's 1e-10
+    # is 10^6 ulp).  The float32 run is therefore held to the float32 ORACLE's own distance from the float64 oracle.
+    w64 = hann(n_fft, np.float64)
+    kw64 = dict(tol=0, hop_length=hop, window=w64)
+    for method, run, okw in (("griffin_lim", si.griffin_lim, dict(max_iter=3, alpha=0.5)), ("admm", si.ADMM, dict(max_iter=2, rho=1.0))):
+        ref = getattr(oracle, method)(init, tol=0, hop_length=hop, window=w, **okw)
+        ref64 = getattr(oracle, method)(init.astype(np.complex128), **okw, **kw64)
+        y = N(run(T(init), tol=0, verbose=False, hop_length=hop, window=torch.from_numpy(w), **okw))
+        assert y.shape == ref.shape
+        e, e0 = rel_l2(y, ref64), rel_l2(ref, ref64)
+        assert e < max(3 * e0, 5 * tol), (method, e, e0)
+
+
 def test_transform_too_large_for_lds_is_refused():
-    """2 * n_fft complex values must fit the 160 KiB of LDS: 16384 points in float32 (and 8192 in float64) are refused
-    with SPECINV_EUNSUPPORTED at plan creation, not run on some slower path."""
-    for n_fft, dtype in ((16384, torch.float32), (8192, torch.float64)):
+    """n_fft complex values must fit the 160 KiB of LDS: 32768 points in float32 (and 16384 in float64) are refused with
+    SPECINV_EUNSUPPORTED at plan creation, not run on some slower path; so is RTISI-LA where its frame buffers (two per look-ahead
+    frame, the two-buffer transform) do not fit."""
+    for n_fft, dtype in ((32768, torch.float32), (16384, torch.float64)):
         mag = torch.rand(1, n_fft // 2 + 1, 4, dtype=dtype, device=dev())
         with pytest.raises(NotImplementedError, match="LDS"):
             si.griffin_lim(mag, max_iter=1, verbose=False, hop_length=n_fft // 4)
+    mag = torch.rand(1, 8193, 6, dtype=torch.float32, device=dev())
+    with pytest.raises(NotImplementedError, match="LDS"):
+        si.RTISI_LA(mag, look_ahead=1, max_iter=2, verbose=False, hop_length=4096)
 
 
 def test_state_spec_parity():
