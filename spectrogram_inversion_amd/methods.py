@@ -81,6 +81,57 @@ def _run_loop(plan, max_iter, tol, verbose, eva_iter, metric):
         return plan.run(max_iter, eva_iter, tol, metric, callback=on_eval if verbose else None)
 
 
+# A plan takes at most this many batch items (the batch is a y / z extent of its launch grids: specinv_plan_create refuses more).
+# The reference has no such bound (every op is batched by torch): the drop-in functions split larger batches into slices.
+_MAX_PLAN_BATCH = 65535
+
+
+def _slices(n_items):
+    return [(lo, min(n_items, lo + _MAX_PLAN_BATCH)) for lo in range(0, n_items, _MAX_PLAN_BATCH)]
+
+
+def _iterative_sliced(which, spec3, args, device, rdtype, coef, max_iter, tol, verbose, eva_iter, metric):
+    """griffin_lim / ADMM on a batch beyond one plan's 65 535 items: one plan per slice, stepped in lockstep; the metric and the
+    stop rule of `_training_loop` (torch_specinv/methods.py:181-190) are whole-batch quantities, so every evaluation adds the
+    slices' sums before the decision - what `distributed.run_loop_global` does across ranks, here across slices."""
+    from .metrics import _from_sums
+    from .plan import Plan, exact_projection
+    assert eva_iter > 0 and max_iter > 0 and tol >= 0
+    assert isinstance(metric, str) and metric.upper() in _lib.METRICS
+    name = metric.upper()
+    plans = []
+    for lo, hi in _slices(spec3.shape[0]):
+        p = Plan(args, hi - lo, spec3.shape[2], rdtype, device)
+        p.set_exact(exact_projection())
+        part = spec3[lo:hi]
+        init = getattr(p, which + "_init")
+        if part.is_complex():
+            init(part, None, coef)
+        else:
+            init(None, part, coef)
+        plans.append(p)
+    done, init_loss, previous = 0, None, None
+    with tqdm(total=max_iter, disable=not verbose) as pbar:
+        while done < max_iter:
+            until = eva_iter - (done % eva_iter)
+            if done + until > max_iter:
+                for p in plans:
+                    p.iterate(max_iter - done)
+                break
+            sums = [p.iterate(until, eval_last=True) for p in plans]
+            s = [sum(v[k] for v in sums) for k in range(4)]
+            done += until
+            m, loss = _from_sums(name, s), s[0] / s[3]
+            pbar.set_postfix(**{name: m}, loss=loss)
+            pbar.update(eva_iter)
+            if not init_loss:
+                init_loss = loss
+            elif (previous - loss) / init_loss < tol and previous > loss:
+                break
+            previous = loss
+    return torch.cat([p.wave() for p in plans], 0)
+
+
 def _iterative(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, stft_kwargs):
     spec3 = _format_spec(spec)
     real_in = not spec3.is_complex()
@@ -88,6 +139,9 @@ def _iterative(which, spec, coef, max_iter, tol, verbose, eva_iter, metric, stft
     _no_complex_window(args)
     device = require_gpu(spec3.device)
     rdtype = spec3.real.dtype if spec3.is_complex() else spec3.dtype
+    if spec3.shape[0] > _MAX_PLAN_BATCH and not (torch.is_grad_enabled() and spec.requires_grad):
+        x = _iterative_sliced(which, spec3.to(device), args, device, rdtype, coef, max_iter, tol, verbose, eva_iter, metric)
+        return _finish(x, spec, spec.device)
     plan = get_plan(args, spec3.shape[0], spec3.shape[2], rdtype, device)
     if torch.is_grad_enabled() and spec.requires_grad:
         # a gradient w.r.t. the spectrogram is wanted: recorded forward + hand-written adjoints (autograd.py)
@@ -166,6 +220,12 @@ def RTISI_LA(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, alpha=0.
         x = rtisi_differentiable(spec3.to(device), plan, look_ahead, asymmetric_window, max_iter, alpha)
     elif verbose and spec3.shape[2] >= 32 and _live_progress():
         x = _rtisi_with_progress(spec3.to(device), look_ahead, asymmetric_window, max_iter, alpha, stft_kwargs)
+    elif spec3.shape[0] > _MAX_PLAN_BATCH:
+        # (items are independent, methods.py:363-404: slices of the batch, one plan each)
+        from .plan import Plan
+        x = torch.cat([Plan(args, hi - lo, spec3.shape[2], spec3.dtype, device).rtisi(spec3[lo:hi], look_ahead, asymmetric_window,
+                                                                                       max_iter, alpha)
+                       for lo, hi in _slices(spec3.shape[0])], 0)
     else:
         # one persistent launch (what the benchmark measures); a bar nobody watches live is completed at the end
         plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
@@ -218,6 +278,11 @@ def phase_init(spec, **stft_kwargs):
     assert spec3.dim() == 3
     args = args_helper(spec3, **stft_kwargs)
     device = require_gpu(spec3.device)
+    if spec3.shape[0] > _MAX_PLAN_BATCH:
+        from .plan import Plan
+        out = torch.cat([Plan(args, hi - lo, spec3.shape[2], spec3.dtype, device).phase_init(spec3[lo:hi])
+                         for lo, hi in _slices(spec3.shape[0])], 0).view(shape).to(spec.device)
+        return out.to(torch.complex32) if half else out
     plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
     out = plan.phase_init(spec3).view(shape).to(spec.device)
     return out.to(torch.complex32) if half else out

@@ -444,3 +444,38 @@ def test_half_precision_spectrograms_are_inverted_in_float32():
     assert torch.equal(torch.view_as_real(c16), torch.view_as_real(c32.to(torch.complex32)))
     y = si.griffin_lim(c16, max_iter=4, alpha=0.3, tol=0, verbose=False, **kw)      # complex32 warm start
     assert y.dtype == torch.float16 and torch.isfinite(y.float()).all()
+
+
+def test_batches_beyond_one_plan(monkeypatch):
+    """The reference batches every op and takes any number of items (torch_specinv/methods.py:99-111); a libspecinv plan takes
+    65 535 (the batch is a grid extent).  The drop-in functions split larger batches into slices that step in lockstep, the
+    whole-batch metric / stop rule of `_training_loop` (:181-190) taken on the summed evaluation sums.  70 000 items x 4 frames
+    against the oracle (every 7 000th item), and - with the slice size lowered so that a tolerance-stopped run needs three plans -
+    against the one-plan run bit for bit, stop iteration included."""
+    from spectrogram_inversion_amd import methods as M
+
+    def T(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rng = np.random.default_rng(70)
+    n_fft, hop, frames, batch = 64, 16, 4, 70000
+    w = hann(n_fft)
+    mag = rng.random((batch, n_fft // 2 + 1, frames), dtype=np.float32) + 0.05
+    kw = dict(hop_length=hop, window=torch.from_numpy(w))
+    y = N(si.griffin_lim(T(mag), max_iter=4, alpha=0.3, tol=0, verbose=False, eva_iter=2, **kw))
+    assert y.shape == (batch, (frames - 1) * hop)
+    pick = np.arange(0, batch, 7000)
+    ref = oracle.griffin_lim(mag[pick], max_iter=4, alpha=0.3, tol=0, hop_length=hop, window=w)
+    assert rel_l2(y[pick], ref) < 1e-4, rel_l2(y[pick], ref)
+    a = N(si.ADMM(T(mag), max_iter=2, rho=1.0, tol=0, verbose=False, **kw))
+    assert rel_l2(a[pick], oracle.admm(mag[pick], max_iter=2, rho=1.0, tol=0, hop_length=hop, window=w)) < 1e-4
+    r = N(si.RTISI_LA(T(mag[:, :, :4]), look_ahead=1, max_iter=2, alpha=0.5, verbose=False, **kw))
+    assert r.shape == (batch, (frames - 1) * hop)
+    assert rel_l2(r[pick], oracle.rtisi_la(mag[pick], look_ahead=1, max_iter=2, alpha=0.5, hop_length=hop, window=w)) < 1e-3
+    p = N(si.phase_init(T(mag), **kw))
+    assert np.abs(p[pick] - oracle.phase_init(mag[pick], hop_length=hop, window=w)).max() < 1e-5
+    # the lockstep loop against one plan: a tolerance that fires (methods.py:186-190 on whole-batch sums)
+    small = T(mag[:50])
+    one = N(si.griffin_lim(small, max_iter=300, alpha=0.99, tol=1e-3, verbose=False, eva_iter=5, **kw))
+    monkeypatch.setattr(M, "_MAX_PLAN_BATCH", 20)
+    three = N(si.griffin_lim(small, max_iter=300, alpha=0.99, tol=1e-3, verbose=False, eva_iter=5, **kw))
+    assert np.array_equal(one, three)
