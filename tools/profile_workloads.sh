@@ -1,6 +1,6 @@
 # rocprofv3 runs of every bench workload (on the GPU box via gpurun); outputs land in gpurun_out/${TAG}_<W>_*.
 # Per workload: 1) kernel trace + stats; 2) PMC passes (separate runs, kernel dispatch only - never combined with trace domains).
-TAG=${1:-r02}
+TAG=${1:-r04}
 shift
 WL=${@:-C2 C4 C3 C5}
 cd /tmp && export TMPDIR=/tmp
@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python3 -m spectrogram_inversion_amd.build --hash > gpurun_out/${TAG}_csrc_sha1.txt   # the sources the profiled library was built from
 for W in $WL; do
-  CMD="python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-check"
+  CMD="python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-extra --no-pmc --no-h2d"
   if [ $W = C5 ]; then CMD="$CMD --outer 2"; fi        # (two optimizer.step calls: the per-dispatch counter files of 50 would not fit gpurun_out)
   P=gpurun_out/${TAG}_${W}
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d ${P}_kt -- $CMD > ${P}_kt.log 2>&1
