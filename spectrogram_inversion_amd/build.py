@@ -107,7 +107,10 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
     `extra_flags` / `out` build tuning variants next to the default library (their objects get their own directory)."""
     target = out or LIB_PATH
     extra_flags = tuple(extra_flags) + tuple(os.environ.get("SPECINV_EXTRA_FLAGS", "").split())
-    if out is None and not force and not extra_flags and not is_stale():
+    if extra_flags and out is None:
+        # a variant built over the default library would stay there, "not stale", for every later caller without the flags
+        raise ValueError("a build with extra flags (extra_flags= / SPECINV_EXTRA_FLAGS) needs its own out= path")
+    if out is None and not force and not is_stale():
         return LIB_PATH
     srcs, _ = sources()
     flags = BASE_FLAGS + list(extra_flags)
@@ -123,12 +126,16 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
 
     def compile_one(u):
         src, obj, dep = u
-        cmd = [hipcc, f"--offload-arch={ARCH}", *flags, "-MD", "-MF", dep, "-c", src, "-o", obj + ".tmp"]
+        # (temporaries carry the pid: two processes building at once - ranks, test workers - each finish their own object and
+        # the rename is atomic)
+        tmp_obj, tmp_dep = f"{obj}.{os.getpid()}.tmp", f"{dep}.{os.getpid()}.tmp"
+        cmd = [hipcc, f"--offload-arch={ARCH}", *flags, "-MD", "-MF", tmp_dep, "-MT", obj, "-c", src, "-o", tmp_obj]
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
-        os.replace(obj + ".tmp", obj)
+        os.replace(tmp_dep, dep)
+        os.replace(tmp_obj, obj)
         return os.path.basename(src), time.time() - t0, r.stderr
 
     if todo:
@@ -152,11 +159,11 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
         with open(times_path, "w") as fh:
             json.dump(times, fh)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", "-Wl,-z,defs",
-           *[u[1] for u in units], "-o", target + ".tmp"]
+           *[u[1] for u in units], "-o", f"{target}.{os.getpid()}.tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(target + ".tmp", target)
+    os.replace(f"{target}.{os.getpid()}.tmp", target)
     if key != "default":
         # a tuning variant's objects are not kept (12 MB each): the whole tree, csrc/build included, travels to the GPU box
         import shutil

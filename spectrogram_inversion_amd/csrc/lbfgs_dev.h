@@ -203,37 +203,33 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
     const bool accept = ys > 1e-10;
     int n_prev = R.n_prev;
     if (accept && m == hist) {                    // drop the oldest pair: matrices up-left, vectors of products by one
-      if (w0) {
-        for (int base = 0; base < (hist - 1) * hist; base += 64) {
-          const int e = base + lane;              // destination element (row-major, row r < hist - 1)
-          const int r = e / hist, c = e - r * hist;
-          double a = 0.0, b = 0.0;
-          const bool live = r < hist - 1 && c < hist - 1;
-          if (live) {
-            a = p.sy[(r + 1) * hist + c + 1];
-            b = p.yy[(r + 1) * hist + c + 1];
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (live) {
-            p.sy[e] = a;
-            p.yy[e] = b;
-          }
+      // every thread of the workgroup moves its share, staged through the LDS scratch (lds_sy holds hist * hist doubles; the
+      // recursion below fills it afterwards): two barriers per matrix instead of ~220 dependent load -> store round trips of
+      // one wave at history 100 (round-3 advice)
+      const int h1 = hist - 1;
+      for (int pass = 0; pass < 2; ++pass) {
+        double* mat = pass == 0 ? p.sy : p.yy;
+        for (int e = tid; e < h1 * h1; e += 256) {
+          const int r = e / h1, c = e - r * h1;
+          lds_sy[e] = mat[(r + 1) * hist + c + 1];
         }
-        for (int base = 0; base < hist - 1; base += 64) {
-          const int i = base + lane;
-          double r0 = 0.0, a0 = 0.0, b0 = 0.0;
-          if (i < hist - 1) {
-            r0 = p.rho[i + 1];
-            a0 = p.sgp[i + 1];
-            b0 = p.ygp[i + 1];
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (i < hist - 1) {
-            p.rho[i] = r0;
-            p.sgp[i] = a0;
-            p.ygp[i] = b0;
-          }
+        __syncthreads();
+        for (int e = tid; e < h1 * h1; e += 256) {
+          const int r = e / h1, c = e - r * h1;
+          mat[r * hist + c] = lds_sy[e];
         }
+        __syncthreads();
+      }
+      for (int i = tid; i < h1; i += 256) {
+        al[i] = p.rho[i + 1];
+        cc[i] = p.sgp[i + 1];
+        yq[i] = p.ygp[i + 1];
+      }
+      __syncthreads();
+      for (int i = tid; i < h1; i += 256) {
+        p.rho[i] = al[i];
+        p.sgp[i] = cc[i];
+        p.ygp[i] = yq[i];
       }
       if (n_prev > 0) n_prev -= 1;
       seq0 += 1;

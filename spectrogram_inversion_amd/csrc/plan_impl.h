@@ -823,6 +823,7 @@ struct PlanT final : PlanBase {
   // the device-resident optimiser (lbfgs_dev.h): float32 on the one-launch objective
   std::vector<std::unique_ptr<LbfgsDev<float>>> lbfgs_devs;
   std::vector<std::unique_ptr<FastBuf>> lbd_pool;     // parameter-sized vectors of optimisers that are gone, for the next one
+  static constexpr size_t kLbdPoolKeep = 3 + 2 * 11;  // (what an optimiser at main.py:43's history_size = 10 needs)
   int lbfgs_dev_create(int64_t n, const specinv_lbfgs_opts* opts, int32_t* handle_out) override {
     SI_CHECK(opts && handle_out, SPECINV_EINVAL, "null pointer");
     if constexpr (std::is_same<T, float>::value) {
@@ -850,7 +851,11 @@ struct PlanT final : PlanBase {
   int lbfgs_dev_destroy(int32_t handle) override {
     SI_CHECK(handle >= 0 && (size_t)handle < lbfgs_devs.size() && lbfgs_devs[handle], SPECINV_EINVAL, "bad optimiser handle");
     SI_HIP(hipStreamSynchronize(stream));
-    for (auto& b : lbfgs_devs[handle]->vecs) lbd_pool.push_back(std::move(b));
+    // the optimiser's parameter-sized vectors go back to the pool for the next one - up to the two gradients, the direction and
+    // a handful of curvature pairs (kLbdPoolKeep vectors): a finished optimiser with history 100 would otherwise leave ~200 of
+    // them (6.9 GB at C5) on the device until the plan is dropped
+    for (auto& b : lbfgs_devs[handle]->vecs)
+      if (lbd_pool.size() < kLbdPoolKeep) lbd_pool.push_back(std::move(b));
     lbfgs_devs[handle].reset();
     return SPECINV_OK;
   }

@@ -599,6 +599,8 @@ class LBFGS:
         except (_lib.SpecinvError, NotImplementedError):
             return False
         self._dev = (plan, handle, target, shape)
+        # the device keeps its own copy of the options from here on: a later change of these attributes would be ignored
+        self._dev_opts = (self.lr, self.max_iter, self.max_eval, self.tol_grad, self.tol_change, self.history_size)
         return True
 
     def _step_device(self, fg):
@@ -609,14 +611,25 @@ class LBFGS:
             raise RuntimeError("this optimiser's state lives on the device with the objective it was first stepped with; "
                                "use a new LBFGS for another transform / shape (SPECINV_LBFGS_DEVICE=0 keeps the state on the host)")
         target = obj[1]
+        if (self.lr, self.max_iter, self.max_eval, self.tol_grad, self.tol_change, self.history_size) != self._dev_opts:
+            raise RuntimeError("this optimiser's options were copied to the device at its first step and cannot change afterwards "
+                               "(lr, max_iter, max_eval, tolerances, history_size); create a new LBFGS, or run with "
+                               "SPECINV_LBFGS_DEVICE=0 to keep the state on the host")
+        if getattr(self, "_dev_poisoned", False):
+            raise RuntimeError("an earlier step of this optimiser failed after part of it had been enqueued: its device state is "
+                               "undefined; create a new LBFGS")
         try:
             info = plan.lbfgs_dev_step(handle, self.x.view(shape), target)
         except NotImplementedError:
             if self.total_iters != 0:
+                self._dev_poisoned = True
                 raise
             plan.lbfgs_dev_destroy(handle)              # a configuration the one-launch objective does not cover: host-driven loop
             self._dev = False
             return self.step(fg)
+        except Exception:
+            self._dev_poisoned = True                   # (kernels of the step may have run: x and the state record may disagree)
+            raise
         self.total_iters, self.func_evals = info.total_iters, info.func_evals
         self.pairs_accepted, self.pairs_rejected = info.pairs_accepted, info.pairs_rejected
         self._dev_history, self.t, self.prev_loss = info.history_len, info.t, info.loss

@@ -229,7 +229,7 @@ def RTISI_LA(spec, look_ahead=-1, asymmetric_window=False, max_iter=25, alpha=0.
     else:
         # one persistent launch (what the benchmark measures); a bar nobody watches live is completed at the end
         plan = get_plan(args, spec3.shape[0], spec3.shape[2], spec3.dtype, device)
-        keep = (args.n_fft - 1) // args.hop_length
+        keep = ((stft_kwargs.get("win_length") or args.n_fft) - 1) // args.hop_length      # num_keep, methods.py:322-324
         with tqdm(total=spec3.shape[2] + (keep if look_ahead < 0 else look_ahead), disable=not verbose) as pbar:   # methods.py:362
             x = plan.rtisi(spec3, look_ahead, asymmetric_window, max_iter, alpha)
             if verbose:
@@ -348,4 +348,6 @@ def L_BFGS(spec, transform_fn, samples=None, init_x0=None, outer_max_iter=1000, 
                 previous_loss = l2
     if not in_place:
         x0.copy_(x)
+    del opt                      # (a device-resident optimiser hands its vectors back to the plan's bounded pool)
+    trim_plan_cache()
     return x0
