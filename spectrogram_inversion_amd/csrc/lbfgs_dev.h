@@ -30,6 +30,10 @@ struct LbdState {                         // device-resident; copied to the host
   double t, h_diag, prev_loss, loss;
   // control of the step being executed
   int active, do_lincomb, do_step, do_eval, n_iter, evals, have_prev, k_lin, k_dot, pad_;
+  // the pair accepted by the last decision is FORMED by the direction kernel (y = g - g_prev, s = t_pair d_old, written to the
+  // ring and used from registers): positions of y_new / s_new in the list of the linear combination, -1: no new pair
+  int pair_y, pair_s;
+  double t_pair;
   double first_loss, gtd;
   // reductions of the last evaluation: loss; {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev}
   double b_loss, b_ps[8];
@@ -195,6 +199,8 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
     if (tid == 0) {
       p.coef[0] = -1.0;
       p.lin_ptr[0] = g;
+      S.pair_y = -1;
+      S.pair_s = -1;
       S.n_prev = -1;
     }
   } else {
@@ -320,6 +326,11 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
     if (tid == 0) {
       p.coef[0] = -h_diag;
       p.lin_ptr[0] = g;
+      // an accepted pair is element m - 1 of the memory: the direction kernel forms it on the way (its slot - the spare one of
+      // the ring - has not been written)
+      S.pair_y = accept ? 1 + (m - 1) : -1;
+      S.pair_s = accept ? 1 + m + (m - 1) : -1;
+      S.t_pair = t_prev;
       S.n_prev = n_prev;
       S.pairs_accepted = R.pairs_accepted + (accept ? 1 : 0);
       S.pairs_rejected = R.pairs_rejected + (accept ? 0 : 1);
@@ -377,16 +388,37 @@ __global__ __launch_bounds__(256) void k_lbd_lincomb_step(LbdPtrs<T> p, T* __res
   const int k = S.k_lin;
   const bool step = S.do_step != 0;
   const T t = (T)S.t;
+  // a pair accepted by the decision just taken: y = g - g_prev and s = t_pair d_old are formed here (the same float operations
+  // k_lbd_pair_stats sums over), stored to their ring slots and used from registers - the evaluation's reductions no longer write
+  // a candidate pair that most decisions (BASELINE C5: every one) throw away: 67 MB per iteration less
+  const int jy = S.pair_y, js = S.pair_s;
+  const T* __restrict__ g = p.gbuf[S.cur];
+  const T* __restrict__ gp = p.gbuf[S.cur ^ 1];
+  const T tp = (T)S.t_pair;
   T* __restrict__ out = p.d;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nv = n / W;
   if (i < nv) {
+    VT yv, sv;
+    if (jy >= 0) {
+      const VT gv = reinterpret_cast<const VT*>(g)[i], pv = reinterpret_cast<const VT*>(gp)[i], dv = reinterpret_cast<const VT*>(out)[i];
+#pragma unroll
+      for (int c = 0; c < W; ++c) {
+        yv[c] = gv[c] - pv[c];
+        sv[c] = tp * dv[c];
+      }
+      reinterpret_cast<VT*>(const_cast<T*>(p.lin_ptr[jy]))[i] = yv;
+      reinterpret_cast<VT*>(const_cast<T*>(p.lin_ptr[js]))[i] = sv;
+    }
     double s[W];
 #pragma unroll
     for (int c = 0; c < W; ++c) s[c] = 0.0;
 #pragma unroll 4
     for (int j = 0; j < k; ++j) {
-      const VT v = reinterpret_cast<const VT*>(p.lin_ptr[j])[i];
+      VT v;
+      if (j == jy) v = yv;
+      else if (j == js) v = sv;
+      else v = reinterpret_cast<const VT*>(p.lin_ptr[j])[i];
       const double cj = p.coef[j];
 #pragma unroll
       for (int c = 0; c < W; ++c) s[c] += cj * (double)v[c];
@@ -403,8 +435,15 @@ __global__ __launch_bounds__(256) void k_lbd_lincomb_step(LbdPtrs<T> p, T* __res
     }
   } else if (i == nv) {
     for (int64_t e = nv * W; e < n; ++e) {
+      T ye = T(0), se = T(0);
+      if (jy >= 0) {
+        ye = g[e] - gp[e];
+        se = tp * out[e];
+        const_cast<T*>(p.lin_ptr[jy])[e] = ye;
+        const_cast<T*>(p.lin_ptr[js])[e] = se;
+      }
       double s = 0.0;
-      for (int j = 0; j < k; ++j) s += p.coef[j] * (double)p.lin_ptr[j][e];
+      for (int j = 0; j < k; ++j) s += p.coef[j] * (double)(j == jy ? ye : j == js ? se : p.lin_ptr[j][e]);
       out[e] = (T)s;
       if (step) xs[e] = fma(t, (T)s, xs[e]);
     }
@@ -412,7 +451,7 @@ __global__ __launch_bounds__(256) void k_lbd_lincomb_step(LbdPtrs<T> p, T* __res
 }
 
 // The evaluation's reductions: k_lbfgs_pair_stats on the state's buffers - g = gbuf[cur ^ 1] (just evaluated), g_prev = gbuf[cur],
-// y / s to the candidate slots; before the first iteration there is no previous gradient: statistics with d = g
+// the sums over y = g - g_prev and s = t d without writing them; before the first iteration there is no previous gradient: statistics with d = g
 // (lbfgs.py:_batch), the pair unused - and k_multi_dot over the device-resident list of memory vectors (ss then ys; it returns at
 // once while the memory is empty).  Two kernels: fused into one they share its 158 registers and the streaming pass over g, g_prev,
 // d runs at three waves per SIMD instead of eight (41 against 30 us at C5).  Per-block partial sums; k_lbd_decide finishes them.
@@ -426,20 +465,14 @@ __global__ __launch_bounds__(256) void k_lbd_pair_stats(LbdPtrs<T> p, int64_t n,
   {
     const T* __restrict__ gp = have_prev ? p.gbuf[S.cur] : g;
     const T* __restrict__ d = have_prev ? p.d : g;
-    T* __restrict__ y = p.cand[0];
-    T* __restrict__ sv = p.cand[1];
     const T t = (T)S.t;
     __shared__ double red[16];
     __shared__ double mx[2][16];
     double s[6] = {0, 0, 0, 0, 0, 0}, mg = 0, md = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
       const T gi = g[i], pi = gp[i], di = d[i];
-      const T yi = gi - pi;
+      const T yi = gi - pi;                     // (the pair itself is formed by k_lbd_lincomb_step if the decision accepts it)
       const T si = t * di;
-      if (have_prev) {
-        y[i] = yi;
-        sv[i] = si;
-      }
       const double g64 = (double)gi, d64 = (double)di, ag = fabs(g64), ad = fabs(d64);
       s[0] += g64 * d64;
       s[1] += ag;

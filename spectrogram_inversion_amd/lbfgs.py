@@ -451,9 +451,10 @@ class LBFGS:
         Same decisions in the same order on the same values.  Returns (loss, g, t, evaluations, g.d, max|g|) of the accepted point and max|d|."""
         ops = self.ops
 
+        trial = torch.empty_like(x0)                       # (the trial point is dropped after its evaluation: one buffer)
+
         def phi(step):
-            trial = x0.clone()
-            ops.axpy(step, d, trial)
+            torch.add(x0, d, alpha=step, out=trial)        # x0 + step d in one launch (a fused multiply-add like `axpy`'s)
             g, f, gd, _, gmax, dmax = self._eval_point(fg, trial, d)
             return [step, f, g, gd, gmax], dmax
 
