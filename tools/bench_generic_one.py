@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""One coverage-path configuration, a few iterations: the process tools/log/r04_final.sh wraps in rocprofv3 for
+profiles/r04_generic_{kernel_stats.csv,pmc.json}.  usage: bench_generic_one.py <n_fft> <hop> <frames> <batch> <f32|f64> [twosided]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from spectrogram_inversion_amd.plan import Plan, args_helper
+
+n_fft, hop, frames, batch = (int(v) for v in sys.argv[1:5])
+dtype = torch.float64 if sys.argv[5] == "f64" else torch.float32
+onesided = not (len(sys.argv) > 6 and sys.argv[6] == "twosided")
+dev = torch.device("cuda", 0)
+F = n_fft // 2 + 1 if onesided else n_fft
+mag = torch.rand((batch, F, frames), dtype=dtype, device=dev)
+plan = Plan(args_helper(mag, hop_length=hop, window=torch.hann_window(n_fft, dtype=dtype), onesided=onesided), batch, frames, dtype, dev)
+plan.force_generic(True)
+plan.gla_init(None, mag, 0.3)
+plan.iterate(12)
+torch.cuda.synchronize()
