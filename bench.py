@@ -732,6 +732,7 @@ EXTRA_LEGS = (          # (key, workload, steps, warmup, option overrides) - sho
     ("C3", "C3", 2, 1, {}),
     ("C5", "C5", 2, 1, {"outer": 50, "c5_variant": "baseline"}),
     ("C5_wolfe", "C5", 2, 1, {"outer": 50, "c5_variant": "wolfe"}),
+    ("C1", "C1", 50, 5, {}),
 )
 
 

@@ -19,7 +19,7 @@ DOMINANT = {
     "C5": [bench.DOMINANT["C5"][0], "specinv::k_lbd_pair_stats<float>", "specinv::k_lbd_lincomb_step<float>",
            "specinv::k_lbd_decide<float>", "specinv::k_objective_epilogue", "specinv::k_lbd_multi_dot<float>"],
 }
-ALGO = {"C2": 64 * 1024 * 24596, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 4416}
+ALGO = {"C2": 64 * 1024 * 8196, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 4416}
 out = os.path.join(ROOT, "profiles")
 traffic_path = os.path.join(out, "traffic.json")
 try:
