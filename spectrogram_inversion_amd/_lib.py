@@ -60,6 +60,7 @@ SIGNATURES = {
     "specinv_plan_n_freq": (C.c_int, [_P]),
     "specinv_plan_length": (_I64, [_P]),
     "specinv_plan_fast_path": (C.c_int, [_P]),
+    "specinv_transform_objective_kind": (C.c_int, [_P]),
     "specinv_plan_device_bytes": (_I64, [_P]),
     "specinv_plan_launch_geometry": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "specinv_plan_force_generic": (C.c_int, [_P, C.c_int]),

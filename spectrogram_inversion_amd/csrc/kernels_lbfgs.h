@@ -1139,12 +1139,16 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   *used = false;
   const bool mag = pl.tf_kind == SPECINV_TF_MAG;
   if (pl.force_generic || !pl.cfg.onesided || !pl.fast.xform_ok || (pl.fast.xform_R != 8 && pl.fast.xform_R != 16)) return SPECINV_OK;
-  if (!mag && (pl.tf_kind != SPECINV_TF_LOGMEL || pl.tf_obj_mt == 0)) return SPECINV_OK;
+  bool sparse = !mag && pl.tf_sp_ok;     // the filterbank in band form: contractions on the vector units (SPECINV_OBJ_SPARSE=0: matrix cores)
+  if (const char* e = getenv("SPECINV_OBJ_SPARSE")) {
+    if (e[0] == '0') sparse = false;
+  }
+  if (!mag && (pl.tf_kind != SPECINV_TF_LOGMEL || (pl.tf_obj_mt == 0 && !sparse))) return SPECINV_OK;
   if (const char* e = getenv("SPECINV_DISABLE_FUSED_OBJECTIVE")) {
     if (e[0] == '1') return SPECINV_OK;
   }
   const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), B = pl.B(), pad = pl.pad, R = pl.fast.xform_R;
-  const int MT = mag ? 3 : pl.tf_obj_mt;
+  const int MT = mag ? 3 : sparse ? 9 : pl.tf_obj_mt;
   if (hop > N || hop < 2 || pad >= len) return SPECINV_OK;
   const int nch = (T + fast::kObjTile - 1) / fast::kObjTile;
   if (nch > 1 && T / nch < (N - 1) / hop + 1) return SPECINV_OK;                // a seam must not reach a tile's own tail
@@ -1163,6 +1167,17 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   a.melA = pl.tf_mel_a.template as<fast::f32x4>();
   a.melB = pl.tf_mel_b.template as<fast::f32x4>();
   a.tab = pl.tf_obj_tab.template as<int>();
+  if (sparse) {
+    a.melA = pl.tf_sp_blob.template as<fast::f32x4>();
+    a.melB = nullptr;
+    a.tab = pl.tf_sp_tab.template as<int>();
+    a.sp_rm = pl.tf_sp.rm;
+    a.sp_cm = pl.tf_sp.cm;
+    a.sp_cw = pl.tf_sp.cw;
+    a.sp_total = pl.tf_sp.total;
+    a.sp_cmax = pl.tf_sp.cmax;
+    a.sp_rows = pl.tf_sp.rows;
+  }
   a.window = pl.window.template as<float>();
   a.partials = pl.partials.template as<double>();
   a.len = len;
@@ -1191,6 +1206,10 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     if (R == 16) fn = (const void*)fast::k_objective_logmel<16, 3, true>;
     else fn = (const void*)fast::k_objective_logmel<8, 3, true>;
     lds = R == 16 ? fast::ObjGeo<16, 3>::lds_bytes() : fast::ObjGeo<8, 3>::lds_bytes();
+  } else if (sparse) {
+    if (R == 16) fn = (const void*)fast::k_objective_logmel<16, 9, false, true>;
+    else fn = (const void*)fast::k_objective_logmel<8, 9, false, true>;
+    lds = R == 16 ? fast::ObjGeo<16, 9>::lds_bytes() : fast::ObjGeo<8, 9>::lds_bytes();
   } else {
     SPECINV_OBJ_CASE(16, 3) SPECINV_OBJ_CASE(16, 4) SPECINV_OBJ_CASE(16, 5) SPECINV_OBJ_CASE(16, 8)
     SPECINV_OBJ_CASE(8, 3) SPECINV_OBJ_CASE(8, 4) SPECINV_OBJ_CASE(8, 5) SPECINV_OBJ_CASE(8, 9)
@@ -1226,6 +1245,7 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   }
 #endif
   *used = true;
+  pl.objective_kind = sparse ? 2 : 1;
   {
     const bool fold = pad > 0 && pl.cfg.pad_mode != SPECINV_PAD_CONSTANT;
     const int64_t n_tail = (nch > 1 && keep > 0) ? (int64_t)B * (nch - 1) * keep : 0;
@@ -1285,10 +1305,29 @@ int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
         SI_HIP(hipMemcpy(pl.tf_obj_tab.p, h_tab.data(), h_tab.size() * sizeof(int), hipMemcpyHostToDevice));
         pl.tf_obj_mt = mt16;
       }
+      // ... and its band form, when the filterbank is sparse enough (a mel filterbank is): k_objective_logmel<R, 9, false, true>
+      pl.tf_sp_ok = false;
+      if (n_mels <= 16 * 9 && pl.cfg.onesided && pl.fast.xform_ok && (pl.fast.xform_R == 8 || pl.fast.xform_R == 16)) {
+        std::vector<float> h_mel((size_t)n_mels * pl.n_freq), blob;
+        std::vector<int> h_tab;
+        SI_HIP(hipMemcpyAsync(h_mel.data(), pl.tf_mel.p, h_mel.size() * sizeof(float), hipMemcpyDeviceToHost, pl.stream));
+        SI_HIP(hipStreamSynchronize(pl.stream));
+        const int uni = pl.fast.xform_R == 16 ? fast::ObjGeo<16, 9>::UNI : fast::ObjGeo<8, 9>::UNI;
+        fast::ObjSparseInfo inf;
+        if (fast::obj_build_sparse(h_mel.data(), pl.n_freq, n_mels, uni, blob, h_tab, inf)) {
+          SI_TRY(pl.tf_sp_blob.reserve(blob.size() * sizeof(float)));
+          SI_TRY(pl.tf_sp_tab.reserve(h_tab.size() * sizeof(int)));
+          SI_HIP(hipMemcpy(pl.tf_sp_blob.p, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+          SI_HIP(hipMemcpy(pl.tf_sp_tab.p, h_tab.data(), h_tab.size() * sizeof(int), hipMemcpyHostToDevice));
+          pl.tf_sp = inf;
+          pl.tf_sp_ok = true;
+        }
+      }
     }
   } else {
     pl.tf_mels = 0;
     pl.tf_obj_mt = 0;
+    pl.tf_sp_ok = false;
   }
   pl.tf_kind = kind;
   return SPECINV_OK;
@@ -1366,6 +1405,7 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
   if (const char* e = getenv("SPECINV_REQUIRE_FUSED_OBJECTIVE")) {     // tests: the shape must be on the one-launch kernel
     SI_CHECK(e[0] != '1', SPECINV_EUNSUPPORTED, "the one-launch objective does not cover this configuration");
   }
+  pl.objective_kind = 0;
   SI_TRY(pl.tf_spec.reserve(pl.nspec() * sizeof(C)));
   SI_TRY(pl.stft_internal(x, len, pl.tf_spec.template as<C>()));
   const int nb = 1024;

@@ -43,7 +43,10 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 // MAG: the magnitude objective mean((|STFT(x)| - target)^2) (`MagSTFT`, the reference's test / demo transform,
 // test/test_lbfgs.py:17-18, main.py:21-43): the same kernel without the contractions - dA = 2/numel (|S| - T) is formed
 // element by element on the |S| tile (MT only sizes the shared scratch then).
-template <int R, int MT, bool MAG>
+// SP: the filterbank in band form (objective_args.h: obj_build_sparse): steps 2 - 4 on the vector units, no partial sums - a lane
+// owns whole rows (forward, log1p and dM in one pass) and whole bin quads (backward); the bands are staged into the FFT scratch,
+// which idles between the transforms.
+template <int R, int MT, bool MAG, bool SP>
 __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs a) {
   using G = Geo<R>;
   using OG = ObjGeo<R, MT>;
@@ -82,7 +85,21 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int q = wib + kObjWaves * i, m = 16 * (q >> 2) + 4 * (lane >> 4) + (q & 3), n = lane & 15;
-    tgt[i] = (!MAG && q < 4 * MT && m < a.n_mels && n < nfr) ? a.target[((long long)b * a.n_mels + m) * a.T + t0 + n] : 0.0f;
+    tgt[i] = (!MAG && !SP && q < 4 * MT && m < a.n_mels && n < nfr) ? a.target[((long long)b * a.n_mels + m) * a.T + t0 + n] : 0.0f;
+  }
+  // SP: this wave's list of row quads (lane i: entry i), and the tile's targets [row][frame] - they wait in the dM tile, where
+  // step 3 replaces each by its dM
+  int sp_list = 0, sp_count = 0;
+  constexpr int NT = (16 * MT * 16 + 64 * kObjWaves - 1) / (64 * kObjWaves);
+  float sp_tgt[NT];
+  if constexpr (SP) {
+    sp_count = a.tab[ObjSp::COUNT + wib];
+    sp_list = a.tab[ObjSp::LIST + ObjSp::MAXQ * wib + (lane & (ObjSp::MAXQ - 1))];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int e = threadIdx.x + 64 * kObjWaves * i, m = e >> 4, n = e & 15;
+      sp_tgt[i] = (m < a.n_mels && n < nfr) ? a.target[((long long)b * a.n_mels + m) * a.T + t0 + n] : 0.0f;
+    }
   }
   for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
   for (int i = threadIdx.x; i < (FP - F) * RS; i += blockDim.x) tile[obj_at(F + (i >> 4), i & 15)] = 0.0f;   // rows the zero-padded filterbank meets
@@ -148,7 +165,18 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   const int* blk_fg = nullptr;
   f32x4 av[kRing];
   int dsc_fg = 0, dsc_mg = 0;
-  if constexpr (!MAG) {
+  f32x4 stg[ObjSp::STAGE];
+  if constexpr (SP) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int e = threadIdx.x + 64 * kObjWaves * i;
+      if (e < 16 * MT * 16) dmt[e] = sp_tgt[i];
+    }
+    // the band blob is requested now and goes to LDS after the barrier
+#pragma unroll
+    for (int i = 0; i < ObjSp::STAGE; ++i) stg[i] = a.melA[min((int)threadIdx.x + 64 * kObjWaves * i, a.sp_total - 1)];
+  }
+  if constexpr (!MAG && !SP) {
     // operand blocks of the forward contraction: a ring of kRing blocks in flight per wave (a mel filterbank leaves a wave
     // fewer blocks than that: all of them are requested here, before the barrier, and land while the other waves finish)
     n_blk = a.tab[ObjTab::BEGIN + KQ];
@@ -186,6 +214,110 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       double tot = 0.0;
       for (int w = 0; w < kObjWaves; ++w) tot += lsum[w];
       a.partials[blockIdx.x] = tot;
+    }
+  } else if constexpr (SP) {
+    // the bands go to LDS (the FFT scratch idles between the transforms): read straight from global memory - 23 KB of L1 / L2
+    // hits on a path of their own - the two loops below wait longer for their operands than the LDS port costs them (measured:
+    // forward 4.5 k -> 5.2 k cycles, backward 3.8 k -> 6.5 k)
+    f32x4* u4 = reinterpret_cast<f32x4*>(uni);
+#pragma unroll
+    for (int i = 0; i < ObjSp::STAGE; ++i) {
+      const int u = threadIdx.x + 64 * kObjWaves * i;
+      if (u < a.sp_total) u4[u] = stg[i];
+    }
+    __syncthreads();
+    OBJ_STAMP(4);
+    // ---- 2 + 3 (bands). lane (r, n): mm = row 4 g + r of the filterbank . |S|[:, n] over the row's band, then log1p, squared
+    // error and dM in place; dM tile plain [row][frame]
+    {
+      const int r = lane >> 4, n = lane & 15;
+      const int* rrec = reinterpret_cast<const int*>(u4 + a.sp_rm);
+      double s2 = 0.0;
+      for (int i = 0; i < sp_count; ++i) {
+        const int e = __builtin_amdgcn_readlane(sp_list, i);
+        const int g = e & 255, len = e >> 8, m = 4 * g + r;
+        const float tv = dmt[m * 16 + n];
+        const int ptr = rrec[2 * m], q0 = rrec[2 * m + 1];
+        float v = 0.0f;
+        // four bin quads per pass (len is a multiple of 4), the next pass's operands requested before this pass's products
+        f32x4 w[4], sv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          w[c] = u4[ptr + c];
+          sv[c] = reinterpret_cast<const f32x4*>(tile)[obj_quad(q0 + c, n)];     // (q0 + len <= FP / 4: obj_build_sparse)
+        }
+        for (int t = 0; t < len; t += 4) {
+          const int tn = t + 4 < len ? t + 4 : t;          // (the last pass requests its own operands again)
+          f32x4 wn[4], sn[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            wn[c] = u4[ptr + tn + c];
+            sn[c] = reinterpret_cast<const f32x4*>(tile)[obj_quad(q0 + tn + c, n)];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            v = fmaf(w[c][0], sv[c][0], v);
+            v = fmaf(w[c][1], sv[c][1], v);
+            v = fmaf(w[c][2], sv[c][2], v);
+            v = fmaf(w[c][3], sv[c][3], v);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            w[c] = wn[c];
+            sv[c] = sn[c];
+          }
+        }
+        float dm = 0.0f;
+        if (m < a.n_mels && n < nfr) {
+          // log1p(v) = log(u) + (v - (u - 1)) / u with u = fl(1 + v): the second term restores what the rounding of 1 + v lost
+          // (v >= 0; a third of log1pf's instructions, the same result to an ulp); 1 / u: v_rcp_f32 and one Newton step
+          const float u = 1.0f + v;
+          float ru = fast_rcp(u);
+          ru = fmaf(fmaf(-u, ru, 1.0f), ru, ru);
+          const float d = (logf(u) + (v - (u - 1.0f)) * ru) - tv;
+          s2 += (double)d * (double)d;
+          dm = (a.dscale * d) * ru;
+        }
+        dmt[m * 16 + n] = dm;
+      }
+      OBJ_STAMP(5);
+      s2 = wave_sum(s2);
+      if (lane == 0) lsum[wib] = s2;
+    }
+    __syncthreads();
+    OBJ_STAMP(6);
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < kObjWaves; ++w) tot += lsum[w];
+      a.partials[blockIdx.x] = tot;
+    }
+    // ---- 4 (bands). thread (bin quad q, frame n): dA[4 q + c, n] = sum_j W[m0 + j, 4 q + c] dM[m0 + j, n]; dA overwrites |S|.
+    // A zero weight may meet one of the three rows past the filterbank's last quad: they hold the zeros of the staged targets
+    // (obj_build_sparse keeps them inside the tile)
+    {
+      const int2* crec = reinterpret_cast<const int2*>(u4 + a.sp_cm);
+      const int n = threadIdx.x & 15;
+      const char* dmn = reinterpret_cast<const char*>(dmt + n);
+      constexpr int QS = (64 * kObjWaves) >> 4, NI = (FP / 4 + QS - 1) / QS;     // bin quads per pass of the workgroup, passes
+      int2 cr[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) cr[i] = crec[min((int)(threadIdx.x >> 4) + QS * i, FP / 4 - 1)];   // all records first: the dM reads hang on them
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int q = (threadIdx.x >> 4) + QS * i;
+        if (q < FP / 4) {
+          const int off[4] = {cr[i].x & 0xffff, (int)((unsigned)cr[i].x >> 16), cr[i].y & 0xffff, (int)((unsigned)cr[i].y >> 16)};
+          f32x4 out = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < a.sp_cmax) {
+              const f32x4 w = u4[a.sp_cw + q * a.sp_cmax + j];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) out[c] = fmaf(w[c], *reinterpret_cast<const float*>(dmn + off[c] + 64 * j), out[c]);
+            }
+          reinterpret_cast<f32x4*>(tile)[obj_quad(q, n)] = out;
+        }
+      }
     }
   } else {
   // ---- 2. forward contraction mm[m, n] = sum_f Mel[m, f] |S|[f, n]: the waves split the list of non-zero blocks -------

@@ -50,6 +50,10 @@ struct ObjArgs {
   float fwd_scale;
   float dscale;            // 2 / numel
   unsigned hop_magic;      // ceil(2^32 / hop) (hop > 1), for the division-free frame lookup of the overlap-add
+  // band form of a sparse filterbank (SP kernels; obj_build_sparse): melA is the blob the workgroup stages into LDS, in 16-byte
+  // units [0, sp_rm) row weights, [sp_rm, sp_cm) row records, [sp_cm, sp_cw) column records, [sp_cw, sp_total) column weights;
+  // tab holds the waves' lists of row quads
+  int sp_rm, sp_cm, sp_cw, sp_total, sp_cmax, sp_rows;
   // device-resident optimiser (lbfgs_dev.h): run only if *ctl_eval != 0; the gradient goes to (*ctl_cur ^ 1 ? grad_alt : grad)
   const int* ctl_eval;
   const int* ctl_cur;
@@ -93,7 +97,7 @@ struct ObjGeo {
 };
 
 // defined in kernels_objective.h, compiled in tu_objective.hip
-template <int R, int MT, bool MAG = false>
+template <int R, int MT, bool MAG = false, bool SP = false>
 __global__ void k_objective_logmel(ObjArgs a);
 
 // Host side: cut the filterbank (n_mels x F, row-major, host copy) into 16 x 16 blocks, keep the non-zero ones in
@@ -150,6 +154,128 @@ inline void obj_build_blocks(const float* mel, int F, int n_mels, int MT, std::v
     tab[ObjTab::mel_group(KQ) + e] = mgs[e];
     tab[ObjTab::bin_group(KQ, E) + e] = fgs[e];
   }
+}
+
+// ---- band form of a sparse filterbank -------------------------------------------------------------------------------------
+// A mel filterbank is triangles around a diagonal: ~2 non-zeros per bin (2 F of n_mels x F), 11 % of the entries of its non-zero
+// 16 x 16 blocks.  The SP kernels contract it on the vector units instead, as bands:
+//   forward   row m = its weights over the bin quads [q0, q0 + len) (16-byte units: four consecutive bins, zero outside the row's
+//             support); lane (r, n) of a wave runs row 4 g + r of row quad g at frame n, four rows of a quad side by side, each
+//             padded to the quad's longest row; the waves take row quads from lists balanced by length (ObjSp::LIST);
+//   backward  bin f = the rows [m0, m0 + cmax) that meet it (zero weights beyond its own count), per bin quad one record of four
+//             16-bit offsets of row m0 in the dM tile and cmax 16-byte units of weights.
+// Every weight is the matrix entry itself, so the sums hold exactly the non-zero products of the dense contraction (in band
+// order).  Eligible: at most 4 rows per bin, <= 255 rows, the blob fits the workgroup's staging registers and the FFT scratch.
+struct ObjSp {
+  static constexpr int MAXQ = 16;                       // row quads per wave
+  static constexpr int STAGE = 4;                       // 16-byte units a thread stages: blob <= STAGE * 512 units
+  static constexpr int COUNT = 8, LIST = 16;            // tab[COUNT + w] row quads of wave w; tab[LIST + MAXQ w + i] = g | len << 8
+};
+struct ObjSparseInfo {
+  int rm = 0, cm = 0, cw = 0, total = 0, cmax = 0, rows = 0;
+};
+
+inline bool obj_build_sparse(const float* mel, int F, int n_mels, int uni_floats, std::vector<float>& blob, std::vector<int>& tab,
+                             ObjSparseInfo& inf) {
+  const int KQ = (F + 15) / 16, FP = 16 * KQ, NBQ = FP / 4, QG = (n_mels + 3) / 4, rows = 4 * QG, W = kObjWaves;
+  if (rows + 3 > 16 * 9) return false;            // (the dM tile of k_objective_logmel<R, 9>; rows m0 + j beyond it meet zero weights only)
+  auto at = [&](int m, int f) { return (m < n_mels && f < F) ? mel[(size_t)m * F + f] : 0.0f; };
+  std::vector<int> q0(rows, 0), nq(rows, 0), m0(FP, 0), cnt(FP, 0);
+  for (int m = 0; m < n_mels; ++m) {
+    int lo = -1, hi = -1;
+    for (int f = 0; f < F; ++f)
+      if (mel[(size_t)m * F + f] != 0.0f) {
+        if (lo < 0) lo = f;
+        hi = f;
+      }
+    if (lo >= 0) {
+      q0[m] = lo / 4;
+      nq[m] = hi / 4 - lo / 4 + 1;
+    }
+  }
+  int cmax = 1;
+  for (int f = 0; f < F; ++f) {
+    int lo = -1, hi = -1;
+    for (int m = 0; m < n_mels; ++m)
+      if (mel[(size_t)m * F + f] != 0.0f) {
+        if (lo < 0) lo = m;
+        hi = m;
+      }
+    if (lo >= 0) {
+      m0[f] = lo;
+      cnt[f] = hi - lo + 1;
+      cmax = std::max(cmax, cnt[f]);
+    }
+  }
+  if (cmax > 4) return false;
+  std::vector<int> glen(QG, 1);
+  for (int g = 0; g < QG; ++g) {
+    for (int r = 0; r < 4; ++r) glen[g] = std::max(glen[g], nq[4 * g + r]);
+    glen[g] = std::min((glen[g] + 3) & ~3, NBQ);      // the kernel walks a band four quads at a time (NBQ is a multiple of 4)
+  }
+  for (int g = 0; g < QG; ++g)
+    if (glen[g] > 0xffff) return false;
+  // longest-first onto the least loaded wave (a quad costs its length + the log1p / division of its four rows)
+  std::vector<int> order(QG);
+  for (int g = 0; g < QG; ++g) order[g] = g;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return glen[x] > glen[y]; });
+  std::vector<std::vector<int>> lists(W);
+  std::vector<long long> load(W, 0);
+  for (int g : order) {
+    int w = 0;
+    for (int v = 1; v < W; ++v)
+      if (load[v] < load[w]) w = v;
+    lists[w].push_back(g);
+    load[w] += glen[g] + 6;
+  }
+  for (int w = 0; w < W; ++w)
+    if ((int)lists[w].size() > ObjSp::MAXQ) return false;
+  // blob: row weights | row records (ptr, q0) | column records | column weights
+  std::vector<int> ptr(rows, 0);
+  int n_rw = 0;
+  for (int g = 0; g < QG; ++g)
+    for (int r = 0; r < 4; ++r) {
+      ptr[4 * g + r] = n_rw;
+      n_rw += glen[g];
+    }
+  // a band never leaves the tile: a short row of a long quad starts early instead (the weights are the matrix entries: zeros)
+  for (int m = 0; m < rows; ++m) q0[m] = std::min(q0[m], NBQ - glen[m / 4]);
+  inf.rm = n_rw;
+  inf.cm = inf.rm + (2 * rows + 3) / 4;
+  inf.cw = inf.cm + (2 * NBQ + 3) / 4;
+  inf.total = inf.cw + NBQ * cmax;
+  inf.cmax = cmax;
+  inf.rows = rows;
+  if (inf.total > ObjSp::STAGE * 64 * kObjWaves || (long long)inf.total * 4 > uni_floats) return false;
+  blob.assign((size_t)inf.total * 4, 0.0f);
+  for (int g = 0; g < QG; ++g)
+    for (int r = 0; r < 4; ++r) {
+      const int m = 4 * g + r;
+      for (int t = 0; t < glen[g]; ++t)
+        for (int c = 0; c < 4; ++c) blob[((size_t)ptr[m] + t) * 4 + c] = at(m, 4 * (q0[m] + t) + c);
+    }
+  int* rec = reinterpret_cast<int*>(blob.data() + (size_t)inf.rm * 4);
+  for (int m = 0; m < rows; ++m) {
+    rec[2 * m] = ptr[m];
+    rec[2 * m + 1] = q0[m];
+  }
+  int* crec = reinterpret_cast<int*>(blob.data() + (size_t)inf.cm * 4);
+  for (int q = 0; q < NBQ; ++q) {
+    // byte offsets of row m0 in the plain [row][16 frames] dM tile, 16 bits each; row m0 + j: + 64 j (the instruction's offset)
+    crec[2 * q] = (m0[4 * q] * 64) | ((m0[4 * q + 1] * 64) << 16);
+    crec[2 * q + 1] = (m0[4 * q + 2] * 64) | ((m0[4 * q + 3] * 64) << 16);
+    for (int j = 0; j < cmax; ++j)
+      for (int c = 0; c < 4; ++c) {
+        const int f = 4 * q + c;
+        blob[((size_t)inf.cw + (size_t)q * cmax + j) * 4 + c] = j < cnt[f] ? at(m0[f] + j, f) : 0.0f;
+      }
+  }
+  tab.assign(ObjSp::LIST + ObjSp::MAXQ * W, 0);
+  for (int w = 0; w < W; ++w) {
+    tab[ObjSp::COUNT + w] = (int)lists[w].size();
+    for (size_t i = 0; i < lists[w].size(); ++i) tab[ObjSp::LIST + ObjSp::MAXQ * w + (int)i] = lists[w][i] | (glen[lists[w][i]] << 8);
+  }
+  return true;
 }
 
 }  // namespace fast

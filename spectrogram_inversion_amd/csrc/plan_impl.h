@@ -96,6 +96,9 @@ struct PlanT final : PlanBase {
   DevBuf tf_mel, tf_mel_tiled, tf_mel_tiled_t, tf_spec, tf_v;   // transform (L_BFGS) scratch
   DevBuf tf_mel_a, tf_mel_b, tf_obj_tab;   // non-zero filterbank blocks in MFMA operand order + block table (one-launch objective)
   int tf_obj_mt = 0;                    // its 16-row mel tiles (0: the objective runs as a kernel chain)
+  DevBuf tf_sp_blob, tf_sp_tab;         // a sparse filterbank in band form (objective_args.h: obj_build_sparse)
+  fast::ObjSparseInfo tf_sp{};
+  bool tf_sp_ok = false;
   std::vector<T> h_window;
   FrameCfg<T> fc{};
   size_t lds_bytes = 0;        // LDS of k_stft / k_iter_pair / k_grad_frames (one buffer when use_inplace)

@@ -184,6 +184,7 @@ int specinv_plan_set_stream(specinv_plan* plan, void* hip_stream) {
 int specinv_plan_n_freq(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->n_freq : SPECINV_EINVAL; }
 int64_t specinv_plan_length(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->length : SPECINV_EINVAL; }
 int specinv_plan_fast_path(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->path_kind() : SPECINV_EINVAL; }
+int specinv_transform_objective_kind(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->objective_kind : SPECINV_EINVAL; }
 int64_t specinv_plan_device_bytes(const specinv_plan* plan) { return plan && plan->impl ? plan->impl->dev_bytes : SPECINV_EINVAL; }
 int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]) {
   SI_CHECK(plan != nullptr && plan->impl && out, SPECINV_EINVAL, "null argument");

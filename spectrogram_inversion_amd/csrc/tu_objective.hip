@@ -14,6 +14,8 @@ template __global__ void k_objective_logmel<16, 3, false>(ObjArgs);
 template __global__ void k_objective_logmel<16, 4, false>(ObjArgs);
 template __global__ void k_objective_logmel<16, 5, false>(ObjArgs);
 template __global__ void k_objective_logmel<16, 8, false>(ObjArgs);
+template __global__ void k_objective_logmel<8, 9, false, true>(ObjArgs);
+template __global__ void k_objective_logmel<16, 9, false, true>(ObjArgs);
 template __global__ void k_objective_logmel<8, 3, true>(ObjArgs);
 template __global__ void k_objective_logmel<16, 3, true>(ObjArgs);
 

@@ -166,6 +166,12 @@ class Plan:
         return self.lib.specinv_plan_fast_path(self._h)
 
     @property
+    def objective_kind(self) -> str:
+        """How the last `transform_loss_grad` of this plan ran (`specinv_transform_objective_kind`): "chain" of kernels,
+        one launch with the mel contractions on the "matrix" cores, one launch with the filterbank as "bands", or "none" yet."""
+        return {0: "chain", 1: "matrix", 2: "bands"}.get(self.lib.specinv_transform_objective_kind(self._h), "none")
+
+    @property
     def launch_geometry(self) -> dict:
         """Diagnostics: how the iteration kernel is launched (`specinv_plan_launch_geometry`)."""
         out = (C.c_int32 * 4)()

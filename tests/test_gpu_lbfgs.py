@@ -261,7 +261,8 @@ def test_gram_direction_follows_the_two_loop_recursion(history):
     (2048, 512, 20, 2, 80, dict(center=False)),                   # no padding: signal of (T-1) hop + n_fft samples
 ])
 def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frames, batch, n_mels, kw):
-    """`specinv_transform_loss_grad` for the log-mel transform as ONE kernel (spectrum kept on the chip) against the same
+    """`specinv_transform_loss_grad` for the log-mel transform as ONE kernel (spectrum kept on the chip) - the filterbank as bands on
+    the vector units (what a mel filterbank gets) and as 16 x 16 blocks on the matrix cores (any matrix) - against the same
     objective as a chain of kernels (spectrum through HBM) and against the float64 oracle: loss and gradient."""
     rng = np.random.default_rng(n_fft + hop + frames)
     center = kw.get("center", True)
@@ -271,25 +272,49 @@ def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frame
     xs = (0.1 * rng.standard_normal((batch, length))).astype(np.float32)
     x0 = (0.05 * rng.standard_normal((batch, length))).astype(np.float32)
     out = {}
-    for mode in ("fused", "chain"):
+    for mode in ("bands", "matrix", "chain"):
         monkeypatch.setenv("SPECINV_DISABLE_FUSED_OBJECTIVE", "1" if mode == "chain" else "0")
-        monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1" if mode == "fused" else "0")
+        monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "0" if mode == "chain" else "1")
+        monkeypatch.setenv("SPECINV_OBJ_SPARSE", "0" if mode == "matrix" else "1")
         tr = LogMelSTFT(T(fb), n_fft, hop_length=hop, window=torch.from_numpy(w), **kw)
         target = tr(T(xs))
         _, fg = tr.bind(T(x0), target)
         loss, grad = fg(T(x0))
+        assert fg.device_objective[0].objective_kind == mode
         loss2, grad2 = fg(T(x0))
         assert loss == loss2 and torch.equal(grad, grad2)           # fixed summation order: bitwise reproducible
         out[mode] = (loss, N(grad), N(target))
-    (lf, gf, tf), (lc, gc, tc) = out["fused"], out["chain"]
-    assert np.array_equal(tf, tc)
-    assert abs(lf - lc) < 2e-6 * abs(lc), (lf, lc)
-    assert rel_l2(gf, gc) < 3e-6, rel_l2(gf, gc)
     a = oracle.args_helper(n_fft // 2 + 1, np.float64, hop_length=hop, window=w.astype(np.float64), **kw)
     ref = LogMelStft(a, fb.astype(np.float64))
     lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
-    assert abs(lf - lo) < 1e-5 * abs(lo), (lf, lo)
-    assert rel_l2(gf, go) < 1e-5, rel_l2(gf, go)
+    lc, gc, tc = out["chain"]
+    for mode in ("bands", "matrix"):
+        lf, gf, tf = out[mode]
+        assert np.array_equal(tf, tc)
+        assert abs(lf - lc) < 2e-6 * abs(lc), (mode, lf, lc)
+        assert rel_l2(gf, gc) < 3e-6, (mode, rel_l2(gf, gc))
+        assert abs(lf - lo) < 1e-5 * abs(lo), (mode, lf, lo)
+        assert rel_l2(gf, go) < 1e-5, (mode, rel_l2(gf, go))
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(2048, 512, 140), (1024, 256, 137)])
+def test_one_launch_objective_beyond_128_bands(monkeypatch, n_fft, hop, n_mels):
+    """The matrix-core kernels stop at 128 bands (8 tiles of 16 rows); the band form takes a mel filterbank of up to 140."""
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    rng = np.random.default_rng(n_mels)
+    frames, batch = 35, 2
+    fb = si.mel_filterbank(22050, n_fft, n_mels)
+    w = hann(n_fft)
+    xs = (0.1 * rng.standard_normal((batch, (frames - 1) * hop))).astype(np.float32)
+    x0 = (0.05 * rng.standard_normal(xs.shape)).astype(np.float32)
+    tr = LogMelSTFT(T(fb), n_fft, hop_length=hop, window=torch.from_numpy(w))
+    _, fg = tr.bind(T(x0), tr(T(xs)))
+    loss, grad = fg(T(x0))
+    assert fg.device_objective[0].objective_kind == "bands"
+    a = oracle.args_helper(n_fft // 2 + 1, np.float64, hop_length=hop, window=w.astype(np.float64))
+    ref = LogMelStft(a, fb.astype(np.float64))
+    lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
+    assert abs(loss - lo) < 1e-5 * abs(lo) and rel_l2(N(grad), go) < 1e-5
 
 
 def test_one_launch_objective_falls_back_where_it_does_not_fit(monkeypatch):
@@ -344,7 +369,7 @@ def test_one_launch_objective_signal_longer_than_its_frames(monkeypatch, center)
 @pytest.mark.parametrize("n_mels", [80, 33])
 def test_one_launch_objective_with_a_dense_matrix(monkeypatch, n_mels):
     """The block list leaves out all-zero 16 x 16 blocks of the filterbank; a dense (random, signed-free) matrix keeps
-    every block, a matrix with one non-zero entry keeps one - both against the float64 oracle."""
+    every block (and stays on the matrix cores), a matrix with one non-zero entry is one band - both against the float64 oracle."""
     n_fft, hop, frames, batch = 1024, 256, 40, 2
     rng = np.random.default_rng(n_mels)
     w = hann(n_fft)
@@ -358,6 +383,8 @@ def test_one_launch_objective_with_a_dense_matrix(monkeypatch, n_mels):
         tr = LogMelSTFT(T(fb), n_fft, hop_length=hop, window=torch.from_numpy(w))
         _, fg = tr.bind(T(x0), tr(T(xs)))
         loss, grad = fg(T(x0))
+        # (a dense matrix has no band form: every bin meets every row; one entry, or none, is the sparsest band there is)
+        assert fg.device_objective[0].objective_kind == ("matrix" if fb is dense else "bands")
         a = oracle.args_helper(n_fft // 2 + 1, np.float64, hop_length=hop, window=w.astype(np.float64))
         ref = LogMelStft(a, fb.astype(np.float64))
         lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
