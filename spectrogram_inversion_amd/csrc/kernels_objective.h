@@ -12,17 +12,22 @@
 //   4. backward contraction dA = Mel^T dM on the matrix cores, the waves split the bin tiles; dA overwrites the |S| tile;
 //   5. each wave forms G = dA S/|S| (interior bins halved: the Hermitian extension) for its two frames, runs the inverse
 //      FFT and applies the window;
-//   6. the windowed frames are staged in LDS (the tiles are free by then) and every output sample gathers the frames
-//      that cover it in frame order; the span's first frames*hop samples go to the gradient, the remaining n_fft - hop
-//      (what the tile adds to its successor's samples) to `xtail`; k_hop_tails_raw and k_grad_fold_margins of the
-//      unfused path finish the seams and the padding.
+//   6. the windowed frames are staged in LDS (the tiles are free by then; with hop = n_fft/2, /4, /8 a wave's two frames are
+//      added in registers first) and every output sample gathers what covers it in frame order; the span's first frames*hop
+//      samples go to the gradient, the remaining n_fft - hop (what the tile adds to its successor's samples) to `xtail`;
+//      k_objective_epilogue finishes the seams and the padding.
 // HBM traffic per frame: 4*hop read + 4*hop written + 4*n_mels target (+ the seams, + the filterbank, which every
 // workgroup streams from L2): SURVEY 8d's 8h + 4 n_mels.
-// The filterbank is cut into 16 x 16 blocks (16 mel rows x 16 bins) stored in MFMA operand order, one copy per
-// contraction: one 16-byte load per lane feeds four MFMAs.  Blocks that are entirely zero are left out of the block list
+// Matrix cores (any filterbank matrix): it is cut into 16 x 16 blocks (16 mel rows x 16 bins) stored in MFMA operand order, one
+// copy per contraction: one 16-byte load per lane feeds four MFMAs.  Blocks that are entirely zero are left out of the block list
 // (obj_build_blocks): adding 0 * x changes nothing, so the result is bit for bit that of the dense contraction, and a mel
 // filterbank - triangles around the diagonal - keeps ~1/3 of its blocks.  A dense matrix keeps all of them.
+// Bands (SP, a sparse matrix - what a mel filterbank is): 2 F non-zeros are 11 % of the entries of those blocks, and float32 MFMA
+// has the vector units' rate; steps 2 - 4 run on the vector units over the rows' / bins' bands instead (objective_args.h:
+// obj_build_sparse), a third of the cycles.
 #pragma once
+#include <type_traits>
+
 #include "objective_args.h"
 
 namespace specinv {
@@ -39,6 +44,18 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
 #define OBJ_STAMP(i) do { } while (0)
 #endif
 
+
+// Step 3 for one output: d = log1p(v) - target, the squared error, dM = dscale d / (1 + v)  (v = (Mel |S|)[m, n] >= 0).
+//   log1p(v) = log(u) + (v - (u - 1)) / u with u = fl(1 + v): the second term restores what the rounding of 1 + v lost (a third of
+//   log1pf's instructions, the same result to an ulp); 1 / u: v_rcp_f32 and one Newton step.
+__device__ __forceinline__ float obj_point(float v, float target, float dscale, double& s2) {
+  const float u = 1.0f + v;
+  float ru = fast_rcp(u);
+  ru = fmaf(fmaf(-u, ru, 1.0f), ru, ru);
+  const float d = (logf(u) + (v - (u - 1.0f)) * ru) - target;
+  s2 += (double)d * (double)d;
+  return (dscale * d) * ru;
+}
 
 // MAG: the magnitude objective mean((|STFT(x)| - target)^2) (`MagSTFT`, the reference's test / demo transform,
 // test/test_lbfgs.py:17-18, main.py:21-43): the same kernel without the contractions - dA = 2/numel (|S| - T) is formed
@@ -268,16 +285,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
           }
         }
         float dm = 0.0f;
-        if (m < a.n_mels && n < nfr) {
-          // log1p(v) = log(u) + (v - (u - 1)) / u with u = fl(1 + v): the second term restores what the rounding of 1 + v lost
-          // (v >= 0; a third of log1pf's instructions, the same result to an ulp); 1 / u: v_rcp_f32 and one Newton step
-          const float u = 1.0f + v;
-          float ru = fast_rcp(u);
-          ru = fmaf(fmaf(-u, ru, 1.0f), ru, ru);
-          const float d = (logf(u) + (v - (u - 1.0f)) * ru) - tv;
-          s2 += (double)d * (double)d;
-          dm = (a.dscale * d) * ru;
-        }
+        if (m < a.n_mels && n < nfr) dm = obj_point(v, tv, a.dscale, s2);
         dmt[m * 16 + n] = dm;
       }
       OBJ_STAMP(5);
@@ -376,11 +384,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
         for (int w = 0; w < kObjWaves; ++w) v += uni[((w * MT + mt) * 4 + r) * 64 + lane];   // fixed order
         const int m = 16 * mt + 4 * (lane >> 4) + r, n = lane & 15;   // D[i = m][j = n]: col = lane & 15, row = 4 (lane >> 4) + r
         float dm = 0.0f;
-        if (m < a.n_mels && n < nfr) {
-          const float d = log1pf(v) - tgt[i];
-          s2 += (double)d * (double)d;
-          dm = a.dscale * d / (1.0f + v);
-        }
+        if (m < a.n_mels && n < nfr) dm = obj_point(v, tgt[i], a.dscale, s2);
         dmt[obj_at(m, n)] = dm;
       }
     }
@@ -472,18 +476,42 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   OBJ_STAMP(10);
 
   // ---- 6. overlap-add: the windowed frames go to LDS (the |S| / dA tile, the dM tile and the scratch are one region of
-  // >= 16 n_fft floats, all free by now), then every output sample gathers the <= n_fft/hop frames that cover it, in
-  // frame order - the order of k_ola's gather in the unfused path, so the sums round the same way ---------------------------
+  // >= 16 n_fft floats, all free by now), then every output sample gathers what covers it, in frame order.  With hop = n_fft/2,
+  // /4 or /8 a wave's two frames are first added in registers (frame 2 w + 1 lies hop samples - a whole number of its lanes'
+  // 128-sample rows - behind frame 2 w): eight spans of n_fft + hop samples instead of sixteen frames, 5/8 of the LDS writes and
+  // of the gather's reads.  Any other hop: the sixteen frames, the order of k_ola's gather in the unfused path. ------------------
   float* frames = tile;
   static_assert((size_t)FP * RS + 16 * MT * RS + OG::UNI >= (size_t)kObjTile * N, "the frame buffers do not fit");
+  const int hrows = a.hop >> 7;                               // the hop in rows of 128 samples (64 lanes x 2)
+  const bool pairs = (a.hop & 127) == 0 && (2 * hrows == R || 4 * hrows == R || 8 * hrows == R);
+  if (pairs) {
+    v2f* p2 = reinterpret_cast<v2f*>(frames + wib * (N + a.hop));
+    auto put = [&](auto hs_c) {
+      constexpr int HS = decltype(hs_c)::value;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    v2f* f2 = reinterpret_cast<v2f*>(frames + (2 * wib + i) * N);
+      for (int u = 0; u < R + HS; ++u) {
+        v2f v = v2f{0.0f, 0.0f};
+        if (u < R) v = fr[0][u < R ? u : 0];
+        if (u >= HS) v = u < R ? v + fr[1][u - HS] : fr[1][u - HS];
+        p2[64 * u + lane] = v;
+      }
+    };
+    if (2 * hrows == R) put(std::integral_constant<int, R / 2>{});
+    else if (4 * hrows == R) put(std::integral_constant<int, R / 4>{});
+    else put(std::integral_constant<int, R / 8>{});
+  } else {
 #pragma unroll
-    for (int u = 0; u < R; ++u) f2[64 * u + lane] = fr[i][u];
+    for (int i = 0; i < 2; ++i) {
+      v2f* f2 = reinterpret_cast<v2f*>(frames + (2 * wib + i) * N);
+#pragma unroll
+      for (int u = 0; u < R; ++u) f2[64 * u + lane] = fr[i][u];
+    }
   }
   __syncthreads();
   OBJ_STAMP(11);
+  // units of the gather: frames (step hop, length n_fft) or pair sums (step 2 hop, length n_fft + hop)
+  const int ulen = pairs ? N + a.hop : N, ustep = pairs ? 2 * a.hop : a.hop, ush = pairs ? 1 : 0;
+  const int ulast = pairs ? (nfr - 1) >> 1 : nfr - 1;
   // the tile's own frames*hop samples are final up to the previous tile's tail; the rest of the span is this tile's tail
   const int span_len = (nfr - 1) * a.hop + N;
   const long long p0 = (long long)t0 * a.hop;
@@ -498,33 +526,36 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     // the common case: 16-byte pieces, everything inside the signal
     v4f* g4 = reinterpret_cast<v4f*>(go + n0);
     v4f* t4 = reinterpret_cast<v4f*>(tl);
+    const int dlt = ulen - ustep;                           // sample s sits at frames[n ulen + s - n ustep] = frames[s + n dlt] in unit n
     for (int s4 = threadIdx.x; s4 < span_len / 4; s4 += blockDim.x) {
       const int s = 4 * s4;
-      // frames n_lo .. n_hi cover sample s (division by the hop: multiplication by ceil(2^32 / hop), exact below 2^16)
-      const int n_lo = s < N ? 0 : (int)__umulhi((unsigned)(s - N), a.hop_magic) + 1;
-      int n_hi = (int)__umulhi((unsigned)s, a.hop_magic);
-      if (n_hi > nfr - 1) n_hi = nfr - 1;
+      // units n_lo .. n_hi cover sample s (division by the hop: multiplication by ceil(2^32 / hop), exact below 2^16)
+      const int n_lo = s < ulen ? 0 : (int)(__umulhi((unsigned)(s - ulen), a.hop_magic) >> ush) + 1;
+      int n_hi = (int)(__umulhi((unsigned)s, a.hop_magic) >> ush);
+      if (n_hi > ulast) n_hi = ulast;
       v4f acc = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      for (int nb = n_lo; nb <= n_hi; nb += 4) {            // four reads in flight, added in frame order
-        v4f t[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nb + q <= n_hi ? nb + q : n_hi;
-          t[q] = *reinterpret_cast<const v4f*>(frames + n * N + (s - n * a.hop));
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (nb + q <= n_hi) acc = acc + t[q];
+      for (int nb = n_lo; nb <= n_hi; nb += 4) {            // four reads in flight, added in unit order
+        const float* p0q = frames + s + nb * dlt;
+        const bool h1 = nb + 1 <= n_hi, h2 = nb + 2 <= n_hi, h3 = nb + 3 <= n_hi;
+        const float* p1q = h1 ? p0q + dlt : p0q;            // (a unit past the last one: its neighbour's address again, not added)
+        const float* p2q = h2 ? p1q + dlt : p1q;
+        const float* p3q = h3 ? p2q + dlt : p2q;
+        const v4f t0 = *reinterpret_cast<const v4f*>(p0q), t1 = *reinterpret_cast<const v4f*>(p1q);
+        const v4f t2 = *reinterpret_cast<const v4f*>(p2q), t3 = *reinterpret_cast<const v4f*>(p3q);
+        acc = acc + t0;
+        if (h1) acc = acc + t1;
+        if (h2) acc = acc + t2;
+        if (h3) acc = acc + t3;
       }
       if (s < lim) g4[s4] = acc;
       else t4[s4 - lim / 4] = acc;
     }
   } else {
     for (int s = threadIdx.x; s < span_len; s += blockDim.x) {
-      int n_lo = s < N ? 0 : (s - N) / a.hop + 1, n_hi = s / a.hop;
-      if (n_hi > nfr - 1) n_hi = nfr - 1;
+      int n_lo = s < ulen ? 0 : (s - ulen) / ustep + 1, n_hi = s / ustep;
+      if (n_hi > ulast) n_hi = ulast;
       float v = 0.0f;
-      for (int n = n_lo; n <= n_hi; ++n) v += frames[n * N + (s - n * a.hop)];
+      for (int n = n_lo; n <= n_hi; ++n) v += frames[n * ulen + (s - n * ustep)];
       if (s < lim) {
         const long long nn = n0 + s;
         if (nn >= 0 && nn < a.len) go[nn] = v;
