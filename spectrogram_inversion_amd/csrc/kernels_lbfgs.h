@@ -1241,6 +1241,12 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
       double all = 0;
       for (int64_t t = 0; t < n_tiles; ++t) all += (double)(h[t * 16 + 12] - h[t * 16]);
       fprintf(stderr, "  %-22s %9.0f\n", "whole tile", all / n_tiles);
+      double g0 = 0, g1 = 0;                     // inside the write-out: to the gather loop's start, through its first trip
+      for (int64_t t = 0; t < n_tiles; ++t) {
+        g0 += (double)(h[t * 16 + 13] - h[t * 16 + 11]);
+        g1 += (double)(h[t * 16 + 14] - h[t * 16 + 13]);
+      }
+      fprintf(stderr, "  %-22s %9.0f %9.0f\n", "gather: setup, trip 1", g0 / n_tiles, g1 / n_tiles);
     }
   }
 #endif

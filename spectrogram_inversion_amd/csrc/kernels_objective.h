@@ -245,31 +245,45 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     __syncthreads();
     OBJ_STAMP(4);
     // ---- 2 + 3 (bands). lane (r, n): mm = row 4 g + r of the filterbank . |S|[:, n] over the row's band, then log1p, squared
-    // error and dM in place; dM tile plain [row][frame]
+    // error and dM in place; dM tile plain [row][frame].  Four bin quads per pass (a band is a multiple of four long); the next
+    // pass's operands - the NEXT row quad's first pass after the last one - are requested before this pass's products, so a wave
+    // waits for its LDS reads once per list, not once per row quad.  (Bands starting on multiples of four quads would save nine
+    // address instructions per pass - the swizzle then moves two bits of n by a lane constant - and cost 34 % more passes.)
     {
       const int r = lane >> 4, n = lane & 15;
       const int* rrec = reinterpret_cast<const int*>(u4 + a.sp_rm);
+      const f32x4* t4s = reinterpret_cast<const f32x4*>(tile);
       double s2 = 0.0;
-      for (int i = 0; i < sp_count; ++i) {
-        const int e = __builtin_amdgcn_readlane(sp_list, i);
-        const int g = e & 255, len = e >> 8, m = 4 * g + r;
-        const float tv = dmt[m * 16 + n];
-        const int ptr = rrec[2 * m], q0 = rrec[2 * m + 1];
-        float v = 0.0f;
-        // four bin quads per pass (len is a multiple of 4), the next pass's operands requested before this pass's products
-        f32x4 w[4], sv[4];
+      int e_cur = __builtin_amdgcn_readlane(sp_list, 0);
+      int m_cur = 4 * (e_cur & 255) + r;
+      int ptr_cur = 0, q0_cur = 0;
+      float tv_cur = 0.0f;
+      f32x4 w[4], sv[4];
+      if (sp_count > 0) {
+        ptr_cur = rrec[2 * m_cur];
+        q0_cur = rrec[2 * m_cur + 1];
+        tv_cur = dmt[m_cur * 16 + n];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          w[c] = u4[ptr + c];
-          sv[c] = reinterpret_cast<const f32x4*>(tile)[obj_quad(q0 + c, n)];     // (q0 + len <= FP / 4: obj_build_sparse)
+          w[c] = u4[ptr_cur + c];
+          sv[c] = t4s[obj_quad(q0_cur + c, n)];               // (q0 + len <= FP / 4: obj_build_sparse)
         }
+      }
+      for (int i = 0; i < sp_count; ++i) {
+        const int len = e_cur >> 8;
+        const int e_nx = __builtin_amdgcn_readlane(sp_list, i + 1 < sp_count ? i + 1 : i);
+        const int m_nx = 4 * (e_nx & 255) + r;
+        const int ptr_nx = rrec[2 * m_nx], q0_nx = rrec[2 * m_nx + 1];
+        const float tv_nx = dmt[m_nx * 16 + n];              // (this lane's own element: nobody else writes it)
+        float v = 0.0f;
         for (int t = 0; t < len; t += 4) {
-          const int tn = t + 4 < len ? t + 4 : t;          // (the last pass requests its own operands again)
+          const bool lastp = t + 4 >= len;
+          const int pn = lastp ? ptr_nx : ptr_cur + t + 4, qn = lastp ? q0_nx : q0_cur + t + 4;
           f32x4 wn[4], sn[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            wn[c] = u4[ptr + tn + c];
-            sn[c] = reinterpret_cast<const f32x4*>(tile)[obj_quad(q0 + tn + c, n)];
+            wn[c] = u4[pn + c];
+            sn[c] = t4s[obj_quad(qn + c, n)];
           }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -285,8 +299,13 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
           }
         }
         float dm = 0.0f;
-        if (m < a.n_mels && n < nfr) dm = obj_point(v, tv, a.dscale, s2);
-        dmt[m * 16 + n] = dm;
+        if (m_cur < a.n_mels && n < nfr) dm = obj_point(v, tv_cur, a.dscale, s2);
+        dmt[m_cur * 16 + n] = dm;
+        e_cur = e_nx;
+        m_cur = m_nx;
+        ptr_cur = ptr_nx;
+        q0_cur = q0_nx;
+        tv_cur = tv_nx;
       }
       OBJ_STAMP(5);
       s2 = wave_sum(s2);
@@ -310,22 +329,42 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       int2 cr[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) cr[i] = crec[min((int)(threadIdx.x >> 4) + QS * i, FP / 4 - 1)];   // all records first: the dM reads hang on them
+      // three bin quads per trip, their weights and dM values all requested before the first product (CM = rows per bin, padded to
+      // 2 or 4 with zero weights by obj_build_sparse)
+      auto backward = [&](auto cm_c) {
+        constexpr int CM = decltype(cm_c)::value, BATCH = CM == 2 ? 3 : 1;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int q = (threadIdx.x >> 4) + QS * i;
-        if (q < FP / 4) {
-          const int off[4] = {cr[i].x & 0xffff, (int)((unsigned)cr[i].x >> 16), cr[i].y & 0xffff, (int)((unsigned)cr[i].y >> 16)};
-          f32x4 out = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ib = 0; ib < NI; ib += BATCH) {
+          f32x4 w[BATCH][CM];
+          float d[BATCH][CM][4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < a.sp_cmax) {
-              const f32x4 w = u4[a.sp_cw + q * a.sp_cmax + j];
+          for (int k = 0; k < BATCH; ++k)
+            if (ib + k < NI) {
+              const int q = min((int)(threadIdx.x >> 4) + QS * (ib + k), FP / 4 - 1);      // (past the end: the last quad again, not stored)
+              const int2 c2 = cr[ib + k];
+              const int off[4] = {c2.x & 0xffff, (int)((unsigned)c2.x >> 16), c2.y & 0xffff, (int)((unsigned)c2.y >> 16)};
 #pragma unroll
-              for (int c = 0; c < 4; ++c) out[c] = fmaf(w[c], *reinterpret_cast<const float*>(dmn + off[c] + 64 * j), out[c]);
+              for (int j = 0; j < CM; ++j) {
+                w[k][j] = u4[a.sp_cw + q * CM + j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[k][j][c] = *reinterpret_cast<const float*>(dmn + off[c] + 64 * j);
+              }
             }
-          reinterpret_cast<f32x4*>(tile)[obj_quad(q, n)] = out;
+#pragma unroll
+          for (int k = 0; k < BATCH; ++k)
+            if (ib + k < NI) {
+              const int q = (threadIdx.x >> 4) + QS * (ib + k);
+              f32x4 out = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+              for (int j = 0; j < CM; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) out[c] = fmaf(w[k][j][c], d[k][j][c], out[c]);
+              if (q < FP / 4) reinterpret_cast<f32x4*>(tile)[obj_quad(q, n)] = out;
+            }
         }
-      }
+      };
+      if (a.sp_cmax == 2) backward(std::integral_constant<int, 2>{});
+      else backward(std::integral_constant<int, 4>{});
     }
   } else {
   // ---- 2. forward contraction mm[m, n] = sum_f Mel[m, f] |S|[f, n]: the waves split the list of non-zero blocks -------
@@ -527,9 +566,49 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
     v4f* g4 = reinterpret_cast<v4f*>(go + n0);
     v4f* t4 = reinterpret_cast<v4f*>(tl);
     const int dlt = ulen - ustep;                           // sample s sits at frames[n ulen + s - n ustep] = frames[s + n dlt] in unit n
-    for (int s4 = threadIdx.x; s4 < span_len / 4; s4 += blockDim.x) {
+    const int total = span_len / 4;
+    // NU units at most cover a sample; five outputs per thread and trip, their reads all requested before the first sum: a trip
+    // of one output at a time waits for its LDS reads three times over (5.2 k cycles of a tile; this form: see DESIGN 3.7)
+    auto gather = [&](auto nu_c) {
+      constexpr int NU = decltype(nu_c)::value, UNR = 5, NTH = 64 * kObjWaves;
+      for (int base = threadIdx.x; base < total; base += UNR * NTH) {
+        v4f t[UNR][NU];
+        bool h[UNR][NU];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+          const int s4 = min(base + k * NTH, total - 1), s = 4 * s4;      // (past the end: the last output again, not stored)
+          // units n_lo .. n_hi cover sample s (division by the hop: multiplication by ceil(2^32 / hop), exact below 2^16)
+          const int n_lo = s < ulen ? 0 : (int)(__umulhi((unsigned)(s - ulen), a.hop_magic) >> ush) + 1;
+          int n_hi = (int)(__umulhi((unsigned)s, a.hop_magic) >> ush);
+          if (n_hi > ulast) n_hi = ulast;
+          const float* q = frames + s + n_lo * dlt;
+          t[k][0] = *reinterpret_cast<const v4f*>(q);
+#pragma unroll
+          for (int j = 1; j < NU; ++j) {
+            h[k][j] = n_lo + j <= n_hi;
+            q = h[k][j] ? q + dlt : q;                      // (a unit past the last one: its neighbour's address again, not added)
+            t[k][j] = *reinterpret_cast<const v4f*>(q);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+          const int s4 = base + k * NTH, s = 4 * s4;
+          v4f acc = t[k][0];
+#pragma unroll
+          for (int j = 1; j < NU; ++j)
+            if (h[k][j]) acc = acc + t[k][j];               // unit order
+          if (s4 < total) {
+            if (s < lim) g4[s4] = acc;
+            else t4[s4 - lim / 4] = acc;
+          }
+        }
+      }
+    };
+    if (ulen <= 3 * ustep) gather(std::integral_constant<int, 3>{});
+    else if (ulen <= 5 * ustep) gather(std::integral_constant<int, 5>{});
+    else
+    for (int s4 = threadIdx.x; s4 < total; s4 += blockDim.x) {
       const int s = 4 * s4;
-      // units n_lo .. n_hi cover sample s (division by the hop: multiplication by ceil(2^32 / hop), exact below 2^16)
       const int n_lo = s < ulen ? 0 : (int)(__umulhi((unsigned)(s - ulen), a.hop_magic) >> ush) + 1;
       int n_hi = (int)(__umulhi((unsigned)s, a.hop_magic) >> ush);
       if (n_hi > ulast) n_hi = ulast;
@@ -537,7 +616,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
       for (int nb = n_lo; nb <= n_hi; nb += 4) {            // four reads in flight, added in unit order
         const float* p0q = frames + s + nb * dlt;
         const bool h1 = nb + 1 <= n_hi, h2 = nb + 2 <= n_hi, h3 = nb + 3 <= n_hi;
-        const float* p1q = h1 ? p0q + dlt : p0q;            // (a unit past the last one: its neighbour's address again, not added)
+        const float* p1q = h1 ? p0q + dlt : p0q;
         const float* p2q = h2 ? p1q + dlt : p1q;
         const float* p3q = h3 ? p2q + dlt : p2q;
         const v4f t0 = *reinterpret_cast<const v4f*>(p0q), t1 = *reinterpret_cast<const v4f*>(p1q);

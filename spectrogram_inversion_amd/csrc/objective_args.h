@@ -208,6 +208,7 @@ inline bool obj_build_sparse(const float* mel, int F, int n_mels, int uni_floats
     }
   }
   if (cmax > 4) return false;
+  cmax = cmax <= 2 ? 2 : 4;                   // (the kernel has these two; the padding rows carry zero weights)
   std::vector<int> glen(QG, 1);
   for (int g = 0; g < QG; ++g) {
     for (int r = 0; r < 4; ++r) glen[g] = std::max(glen[g], nq[4 * g + r]);
