@@ -168,7 +168,7 @@ inline void obj_build_blocks(const float* mel, int F, int n_mels, int MT, std::v
 // order).  Eligible: at most 4 rows per bin, <= 255 rows, the blob fits the workgroup's staging registers and the FFT scratch.
 struct ObjSp {
   static constexpr int MAXQ = 16;                       // row quads per wave
-  static constexpr int STAGE = 4;                       // 16-byte units a thread stages: blob <= STAGE * 512 units
+  static constexpr int STAGE = 6;                       // 16-byte units a thread stages: blob <= STAGE * 512 units
   static constexpr int COUNT = 8, LIST = 16;            // tab[COUNT + w] row quads of wave w; tab[LIST + MAXQ w + i] = g | len << 8
 };
 struct ObjSparseInfo {

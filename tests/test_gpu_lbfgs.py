@@ -366,6 +366,34 @@ def test_one_launch_objective_signal_longer_than_its_frames(monkeypatch, center)
             assert not N(grad)[:, -97:].any() and not go[:, -97:].any()
 
 
+@pytest.mark.parametrize("n_fft,hop,rows,per_bin", [(2048, 512, 60, 4), (1024, 256, 90, 3), (2048, 1024, 24, 1), (1024, 128, 40, 5)])
+def test_one_launch_objective_with_a_banded_matrix(monkeypatch, n_fft, hop, rows, per_bin):
+    """A filterbank whose rows are overlapping random bands, `per_bin` rows meeting every bin: up to four per bin run as bands (the
+    kernel has the two forms 'two rows per bin' and 'four', shorter columns padded with zero weights), five stay on the matrix
+    cores.  Against the float64 oracle."""
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    rng = np.random.default_rng(rows + per_bin)
+    F, frames, batch = n_fft // 2 + 1, 37, 2
+    fb = np.zeros((rows, F), np.float32)
+    step = F / rows
+    for m in range(rows):                       # row m covers bins [m step, (m + per_bin) step): per_bin rows over every bin
+        lo, hi = int(m * step), min(F, int((m + per_bin) * step))
+        fb[m, lo:hi] = 0.01 + 0.02 * rng.random(hi - lo)
+    assert np.count_nonzero(fb, axis=0).max() == per_bin
+    w = hann(n_fft)
+    xs = (0.1 * rng.standard_normal((batch, (frames - 1) * hop))).astype(np.float32)
+    x0 = (0.05 * rng.standard_normal(xs.shape)).astype(np.float32)
+    tr = LogMelSTFT(T(fb), n_fft, hop_length=hop, window=torch.from_numpy(w))
+    _, fg = tr.bind(T(x0), tr(T(xs)))
+    loss, grad = fg(T(x0))
+    assert fg.device_objective[0].objective_kind == ("bands" if per_bin <= 4 else "matrix")
+    a = oracle.args_helper(F, np.float64, hop_length=hop, window=w.astype(np.float64))
+    ref = LogMelStft(a, fb.astype(np.float64))
+    lo_, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
+    assert abs(loss - lo_) < 1e-5 * abs(lo_), (loss, lo_)
+    assert rel_l2(N(grad), go) < 1e-5, rel_l2(N(grad), go)
+
+
 @pytest.mark.parametrize("n_mels", [80, 33])
 def test_one_launch_objective_with_a_dense_matrix(monkeypatch, n_mels):
     """The block list leaves out all-zero 16 x 16 blocks of the filterbank; a dense (random, signed-free) matrix keeps
