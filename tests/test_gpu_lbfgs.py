@@ -318,8 +318,8 @@ def test_one_launch_objective_beyond_128_bands(monkeypatch, n_fft, hop, n_mels):
 
 
 def test_one_launch_objective_falls_back_where_it_does_not_fit(monkeypatch):
-    """Configurations the one-launch kernel does not cover (n_fft other than 1024 / 2048; a signal whose last samples no
-    frame reaches; more than 128 mel bands; float64; two-sided spectra) run the kernel chain - same results as ever."""
+    """Configurations the one-launch kernel does not cover (n_fft other than 1024 / 2048; a dense matrix of more than 128 rows, a
+    mel filterbank of more than 140 bands; float64; two-sided spectra) run the kernel chain - same results as ever."""
     fb = si.mel_filterbank(22050, 512, 40)
     x = 0.1 * torch.randn(2, 30 * 128, device=dev())
     tr = LogMelSTFT(T(fb), 512, hop_length=128, window=torch.from_numpy(hann(512)))
