@@ -1230,6 +1230,7 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     SI_HIP(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     static int calls = 0;
     if (++calls == 5) {
+      // (band form: "forward GEMM" = staging the bands, its "wait" = the band forward with step 3, "reduce" = the barrier behind it)
       const char* names[12] = {"tables + twiddle regs", "analysis (2 frames)", "  wait", "forward GEMM", "  wait", "reduce+log1p+dM",
                                "backward GEMM", "  wait", "synthesis (2 frames)", "  wait", "frames to LDS", "overlap-add"};
       double tot[13] = {0};
@@ -1241,12 +1242,6 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
       double all = 0;
       for (int64_t t = 0; t < n_tiles; ++t) all += (double)(h[t * 16 + 12] - h[t * 16]);
       fprintf(stderr, "  %-22s %9.0f\n", "whole tile", all / n_tiles);
-      double g0 = 0, g1 = 0;                     // inside the write-out: to the gather loop's start, through its first trip
-      for (int64_t t = 0; t < n_tiles; ++t) {
-        g0 += (double)(h[t * 16 + 13] - h[t * 16 + 11]);
-        g1 += (double)(h[t * 16 + 14] - h[t * 16 + 13]);
-      }
-      fprintf(stderr, "  %-22s %9.0f %9.0f\n", "gather: setup, trip 1", g0 / n_tiles, g1 / n_tiles);
     }
   }
 #endif
