@@ -1039,7 +1039,8 @@ static __global__ void k_objective_epilogue(float* __restrict__ grad, const floa
                                      int n_part, double scale, fast::ObjCtl ctl) {
   if (ctl.do_eval != nullptr) {                  // device-resident optimiser: gate and gradient ping-pong (lbfgs_dev.h)
     if (*ctl.do_eval == 0) return;
-    if ((*ctl.cur ^ 1) != 0) grad = ctl.grad_alt;
+    if (ctl.sel != nullptr) grad = ctl.tab[*ctl.sel];
+    else if ((*ctl.cur ^ 1) != 0) grad = ctl.grad_alt;
   }
   const int64_t tail_blocks = (n_tail + 255) / 256, margin_blocks = (n_margin + 255) / 256;
   const bool fold = pad > 0 && pad_mode != SPECINV_PAD_CONSTANT;
@@ -1194,6 +1195,8 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     a.ctl_eval = ctl->do_eval;
     a.ctl_cur = ctl->cur;
     a.grad_alt = ctl->grad_alt;
+    a.ctl_sel = ctl->sel;
+    a.ctl_tab = ctl->tab;
   }
   const void* fn = nullptr;
   size_t lds = 0;

@@ -75,37 +75,31 @@ __device__ inline double lbd_wave_sum(double v) {
   return v;
 }
 
-// The decisions of iteration k (1-based) of a step, preceded by the reductions the evaluation left unfinished (its kernels write
-// per-block partial sums; finishing them here saves two one-workgroup launches per iteration).  256 threads finish the sums, wave 0
-// decides; the Gram matrix s_i.y_j is staged in LDS for the two triangular recursions.  Every branch below is uniform over the
-// workgroup, so all four waves reach every barrier.
-template <typename T>
-__global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const double* __restrict__ part_pair, int nb,
-                                                    const double* __restrict__ part_dot, const double* __restrict__ loss_slot) {
-  extern __shared__ double lds_sy[];              // [m * m]
-  __shared__ double al[kLbdMaxHist], cc[kLbdMaxHist], yq[kLbdMaxHist], sgv[kLbdMaxHist], ygv[kLbdMaxHist];
-  __shared__ double dotv[2 * kLbdMaxHist], bps[8], red[16], mx[2][4];
-  __shared__ LbdState R;                          // the state as it was at entry: one coalesced read instead of a chain of
-  LbdState& S = *p.st;                            // dependent global loads; writes go to S
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bool w0 = wv == 0;
+// Scratch of the decision kernels (one workgroup of 256): the state as it was at entry (one coalesced read instead of a chain of
+// dependent global loads), the finished sums of the evaluation, the vectors of the two triangular recursions.
+struct LbdShared {
+  double al[kLbdMaxHist], cc[kLbdMaxHist], yq[kLbdMaxHist], sgv[kLbdMaxHist], ygv[kLbdMaxHist];
+  double dotv[2 * kLbdMaxHist], bps[8], red[16], mx[2][4];
+  LbdState R;
+};
+
+__device__ inline void lbd_load_state(LbdShared& sh, const LbdState* st) {
   static_assert(sizeof(LbdState) % 8 == 0 && sizeof(LbdState) / 8 <= 256, "LbdState is copied by one pass of doubles");
-  if (tid < (int)(sizeof(LbdState) / 8)) reinterpret_cast<double*>(&R)[tid] = reinterpret_cast<const double*>(p.st)[tid];
+  const int tid = threadIdx.x;
+  if (tid < (int)(sizeof(LbdState) / 8)) reinterpret_cast<double*>(&sh.R)[tid] = reinterpret_cast<const double*>(st)[tid];
   __syncthreads();
-  const int hist = R.hist;
-  auto stop = [&]() {                             // the step ends here: everything still enqueued for it is a no-op
-    if (tid == 0) {
-      S.active = 0;
-      S.do_lincomb = 0;
-      S.do_step = 0;
-      S.do_eval = 0;
-      p.board[0] = 0.0;
-    }
-  };
-  if (!R.active) {
-    stop();
-    return;
-  }
+}
+
+// The reductions an evaluation left unfinished (its kernels write per-block partial sums; finishing them here saves two
+// one-workgroup launches per evaluation): sh.bps = {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev} over the nb blocks of
+// k_lbd_pair_stats (fixed order), sh.dotv = the kd products of g with the memory.
+__device__ inline void lbd_finish_sums(LbdShared& sh, const double* __restrict__ part_pair, int nb, const double* __restrict__ part_dot,
+                                       int kd) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double(&bps)[8] = sh.bps;
+  double(&dotv)[2 * kLbdMaxHist] = sh.dotv;
+  double(&red)[16] = sh.red;
+  double(&mx)[2][4] = sh.mx;
   // ---- finish the evaluation's sums: {g.d, sum|g|, y.s, y.y, g.g, g.g_prev} + max|g|, max|d| over the nb blocks of
   // k_lbd_pair_dots (fixed order), and the products of g with the memory
   {
@@ -144,7 +138,6 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
       bps[6] = tot[4];
       bps[7] = tot[5];
     }
-    const int kd = R.k_dot;
     for (int j = wv; j < kd; j += 4) {            // one wave per product
       double sj = 0.0;
       for (int i = lane; i < nb; i += 64) sj += part_dot[(int64_t)j * nb + i];
@@ -153,43 +146,40 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
     }
     __syncthreads();
   }
-  // ---- the tests that follow an evaluation (torch.optim.LBFGS.step: opt_cond at entry; max_eval, opt_cond, step and loss
-  // tolerances at the end of an iteration)
-  const double loss = *loss_slot, gmax = bps[2];
-  if (k == 1) {
-    if (tid == 0) {
-      S.first_loss = loss;
-      S.loss = loss;
-      S.evals = 1;
-      S.func_evals = R.func_evals + 1;
-    }
-    if (gmax <= R.tol_grad) {
-      stop();
-      return;
-    }
-  } else {
-    const int evals = R.evals + 1;
-    const bool end = evals >= R.max_eval || gmax <= R.tol_grad || fabs(R.t) * bps[3] <= R.tol_change ||
-                     fabs(loss - R.prev_loss) < R.tol_change;
-    __syncthreads();                              // (everybody has read R.evals / S.t / R.prev_loss)
-    if (tid == 0) {
-      S.loss = loss;
-      S.evals = evals;
-      S.func_evals = R.func_evals + 1;
-    }
-    if (end) {
-      stop();                                     // (the gradient just evaluated is dropped: prev_flat_grad stays gbuf[cur])
-      return;
-    }
-  }
-  // ---- iteration k begins: the evaluated gradient is the current one
-  const int cur = R.cur ^ 1;
-  const T* g = p.gbuf[cur];
+}
+
+struct LbdDirection {
+  double gtd, t;
+  int m;
+};
+
+// Iteration `total` of the optimiser begins at the gradient g (its sums in sh.bps - for total > 1 taken against the previous
+// gradient and s = t_prev d - and its products with the memory in sh.dotv): the curvature guard and the memory update, the Gram
+// matrices, the two-loop recursion on scalars, the coefficient / pointer lists of the direction, the step length and g.d
+// (torch.optim.LBFGS.step between "compute gradient descent direction" and "compute step length").  Writes what the direction
+// kernel and the next evaluation's reductions read; the caller sets the control flags.  Every branch is uniform over the
+// workgroup.
+template <typename T>
+__device__ inline LbdDirection lbd_iteration(const LbdPtrs<T>& p, LbdShared& sh, double* lds_sy, const T* g, double loss, double t_prev,
+                                             int k) {
+  const LbdState& R = sh.R;
+  LbdState& S = *p.st;
+  double(&al)[kLbdMaxHist] = sh.al;
+  double(&cc)[kLbdMaxHist] = sh.cc;
+  double(&yq)[kLbdMaxHist] = sh.yq;
+  double(&sgv)[kLbdMaxHist] = sh.sgv;
+  double(&ygv)[kLbdMaxHist] = sh.ygv;
+  double(&dotv)[2 * kLbdMaxHist] = sh.dotv;
+  double(&bps)[8] = sh.bps;
+  double(&red)[16] = sh.red;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool w0 = (tid >> 6) == 0;
+  const int hist = R.hist;
   const int total = R.total_iters + 1;
   const int m_board = R.m;                        // the evaluation's products: ss[0..m_board) then ys[0..m_board)
   int m = m_board, seq0 = R.seq0;
   double gtd, h_diag = R.h_diag;
-  const double t_prev = R.t, g_abssum = bps[1];
+  const double g_abssum = bps[1];
   __syncthreads();
   if (total == 1) {
     m = 0;                                        // (lbfgs.py:_forget)
@@ -341,12 +331,11 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
     p.dot_ptr[i] = p.ss_slot[(seq0 + i) % (hist + 1)];
     p.dot_ptr[m + i] = p.ys_slot[(seq0 + i) % (hist + 1)];
   }
+  const double t = total == 1 ? fmin(1.0, 1.0 / g_abssum) * R.lr : R.lr;
   if (tid == 0) {
-    const double t = total == 1 ? fmin(1.0, 1.0 / g_abssum) * R.lr : R.lr;
 #pragma unroll
     for (int c = 0; c < 8; ++c) S.b_ps[c] = bps[c];
     S.b_loss = loss;
-    S.cur = cur;
     S.total_iters = total;
     S.n_iter = k;
     S.m = m;
@@ -360,8 +349,72 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
     S.have_prev = 1;
     p.cand[0] = p.ys_slot[(seq0 + m) % (hist + 1)];
     p.cand[1] = p.ss_slot[(seq0 + m) % (hist + 1)];
+  }
+  return LbdDirection{gtd, t, m};
+}
+
+// The decisions of iteration k (1-based) of a step without a line search, preceded by the reductions of the evaluation: 256
+// threads finish the sums, wave 0 decides; the Gram matrix s_i.y_j is staged in LDS for the two triangular recursions.  Every
+// branch below is uniform over the workgroup, so all four waves reach every barrier.
+template <typename T>
+__global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const double* __restrict__ part_pair, int nb,
+                                                    const double* __restrict__ part_dot, const double* __restrict__ loss_slot) {
+  extern __shared__ double lds_sy[];              // [m * m]
+  __shared__ LbdShared sh;
+  const LbdState& R = sh.R;
+  LbdState& S = *p.st;                            // writes go to S
+  const int tid = threadIdx.x;
+  lbd_load_state(sh, p.st);
+  auto stop = [&]() {                             // the step ends here: everything still enqueued for it is a no-op
+    if (tid == 0) {
+      S.active = 0;
+      S.do_lincomb = 0;
+      S.do_step = 0;
+      S.do_eval = 0;
+      p.board[0] = 0.0;
+    }
+  };
+  if (!R.active) {
+    stop();
+    return;
+  }
+  lbd_finish_sums(sh, part_pair, nb, part_dot, R.k_dot);
+  // ---- the tests that follow an evaluation (torch.optim.LBFGS.step: opt_cond at entry; max_eval, opt_cond, step and loss
+  // tolerances at the end of an iteration)
+  const double loss = *loss_slot, gmax = sh.bps[2];
+  if (k == 1) {
+    if (tid == 0) {
+      S.first_loss = loss;
+      S.loss = loss;
+      S.evals = 1;
+      S.func_evals = R.func_evals + 1;
+    }
+    if (gmax <= R.tol_grad) {
+      stop();
+      return;
+    }
+  } else {
+    const int evals = R.evals + 1;
+    const bool end = evals >= R.max_eval || gmax <= R.tol_grad || fabs(R.t) * sh.bps[3] <= R.tol_change ||
+                     fabs(loss - R.prev_loss) < R.tol_change;
+    __syncthreads();                              // (everybody has read R.evals / S.t / R.prev_loss)
+    if (tid == 0) {
+      S.loss = loss;
+      S.evals = evals;
+      S.func_evals = R.func_evals + 1;
+    }
+    if (end) {
+      stop();                                     // (the gradient just evaluated is dropped: prev_flat_grad stays gbuf[cur])
+      return;
+    }
+  }
+  // ---- iteration k begins: the evaluated gradient is the current one
+  const int cur = R.cur ^ 1;
+  const LbdDirection dir = lbd_iteration<T>(p, sh, lds_sy, p.gbuf[cur], loss, R.t, k);
+  if (tid == 0) {
+    S.cur = cur;
     S.do_lincomb = 1;
-    if (gtd > -R.tol_change) {                    // no descent left: the direction is formed, no step, the loop ends
+    if (dir.gtd > -R.tol_change) {                // no descent left: the direction is formed, no step, the loop ends
       S.do_step = 0;
       S.do_eval = 0;
       S.active = 0;

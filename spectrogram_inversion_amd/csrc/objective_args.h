@@ -54,10 +54,13 @@ struct ObjArgs {
   // units [0, sp_rm) row weights, [sp_rm, sp_cm) row records, [sp_cm, sp_cw) column records, [sp_cw, sp_total) column weights;
   // tab holds the waves' lists of row quads
   int sp_rm, sp_cm, sp_cw, sp_total, sp_cmax, sp_rows;
-  // device-resident optimiser (lbfgs_dev.h): run only if *ctl_eval != 0; the gradient goes to (*ctl_cur ^ 1 ? grad_alt : grad)
+  // device-resident optimiser (lbfgs_dev.h): run only if *ctl_eval != 0; the gradient goes to (*ctl_cur ^ 1 ? grad_alt : grad), or -
+  // with the line search on the device, which keeps four gradients - to ctl_tab[*ctl_sel]
   const int* ctl_eval;
   const int* ctl_cur;
   float* grad_alt;
+  const int* ctl_sel;
+  float* const* ctl_tab;
 #if SPECINV_OBJ_STAMPS
   unsigned long long* stamps;   // [tiles][16]
 #endif
@@ -68,6 +71,8 @@ struct ObjCtl {
   const int* do_eval;
   const int* cur;
   float* grad_alt;
+  const int* sel;          // != nullptr: the gradient buffer is tab[*sel] (lbfgs_dev.h, line search)
+  float* const* tab;
 };
 
 // Layout of the block table (ints): the non-zero blocks are sorted by bin group, then mel group.
