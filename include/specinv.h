@@ -291,6 +291,8 @@ typedef struct specinv_lbfgs_opts {
   int32_t max_iter, max_eval, history_size;
   int32_t time_objective;  /* k > 0: bracket every k-th objective evaluation of a step with HIP events (benchmarks:
                               specinv_lbfgs_info.objective_ms / objective_timed; an event pair costs ~10 us of the timeline) */
+  int32_t line_search;     /* 0: none (the step length is lr); 1: 'strong_wolfe' - torch.optim.lbfgs._strong_wolfe's bracketing,
+                              cubic interpolation and zoom decided by a kernel after every evaluation */
 } specinv_lbfgs_opts;
 typedef struct specinv_lbfgs_info {
   double first_loss;      /* what optimizer.step returns: the loss at the entry evaluation */

@@ -32,7 +32,8 @@ class Eval(C.Structure):
 
 class LbfgsOpts(C.Structure):
     _fields_ = [("lr", C.c_double), ("tolerance_grad", C.c_double), ("tolerance_change", C.c_double),
-                ("max_iter", C.c_int32), ("max_eval", C.c_int32), ("history_size", C.c_int32), ("time_objective", C.c_int32)]
+                ("max_iter", C.c_int32), ("max_eval", C.c_int32), ("history_size", C.c_int32), ("time_objective", C.c_int32),
+                ("line_search", C.c_int32)]
 
 
 class LbfgsInfo(C.Structure):

@@ -20,6 +20,13 @@
 namespace specinv {
 
 constexpr int kLbdMaxHist = 120;          // history_size the device path takes (Gram matrix in LDS: hist^2 doubles)
+constexpr int kLbdInfo = 2;               // pinned board: [0] the step is live, [1] slots decided, [kLbdInfo ..] what the step leaves (lbfgs_dev_ls.h)
+constexpr int kLbdBoard = 16;             // doubles of the board
+
+struct LbdPoint {                         // a point of the line search: step length, loss, g.d, max|g|, the evaluation's eight sums, its gradient buffer
+  double t, f, gtd, gmax, ps[8];
+  int g, pad_;
+};
 
 struct LbdState {                         // device-resident; copied to the host at the end of a step
   // options
@@ -37,7 +44,17 @@ struct LbdState {                         // device-resident; copied to the host
   double first_loss, gtd;
   // reductions of the last evaluation: loss; {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev}
   double b_loss, b_ps[8];
+  // ---- strong-Wolfe line search on the device (lbfgs_dev_ls.h) ------------------------------------------------------------
+  int ls;                                 // option: line_search_fn = 'strong_wolfe'
+  int mode;                               // what the slot that ends with the next decision carries (LbdMode)
+  int do_trial, do_mdot, need_fix;        // x = x0 + t d;  memory products of gradient g_md;  ... with t_fix (the accepted point was not the last trial)
+  int g_cur, g_old, g_eval, g_md;         // gradient buffers (of four): prev_flat_grad, the one before it, where the next evaluation writes, whose products
+  int ls_phase, ls_it, ls_max, ls_lo, ls_hi, ls_nbr, ls_stalled, ls_first, pad3_;
+  unsigned long long eval_slots;          // bit s: slot s of the step executed an evaluation (benchmarks: which event pairs count)
+  double t_fix, ls_f0, ls_gtd0, ls_dnorm;
+  LbdPoint ls_prev, ls_start, ls_br[2], ls_acc;
 };
+enum LbdMode { LBD_IDLE = 0, LBD_ENTRY = 1, LBD_TRIAL = 2, LBD_POST = 3 };
 
 template <typename T>
 struct LbdPtrs {                          // kernel argument: where everything lives
@@ -55,6 +72,9 @@ struct LbdPtrs {                          // kernel argument: where everything l
   T** ss_slot;         // [hist + 1]
   T** cand;            // [2]            where the next evaluation's y and s go
   T* gbuf[2];          // gradient ping-pong: the evaluation writes gbuf[cur ^ 1], reads gbuf[cur] as the previous gradient
+  T* g4[4];            // line search: four gradient buffers (g4[0], g4[1] = gbuf), chosen by the state's g_* indices
+  T* const* g4_dev;    // ... the same table in device memory (the objective kernel's ObjCtl.tab)
+  T* x0;               // ... the point the line search started from
   T* d;
   double* board;       // pinned host memory: [0] = active (a peek, not a synchronisation)
 };
@@ -514,9 +534,9 @@ __global__ __launch_bounds__(256) void k_lbd_pair_stats(LbdPtrs<T> p, int64_t n,
   const LbdState& S = *p.st;
   if (!S.do_eval) return;
   const bool have_prev = S.have_prev != 0;
-  const T* __restrict__ g = p.gbuf[S.cur ^ 1];
+  const T* __restrict__ g = S.ls ? p.g4[S.g_eval] : p.gbuf[S.cur ^ 1];
   {
-    const T* __restrict__ gp = have_prev ? p.gbuf[S.cur] : g;
+    const T* __restrict__ gp = have_prev ? (S.ls ? p.g4[S.g_cur] : p.gbuf[S.cur]) : g;
     const T* __restrict__ d = have_prev ? p.d : g;
     const T t = (T)S.t;
     __shared__ double red[16];
@@ -567,8 +587,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_lbd_multi_dot(LbdPtrs<T> p, int64_t n, double* __restrict__ part_dot) {
   const LbdState& S = *p.st;
   const int kk = S.k_dot;
-  if (!S.do_eval || kk == 0) return;
-  const T* __restrict__ g = p.gbuf[S.cur ^ 1];
+  if (!(S.ls ? S.do_mdot : S.do_eval) || kk == 0) return;
+  const T* __restrict__ g = S.ls ? p.g4[S.g_md] : p.gbuf[S.cur ^ 1];
   constexpr int W = 16 / sizeof(T);
   constexpr int Q = 8;
   typedef T VT __attribute__((ext_vector_type(W)));
@@ -629,6 +649,10 @@ struct LbfgsDev {
   std::vector<std::unique_ptr<FastBuf>> vecs;
   T* g0 = nullptr;
   T* g1 = nullptr;
+  T* g2 = nullptr;                        // (line search: two more gradients and the starting point)
+  T* g3 = nullptr;
+  T* x0 = nullptr;
+  FastBuf gtab;
   T* d = nullptr;
   std::vector<T*> pairs_y, pairs_s;       // host mirror of the slot tables (allocated so far)
   double* board_host = nullptr;          // pinned, device-mapped: owned here (a plan outlives many optimisers)
@@ -661,6 +685,12 @@ struct LbfgsDev {
     p.cand = cand.as<T*>();
     p.gbuf[0] = g0;
     p.gbuf[1] = g1;
+    p.g4[0] = g0;
+    p.g4[1] = g1;
+    p.g4[2] = g2;
+    p.g4[3] = g3;
+    p.g4_dev = gtab.as<T*>();
+    p.x0 = x0;
     p.d = d;
     p.board = board_dev;
     return p;
@@ -704,6 +734,7 @@ int lbd_create(P& pl, LbfgsDev<float>& L, int64_t n, const specinv_lbfgs_opts& o
   L.h.hist = hist;
   L.h.h_diag = 1.0;
   L.h.n_prev = -1;
+  L.h.ls = o.line_search != 0 ? 1 : 0;
   SI_TRY(L.st.reserve(sizeof(LbdState)));
   SI_TRY(L.dots.reserve((size_t)2 * hist * sizeof(double)));
   SI_TRY(L.sgp.reserve((size_t)hist * sizeof(double)));
@@ -720,6 +751,14 @@ int lbd_create(P& pl, LbfgsDev<float>& L, int64_t n, const specinv_lbfgs_opts& o
   SI_TRY(lbd_take(pl, L, &L.g0));
   SI_TRY(lbd_take(pl, L, &L.g1));
   SI_TRY(lbd_take(pl, L, &L.d));
+  if (L.h.ls) {
+    SI_TRY(lbd_take(pl, L, &L.g2));
+    SI_TRY(lbd_take(pl, L, &L.g3));
+    SI_TRY(lbd_take(pl, L, &L.x0));
+    SI_TRY(L.gtab.reserve(4 * sizeof(void*)));
+    float* tab[4] = {L.g0, L.g1, L.g2, L.g3};
+    SI_HIP(hipMemcpy(L.gtab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
+  }
   SI_TRY(L.part.reserve((size_t)8 * 1024 * sizeof(double)));
   SI_TRY(L.mpart.reserve((size_t)kLbdMaxVec * 1024 * sizeof(double)));
   SI_TRY(L.loss_slot.reserve(sizeof(double)));
@@ -731,15 +770,17 @@ int lbd_create(P& pl, LbfgsDev<float>& L, int64_t n, const specinv_lbfgs_opts& o
   {
     void* hp = nullptr;
     void* dp = nullptr;
-    SI_HIP(hipHostMalloc(&hp, 4 * sizeof(double), hipHostMallocMapped));
+    // (coherent: the device's writes - "the step has ended", "slot s is decided" - are to be seen by the host while later kernels of
+    // the stream still run, not when the queue drains)
+    SI_HIP(hipHostMalloc(&hp, kLbdBoard * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     L.board_host = static_cast<double*>(hp);
-    std::memset(hp, 0, 4 * sizeof(double));
+    std::memset(hp, 0, kLbdBoard * sizeof(double));
     SI_HIP(hipHostGetDevicePointer(&dp, hp, 0));
     L.board_dev = static_cast<double*>(dp);
   }
   L.time_objective = o.time_objective > 0 ? o.time_objective : 0;
   if (L.time_objective) {
-    L.ev.resize((size_t)2 * o.max_iter);
+    L.ev.resize((size_t)2 * (L.h.ls ? 64 : o.max_iter));
     for (auto& e : L.ev) SI_HIP(hipEventCreate(&e));
   }
   SI_HIP(hipStreamSynchronize(pl.stream));

@@ -13,6 +13,7 @@
 #include "kernels_generic.h"
 #include "kernels_lbfgs.h"
 #include "lbfgs_dev.h"
+#include "lbfgs_dev_ls.h"
 #include "kernels_rtisi.h"
 #include "plan.h"
 
@@ -846,6 +847,8 @@ struct PlanT final : PlanBase {
   int lbfgs_dev_step(int32_t handle, void* xs, int64_t len, const void* target, specinv_lbfgs_info* info) override {
     if constexpr (std::is_same<T, float>::value) {
       SI_CHECK(handle >= 0 && (size_t)handle < lbfgs_devs.size() && lbfgs_devs[handle], SPECINV_EINVAL, "bad optimiser handle");
+      if (lbfgs_devs[handle]->h.ls)
+        return lbd_step_ls(*this, *lbfgs_devs[handle], static_cast<float*>(xs), len, static_cast<const float*>(target), info);
       return lbd_step(*this, *lbfgs_devs[handle], static_cast<float*>(xs), len, static_cast<const float*>(target), info);
     } else {
       return fail(SPECINV_EUNSUPPORTED, "the device-resident optimiser is float32 only");

@@ -579,14 +579,19 @@ class LBFGS:
 
     # ---- one optimizer.step with the decisions on the device: one host synchronisation per STEP -------------------
     def _device_ok(self, fg):
-        """The device-resident optimiser (csrc/lbfgs_dev.h) serves float32 parameters on the one-launch objective, no line
-        search, history_size <= 120.  Decided at the first step; an optimiser never changes paths afterwards (its state
+        """The device-resident optimiser (csrc/lbfgs_dev.h, lbfgs_dev_ls.h) serves float32 parameters on the one-launch objective,
+        without a line search or with 'strong_wolfe', history_size <= 120.  Decided at the first step; an optimiser never changes paths afterwards (its state
         lives where its path keeps it)."""
         if self._dev is not None:
             return self._dev is not False
         self._dev = False
         obj = getattr(fg, "device_objective", None)
-        if obj is None or self.line_search is not None or not self.gram or os.environ.get("SPECINV_LBFGS_DEVICE", "1") == "0":
+        if obj is None or not self.gram or os.environ.get("SPECINV_LBFGS_DEVICE", "1") == "0":
+            return False
+        if self.line_search is not None and os.environ.get("SPECINV_LBFGS_DEVICE_WOLFE", "0") != "1":
+            # the line search driven from the host (_step_wolfe_packed) unless asked otherwise: the state machine on the device
+            # (csrc/lbfgs_dev_ls.h) retraces it decision for decision without a synchronisation per evaluation, but its gated launches
+            # cost what the read-backs did (DESIGN 3.7: C5 `wolfe` 47 M against 77 M evaluations*frames/s, `memory` 9.9 against 10.1)
             return False
         plan, target, shape = obj
         x = self.x
@@ -596,7 +601,7 @@ class LBFGS:
         from . import _lib
         try:
             handle = plan.lbfgs_dev_create(x.numel(), self.lr, self.max_iter, self.max_eval, self.tol_grad, self.tol_change,
-                                           self.history_size, self.time_objective)
+                                           self.history_size, self.time_objective, self.line_search is not None)
         except (_lib.SpecinvError, NotImplementedError):
             return False
         self._dev = (plan, handle, target, shape)

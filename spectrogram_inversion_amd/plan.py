@@ -544,10 +544,11 @@ class Plan:
 
     # ---- the device-resident optimiser (csrc/lbfgs_dev.h) --------------------------------------------------------------
     def lbfgs_dev_create(self, n: int, lr, max_iter, max_eval, tolerance_grad, tolerance_change, history_size,
-                         time_objective=False) -> int:
+                         time_objective=False, line_search=False) -> int:
         self._sync_stream()
         o = _lib.LbfgsOpts(float(lr), float(tolerance_grad), float(tolerance_change), int(max_iter),
-                           int(max_eval) if max_eval is not None else 0, int(history_size), int(time_objective))
+                           int(max_eval) if max_eval is not None else 0, int(history_size), int(time_objective),
+                           int(bool(line_search)))
         h = C.c_int32(-1)
         _lib.check(self.lib.specinv_lbfgs_dev_create(self._h, int(n), C.byref(o), C.byref(h)))
         return h.value

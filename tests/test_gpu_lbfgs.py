@@ -625,6 +625,7 @@ def test_device_resident_optimiser_at_the_optimum_and_reuse(monkeypatch):
 # ---- strong Wolfe with one read-back per evaluation (lbfgs.py:_step_wolfe_packed) -------------------------------------------
 def _run_wolfe(monkeypatch, packed, tr, target, x0, steps, **kw):
     monkeypatch.setenv("SPECINV_LBFGS_PACKED", "1" if packed else "0")
+    monkeypatch.setenv("SPECINV_LBFGS_DEVICE_WOLFE", "0")         # (the line search driven from the host)
     x = x0.clone()
     _, fg = tr.bind(x, target)
     opt = LBFGS(x, device=dev(), line_search_fn="strong_wolfe", **kw)
@@ -662,6 +663,45 @@ def test_packed_wolfe_step_retraces_the_general_step(monkeypatch, kind, kw, step
         assert rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()) < tol, (i, a[5], rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()))
     np.testing.assert_allclose(lb, la, rtol=1e-3)
     assert sa[-1][3] > 0 and la[-1] < 0.5 * la[0]                # pairs were accepted, the loss fell
+
+
+def _run_wolfe_device(monkeypatch, on_device, tr, target, x0, steps, **kw):
+    monkeypatch.setenv("SPECINV_LBFGS_PACKED", "1")
+    monkeypatch.setenv("SPECINV_LBFGS_DEVICE", "1")
+    monkeypatch.setenv("SPECINV_LBFGS_DEVICE_WOLFE", "1" if on_device else "0")
+    x = x0.clone()
+    _, fg = tr.bind(x, target)
+    opt = LBFGS(x, device=dev(), line_search_fn="strong_wolfe", **kw)
+    losses, snaps = [], []
+    for _ in range(steps):
+        losses.append(opt.step(fg))
+        snaps.append((x.clone(), opt.total_iters, opt.func_evals, int(opt.pairs_accepted), int(opt.pairs_rejected), opt.history_len))
+    assert bool(opt._dev) == on_device
+    return losses, snaps
+
+
+@pytest.mark.parametrize("kind,kw,steps", [
+    ("logmel", dict(), 3),                                       # torch.optim.LBFGS defaults + strong Wolfe: max_iter 20, history 100
+    ("logmel", dict(max_iter=12, history_size=3), 3),            # the memory wraps; a slot per iteration for the memory products
+    ("mag", dict(max_iter=10), 3),
+    ("mag", dict(max_iter=20, max_eval=8), 3),                   # max_eval ends line searches early (max_ls = max_eval - evaluations)
+    ("mag", dict(max_iter=4, lr=8.0), 3),                        # a first step far too long: brackets, zooms, accepted points that are not the last trial
+    ("logmel", dict(max_iter=5, lr=0.05, tolerance_change=0), 2),   # a first step too short: the bracket phase walks outwards
+])
+def test_device_resident_wolfe_retraces_the_host_driven_search(monkeypatch, kind, kw, steps):
+    """`line_search_fn='strong_wolfe'` with the state machine of torch.optim.lbfgs._strong_wolfe in `k_lbd_decide_ls` - one host
+    synchronisation per `optimizer.step` - against the same search driven from the host with one read-back per evaluation
+    (`_step_wolfe_packed`, itself retraced against the general step and torch.optim.LBFGS): the same counters after every step,
+    losses and iterates equal to the rounding of the float64 sums."""
+    tr, target, x0 = _device_problem(kind)
+    la, sa = _run_wolfe_device(monkeypatch, False, tr, target, x0, steps, **kw)
+    lb, sb = _run_wolfe_device(monkeypatch, True, tr, target, x0, steps, **kw)
+    for i, (a, b) in enumerate(zip(sa, sb)):
+        assert a[1:] == b[1:], (i, a[1:], b[1:])                  # total_iters, func_evals, accepted, rejected, history
+        tol = 2e-4 if a[5] <= 12 else 5e-3
+        assert rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()) < tol, (i, a[5], rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()))
+    np.testing.assert_allclose(lb, la, rtol=1e-3)
+    assert la[-1] < la[0]
 
 
 def test_l_bfgs_strong_wolfe_golden():
