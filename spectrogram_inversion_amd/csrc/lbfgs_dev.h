@@ -1,5 +1,6 @@
 // L-BFGS with the decisions on the device: one `optimizer.step` (reference: torch_specinv/methods.py:553 ->
-// torch.optim.LBFGS.step, third-party; no line search) is ENQUEUED as a whole - objective, curvature pair + statistics, memory
+// torch.optim.LBFGS.step, third-party; this file: no line search - strong Wolfe: lbfgs_dev_ls.h, on the state record, the decision
+// functions and the reduction kernels defined here) is ENQUEUED as a whole - objective, curvature pair + statistics, memory
 // products, a one-wave decision kernel, direction + step - and the host synchronises once per step instead of once per inner
 // iteration (kernels_lbfgs.h / lbfgs.py:_step_packed: ~0.05 ms of host turnaround around a 0.15 ms objective).
 //
