@@ -20,18 +20,22 @@ Other workloads (`--workload`), same JSON contract:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1 [--workload C4]
 
-Rank 0 prints ONE JSON line (the driver contract).  Beside the contract's keys:
-  roofline       the dominant kernel against the resource that BINDS it (`bound`): "valu" -> share of the chip's vector issue
-                 slots in use, "hbm" -> HBM bytes the counters saw / launch time / 8 TB/s, "latency" -> (RTISI-LA) vector issue
-                 share, reported with the dependent-step rate.  Launch time: HIP events on the launch stream inside the timed
-                 region.  Counters: rocprofv3 --pmc passes over a child process of THIS run (N = 1; `--no-pmc` or a failed pass
-                 falls back to profiles/traffic.json and says so).  `roofline.hbm` always carries the HBM view (counter
-                 bytes and the bytes the kernel must move), `roofline.reference_bytes_equiv` SURVEY 8d's bytes of the
-                 REFERENCE ALGORITHM over the same launch time (a speed-up over that algorithm: may exceed the peak).
+Rank 0 prints ONE compact JSON line (< 6 KB: the driver keeps an 8 KB tail; `--verbose` prints the verbose record instead, which
+is always written to gpurun_out/bench_detail.json).  Beside the contract's keys:
+  roofline       the dominant kernel: `achieved` = the bytes the kernel HAS to move per launch (bytes_per_unit x
+                 units_per_launch) / launch time, against the 8 TB/s HBM peak (`frac`); `traffic` = the HBM bytes the counters saw
+                 per launch; `limiter` / `limiter_frac` = the resource that binds the kernel and how much of it is in use ("valu": share
+                 of the chip's vector issue slots, "hbm": counter bytes / launch time / 8 TB/s, "latency": RTISI-LA, reported with
+                 the dependent-step rate).  Launch time: HIP events on the launch stream inside the timed region.  Counters:
+                 rocprofv3 --pmc passes over a child process of THIS run (N = 1; `--no-pmc` or a failed pass falls back to
+                 profiles/traffic.json and says so).  `reference_bytes_frac`: SURVEY 8d's bytes of the REFERENCE ALGORITHM over the
+                 same launch time (a speed-up over that algorithm: may exceed 1).
   value_incl_h2d the same step with the target magnitudes staged from pinned host memory each step (SURVEY 8d "report both")
-  extra.workloads short C4 / C3 / C5 legs run in the same process after the timed region (default C2 run at N = 1 only)
+  legs           short C4 / C3 / C5 / C5_mfma / C5_wolfe / C5_memory / C1 legs run in the same process after the timed region (default
+                 C2 run at N = 1 only), one row each (`legs_cols`)
   cpu_baseline   the NumPy oracle timed on the host cores on a bounded sample of the same workload (N = 1, rank 0)
   check          an independent re-evaluation of the result outside the timed region
+  legend         what the figures mean, every string once
 """
 import argparse
 import csv
@@ -540,27 +544,24 @@ class Leg:
             hbm["achieved"] = traffic / secs / 1e9
             hbm["frac"] = hbm["achieved"] / HBM_PEAK_GBS
             hbm["traffic_over_algorithmic"] = traffic / (must_unit * units)
-        roof = {"bound": bound, "kernel": kernel, "dominant_kernel_symbol": DOMINANT[self.workload][0] if default_shape else None,
+        roof = {"bound": "hbm", "limiter": bound, "kernel": kernel,
+                "dominant_kernel_symbol": DOMINANT[self.workload][0] if default_shape else None,
                 "launch_ms": launch_ms, "launches_timed": n_launch, "traffic": traffic, "traffic_source": pmc_source,
                 "csrc_sha1": sources_hash()}
         if stale is not None:
             roof["traffic_stale"], roof["traffic_csrc_sha1"] = bool(stale), stored_sha
-        if bound == "hbm":
-            a = hbm.get("achieved", hbm["achieved_algorithmic"])
-            roof.update(achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
-                        frac_is="HBM bytes the counters saw per launch / launch time / 8 TB/s" if traffic else
-                                "no counters in this run: the bytes the kernel has to move / launch time / 8 TB/s")
-        else:
-            # vector issue: achieved = VALU-busy cycles per second over all SIMDs, peak = 1024 SIMDs x the clock the chip held
-            c = pmc.get("counters", {})
-            if vfrac is not None and c.get("GRBM_GUI_ACTIVE"):
-                clock_cycles = c["GRBM_GUI_ACTIVE"] / 8                   # per launch, under the profiler
-                roof.update(achieved=c["SQ_ACTIVE_INST_VALU"] * 4 / clock_cycles, peak=float(N_SIMD),
-                            unit="SIMDs issuing a vector instruction (mean over the launch, of 1024)", frac=vfrac)
-            else:
-                roof.update(achieved=None if vfrac is None else vfrac * N_SIMD, peak=float(N_SIMD),
-                            unit="SIMDs issuing a vector instruction (mean over the launch, of 1024)", frac=vfrac)
-            roof["frac_is"] = VALU_FORMULA
+        # the contract's figures: ALGORITHMIC bytes the kernel has to move per launch (bytes per unit x units per launch)
+        # over the launch time measured by HIP events, against the 8 TB/s HBM peak; `traffic` = what the counters saw per launch
+        roof.update(achieved=hbm["achieved_algorithmic"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac_algorithmic"],
+                    bytes_per_unit=must_unit, units_per_launch=units)
+        if traffic:
+            roof["traffic_frac"] = hbm["frac"]
+        # ... and the resource that really limits the kernel (`limiter`): "valu" -> the share of the chip's vector issue slots in use,
+        # "hbm" -> the counters' bytes over the launch time, "latency" -> dependent steps per second
+        c = pmc.get("counters", {})
+        if vfrac is not None:
+            roof["valu_issue_frac"] = vfrac
+        roof["limiter_frac"] = {"valu": vfrac, "hbm": hbm.get("frac", hbm["frac_algorithmic"]), "latency": vfrac}[bound]
         roof["hbm"] = hbm
         for k in ("valu_issue_frac", "valu_share_of_wave_life", "lds_conflict_frac", "launches_counted"):
             if pmc.get(k) is not None:
@@ -727,12 +728,132 @@ def reference_trace_check(leg):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-EXTRA_LEGS = (          # (key, workload, steps, warmup, option overrides) - short legs after the headline's timed region
-    ("C4", "C4", 5, 1, {}),
-    ("C3", "C3", 2, 1, {}),
-    ("C5", "C5", 2, 1, {"outer": 50, "c5_variant": "baseline"}),
-    ("C5_wolfe", "C5", 2, 1, {"outer": 50, "c5_variant": "wolfe"}),
-    ("C1", "C1", 50, 5, {}),
+# The ONE line the driver keeps a tail of: everything a reader needs to recompute the claims, every string once (`legend`), the
+# short legs as rows of one table; the verbose record (every `what` / `formula`, raw counters per leg) goes to a side file.
+LEG_COLS = ["value", "unit", "ms_per_step", "steps", "launch_ms", "roofline_frac_hbm", "traffic_bytes", "limiter", "limiter_frac",
+            "lds_conflict_frac", "check_ok", "note"]
+LEGEND = {
+    "roofline": "dominant kernel: achieved = bytes_per_unit x units_per_launch (the bytes the kernel HAS to move, DESIGN 3) / launch_ms "
+                "(HIP events on the launch stream, timed region); peak 8 TB/s; traffic = (2 FETCH_SIZE + WRITE_SIZE) x 1024 B per "
+                "launch (gfx950 correction, separate rocprofv3 --pmc passes over a child of this run); limiter = what binds the kernel: "
+                "valu -> SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024) issue slots in use, hbm -> traffic / launch_ms / 8 TB/s, "
+                "latency -> dependent steps/s; reference_bytes_frac = SURVEY 8d's bytes of the REFERENCE algorithm over the same time "
+                "(a speed-up over that algorithm, may exceed 1)",
+    "legs": "short legs of the other BASELINE workloads in this process after the headline's timed region, same timing rules; columns "
+            "in legs_cols; note = evaluations | pairs accepted/rejected | who decides (C5), dependent steps/s (C3), objective form",
+    "check": "tripwires outside the timed region (parity is tests/): SC_lin of item 0 vs a float64 re-run; reference = the ten "
+             "whole-batch evaluations of the last step vs the unmodified reference's run (tests/golden/g16b_c2_headline.npz)",
+    "h2d": "value_incl_h2d: the 268 MB target staged from pinned host memory every step, double-buffered on a second stream (serial: "
+           "copy in front of every step)",
+}
+
+
+def _r(v, sig=6):
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _short_workload(w):
+    return (w.replace("batch=", "B").replace("n_frames=", "T=").replace("maxiter=", "it=").replace("look_ahead=", "LA=")
+             .replace("asymmetric_window=", "asym=").replace("(optimizer.step calls) x ", ""))[:118]
+
+
+def _compact_roof(r):
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac", "launch_ms", "launches_timed", "bytes_per_unit",
+            "units_per_launch", "limiter", "limiter_frac", "valu_issue_frac", "valu_share_of_wave_life", "lds_conflict_frac",
+            "launches_counted", "dependent_steps_per_s", "csrc_sha1", "traffic_stale")
+    out = {k: r[k] for k in keep if r.get(k) is not None}
+    out["kernel"] = r.get("dominant_kernel_symbol") or r.get("kernel")
+    src = r.get("traffic_source") or ""
+    out["traffic_source"] = "live" if src.startswith("measured in this run") else src[:80]
+    if r.get("hbm", {}).get("traffic_over_algorithmic") is not None:
+        out["traffic_over_algorithmic"] = r["hbm"]["traffic_over_algorithmic"]
+    if r.get("reference_bytes_equiv"):
+        out["reference_bytes_frac"] = r["reference_bytes_equiv"]["over_hbm_peak"]
+    if r.get("counters_mean_per_launch"):
+        out["counters"] = r["counters_mean_per_launch"]
+    return out
+
+
+def _leg_row(e):
+    if "error" in e:
+        return {"error": e["error"][:160]}
+    r = e.get("roofline", {})
+    lb = e.get("lbfgs")
+    note = None
+    if lb:
+        note = (f"{lb['evaluations']} ev | {lb['pairs_accepted']}/{lb['pairs_rejected']} pairs | hist {lb['history_len']} | "
+                f"{'device' if lb['decisions'].startswith('on the device') else 'host'}-decided | objective "
+                f"{ {1: 'mfma', 2: 'bands'}.get(e.get('objective_kind'), e.get('objective_kind')) }")
+    elif r.get("dependent_steps_per_s"):
+        note = f"{r['dependent_steps_per_s']:.0f} dependent steps/s"
+    ck = e.get("check") or {}
+    return [e["value"], e["unit"], e["ms_per_step"], e["steps"], e.get("launch_ms"), r.get("frac"), r.get("traffic"), r.get("limiter"),
+            r.get("limiter_frac"), r.get("lds_conflict_frac"), ck.get("ok"), note]
+
+
+def compact_line(full):
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in full}
+    cfg = dict(full["config"])
+    cfg["workload"] = _short_workload(cfg["workload"])
+    geo = cfg.pop("launch_geometry", None)
+    if geo:
+        cfg["kernel"] = geo.get("kernel")
+    out["config"] = cfg
+    for k in ("value_incl_h2d", "ms_per_step_incl_h2d"):
+        if k in full:
+            out[k] = full[k]
+    if full.get("h2d"):
+        out["h2d_serial"] = [full["h2d"]["serial"]["value"], full["h2d"]["serial"]["ms_per_step"]]
+    out["roofline"] = _compact_roof(full["roofline"])
+    if full.get("cpu_baseline"):
+        out["cpu_baseline"] = full["cpu_baseline"]
+    if full.get("multi_gpu"):
+        out["multi_gpu"] = full["multi_gpu"]
+    ck = full.get("check")
+    if ck:
+        out["check"] = {k: ck[k] for k in ("ok", "sc_lin", "sc_lin_ref", "abs_diff", "tol", "loss", "mse") if k in ck}
+        if ck.get("reference"):
+            out["check"]["reference"] = {k: v for k, v in ck["reference"].items() if k != "what"}
+    legs = (full.get("extra") or {}).get("workloads")
+    if legs:
+        out["legs_cols"] = LEG_COLS
+        out["legs"] = {k: _leg_row(e) for k, e in legs.items()}
+        out["legs_workloads"] = {k: _short_workload(e["workload"]) for k, e in legs.items() if "workload" in e}
+    out["legend"] = LEGEND
+    for k in ("bench_seconds", "detail"):
+        if k in full:
+            out[k] = full[k]
+    return _r(out)
+
+
+def write_detail(full):
+    """The verbose record beside the line: gpurun_out/bench_detail.json (or $SPECINV_BENCH_DETAIL); best effort."""
+    path = os.environ.get("SPECINV_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(full, fh)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+EXTRA_LEGS = (          # (key, workload, steps, warmup, option overrides, environment) - short legs after the headline's timed region
+    ("C4", "C4", 5, 1, {}, {}),
+    ("C3", "C3", 2, 1, {}, {}),
+    ("C5", "C5", 2, 1, {"outer": 50, "c5_variant": "baseline"}, {}),
+    ("C5_mfma", "C5", 2, 1, {"outer": 50, "c5_variant": "baseline"}, {"SPECINV_OBJ_SPARSE": "0"}),   # the filterbank on the matrix cores
+    ("C5_wolfe", "C5", 2, 1, {"outer": 50, "c5_variant": "wolfe"}, {}),
+    ("C5_memory", "C5", 1, 1, {"outer": 8, "c5_variant": "memory"}, {}),                             # the memory fills: the recursion carries weight
+    ("C1", "C1", 50, 5, {}, {}),
 )
 
 
@@ -747,8 +868,10 @@ def leg_options(args, **over):
 def run_extra(args, dev, pmc_all, pmc_source):
     from spectrogram_inversion_amd.plan import clear_plan_cache
     out = {}
-    for key, workload, steps, warmup, over in EXTRA_LEGS:
+    for key, workload, steps, warmup, over, env in EXTRA_LEGS:
         t0 = time.perf_counter()
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
             leg = Leg(workload, leg_options(args, **over), 0, 1, dev, "nccl")
             el, _ = leg.run(steps, warmup)
@@ -758,15 +881,19 @@ def run_extra(args, dev, pmc_all, pmc_source):
             pmc = pmc_all.get(workload)
             src = pmc_source
             stale = sha = None
-            if not pmc:
+            if key != workload:                               # a variant of the workload: the counted kernel is not the one that ran
+                pmc, src = {}, "not counted (variant leg)"
+            elif not pmc:
                 pmc, sha, stale = stored_pmc(workload)
                 src = "stored: profiles/traffic.json (rocprofv3 --pmc summary), not measured in this run"
             roof = leg.roofline(pmc, src, stale, sha)
             entry["launch_ms"] = roof["launch_ms"]
             entry["frac"] = roof.get("frac")
-            entry["roofline"] = {k: roof[k] for k in ("bound", "kernel", "frac", "achieved", "peak", "unit", "traffic", "traffic_source",
-                                                       "hbm", "valu_issue_frac", "lds_conflict_frac", "dependent_steps_per_s",
-                                                       "evaluations_timed") if k in roof}
+            entry["roofline"] = {k: roof[k] for k in ("bound", "limiter", "limiter_frac", "kernel", "frac", "achieved", "peak", "unit",
+                                                       "traffic", "traffic_frac", "traffic_source", "hbm", "valu_issue_frac",
+                                                       "lds_conflict_frac", "dependent_steps_per_s", "evaluations_timed",
+                                                       "bytes_per_unit", "units_per_launch") if k in roof}
+            entry["objective_kind"] = getattr(getattr(leg, "tr", None), "objective_kind", None)
             if leg.method == "L_BFGS":
                 entry["lbfgs"] = leg.lbfgs_info()
             if not args.no_check:
@@ -776,6 +903,11 @@ def run_extra(args, dev, pmc_all, pmc_source):
             del leg
         except Exception as e:                                # an extra leg must never take the headline line down with it
             out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         clear_plan_cache()
         torch.cuda.empty_cache()
     return out
@@ -837,6 +969,9 @@ def build_parser():
                          "the chip with an exactly-full iteration launch")
     ap.add_argument("--keep-pmc", default=None, help="directory to keep the raw per-dispatch counter CSVs of the live passes in")
     ap.add_argument("--generic", action="store_true", help="force the generic (unfused) kernels")
+    ap.add_argument("--verbose", action="store_true", help="print the verbose record (every what / formula string, raw counters per "
+                                                           "leg) instead of the compact line; it is always written to "
+                                                           "gpurun_out/bench_detail.json")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     return ap
 
@@ -982,7 +1117,10 @@ def main():
                                                WORKLOADS[args.workload][4],
                                                WORKLOADS[args.workload][6] if WORKLOADS[args.workload][6] is not None else 0.0)
         out["bench_seconds"] = time.perf_counter() - t_begin
-        print(json.dumps(out), flush=True)
+        detail = write_detail(out)
+        if detail:
+            out["detail"] = detail
+        print(json.dumps(out if args.verbose else compact_line(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
