@@ -437,8 +437,8 @@ class Leg:
         # launches with HIP events on the launch stream (LBFGS.time_objective) and counts the evaluations the device executed
         if hasattr(fg_raw, "device_objective"):
             fg.device_objective = fg_raw.device_objective
-        if hasattr(fg_raw, "device_wolfe"):
-            fg.device_wolfe = fg_raw.device_wolfe
+        if hasattr(fg_raw, "dev_stats"):              # (strong Wolfe, host-driven: objective + step statistics in one go)
+            fg.dev_stats = lambda v, d, out_ptr: timed_eval(lambda: fg_raw.dev_stats(v, d, out_ptr))
         return fg
 
     def fence(self):
@@ -789,7 +789,7 @@ def _leg_row(e):
     if lb:
         note = (f"{lb['evaluations']} ev | {lb['pairs_accepted']}/{lb['pairs_rejected']} pairs | hist {lb['history_len']} | "
                 f"{'device' if lb['decisions'].startswith('on the device') else 'host'}-decided | objective "
-                f"{ {1: 'mfma', 2: 'bands'}.get(e.get('objective_kind'), e.get('objective_kind')) }")
+                f"{e.get('objective_kind')}")
     elif r.get("dependent_steps_per_s"):
         note = f"{r['dependent_steps_per_s']:.0f} dependent steps/s"
     ck = e.get("check") or {}
@@ -893,7 +893,8 @@ def run_extra(args, dev, pmc_all, pmc_source):
                                                        "traffic", "traffic_frac", "traffic_source", "hbm", "valu_issue_frac",
                                                        "lds_conflict_frac", "dependent_steps_per_s", "evaluations_timed",
                                                        "bytes_per_unit", "units_per_launch") if k in roof}
-            entry["objective_kind"] = getattr(getattr(leg, "tr", None), "objective_kind", None)
+            obj = getattr(getattr(leg, "fg_raw", None), "device_objective", None)
+            entry["objective_kind"] = obj[0].objective_kind if obj else None
             if leg.method == "L_BFGS":
                 entry["lbfgs"] = leg.lbfgs_info()
             if not args.no_check:

@@ -261,6 +261,13 @@ int specinv_lbfgs_stats(specinv_plan* plan, const void* g, const void* d, int64_
  * multi_dot: out_dev[k]; loss_grad: *loss_dev = the loss. */
 int specinv_transform_loss_grad_dev(specinv_plan* plan, const void* x, int64_t length, const void* target,
                                     double* loss_dev, void* grad_out);
+/* The objective and the step statistics of its gradient in one go: out5_dev = {loss, g.d, sum|g|, max|g|, max|d|} with g the
+ * gradient written to grad_out and d a device vector of the signal's shape (NULL: d = g) - what a trial point of the strong-Wolfe
+ * search needs (torch.optim.lbfgs._strong_wolfe: f_new, gtd_new; torch.optim.LBFGS.step: opt_cond, d.abs().max()).  Where the
+ * one-launch objective serves the plan the statistics are taken inside its launches, as each gradient sample becomes final;
+ * otherwise by specinv_lbfgs_stats_dev's pass. */
+int specinv_transform_loss_grad_stats_dev(specinv_plan* plan, const void* x, int64_t length, const void* target, const void* d,
+                                          double* out5_dev, void* grad_out);
 int specinv_vec_multi_dot_dev(specinv_plan* plan, const void* g, const void* const* vecs_host, int k, int64_t n,
                               double* out_dev);
 int specinv_lbfgs_pair_dev(specinv_plan* plan, const void* g, const void* g_prev, const void* d, double t, void* y_out,
@@ -279,10 +286,10 @@ int specinv_stream_wait(specinv_plan* plan);
 
 /* ---- L-BFGS with the decisions on the device (float32, the one-launch objective of specinv_transform_setup) --------------
  * Replaces the inner loop of torch.optim.LBFGS.step as torch_specinv/methods.py:553 drives it (no line search): one call
- * enqueues a whole optimizer.step - for each inner iteration the objective, the curvature pair and its statistics, the products
- * with the memory, a one-wave decision kernel (tolerance tests, y.s > 1e-10, memory ring, two-loop recursion on Gram matrices,
- * step length) and direction + step - and synchronises ONCE, at the end; after a break the rest of the enqueued step runs as
- * no-ops.  The optimiser's state (memory, d, t, previous gradient / loss, counters) lives on the device between steps.
+ * enqueues a whole optimizer.step - for each inner iteration the objective (which takes the statistics of its gradient on the
+ * way) and ONE kernel that decides (tolerance tests, y.s > 1e-10, step length) and forms direction + step; with pairs in the
+ * memory also the products with them and a one-workgroup decision kernel (memory ring, two-loop recursion on Gram matrices) -
+ * and synchronises ONCE, at the end; after a break the rest of the enqueued step runs as no-ops.  The optimiser's state (memory, d, t, previous gradient / loss, counters) lives on the device between steps.
  * Options carry torch.optim.LBFGS's names; max_eval <= 0 means max_iter * 5 / 4.  history_size <= 120.
  * SPECINV_EUNSUPPORTED when the plan's transform is not served by the one-launch objective (the caller then runs the
  * host-driven loop on the *_dev entry points above). */
@@ -291,8 +298,6 @@ typedef struct specinv_lbfgs_opts {
   int32_t max_iter, max_eval, history_size;
   int32_t time_objective;  /* k > 0: bracket every k-th objective evaluation of a step with HIP events (benchmarks:
                               specinv_lbfgs_info.objective_ms / objective_timed; an event pair costs ~10 us of the timeline) */
-  int32_t line_search;     /* 0: none (the step length is lr); 1: 'strong_wolfe' - torch.optim.lbfgs._strong_wolfe's bracketing,
-                              cubic interpolation and zoom decided by a kernel after every evaluation */
 } specinv_lbfgs_opts;
 typedef struct specinv_lbfgs_info {
   double first_loss;      /* what optimizer.step returns: the loss at the entry evaluation */
@@ -301,6 +306,10 @@ typedef struct specinv_lbfgs_info {
   int32_t objective_launches;  /* evaluations this step executed, ... */
   int32_t objective_timed;     /* ... how many of them were bracketed with events (time_objective) ... */
   double objective_ms;         /* ... and the summed duration of those (objective + epilogue launch) */
+  int32_t lean_iterations;     /* iterations enqueued so far in the lean form (objective, epilogue, decision + direction: memory empty) */
+  int32_t full_iterations;     /* ... in the full form (+ memory products, one-workgroup decision kernel) */
+  int32_t suspensions;         /* lean chains that met a non-empty memory and were resumed in the full form */
+  int32_t reserved_;
 } specinv_lbfgs_info;
 /* `n` = elements of the parameter (batch * length); *handle_out identifies the optimiser within the plan */
 int specinv_lbfgs_dev_create(specinv_plan* plan, int64_t n, const specinv_lbfgs_opts* opts, int32_t* handle_out);

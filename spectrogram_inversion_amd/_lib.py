@@ -32,15 +32,15 @@ class Eval(C.Structure):
 
 class LbfgsOpts(C.Structure):
     _fields_ = [("lr", C.c_double), ("tolerance_grad", C.c_double), ("tolerance_change", C.c_double),
-                ("max_iter", C.c_int32), ("max_eval", C.c_int32), ("history_size", C.c_int32), ("time_objective", C.c_int32),
-                ("line_search", C.c_int32)]
+                ("max_iter", C.c_int32), ("max_eval", C.c_int32), ("history_size", C.c_int32), ("time_objective", C.c_int32)]
 
 
 class LbfgsInfo(C.Structure):
     _fields_ = [("first_loss", C.c_double), ("loss", C.c_double), ("t", C.c_double),
                 ("total_iters", C.c_int32), ("func_evals", C.c_int32), ("n_iter", C.c_int32), ("history_len", C.c_int32),
                 ("pairs_accepted", C.c_int32), ("pairs_rejected", C.c_int32), ("objective_launches", C.c_int32),
-                ("objective_timed", C.c_int32), ("objective_ms", C.c_double)]
+                ("objective_timed", C.c_int32), ("objective_ms", C.c_double),
+                ("lean_iterations", C.c_int32), ("full_iterations", C.c_int32), ("suspensions", C.c_int32), ("reserved_", C.c_int32)]
 
 
 EVAL_CB = C.CFUNCTYPE(C.c_int, C.POINTER(Eval), C.c_void_p)
@@ -113,6 +113,7 @@ SIGNATURES = {
     "specinv_lbfgs_dev_destroy": (C.c_int, [_P, C.c_int32]),
     "specinv_vec_lincomb_step": (C.c_int, [_P, C.POINTER(_P), _DP, C.c_int, _I64, _P, C.c_double, _P]),
     "specinv_transform_loss_grad_dev": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "specinv_transform_loss_grad_stats_dev": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "specinv_vec_multi_dot_dev": (C.c_int, [_P, _P, C.POINTER(_P), C.c_int, _I64, _P]),
     "specinv_lbfgs_pair_dev": (C.c_int, [_P, _P, _P, _P, _D, _P, _P, _I64, _P]),
     "specinv_lbfgs_stats_dev": (C.c_int, [_P, _P, _P, _I64, _P]),

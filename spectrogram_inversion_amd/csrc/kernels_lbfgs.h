@@ -1027,48 +1027,230 @@ inline int obj_mel_tiles(int n_mels, int R) {
   return mt <= 3 ? 3 : mt <= 4 ? 4 : mt <= 5 ? 5 : mt <= 8 ? (R == 8 ? 9 : 8) : 0;
 }
 
-// What follows k_objective_logmel, in ONE launch (three small kernels before: ~8 us of a 0.16 ms evaluation):
+// nine figures over the 256 threads of a workgroup, lanes then waves in a fixed order: v[0 .. 6] sums, v[7], v[8] maxima; every
+// thread leaves with the totals
+__device__ inline void block_reduce9(double (&v)[9], double (*red)[9]) {       // red: [waves of the workgroup][9]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) v[i] = wave_sum(v[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v[7] = fmax(v[7], __shfl_xor(v[7], off, 64));
+    v[8] = fmax(v[8], __shfl_xor(v[8], off, 64));
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) red[wave][i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    double t = red[0][i];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = i < 7 ? t + red[w][i] : fmax(t, red[w][i]);
+    v[i] = t;
+  }
+  __syncthreads();
+}
+
+// What follows k_objective_logmel, in ONE launch of kObjRows blocks (grid-stride over the work):
 //   * chunk seams: grad[n] += the previous tile's tail over the first n_fft - hop samples of tiles 1.. (k_hop_tails_raw),
 //   * fold of the padded margins onto the signal (k_grad_fold_margins with `margins` given),
-//   * loss = scale * sum(partials), summed like k_finish_scaled by the last block.
+//   * the statistics of the gradient (fast::ObjStatReq; none: st.rows == nullptr): the pass over the seams becomes a pass over the
+//     WHOLE gradient with g_prev and d beside it - every sample counted once, by the thread that finishes it - and leaves the
+//     first level of the reduction tree: block j adds the squared-error sums of the tiles [j n_tiles / kObjRows, (j + 1) n_tiles /
+//     kObjRows) of the objective kernel to its own figures and writes ONE row of kObjStatRow doubles - {g.d, sum|g|, y.s, y.y,
+//     g.g, g.g_prev, max|g|, max|d|, squared error}, stored component-major [kObjStatRow][kObjRows]; whoever needs the figures (k_objective_finish_rows, the optimiser's
+//     decision kernels) reads kObjRows rows.  (Round 4: k_lbd_pair_stats, a pass of its own after this kernel.  Taken inside the
+//     objective kernel's gather instead, the statistics cost more than that pass: 0.156 against 0.124 ms per evaluation at C5 -
+//     with one workgroup per CU nothing hides the loads of g_prev and d.)
+//   * without statistics: loss = scale * sum(partials) by one extra block (block kObjRows), as k_finish_scaled would.
 // A margin sample that also lies in a seam region is finished by its margin thread (own + tail first, then the fold: the order
 // of the separate launches); the seam threads leave those samples alone, so no two threads touch the same sample.
-static __global__ void k_objective_epilogue(float* __restrict__ grad, const float* __restrict__ xtail, const float* __restrict__ margins,
-                                     const double* __restrict__ part, double* __restrict__ slot, int T, int nchunks, int n_fft, int hop,
-                                     int keep, int pad, int pad_mode, int64_t len, int64_t rows, int64_t n_tail, int64_t n_margin,
-                                     int n_part, double scale, fast::ObjCtl ctl) {
+constexpr int kObjEpiThreads = 1024;   // a streaming pass wants waves in flight: 16 per CU at one block per CU
+static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(float* __restrict__ grad, const float* __restrict__ xtail,
+                                                                   const float* __restrict__ margins, const double* __restrict__ part,
+                                                                   double* __restrict__ slot, int T, int nchunks, int n_fft, int hop,
+                                                                   int keep, int pad, int pad_mode, int64_t len, int64_t rows,
+                                                                   int64_t n_tail, int64_t n_margin, int n_part, double scale,
+                                                                   fast::ObjCtl ctl, fast::ObjStatReq st, int vec_ok) {
+  float* grad_other = ctl.grad_alt;
   if (ctl.do_eval != nullptr) {                  // device-resident optimiser: gate and gradient ping-pong (lbfgs_dev.h)
     if (*ctl.do_eval == 0) return;
-    if (ctl.sel != nullptr) grad = ctl.tab[*ctl.sel];
-    else if ((*ctl.cur ^ 1) != 0) grad = ctl.grad_alt;
+    if ((*ctl.cur ^ 1) != 0) {
+      grad_other = grad;
+      grad = ctl.grad_alt;
+    }
   }
-  const int64_t tail_blocks = (n_tail + 255) / 256, margin_blocks = (n_margin + 255) / 256;
-  const bool fold = pad > 0 && pad_mode != SPECINV_PAD_CONSTANT;
-  const int64_t covered = (int64_t)(T - 1) * hop + n_fft;                // padded positions that receive any frame
-  if ((int64_t)blockIdx.x < tail_blocks) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // (b, c - 1, j)
-    if (i >= n_tail) return;
-    const int j = (int)(i % keep);
-    const int c = (int)((i / keep) % (nchunks - 1)) + 1;
-    const int64_t b = i / ((int64_t)keep * (nchunks - 1));
-    const int64_t n = (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop + j - pad;
-    if (n < 0 || n >= len) return;
-    if (fold && (n <= pad || n >= len - 1 - pad)) return;                 // finished by the margin thread of this sample
-    grad[b * len + n] += xtail[(b * nchunks + (c - 1)) * keep + j];
+  __shared__ double red[16];
+  if (st.rows == nullptr && blockIdx.x == fast::kObjRows) {
+    double sacc = 0;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) sacc += part[i];
+    const double t = block_sum(sacc, red);
+    if (threadIdx.x == 0) *slot = scale * t;
     return;
   }
-  if ((int64_t)blockIdx.x < tail_blocks + margin_blocks) {
+  const bool st_on = st.rows != nullptr;
+  const float* st_d = st.d;
+  const float* st_gp = st.gp;
+  float st_t = st.t;
+  bool d_impl = false;
+  double c0_d = 0.0;
+  if (st_on && st.have != nullptr) {
+    const bool have = *st.have != 0;
+    st_t = (float)*st.t_dev;
+    st_gp = have ? grad_other : nullptr;
+    st_d = have ? st.d : nullptr;
+    if (have && st.d_implicit != nullptr && *st.d_implicit != 0) {    // d = (float)(c0 (double)g_prev): recomputed, not read
+      d_impl = true;
+      c0_d = *st.c0_d;
+      st_d = nullptr;
+    }
+  }
+  auto d_of = [&](float gpv) { return (float)(c0_d * (double)gpv); };
+  fast::ObjStatAcc sta;
+  const bool fold = pad > 0 && pad_mode != SPECINV_PAD_CONSTANT;
+  const bool seams = keep > 0 && nchunks > 1;
+  const int64_t covered = (int64_t)(T - 1) * hop + n_fft;                // padded positions that receive any frame
+  const int64_t stride = (int64_t)fast::kObjRows * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the seam sample n may lie in: the first n_fft - hop padded positions of the tile that holds frame (n + pad) / hop (at most one
+  // seam: tiles are longer than a frame); returns the index into xtail or -1
+  auto seam_of = [&](int64_t b, int64_t n) -> int64_t {
+    if (!seams) return -1;
+    int64_t f0 = (n + pad) / hop;
+    if (f0 > T - 1) f0 = T - 1;
+    int c = (int)(((f0 + 1) * nchunks - 1) / T);        // largest c with c * T / nchunks <= f0, up to rounding: corrected below
+    while (c + 1 < nchunks && fast::hop_chunk_begin(c + 1, T, nchunks) <= f0) ++c;
+    while (c > 0 && fast::hop_chunk_begin(c, T, nchunks) > f0) --c;
+    if (c < 1) return -1;
+    const int64_t j0 = n + pad - (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop;
+    return (j0 >= 0 && j0 < keep) ? (b * nchunks + (c - 1)) * keep + j0 : -1;
+  };
+  if (st_on) {
+    // ---- the whole gradient: seams finished on the way, every sample outside the folded stretches counted
+    if (vec_ok) {
+      // 16-byte pieces (keep, hop, pad, len multiples of 4), tile by tile: the samples between the first frame of tile c and the
+      // first frame of tile c + 1 (the first tile from 0, the last to the end), whose first n_fft - hop are the seam with tile c - 1
+      // - no division per piece; a piece lies in a seam whole or not at all
+      // Two groups of 512 threads walk tiles of their own, three pieces per thread and trip with their loads all requested first:
+      // 9 - 12 loads of 16 bytes in flight per thread (four pieces: 46 registers spilled at 16 waves per CU).
+      const int64_t n_pairs = rows * nchunks;
+      constexpr int GT = kObjEpiThreads / 2;
+      const int grp = threadIdx.x / GT, tig = threadIdx.x - grp * GT;
+      for (int64_t pr = 2 * (int64_t)blockIdx.x + grp; pr < n_pairs; pr += 2 * (int64_t)gridDim.x) {
+        const int64_t b = pr / nchunks;
+        const int c = (int)(pr - b * nchunks);
+        const int64_t t_lo = (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop - pad;       // span[0] of tile c (may be < 0)
+        const int64_t t_hi = (int64_t)fast::hop_chunk_begin(c + 1, T, nchunks) * hop - pad;
+        const int64_t n_lo = c == 0 ? 0 : (t_lo < 0 ? 0 : (t_lo > len ? len : t_lo));
+        const int64_t n_hi = c == nchunks - 1 ? len : (t_hi < 0 ? 0 : (t_hi > len ? len : t_hi));
+        // (offsets inside a tile are ints: pointers to the tile's first sample, the fold stretches as offsets too)
+        const int span = (int)(n_hi - n_lo), seam_end = (seams && c >= 1) ? (int)(t_lo + keep - n_lo) : 0;   // pieces below seam_end: + tail
+        const float* tl = xtail + (b * nchunks + (c - 1)) * keep + (n_lo - t_lo);
+        float* gb = grad + b * len + n_lo;
+        const float* pb = st_gp ? st_gp + b * len + n_lo : nullptr;
+        const float* db = st_d ? st_d + b * len + n_lo : nullptr;
+        // offsets o with n_lo + o <= pad or n_lo + o >= len - 1 - pad lie in a folded stretch
+        const int64_t fl = fold ? pad - n_lo : -1, fh = fold ? len - 1 - pad - n_lo : (int64_t)1 << 40;
+        const int f_lo = fl < -1 ? -1 : (fl > span ? span : (int)fl), f_hi = fh > span ? span : (fh < 0 ? 0 : (int)fh);
+        constexpr int U = 3;
+        for (int o0 = 4 * tig; o0 < span; o0 += U * 4 * GT) {
+          int of[U];
+          fast::v4f gv[U], pv[U], dv[U], tv[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            of[u] = o0 + u * 4 * GT < span ? o0 + u * 4 * GT : o0;
+            gv[u] = *reinterpret_cast<const fast::v4f*>(gb + of[u]);
+            pv[u] = pb ? *reinterpret_cast<const fast::v4f*>(pb + of[u]) : gv[u];
+            dv[u] = db ? *reinterpret_cast<const fast::v4f*>(db + of[u]) : gv[u];
+            if (d_impl) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dv[u][e] = d_of(pv[u][e]);
+            }
+            tv[u] = of[u] < seam_end ? *reinterpret_cast<const fast::v4f*>(tl + of[u]) : fast::v4f{0.0f, 0.0f, 0.0f, 0.0f};
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (u > 0 && o0 + u * 4 * GT >= span) continue;
+            const int o = of[u];
+            const bool sm = o < seam_end;
+            if (o > f_lo && o + 3 < f_hi) {
+              if (sm) {
+                gv[u] = gv[u] + tv[u];
+                *reinterpret_cast<fast::v4f*>(gb + o) = gv[u];
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sta.add(gv[u][e], pb ? pv[u][e] : gv[u][e], (db || d_impl) ? dv[u][e] : gv[u][e], st_t);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (o + e <= f_lo || o + e >= f_hi) continue;             // finished - and counted - by the margin thread of this sample
+                const float g1 = sm ? gv[u][e] + tv[u][e] : gv[u][e];
+                if (sm) gb[o + e] = g1;
+                sta.add(g1, pb ? pv[u][e] : g1, (db || d_impl) ? dv[u][e] : g1, st_t);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      const int64_t items = rows * len;
+      for (int64_t i = first; i < items; i += stride) {
+        const int64_t b = i / len, n = i - b * len;
+        if (fold && (n <= pad || n >= len - 1 - pad)) continue;
+        float g1 = grad[i];
+        const int64_t sx = seam_of(b, n);
+        if (sx >= 0) {
+          g1 += xtail[sx];
+          grad[i] = g1;
+        }
+        sta.add(g1, st_gp ? st_gp[i] : g1, d_impl ? d_of(st_gp[i]) : st_d ? st_d[i] : g1, st_t);
+      }
+    }
+  } else if (vec_ok) {
+    // ---- seams only
+    const int n4 = keep / 4;
+    const int64_t items = n_tail / 4;
+    for (int64_t i = first; i < items; i += stride) {
+      const int q = (int)(i / n4), j = 4 * (int)(i - (int64_t)q * n4);
+      const int b = q / (nchunks - 1), c = q - b * (nchunks - 1) + 1;
+      const int64_t n = (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+      if (n < 0 || n >= len) continue;
+      const fast::v4f tv = *reinterpret_cast<const fast::v4f*>(xtail + ((int64_t)b * nchunks + (c - 1)) * keep + j);
+      float* gq = grad + (int64_t)b * len + n;
+      const fast::v4f gv = *reinterpret_cast<const fast::v4f*>(gq);
+      if (!(fold && (n <= pad || n + 3 >= len - 1 - pad))) {
+        *reinterpret_cast<fast::v4f*>(gq) = gv + tv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t ne = n + e;
+          if (ne <= pad || ne >= len - 1 - pad) continue;                 // finished by the margin thread of this sample
+          gq[e] = gv[e] + tv[e];
+        }
+      }
+    }
+  } else {
+    for (int64_t i = first; i < n_tail; i += stride) {                   // (b, c - 1, j)
+      const int j = (int)(i % keep);
+      const int c = (int)((i / keep) % (nchunks - 1)) + 1;
+      const int64_t b = i / ((int64_t)keep * (nchunks - 1));
+      const int64_t n = (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+      if (n < 0 || n >= len) continue;
+      if (fold && (n <= pad || n >= len - 1 - pad)) continue;             // finished by the margin thread of this sample
+      grad[b * len + n] += xtail[(b * nchunks + (c - 1)) * keep + j];
+    }
+  }
+  // ---- margins
+  for (int64_t i = first; i < n_margin; i += stride) {
     const int64_t per_row = 2 * ((int64_t)pad + 1);
-    const int64_t i = ((int64_t)blockIdx.x - tail_blocks) * 256 + threadIdx.x;
-    if (i >= n_margin) return;
     const int64_t bi = i / per_row, j = i - bi * per_row;
     int64_t n;
     if (j <= pad) {
       n = j;                                            // left stretch 0 .. pad
-      if (n >= len) return;
+      if (n >= len) continue;
     } else {
       n = len - 1 - pad + (j - pad - 1);                // right stretch len-1-pad .. len-1
-      if (n <= pad || n >= len) return;                 // (short signals: already covered by the left stretch)
+      if (n <= pad || n >= len) continue;               // (short signals: already covered by the left stretch)
     }
     const float* mg = margins + bi * 2 * pad;
     auto at = [&](int64_t np) -> float {                // gradient w.r.t. padded sample np
@@ -1097,27 +1279,57 @@ static __global__ void k_objective_epilogue(float* __restrict__ grad, const floa
         break;
     }
     float v = grad[bi * len + n];
-    if (keep > 0 && nchunks > 1) {
-      // the seam this sample may lie in: the first n_fft - hop padded positions of the tile that holds frame (n + pad) / hop
-      // (at most one seam: tiles are longer than a frame)
-      int64_t f0 = (n + pad) / hop;
-      if (f0 > T - 1) f0 = T - 1;
-      int c = (int)(((f0 + 1) * nchunks - 1) / T);      // largest c with c * T / nchunks <= f0, up to rounding: corrected below
-      while (c + 1 < nchunks && fast::hop_chunk_begin(c + 1, T, nchunks) <= f0) ++c;
-      while (c > 0 && fast::hop_chunk_begin(c, T, nchunks) > f0) --c;
-      if (c >= 1) {
-        const int64_t j0 = n + pad - (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop;
-        if (j0 >= 0 && j0 < keep) v += xtail[(bi * nchunks + (c - 1)) * keep + j0];
-      }
-    }
-    grad[bi * len + n] = v + g;
-    return;
+    const int64_t sx = seam_of(bi, n);
+    if (sx >= 0) v += xtail[sx];
+    const float g1 = v + g;
+    grad[bi * len + n] = g1;
+    if (st_on) sta.add(g1, st_gp ? st_gp[bi * len + n] : g1, d_impl ? d_of(st_gp[bi * len + n]) : st_d ? st_d[bi * len + n] : g1, st_t);
   }
-  __shared__ double red[16];
-  double sacc = 0;
-  for (int i = threadIdx.x; i < n_part; i += blockDim.x) sacc += part[i];
-  const double t = block_sum(sacc, red);
-  if (threadIdx.x == 0) *slot = scale * t;
+  if (!st_on) return;
+  // ---- this block's row: its own figures + the squared-error sums of its share of the objective kernel's tiles
+  __shared__ double red9[kObjEpiThreads / 64][9];
+  double v[9] = {sta.s[0], sta.s[1], sta.s[2], sta.s[3], sta.s[4], sta.s[5], 0.0, (double)sta.mg, (double)sta.md};
+  const int lo = (int)((int64_t)n_part * blockIdx.x / fast::kObjRows), hi = (int)((int64_t)n_part * (blockIdx.x + 1) / fast::kObjRows);
+  for (int tl = lo + threadIdx.x; tl < hi; tl += blockDim.x) v[6] += part[tl];
+  block_reduce9(v, red9);
+  if (threadIdx.x == 0) {                       // component-major: readers take one component of every row with one coalesced load
+    double* row = st.rows + blockIdx.x;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) row[c * fast::kObjRows] = v[c];
+    row[6 * fast::kObjRows] = v[7];
+    row[7 * fast::kObjRows] = v[8];
+    row[8 * fast::kObjRows] = v[6];
+  }
+}
+
+// the second level of the tree: out = {loss, g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev} from the epilogue's rows (one
+// workgroup, fixed order; the layout lbfgs.py:_batch reads from its board)
+static __global__ __launch_bounds__(256) void k_objective_finish_rows(const double* __restrict__ rows, double scale, double* __restrict__ out,
+                                                                      int n_out) {
+  __shared__ double red9[4][9];
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = threadIdx.x; r < fast::kObjRows; r += blockDim.x) {
+    const double* q = rows + r;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] += q[c * fast::kObjRows];
+    v[6] += q[8 * fast::kObjRows];
+    v[7] = fmax(v[7], q[6 * fast::kObjRows]);
+    v[8] = fmax(v[8], q[7 * fast::kObjRows]);
+  }
+  block_reduce9(v, red9);
+  if (threadIdx.x == 0) {
+    out[0] = scale * v[6];
+    out[1] = v[0];
+    out[2] = v[1];
+    out[3] = v[7];
+    out[4] = v[8];
+    if (n_out > 5) {
+      out[5] = v[2];
+      out[6] = v[3];
+      out[7] = v[4];
+      out[8] = v[5];
+    }
+  }
 }
 
 // loss = sum(partials) / numel, to the host (synchronises) or to a device scalar (nothing waits)
@@ -1136,7 +1348,7 @@ int tf_finish_loss(P& pl, int64_t n_part, double numel, double* loss_host, doubl
 // `*used` stays false when the configuration is not covered: the caller then runs the kernel chain.
 template <typename P>
 int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, double* loss, float* grad, bool* used,
-                       double* loss_dev = nullptr, const fast::ObjCtl* ctl = nullptr) {
+                       double* loss_dev = nullptr, const fast::ObjCtl* ctl = nullptr, const fast::ObjStatReq* st = nullptr) {
   *used = false;
   const bool mag = pl.tf_kind == SPECINV_TF_MAG;
   if (pl.force_generic || !pl.cfg.onesided || !pl.fast.xform_ok || (pl.fast.xform_R != 8 && pl.fast.xform_R != 16)) return SPECINV_OK;
@@ -1195,8 +1407,6 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     a.ctl_eval = ctl->do_eval;
     a.ctl_cur = ctl->cur;
     a.grad_alt = ctl->grad_alt;
-    a.ctl_sel = ctl->sel;
-    a.ctl_tab = ctl->tab;
   }
   const void* fn = nullptr;
   size_t lds = 0;
@@ -1254,13 +1464,18 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     const bool fold = pad > 0 && pl.cfg.pad_mode != SPECINV_PAD_CONSTANT;
     const int64_t n_tail = (nch > 1 && keep > 0) ? (int64_t)B * (nch - 1) * keep : 0;
     const int64_t n_margin = fold ? (int64_t)B * 2 * (pad + 1) : 0;
-    const int64_t blocks = ceil_div(n_tail, 256) + ceil_div(n_margin, 256) + 1;
+    const bool with_rows = st && st->rows;
+    const int blocks = fast::kObjRows + (with_rows ? 0 : 1);
     double* slot = loss_dev ? loss_dev : pl.sums.template as<double>();
-    hipLaunchKernelGGL(k_objective_epilogue, dim3((unsigned)blocks), dim3(256), 0, pl.stream, grad, (const float*)a.xtail,
+    const int vec_ok = ((keep | hop | pad) & 3) == 0 && (len & 3) == 0 && ((uintptr_t)grad & 15) == 0 &&
+                       (!ctl || ((uintptr_t)ctl->grad_alt & 15) == 0) && n_tail / 4 / std::max(1, keep / 4) < (1ll << 31) &&
+                       (!with_rows || ((((uintptr_t)st->d | (uintptr_t)st->gp) & 15) == 0));
+    hipLaunchKernelGGL(k_objective_epilogue, dim3((unsigned)blocks), dim3(kObjEpiThreads), 0, pl.stream, grad, (const float*)a.xtail,
                        (const float*)a.margins, (const double*)pl.partials.template as<double>(), slot, T, nch, N, hop, keep,
                        pad, pl.cfg.pad_mode, (int64_t)len, (int64_t)B, n_tail, n_margin, (int)n_tiles, 1.0 / numel,
-                       ctl ? *ctl : fast::ObjCtl{});
+                       ctl ? *ctl : fast::ObjCtl{}, with_rows ? *st : fast::ObjStatReq{}, vec_ok);
     SI_HIP(hipGetLastError());
+    if (with_rows) return SPECINV_OK;      // (loss and figures are in the rows: the caller finishes them)
   }
   if (loss_dev) return SPECINV_OK;
   SI_HIP(hipMemcpyAsync(loss, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
@@ -1391,9 +1606,13 @@ int tf_forward(P& pl, const T* x, int64_t len, T* v_out) {
 }
 
 template <typename P, typename T>
-int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, T* grad, double* loss_dev = nullptr) {
+int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, T* grad, double* loss_dev = nullptr,
+                 bool with_stats = false, const T* stat_d = nullptr) {
+  // with_stats: loss_dev[0 .. 4] = {loss, g.d, sum|g|, max|g|, max|d|} (stat_d == nullptr: d = g) - from the objective's own launch
+  // where the one-launch kernel serves the configuration, by a pass over g and d otherwise
   SI_CHECK(pl.tf_kind >= 0, SPECINV_ESTATE, "specinv_transform_setup has not been called");
   SI_CHECK(x && target && (loss || loss_dev) && grad, SPECINV_EINVAL, "null pointer");
+  SI_CHECK(!with_stats || loss_dev, SPECINV_EINVAL, "statistics go to device memory");
   using C = cplx<T>;
   const int64_t BT = (int64_t)pl.B() * pl.Tn();
   {
@@ -1403,8 +1622,27 @@ int tf_loss_grad(P& pl, const T* x, int64_t len, const T* target, double* loss, 
   }
   if constexpr (std::is_same<T, float>::value) {
     bool used = false;
-    SI_TRY(tf_loss_grad_fused(pl, x, len, target, loss, grad, &used, loss_dev));
-    if (used) return SPECINV_OK;
+    if (with_stats && (((uintptr_t)stat_d | (uintptr_t)grad) & 15) == 0) {
+      SI_TRY(pl.tf_rows.reserve((size_t)fast::kObjRows * fast::kObjStatRow * sizeof(double)));
+      fast::ObjStatReq sr{};
+      sr.d = stat_d;
+      sr.rows = pl.tf_rows.template as<double>();
+      SI_TRY(tf_loss_grad_fused(pl, x, len, target, nullptr, grad, &used, loss_dev, nullptr, &sr));
+      if (used) {
+        const double numel = (double)BT * (pl.tf_kind == SPECINV_TF_MAG ? pl.n_freq : pl.tf_mels);
+        hipLaunchKernelGGL(k_objective_finish_rows, dim3(1), dim3(256), 0, pl.stream, (const double*)sr.rows, 1.0 / numel, loss_dev, 5);
+        SI_HIP(hipGetLastError());
+        return SPECINV_OK;
+      }
+    } else {
+      SI_TRY(tf_loss_grad_fused(pl, x, len, target, loss, grad, &used, loss_dev));
+      if (used && with_stats) return lb_stats(pl, (const T*)grad, stat_d ? stat_d : (const T*)grad, (int64_t)pl.B() * len, nullptr, loss_dev + 1);
+      if (used) return SPECINV_OK;
+    }
+  }
+  if (with_stats) {
+    SI_TRY((tf_loss_grad<P, T>(pl, x, len, target, loss, grad, loss_dev)));
+    return lb_stats(pl, (const T*)grad, stat_d ? stat_d : (const T*)grad, (int64_t)pl.B() * len, nullptr, loss_dev + 1);
   }
   if (const char* e = getenv("SPECINV_REQUIRE_FUSED_OBJECTIVE")) {     // tests: the shape must be on the one-launch kernel
     SI_CHECK(e[0] != '1', SPECINV_EUNSUPPORTED, "the one-launch objective does not cover this configuration");

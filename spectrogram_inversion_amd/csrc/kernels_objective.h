@@ -77,8 +77,7 @@ __global__ __launch_bounds__(64 * kObjWaves, 2) void k_objective_logmel(ObjArgs 
   if (a.ctl_eval != nullptr && *a.ctl_eval == 0) return;     // (the optimiser has stopped: the rest of its enqueued step is no-ops)
   // where the gradient goes (read here, not in front of the gather that needs it: a scalar load from device memory)
   float* grad_base = a.grad;
-  if (a.ctl_sel != nullptr) grad_base = a.ctl_tab[*a.ctl_sel];
-  else if (a.ctl_cur != nullptr && (*a.ctl_cur ^ 1) != 0) grad_base = a.grad_alt;
+  if (a.ctl_cur != nullptr && (*a.ctl_cur ^ 1) != 0) grad_base = a.grad_alt;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   v2f* tr = reinterpret_cast<v2f*>(uni) + wib * G::TR;
   const LaneConst<R> k = lane_consts<R>();

@@ -1,16 +1,24 @@
 // L-BFGS with the decisions on the device: one `optimizer.step` (reference: torch_specinv/methods.py:553 ->
-// torch.optim.LBFGS.step, third-party; this file: no line search - strong Wolfe: lbfgs_dev_ls.h, on the state record, the decision
-// functions and the reduction kernels defined here) is ENQUEUED as a whole - objective, curvature pair + statistics, memory
-// products, a one-wave decision kernel, direction + step - and the host synchronises once per step instead of once per inner
-// iteration (kernels_lbfgs.h / lbfgs.py:_step_packed: ~0.05 ms of host turnaround around a 0.15 ms objective).
+// torch.optim.LBFGS.step, third-party; no line search - strong Wolfe runs on the host-driven packed loop, lbfgs.py) is ENQUEUED as a
+// whole and the host synchronises once per step instead of once per inner iteration (kernels_lbfgs.h / lbfgs.py:_step_packed:
+// ~0.05 ms of host turnaround around a 0.15 ms objective).
 //
-// What the host used to decide after reading the iteration's scalars now happens in `k_lbd_decide` (a single wave), in the order of
-// torch.optim.LBFGS.step: the tolerance tests that end a step, the curvature guard y.s > 1e-10 and the memory update (ring of
-// history_size + 1 vector slots: the candidate pair is written to the spare slot, so a rejected pair costs nothing), the Gram
-// matrices s_i.y_j / y_i.y_j and the two-loop recursion on scalars (lbfgs.py:_gram_append / _gram_coefficients), t, g.d.  The
-// kernels that follow read what they need from the state record in device memory: the coefficient / pointer lists of the linear
-// combination, the step length, which of the two gradient buffers is current, and whether they are to run at all (after a
-// break the rest of the enqueued step is a chain of no-ops).  Objective: the one-launch kernel (kernels_objective.h) only.
+// An inner iteration is THREE launches while the memory is empty (round 5; six before):
+//   k_objective_logmel    loss + gradient, and the statistics of the new gradient - {g.d, sum|g|, y.s, y.y, g.g, g.g_prev, max|g|,
+//                         max|d|} - taken where each sample becomes final (ObjArgs::st_*), not by a pass of their own
+//   k_objective_epilogue  seams, margins, their share of the statistics, and the first level of the reduction: kObjRows rows
+//   k_lbd_direction_lean  every workgroup finishes the rows and takes the iteration's decisions itself (scalars: the tolerance
+//                         tests that end a step, the curvature guard y.s > 1e-10, a memory of at most the ONE pair this iteration
+//                         accepts), then forms its share of d and x += t d; workgroup 0 writes the state record - into the OTHER of
+//                         two buffers, so that no workgroup reads what another has already replaced.
+// With pairs in the memory (BASELINE C5 never gets there: every pair fails the guard) an iteration needs the products of g with
+// them and the two-loop recursion, and takes the full form: k_lbd_multi_dot, k_lbd_decide (one workgroup: Gram matrices s_i.y_j /
+// y_i.y_j and the recursion on scalars, lbfgs.py:_gram_append / _gram_coefficients), k_lbd_lincomb_step.  The host picks the form
+// at the start of a step from the memory length it last read; a lean chain that meets a non-empty memory (the iteration after
+// its first accepted pair) SUSPENDS the step - the rest of the chain runs as no-ops - and the host resumes it in the full form.
+// The kernels read what they need from the state record in device memory: coefficient / pointer lists, step length, which of the
+// two gradient buffers is current, whether they are to run at all (after a break the rest of the enqueued step is a chain of
+// no-ops).  Objective: the one-launch kernel (kernels_objective.h) only.
 #pragma once
 #include <cstring>
 #include <memory>
@@ -24,12 +32,7 @@ constexpr int kLbdMaxHist = 120;          // history_size the device path takes 
 constexpr int kLbdInfo = 2;               // pinned board: [0] the step is live, [1] slots decided, [kLbdInfo ..] what the step leaves (lbfgs_dev_ls.h)
 constexpr int kLbdBoard = 16;             // doubles of the board
 
-struct LbdPoint {                         // a point of the line search: step length, loss, g.d, max|g|, the evaluation's eight sums, its gradient buffer
-  double t, f, gtd, gmax, ps[8];
-  int g, pad_;
-};
-
-struct LbdState {                         // device-resident; copied to the host at the end of a step
+struct LbdState {                         // device-resident (two buffers, see above); copied to the host at the end of a step
   // options
   double lr, tol_grad, tol_change;
   int max_iter, max_eval, hist;
@@ -37,7 +40,14 @@ struct LbdState {                         // device-resident; copied to the host
   int total_iters, func_evals, m, seq0, cur, pairs_accepted, pairs_rejected, n_prev;
   double t, h_diag, prev_loss, loss;
   // control of the step being executed
-  int active, do_lincomb, do_step, do_eval, n_iter, evals, have_prev, k_lin, k_dot, pad_;
+  int active, do_lincomb, do_step, do_eval, n_iter, evals, have_prev, k_lin, k_dot;
+  int suspended;                          // a lean chain met a non-empty memory at iteration resume_k: the host continues in the full form
+  int resume_k;
+  // lean iterations that accept no pair form d = (float)(c0 (double)g) and x += t d in registers and do not STORE d: whoever needs it
+  // (the next evaluation's statistics, the pair s = t d of the iteration that does accept) recomputes it from the gradient it was
+  // formed from - gbuf[cur], the previous gradient by then - bit for bit.  Cleared by the lean iteration that accepts a pair.
+  int d_implicit;
+  double c0_d;
   // the pair accepted by the last decision is FORMED by the direction kernel (y = g - g_prev, s = t_pair d_old, written to the
   // ring and used from registers): positions of y_new / s_new in the list of the linear combination, -1: no new pair
   int pair_y, pair_s;
@@ -45,22 +55,12 @@ struct LbdState {                         // device-resident; copied to the host
   double first_loss, gtd;
   // reductions of the last evaluation: loss; {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev}
   double b_loss, b_ps[8];
-  // ---- strong-Wolfe line search on the device (lbfgs_dev_ls.h) ------------------------------------------------------------
-  int ls;                                 // option: line_search_fn = 'strong_wolfe'
-  int mode;                               // what the slot that ends with the next decision carries (LbdMode)
-  int do_trial, do_mdot, need_fix;        // x = x0 + t d;  memory products of gradient g_md;  ... with t_fix (the accepted point was not the last trial)
-  int g_cur, g_old, g_eval, g_md;         // gradient buffers (of four): prev_flat_grad, the one before it, where the next evaluation writes, whose products
-  int ls_phase, ls_it, ls_max, ls_lo, ls_hi, ls_nbr, ls_stalled, ls_first, pad3_;
-  unsigned long long eval_slots;          // bit s: slot s of the step executed an evaluation (benchmarks: which event pairs count)
-  double t_fix, ls_f0, ls_gtd0, ls_dnorm;
-  LbdPoint ls_prev, ls_start, ls_br[2], ls_acc;
 };
-enum LbdMode { LBD_IDLE = 0, LBD_ENTRY = 1, LBD_TRIAL = 2, LBD_POST = 3 };
 
 template <typename T>
 struct LbdPtrs {                          // kernel argument: where everything lives
-  LbdState* st;
-  double* dots;        // [2 hist]  g . (ss then ys) of the last evaluation
+  LbdState* st;        // the state record this launch reads (and, but for the lean direction kernel, writes)
+  LbdState* st_next;   // lean direction kernel: the record it writes
   double* sgp;         // [hist]    s_i . g of the previous direction (lbfgs.py: _sg)
   double* ygp;         // [hist]
   double* rho;         // [hist]
@@ -71,11 +71,7 @@ struct LbdPtrs {                          // kernel argument: where everything l
   const T** dot_ptr;   // [2 hist]       ss then ys
   T** ys_slot;         // [hist + 1]     ring of vector slots (slot of pair number q: q mod (hist + 1))
   T** ss_slot;         // [hist + 1]
-  T** cand;            // [2]            where the next evaluation's y and s go
   T* gbuf[2];          // gradient ping-pong: the evaluation writes gbuf[cur ^ 1], reads gbuf[cur] as the previous gradient
-  T* g4[4];            // line search: four gradient buffers (g4[0], g4[1] = gbuf), chosen by the state's g_* indices
-  T* const* g4_dev;    // ... the same table in device memory (the objective kernel's ObjCtl.tab)
-  T* x0;               // ... the point the line search started from
   T* d;
   double* board;       // pinned host memory: [0] = active (a peek, not a synchronisation)
 };
@@ -100,73 +96,51 @@ __device__ inline double lbd_wave_sum(double v) {
 // dependent global loads), the finished sums of the evaluation, the vectors of the two triangular recursions.
 struct LbdShared {
   double al[kLbdMaxHist], cc[kLbdMaxHist], yq[kLbdMaxHist], sgv[kLbdMaxHist], ygv[kLbdMaxHist];
-  double dotv[2 * kLbdMaxHist], bps[8], red[16], mx[2][4];
+  double dotv[2 * kLbdMaxHist], bps[8], red[16], red9[4][9], loss;
   LbdState R;
 };
 
-__device__ inline void lbd_load_state(LbdShared& sh, const LbdState* st) {
+__device__ inline void lbd_load_state(LbdState& R, const LbdState* st) {
   static_assert(sizeof(LbdState) % 8 == 0 && sizeof(LbdState) / 8 <= 256, "LbdState is copied by one pass of doubles");
   const int tid = threadIdx.x;
-  if (tid < (int)(sizeof(LbdState) / 8)) reinterpret_cast<double*>(&sh.R)[tid] = reinterpret_cast<const double*>(st)[tid];
+  if (tid < (int)(sizeof(LbdState) / 8)) reinterpret_cast<double*>(&R)[tid] = reinterpret_cast<const double*>(st)[tid];
   __syncthreads();
 }
 
-// The reductions an evaluation left unfinished (its kernels write per-block partial sums; finishing them here saves two
-// one-workgroup launches per evaluation): sh.bps = {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev} over the nb blocks of
-// k_lbd_pair_stats (fixed order), sh.dotv = the kd products of g with the memory.
-__device__ inline void lbd_finish_sums(LbdShared& sh, const double* __restrict__ part_pair, int nb, const double* __restrict__ part_dot,
-                                       int kd) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  double(&bps)[8] = sh.bps;
-  double(&dotv)[2 * kLbdMaxHist] = sh.dotv;
-  double(&red)[16] = sh.red;
-  double(&mx)[2][4] = sh.mx;
-  // ---- finish the evaluation's sums: {g.d, sum|g|, y.s, y.y, g.g, g.g_prev} + max|g|, max|d| over the nb blocks of
-  // k_lbd_pair_dots (fixed order), and the products of g with the memory
-  {
-    double s6[6] = {0, 0, 0, 0, 0, 0}, m0 = 0, m1 = 0;
-    for (int i = tid; i < nb; i += 256) {
+// The second level of the evaluation's reduction tree (the first: k_objective_epilogue's rows): every thread of the workgroup
+// leaves with bps = {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev} and the loss, summed in a fixed order.
+__device__ inline void lbd_finish_rows(double (&bps)[8], double& loss, double (*red9)[9], const double* __restrict__ rows, double scale) {
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = threadIdx.x; r < fast::kObjRows; r += blockDim.x) {
+    const double* q = rows + r;                     // component-major rows (k_objective_epilogue)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) s6[c] += part_pair[8 * i + c];
-      m0 = part_pair[8 * i + 6] > m0 ? part_pair[8 * i + 6] : m0;
-      m1 = part_pair[8 * i + 7] > m1 ? part_pair[8 * i + 7] : m1;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double o0 = __shfl_xor(m0, off, 64), o1 = __shfl_xor(m1, off, 64);
-      m0 = o0 > m0 ? o0 : m0;
-      m1 = o1 > m1 ? o1 : m1;
-    }
-    if (lane == 0) {
-      mx[0][wv] = m0;
-      mx[1][wv] = m1;
-    }
-    double tot[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) tot[c] = block_sum(s6[c], red);
-    if (tid == 0) {
-      double r0 = 0, r1 = 0;
-      for (int w = 0; w < 4; ++w) {
-        r0 = mx[0][w] > r0 ? mx[0][w] : r0;
-        r1 = mx[1][w] > r1 ? mx[1][w] : r1;
-      }
-      bps[0] = tot[0];
-      bps[1] = tot[1];
-      bps[2] = r0;
-      bps[3] = r1;
-      bps[4] = tot[2];
-      bps[5] = tot[3];
-      bps[6] = tot[4];
-      bps[7] = tot[5];
-    }
-    for (int j = wv; j < kd; j += 4) {            // one wave per product
-      double sj = 0.0;
-      for (int i = lane; i < nb; i += 64) sj += part_dot[(int64_t)j * nb + i];
-      sj = lbd_wave_sum(sj);
-      if (lane == 0) dotv[j] = sj;
-    }
-    __syncthreads();
+    for (int c = 0; c < 6; ++c) v[c] += q[c * fast::kObjRows];
+    v[6] += q[8 * fast::kObjRows];
+    v[7] = fmax(v[7], q[6 * fast::kObjRows]);
+    v[8] = fmax(v[8], q[7 * fast::kObjRows]);
   }
+  block_reduce9(v, red9);
+  bps[0] = v[0];
+  bps[1] = v[1];
+  bps[2] = v[7];
+  bps[3] = v[8];
+  bps[4] = v[2];
+  bps[5] = v[3];
+  bps[6] = v[4];
+  bps[7] = v[5];
+  loss = scale * v[6];
+}
+
+// ... and the products of g with the memory, from k_lbd_multi_dot's per-block partial sums: one wave per product
+__device__ inline void lbd_finish_dots(LbdShared& sh, const double* __restrict__ part_dot, int nb, int kd) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int j = wv; j < kd; j += 4) {
+    double sj = 0.0;
+    for (int i = lane; i < nb; i += 64) sj += part_dot[(int64_t)j * nb + i];
+    sj = lbd_wave_sum(sj);
+    if (lane == 0) sh.dotv[j] = sj;
+  }
+  __syncthreads();
 }
 
 struct LbdDirection {
@@ -347,7 +321,7 @@ __device__ inline LbdDirection lbd_iteration(const LbdPtrs<T>& p, LbdShared& sh,
       S.pairs_rejected = R.pairs_rejected + (accept ? 0 : 1);
     }
   }
-  // memory products of the next evaluation, and where its candidate pair goes (the spare slot of the ring)
+  // memory products of the next evaluation
   for (int i = tid; i < m; i += 256) {
     p.dot_ptr[i] = p.ss_slot[(seq0 + i) % (hist + 1)];
     p.dot_ptr[m + i] = p.ys_slot[(seq0 + i) % (hist + 1)];
@@ -368,24 +342,35 @@ __device__ inline LbdDirection lbd_iteration(const LbdPtrs<T>& p, LbdShared& sh,
     S.k_lin = 1 + 2 * m;
     S.k_dot = 2 * m;
     S.have_prev = 1;
-    p.cand[0] = p.ys_slot[(seq0 + m) % (hist + 1)];
-    p.cand[1] = p.ss_slot[(seq0 + m) % (hist + 1)];
   }
   return LbdDirection{gtd, t, m};
 }
 
-// The decisions of iteration k (1-based) of a step without a line search, preceded by the reductions of the evaluation: 256
-// threads finish the sums, wave 0 decides; the Gram matrix s_i.y_j is staged in LDS for the two triangular recursions.  Every
-// branch below is uniform over the workgroup, so all four waves reach every barrier.
+// What follows an evaluation in torch.optim.LBFGS.step - opt_cond at the entry evaluation (k == 1); max_eval, opt_cond, the step
+// and loss tolerances at the end of an iteration - on the finished sums: does the step end here?  `evals`: evaluations of this
+// step including this one.
+__device__ inline bool lbd_step_ends(const LbdState& R, const double (&bps)[8], double loss, int k, int& evals) {
+  const double gmax = bps[2];
+  if (k == 1) {
+    evals = 1;
+    return gmax <= R.tol_grad;
+  }
+  evals = R.evals + 1;
+  return evals >= R.max_eval || gmax <= R.tol_grad || fabs(R.t) * bps[3] <= R.tol_change || fabs(loss - R.prev_loss) < R.tol_change;
+}
+
+// The decisions of iteration k (1-based) of a step with pairs in the memory, preceded by the second level of the evaluation's
+// reductions: 256 threads finish the sums, wave 0 decides; the Gram matrix s_i.y_j is staged in LDS for the two triangular
+// recursions.  Every branch below is uniform over the workgroup, so all four waves reach every barrier.
 template <typename T>
-__global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const double* __restrict__ part_pair, int nb,
-                                                    const double* __restrict__ part_dot, const double* __restrict__ loss_slot) {
+__global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const double* __restrict__ rows, double scale,
+                                                    const double* __restrict__ part_dot, int nb) {
   extern __shared__ double lds_sy[];              // [m * m]
   __shared__ LbdShared sh;
   const LbdState& R = sh.R;
   LbdState& S = *p.st;                            // writes go to S
   const int tid = threadIdx.x;
-  lbd_load_state(sh, p.st);
+  lbd_load_state(sh.R, p.st);
   auto stop = [&]() {                             // the step ends here: everything still enqueued for it is a no-op
     if (tid == 0) {
       S.active = 0;
@@ -399,35 +384,21 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
     stop();
     return;
   }
-  lbd_finish_sums(sh, part_pair, nb, part_dot, R.k_dot);
-  // ---- the tests that follow an evaluation (torch.optim.LBFGS.step: opt_cond at entry; max_eval, opt_cond, step and loss
-  // tolerances at the end of an iteration)
-  const double loss = *loss_slot, gmax = sh.bps[2];
-  if (k == 1) {
-    if (tid == 0) {
-      S.first_loss = loss;
-      S.loss = loss;
-      S.evals = 1;
-      S.func_evals = R.func_evals + 1;
-    }
-    if (gmax <= R.tol_grad) {
-      stop();
-      return;
-    }
-  } else {
-    const int evals = R.evals + 1;
-    const bool end = evals >= R.max_eval || gmax <= R.tol_grad || fabs(R.t) * sh.bps[3] <= R.tol_change ||
-                     fabs(loss - R.prev_loss) < R.tol_change;
-    __syncthreads();                              // (everybody has read R.evals / S.t / R.prev_loss)
-    if (tid == 0) {
-      S.loss = loss;
-      S.evals = evals;
-      S.func_evals = R.func_evals + 1;
-    }
-    if (end) {
-      stop();                                     // (the gradient just evaluated is dropped: prev_flat_grad stays gbuf[cur])
-      return;
-    }
+  lbd_finish_rows(sh.bps, sh.loss, sh.red9, rows, scale);
+  lbd_finish_dots(sh, part_dot, nb, R.k_dot);
+  const double loss = sh.loss;
+  int evals;
+  const bool end = lbd_step_ends(R, sh.bps, loss, k, evals);
+  __syncthreads();                                // (everybody has read R.evals / R.t / R.prev_loss)
+  if (tid == 0) {
+    if (k == 1) S.first_loss = loss;
+    S.loss = loss;
+    S.evals = evals;
+    S.func_evals = R.func_evals + 1;
+  }
+  if (end) {
+    stop();                                       // (the gradient just evaluated is dropped: prev_flat_grad stays gbuf[cur])
+    return;
   }
   // ---- iteration k begins: the evaluated gradient is the current one
   const int cur = R.cur ^ 1;
@@ -524,72 +495,278 @@ __global__ __launch_bounds__(256) void k_lbd_lincomb_step(LbdPtrs<T> p, T* __res
   }
 }
 
-// The evaluation's reductions: k_lbfgs_pair_stats on the state's buffers - g = gbuf[cur ^ 1] (just evaluated), g_prev = gbuf[cur],
-// the sums over y = g - g_prev and s = t d without writing them; before the first iteration there is no previous gradient: statistics with d = g
-// (lbfgs.py:_batch), the pair unused - and k_multi_dot over the device-resident list of memory vectors (ss then ys; it returns at
-// once while the memory is empty).  Two kernels: fused into one they share its 158 registers and the streaming pass over g, g_prev,
-// d runs at three waves per SIMD instead of eight (41 against 30 us at C5).  Per-block partial sums; k_lbd_decide finishes them.
-constexpr int kLbdMaxVec = 2 * kLbdMaxHist;
+// ---- the lean iteration: decisions and direction in one kernel (file header) ------------------------------------------------
+// What one iteration decides while the memory holds no pair when it begins: plain scalars, computed by every thread alike.
+struct LbdLean {
+  int stop, suspend, accept;      // the step ends at this evaluation / a memory to multiply with: not for this kernel / pair accepted
+  int evals, total, m, n_prev, cur, do_step, do_eval, active;
+  double loss, c0, cy, cs, t, gtd, h_diag, rho0, sg0, yg0, ys, yy;
+};
+
+__device__ inline LbdLean lbd_lean_decide(const LbdState& R, const double (&bps)[8], double loss, int k) {
+  LbdLean o{};
+  o.loss = loss;
+  o.stop = lbd_step_ends(R, bps, loss, k, o.evals) ? 1 : 0;
+  if (o.stop) return o;
+  if (R.total_iters >= 1 && R.m > 0) {            // (the iteration after this chain's first accepted pair)
+    o.suspend = 1;
+    return o;
+  }
+  o.cur = R.cur ^ 1;
+  o.total = R.total_iters + 1;
+  o.h_diag = R.h_diag;
+  if (o.total == 1) {                             // (lbfgs.py:_forget) the statistics were taken with d = g
+    o.h_diag = 1.0;
+    o.c0 = -1.0;
+    o.gtd = -bps[0];
+    o.n_prev = -1;
+    o.t = fmin(1.0, 1.0 / bps[1]) * R.lr;
+  } else {
+    const double gd = bps[0], ys = bps[4], yyn = bps[5], gg = bps[6], ggp = bps[7];
+    o.accept = ys > 1e-10 ? 1 : 0;
+    double part = 0.0;
+    if (o.accept) {                               // lbd_iteration with m = 1: the recursion on the one pair
+      o.ys = ys;
+      o.yy = yyn;
+      o.rho0 = 1.0 / ys;
+      o.sg0 = R.t * gd;                           // s_new . g = t_prev (d . g)
+      o.yg0 = gg - ggp;                           // y_new . g = g . g - g_prev . g
+      o.h_diag = ys / yyn;
+      const double al0 = o.rho0 * o.sg0;
+      const double yq0 = o.yg0 - yyn * al0;
+      const double cc0 = al0 - o.rho0 * (o.h_diag * yq0);
+      o.cy = o.h_diag * al0;
+      o.cs = -cc0;
+      part = o.cy * o.yg0 + o.cs * o.sg0;
+      o.m = 1;
+    }
+    o.n_prev = o.m;
+    o.c0 = -o.h_diag;
+    o.gtd = -o.h_diag * gg + part;
+    o.t = R.lr;
+  }
+  if (o.gtd > -R.tol_change) {                    // no descent left: the direction is formed, no step, the loop ends
+    o.do_step = 0;
+    o.do_eval = 0;
+    o.active = 0;
+  } else {
+    o.do_step = 1;
+    o.do_eval = k != R.max_iter ? 1 : 0;
+    o.active = k != R.max_iter ? 1 : 0;
+  }
+  return o;
+}
+
+constexpr int kLbdLeanItems = 2;                  // 16-byte pieces per thread and trip of the lean direction kernel
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_lbd_pair_stats(LbdPtrs<T> p, int64_t n, double* __restrict__ part) {
-  const LbdState& S = *p.st;
-  if (!S.do_eval) return;
-  const bool have_prev = S.have_prev != 0;
-  const T* __restrict__ g = S.ls ? p.g4[S.g_eval] : p.gbuf[S.cur ^ 1];
-  {
-    const T* __restrict__ gp = have_prev ? (S.ls ? p.g4[S.g_cur] : p.gbuf[S.cur]) : g;
-    const T* __restrict__ d = have_prev ? p.d : g;
-    const T t = (T)S.t;
-    __shared__ double red[16];
-    __shared__ double mx[2][16];
-    double s[6] = {0, 0, 0, 0, 0, 0}, mg = 0, md = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-      const T gi = g[i], pi = gp[i], di = d[i];
-      const T yi = gi - pi;                     // (the pair itself is formed by k_lbd_lincomb_step if the decision accepts it)
-      const T si = t * di;
-      const double g64 = (double)gi, d64 = (double)di, ag = fabs(g64), ad = fabs(d64);
-      s[0] += g64 * d64;
-      s[1] += ag;
-      s[2] += (double)yi * (double)si;
-      s[3] += (double)yi * (double)yi;
-      s[4] += g64 * g64;
-      s[5] += g64 * (double)pi;
-      mg = ag > mg ? ag : mg;
-      md = ad > md ? ad : md;
-    }
+__global__ __launch_bounds__(256) void k_lbd_direction_lean(LbdPtrs<T> p, int k, T* __restrict__ xs, int64_t n,
+                                                            const double* __restrict__ rows, double scale) {
+  __shared__ LbdState R;
+  __shared__ double red9[4][9];
+  const int tid = threadIdx.x;
+  const bool writer = blockIdx.x == 0 && tid == 0;
+  lbd_load_state(R, p.st);
+  LbdState& N = *p.st_next;
+  if (!R.active) {                                // the step is over (or suspended): hand the record on unchanged
+    if (blockIdx.x == 0 && tid < (int)(sizeof(LbdState) / 8))
+      reinterpret_cast<double*>(&N)[tid] = reinterpret_cast<const double*>(&R)[tid];
+    return;
+  }
+  // the new gradient and x of this thread's first trip are requested BEFORE the rows are finished and the decisions taken: they
+  // do not depend on them (if the step ends here they were read for nothing), and their latency covers the head's
+  constexpr int W = 16 / sizeof(T);
+  typedef T VT __attribute__((ext_vector_type(W)));
+  const T* __restrict__ g = p.gbuf[R.cur ^ 1];
+  const T* __restrict__ gp = p.gbuf[R.cur];
+  T* __restrict__ out = p.d;
+  const int64_t nv = n / W;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  VT ng[kLbdLeanItems], nx[kLbdLeanItems];
+  auto request = [&](int64_t base) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double o1 = __shfl_xor(mg, off, 64), o2 = __shfl_xor(md, off, 64);
-      mg = o1 > mg ? o1 : mg;
-      md = o2 > md ? o2 : md;
-    }
-    if ((threadIdx.x & 63) == 0) {
-      mx[0][threadIdx.x >> 6] = mg;
-      mx[1][threadIdx.x >> 6] = md;
-    }
-    double tot[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) tot[c] = block_sum(s[c], red);
-    if (threadIdx.x == 0) {
-      double m0 = 0, m1 = 0;
-      for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) {
-        m0 = mx[0][w] > m0 ? mx[0][w] : m0;
-        m1 = mx[1][w] > m1 ? mx[1][w] : m1;
+    for (int e = 0; e < kLbdLeanItems; ++e) {
+      const int64_t i = base + e * stride;
+      if (i < nv) {
+        ng[e] = reinterpret_cast<const VT*>(g)[i];
+        nx[e] = reinterpret_cast<const VT*>(xs)[i];
       }
+    }
+  };
+  const int64_t base0 = (int64_t)blockIdx.x * blockDim.x + tid;
+  request(base0);
+  double bps[8], loss;
+  lbd_finish_rows(bps, loss, red9, rows, scale);
+  const LbdLean o = lbd_lean_decide(R, bps, loss, k);
+  if (blockIdx.x == 0) {
+    // the record of the next launches: a copy with this iteration's changes (one thread; everybody has read R long before any
+    // later kernel reads N)
+    __syncthreads();
+    if (tid < (int)(sizeof(LbdState) / 8)) reinterpret_cast<double*>(&N)[tid] = reinterpret_cast<const double*>(&R)[tid];
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (o.suspend) {
+    if (writer) {
+      N.suspended = 1;
+      N.resume_k = k;
+      N.active = 0;
+      N.do_lincomb = 0;
+      N.do_step = 0;
+      N.do_eval = 0;
+      p.board[0] = 0.0;
+    }
+    return;
+  }
+  if (writer) {
+    if (k == 1) N.first_loss = loss;
+    N.loss = loss;
+    N.evals = o.evals;
+    N.func_evals = R.func_evals + 1;
+  }
+  if (o.stop) {                                   // (the gradient just evaluated is dropped: prev_flat_grad stays gbuf[cur])
+    if (writer) {
+      N.active = 0;
+      N.do_lincomb = 0;
+      N.do_step = 0;
+      N.do_eval = 0;
+      p.board[0] = 0.0;
+    }
+    return;
+  }
+  const int hist = R.hist;
+  const int slot = R.seq0 % (hist + 1);           // (the memory is empty: the new pair is number seq0 of the ring)
+  if (writer) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) part[8 * blockIdx.x + c] = tot[c];
-      part[8 * blockIdx.x + 6] = m0;
-      part[8 * blockIdx.x + 7] = m1;
+    for (int c = 0; c < 8; ++c) N.b_ps[c] = bps[c];
+    N.b_loss = loss;
+    N.total_iters = o.total;
+    N.n_iter = k;
+    N.m = o.m;
+    if (o.total == 1) N.seq0 = 0;
+    N.h_diag = o.h_diag;
+    N.prev_loss = loss;
+    N.t = o.t;
+    N.gtd = o.gtd;
+    N.k_lin = 1 + 2 * o.m;
+    N.k_dot = 2 * o.m;
+    N.have_prev = 1;
+    N.n_prev = o.n_prev;
+    N.cur = o.cur;
+    N.pair_y = o.accept ? 1 : -1;
+    N.pair_s = o.accept ? 2 : -1;
+    N.t_pair = R.t;
+    N.do_lincomb = 1;
+    N.do_step = o.do_step;
+    N.do_eval = o.do_eval;
+    N.active = o.active;
+    N.d_implicit = o.accept ? 0 : 1;
+    N.c0_d = o.c0;
+    if (o.total > 1) {
+      N.pairs_accepted = R.pairs_accepted + o.accept;
+      N.pairs_rejected = R.pairs_rejected + (o.accept ? 0 : 1);
+    }
+    if (!o.active) p.board[0] = 0.0;
+    if (o.accept) {                               // what the full form finds when it takes over: Gram entries, products, lists
+      p.rho[0] = o.rho0;
+      p.sgp[0] = o.sg0;
+      p.ygp[0] = o.yg0;
+      p.sy[0] = o.ys;
+      p.yy[0] = o.yy;
+      p.dot_ptr[0] = p.ss_slot[slot];
+      p.dot_ptr[1] = p.ys_slot[slot];
+    }
+  }
+  // ---- d = c0 g (+ cy y + cs s of the pair just accepted, formed here and stored to its ring slot), x += t d: the float
+  // operations of k_lbd_lincomb_step over the list [g, y, s]
+  const bool acc = o.accept != 0, step = o.do_step != 0;
+  const T tp = (T)R.t, t = (T)o.t;
+  T* ysl = acc ? p.ys_slot[slot] : nullptr;
+  T* ssl = acc ? p.ss_slot[slot] : nullptr;
+  for (int64_t base = base0; base < nv; base += kLbdLeanItems * stride) {
+    VT gv[kLbdLeanItems], xv[kLbdLeanItems], pv[kLbdLeanItems], dv[kLbdLeanItems];
+#pragma unroll
+    for (int e = 0; e < kLbdLeanItems; ++e) {
+      gv[e] = ng[e];
+      xv[e] = nx[e];
+      const int64_t i = base + e * stride;
+      if (acc && i < nv) {
+        pv[e] = reinterpret_cast<const VT*>(gp)[i];
+        if (R.d_implicit) {
+#pragma unroll
+          for (int c = 0; c < W; ++c) dv[e][c] = (T)(R.c0_d * (double)pv[e][c]);
+        } else {
+          dv[e] = reinterpret_cast<const VT*>(out)[i];
+        }
+      }
+    }
+    if (base + kLbdLeanItems * stride < nv) request(base + kLbdLeanItems * stride);     // the next trip's, a trip ahead
+#pragma unroll
+    for (int e = 0; e < kLbdLeanItems; ++e) {
+      const int64_t i = base + e * stride;
+      if (i < nv) {
+        VT r;
+        if (acc) {
+          VT yv, sv;
+#pragma unroll
+          for (int c = 0; c < W; ++c) {
+            yv[c] = gv[e][c] - pv[e][c];
+            sv[c] = tp * dv[e][c];
+            double s = 0.0;
+            s += o.c0 * (double)gv[e][c];
+            s += o.cy * (double)yv[c];
+            s += o.cs * (double)sv[c];
+            r[c] = (T)s;
+          }
+          reinterpret_cast<VT*>(ysl)[i] = yv;
+          reinterpret_cast<VT*>(ssl)[i] = sv;
+        } else {
+#pragma unroll
+          for (int c = 0; c < W; ++c) {
+            double s = 0.0;
+            s += o.c0 * (double)gv[e][c];
+            r[c] = (T)s;
+          }
+        }
+        if (acc) reinterpret_cast<VT*>(out)[i] = r;     // (otherwise d stays implicit: LbdState::d_implicit)
+        if (step) {
+#pragma unroll
+          for (int c = 0; c < W; ++c) xv[e][c] = fma(t, r[c], xv[e][c]);
+          reinterpret_cast<VT*>(xs)[i] = xv[e];
+        }
+      }
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    for (int64_t e = nv * W; e < n; ++e) {
+      T ye = T(0), se = T(0);
+      if (acc) {
+        ye = g[e] - gp[e];
+        se = tp * (R.d_implicit ? (T)(R.c0_d * (double)gp[e]) : out[e]);
+        ysl[e] = ye;
+        ssl[e] = se;
+      }
+      double s = 0.0;
+      s += o.c0 * (double)g[e];
+      if (acc) {
+        s += o.cy * (double)ye;
+        s += o.cs * (double)se;
+      }
+      if (acc) out[e] = (T)s;
+      if (step) xs[e] = fma(t, (T)s, xs[e]);
     }
   }
 }
 
+// The products of the evaluated gradient g = gbuf[cur ^ 1] with the memory (ss then ys, the device-resident list): per-block
+// partial sums, finished by k_lbd_decide.  Full form only (the lean chain never has a memory to multiply with).
+constexpr int kLbdMaxVec = 2 * kLbdMaxHist;
 template <typename T>
 __global__ __launch_bounds__(256) void k_lbd_multi_dot(LbdPtrs<T> p, int64_t n, double* __restrict__ part_dot) {
   const LbdState& S = *p.st;
   const int kk = S.k_dot;
-  if (!(S.ls ? S.do_mdot : S.do_eval) || kk == 0) return;
-  const T* __restrict__ g = S.ls ? p.g4[S.g_md] : p.gbuf[S.cur ^ 1];
+  if (!S.active || kk == 0) return;
+  const T* __restrict__ g = p.gbuf[S.cur ^ 1];
   constexpr int W = 16 / sizeof(T);
   constexpr int Q = 8;
   typedef T VT __attribute__((ext_vector_type(W)));
@@ -638,22 +815,30 @@ __global__ __launch_bounds__(256) void k_lbd_multi_dot(LbdPtrs<T> p, int64_t n, 
     part_dot[(int64_t)j * gridDim.x + blockIdx.x] = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
 }
 
+// an implicit direction made explicit (the full form reads d from memory): d = (float)(c0_d (double)gbuf[cur])
+template <typename T>
+__global__ __launch_bounds__(256) void k_lbd_materialise_d(LbdPtrs<T> p, int64_t n) {
+  LbdState& S = *p.st;
+  if (!S.d_implicit) return;
+  const T* __restrict__ g = p.gbuf[S.cur];
+  const double c0 = S.c0_d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p.d[i] = (T)(c0 * (double)g[i]);
+}
+static __global__ void k_lbd_clear_implicit(LbdState* st) { st->d_implicit = 0; }
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 template <typename T>
 struct LbfgsDev {
   LbdState h{};                           // host mirror (valid after a step)
   int64_t n = 0;                          // elements of x
-  FastBuf st, dots, sgp, ygp, rho, sy, yy, coef, lin_ptr, dot_ptr, ys_slot, ss_slot, cand, part, mpart, loss_slot;
+  int par = 0;                            // which of the two state records is current
+  FastBuf st, sgp, ygp, rho, sy, yy, coef, lin_ptr, dot_ptr, ys_slot, ss_slot, rows, mpart;
   // the parameter-sized vectors (two gradients, the direction, the ring of curvature pairs) come from - and go back to - a pool
   // the plan keeps: an optimiser is created per L_BFGS call, and 2 (history + 1) + 3 hipMallocs of the parameter's size per call
   // would cost more than the step they serve
   std::vector<std::unique_ptr<FastBuf>> vecs;
   T* g0 = nullptr;
   T* g1 = nullptr;
-  T* g2 = nullptr;                        // (line search: two more gradients and the starting point)
-  T* g3 = nullptr;
-  T* x0 = nullptr;
-  FastBuf gtab;
   T* d = nullptr;
   std::vector<T*> pairs_y, pairs_s;       // host mirror of the slot tables (allocated so far)
   double* board_host = nullptr;          // pinned, device-mapped: owned here (a plan outlives many optimisers)
@@ -661,6 +846,7 @@ struct LbfgsDev {
   int64_t accepted_seen = 0;
   int time_objective = 0;                 // > 0: HIP events around every time_objective-th evaluation (benchmarks)
   std::vector<hipEvent_t> ev;             // 2 per evaluation of a step
+  int lean_launches = 0, full_launches = 0, suspensions = 0;   // diagnostics (tests: which form ran)
   LbfgsDev() = default;
   LbfgsDev(const LbfgsDev&) = delete;
   LbfgsDev& operator=(const LbfgsDev&) = delete;
@@ -669,10 +855,11 @@ struct LbfgsDev {
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
   }
 
+  LbdState* state(int which) const { return st.as<LbdState>() + which; }
   LbdPtrs<T> ptrs() const {
     LbdPtrs<T> p{};
-    p.st = st.as<LbdState>();
-    p.dots = dots.as<double>();
+    p.st = state(par);
+    p.st_next = state(par ^ 1);
     p.sgp = sgp.as<double>();
     p.ygp = ygp.as<double>();
     p.rho = rho.as<double>();
@@ -683,15 +870,8 @@ struct LbfgsDev {
     p.dot_ptr = dot_ptr.as<const T*>();
     p.ys_slot = ys_slot.as<T*>();
     p.ss_slot = ss_slot.as<T*>();
-    p.cand = cand.as<T*>();
     p.gbuf[0] = g0;
     p.gbuf[1] = g1;
-    p.g4[0] = g0;
-    p.g4[1] = g1;
-    p.g4[2] = g2;
-    p.g4[3] = g3;
-    p.g4_dev = gtab.as<T*>();
-    p.x0 = x0;
     p.d = d;
     p.board = board_dev;
     return p;
@@ -726,6 +906,7 @@ int lbd_create(P& pl, LbfgsDev<float>& L, int64_t n, const specinv_lbfgs_opts& o
   SI_CHECK(o.max_iter >= 1, SPECINV_EINVAL, "max_iter must be >= 1");
   const int hist = o.history_size;
   L.n = n;
+  L.par = 0;
   std::memset(&L.h, 0, sizeof(L.h));
   L.h.lr = o.lr;
   L.h.tol_grad = o.tolerance_grad;
@@ -735,9 +916,9 @@ int lbd_create(P& pl, LbfgsDev<float>& L, int64_t n, const specinv_lbfgs_opts& o
   L.h.hist = hist;
   L.h.h_diag = 1.0;
   L.h.n_prev = -1;
-  L.h.ls = o.line_search != 0 ? 1 : 0;
-  SI_TRY(L.st.reserve(sizeof(LbdState)));
-  SI_TRY(L.dots.reserve((size_t)2 * hist * sizeof(double)));
+  L.h.pair_y = -1;
+  L.h.pair_s = -1;
+  SI_TRY(L.st.reserve(2 * sizeof(LbdState)));
   SI_TRY(L.sgp.reserve((size_t)hist * sizeof(double)));
   SI_TRY(L.ygp.reserve((size_t)hist * sizeof(double)));
   SI_TRY(L.rho.reserve((size_t)hist * sizeof(double)));
@@ -748,31 +929,22 @@ int lbd_create(P& pl, LbfgsDev<float>& L, int64_t n, const specinv_lbfgs_opts& o
   SI_TRY(L.dot_ptr.reserve((size_t)2 * hist * sizeof(void*)));
   SI_TRY(L.ys_slot.reserve((size_t)(hist + 1) * sizeof(void*)));
   SI_TRY(L.ss_slot.reserve((size_t)(hist + 1) * sizeof(void*)));
-  SI_TRY(L.cand.reserve(2 * sizeof(void*)));
   SI_TRY(lbd_take(pl, L, &L.g0));
   SI_TRY(lbd_take(pl, L, &L.g1));
   SI_TRY(lbd_take(pl, L, &L.d));
-  if (L.h.ls) {
-    SI_TRY(lbd_take(pl, L, &L.g2));
-    SI_TRY(lbd_take(pl, L, &L.g3));
-    SI_TRY(lbd_take(pl, L, &L.x0));
-    SI_TRY(L.gtab.reserve(4 * sizeof(void*)));
-    float* tab[4] = {L.g0, L.g1, L.g2, L.g3};
-    SI_HIP(hipMemcpy(L.gtab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
-  }
-  SI_TRY(L.part.reserve((size_t)8 * 1024 * sizeof(double)));
+  SI_TRY(L.rows.reserve((size_t)fast::kObjRows * fast::kObjStatRow * sizeof(double)));
   SI_TRY(L.mpart.reserve((size_t)kLbdMaxVec * 1024 * sizeof(double)));
-  SI_TRY(L.loss_slot.reserve(sizeof(double)));
   SI_HIP(hipMemsetAsync(L.sy.p, 0, (size_t)hist * hist * sizeof(double), pl.stream));
   SI_HIP(hipMemsetAsync(L.yy.p, 0, (size_t)hist * hist * sizeof(double), pl.stream));
   SI_HIP(hipMemsetAsync(L.ys_slot.p, 0, (size_t)(hist + 1) * sizeof(void*), pl.stream));
   SI_HIP(hipMemsetAsync(L.ss_slot.p, 0, (size_t)(hist + 1) * sizeof(void*), pl.stream));
-  SI_HIP(hipMemcpyAsync(L.st.p, &L.h, sizeof(LbdState), hipMemcpyHostToDevice, pl.stream));
+  SI_HIP(hipMemcpyAsync(L.state(0), &L.h, sizeof(LbdState), hipMemcpyHostToDevice, pl.stream));
+  SI_HIP(hipMemcpyAsync(L.state(1), &L.h, sizeof(LbdState), hipMemcpyHostToDevice, pl.stream));
   {
     void* hp = nullptr;
     void* dp = nullptr;
-    // (coherent: the device's writes - "the step has ended", "slot s is decided" - are to be seen by the host while later kernels of
-    // the stream still run, not when the queue drains)
+    // (coherent: the device's write - "the step has ended" - is to be seen by the host while later kernels of the stream still
+    // run, not when the queue drains)
     SI_HIP(hipHostMalloc(&hp, kLbdBoard * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     L.board_host = static_cast<double*>(hp);
     std::memset(hp, 0, kLbdBoard * sizeof(double));
@@ -781,7 +953,7 @@ int lbd_create(P& pl, LbfgsDev<float>& L, int64_t n, const specinv_lbfgs_opts& o
   }
   L.time_objective = o.time_objective > 0 ? o.time_objective : 0;
   if (L.time_objective) {
-    L.ev.resize((size_t)2 * (L.h.ls ? 64 : o.max_iter));
+    L.ev.resize((size_t)2 * (2 * o.max_iter + 2));     // (a suspended chain's evaluations are launched twice: lean no-ops, then full)
     for (auto& e : L.ev) SI_HIP(hipEventCreate(&e));
   }
   SI_HIP(hipStreamSynchronize(pl.stream));
@@ -809,58 +981,92 @@ int lbd_grow(P& pl, LbfgsDev<float>& L, int iterations_ahead) {
   return SPECINV_OK;
 }
 
-// one optimizer.step: everything enqueued, one synchronisation at the end
+// one optimizer.step: everything enqueued, one synchronisation at the end (one more if a lean chain is suspended)
 template <typename P>
 int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* target, specinv_lbfgs_info* info) {
   SI_CHECK(x && target && info, SPECINV_EINVAL, "null pointer");
   SI_CHECK((int64_t)pl.B() * len == L.n, SPECINV_EINVAL, "signal size does not match the optimiser's parameter vector");
   SI_CHECK(((uintptr_t)x & 15) == 0, SPECINV_EINVAL, "x is not 16-byte aligned");
   SI_TRY(lbd_grow(pl, L, L.h.max_iter));
-  LbdPtrs<float> p = L.ptrs();
-  if (L.pairs_y.size() > 0 && L.h.total_iters == 0) {
-    // before the first decision the candidate slots are not set: point them at the first slot (unused until a pair exists)
-    void* c[2] = {L.pairs_y[0], L.pairs_s[0]};
-    SI_HIP(hipMemcpy(L.cand.p, c, sizeof(c), hipMemcpyHostToDevice));
-  }
   const int64_t n = L.n;
   const int nb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 256 * 8)));
   const int hist = L.h.hist;
+  const double scale = 1.0 / ((double)pl.B() * pl.Tn() * (pl.tf_kind == SPECINV_TF_MAG ? pl.n_freq : pl.tf_mels));
   L.board_host[0] = 1.0;
-  hipLaunchKernelGGL(k_lbd_begin, dim3(1), dim3(1), 0, pl.stream, p.st);
+  hipLaunchKernelGGL(k_lbd_begin, dim3(1), dim3(1), 0, pl.stream, L.state(L.par));
   SI_HIP(hipGetLastError());
-  fast::ObjCtl ctl{};
-  ctl.do_eval = &p.st->do_eval;
-  ctl.cur = &p.st->cur;
-  ctl.grad_alt = p.gbuf[1];
   int n_eval_launched = 0;
-  auto evaluate = [&]() -> int {
+  auto evaluate = [&]() -> int {                    // objective + epilogue on the record that is current NOW
+    LbdState* st = L.state(L.par);
+    fast::ObjCtl ctl{};
+    ctl.do_eval = &st->do_eval;
+    ctl.cur = &st->cur;
+    ctl.grad_alt = L.g1;
+    fast::ObjStatReq sr{};
+    sr.d = L.d;
+    sr.have = &st->have_prev;
+    sr.t_dev = &st->t;
+    sr.d_implicit = &st->d_implicit;
+    sr.c0_d = &st->c0_d;
+    sr.rows = L.rows.template as<double>();
     bool used = false;
-    const bool timed = L.time_objective > 0 && n_eval_launched % L.time_objective == 0;
+    const bool timed = L.time_objective > 0 && n_eval_launched % L.time_objective == 0 && (size_t)(2 * n_eval_launched + 1) < L.ev.size();
     if (timed) SI_HIP(hipEventRecord(L.ev[2 * n_eval_launched], pl.stream));
-    SI_TRY(tf_loss_grad_fused(pl, x, len, target, nullptr, p.gbuf[0], &used, L.loss_slot.template as<double>(), &ctl));
+    SI_TRY(tf_loss_grad_fused(pl, x, len, target, nullptr, L.g0, &used, nullptr, &ctl, &sr));
     SI_CHECK(used, SPECINV_EUNSUPPORTED, "the one-launch objective does not cover this configuration");
     if (timed) SI_HIP(hipEventRecord(L.ev[2 * n_eval_launched + 1], pl.stream));
     ++n_eval_launched;
-    hipLaunchKernelGGL((k_lbd_pair_stats<float>), dim3(nb), dim3(256), 0, pl.stream, p, n, L.part.template as<double>());
-    hipLaunchKernelGGL((k_lbd_multi_dot<float>), dim3(nb), dim3(256), 0, pl.stream, p, n, L.mpart.template as<double>());
-    SI_HIP(hipGetLastError());
     return SPECINV_OK;
   };
   SI_TRY(evaluate());
   const size_t lds = (size_t)hist * hist * sizeof(double);
   SI_HIP(hipFuncSetAttribute((const void*)k_lbd_decide<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t pieces = n / 4 + 1;
-  for (int k = 1; k <= L.h.max_iter; ++k) {
-    if (k > 1 && L.board_host[0] == 0.0) break;     // a peek at what the device has decided so far (may lag: only saves no-ops)
-    hipLaunchKernelGGL((k_lbd_decide<float>), dim3(1), dim3(256), lds, pl.stream, p, k, (const double*)L.part.template as<double>(), nb,
-                       (const double*)L.mpart.template as<double>(), (const double*)L.loss_slot.template as<double>());
-    hipLaunchKernelGGL((k_lbd_lincomb_step<float>), dim3((unsigned)ceil_div(pieces, 256)), dim3(256), 0, pl.stream, p, x, n);
-    SI_HIP(hipGetLastError());
-    if (k < L.h.max_iter) SI_TRY(evaluate());
+  const int lean_grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(pieces, 256 * kLbdLeanItems)));
+  const double* rows = L.rows.template as<double>();
+  bool lean = L.h.m == 0;                           // the memory as the host last saw it (a fresh optimiser: empty)
+  if (const char* e = getenv("SPECINV_LBFGS_LEAN")) {
+    if (e[0] == '0') lean = false;                  // (tests / A-B runs: the full form from the first iteration)
   }
-  // a step cut short by the peek leaves `active` set on the device only if the device had not stopped: it had (the peek read 0)
-  SI_HIP(hipMemcpyAsync(&L.h, L.st.p, sizeof(LbdState), hipMemcpyDeviceToHost, pl.stream));
-  SI_HIP(hipStreamSynchronize(pl.stream));
+  if (!lean && L.h.d_implicit) {                    // (only when the form is forced: a lean chain clears the flag before it hands over)
+    hipLaunchKernelGGL((k_lbd_materialise_d<float>), dim3(1024), dim3(256), 0, pl.stream, L.ptrs(), n);
+    hipLaunchKernelGGL(k_lbd_clear_implicit, dim3(1), dim3(1), 0, pl.stream, L.state(L.par));
+    SI_HIP(hipGetLastError());
+  }
+  int k = 1, k_first = 1;
+  for (;;) {
+    for (; k <= L.h.max_iter; ++k) {
+      if (k > k_first && L.board_host[0] == 0.0) break;   // a peek at what the device has decided so far (may lag: only saves no-ops)
+      LbdPtrs<float> p = L.ptrs();
+      if (lean) {
+        hipLaunchKernelGGL((k_lbd_direction_lean<float>), dim3(lean_grid), dim3(256), 0, pl.stream, p, k, x, n, rows, scale);
+        L.par ^= 1;
+        ++L.lean_launches;
+      } else {
+        hipLaunchKernelGGL((k_lbd_multi_dot<float>), dim3(nb), dim3(256), 0, pl.stream, p, n, L.mpart.template as<double>());
+        hipLaunchKernelGGL((k_lbd_decide<float>), dim3(1), dim3(256), lds, pl.stream, p, k, rows, scale,
+                           (const double*)L.mpart.template as<double>(), nb);
+        hipLaunchKernelGGL((k_lbd_lincomb_step<float>), dim3((unsigned)ceil_div(pieces, 256)), dim3(256), 0, pl.stream, p, x, n);
+        ++L.full_launches;
+      }
+      SI_HIP(hipGetLastError());
+      if (k < L.h.max_iter) SI_TRY(evaluate());
+    }
+    // a step cut short by the peek leaves `active` set on the device only if the device had not stopped: it had (the peek read 0)
+    SI_HIP(hipMemcpyAsync(&L.h, L.state(L.par), sizeof(LbdState), hipMemcpyDeviceToHost, pl.stream));
+    SI_HIP(hipStreamSynchronize(pl.stream));
+    if (!L.h.suspended) break;
+    // the lean chain met a memory to multiply with at iteration resume_k (whose evaluation is done: gradient, rows and record
+    // are as it left them - everything enqueued behind it ran as no-ops): the full form takes over from that decision
+    ++L.suspensions;
+    lean = false;
+    k = k_first = L.h.resume_k;
+    L.h.suspended = 0;
+    L.h.active = 1;
+    L.h.do_eval = 1;
+    SI_HIP(hipMemcpyAsync(L.state(L.par), &L.h, sizeof(LbdState), hipMemcpyHostToDevice, pl.stream));
+    L.board_host[0] = 1.0;
+  }
   L.accepted_seen = L.h.pairs_accepted;
   info->first_loss = L.h.first_loss;
   info->loss = L.h.loss;
@@ -874,8 +1080,13 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
   info->objective_launches = L.h.evals;
   info->objective_timed = 0;
   info->objective_ms = 0.0;
+  info->lean_iterations = L.lean_launches;
+  info->full_iterations = L.full_launches;
+  info->suspensions = L.suspensions;
+  info->reserved_ = 0;
   if (L.time_objective) {
     for (int i = 0; i < std::min(L.h.evals, n_eval_launched); i += L.time_objective) {   // (executed ones; gated launches are no-ops)
+      if ((size_t)(2 * i + 1) >= L.ev.size()) break;
       float ms = 0.0f;
       SI_HIP(hipEventElapsedTime(&ms, L.ev[2 * i], L.ev[2 * i + 1]));
       info->objective_ms += ms;

@@ -54,13 +54,10 @@ struct ObjArgs {
   // units [0, sp_rm) row weights, [sp_rm, sp_cm) row records, [sp_cm, sp_cw) column records, [sp_cw, sp_total) column weights;
   // tab holds the waves' lists of row quads
   int sp_rm, sp_cm, sp_cw, sp_total, sp_cmax, sp_rows;
-  // device-resident optimiser (lbfgs_dev.h): run only if *ctl_eval != 0; the gradient goes to (*ctl_cur ^ 1 ? grad_alt : grad), or -
-  // with the line search on the device, which keeps four gradients - to ctl_tab[*ctl_sel]
+  // device-resident optimiser (lbfgs_dev.h): run only if *ctl_eval != 0; the gradient goes to (*ctl_cur ^ 1 ? grad_alt : grad)
   const int* ctl_eval;
   const int* ctl_cur;
   float* grad_alt;
-  const int* ctl_sel;
-  float* const* ctl_tab;
 #if SPECINV_OBJ_STAMPS
   unsigned long long* stamps;   // [tiles][16]
 #endif
@@ -71,8 +68,44 @@ struct ObjCtl {
   const int* do_eval;
   const int* cur;
   float* grad_alt;
-  const int* sel;          // != nullptr: the gradient buffer is tab[*sel] (lbfgs_dev.h, line search)
-  float* const* tab;
+};
+
+// the statistics of the evaluated gradient: what the caller hands in, and where the figures go.  d / gp == nullptr: the gradient
+// itself stands in (d = g before the first iteration, lbfgs.py:_batch).  Device-resident optimiser: *have == 0 -> d = g_prev = g,
+// else d as given and g_prev = the gradient buffer this evaluation does NOT write; t = *t_dev.
+constexpr int kObjStatRow = 9;    // a row of the epilogue's tree: the eight + the squared-error sum
+constexpr int kObjRows = 256;     // rows the epilogue leaves (one per block of its grid)
+struct ObjStatReq {
+  const float* d = nullptr;       // direction (nullptr: d = g)
+  const float* gp = nullptr;      // previous gradient (nullptr: g_prev = g)
+  float t = 0.0f;
+  const int* have = nullptr;      // device-resident optimiser: see above
+  const double* t_dev = nullptr;
+  // ... whose direction may be IMPLICIT (lbfgs_dev.h, lean iterations): *d_implicit != 0 -> d = (float)(*c0_d * (double)g_prev), the
+  // float operations that formed it from the gradient it was formed from - nobody stores or reads d
+  const int* d_implicit = nullptr;
+  const double* c0_d = nullptr;
+  double* rows = nullptr;         // [kObjRows][kObjStatRow]: out
+};
+
+// Statistics of the gradient an evaluation produces (ObjStatReq): the sums k_lbfgs_pair_stats takes over g, g_prev, d - the same
+// float operations for y = g - g_prev and s = t d, products and sums in float64 - accumulated per thread by k_objective_epilogue,
+// whose pass over the seams becomes a pass over the whole gradient.
+struct ObjStatAcc {
+  double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  float mg = 0.0f, md = 0.0f;
+  __device__ __forceinline__ void add(float g, float gp, float d, float t) {
+    const float y = g - gp, sv = t * d;
+    const double g64 = (double)g;
+    s[0] += g64 * (double)d;
+    s[1] += fabs(g64);
+    s[2] += (double)y * (double)sv;
+    s[3] += (double)y * (double)y;
+    s[4] += g64 * g64;
+    s[5] += g64 * (double)gp;
+    mg = fmaxf(mg, fabsf(g));
+    md = fmaxf(md, fabsf(d));
+  }
 };
 
 // Layout of the block table (ints): the non-zero blocks are sorted by bin group, then mel group.

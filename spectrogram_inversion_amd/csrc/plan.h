@@ -70,7 +70,7 @@ struct PlanBase {
   virtual int transform_setup(int kind, const void* mel_fb, int n_mels) = 0;
   virtual int transform_forward(const void* x, int64_t len, void* v_out) = 0;
   virtual int transform_loss_grad(const void* x, int64_t len, const void* target, double* loss, void* grad,
-                                  double* loss_dev = nullptr) = 0;
+                                  double* loss_dev = nullptr, bool with_stats = false, const void* stat_d = nullptr) = 0;
   virtual int vec_dot(const void* a, const void* b, int64_t n, double* out) = 0;
   virtual int vec_axpy(double alpha, const void* x, void* y, int64_t n) = 0;
   virtual int vec_scale(double alpha, const void* x, void* y, int64_t n) = 0;

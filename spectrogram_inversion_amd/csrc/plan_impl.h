@@ -13,7 +13,6 @@
 #include "kernels_generic.h"
 #include "kernels_lbfgs.h"
 #include "lbfgs_dev.h"
-#include "lbfgs_dev_ls.h"
 #include "kernels_rtisi.h"
 #include "plan.h"
 
@@ -97,6 +96,7 @@ struct PlanT final : PlanBase {
   DevBuf tf_mel, tf_mel_tiled, tf_mel_tiled_t, tf_spec, tf_v;   // transform (L_BFGS) scratch
   DevBuf tf_mel_a, tf_mel_b, tf_obj_tab;   // non-zero filterbank blocks in MFMA operand order + block table (one-launch objective)
   int tf_obj_mt = 0;                    // its 16-row mel tiles (0: the objective runs as a kernel chain)
+  DevBuf tf_rows;                       // statistics of the objective's gradient: the epilogue's rows (objective_args.h)
   DevBuf tf_sp_blob, tf_sp_tab;         // a sparse filterbank in band form (objective_args.h: obj_build_sparse)
   fast::ObjSparseInfo tf_sp{};
   bool tf_sp_ok = false;
@@ -747,9 +747,10 @@ struct PlanT final : PlanBase {
   int transform_forward(const void* xin, int64_t len, void* v_out) override {
     return tf_forward(*this, static_cast<const T*>(xin), len, static_cast<T*>(v_out));
   }
-  int transform_loss_grad(const void* xin, int64_t len, const void* target, double* loss, void* grad, double* loss_dev) override {
+  int transform_loss_grad(const void* xin, int64_t len, const void* target, double* loss, void* grad, double* loss_dev,
+                          bool with_stats, const void* stat_d) override {
     return tf_loss_grad(*this, static_cast<const T*>(xin), len, static_cast<const T*>(target), loss,
-                        static_cast<T*>(grad), loss_dev);
+                        static_cast<T*>(grad), loss_dev, with_stats, static_cast<const T*>(stat_d));
   }
   int vec_dot(const void* a, const void* b, int64_t n, double* out) override {
     return lb_dot(*this, static_cast<const T*>(a), static_cast<const T*>(b), n, out);
@@ -847,8 +848,6 @@ struct PlanT final : PlanBase {
   int lbfgs_dev_step(int32_t handle, void* xs, int64_t len, const void* target, specinv_lbfgs_info* info) override {
     if constexpr (std::is_same<T, float>::value) {
       SI_CHECK(handle >= 0 && (size_t)handle < lbfgs_devs.size() && lbfgs_devs[handle], SPECINV_EINVAL, "bad optimiser handle");
-      if (lbfgs_devs[handle]->h.ls)
-        return lbd_step_ls(*this, *lbfgs_devs[handle], static_cast<float*>(xs), len, static_cast<const float*>(target), info);
       return lbd_step(*this, *lbfgs_devs[handle], static_cast<float*>(xs), len, static_cast<const float*>(target), info);
     } else {
       return fail(SPECINV_EUNSUPPORTED, "the device-resident optimiser is float32 only");

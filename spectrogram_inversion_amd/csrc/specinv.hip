@@ -363,6 +363,12 @@ int specinv_transform_loss_grad_dev(specinv_plan* plan, const void* x, int64_t l
   SI_CHECK(loss_dev, SPECINV_EINVAL, "loss_dev is NULL");
   return plan->impl->transform_loss_grad(x, length, target, nullptr, grad_out, loss_dev);
 }
+int specinv_transform_loss_grad_stats_dev(specinv_plan* plan, const void* x, int64_t length, const void* target, const void* d,
+                                          double* out5_dev, void* grad_out) {
+  ENTER(plan);
+  SI_CHECK(out5_dev, SPECINV_EINVAL, "out5_dev is NULL");
+  return plan->impl->transform_loss_grad(x, length, target, nullptr, grad_out, out5_dev, true, d);
+}
 int specinv_vec_dot(specinv_plan* plan, const void* a, const void* b, int64_t n, double* out_host) {
   ENTER(plan);
   return plan->impl->vec_dot(a, b, n, out_host);

@@ -430,8 +430,11 @@ class LBFGS:
         if self._board is None or self._board.numel() < 9 + 2 * self.history_size:
             self._board = ops.board(9 + 2 * self.history_size)
         bd = self._board
-        g = ops.eval_into(fg, x, bd, 0)
-        ops.stats_into(g, g if d is None else d, bd, 1)
+        if hasattr(fg, "dev_stats") and os.environ.get("SPECINV_LBFGS_FUSED_STATS", "1") != "0":
+            g = fg.dev_stats(x, d, bd.data_ptr())          # the statistics ride on the objective's own launches
+        else:
+            g = ops.eval_into(fg, x, bd, 0)
+            ops.stats_into(g, g if d is None else d, bd, 1)
         v = ops.read(bd, 5)
         return g, v[0], v[1], v[2], v[3], v[4]
 
@@ -579,8 +582,8 @@ class LBFGS:
 
     # ---- one optimizer.step with the decisions on the device: one host synchronisation per STEP -------------------
     def _device_ok(self, fg):
-        """The device-resident optimiser (csrc/lbfgs_dev.h, lbfgs_dev_ls.h) serves float32 parameters on the one-launch objective,
-        without a line search or with 'strong_wolfe', history_size <= 120.  Decided at the first step; an optimiser never changes paths afterwards (its state
+        """The device-resident optimiser (csrc/lbfgs_dev.h) serves float32 parameters on the one-launch objective, without a line
+        search, history_size <= 120.  Decided at the first step; an optimiser never changes paths afterwards (its state
         lives where its path keeps it)."""
         if self._dev is not None:
             return self._dev is not False
@@ -588,10 +591,10 @@ class LBFGS:
         obj = getattr(fg, "device_objective", None)
         if obj is None or not self.gram or os.environ.get("SPECINV_LBFGS_DEVICE", "1") == "0":
             return False
-        if self.line_search is not None and os.environ.get("SPECINV_LBFGS_DEVICE_WOLFE", "0") != "1":
-            # the line search driven from the host (_step_wolfe_packed) unless asked otherwise: the state machine on the device
-            # (csrc/lbfgs_dev_ls.h) retraces it decision for decision without a synchronisation per evaluation, but its gated launches
-            # cost what the read-backs did (C5 `wolfe` 47 M against 77 M evaluations*frames/s, `memory` 9.9 against 10.1)
+        if self.line_search is not None:
+            # strong Wolfe is driven from the host (_step_wolfe_packed: one read-back per evaluation).  Round 4 also built its state
+            # machine as a decision kernel; measured slower (47 M against 77 M evaluations*frames/s at C5: six gated launches per
+            # slot cost what the read-backs did) and removed in round 5
             return False
         plan, target, shape = obj
         x = self.x
@@ -601,7 +604,7 @@ class LBFGS:
         from . import _lib
         try:
             handle = plan.lbfgs_dev_create(x.numel(), self.lr, self.max_iter, self.max_eval, self.tol_grad, self.tol_change,
-                                           self.history_size, self.time_objective, self.line_search is not None)
+                                           self.history_size, self.time_objective)
         except (_lib.SpecinvError, NotImplementedError):
             return False
         self._dev = (plan, handle, target, shape)
@@ -642,6 +645,7 @@ class LBFGS:
         self.objective_ms += info.objective_ms
         self.objective_timed += info.objective_timed
         self.objective_launches += info.objective_launches
+        self.dev_iterations = (info.lean_iterations, info.full_iterations, info.suspensions)
         return info.first_loss
 
     def __del__(self):

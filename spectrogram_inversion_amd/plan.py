@@ -514,6 +514,18 @@ class Plan:
                                                             grad.data_ptr()))
         return grad
 
+    def transform_loss_grad_stats_dev(self, x: torch.Tensor, target: torch.Tensor, d, out_ptr: int) -> torch.Tensor:
+        """gradient now; {loss, g.d, sum|g|, max|g|, max|d|} left in device memory at `out_ptr` (d None: d = g)."""
+        self._sync_stream()
+        x = self._in(x, self.dtype)
+        target = self._in(target, self.dtype, (self.batch, self.n_out, self.n_frames))
+        grad = torch.empty_like(x)
+        if d is not None:
+            assert d.is_contiguous() and d.dtype == x.dtype and d.numel() == x.numel() and d.device == x.device
+        _lib.check(self.lib.specinv_transform_loss_grad_stats_dev(self._h, x.data_ptr(), x.shape[-1], target.data_ptr(),
+                                                                  d.data_ptr() if d is not None else None, out_ptr, grad.data_ptr()))
+        return grad
+
     def vec_multi_dot_dev(self, g, vecs, out_ptr: int):
         self._sync_stream()
         k = len(vecs)
@@ -544,11 +556,10 @@ class Plan:
 
     # ---- the device-resident optimiser (csrc/lbfgs_dev.h) --------------------------------------------------------------
     def lbfgs_dev_create(self, n: int, lr, max_iter, max_eval, tolerance_grad, tolerance_change, history_size,
-                         time_objective=False, line_search=False) -> int:
+                         time_objective=False) -> int:
         self._sync_stream()
         o = _lib.LbfgsOpts(float(lr), float(tolerance_grad), float(tolerance_change), int(max_iter),
-                           int(max_eval) if max_eval is not None else 0, int(history_size), int(time_objective),
-                           int(bool(line_search)))
+                           int(max_eval) if max_eval is not None else 0, int(history_size), int(time_objective))
         h = C.c_int32(-1)
         _lib.check(self.lib.specinv_lbfgs_dev_create(self._h, int(n), C.byref(o), C.byref(h)))
         return h.value

@@ -79,7 +79,13 @@ class DeviceTransform:
             """gradient now, loss left in device memory at `loss_ptr` (no host synchronisation)"""
             return plan.transform_loss_grad_dev(v.reshape(x2.shape), tgt, loss_ptr).reshape(v.shape)
 
+        def fg_dev_stats(v, d, out_ptr):
+            """gradient now; {loss, g.d, sum|g|, max|g|, max|d|} left in device memory at `out_ptr` (d None: d = g)"""
+            return plan.transform_loss_grad_stats_dev(v.reshape(x2.shape), tgt, None if d is None else d.reshape(x2.shape),
+                                                      out_ptr).reshape(v.shape)
+
         fg.dev = fg_dev
+        fg.dev_stats = fg_dev_stats
         # what the device-resident optimiser needs (lbfgs.py:_step_device): the plan that owns the objective, and its target
         fg.device_objective = (plan, tgt, tuple(x2.shape))
         return fwd, fg

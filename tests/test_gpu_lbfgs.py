@@ -625,7 +625,6 @@ def test_device_resident_optimiser_at_the_optimum_and_reuse(monkeypatch):
 # ---- strong Wolfe with one read-back per evaluation (lbfgs.py:_step_wolfe_packed) -------------------------------------------
 def _run_wolfe(monkeypatch, packed, tr, target, x0, steps, **kw):
     monkeypatch.setenv("SPECINV_LBFGS_PACKED", "1" if packed else "0")
-    monkeypatch.setenv("SPECINV_LBFGS_DEVICE_WOLFE", "0")         # (the line search driven from the host)
     x = x0.clone()
     _, fg = tr.bind(x, target)
     opt = LBFGS(x, device=dev(), line_search_fn="strong_wolfe", **kw)
@@ -665,43 +664,111 @@ def test_packed_wolfe_step_retraces_the_general_step(monkeypatch, kind, kw, step
     assert sa[-1][3] > 0 and la[-1] < 0.5 * la[0]                # pairs were accepted, the loss fell
 
 
-def _run_wolfe_device(monkeypatch, on_device, tr, target, x0, steps, **kw):
-    monkeypatch.setenv("SPECINV_LBFGS_PACKED", "1")
+@pytest.mark.parametrize("fused", [True, False])
+def test_packed_wolfe_with_and_without_fused_statistics(monkeypatch, fused):
+    """The trial points of the host-driven search take their statistics from the objective's own launches
+    (specinv_transform_loss_grad_stats_dev) or from a pass of their own (SPECINV_LBFGS_FUSED_STATS=0): the same counters, iterates
+    equal to the order of the float64 sums."""
+    tr, target, x0 = _device_problem("logmel")
+    monkeypatch.setenv("SPECINV_LBFGS_FUSED_STATS", "0")
+    la, sa = _run_wolfe(monkeypatch, True, tr, target, x0, 3)
+    monkeypatch.setenv("SPECINV_LBFGS_FUSED_STATS", "1" if fused else "0")
+    lb, sb = _run_wolfe(monkeypatch, True, tr, target, x0, 3)
+    for i, (a, b) in enumerate(zip(sa, sb)):
+        assert a[1:] == b[1:], (i, a[1:], b[1:])
+        assert rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()) < (1e-6 if a[5] <= 12 else 5e-3), i
+    np.testing.assert_allclose(lb, la, rtol=1e-6)
+
+
+# ---- the statistics of the gradient taken inside the objective's launches (kernels_objective.h: ObjArgs::st_*) -------------------
+@pytest.mark.parametrize("kind,n_fft,hop,frames,batch,kw", [
+    ("logmel", 2048, 512, 40, 2, {}),                                # seams between three tiles, reflect margins folded back
+    ("logmel", 2048, 512, 16, 1, {}),                                # ONE tile: no seam
+    ("logmel", 1024, 256, 70, 3, dict(pad_mode="constant")),         # margins dropped
+    ("logmel", 1024, 64, 80, 2, dict(pad_mode="circular")),          # a fold stretch that reaches into the second and third tile
+    ("logmel", 2048, 333, 37, 2, {}),                                # a hop that is no multiple of 4: scalar seams, scalar gather
+    ("logmel", 1024, 256, 33, 2, dict(center=False)),
+    ("mag", 1024, 256, 45, 2, dict(pad_mode="replicate")),
+    ("mag", 2048, 1024, 20, 2, {}),
+])
+@pytest.mark.parametrize("with_d", [True, False])
+def test_objective_statistics_ride_on_the_objective(monkeypatch, kind, n_fft, hop, frames, batch, kw, with_d):
+    """{loss, g.d, sum|g|, max|g|, max|d|} from the objective's own launches - every gradient sample counted once, where it becomes
+    final: by the epilogue's pass over the gradient, which finishes the seams on its way, or by the thread that folds a margin onto it - against the objective followed by k_lbfgs_stats' pass over g and d:
+    the same gradient bit for bit, the maxima exactly, the sums to the order of their float64 additions."""
+    monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    rng = np.random.default_rng(5)
+    win = torch.from_numpy(hann(n_fft))
+    if kind == "logmel":
+        tr = LogMelSTFT(torch.from_numpy(si.mel_filterbank(22050, n_fft, 80)).to(dev()), n_fft, hop_length=hop, window=win, **kw)
+    else:
+        tr = MagSTFT(n_fft, hop_length=hop, window=win, **kw)
+    length = (frames - 1) * hop + (0 if kw.get("center", True) else n_fft)
+    xs = torch.from_numpy((0.1 * rng.standard_normal((batch, length))).astype(np.float32)).to(dev())
+    x = torch.from_numpy((0.05 * rng.standard_normal((batch, length))).astype(np.float32)).to(dev())
+    d = torch.from_numpy(rng.standard_normal((batch, length)).astype(np.float32)).to(dev()) if with_d else None
+    _, fg = tr.bind(x, tr(xs))
+    opt = LBFGS(x.clone(), device=dev())
+    bd = opt.ops.board(9 + 2 * 100)
+    g1 = fg.dev_stats(x, d, bd.data_ptr())
+    got = np.array(opt.ops.read(bd, 5), dtype=np.float64).copy()
+    g2 = opt.ops.eval_into(fg, x, bd, 0)
+    opt.ops.stats_into(g2, g2 if d is None else d, bd, 1)
+    want = np.array(opt.ops.read(bd, 5), dtype=np.float64).copy()
+    assert torch.equal(g1, g2)
+    assert got[3] == want[3] and got[4] == want[4]                   # maxima
+    g64 = g1.double()
+    scale = float((g64.abs() * (g64 if d is None else d.double()).abs()).sum())
+    assert abs(got[0] - want[0]) <= 1e-12 * abs(want[0])             # loss
+    assert abs(got[1] - want[1]) <= 1e-12 * scale                    # g . d
+    assert abs(got[2] - want[2]) <= 1e-12 * want[2]                  # sum |g|
+
+
+# ---- the lean iteration (csrc/lbfgs_dev.h: three launches while the memory is empty) against the full form -----------------------
+@pytest.mark.parametrize("kind,kw,steps", [
+    ("logmel", dict(), 3),                                       # pairs are accepted: the first chain is suspended and resumed in the full form
+    ("mag", dict(max_iter=10), 3),
+    ("mag", dict(max_iter=20, tolerance_change=1e-4), 3),        # a tolerance that ends steps inside the lean chain
+    ("logmel", dict(max_iter=6, max_eval=4), 3),
+])
+def test_lean_iteration_retraces_the_full_form(monkeypatch, kind, kw, steps):
+    """`k_lbd_direction_lean` - every workgroup finishes the evaluation's rows, takes the iteration's decisions and forms its share
+    of the direction - against the full form from the first iteration on (SPECINV_LBFGS_LEAN=0: memory products, k_lbd_decide,
+    k_lbd_lincomb_step): the same counters after every step and the same iterates (the same float operations on the same sums;
+    the one accepted pair of a lean chain goes through the same scalar recursion)."""
+    tr, target, x0 = _device_problem(kind)
+    monkeypatch.setenv("SPECINV_LBFGS_LEAN", "0")
+    la, sa = _run_steps(monkeypatch, True, tr, target, x0, steps, **kw)
+    monkeypatch.setenv("SPECINV_LBFGS_LEAN", "1")
+    lb, sb = _run_steps(monkeypatch, True, tr, target, x0, steps, **kw)
+    for i, (a, b) in enumerate(zip(sa, sb)):
+        assert a[1:] == b[1:], (i, a[1:], b[1:])
+        assert rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()) < 1e-6, (i, rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()))
+    np.testing.assert_allclose(lb, la, rtol=1e-9)
+
+
+def test_lean_chain_is_suspended_once_and_resumed(monkeypatch):
+    """Which form ran: a fresh optimiser starts lean; the iteration after its first accepted pair suspends the chain and the step
+    continues in the full form (one extra synchronisation, once per optimisation); with every pair rejected - BASELINE C5's
+    tiny gradients - the chain stays lean for good."""
     monkeypatch.setenv("SPECINV_LBFGS_DEVICE", "1")
-    monkeypatch.setenv("SPECINV_LBFGS_DEVICE_WOLFE", "1" if on_device else "0")
+    tr, target, x0 = _device_problem("logmel")
     x = x0.clone()
     _, fg = tr.bind(x, target)
-    opt = LBFGS(x, device=dev(), line_search_fn="strong_wolfe", **kw)
-    losses, snaps = [], []
-    for _ in range(steps):
-        losses.append(opt.step(fg))
-        snaps.append((x.clone(), opt.total_iters, opt.func_evals, int(opt.pairs_accepted), int(opt.pairs_rejected), opt.history_len))
-    assert bool(opt._dev) == on_device
-    return losses, snaps
-
-
-@pytest.mark.parametrize("kind,kw,steps", [
-    ("logmel", dict(), 3),                                       # torch.optim.LBFGS defaults + strong Wolfe: max_iter 20, history 100
-    ("logmel", dict(max_iter=12, history_size=3), 3),            # the memory wraps; a slot per iteration for the memory products
-    ("mag", dict(max_iter=10), 3),
-    ("mag", dict(max_iter=20, max_eval=8), 3),                   # max_eval ends line searches early (max_ls = max_eval - evaluations)
-    ("mag", dict(max_iter=4, lr=8.0), 3),                        # a first step far too long: brackets, zooms, accepted points that are not the last trial
-    ("logmel", dict(max_iter=5, lr=0.05, tolerance_change=0), 2),   # a first step too short: the bracket phase walks outwards
-])
-def test_device_resident_wolfe_retraces_the_host_driven_search(monkeypatch, kind, kw, steps):
-    """`line_search_fn='strong_wolfe'` with the state machine of torch.optim.lbfgs._strong_wolfe in `k_lbd_decide_ls` - one host
-    synchronisation per `optimizer.step` - against the same search driven from the host with one read-back per evaluation
-    (`_step_wolfe_packed`, itself retraced against the general step and torch.optim.LBFGS): the same counters after every step,
-    losses and iterates equal to the rounding of the float64 sums."""
-    tr, target, x0 = _device_problem(kind)
-    la, sa = _run_wolfe_device(monkeypatch, False, tr, target, x0, steps, **kw)
-    lb, sb = _run_wolfe_device(monkeypatch, True, tr, target, x0, steps, **kw)
-    for i, (a, b) in enumerate(zip(sa, sb)):
-        assert a[1:] == b[1:], (i, a[1:], b[1:])                  # total_iters, func_evals, accepted, rejected, history
-        tol = 2e-4 if a[5] <= 12 else 5e-3
-        assert rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()) < tol, (i, a[5], rel_l2(b[0].cpu().numpy(), a[0].cpu().numpy()))
-    np.testing.assert_allclose(lb, la, rtol=1e-3)
-    assert la[-1] < la[0]
+    opt = LBFGS(x, device=dev())
+    opt.step(fg)
+    lean, full, susp = opt.dev_iterations
+    assert opt._dev and lean >= 2 and full >= 1 and susp == 1 and opt.pairs_accepted > 0
+    opt.step(fg)
+    assert opt.dev_iterations[0] == lean and opt.dev_iterations[2] == 1       # the memory is not empty: full form from the start
+    x = x0.clone()                                                         # steps of 1e-7: y.s never passes 1e-10
+    _, fg = tr.bind(x, target)
+    opt = LBFGS(x, device=dev(), lr=1e-7)
+    for _ in range(3):
+        opt.step(fg)
+    lean, full, susp = opt.dev_iterations
+    # (iterations ENQUEUED in each form: a step enqueues up to max_iter of them, what follows a break runs as no-ops)
+    assert lean >= opt.total_iters > 0 and full == 0 and susp == 0 and opt.pairs_accepted == 0 and opt.pairs_rejected > 0
 
 
 def test_l_bfgs_strong_wolfe_golden():
