@@ -201,9 +201,11 @@ struct FastState<float> {
       // Large enough problems keep the overlap-add on the chip (k_hop): a wave per chunk of frames, 8-wave workgroups,
       // one per CU (2048 wave slots).  A chunk must emit the n_fft - hop samples it shares with its predecessor with
       // its regular frames: at least (n_fft - 1) / hop + 1 frames.  n_fft 4096 does not fit (ring + scratch in LDS).
-      // (a wave walks >= 8 frames one after the other there: measured against k_semi + k_ola, it pays from ~16 k frames
-      // at n_fft 2048 - 0.126 vs 0.142 ms per iteration - and ~32 k frames at 1024 and 512)
-      long long hop_from = R >= 16 ? 16384 : 32768;
+      // (a wave walks >= 8 frames one after the other there: measured against k_semi + k_ola, it pays from ~12 k frames
+      // at n_fft 2048 and ~32 k frames at 1024 and 512)
+      // (round 5's sweep, n_fft 2048 / hop 333, T 300: B 48 = 14 400 frames 145 M against 128 M it*frames/s for k_semi + k_ola,
+      // B 32 = 9 600 frames 102 against 120: the crossover at n_fft 2048 is nearer 12 k; n_fft 1024 / hop 300 at 14 400: 260 vs 257)
+      long long hop_from = R >= 16 ? 12288 : 32768;
       if (const char* e = getenv("SPECINV_SMALL_FRAMES")) hop_from = atoll(e);          // (tests: 0 pins the chunked kernels)
       bool want_hop = R <= 16 && (long long)cfg.batch * cfg.n_frames >= hop_from && !small && cfg.hop_length >= 1 &&
                       cfg.hop_length <= cfg.n_fft && pad < length;
@@ -262,6 +264,28 @@ struct FastState<float> {
         best_nch = nch;
       }
     }
+    // The waves of a SIMD do not run at the same speed (begin_t: skewed chunks): where the skew applies - hop = n_fft/4 at n_fft
+    // 2048 (chunk pairs) and 1024 (chunk triples) - a chunk count that pairs / triples up is preferred when it costs at most 4 %
+    // more frame times than the best one (round 5: B 65 or 100 at T 1024 took 31 / 20 chunks and ran unskewed)
+    if (OV == 4 && (R == 16 || (SPECINV_R8_W3 && R == 8))) {
+      const int mult = R == 16 ? 2 : 3;
+      auto cost_of = [&](int nch) {
+        const long long waves = (long long)cfg.batch * nch;
+        const long long rounds = (waves + slots - 1) / slots;
+        const int longest = (cfg.n_frames + nch - 1) / nch;
+        return (double)rounds * (longest + 2.0) * (1.0 + 0.0015 * std::max(0, longest - 32));
+      };
+      if (best_nch % mult != 0) {
+        int pick = 0;
+        double pick_cost = 1e300;
+        for (int nch = std::max(mult, best_nch - mult); nch <= std::min(best_nch + mult, std::max(1, cfg.n_frames / floor_ch)); ++nch)
+          if (nch % mult == 0 && cost_of(nch) < pick_cost) {
+            pick = nch;
+            pick_cost = cost_of(nch);
+          }
+        if (pick > 0 && pick_cost <= 1.04 * best_cost) best_nch = pick;
+      }
+    }
     nchunks = best_nch;
     if (const char* e = getenv("SPECINV_FAST_CHUNK")) {
       const int v = atoi(e);
@@ -310,14 +334,26 @@ struct FastState<float> {
     // the launch shape this was measured on - the signal-form kernel at two waves per SIMD with exactly as many waves as the
     // chip has slots for them (BASELINE C2 per GPU: 2048).  SPECINV_TD_SKEW overrides (experiments; 0 switches it off).
     // Also tried: s_setprio by frame parity or by time slice so that the two waves take turns (-2...3 %, no better with the skew).
+    // Round 5: not only at the launch shape this was measured on.  With one 8-wave workgroup per CU (fused_wgw) waves i and i + 4
+    // of a workgroup share a SIMD whatever the number of workgroups or rounds, so the pairing holds for any launch that puts two
+    // waves on a SIMD (more waves than SIMDs); the skew scales with the chunk: a quarter of its frames (10 of 32 at C2), the
+    // shorter chunk keeping >= 8 (the floor of a chunk: its seams).
     skew = 0;
-    if (td && !semi && RR == 16 && n_waves == 2048 && (nchunks & 1) == 0 && pl.Tn() / nchunks >= 24) skew = SPECINV_TD_SKEW_DEFAULT;
-    // ... and the n_fft 1024 kernels (spectral state or signal form) at three waves per SIMD (12-wave workgroups, the hardware slot
-    // is the wave's index in the workgroup / 4, kernels_fused.h): chunk triples, the oldest wave the longest.  BASELINE C4's
-    // shard: 3072 waves.
-    if (!semi && RR == 8 && OV == 4 && !use_template && fused_wgw() == 12 && n_waves == 3072 && nchunks % 3 == 0 &&
-        pl.Tn() / nchunks >= 16)
-      skew = 0x10000 | (SPECINV_K4_SKEW1 << 8) | SPECINV_K4_SKEW2;
+    {
+      const int len_ch = pl.Tn() / std::max(1, nchunks);
+      if (td && !semi && RR == 16 && OV == 4 && n_waves > 1024 && (nchunks & 1) == 0 && len_ch >= 12) {
+        skew = n_waves == 2048 && len_ch == 32 ? SPECINV_TD_SKEW_DEFAULT : std::min((len_ch + 2) / 4, len_ch - 8);
+        if (skew < 2) skew = 0;
+      }
+      // ... and the n_fft 1024 kernels (spectral state or signal form) at three waves per SIMD (12-wave workgroups, the hardware
+      // slot is the wave's index in the workgroup / 4, kernels_fused.h): chunk triples, the oldest wave the longest.  BASELINE
+      // C4's shard: 3072 waves, chunks of 64 frames, begin shifts 4 / 6; other chunk lengths scale them.
+      if (!semi && RR == 8 && OV == 4 && !use_template && fused_wgw() == 12 && nchunks % 3 == 0 && len_ch >= 16) {
+        const int s1 = len_ch == 64 ? SPECINV_K4_SKEW1 : (SPECINV_K4_SKEW1 * len_ch + 32) / 64;
+        const int s2 = len_ch == 64 ? SPECINV_K4_SKEW2 : (SPECINV_K4_SKEW2 * len_ch + 32) / 64;
+        if ((s1 | s2) && len_ch - s2 >= 8 && len_ch + s2 - s1 >= 8) skew = 0x10000 | (s1 << 8) | s2;
+      }
+    }
     if (const char* e = getenv("SPECINV_K4_SKEW")) {          // "s1,s2" (experiments; "0,0" switches it off)
       int s1 = 0, s2 = 0;
       if (sscanf(e, "%d,%d", &s1, &s2) == 2 && !semi && fused_wgw() == 12 && nchunks % 3 == 0 && n_waves % 12 == 0 && s1 >= 0 && s2 >= 0 &&
@@ -538,7 +574,12 @@ struct FastState<float> {
   // slot is filled; fewer waves than slots: smaller workgroups reach more CUs
   int fused_wgw() const {
     if (const char* e = getenv("SPECINV_FUSED_WGW")) return atoi(e);           // (experiments)
-    if (SPECINV_R8_W3 && R == 8 && OV == 4 && !use_template && n_waves >= 3072) return 12;
+    if (SPECINV_R8_W3 && R == 8 && OV == 4 && !use_template) {
+      // three waves per SIMD: a 12-wave workgroup is a whole CU, and 8-wave workgroups do not pair up there (2 + 2 waves on a SIMD
+      // that holds 3: at 2048 ... 3071 waves every CU's second workgroup waited for the first - round 5's sweep, B 64 x T 300:
+      // 316 M against 400 M at B 48).  Below a full chip, 4-wave workgroups: three fit a CU.
+      return n_waves >= 3072 ? 12 : 4;
+    }
     // (the signal-form kernel at n_fft 2048 measured 2 % faster with two 4-wave workgroups per CU than with one 8-wave one:
     // C2 25.8 vs 26.3 ms per step on one box, three runs each - the opposite of k_fused4)
     // ... except when the chunks are skewed (begin_t): one 8-wave workgroup per CU makes the hardware slot of a wave its index in
