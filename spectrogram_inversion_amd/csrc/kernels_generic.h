@@ -31,7 +31,29 @@ struct FrameCfg {
   // 16384 (float32) / 8192 (float64) in 128 KiB.  Radices 2, 3, 4, 5, 7, 8 only (a larger prime factor keeps the two-buffer form).
   // A compile-time property of the kernel (template parameter IP); these fields only record the plan's choice.
   int inplace, maxb;
+  // Power-of-two n_fft (k_iter_pair_dr): decimation in frequency forward, decimation in time back, both in place with ONE barrier
+  // per stage - a butterfly reads and writes the same positions - the spectrum staying in digit-reversed order in between.
+  // Stage i (radix dr_radix[i] = 1 << dr_bits[i]) works on blocks of dr_m[i] * radix points; bin f sits at
+  // sum_i digit_i(f) * dr_m[i], digit_i the i-th least significant digit of f in the mixed radix dr_radix[0], dr_radix[1], ...
+  int dr_stages, dr_lg8;                             // stages; log2(n_fft / 8): the octant of the twiddle table (dr_tw)
+  int tw_lds;                                        // k_iter_pair: a copy of `tw` (n_fft entries) sits behind its LDS buffers
+  int dr_bits[kMaxStages], dr_shift[kMaxStages];     // log2 radix, log2 dr_m
 };
+
+// Padded LDS layout of the digit-reversed transform: one element of slack after every 32 - the strided accesses of the small-block
+// stages (thread j at j * radix + q) and of the bin update (consecutive bins sit n_fft / radix apart) then spread over all banks
+// (complex float64: 16 lanes per pass, the minimum; complex float32: 32)
+__device__ __host__ __forceinline__ int dr_phys(int p) { return p + (p >> 5); }
+template <typename T>
+__device__ __forceinline__ int dr_pos(const FrameCfg<T>& c, int f) {
+  int pos = 0;
+#pragma unroll 1
+  for (int i = 0; i < c.dr_stages; ++i) {
+    pos += (f & ((1 << c.dr_bits[i]) - 1)) << c.dr_shift[i];
+    f >>= c.dr_bits[i];
+  }
+  return pos;
+}
 
 // ---- signal access with torch.stft's centre padding (methods.py:241 -> F.pad) -----------
 template <typename T>
@@ -152,7 +174,7 @@ __device__ __forceinline__ int div_magic(int j, int d, unsigned magic) {
 
 template <typename T, int R, bool INV>
 __device__ __forceinline__ void fft_stage(const cplx<T>* __restrict__ a, cplx<T>* __restrict__ b, const FrameCfg<T>& c,
-                                          int s, int ns, int tid, int nthr) {
+                                          int s, int ns, int tid, int nthr, const cplx<T>* __restrict__ tw) {
   const int N = c.n_fft, nb = (unsigned)N / (unsigned)R, tws = c.tw_step[s];
   const unsigned magic = c.ns_magic[s];
   for (int j = tid; j < nb; j += nthr) {
@@ -164,12 +186,12 @@ __device__ __forceinline__ void fft_stage(const cplx<T>* __restrict__ a, cplx<T>
       const int kt = k * tws;                 // W_m^(k q) = tw[k q N/m], k q < m
 #pragma unroll
       for (int q = 1; q < R; ++q) {
-        cplx<T> w = c.tw[kt * q];
+        cplx<T> w = tw[kt * q];
         if (INV) w.y = -w.y;
         v[q] = cmul(v[q], w);
       }
     }
-    Butterfly<T, R, INV>::run(v, c.tw, N);
+    Butterfly<T, R, INV>::run(v, tw, N);
     const int base = blk * ns * R + k;
 #pragma unroll
     for (int r = 0; r < R; ++r) b[base + r * ns] = v[r];
@@ -179,7 +201,7 @@ __device__ __forceinline__ void fft_stage(const cplx<T>* __restrict__ a, cplx<T>
 // any radix: one output per thread, direct DFT_R
 template <typename T>
 __device__ inline void fft_stage_any(const cplx<T>* __restrict__ a, cplx<T>* __restrict__ b, const FrameCfg<T>& c, int R,
-                                     int s, int ns, bool inverse, int tid, int nthr) {
+                                     int s, int ns, bool inverse, int tid, int nthr, const cplx<T>* __restrict__ tw) {
   const int N = c.n_fft, m = ns * R, stride = N / R, twstep = c.tw_step[s];
   const unsigned magic_m = c.m_magic[s], magic_ns = c.ns_magic[s];
   for (int o = tid; o < N; o += nthr) {
@@ -193,7 +215,7 @@ __device__ inline void fft_stage_any(const cplx<T>* __restrict__ a, cplx<T>* __r
     int e = 0;
     for (int q = 0; q < R; ++q) {
       const cplx<T> v = a[j + q * stride];
-      cplx<T> w = c.tw[e * twstep];
+      cplx<T> w = tw[e * twstep];
       if (inverse) w.y = -w.y;
       accx += v.x * w.x - v.y * w.y;
       accy += v.x * w.y + v.y * w.x;
@@ -207,7 +229,8 @@ __device__ inline void fft_stage_any(const cplx<T>* __restrict__ a, cplx<T>* __r
 // One stage of the transform IN PLACE: every butterfly of the stage is read and computed, then - after a barrier - written to the
 // Stockham positions of the same buffer.  Thread `tid` owns butterflies tid, tid + nthr, ... (at most MB of them).
 template <typename T, int R, bool INV, int MB>
-__device__ __forceinline__ void fft_stage_inplace(cplx<T>* __restrict__ a, const FrameCfg<T>& c, int s, int ns, int tid, int nthr) {
+__device__ __forceinline__ void fft_stage_inplace(cplx<T>* __restrict__ a, const FrameCfg<T>& c, int s, int ns, int tid, int nthr,
+                                                  const cplx<T>* __restrict__ tw) {
   const int N = c.n_fft, nb = (unsigned)N / (unsigned)R, tws = c.tw_step[s];
   const unsigned magic = c.ns_magic[s];
   cplx<T> v[MB][R];
@@ -224,12 +247,12 @@ __device__ __forceinline__ void fft_stage_inplace(cplx<T>* __restrict__ a, const
         const int kt = k * tws;
 #pragma unroll
         for (int q = 1; q < R; ++q) {
-          cplx<T> w = c.tw[kt * q];
+          cplx<T> w = tw[kt * q];
           if (INV) w.y = -w.y;
           v[it][q] = cmul(v[it][q], w);
         }
       }
-      Butterfly<T, R, INV>::run(v[it], c.tw, N);
+      Butterfly<T, R, INV>::run(v[it], tw, N);
       base[it] = blk * ns * R + k;
     }
   }
@@ -257,17 +280,17 @@ inline int ip_butterflies_per_thread(int radix, bool f64) {          // (the sam
 }
 
 template <typename T, bool INV>
-__device__ inline void lds_fft_inplace(cplx<T>* a, const FrameCfg<T>& c, int tid, int nthr) {
+__device__ inline void lds_fft_inplace(cplx<T>* a, const FrameCfg<T>& c, int tid, int nthr, const cplx<T>* tw) {
   int ns = 1;
   for (int s = 0; s < c.n_stages; ++s) {
     const int R = c.radix[s];
     switch (R) {
-      case 2: fft_stage_inplace<T, 2, INV, IpMB<T, 2>::value>(a, c, s, ns, tid, nthr); break;
-      case 3: fft_stage_inplace<T, 3, INV, IpMB<T, 3>::value>(a, c, s, ns, tid, nthr); break;
-      case 4: fft_stage_inplace<T, 4, INV, IpMB<T, 4>::value>(a, c, s, ns, tid, nthr); break;
-      case 5: fft_stage_inplace<T, 5, INV, IpMB<T, 5>::value>(a, c, s, ns, tid, nthr); break;
-      case 7: fft_stage_inplace<T, 7, INV, IpMB<T, 7>::value>(a, c, s, ns, tid, nthr); break;
-      default: fft_stage_inplace<T, 8, INV, IpMB<T, 8>::value>(a, c, s, ns, tid, nthr); break;
+      case 2: fft_stage_inplace<T, 2, INV, IpMB<T, 2>::value>(a, c, s, ns, tid, nthr, tw); break;
+      case 3: fft_stage_inplace<T, 3, INV, IpMB<T, 3>::value>(a, c, s, ns, tid, nthr, tw); break;
+      case 4: fft_stage_inplace<T, 4, INV, IpMB<T, 4>::value>(a, c, s, ns, tid, nthr, tw); break;
+      case 5: fft_stage_inplace<T, 5, INV, IpMB<T, 5>::value>(a, c, s, ns, tid, nthr, tw); break;
+      case 7: fft_stage_inplace<T, 7, INV, IpMB<T, 7>::value>(a, c, s, ns, tid, nthr, tw); break;
+      default: fft_stage_inplace<T, 8, INV, IpMB<T, 8>::value>(a, c, s, ns, tid, nthr, tw); break;
     }
     __syncthreads();
     ns *= R;
@@ -275,18 +298,18 @@ __device__ inline void lds_fft_inplace(cplx<T>* a, const FrameCfg<T>& c, int tid
 }
 
 template <typename T, bool INV>
-__device__ inline void lds_fft_dir(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, int tid, int nthr) {
+__device__ inline void lds_fft_dir(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, int tid, int nthr, const cplx<T>* tw) {
   int ns = 1;
   for (int s = 0; s < c.n_stages; ++s) {
     const int R = c.radix[s];
     switch (R) {
-      case 2: fft_stage<T, 2, INV>(a, b, c, s, ns, tid, nthr); break;
-      case 3: fft_stage<T, 3, INV>(a, b, c, s, ns, tid, nthr); break;
-      case 4: fft_stage<T, 4, INV>(a, b, c, s, ns, tid, nthr); break;
-      case 5: fft_stage<T, 5, INV>(a, b, c, s, ns, tid, nthr); break;
-      case 7: fft_stage<T, 7, INV>(a, b, c, s, ns, tid, nthr); break;
-      case 8: fft_stage<T, 8, INV>(a, b, c, s, ns, tid, nthr); break;
-      default: fft_stage_any<T>(a, b, c, R, s, ns, INV, tid, nthr); break;
+      case 2: fft_stage<T, 2, INV>(a, b, c, s, ns, tid, nthr, tw); break;
+      case 3: fft_stage<T, 3, INV>(a, b, c, s, ns, tid, nthr, tw); break;
+      case 4: fft_stage<T, 4, INV>(a, b, c, s, ns, tid, nthr, tw); break;
+      case 5: fft_stage<T, 5, INV>(a, b, c, s, ns, tid, nthr, tw); break;
+      case 7: fft_stage<T, 7, INV>(a, b, c, s, ns, tid, nthr, tw); break;
+      case 8: fft_stage<T, 8, INV>(a, b, c, s, ns, tid, nthr, tw); break;
+      default: fft_stage_any<T>(a, b, c, R, s, ns, INV, tid, nthr, tw); break;
     }
     __syncthreads();
     cplx<T>* tmp = a;
@@ -300,17 +323,138 @@ __device__ inline void lds_fft_dir(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& 
 // carries the registers of one form only
 template <typename T, bool IP = false>
 __device__ inline void lds_fft(cplx<T>*& a, cplx<T>*& b, const FrameCfg<T>& c, bool inverse, int tid = -1,
-                               int nthr = 0) {
+                               int nthr = 0, const cplx<T>* tw = nullptr) {      // tw: the twiddle table to read (default: c.tw)
   if (tid < 0) {
     tid = threadIdx.x;
     nthr = blockDim.x;
   }
+  if (tw == nullptr) tw = c.tw;
   if constexpr (IP) {
-    if (inverse) lds_fft_inplace<T, true>(a, c, tid, nthr);
-    else lds_fft_inplace<T, false>(a, c, tid, nthr);
+    if (inverse) lds_fft_inplace<T, true>(a, c, tid, nthr, tw);
+    else lds_fft_inplace<T, false>(a, c, tid, nthr, tw);
   } else {
-    if (inverse) lds_fft_dir<T, true>(a, b, c, tid, nthr);
-    else lds_fft_dir<T, false>(a, b, c, tid, nthr);
+    if (inverse) lds_fft_dir<T, true>(a, b, c, tid, nthr, tw);
+    else lds_fft_dir<T, false>(a, b, c, tid, nthr, tw);
+  }
+}
+
+// ---- the digit-reversed in-place transform (power-of-two n_fft; FrameCfg::dr_*) -----------------------------------------------------
+// Twiddles of the digit-reversed transform from an OCTANT table in LDS: tab[j] = (cos, sin)(2 pi j / N), 0 <= j <= N / 8, the
+// other seven octants by swaps and signs.  (From the global table every stage waited an L2 round trip for its R - 1 twiddles:
+// float64 n_fft 2048 0.416 -> 0.355 ms per iteration with the loads stubbed out - round 5, tools/log/EXPERIMENTS.md.)
+template <typename T>
+__device__ __forceinline__ cplx<T> dr_tw(const cplx<T>* __restrict__ tab, int lg8, int i) {
+  const int n8 = 1 << lg8, o = i >> lg8, jp = i & (n8 - 1);
+  const cplx<T> t = tab[(o & 1) ? n8 - jp : jp];
+  const bool sw = ((o + 1) >> 1) & 1;                  // octants 1, 2, 5, 6: cosine and sine trade places
+  const T ca = sw ? t.y : t.x, sa = sw ? t.x : t.y;    // |cos|, |sin| of the angle
+  return mk<T>((((o + 2) >> 2) & 1) ? -ca : ca, (o >> 2) ? sa : -sa);     // exp(-i angle) = (cos, -sin)
+}
+// forward stage: v = DFT_R of the block's R points m apart, output r times W_L^(k r) (L = R m), written where it was read.  A
+// thread takes MB butterflies per trip, their reads all requested first (nothing else hides the LDS and twiddle latencies of a
+// workgroup that has one wave per SIMD).
+template <typename T, int R>
+struct DrMB {
+  // (float64: one - two radix-8 butterflies and their twiddles spill ~90 registers at four waves per SIMD, 0.42 -> 0.68 ms per
+  // iteration at n_fft 2048; float32: two)
+  static constexpr int value = sizeof(T) == 8 ? 1 : (R >= 8 ? 1 : 2);
+};
+template <typename T, int R>
+__device__ __forceinline__ void dr_stage_fwd(cplx<T>* __restrict__ a, const cplx<T>* __restrict__ tab, int lg8, const FrameCfg<T>& c, int lm) {
+  constexpr int MB = DrMB<T, R>::value;
+  const int N = c.n_fft, nb = N / R, m = 1 << lm, tws = N / (R * m);
+  for (int j0 = threadIdx.x; j0 < nb; j0 += MB * blockDim.x) {
+    cplx<T> v[MB][R], w[MB][R];
+    int base[MB];
+#pragma unroll
+    for (int it = 0; it < MB; ++it) {
+      const int j = j0 + it * blockDim.x;
+      base[it] = -1;
+      if (j < nb) {
+        const int blk = j >> lm, k = j & (m - 1);
+        base[it] = blk * (R * m) + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[it][q] = a[dr_phys(base[it] + q * m)];
+        if (m > 1) {
+          const int kt = k * tws;
+#pragma unroll
+          for (int r = 1; r < R; ++r) w[it][r] = dr_tw<T>(tab, lg8, kt * r);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < MB; ++it) {
+      if (base[it] >= 0) {
+        Butterfly<T, R, false>::run(v[it], c.tw, N);
+        if (m > 1) {
+#pragma unroll
+          for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], w[it][r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[dr_phys(base[it] + r * m)] = v[it][r];
+      }
+    }
+  }
+}
+// inverse stage: the adjoint - input q times conj W_L^(k q), inverse DFT_R, in place
+template <typename T, int R>
+__device__ __forceinline__ void dr_stage_inv(cplx<T>* __restrict__ a, const cplx<T>* __restrict__ tab, int lg8, const FrameCfg<T>& c, int lm) {
+  constexpr int MB = DrMB<T, R>::value;
+  const int N = c.n_fft, nb = N / R, m = 1 << lm, tws = N / (R * m);
+  for (int j0 = threadIdx.x; j0 < nb; j0 += MB * blockDim.x) {
+    cplx<T> v[MB][R], w[MB][R];
+    int base[MB];
+#pragma unroll
+    for (int it = 0; it < MB; ++it) {
+      const int j = j0 + it * blockDim.x;
+      base[it] = -1;
+      if (j < nb) {
+        const int blk = j >> lm, k = j & (m - 1);
+        base[it] = blk * (R * m) + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[it][q] = a[dr_phys(base[it] + q * m)];
+        if (m > 1) {
+          const int kt = k * tws;
+#pragma unroll
+          for (int q = 1; q < R; ++q) w[it][q] = dr_tw<T>(tab, lg8, kt * q);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < MB; ++it) {
+      if (base[it] >= 0) {
+        if (m > 1) {
+#pragma unroll
+          for (int q = 1; q < R; ++q) v[it][q] = cmul(v[it][q], conj(w[it][q]));
+        }
+        Butterfly<T, R, true>::run(v[it], c.tw, N);
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[dr_phys(base[it] + r * m)] = v[it][r];
+      }
+    }
+  }
+}
+// natural order in -> digit-reversed out / digit-reversed in -> natural out; every stage ends with the workgroup synchronised
+template <typename T>
+__device__ inline void dr_fft_fwd(cplx<T>* a, const cplx<T>* tab, int lg8, const FrameCfg<T>& c) {
+  for (int i = 0; i < c.dr_stages; ++i) {
+    switch (c.dr_bits[i]) {
+      case 1: dr_stage_fwd<T, 2>(a, tab, lg8, c, c.dr_shift[i]); break;
+      case 2: dr_stage_fwd<T, 4>(a, tab, lg8, c, c.dr_shift[i]); break;
+      default: dr_stage_fwd<T, 8>(a, tab, lg8, c, c.dr_shift[i]); break;
+    }
+    __syncthreads();
+  }
+}
+template <typename T>
+__device__ inline void dr_fft_inv(cplx<T>* a, const cplx<T>* tab, int lg8, const FrameCfg<T>& c) {
+  for (int i = c.dr_stages - 1; i >= 0; --i) {
+    switch (c.dr_bits[i]) {
+      case 1: dr_stage_inv<T, 2>(a, tab, lg8, c, c.dr_shift[i]); break;
+      case 2: dr_stage_inv<T, 4>(a, tab, lg8, c, c.dr_shift[i]); break;
+      default: dr_stage_inv<T, 8>(a, tab, lg8, c, c.dr_shift[i]); break;
+    }
+    __syncthreads();
   }
 }
 
@@ -472,6 +616,16 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
   __shared__ double red[16];
   cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
   cplx<T>* b = IP ? a : a + c.n_fft;     // (in place: a bin pair (f, N - f) is read and rewritten by one thread)
+  // Small transforms keep a copy of the twiddle table in LDS (FrameCfg::tw_lds): every stage otherwise waits an L2 round trip for
+  // its radix - 1 twiddles, with one wave per SIMD and nothing else to run (round 5: 15 - 20 % of an iteration).  The stages read
+  // it through a pointer handed down to them (a flat address into LDS; a modified copy of the argument record would live in
+  // scratch memory: 3 x slower); the first barrier of the frame load makes it visible.
+  const cplx<T>* twp = c.tw;
+  if (c.tw_lds) {
+    cplx<T>* twl = a + (IP ? 1 : 2) * c.n_fft;
+    for (int i = threadIdx.x; i < c.n_fft; i += blockDim.x) twl[i] = c.tw[i];
+    twp = twl;
+  }
   const int N = c.n_fft, F = c.n_freq;
   const int t0 = 2 * blockIdx.x, bi = blockIdx.y;
   const T* xr = x + (int64_t)bi * c.length;
@@ -508,7 +662,7 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
       for (int n = threadIdx.x; n < N; n += blockDim.x) a[n].y = T(0);
       __syncthreads();
     }
-    lds_fft<T, IP>(a, b, c, false);
+    lds_fft<T, IP>(a, b, c, false, -1, 0, twp);
     const int64_t base_a = ((int64_t)bi * c.n_frames + ta) * F, base_b = ((int64_t)bi * c.n_frames + tb) * F;
     const bool has_b = tb >= 0;
     if (c.onesided) {
@@ -565,13 +719,135 @@ __global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __r
       a = b;
       b = tmp;
     }
-    lds_fft<T, IP>(a, b, c, true);
+    lds_fft<T, IP>(a, b, c, true, -1, 0, twp);
     T* fa = frames + ((int64_t)bi * c.n_frames + ta) * N;
     T* fb = frames + ((int64_t)bi * c.n_frames + tb) * N;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
       const T w = c.window[n];
       fa[n] = (a[n].x * c.inv_scale) * w;
       if (has_b) fb[n] = (a[n].y * c.inv_scale) * w;
+    }
+    if (!split) break;
+    ta = t0 + 1;          // second pass: the other frame on its own
+    __syncthreads();      // everyone is done reading `a` before the next load overwrites it
+  }
+  if (EVAL) {
+    const double d = block_sum(s_d, red);
+    const double o = block_sum(s_o, red);
+    if (threadIdx.x == 0) {
+      const int64_t pi = (int64_t)bi * gridDim.x + blockIdx.x;
+      partials[2 * pi] = d;
+      partials[2 * pi + 1] = o;
+    }
+  }
+}
+
+// k_iter_pair on the digit-reversed in-place transform (power-of-two n_fft, any dtype / sidedness / padding): the same arithmetic
+// on the same values - a frame pair per complex transform, update_core per bin - with half the stage barriers of the in-place
+// Stockham form and LDS accesses that spread over the banks (round 4's counters on k_iter_pair<double>: 77 % of a wave's life at
+// stage barriers, SQ_LDS_BANK_CONFLICT 36 % of the LDS cycles).  Butterflies of radix 8 / 4 / 2; only their ORDER differs from the
+// Stockham kernel's, so results agree to rounding, not bit for bit.
+template <typename T, int MODE, bool EVAL>
+__global__ void k_iter_pair_dr(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ S0, cplx<T>* __restrict__ S1,
+                               const T* __restrict__ mag, T coef, T inv1p, T* __restrict__ frames, double* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double red[16];
+  cplx<T>* a = reinterpret_cast<cplx<T>*>(smem);
+  const int N = c.n_fft, F = c.n_freq;
+  // the octant twiddle table behind the frame buffer (dr_tw): N / 8 + 1 entries (cos, sin) from the plan's table of exp(-i angle);
+  // the load's barrier below makes it visible
+  cplx<T>* tab = a + dr_phys(N) + 1;
+  const int lg8 = c.dr_lg8;
+  for (int i = threadIdx.x; i <= N / 8; i += blockDim.x) {
+    const cplx<T> w = c.tw[i];
+    tab[i] = mk<T>(w.x, -w.y);
+  }
+  const int t0 = 2 * blockIdx.x, bi = blockIdx.y;
+  const T* xr = x + (int64_t)bi * c.length;
+  const T hs = T(0.5) * c.fwd_scale;
+  double s_d = 0, s_o = 0;
+  int ta = t0, tb = t0 + 1 < c.n_frames ? t0 + 1 : -1;
+  for (int pass = 0; pass < 2; ++pass) {
+    int bad = 0;
+    {
+      const int64_t sa = (int64_t)ta * c.hop - c.pad, sb = (int64_t)tb * c.hop - c.pad;
+      if (sa >= 0 && tb >= 0 && sb + N <= c.length) {          // both frames inside the signal: no padding tests
+        const T *pa = xr + sa, *pb = xr + sb;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+          const T w = c.window[n];
+          const T va = pa[n] * w, vb = pb[n] * w;
+          bad |= !__builtin_isfinite(va) || !__builtin_isfinite(vb);
+          a[dr_phys(n)] = mk<T>(va, vb);
+        }
+      } else {
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+          const T w = c.window[n];
+          const T va = load_padded(xr, c.length, sa + n, c.pad_mode) * w;
+          const T vb = tb >= 0 ? load_padded(xr, c.length, sb + n, c.pad_mode) * w : T(0);
+          bad |= !__builtin_isfinite(va) || !__builtin_isfinite(vb);
+          a[dr_phys(n)] = mk<T>(va, vb);
+        }
+      }
+    }
+    const bool split = __syncthreads_or(bad) && tb >= 0;   // (also the barrier after the load)
+    if (split) {                                           // a non-finite sample stays inside its own frame (k_iter_pair)
+      tb = -1;
+      for (int n = threadIdx.x; n < N; n += blockDim.x) a[dr_phys(n)].y = T(0);
+      __syncthreads();
+    }
+    dr_fft_fwd<T>(a, tab, lg8, c);
+    const int64_t base_a = ((int64_t)bi * c.n_frames + ta) * F, base_b = ((int64_t)bi * c.n_frames + tb) * F;
+    const bool has_b = tb >= 0;
+    const cplx<T> zero = mk<T>(T(0), T(0));
+    // one thread owns the bin pair (f, N - f) of both frames: it reads and rewrites their two positions
+    for (int f = threadIdx.x; f <= N / 2; f += blockDim.x) {
+      const int g = f ? N - f : 0;
+      const int pf = dr_phys(dr_pos(c, f)), pg = g == f ? pf : dr_phys(dr_pos(c, g));
+      const cplx<T> zf = a[pf], zg = a[pg];
+      const cplx<T> ra = mk<T>((zf.x + zg.x) * hs, (zf.y - zg.y) * hs);
+      const cplx<T> rb = mk<T>((zf.y + zg.y) * hs, (zg.x - zf.x) * hs);
+      if (c.onesided) {
+        cplx<T> n0, n1, hb = zero;
+        cplx<T> ha = update_core<T, MODE>(ra, mag[base_a + f], S0[base_a + f], MODE == 1 ? S1[base_a + f] : zero, coef, inv1p, EVAL,
+                                          s_d, s_o, n0, n1);
+        S0[base_a + f] = n0;
+        if (MODE == 1) S1[base_a + f] = n1;
+        if (has_b) {
+          hb = update_core<T, MODE>(rb, mag[base_b + f], S0[base_b + f], MODE == 1 ? S1[base_b + f] : zero, coef, inv1p, EVAL, s_d,
+                                    s_o, n0, n1);
+          S0[base_b + f] = n0;
+          if (MODE == 1) S1[base_b + f] = n1;
+        }
+        if (g == f) {
+          ha.y = T(0);
+          hb.y = T(0);
+        }
+        a[pf] = mk<T>(ha.x - hb.y, ha.y + hb.x);
+        if (g != f) a[pg] = mk<T>(ha.x + hb.y, hb.x - ha.y);
+      } else {
+        const cplx<T> yaf = update_one<T, MODE>(ra, S0, S1, mag, base_a + f, coef, inv1p, EVAL, s_d, s_o);
+        const cplx<T> ybf = has_b ? update_one<T, MODE>(rb, S0, S1, mag, base_b + f, coef, inv1p, EVAL, s_d, s_o) : zero;
+        cplx<T> yag = yaf, ybg = ybf;
+        if (g != f) {
+          yag = update_one<T, MODE>(conj(ra), S0, S1, mag, base_a + g, coef, inv1p, EVAL, s_d, s_o);
+          if (has_b) ybg = update_one<T, MODE>(conj(rb), S0, S1, mag, base_b + g, coef, inv1p, EVAL, s_d, s_o);
+        }
+        // Hermitian parts of the updated spectra at bin f
+        const cplx<T> ha = mk<T>(T(0.5) * (yaf.x + yag.x), T(0.5) * (yaf.y - yag.y));
+        const cplx<T> hb = mk<T>(T(0.5) * (ybf.x + ybg.x), T(0.5) * (ybf.y - ybg.y));
+        a[pf] = mk<T>(ha.x - hb.y, ha.y + hb.x);
+        if (g != f) a[pg] = mk<T>(ha.x + hb.y, hb.x - ha.y);
+      }
+    }
+    __syncthreads();
+    dr_fft_inv<T>(a, tab, lg8, c);
+    T* fa = frames + ((int64_t)bi * c.n_frames + ta) * N;
+    T* fb = frames + ((int64_t)bi * c.n_frames + tb) * N;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      const T w = c.window[n];
+      const cplx<T> v = a[dr_phys(n)];
+      fa[n] = (v.x * c.inv_scale) * w;
+      if (has_b) fb[n] = (v.y * c.inv_scale) * w;
     }
     if (!split) break;
     ta = t0 + 1;          // second pass: the other frame on its own

@@ -106,6 +106,10 @@ struct PlanT final : PlanBase {
   size_t lds_bytes2 = 0;       // two buffers (the kernels that keep the two-buffer transform)
   bool use_inplace = false;
   int ip_threads = 0, ip_maxb = 0;
+  bool tw_lds = false;         // k_iter_pair: the twiddle table copied to LDS (small n_fft)
+  bool use_dr = false;         // k_iter_pair_dr: the digit-reversed in-place transform (power-of-two n_fft)
+  size_t dr_lds = 0;
+  int dr_threads = 0;
   double sum_m2 = 0, count = 0;
   T coef = 0;  // lr (GLA) or rho (ADMM)
   FastState<T> fast;
@@ -210,18 +214,70 @@ struct PlanT final : PlanBase {
     lds_bytes = use_inplace ? lds_bytes2 / 2 : lds_bytes2;
     SI_CHECK(lds_bytes <= 160 * 1024 - 256, SPECINV_EUNSUPPORTED,
              "n_fft=%d needs %zu bytes of LDS per frame (limit 160 KiB)", n, lds_bytes);
-    if (lds_bytes > 48 * 1024) {
+    // small transforms: the iteration kernel keeps the twiddle table in LDS (kernels_generic.h: FrameCfg::tw_lds)
+    {
+      const char* e1 = getenv("SPECINV_GENERIC_TWLDS");            // (experiments: 0 never)
+      // (workgroups of four waves: with one-wave workgroups - n_fft 512 - LDS is what limits the workgroups per CU, and the table
+      // costs more occupancy than its latency saves: float64 512 two-sided 1.03 -> 1.26 ms per iteration; float32 1024 0.492 ->
+      // 0.448, float64 1000 0.259 -> 0.245)
+      tw_lds = (size_t)n * sizeof(C) <= 16 * 1024 && frame_threads() >= 256 && !(e1 && e1[0] == '0');
+    }
+    // Power-of-two n_fft: the iteration kernel on the digit-reversed in-place transform (kernels_generic.h: k_iter_pair_dr) -
+    // radix 8 stages, then 4 (or 4, 4; a lone 2): the small blocks last, where no twiddles are left
+    fc.dr_stages = 0;
+    use_dr = false;
+    if (n >= 8 && (n & (n - 1)) == 0) {
+      int e = 0;
+      while ((1 << e) < n) ++e;
+      std::vector<int> bits;
+      if (e % 3 == 0) bits.assign(e / 3, 3);
+      else if (e % 3 == 2) {
+        bits.assign(e / 3, 3);
+        bits.push_back(2);
+      } else {
+        bits.assign((e - 4) / 3, 3);
+        bits.push_back(2);
+        bits.push_back(2);
+      }
+      int left = e;
+      for (size_t i = 0; i < bits.size(); ++i) {
+        left -= bits[i];
+        fc.dr_bits[i] = bits[i];
+        fc.dr_shift[i] = left;                                    // log2 of n / (R_1 ... R_i)
+      }
+      fc.dr_stages = (int)bits.size();
+      fc.dr_lg8 = e - 3;
+      dr_lds = (size_t)(n + n / 32 + 2 + n / 8 + 1) * sizeof(C);   // padded frame buffer + octant twiddle table
+      {
+        // threads: n_fft / 4 up to 256 (the loads and the bin update like more threads than a radix-8 stage has butterflies);
+        // beyond that as many as keep a thread's butterflies per stage within two trips (kernels_generic.h: DrMB), at most 1024
+        const int per_trip = sizeof(T) == 8 ? 1 : 2;
+        dr_threads = std::min(256, std::max(64, n / 4 / 64 * 64));
+        while (dr_threads < 1024 && n / 8 > dr_threads * per_trip * 2) dr_threads *= 2;
+      }
+      if (const char* e2 = getenv("SPECINV_GENERIC_DR_THREADS")) dr_threads = std::max(64, std::min(1024, atoi(e2) / 64 * 64));
+      const char* dr_env = getenv("SPECINV_GENERIC_DR");          // (experiments / tests: 0 keeps the Stockham kernels)
+      // where it wins (round 5, tools/bench_generic_r05.py, one box): float64 n_fft 1024 / 2048 -10 ... -13 %, float32 n_fft 2048
+      // (two-sided) -32 %; float64 512 +-3 %, float64 4096 +12 %, float32 <= 1024 +2 ... +5 %, n_fft >= 8192 +2 ... +20 %: those
+      // keep the Stockham kernels (SPECINV_GENERIC_DR=1 forces this one wherever it fits)
+      const bool wins = sizeof(T) == 8 ? (n == 1024 || n == 2048) : n == 2048;
+      use_dr = dr_lds <= 160 * 1024 - 256 && !(dr_env && dr_env[0] == '0') && (wins || (dr_env && dr_env[0] == '1'));
+    }
+    if (std::max(lds_bytes, use_dr ? dr_lds : (size_t)0) > 48 * 1024) {
       // (the attribute belongs to the kernel, not to the plan: never lower what another plan has asked for)
       static std::atomic<int> lds_cap{0};
+      const int need = (int)std::max(lds_bytes, use_dr ? dr_lds : (size_t)0);
       int seen = lds_cap.load();
-      while (seen < (int)lds_bytes && !lds_cap.compare_exchange_weak(seen, (int)lds_bytes)) {}
-      const int lim = std::max(seen, (int)lds_bytes);
+      while (seen < need && !lds_cap.compare_exchange_weak(seen, need)) {}
+      const int lim = std::max(seen, need);
       const void* fns[] = {(const void*)k_stft<T, false>, (const void*)k_stft<T, true>, (const void*)k_grad_frames<T, false>,
                            (const void*)k_grad_frames<T, true>,
                            (const void*)k_iter_pair<T, 0, false, false>, (const void*)k_iter_pair<T, 0, true, false>,
                            (const void*)k_iter_pair<T, 1, false, false>, (const void*)k_iter_pair<T, 1, true, false>,
                            (const void*)k_iter_pair<T, 0, false, true>, (const void*)k_iter_pair<T, 0, true, true>,
-                           (const void*)k_iter_pair<T, 1, false, true>, (const void*)k_iter_pair<T, 1, true, true>};
+                           (const void*)k_iter_pair<T, 1, false, true>, (const void*)k_iter_pair<T, 1, true, true>,
+                           (const void*)k_iter_pair_dr<T, 0, false>, (const void*)k_iter_pair_dr<T, 0, true>,
+                           (const void*)k_iter_pair_dr<T, 1, false>, (const void*)k_iter_pair_dr<T, 1, true>};
       for (const void* fn : fns) SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     }
     SI_TRY(sums.reserve(16 * sizeof(double)));
@@ -235,7 +291,7 @@ struct PlanT final : PlanBase {
     if (fast_path()) {
       fast.geometry(out);
     } else {                                   // generic: one workgroup per frame pair
-      out[0] = frame_threads() / 64;
+      out[0] = (use_dr ? dr_threads : frame_threads()) / 64;
       out[1] = (Tn() + 1) / 2;
       out[2] = out[0] * out[1] * B();
       out[3] = 0;
@@ -260,6 +316,7 @@ struct PlanT final : PlanBase {
     c.length = len;
     c.inplace = use_inplace ? 1 : 0;
     c.maxb = use_inplace ? ip_maxb : 0;
+    c.tw_lds = 0;
     return c;
   }
 
@@ -510,15 +567,18 @@ struct PlanT final : PlanBase {
       const FrameCfg<T> fci = frame_cfg(length);
       for (int i = 0; i < n_iter; ++i) {
         const bool ev = eval_last && i == n_iter - 1;
-        const dim3 grid((Tn() + 1) / 2, B()), blk(frame_threads());   // two frames per complex FFT
+        const dim3 grid((Tn() + 1) / 2, B()), blk(use_dr ? dr_threads : frame_threads());   // two frames per complex FFT
         {
           const void* fn = nullptr;
           const int mode = method == Method::Gla ? 0 : 1;
-          if (use_inplace) fn = mode == 0 ? (ev ? (const void*)k_iter_pair<T, 0, true, true> : (const void*)k_iter_pair<T, 0, false, true>)
+          if (use_dr) fn = mode == 0 ? (ev ? (const void*)k_iter_pair_dr<T, 0, true> : (const void*)k_iter_pair_dr<T, 0, false>)
+                                     : (ev ? (const void*)k_iter_pair_dr<T, 1, true> : (const void*)k_iter_pair_dr<T, 1, false>);
+          else if (use_inplace) fn = mode == 0 ? (ev ? (const void*)k_iter_pair<T, 0, true, true> : (const void*)k_iter_pair<T, 0, false, true>)
                                           : (ev ? (const void*)k_iter_pair<T, 1, true, true> : (const void*)k_iter_pair<T, 1, false, true>);
           else fn = mode == 0 ? (ev ? (const void*)k_iter_pair<T, 0, true, false> : (const void*)k_iter_pair<T, 0, false, false>)
                               : (ev ? (const void*)k_iter_pair<T, 1, true, false> : (const void*)k_iter_pair<T, 1, false, false>);
           FrameCfg<T> ca = fci;
+          ca.tw_lds = (!use_dr && tw_lds) ? 1 : 0;
           const T* xa = x.as<T>();
           C* sa = specA.as<C>();
           C* sb = mode == 0 ? (C*)nullptr : specB.as<C>();
@@ -527,7 +587,7 @@ struct PlanT final : PlanBase {
           T* fra = frames.as<T>();
           double* pa = partials.as<double>();
           void* kargs[] = {&ca, &xa, &sa, &sb, &ma, &cf, &ip, &fra, &pa};
-          SI_HIP(hipLaunchKernel(fn, grid, blk, kargs, lds_bytes, stream));
+          SI_HIP(hipLaunchKernel(fn, grid, blk, kargs, use_dr ? dr_lds : lds_bytes + (tw_lds ? (size_t)N() * sizeof(C) : 0), stream));
         }
         SI_HIP(hipGetLastError());
         SI_TRY(launch_ola(frames.as<T>(), x.as<T>(), true));

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""ms per iteration of the coverage path (kernels_generic.h) on power-of-two n_fft: float32 / float64, one- and two-sided, Griffin-Lim
+and ADMM, with the HBM fraction of 8 hop + 20 F + 8 N elements per frame and iteration (ADMM: 36 F).  A/B of the iteration kernels
+through the environment: SPECINV_GENERIC_DR=0 keeps the Stockham kernels (k_iter_pair), default = the plan's choice."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from spectrogram_inversion_amd.plan import Plan, args_helper
+
+dev = torch.device("cuda", 0)
+CASES = [  # n_fft, win_length, hop, frames, batch, dtype, onesided, method
+    (2048, None, 512, 1024, 16, torch.float64, True, "gla"),
+    (2048, None, 512, 1024, 16, torch.float64, True, "admm"),
+    (4096, None, 1024, 512, 16, torch.float64, True, "gla"),
+    (1024, None, 256, 2048, 16, torch.float64, True, "gla"),
+    (512, None, 128, 2048, 32, torch.float64, True, "gla"),
+    (512, 300, 100, 2048, 64, torch.float64, False, "gla"),
+    (512, 300, 100, 2048, 64, torch.float32, False, "gla"),
+    (256, None, 64, 4096, 64, torch.float32, True, "gla"),
+    (1024, None, 256, 2048, 32, torch.float32, True, "gla"),
+    (2048, None, 512, 1024, 32, torch.float32, False, "gla"),
+    (8192, None, 2048, 256, 16, torch.float32, True, "gla"),
+    (16384, None, 4096, 128, 16, torch.float32, True, "gla"),
+    (8192, None, 2048, 128, 16, torch.float64, True, "gla"),
+]
+for n_fft, wl, hop, frames, batch, dtype, onesided, method in CASES:
+    F = n_fft // 2 + 1 if onesided else n_fft
+    w = torch.hann_window(wl or n_fft, dtype=dtype)
+    mag = torch.rand((batch, F, frames), dtype=dtype, device=dev)
+    kw = dict(hop_length=hop, window=w, onesided=onesided)
+    if wl:
+        kw["win_length"] = wl
+    plan = Plan(args_helper(mag, **kw), batch, frames, dtype, dev)
+    plan.force_generic(True)
+    (plan.gla_init if method == "gla" else plan.admm_init)(None, mag, 0.3 if method == "gla" else 0.1)
+    plan.iterate(3)
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        plan.iterate(20)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 20)
+    es = 4 if dtype == torch.float32 else 8
+    per_frame = (2 * hop + (5 if method == "gla" else 9) * F + 2 * n_fft) * es
+    gbs = per_frame * batch * frames / (best * 1e-3) / 1e9
+    print(f"{method:4s} n_fft {n_fft:5d} win {wl or n_fft:5d} hop {hop:5d} T {frames:5d} B {batch:3d} {str(dtype)[6:]:8s} onesided={onesided!s:5s} "
+          f"{best:8.3f} ms/it {batch * frames / best / 1e3:8.1f} M frames/s {100 * gbs / 8000:5.1f} % of 8 TB/s  wg {plan.launch_geometry['waves_per_workgroup']} waves",
+          flush=True)
+    del plan
