@@ -20,6 +20,12 @@
 #define SPECINV_RTISI_PK 0
 #endif
 
+#if SPECINV_IEEE
+#define RTISI_MSCALE a.inv_scale     // the target carries the inverse transform's scale (a power of two: exact)
+#else
+#define RTISI_MSCALE 1.0f
+#endif
+
 namespace specinv {
 namespace fast {
 
@@ -129,20 +135,34 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
 #pragma unroll
   for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = lds_tw1[(k1 - 1) * 64 + lane];
 
-  for (int i = a.i_begin; i < a.i_end; ++i) {
-    // target of this wave's frame for the whole outer step (zero outside the spectrogram: methods.py:339)
+  // target of this wave's frame at outer step i (zero outside the spectrogram: methods.py:339); requested a step ahead - the only
+  // global load of a step would otherwise sit, exposed, in front of its first inner iteration
+  v4f mnext[H / 2];
+  float mnext_mid = 0.0f;
+  auto request_target = [&](int i) {
     const int tt = i + q - la;
-    v4f mm[H / 2];
-    float mmid = 0.0f;
 #pragma unroll
-    for (int j = 0; j < H / 2; ++j) mm[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    if (tt >= 0 && tt < a.n_valid) {
+    for (int j = 0; j < H / 2; ++j) mnext[j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    mnext_mid = 0.0f;
+    if (i < a.i_end && tt >= 0 && tt < a.n_valid) {
       const long long mrow = f0 + (a.mag_ring ? tt % a.mag_ring : tt);
       const v4f* mp = a.m_pairs + mrow * (H / 2 * 64);
 #pragma unroll
-      for (int j = 0; j < H / 2; ++j) mm[j] = mp[j * 64u + ulane];
-      if (lane == 0) mmid = a.m_mid[mrow];
+      for (int j = 0; j < H / 2; ++j) mnext[j] = mp[j * 64u + ulane];
+      if (lane == 0) mnext_mid = a.m_mid[mrow];
     }
+  };
+  // (one wave per SIMD - look_ahead <= 3 - has the registers for it; the two-wave form at n_fft 2048 would spill: it loads where it
+  // needs them, as before)
+  constexpr bool kAhead = MAXT == 256;
+  if (kAhead) request_target(a.i_begin);
+  for (int i = a.i_begin; i < a.i_end; ++i) {
+    if (!kAhead) request_target(i);
+    v4f mm[H / 2];
+#pragma unroll
+    for (int j = 0; j < H / 2; ++j) mm[j] = mnext[j] * RTISI_MSCALE;
+    float mmid = mnext_mid * RTISI_MSCALE;
+    if (kAhead) request_target(i + 1);
 
     // ---- overlap-add (methods.py:365-370), the part that does not change during the inner iterations: the kept
     // frames (ring frames 0..K-1) that reach into this frame.  Frame kf covers hop-block qi of this frame with its own
@@ -221,8 +241,15 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         pre[j] = v4f{sk.x, sk.y, sm.x, sm.y};        // :392
         const float mk = (j & 1) ? mm[j / 2].z : mm[j / 2].x;
         const float mq = (j & 1) ? mm[j / 2].w : mm[j / 2].y;
+#if SPECINV_IEEE
+        // :394-396 in the reference's operation order, (s m) r with r the correctly rounded 1 / |s| (fast_core.h: ref_rcp_abs, as in
+        // the Griffin-Lim / ADMM kernels since round 4); the inverse transform's 1 / n_fft - a power of two - rides on m
+        const v2f rr = ref_rcp_abs2(v2f{ref_norm2(sk), ref_norm2(sm)});
+        const float ik = rr.x, im = rr.y;
+#else
         const float ik = __builtin_amdgcn_rcpf(fast_abs(sk) + 1e-16f) * a.inv_scale;   // :394-396
         const float im = __builtin_amdgcn_rcpf(fast_abs(sm) + 1e-16f) * a.inv_scale;
+#endif
         v2f ak = v2f{(sk.x * mk) * ik, (sk.y * mk) * ik};
         v2f am = v2f{(sm.x * mq) * im, (sm.y * mq) * im};
         if (j == 0 && lane == 0) {
@@ -240,7 +267,11 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         const v2f p = premid;
         const v2f s = v2f{fmaf(-lr, p.x, xmid.x), fmaf(-lr, p.y, xmid.y)};
         premid = s;
+#if SPECINV_IEEE
+        const float inv = ref_rcp_abs(ref_norm2(s));
+#else
         const float inv = __builtin_amdgcn_rcpf(fast_abs(s) + 1e-16f) * a.inv_scale;
+#endif
         zmid = v2f{(s.x * mmid) * inv, (s.y * mmid) * inv} * v2f{2.0f, -2.0f};
       }
 #pragma unroll

@@ -203,7 +203,7 @@ def test_c3_full_size_vs_oracle_prefix_and_generic(asym):
         ref64 = oracle.rtisi_la(mag_np[:1, :, :pre].astype(np.float64), look_ahead=la, asymmetric_window=asym, max_iter=its,
                                 alpha=alpha, hop_length=hop, window=hann(n_fft, np.float64))[0]
         noise = rel_l2(ref[:n], ref64[:n])
-        assert rel_l2(y[0, :n], ref64[:n]) < max(1e-4, 5 * noise), (rel_l2(y[0, :n], ref64[:n]), noise)
+        assert rel_l2(y[0, :n], ref64[:n]) < max(1e-4, 3 * noise), (rel_l2(y[0, :n], ref64[:n]), noise)
     else:
         # the zero-phase first frame makes two float32 runs decorrelate: equally consistent instead
         m60 = mag_np[0, :, :cmp_frames - 4]

@@ -35,7 +35,7 @@ def test_rtisi_golden(i):
     assert y.shape == ref.shape
     # asymmetric_window=False amplifies rounding noise (zero-phase first frame has an exactly real spectrum,
     # SURVEY 8c); gate at a multiple of the reference's own float32-vs-float64 difference
-    tol = max(5 * noise, 1e-5) if int(asym) else max(30 * noise, 2e-4)
+    tol = max(3 * noise, 1e-5) if int(asym) else max(30 * noise, 2e-4)
     assert rel_l2(y, ref) < tol, (g["meta"][i], rel_l2(y, ref), noise)
 
 
@@ -95,7 +95,9 @@ def test_rtisi_config3_shape_vs_oracle(asym, n_fft, la, ov):
         noise = rel_l2(ref, ref64)
         # (three float32 implementations - oracle, generic kernel, wave-level kernel - land between 1.7e-4 and 1.7e-3
         # of the float64 result at hop = n_fft/8 after three inner iterations while agreeing to 5e-5 after one)
-        assert rel_l2(y, ref64) < max(1e-4, 5 * noise), (rel_l2(y, ref64), noise)
+        # (round 5: 3 x the spread with the projection in the reference's operation order - 5 x before; hop = n_fft/8 with its
+        # seven look-ahead frames keeps 5 x: the case described above)
+        assert rel_l2(y, ref64) < max(1e-4, (5 if ov == 8 and la < 0 else 3) * noise), (rel_l2(y, ref64), noise)
         return
     # asymmetric_window=False: the waveform decorrelates between any two float32 implementations
     # (SURVEY 8c); the reconstructions must still be equally consistent with the target
