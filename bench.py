@@ -74,7 +74,7 @@ DOMINANT = {
     "C2": ("specinv::fast::k_fused4_td<16, false, false>", "valu"),
     "C4": ("specinv::fast::k_fused4<8, 1, false>", "hbm"),
     "C3": ("specinv::fast::k_rtisi_fast<16, 256, 4>", "latency"),
-    "C5": ("specinv::fast::k_objective_logmel<16, 9, false, true>", "valu"),
+    "C5": ("specinv::fast::k_objective_walk<16>", "valu"),
     "C1": ("specinv::fast::k_semi<8", "latency"),
 }
 PMC_PASSES = (

@@ -1072,7 +1072,9 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
                                                                    double* __restrict__ slot, int T, int nchunks, int n_fft, int hop,
                                                                    int keep, int pad, int pad_mode, int64_t len, int64_t rows,
                                                                    int64_t n_tail, int64_t n_margin, int n_part, double scale,
-                                                                   fast::ObjCtl ctl, fast::ObjStatReq st, int vec_ok) {
+                                                                   fast::ObjCtl ctl, fast::ObjStatReq st, int vec_ok, int skew) {
+  // (chunks of frames: k_objective_logmel's tiles - even, skew 0 - or k_objective_walk's, which may be skewed in pairs)
+  auto hop_chunk_begin_ = [&](int c_, int T_, int n_) { return fast::chunk_begin(c_, T_, n_, skew); };
   float* grad_other = ctl.grad_alt;
   if (ctl.do_eval != nullptr) {                  // device-resident optimiser: gate and gradient ping-pong (lbfgs_dev.h)
     if (*ctl.do_eval == 0) return;
@@ -1119,10 +1121,10 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
     int64_t f0 = (n + pad) / hop;
     if (f0 > T - 1) f0 = T - 1;
     int c = (int)(((f0 + 1) * nchunks - 1) / T);        // largest c with c * T / nchunks <= f0, up to rounding: corrected below
-    while (c + 1 < nchunks && fast::hop_chunk_begin(c + 1, T, nchunks) <= f0) ++c;
-    while (c > 0 && fast::hop_chunk_begin(c, T, nchunks) > f0) --c;
+    while (c + 1 < nchunks && hop_chunk_begin_(c + 1, T, nchunks) <= f0) ++c;
+    while (c > 0 && hop_chunk_begin_(c, T, nchunks) > f0) --c;
     if (c < 1) return -1;
-    const int64_t j0 = n + pad - (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop;
+    const int64_t j0 = n + pad - (int64_t)hop_chunk_begin_(c, T, nchunks) * hop;
     return (j0 >= 0 && j0 < keep) ? (b * nchunks + (c - 1)) * keep + j0 : -1;
   };
   if (st_on) {
@@ -1139,8 +1141,8 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
       for (int64_t pr = 2 * (int64_t)blockIdx.x + grp; pr < n_pairs; pr += 2 * (int64_t)gridDim.x) {
         const int64_t b = pr / nchunks;
         const int c = (int)(pr - b * nchunks);
-        const int64_t t_lo = (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop - pad;       // span[0] of tile c (may be < 0)
-        const int64_t t_hi = (int64_t)fast::hop_chunk_begin(c + 1, T, nchunks) * hop - pad;
+        const int64_t t_lo = (int64_t)hop_chunk_begin_(c, T, nchunks) * hop - pad;       // span[0] of tile c (may be < 0)
+        const int64_t t_hi = (int64_t)hop_chunk_begin_(c + 1, T, nchunks) * hop - pad;
         const int64_t n_lo = c == 0 ? 0 : (t_lo < 0 ? 0 : (t_lo > len ? len : t_lo));
         const int64_t n_hi = c == nchunks - 1 ? len : (t_hi < 0 ? 0 : (t_hi > len ? len : t_hi));
         // (offsets inside a tile are ints: pointers to the tile's first sample, the fold stretches as offsets too)
@@ -1213,7 +1215,7 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
     for (int64_t i = first; i < items; i += stride) {
       const int q = (int)(i / n4), j = 4 * (int)(i - (int64_t)q * n4);
       const int b = q / (nchunks - 1), c = q - b * (nchunks - 1) + 1;
-      const int64_t n = (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+      const int64_t n = (int64_t)hop_chunk_begin_(c, T, nchunks) * hop + j - pad;
       if (n < 0 || n >= len) continue;
       const fast::v4f tv = *reinterpret_cast<const fast::v4f*>(xtail + ((int64_t)b * nchunks + (c - 1)) * keep + j);
       float* gq = grad + (int64_t)b * len + n;
@@ -1234,7 +1236,7 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
       const int j = (int)(i % keep);
       const int c = (int)((i / keep) % (nchunks - 1)) + 1;
       const int64_t b = i / ((int64_t)keep * (nchunks - 1));
-      const int64_t n = (int64_t)fast::hop_chunk_begin(c, T, nchunks) * hop + j - pad;
+      const int64_t n = (int64_t)hop_chunk_begin_(c, T, nchunks) * hop + j - pad;
       if (n < 0 || n >= len) continue;
       if (fold && (n <= pad || n >= len - 1 - pad)) continue;             // finished by the margin thread of this sample
       grad[b * len + n] += xtail[(b * nchunks + (c - 1)) * keep + j];
@@ -1363,6 +1365,83 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), B = pl.B(), pad = pl.pad, R = pl.fast.xform_R;
   const int MT = mag ? 3 : sparse ? 9 : pl.tf_obj_mt;
   if (hop > N || hop < 2 || pad >= len) return SPECINV_OK;
+  // ---- the frame walk (kernels_objective_walk.h): hop = n_fft / 4, centred, a filterbank with at most two rows per bin
+  {
+    bool walk = !mag && pl.tf_walk_ok && 4 * hop == N && 2 * pad == N && len == (int64_t)(T - 1) * hop && T >= 8;
+    if (const char* e = getenv("SPECINV_OBJ_WALK")) {
+      if (e[0] == '0') walk = false;
+    }
+    if (const char* e = getenv("SPECINV_OBJ_SPARSE")) {     // (the matrix-core form was asked for)
+      if (e[0] == '0') walk = false;
+    }
+    if (walk) {
+      // chunks: one round of two waves per SIMD where the frames allow it (>= 8 frames per wave), an even count so that the two
+      // waves of a SIMD can take a long and a short chunk (the older wave runs faster: kernels_fast_td.h)
+      int nch = (int)std::max<int64_t>(1, std::min<int64_t>(T / 8, 2048 / std::max(1, B)));
+      if (nch > 1 && (nch & 1)) --nch;
+      if (const char* e = getenv("SPECINV_OBJ_WALK_CHUNKS")) nch = std::max(1, std::min(T / 4, atoi(e)));
+      const int len_ch = T / nch;
+      int skew = 0;
+      if ((nch & 1) == 0 && (int64_t)B * nch > 1024 && len_ch >= 8) skew = std::min(len_ch / 4, len_ch - 6);
+      if (const char* e = getenv("SPECINV_OBJ_WALK_SKEW")) skew = ((nch & 1) == 0 && len_ch - atoi(e) >= 4) ? std::max(0, atoi(e)) : 0;
+      const int keep = N - hop;
+      const int64_t n_waves = (int64_t)B * nch;
+      SI_TRY(pl.fast.hop_inv_tail.reserve((size_t)n_waves * keep * sizeof(float) + 16));
+      SI_TRY(pl.fast.hop_inv_margins.reserve((size_t)B * 2 * pad * sizeof(float)));
+      SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)n_waves, 3 * 1024) * sizeof(double)));
+      const double numel = (double)B * T * pl.tf_mels;
+      fast::ObjWalkArgs a{};
+      a.x = x;
+      a.grad = grad;
+      a.margins = pl.fast.hop_inv_margins.template as<float>();
+      a.xtail = pl.fast.hop_inv_tail.template as<float>();
+      a.target = target;
+      a.blob = pl.tf_walk_blob.template as<fast::f32x4>();
+      a.window = pl.window.template as<float>();
+      a.partials = pl.partials.template as<double>();
+      a.len = len;
+      a.T = T;
+      a.nchunks = nch;
+      a.n_waves = (int)n_waves;
+      a.skew = skew;
+      a.pad_mode = pl.cfg.pad_mode;
+      a.n_mels = pl.tf_mels;
+      a.fwd_scale = pl.fc.fwd_scale;
+      a.dscale = (float)(2.0 / numel);
+      a.w = pl.tf_walk;
+      if (ctl) {
+        a.ctl_eval = ctl->do_eval;
+        a.ctl_cur = ctl->cur;
+        a.grad_alt = ctl->grad_alt;
+      }
+      const void* fn = R == 16 ? (const void*)fast::k_objective_walk<16> : (const void*)fast::k_objective_walk<8>;
+      const size_t lds = R == 16 ? fast::obj_walk_lds_bytes<16>(pl.tf_walk.total) : fast::obj_walk_lds_bytes<8>(pl.tf_walk.total);
+      if (lds <= 160 * 1024 - 512) {
+        SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        void* kargs[] = {&a};
+        SI_HIP(hipLaunchKernel(fn, dim3((unsigned)ceil_div(n_waves, fast::kWalkWaves)), dim3(64 * fast::kWalkWaves), kargs, lds, pl.stream));
+        *used = true;
+        pl.objective_kind = 3;
+        const bool fold = pl.cfg.pad_mode != SPECINV_PAD_CONSTANT;
+        const int64_t n_tail = nch > 1 ? (int64_t)B * (nch - 1) * keep : 0;
+        const int64_t n_margin = fold ? (int64_t)B * 2 * (pad + 1) : 0;
+        const bool with_rows = st && st->rows;
+        const int blocks = fast::kObjRows + (with_rows ? 0 : 1);
+        double* slot = loss_dev ? loss_dev : pl.sums.template as<double>();
+        const int vec_ok = (len & 3) == 0 && ((uintptr_t)grad & 15) == 0 && (!ctl || ((uintptr_t)ctl->grad_alt & 15) == 0) &&
+                           (!with_rows || ((((uintptr_t)st->d | (uintptr_t)st->gp) & 15) == 0));
+        hipLaunchKernelGGL(k_objective_epilogue, dim3((unsigned)blocks), dim3(kObjEpiThreads), 0, pl.stream, grad, (const float*)a.xtail,
+                           (const float*)a.margins, (const double*)pl.partials.template as<double>(), slot, T, nch, N, hop, keep,
+                           pad, pl.cfg.pad_mode, (int64_t)len, (int64_t)B, n_tail, n_margin, (int)n_waves, 1.0 / numel,
+                           ctl ? *ctl : fast::ObjCtl{}, with_rows ? *st : fast::ObjStatReq{}, vec_ok, skew);
+        SI_HIP(hipGetLastError());
+        if (with_rows || loss_dev) return SPECINV_OK;
+        SI_HIP(hipMemcpyAsync(loss, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
+        SI_HIP(si_stream_wait_short(pl.stream));
+        return SPECINV_OK;
+      }
+    }
+  }
   const int nch = (T + fast::kObjTile - 1) / fast::kObjTile;
   if (nch > 1 && T / nch < (N - 1) / hop + 1) return SPECINV_OK;                // a seam must not reach a tile's own tail
   const int keep = N - hop;
@@ -1473,7 +1552,7 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     hipLaunchKernelGGL(k_objective_epilogue, dim3((unsigned)blocks), dim3(kObjEpiThreads), 0, pl.stream, grad, (const float*)a.xtail,
                        (const float*)a.margins, (const double*)pl.partials.template as<double>(), slot, T, nch, N, hop, keep,
                        pad, pl.cfg.pad_mode, (int64_t)len, (int64_t)B, n_tail, n_margin, (int)n_tiles, 1.0 / numel,
-                       ctl ? *ctl : fast::ObjCtl{}, with_rows ? *st : fast::ObjStatReq{}, vec_ok);
+                       ctl ? *ctl : fast::ObjCtl{}, with_rows ? *st : fast::ObjStatReq{}, vec_ok, 0);
     SI_HIP(hipGetLastError());
     if (with_rows) return SPECINV_OK;      // (loss and figures are in the rows: the caller finishes them)
   }
@@ -1526,6 +1605,7 @@ int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
       }
       // ... and its band form, when the filterbank is sparse enough (a mel filterbank is): k_objective_logmel<R, 9, false, true>
       pl.tf_sp_ok = false;
+      pl.tf_walk_ok = false;
       if (n_mels <= 16 * 9 && pl.cfg.onesided && pl.fast.xform_ok && (pl.fast.xform_R == 8 || pl.fast.xform_R == 16)) {
         std::vector<float> h_mel((size_t)n_mels * pl.n_freq), blob;
         std::vector<int> h_tab;
@@ -1541,12 +1621,23 @@ int tf_setup(P& pl, int kind, const T* mel_fb, int n_mels) {
           pl.tf_sp = inf;
           pl.tf_sp_ok = true;
         }
+        // ... and the tables of the frame walk (kernels_objective_walk.h)
+        pl.tf_walk_ok = false;
+        std::vector<float> wblob;
+        fast::ObjWalkInfo winf;
+        if (fast::obj_build_walk(h_mel.data(), pl.n_freq, n_mels, pl.fast.xform_R, wblob, winf)) {
+          SI_TRY(pl.tf_walk_blob.reserve(wblob.size() * sizeof(float)));
+          SI_HIP(hipMemcpy(pl.tf_walk_blob.p, wblob.data(), wblob.size() * sizeof(float), hipMemcpyHostToDevice));
+          pl.tf_walk = winf;
+          pl.tf_walk_ok = true;
+        }
       }
     }
   } else {
     pl.tf_mels = 0;
     pl.tf_obj_mt = 0;
     pl.tf_sp_ok = false;
+    pl.tf_walk_ok = false;
   }
   pl.tf_kind = kind;
   return SPECINV_OK;

@@ -317,5 +317,156 @@ inline bool obj_build_sparse(const float* mel, int F, int n_mels, int uni_floats
   return true;
 }
 
+
+// ---- the objective as a frame walk (kernels_objective_walk.h: k_objective_walk) ------------------------------------------------
+// The kernel of BASELINE configs[4] rebuilt in the Griffin-Lim kernel's form (round 5): a wave walks a chunk of consecutive frames
+// of one item - sample window carried in registers, analysis, the filterbank contractions on the frame's OWN spectrum, synthesis,
+// overlap-add in registers - and no workgroup barrier separates anything: while one wave of a SIMD contracts (LDS) the other
+// transforms (vector units).  The filterbank in two tables, both staged to LDS once per workgroup:
+//   forward   tasks: the band of row m (bin quads [q0, q0 + len) of the frame's |S| column) cut into 1, 2, 4, 8 or 16 segments of at
+//             most kObjWalkSeg quads, a lane per segment, the segments of a row in adjacent lanes (summed with xor shuffles);
+//             rows with equal segment counts share a pass of 64 lanes.  Task = {weights (16-byte units), first quad, quads, row |
+//             leader << 16}; pass p: tasks [64 p, 64 p + 64), log2(segments) in `pass_gs`.
+//   backward  in the lanes' own conjugate-pair order: for pair j of lane l (bins k = l + 64 j and M - k) the two weights of each
+//             bin (a mel filterbank meets a bin with at most two rows) and their first rows.
+constexpr int kObjWalkSeg = 4;          // quads per forward task
+constexpr int kObjWalkMaxPass = 16;
+struct ObjWalkInfo {
+  int rows = 0, n_pass = 0;
+  int task_off = 0, bw_off = 0, bm_off = 0, mid_off = 0, total = 0;   // offsets into the blob, in 16-byte units ([0, task_off): weights)
+  int pass_gs[kObjWalkMaxPass] = {};
+};
+struct ObjWalkArgs {
+  const float* x;          // (B, len), len = (T - 1) hop
+  float* grad;
+  float* margins;          // (B, 2, pad)
+  float* xtail;            // (B, nchunks, n_fft - hop)
+  const float* target;     // (B, n_mels, T)
+  const f32x4* blob;
+  const float* window;
+  double* partials;        // [n_waves] squared-error sums
+  long long len;
+  int T, nchunks, n_waves, skew, pad_mode, n_mels;
+  float fwd_scale, dscale;
+  ObjWalkInfo w;
+  const int* ctl_eval;     // device-resident optimiser: as ObjArgs
+  const int* ctl_cur;
+  float* grad_alt;
+};
+template <int R>
+__global__ void k_objective_walk(ObjWalkArgs a);
+constexpr int kWalkWaves = 8;     // waves per workgroup, one workgroup per CU (two waves per SIMD)
+constexpr int kWalkMM = 144;      // floats of a wave's mm / dM vector (rows <= 128, + 1 zero behind the last row)
+
+template <int R>
+constexpr size_t obj_walk_lds_bytes(int blob_units) {
+  return sizeof(v2f) * (size_t)(Geo<R>::M + (R - 1) * 64) + 16 * (size_t)blob_units +
+         (size_t)kWalkWaves * (sizeof(v2f) * Geo<R>::TR + sizeof(float) * kWalkMM);
+}
+
+
+// Host side: the two tables.  false: not a filterbank this kernel takes (more than two rows on a bin, rows that are not adjacent,
+// too many rows or passes) - the tile kernel serves it.
+inline bool obj_build_walk(const float* mel, int F, int n_mels, int R, std::vector<float>& blob, ObjWalkInfo& inf) {
+  const int M = 64 * R, H = R / 2, NBQ = (F + 3) / 4;
+  if (F != M + 1 || n_mels < 1 || n_mels > 128) return false;
+  auto at = [&](int m, int f) { return (m >= 0 && m < n_mels && f < F) ? mel[(size_t)m * F + f] : 0.0f; };
+  // rows of a bin: at most two, adjacent
+  std::vector<int> m0(F, 0);
+  for (int f = 0; f < F; ++f) {
+    int lo = -1, hi = -1;
+    for (int m = 0; m < n_mels; ++m)
+      if (mel[(size_t)m * F + f] != 0.0f) {
+        if (lo < 0) lo = m;
+        hi = m;
+      }
+    if (lo >= 0) {
+      if (hi - lo > 1) return false;
+      m0[f] = lo;
+    }
+  }
+  // forward tasks
+  struct Row { int m, q0, len, nseg; };
+  std::vector<Row> rows;
+  for (int m = 0; m < n_mels; ++m) {
+    int lo = -1, hi = -1;
+    for (int f = 0; f < F; ++f)
+      if (mel[(size_t)m * F + f] != 0.0f) {
+        if (lo < 0) lo = f;
+        hi = f;
+      }
+    Row r{m, 0, 0, 1};
+    if (lo >= 0) {
+      r.q0 = lo / 4;
+      r.len = hi / 4 - lo / 4 + 1;
+      int need = (r.len + kObjWalkSeg - 1) / kObjWalkSeg;
+      while (r.nseg < need && r.nseg < 16) r.nseg *= 2;
+    }
+    rows.push_back(r);
+  }
+  std::stable_sort(rows.begin(), rows.end(), [](const Row& x, const Row& y) { return x.nseg > y.nseg; });
+  std::vector<float> weights;
+  std::vector<int> tasks;          // 4 ints each
+  int n_pass = 0;
+  size_t i = 0;
+  while (i < rows.size()) {
+    const int nseg = rows[i].nseg, per = 64 / nseg;
+    if (n_pass == kObjWalkMaxPass) return false;
+    int gs = 0;
+    while ((1 << gs) < nseg) ++gs;
+    inf.pass_gs[n_pass] = gs;
+    int lane = 0;
+    for (int r = 0; r < per && i < rows.size() && rows[i].nseg == nseg; ++r, ++i) {
+      const Row& row = rows[i];
+      const int seglen = (row.len + nseg - 1) / nseg;
+      for (int sg = 0; sg < nseg; ++sg, ++lane) {
+        const int b = std::min(row.len, sg * seglen), e = std::min(row.len, (sg + 1) * seglen);
+        tasks.push_back((int)(weights.size() / 4));
+        tasks.push_back(row.q0 + b);
+        tasks.push_back(e - b);
+        tasks.push_back(row.m | (sg == 0 ? 0x10000 : 0));
+        for (int q = row.q0 + b; q < row.q0 + e; ++q)
+          for (int c = 0; c < 4; ++c) weights.push_back(at(row.m, 4 * q + c));
+      }
+    }
+    for (; lane < 64; ++lane) {          // idle lanes of the pass
+      tasks.push_back(0);
+      tasks.push_back(0);
+      tasks.push_back(0);
+      tasks.push_back(0x7fff);           // (no row: never a leader)
+    }
+    ++n_pass;
+  }
+  (void)NBQ;
+  inf.rows = n_mels;
+  inf.n_pass = n_pass;
+  inf.task_off = (int)(weights.size() / 4);
+  inf.bw_off = inf.task_off + n_pass * 64;
+  inf.bm_off = inf.bw_off + H * 64;
+  inf.mid_off = inf.bm_off + (H * 64 + 3) / 4;
+  inf.total = inf.mid_off + 2;
+  blob.assign((size_t)inf.total * 4, 0.0f);
+  std::copy(weights.begin(), weights.end(), blob.begin());
+  int* tk = reinterpret_cast<int*>(blob.data() + (size_t)inf.task_off * 4);
+  std::copy(tasks.begin(), tasks.end(), tk);
+  float* bw = blob.data() + (size_t)inf.bw_off * 4;
+  int* bm = reinterpret_cast<int*>(blob.data() + (size_t)inf.bm_off * 4);
+  for (int j = 0; j < H; ++j)
+    for (int l = 0; l < 64; ++l) {
+      const int k = l + 64 * j, kk = M - k;
+      float* w = bw + ((size_t)j * 64 + l) * 4;
+      w[0] = at(m0[k], k);
+      w[1] = at(m0[k] + 1, k);
+      w[2] = at(m0[kk], kk);
+      w[3] = at(m0[kk] + 1, kk);
+      bm[j * 64 + l] = m0[k] | (m0[kk] << 16);
+    }
+  float* md = blob.data() + (size_t)inf.mid_off * 4;
+  md[0] = at(m0[M / 2], M / 2);
+  md[1] = at(m0[M / 2] + 1, M / 2);
+  reinterpret_cast<int*>(md)[4] = m0[M / 2];
+  return true;
+}
+
 }  // namespace fast
 }  // namespace specinv

@@ -98,6 +98,9 @@ struct PlanT final : PlanBase {
   int tf_obj_mt = 0;                    // its 16-row mel tiles (0: the objective runs as a kernel chain)
   DevBuf tf_rows;                       // statistics of the objective's gradient: the epilogue's rows (objective_args.h)
   DevBuf tf_sp_blob, tf_sp_tab;         // a sparse filterbank in band form (objective_args.h: obj_build_sparse)
+  DevBuf tf_walk_blob;                  // ... and as the frame walk's tables (obj_build_walk)
+  fast::ObjWalkInfo tf_walk;
+  bool tf_walk_ok = false;
   fast::ObjSparseInfo tf_sp{};
   bool tf_sp_ok = false;
   std::vector<T> h_window;

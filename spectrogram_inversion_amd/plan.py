@@ -169,7 +169,7 @@ class Plan:
     def objective_kind(self) -> str:
         """How the last `transform_loss_grad` of this plan ran (`specinv_transform_objective_kind`): "chain" of kernels,
         one launch with the mel contractions on the "matrix" cores, one launch with the filterbank as "bands", or "none" yet."""
-        return {0: "chain", 1: "matrix", 2: "bands"}.get(self.lib.specinv_transform_objective_kind(self._h), "none")
+        return {0: "chain", 1: "matrix", 2: "bands", 3: "walk"}.get(self.lib.specinv_transform_objective_kind(self._h), "none")
 
     @property
     def launch_geometry(self) -> dict:

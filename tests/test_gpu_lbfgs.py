@@ -259,6 +259,9 @@ def test_gram_direction_follows_the_two_loop_recursion(history):
     (2048, 512, 24, 2, 128, {}),                                  # 8 mel tiles at n_fft 2048
     (1024, 256, 40, 2, 20, dict(normalized=True)),                # padded mel tile, ortho scaling
     (2048, 512, 20, 2, 80, dict(center=False)),                   # no padding: signal of (T-1) hop + n_fft samples
+    (2048, 512, 100, 24, 80, {}),                                 # the frame walk on 288 chunks of 8 / 9 frames, skewed pairs
+    (1024, 256, 259, 5, 64, dict(pad_mode="replicate")),          # ... chunks of 8 ... 9 frames at n_fft 1024, an odd frame count
+    (2048, 512, 9, 1, 80, {}),                                    # ... ONE chunk
 ])
 def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frames, batch, n_mels, kw):
     """`specinv_transform_loss_grad` for the log-mel transform as ONE kernel (spectrum kept on the chip) - the filterbank as bands on
@@ -272,15 +275,18 @@ def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frame
     xs = (0.1 * rng.standard_normal((batch, length))).astype(np.float32)
     x0 = (0.05 * rng.standard_normal((batch, length))).astype(np.float32)
     out = {}
-    for mode in ("bands", "matrix", "chain"):
+    # the frame walk (kernels_objective_walk.h) serves hop = n_fft / 4, centred; where it does not apply the default is the band form
+    walks = 4 * hop == n_fft and center and n_mels <= 128
+    for mode in ("walk", "bands", "matrix", "chain"):
         monkeypatch.setenv("SPECINV_DISABLE_FUSED_OBJECTIVE", "1" if mode == "chain" else "0")
         monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "0" if mode == "chain" else "1")
         monkeypatch.setenv("SPECINV_OBJ_SPARSE", "0" if mode == "matrix" else "1")
+        monkeypatch.setenv("SPECINV_OBJ_WALK", "1" if mode == "walk" else "0")
         tr = LogMelSTFT(T(fb), n_fft, hop_length=hop, window=torch.from_numpy(w), **kw)
         target = tr(T(xs))
         _, fg = tr.bind(T(x0), target)
         loss, grad = fg(T(x0))
-        assert fg.device_objective[0].objective_kind == mode
+        assert fg.device_objective[0].objective_kind == (mode if mode != "walk" or walks else "bands")
         loss2, grad2 = fg(T(x0))
         assert loss == loss2 and torch.equal(grad, grad2)           # fixed summation order: bitwise reproducible
         out[mode] = (loss, N(grad), N(target))
@@ -288,7 +294,7 @@ def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frame
     ref = LogMelStft(a, fb.astype(np.float64))
     lo, go = ref.loss_grad(x0.astype(np.float64), ref.forward(xs.astype(np.float64)))
     lc, gc, tc = out["chain"]
-    for mode in ("bands", "matrix"):
+    for mode in ("walk", "bands", "matrix"):
         lf, gf, tf = out[mode]
         assert np.array_equal(tf, tc)
         assert abs(lf - lc) < 2e-6 * abs(lc), (mode, lf, lc)
@@ -372,6 +378,7 @@ def test_one_launch_objective_with_a_banded_matrix(monkeypatch, n_fft, hop, rows
     kernel has the two forms 'two rows per bin' and 'four', shorter columns padded with zero weights), five stay on the matrix
     cores.  Against the float64 oracle."""
     monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    monkeypatch.setenv("SPECINV_OBJ_WALK", "0")                  # (the tile kernel's band forms are what this test is about)
     rng = np.random.default_rng(rows + per_bin)
     F, frames, batch = n_fft // 2 + 1, 37, 2
     fb = np.zeros((rows, F), np.float32)
@@ -407,6 +414,7 @@ def test_one_launch_objective_with_a_dense_matrix(monkeypatch, n_mels):
     single = np.zeros_like(dense)
     single[n_mels - 1, 300] = 0.5
     monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "1")
+    monkeypatch.setenv("SPECINV_OBJ_WALK", "0")
     for fb in (dense, single, np.zeros_like(dense)):
         tr = LogMelSTFT(T(fb), n_fft, hop_length=hop, window=torch.from_numpy(w))
         _, fg = tr.bind(T(x0), tr(T(xs)))
