@@ -1043,12 +1043,18 @@ __device__ inline void block_reduce9(double (&v)[9], double (*red)[9]) {       /
     for (int i = 0; i < 9; ++i) red[wave][i] = v[i];
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
+  // (nine threads add the waves' rows and publish the totals: every thread walking all rows cost 144 LDS reads each - 4 us of a
+  // 1024-thread workgroup)
+  const int nw = (int)(blockDim.x >> 6);
+  if (threadIdx.x < 9) {
+    const int i = threadIdx.x;
     double t = red[0][i];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = i < 7 ? t + red[w][i] : fmax(t, red[w][i]);
-    v[i] = t;
+    for (int w = 1; w < nw; ++w) t = i < 7 ? t + red[w][i] : fmax(t, red[w][i]);
+    red[0][i] = t;
   }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[i] = red[0][i];
   __syncthreads();
 }
 
@@ -1066,6 +1072,12 @@ __device__ inline void block_reduce9(double (&v)[9], double (*red)[9]) {       /
 //   * without statistics: loss = scale * sum(partials) by one extra block (block kObjRows), as k_finish_scaled would.
 // A margin sample that also lies in a seam region is finished by its margin thread (own + tail first, then the fold: the order
 // of the separate launches); the seam threads leave those samples alone, so no two threads touch the same sample.
+#ifndef SPECINV_EPI_ABL              // (timing experiments, wrong results: 1 no margins, 2 no statistics arithmetic, 4 no g_prev loads, 8 no seams)
+#define SPECINV_EPI_ABL 0
+#endif
+#ifndef SPECINV_EPI_GROUP            // threads that walk one tile together in the epilogue's statistics pass
+#define SPECINV_EPI_GROUP 128      // (C5: 512 / 256 / 128 -> 122.7 / 121.2 / 120.8 ms per step)
+#endif
 constexpr int kObjEpiThreads = 1024;   // a streaming pass wants waves in flight: 16 per CU at one block per CU
 static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(float* __restrict__ grad, const float* __restrict__ xtail,
                                                                    const float* __restrict__ margins, const double* __restrict__ part,
@@ -1116,11 +1128,12 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
   const int64_t stride = (int64_t)fast::kObjRows * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // the seam sample n may lie in: the first n_fft - hop padded positions of the tile that holds frame (n + pad) / hop (at most one
   // seam: tiles are longer than a frame); returns the index into xtail or -1
+  const bool small = covered < ((int64_t)1 << 31) && (int64_t)T * nchunks < ((int64_t)1 << 31);   // 32-bit divisions (a 64-bit one is ~200 instructions)
   auto seam_of = [&](int64_t b, int64_t n) -> int64_t {
     if (!seams) return -1;
-    int64_t f0 = (n + pad) / hop;
+    int64_t f0 = small ? (int64_t)((unsigned)(n + pad) / (unsigned)hop) : (n + pad) / hop;
     if (f0 > T - 1) f0 = T - 1;
-    int c = (int)(((f0 + 1) * nchunks - 1) / T);        // largest c with c * T / nchunks <= f0, up to rounding: corrected below
+    int c = small ? (int)(((unsigned)(f0 + 1) * (unsigned)nchunks - 1u) / (unsigned)T) : (int)(((f0 + 1) * nchunks - 1) / T);   // largest c with c * T / nchunks <= f0, up to rounding: corrected below
     while (c + 1 < nchunks && hop_chunk_begin_(c + 1, T, nchunks) <= f0) ++c;
     while (c > 0 && hop_chunk_begin_(c, T, nchunks) > f0) --c;
     if (c < 1) return -1;
@@ -1136,11 +1149,21 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
       // Two groups of 512 threads walk tiles of their own, three pieces per thread and trip with their loads all requested first:
       // 9 - 12 loads of 16 bytes in flight per thread (four pieces: 46 registers spilled at 16 waves per CU).
       const int64_t n_pairs = rows * nchunks;
-      constexpr int GT = kObjEpiThreads / 2;
+      constexpr int GT = SPECINV_EPI_GROUP, NG = kObjEpiThreads / GT;
       const int grp = threadIdx.x / GT, tig = threadIdx.x - grp * GT;
-      for (int64_t pr = 2 * (int64_t)blockIdx.x + grp; pr < n_pairs; pr += 2 * (int64_t)gridDim.x) {
-        const int64_t b = pr / nchunks;
-        const int c = (int)(pr - b * nchunks);
+      // (b, c) of a group's tiles advance by additions: an integer division per tile - and the plain form had three, one of them
+      // 64-bit - is a few hundred vector instructions that every wave of the group repeats (round 5: 15 of the pass's 29 us went
+      // into index arithmetic)
+      const unsigned pr0 = (unsigned)(NG * (int)blockIdx.x + grp), pstep = (unsigned)(NG * (int)gridDim.x);
+      unsigned bq = pr0 / (unsigned)nchunks, cq = pr0 - bq * (unsigned)nchunks;
+      const unsigned bstep = pstep / (unsigned)nchunks, cstep = pstep - bstep * (unsigned)nchunks;
+      for (int64_t pr = pr0; pr < n_pairs; pr += pstep, bq += bstep, cq += cstep) {
+        if (cq >= (unsigned)nchunks) {
+          cq -= (unsigned)nchunks;
+          ++bq;
+        }
+        const int64_t b = bq;
+        const int c = (int)cq;
         const int64_t t_lo = (int64_t)hop_chunk_begin_(c, T, nchunks) * hop - pad;       // span[0] of tile c (may be < 0)
         const int64_t t_hi = (int64_t)hop_chunk_begin_(c + 1, T, nchunks) * hop - pad;
         const int64_t n_lo = c == 0 ? 0 : (t_lo < 0 ? 0 : (t_lo > len ? len : t_lo));
@@ -1161,27 +1184,30 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             of[u] = o0 + u * 4 * GT < span ? o0 + u * 4 * GT : o0;
-            gv[u] = *reinterpret_cast<const fast::v4f*>(gb + of[u]);
-            pv[u] = pb ? *reinterpret_cast<const fast::v4f*>(pb + of[u]) : gv[u];
+            gv[u] = (SPECINV_EPI_ABL & 16) ? fast::v4f{1.0f, 2.0f, 3.0f, (float)of[u]} : *reinterpret_cast<const fast::v4f*>(gb + of[u]);
+            pv[u] = (pb && !(SPECINV_EPI_ABL & 4)) ? *reinterpret_cast<const fast::v4f*>(pb + of[u]) : gv[u];
             dv[u] = db ? *reinterpret_cast<const fast::v4f*>(db + of[u]) : gv[u];
             if (d_impl) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) dv[u][e] = d_of(pv[u][e]);
             }
-            tv[u] = of[u] < seam_end ? *reinterpret_cast<const fast::v4f*>(tl + of[u]) : fast::v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            tv[u] = (of[u] < seam_end && !(SPECINV_EPI_ABL & 8)) ? *reinterpret_cast<const fast::v4f*>(tl + of[u]) : fast::v4f{0.0f, 0.0f, 0.0f, 0.0f};
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if (u > 0 && o0 + u * 4 * GT >= span) continue;
             const int o = of[u];
-            const bool sm = o < seam_end;
+            const bool sm = o < seam_end && !(SPECINV_EPI_ABL & 8);
             if (o > f_lo && o + 3 < f_hi) {
               if (sm) {
                 gv[u] = gv[u] + tv[u];
                 *reinterpret_cast<fast::v4f*>(gb + o) = gv[u];
               }
 #pragma unroll
-              for (int e = 0; e < 4; ++e) sta.add(gv[u][e], pb ? pv[u][e] : gv[u][e], (db || d_impl) ? dv[u][e] : gv[u][e], st_t);
+              for (int e = 0; e < 4; ++e) {
+                if (SPECINV_EPI_ABL & 2) sta.mg = fmaxf(sta.mg, gv[u][e] + pv[u][e] + dv[u][e]);
+                else sta.add(gv[u][e], pb ? pv[u][e] : gv[u][e], (db || d_impl) ? dv[u][e] : gv[u][e], st_t);
+              }
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -1243,9 +1269,9 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
     }
   }
   // ---- margins
-  for (int64_t i = first; i < n_margin; i += stride) {
+  for (int64_t i = first; i < ((SPECINV_EPI_ABL & 1) ? 0 : n_margin); i += stride) {
     const int64_t per_row = 2 * ((int64_t)pad + 1);
-    const int64_t bi = i / per_row, j = i - bi * per_row;
+    const int64_t bi = n_margin < ((int64_t)1 << 31) ? (int64_t)((unsigned)i / (unsigned)per_row) : i / per_row, j = i - bi * per_row;
     int64_t n;
     if (j <= pad) {
       n = j;                                            // left stretch 0 .. pad
@@ -1293,7 +1319,7 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
   double v[9] = {sta.s[0], sta.s[1], sta.s[2], sta.s[3], sta.s[4], sta.s[5], 0.0, (double)sta.mg, (double)sta.md};
   const int lo = (int)((int64_t)n_part * blockIdx.x / fast::kObjRows), hi = (int)((int64_t)n_part * (blockIdx.x + 1) / fast::kObjRows);
   for (int tl = lo + threadIdx.x; tl < hi; tl += blockDim.x) v[6] += part[tl];
-  block_reduce9(v, red9);
+  if (!(SPECINV_EPI_ABL & 32)) block_reduce9(v, red9);
   if (threadIdx.x == 0) {                       // component-major: readers take one component of every row with one coalesced load
     double* row = st.rows + blockIdx.x;
 #pragma unroll
@@ -1382,7 +1408,9 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
       if (const char* e = getenv("SPECINV_OBJ_WALK_CHUNKS")) nch = std::max(1, std::min(T / 4, atoi(e)));
       const int len_ch = T / nch;
       int skew = 0;
-      if ((nch & 1) == 0 && (int64_t)B * nch > 1024 && len_ch >= 8) skew = std::min(len_ch / 4, len_ch - 6);
+      // (C5, chunks of 8 frames, one box: skew 0 / 1 / 2 / 3 -> 126.1 / 122.0 / 124.9 / 128.0 ms per step: an eighth of the chunk -
+      // the contractions' LDS waits leave the younger wave more of the SIMD than the Griffin-Lim kernel's pure transforms do)
+      if ((nch & 1) == 0 && (int64_t)B * nch > 1024 && len_ch >= 8) skew = std::max(1, len_ch / 8);
       if (const char* e = getenv("SPECINV_OBJ_WALK_SKEW")) skew = ((nch & 1) == 0 && len_ch - atoi(e) >= 4) ? std::max(0, atoi(e)) : 0;
       const int keep = N - hop;
       const int64_t n_waves = (int64_t)B * nch;
