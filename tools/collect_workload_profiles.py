@@ -6,7 +6,7 @@ FETCH_SIZE counts a 16-B/lane streaming read at half its bytes, MI355X_MICROARCH
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 sys.path.insert(0, ROOT)
 import bench                                           # noqa: E402  (the dominant-kernel table is bench.py's)
 
@@ -16,8 +16,7 @@ DOMINANT = {
            "specinv::fast::k_phase_init_pairs<16>"],
     "C4": [bench.DOMINANT["C4"][0], "specinv::fast::k_fused4<8, 1, true>"],
     "C3": [bench.DOMINANT["C3"][0]],
-    "C5": [bench.DOMINANT["C5"][0], "specinv::k_lbd_pair_stats<float>", "specinv::k_lbd_lincomb_step<float>",
-           "specinv::k_lbd_decide<float>", "specinv::k_objective_epilogue", "specinv::k_lbd_multi_dot<float>"],
+    "C5": [bench.DOMINANT["C5"][0], "specinv::k_objective_epilogue", "specinv::k_lbd_direction_lean<float>"],
 }
 ALGO = {"C2": 64 * 1024 * 8196, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 4416}
 out = os.path.join(ROOT, "profiles")

@@ -1,6 +1,6 @@
 # rocprofv3 runs of every bench workload (on the GPU box via gpurun); outputs land in gpurun_out/${TAG}_<W>_*.
 # Per workload: 1) kernel trace + stats; 2) PMC passes (separate runs, kernel dispatch only - never combined with trace domains).
-TAG=${1:-r04}
+TAG=${1:-r05}
 shift
 WL=${@:-C2 C4 C3 C5}
 cd /tmp && export TMPDIR=/tmp
