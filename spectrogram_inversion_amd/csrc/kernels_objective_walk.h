@@ -55,6 +55,28 @@ __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkAr
   float* col = reinterpret_cast<float*>(priv);                // ... and, between the transforms, the frame's |S| column
   float* mmv = reinterpret_cast<float*>(priv + sizeof(v2f) * G::TR);   // mm, then dM, of the frame
 
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  // chunk of this wave: waves i and i + 4 of a workgroup share a SIMD, the older one (i < 4) takes the longer chunk of a skewed
+  // pair (kernels_fast_td.h)
+  int w = __builtin_amdgcn_readfirstlane(blockIdx.x * kWalkWaves + wib);
+  if (a.skew != 0) w = 2 * ((int)blockIdx.x * 4 + (wib & 3)) + (wib >> 2);
+  const bool idle = w >= a.n_waves;            // (a wave past the last chunk still helps staging the tables)
+  if (idle) w = a.n_waves - 1;
+  const int b = w / a.nchunks, c = w - b * a.nchunks;
+  const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew), t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
+  const float* xrow = a.x + (long long)b * a.len;
+  float* go = grad_base + (long long)b * a.len;
+  float* mgn = a.margins + (long long)b * 2 * (PB * HOP);
+  const float* tg = a.target + (long long)b * a.n_mels * a.T;
+  // the sample window (the signal is read-only here: no chunk seams to resolve - the loader is told it walks the whole item),
+  // requested before the tables are staged: the chunk's first samples fly while the workgroup builds them
+  v2f xq[NB][QU], xn[QU];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) load_block4<R>(xrow, nullptr, a.len, a.T, 0, 0, a.T, t_begin + q, lane, a.pad_mode, xq[q]);
+  load_block4<R>(xrow, nullptr, a.len, a.T, 0, 0, a.T, t_begin + NB, lane, a.pad_mode, xn);
+
   // ---- tables: window, pass-1 twiddles, the filterbank (once per workgroup: the only barrier)
   for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
   for (int i = threadIdx.x; i < (R - 1) * 64; i += blockDim.x) {
@@ -64,20 +86,7 @@ __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkAr
   for (int i = threadIdx.x; i < a.w.total; i += blockDim.x) blob[i] = a.blob[i];
   __syncthreads();
 
-  const LaneConst<R> k = lane_consts<R>();
-  const int lane = k.lane;
-  const unsigned ulane = (unsigned)lane;
-  // chunk of this wave: waves i and i + 4 of a workgroup share a SIMD, the older one (i < 4) takes the longer chunk of a skewed
-  // pair (kernels_fast_td.h)
-  int w = __builtin_amdgcn_readfirstlane(blockIdx.x * kWalkWaves + wib);
-  if (a.skew != 0) w = 2 * ((int)blockIdx.x * 4 + (wib & 3)) + (wib >> 2);
-  if (w >= a.n_waves) return;
-  const int b = w / a.nchunks, c = w - b * a.nchunks;
-  const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew), t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
-  const float* xrow = a.x + (long long)b * a.len;
-  float* go = grad_base + (long long)b * a.len;
-  float* mgn = a.margins + (long long)b * 2 * (PB * HOP);
-  const float* tg = a.target + (long long)b * a.n_mels * a.T;
+  if (idle) return;
   const int rows = a.w.rows;
   for (int i = lane; i < kWalkMM; i += 64) mmv[i] = 0.0f;     // (the entry behind the last row stays zero: dM[m0 + 1] of the top row)
 
@@ -104,12 +113,6 @@ __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkAr
 #pragma unroll
   for (int i = 0; i < NB * QU; ++i) acc[i] = v2f{0.0f, 0.0f};
   double s2 = 0.0;
-  // the sample window (the signal is read-only here: no chunk seams to resolve - the loader is told it walks the whole item)
-  v2f xq[NB][QU], xn[QU];
-#pragma unroll
-  for (int q = 0; q < NB; ++q) load_block4<R>(xrow, nullptr, a.len, a.T, 0, 0, a.T, t_begin + q, lane, a.pad_mode, xq[q]);
-  load_block4<R>(xrow, nullptr, a.len, a.T, 0, 0, a.T, t_begin + NB, lane, a.pad_mode, xn);
-
   for (int t = t_begin; t < t_end; ++t) {
     asm volatile("" ::: "memory");     // (window / table reads stay inside the loop)
     // ---- targets of this frame: a row per lane (rows 64 .. in a second register), requested now, used after the contraction
