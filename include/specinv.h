@@ -222,7 +222,7 @@ int specinv_transform_loss_grad(specinv_plan* plan, const void* x, int64_t lengt
  * 1 one launch, the mel contractions on the matrix cores (float32, one-sided, n_fft 1024 / 2048, <= 128 bands, any matrix),
  * 2 one launch, the filterbank in band form on the vector units (a sparse matrix - at most 4 rows per bin, <= 140 bands:
  * what a mel filterbank is; SPECINV_OBJ_SPARSE=0 in the environment selects 1 instead), 3 the frame walk (a wave per chunk of
- * frames, the contractions on each frame's own spectrum: hop = n_fft / 4, centred, at most two rows per bin; SPECINV_OBJ_WALK=0
+ * frames, the contractions on each frame's own spectrum: hop = n_fft / 2, / 4, / 8, centred, at most two rows per bin; SPECINV_OBJ_WALK=0
  * selects 2 instead), -1 none yet. */
 int specinv_transform_objective_kind(const specinv_plan* plan);
 /* flat-vector kernels of the two-loop recursion (n elements of the plan dtype) */

@@ -1393,7 +1393,8 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   if (hop > N || hop < 2 || pad >= len) return SPECINV_OK;
   // ---- the frame walk (kernels_objective_walk.h): hop = n_fft / 4, centred, a filterbank with at most two rows per bin
   {
-    bool walk = !mag && pl.tf_walk_ok && 4 * hop == N && 2 * pad == N && len == (int64_t)(T - 1) * hop && T >= 8;
+    const int ov = hop > 0 && N % hop == 0 ? N / hop : 0;
+    bool walk = !mag && pl.tf_walk_ok && (ov == 2 || ov == 4 || ov == 8) && 2 * pad == N && len == (int64_t)(T - 1) * hop && T >= (ov == 8 ? 16 : 8);
     if (const char* e = getenv("SPECINV_OBJ_WALK")) {
       if (e[0] == '0') walk = false;
     }
@@ -1403,15 +1404,18 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     if (walk) {
       // chunks: one round of two waves per SIMD where the frames allow it (>= 8 frames per wave), an even count so that the two
       // waves of a SIMD can take a long and a short chunk (the older wave runs faster: kernels_fast_td.h)
-      int nch = (int)std::max<int64_t>(1, std::min<int64_t>(T / 8, 2048 / std::max(1, B)));
+      // (hop = n_fft / 8: seven of a chunk's hop-blocks are its seam with the chunk before - chunks of >= 16 frames there)
+      const int floor_ch = ov == 8 ? 16 : 8;
+      int nch = (int)std::max<int64_t>(1, std::min<int64_t>(T / floor_ch, 2048 / std::max(1, B)));
       if (nch > 1 && (nch & 1)) --nch;
-      if (const char* e = getenv("SPECINV_OBJ_WALK_CHUNKS")) nch = std::max(1, std::min(T / 4, atoi(e)));
+      if (const char* e = getenv("SPECINV_OBJ_WALK_CHUNKS")) nch = std::max(1, std::min(T / floor_ch, atoi(e)));
       const int len_ch = T / nch;
       int skew = 0;
       // (C5, chunks of 8 frames, one box: skew 0 / 1 / 2 / 3 -> 126.1 / 122.0 / 124.9 / 128.0 ms per step: an eighth of the chunk -
       // the contractions' LDS waits leave the younger wave more of the SIMD than the Griffin-Lim kernel's pure transforms do)
       if ((nch & 1) == 0 && (int64_t)B * nch > 1024 && len_ch >= 8) skew = std::max(1, len_ch / 8);
-      if (const char* e = getenv("SPECINV_OBJ_WALK_SKEW")) skew = ((nch & 1) == 0 && len_ch - atoi(e) >= 4) ? std::max(0, atoi(e)) : 0;
+      if (const char* e = getenv("SPECINV_OBJ_WALK_SKEW")) skew = (nch & 1) == 0 ? std::max(0, atoi(e)) : 0;
+      if (len_ch - skew < std::max(ov, 6)) skew = 0;            // (the shorter chunk of a pair still holds its seam and a frame more)
       const int keep = N - hop;
       const int64_t n_waves = (int64_t)B * nch;
       SI_TRY(pl.fast.hop_inv_tail.reserve((size_t)n_waves * keep * sizeof(float) + 16));
@@ -1442,7 +1446,10 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
         a.ctl_cur = ctl->cur;
         a.grad_alt = ctl->grad_alt;
       }
-      const void* fn = R == 16 ? (const void*)fast::k_objective_walk<16> : (const void*)fast::k_objective_walk<8>;
+      const void* fn = R == 16 ? (ov == 2 ? (const void*)fast::k_objective_walk<16, 2> : ov == 4 ? (const void*)fast::k_objective_walk<16, 4>
+                                                                                                 : (const void*)fast::k_objective_walk<16, 8>)
+                               : (ov == 2 ? (const void*)fast::k_objective_walk<8, 2> : ov == 4 ? (const void*)fast::k_objective_walk<8, 4>
+                                                                                                : (const void*)fast::k_objective_walk<8, 8>);
       const size_t lds = R == 16 ? fast::obj_walk_lds_bytes<16>(pl.tf_walk.total) : fast::obj_walk_lds_bytes<8>(pl.tf_walk.total);
       if (lds <= 160 * 1024 - 512) {
         SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -19,7 +19,7 @@
 // transforms (vector units).  The tile kernel ran its two FFT phases at the pace of the younger wave of each SIMD and could overlap
 // nothing with them (0.37 of the issue slots); per frame and SIMD it took 6.7 us where the Griffin-Lim kernel - two
 // transforms, projection, overlap-add - takes 2.6.
-// Shapes: float32, one-sided, centred, hop = n_fft / 4, n_fft 1024 / 2048, len = (T - 1) hop, a filterbank obj_build_walk accepts;
+// Shapes: float32, one-sided, centred, hop = n_fft / 2, / 4, / 8, n_fft 1024 / 2048, len = (T - 1) hop, a filterbank obj_build_walk accepts;
 // everything else stays on k_objective_logmel / the kernel chain.
 #pragma once
 #include "objective_args.h"
@@ -37,10 +37,18 @@ __device__ __forceinline__ float walk_point(float v, float target, float dscale,
   return (dscale * d) * ru;
 }
 
-template <int R>
+// one hop-block of the read-only signal (the loaders of the Griffin-Lim kernels, told that the wave walks the whole item: no seams)
+template <int R, int OV>
+__device__ __forceinline__ void walk_load_block(const float* __restrict__ xrow, long long L, int T, int j, int lane, int pad_mode,
+                                                v2f (&q)[R / OV]) {
+  if constexpr (OV == 4) load_block4<R>(xrow, nullptr, L, T, 0, 0, T, j, lane, pad_mode, q);
+  else load_block<R, OV>(xrow, nullptr, L, T, 0, 0, T, j, lane, pad_mode, q);
+}
+
+template <int R, int OV>
 __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkArgs a) {
   using G = Geo<R>;
-  using O = Ovl<R, 4>;
+  using O = Ovl<R, OV>;
   constexpr int H = G::H, M = G::M, QU = O::QU, HOP = O::HOP, NB = O::NB, PB = O::PB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (a.ctl_eval != nullptr && *a.ctl_eval == 0) return;     // (the optimiser has stopped: the rest of its enqueued step is no-ops)
@@ -74,8 +82,8 @@ __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkAr
   // requested before the tables are staged: the chunk's first samples fly while the workgroup builds them
   v2f xq[NB][QU], xn[QU];
 #pragma unroll
-  for (int q = 0; q < NB; ++q) load_block4<R>(xrow, nullptr, a.len, a.T, 0, 0, a.T, t_begin + q, lane, a.pad_mode, xq[q]);
-  load_block4<R>(xrow, nullptr, a.len, a.T, 0, 0, a.T, t_begin + NB, lane, a.pad_mode, xn);
+  for (int q = 0; q < NB; ++q) walk_load_block<R, OV>(xrow, a.len, a.T, t_begin + q, lane, a.pad_mode, xq[q]);
+  walk_load_block<R, OV>(xrow, a.len, a.T, t_begin + NB, lane, a.pad_mode, xn);
 
   // ---- tables: window, pass-1 twiddles, the filterbank (once per workgroup: the only barrier)
   for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkAr
       for (int q = 0; q + 1 < NB; ++q) xq[q][i] = xq[q + 1][i];
       xq[NB - 1][i] = xn[i];
     }
-    if (t + 1 < t_end) load_block4<R>(xrow, nullptr, a.len, a.T, 0, 0, a.T, t + 4, lane, a.pad_mode, xn);
+    if (t + 1 < t_end) walk_load_block<R, OV>(xrow, a.len, a.T, t + OV, lane, a.pad_mode, xn);
     fft_forward_t<R>(z, k, twr, tr);
     v2f un[H], um[H], umid;
     {
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkAr
     }
   }
   if (t_end == a.T) {
-    // the chunk that holds the last frame finishes the three blocks behind it as well
+    // the chunk that holds the last frame finishes the NB blocks behind it as well
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       v2f out[QU];

@@ -353,7 +353,7 @@ struct ObjWalkArgs {
   const int* ctl_cur;
   float* grad_alt;
 };
-template <int R>
+template <int R, int OV>
 __global__ void k_objective_walk(ObjWalkArgs a);
 constexpr int kWalkWaves = 8;     // waves per workgroup, one workgroup per CU (two waves per SIMD)
 constexpr int kWalkMM = 144;      // floats of a wave's mm / dM vector (rows <= 128, + 1 zero behind the last row)

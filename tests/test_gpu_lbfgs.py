@@ -262,6 +262,8 @@ def test_gram_direction_follows_the_two_loop_recursion(history):
     (2048, 512, 100, 24, 80, {}),                                 # the frame walk on 288 chunks of 8 / 9 frames, skewed pairs
     (1024, 256, 259, 5, 64, dict(pad_mode="replicate")),          # ... chunks of 8 ... 9 frames at n_fft 1024, an odd frame count
     (2048, 512, 9, 1, 80, {}),                                    # ... ONE chunk
+    (2048, 256, 200, 12, 80, {}),                                 # ... hop = n_fft/8: chunks of 16 / 17 frames, seven-block seams
+    (1024, 512, 300, 9, 40, dict(pad_mode="circular")),           # ... hop = n_fft/2
 ])
 def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frames, batch, n_mels, kw):
     """`specinv_transform_loss_grad` for the log-mel transform as ONE kernel (spectrum kept on the chip) - the filterbank as bands on
@@ -275,8 +277,8 @@ def test_one_launch_objective_vs_chain_and_oracle(monkeypatch, n_fft, hop, frame
     xs = (0.1 * rng.standard_normal((batch, length))).astype(np.float32)
     x0 = (0.05 * rng.standard_normal((batch, length))).astype(np.float32)
     out = {}
-    # the frame walk (kernels_objective_walk.h) serves hop = n_fft / 4, centred; where it does not apply the default is the band form
-    walks = 4 * hop == n_fft and center and n_mels <= 128
+    # the frame walk (kernels_objective_walk.h) serves hop = n_fft / 2, / 4, / 8, centred; where it does not apply the default is the band form
+    walks = n_fft // hop in (2, 4, 8) and n_fft % hop == 0 and center and n_mels <= 128 and frames >= (16 if 8 * hop == n_fft else 8)
     for mode in ("walk", "bands", "matrix", "chain"):
         monkeypatch.setenv("SPECINV_DISABLE_FUSED_OBJECTIVE", "1" if mode == "chain" else "0")
         monkeypatch.setenv("SPECINV_REQUIRE_FUSED_OBJECTIVE", "0" if mode == "chain" else "1")
