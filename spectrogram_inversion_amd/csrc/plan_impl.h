@@ -12,6 +12,7 @@
 #include "fast_state.h"
 #include "kernels_generic.h"
 #include "kernels_lbfgs.h"
+#include "kernels_big.h"
 #include "lbfgs_dev.h"
 #include "kernels_rtisi.h"
 #include "plan.h"
@@ -109,6 +110,11 @@ struct PlanT final : PlanBase {
   size_t lds_bytes2 = 0;       // two buffers (the kernels that keep the two-buffer transform)
   bool use_inplace = false;
   int ip_threads = 0, ip_maxb = 0;
+  // frames beyond one workgroup's LDS (kernels_big.h): n_fft = big_n1 * nf, the LDS kernels transform nf points
+  bool big = false;
+  int big_n1 = 1, nf = 0;
+  FrameCfg<T> fc2{};           // the sub-transform's stages (n_fft = nf, tw = tw2)
+  DevBuf tw2, big_y;
   bool tw_lds = false;         // k_iter_pair: the twiddle table copied to LDS (small n_fft)
   bool use_dr = false;         // k_iter_pair_dr: the digit-reversed in-place transform (power-of-two n_fft)
   size_t dr_lds = 0;
@@ -164,7 +170,25 @@ struct PlanT final : PlanBase {
     SI_TRY(env.reserve(length * sizeof(T)));
     SI_HIP(hipMemcpy(env.p, h_env.data(), length * sizeof(T), hipMemcpyHostToDevice));
 
-    std::vector<int> rad = factorize(n);
+    // A frame's transform lives in one workgroup's LDS up to 16384 points in float32, 8192 in float64 (in place); beyond that it is
+    // cut into big_n1 in {2, 4, 8} rows of nf points and takes four steps through device memory (kernels_big.h)
+    big = false;
+    big_n1 = 1;
+    nf = n;
+    {
+      const size_t cap = (size_t)128 * 1024 / sizeof(C);          // points one in-place buffer may hold
+      if ((size_t)n > cap) {
+        for (int n1 = 2; n1 <= 8 && !big; n1 *= 2)
+          if (n % n1 == 0 && (size_t)(n / n1) * 2 <= cap) {        // (rows of half the cap: two workgroups per CU)
+            big = true;
+            big_n1 = n1;
+            nf = n / n1;
+          }
+        SI_CHECK(big, SPECINV_EUNSUPPORTED, "n_fft=%d: frames above %zu points are transformed as 2, 4 or 8 rows of at most %zu",
+                 n, cap, cap / 2);
+      }
+    }
+    std::vector<int> rad = factorize(nf);
     SI_CHECK((int)rad.size() <= kMaxStages, SPECINV_EUNSUPPORTED, "n_fft=%d has too many prime factors", n);
     fc.n_fft = n;
     fc.n_freq = n_freq;
@@ -182,14 +206,14 @@ struct PlanT final : PlanBase {
       const uint64_t m = (uint64_t)ns * rad[i];
       fc.ns_magic[i] = (unsigned)(((1ull << 32) + ns - 1) / ns);      // ns = 1: wraps to 0, never used
       fc.m_magic[i] = (unsigned)(((1ull << 32) + m - 1) / m);
-      fc.tw_step[i] = (int)(n / m);
+      fc.tw_step[i] = (int)(nf / m);
       ns = m;
     }
     fc.tw = tw.as<C>();
     fc.window = window.as<T>();
     fc.inplace = 0;
     fc.maxb = 0;
-    lds_bytes2 = 2 * (size_t)n * sizeof(C);          // two buffers: every kernel can run (RTISI-LA and the L-BFGS chain need them)
+    lds_bytes2 = 2 * (size_t)nf * sizeof(C);         // two buffers: every kernel can run (RTISI-LA and the L-BFGS chain need them)
     // In-place transforms (kernels_generic.h: FrameCfg::inplace) for k_stft / k_iter_pair / k_grad_frames: one buffer - more
     // workgroups per CU for a latency-bound kernel (measured, tools/bench_generic_r04.py: float64 2048 / 512 0.58 -> 0.44 ms per
     // iteration, float64 512 two-sided 1.40 -> 1.02, float32 8192 0.64 -> 0.31; float32 at n_fft <= 1024 2 % slower: the extra
@@ -202,13 +226,13 @@ struct PlanT final : PlanBase {
     if (ip_ok) {
       auto fits = [&](int threads) {
         for (int r : rad)
-          if ((n / r + threads - 1) / threads > ip_butterflies_per_thread(r, sizeof(T) == 8)) return false;
+          if ((nf / r + threads - 1) / threads > ip_butterflies_per_thread(r, sizeof(T) == 8)) return false;
         return true;
       };
       // (at least a thread per butterfly of the widest stage up to 256 threads, like the two-buffer form)
       int rmin = 8;
       for (int r : rad) rmin = std::min(rmin, r);
-      while (ip_threads < 256 && ip_threads < n / std::max(2, rmin)) ip_threads *= 2;
+      while (ip_threads < 256 && ip_threads < nf / std::max(2, rmin)) ip_threads *= 2;
       while (ip_threads < 1024 && !fits(ip_threads)) ip_threads *= 2;
       ip_ok = fits(ip_threads);
     }
@@ -223,13 +247,13 @@ struct PlanT final : PlanBase {
       // (workgroups of four waves: with one-wave workgroups - n_fft 512 - LDS is what limits the workgroups per CU, and the table
       // costs more occupancy than its latency saves: float64 512 two-sided 1.03 -> 1.26 ms per iteration; float32 1024 0.492 ->
       // 0.448, float64 1000 0.259 -> 0.245)
-      tw_lds = (size_t)n * sizeof(C) <= 16 * 1024 && frame_threads() >= 256 && !(e1 && e1[0] == '0');
+      tw_lds = !big && (size_t)n * sizeof(C) <= 16 * 1024 && frame_threads() >= 256 && !(e1 && e1[0] == '0');
     }
     // Power-of-two n_fft: the iteration kernel on the digit-reversed in-place transform (kernels_generic.h: k_iter_pair_dr) -
     // radix 8 stages, then 4 (or 4, 4; a lone 2): the small blocks last, where no twiddles are left
     fc.dr_stages = 0;
     use_dr = false;
-    if (n >= 8 && (n & (n - 1)) == 0) {
+    if (!big && n >= 8 && (n & (n - 1)) == 0) {
       int e = 0;
       while ((1 << e) < n) ++e;
       std::vector<int> bits;
@@ -282,6 +306,25 @@ struct PlanT final : PlanBase {
                            (const void*)k_iter_pair_dr<T, 0, false>, (const void*)k_iter_pair_dr<T, 0, true>,
                            (const void*)k_iter_pair_dr<T, 1, false>, (const void*)k_iter_pair_dr<T, 1, true>};
       for (const void* fn : fns) SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    }
+    if (big) {
+      // the sub-transform: fc's stages with its own size and twiddle table W_nf^j = W_N^(j big_n1)
+      std::vector<C> h2(nf);
+      for (int i = 0; i < nf; ++i) {
+        const long double a = -2.0L * 3.141592653589793238462643383279502884L * i / nf;
+        h2[i] = mk<T>((T)cosl(a), (T)sinl(a));
+      }
+      SI_TRY(tw2.reserve((size_t)nf * sizeof(C)));
+      SI_HIP(hipMemcpy(tw2.p, h2.data(), (size_t)nf * sizeof(C), hipMemcpyHostToDevice));
+      fc2 = fc;
+      fc2.n_fft = nf;
+      fc2.tw = tw2.as<C>();
+      fc2.inplace = use_inplace ? 1 : 0;
+      fc2.maxb = use_inplace ? ip_maxb : 0;
+      SI_TRY(big_y.reserve((size_t)B() * Tn() * n * sizeof(C)));
+      const void* fns[] = {(const void*)k_big_rows<T, false, false>, (const void*)k_big_rows<T, false, true>,
+                           (const void*)k_big_rows<T, true, false>, (const void*)k_big_rows<T, true, true>};
+      for (const void* fn : fns) SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_bytes, 64 * 1024)));
     }
     SI_TRY(sums.reserve(16 * sizeof(double)));
     SI_TRY(fast.setup(cfg, h_window, length, pad));
@@ -378,7 +421,7 @@ struct PlanT final : PlanBase {
     if (use_inplace) return ip_threads;
     int rmin = 8;
     for (int i = 0; i < fc.n_stages; ++i) rmin = std::min(rmin, fc.radix[i]);
-    const int want = (N() / std::max(2, rmin) + 63) / 64 * 64;
+    const int want = (nf / std::max(2, rmin) + 63) / 64 * 64;
     return std::min(256, std::max(64, want));
   }
 
@@ -389,6 +432,48 @@ struct PlanT final : PlanBase {
     SI_TRY(frames_needed());
     SI_TRY(inverse_frames(spec_btf, frames.as<T>(), fc.inv_scale, length));
     return launch_ola(frames.as<T>(), out, true);
+  }
+
+  // ---- frames in four steps (kernels_big.h) ---------------------------------------------------------------------------
+  BigCfg<T> big_cfg(int64_t len) const {
+    BigCfg<T> c{};
+    c.f = fc;
+    c.f.length = len;
+    c.s = fc2;
+    c.n1 = big_n1;
+    c.n2 = nf;
+    c.n_frames = Tn();
+    c.y = big_y.as<C>();
+    return c;
+  }
+  int big_rows(const BigCfg<T>& c, bool inverse) {
+    const dim3 grid(big_n1, Tn(), B()), blk(frame_threads());
+    if (use_inplace) {
+      if (inverse) hipLaunchKernelGGL((k_big_rows<T, true, true>), grid, blk, lds_bytes, stream, c);
+      else hipLaunchKernelGGL((k_big_rows<T, true, false>), grid, blk, lds_bytes, stream, c);
+    } else {
+      if (inverse) hipLaunchKernelGGL((k_big_rows<T, false, true>), grid, blk, lds_bytes, stream, c);
+      else hipLaunchKernelGGL((k_big_rows<T, false, false>), grid, blk, lds_bytes, stream, c);
+    }
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
+  }
+  int big_forward(const BigCfg<T>& c, const T* xin) {            // x -> y: every frame's spectrum, bin k at big_pos(k)
+    const dim3 grid((unsigned)ceil_div(nf, 256), Tn(), B());
+    if (big_n1 == 2) hipLaunchKernelGGL((k_big_pass1<T, 2>), grid, dim3(256), 0, stream, c, xin);
+    else if (big_n1 == 4) hipLaunchKernelGGL((k_big_pass1<T, 4>), grid, dim3(256), 0, stream, c, xin);
+    else hipLaunchKernelGGL((k_big_pass1<T, 8>), grid, dim3(256), 0, stream, c, xin);
+    SI_HIP(hipGetLastError());
+    return big_rows(c, false);
+  }
+  int big_inverse(const BigCfg<T>& c, T* fr) {                   // y (what an inverse real transform sees) -> windowed frames
+    SI_TRY(big_rows(c, true));
+    const dim3 grid((unsigned)ceil_div(nf, 256), Tn(), B());
+    if (big_n1 == 2) hipLaunchKernelGGL((k_big_pass4<T, 2>), grid, dim3(256), 0, stream, c, fr);
+    else if (big_n1 == 4) hipLaunchKernelGGL((k_big_pass4<T, 4>), grid, dim3(256), 0, stream, c, fr);
+    else hipLaunchKernelGGL((k_big_pass4<T, 8>), grid, dim3(256), 0, stream, c, fr);
+    SI_HIP(hipGetLastError());
+    return SPECINV_OK;
   }
 
   // pad_mode_override >= 0 / scale_override > 0 replace the plan's pad mode / forward scale (used by the adjoints)
@@ -405,6 +490,14 @@ struct PlanT final : PlanBase {
         return fast.launch_xform(*this, true, xin, (long long)len, reinterpret_cast<fast::v2f*>(spec_btf), nullptr, sc,
                                  pm);
     }
+    if (big) {
+      BigCfg<T> bc = big_cfg(len);
+      bc.f.pad_mode = pm;
+      SI_TRY(big_forward(bc, xin));
+      hipLaunchKernelGGL((k_big_split_out<T>), dim3((unsigned)ceil_div(n_freq, 256), Tn(), B()), dim3(256), 0, stream, bc, spec_btf, sc);
+      SI_HIP(hipGetLastError());
+      return SPECINV_OK;
+    }
     FrameCfg<T> c = frame_cfg(len);
     c.pad_mode = pm;
     c.fwd_scale = sc;
@@ -420,6 +513,13 @@ struct PlanT final : PlanBase {
       if (fast.xform_ok && !force_generic)
         return fast.launch_xform(*this, false, nullptr, (long long)len,
                                  const_cast<fast::v2f*>(reinterpret_cast<const fast::v2f*>(spec_btf)), fr, scale);
+    }
+    if (big) {
+      BigCfg<T> bc = big_cfg(len);
+      bc.f.inv_scale = scale;
+      hipLaunchKernelGGL((k_big_merge_in<T>), dim3((unsigned)ceil_div(N() / 2 + 1, 256), Tn(), B()), dim3(256), 0, stream, bc, spec_btf);
+      SI_HIP(hipGetLastError());
+      return big_inverse(bc, fr);
     }
     FrameCfg<T> c = frame_cfg(len);
     c.inv_scale = scale;
@@ -570,6 +670,25 @@ struct PlanT final : PlanBase {
       const FrameCfg<T> fci = frame_cfg(length);
       for (int i = 0; i < n_iter; ++i) {
         const bool ev = eval_last && i == n_iter - 1;
+        if (big) {                                   // the same iteration in four steps through device memory (kernels_big.h)
+          const BigCfg<T> bc = big_cfg(length);
+          SI_TRY(big_forward(bc, x.as<T>()));
+          const dim3 ug((unsigned)ceil_div(N() / 2 + 1, 256), Tn(), B());
+          const int mode = method == Method::Gla ? 0 : 1;
+          C* sb = mode == 0 ? (C*)nullptr : specB.as<C>();
+          if (ev) SI_TRY(partials.reserve((size_t)2 * ug.x * ug.y * ug.z * sizeof(double)));
+          if (mode == 0) {
+            if (ev) hipLaunchKernelGGL((k_big_update<T, 0, true>), ug, dim3(256), 0, stream, bc, specA.as<C>(), sb, mag.as<T>(), coef, inv1p, partials.as<double>());
+            else hipLaunchKernelGGL((k_big_update<T, 0, false>), ug, dim3(256), 0, stream, bc, specA.as<C>(), sb, mag.as<T>(), coef, inv1p, partials.as<double>());
+          } else {
+            if (ev) hipLaunchKernelGGL((k_big_update<T, 1, true>), ug, dim3(256), 0, stream, bc, specA.as<C>(), sb, mag.as<T>(), coef, inv1p, partials.as<double>());
+            else hipLaunchKernelGGL((k_big_update<T, 1, false>), ug, dim3(256), 0, stream, bc, specA.as<C>(), sb, mag.as<T>(), coef, inv1p, partials.as<double>());
+          }
+          SI_HIP(hipGetLastError());
+          SI_TRY(big_inverse(bc, frames.as<T>()));
+          SI_TRY(launch_ola(frames.as<T>(), x.as<T>(), true));
+          continue;
+        }
         const dim3 grid((Tn() + 1) / 2, B()), blk(use_dr ? dr_threads : frame_threads());   // two frames per complex FFT
         {
           const void* fn = nullptr;
@@ -597,7 +716,8 @@ struct PlanT final : PlanBase {
       }
     }
     if (eval_last) {
-      const int64_t n_part = fast_path() ? (int64_t)fast.n_partials : (int64_t)B() * ((Tn() + 1) / 2);
+      const int64_t n_part = fast_path() ? (int64_t)fast.n_partials
+                             : big ? (int64_t)B() * Tn() * ceil_div(N() / 2 + 1, 256) : (int64_t)B() * ((Tn() + 1) / 2);
       if (deferred_slot >= 0) {
         // deferred evaluation (run_loop with tol == 0 and no callback): keep the sums on the device
         SI_TRY(eval_log.reserve((size_t)(deferred_slot + 1) * 2 * sizeof(double)));

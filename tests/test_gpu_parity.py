@@ -502,13 +502,59 @@ def test_transforms_beyond_two_lds_buffers(n_fft, dtype, tol):
         assert e < max(3 * e0, 5 * tol), (method, e, e0)
 
 
-def test_transform_too_large_for_lds_is_refused():
-    """n_fft complex values must fit the 160 KiB of LDS: 32768 points in float32 (and 16384 in float64) are refused with
-    SPECINV_EUNSUPPORTED at plan creation, not run on some slower path; so is RTISI-LA where its frame buffers (two per look-ahead
-    frame, the two-buffer transform) do not fit."""
-    for n_fft, dtype in ((32768, torch.float32), (16384, torch.float64)):
+@pytest.mark.parametrize("n_fft,dtype,onesided,tol", [
+    (32768, np.float32, True, 2e-5),      # 4 rows of 8192 points
+    (65536, np.float32, True, 2e-5),      # 8 rows: the largest float32 frame
+    (32768, np.float32, False, 2e-5),     # two-sided
+    (16384, np.float64, True, 1e-10),     # 4 rows of 4096
+    (32768, np.float64, True, 1e-10),     # 8 rows: the largest float64 frame
+    (3 * 16384, np.float32, True, 2e-5),  # 8 rows of 6144 = 2^11 * 3 points
+])
+def test_frames_beyond_the_lds_take_four_steps(n_fft, dtype, onesided, tol):
+    """The reference derives n_fft from the spectrogram with no bound (torch_specinv/methods.py:65-68).  A frame above 16384 points
+    in float32 / 8192 in float64 - refused until round 5 - is transformed as 2, 4 or 8 rows through device memory (kernels_big.h):
+    phase_init, the transforms, Griffin-Lim and ADMM against the oracle (the float32 runs held to the float32 oracle's own distance
+    from the float64 one, as in test_transforms_beyond_two_lds_buffers)."""
+    rng = np.random.default_rng(n_fft)
+    hop, frames = n_fft // 4, 5
+    F = n_fft // 2 + 1 if onesided else n_fft
+    mag = (rng.random((2, F, frames)) + 0.05).astype(dtype)
+    w = hann(n_fft, dtype)
+    w64 = hann(n_fft, np.float64)
+    kw = dict(hop_length=hop, onesided=onesided)
+    init = oracle.phase_init(mag, window=w, **kw)
+    got = N(si.phase_init(T(mag), window=torch.from_numpy(w), **kw))
+    assert rel_l2(got, init) < 1e-6
+    # the building blocks: x -> STFT -> ISTFT is the identity up to rounding
+    x = rng.standard_normal((2, (frames - 1) * hop)).astype(dtype)
+    a = args_helper(T(mag), window=torch.from_numpy(w), **kw)
+    plan = get_plan(a, 2, frames, torch.from_numpy(w).dtype, dev())
+    sp = plan.stft(T(x))
+    ref_sp = oracle.stft(x.astype(np.float64), oracle.args_helper(F, np.float64, window=w64, **kw))
+    assert rel_l2(N(sp), ref_sp) < 20 * tol
+    assert rel_l2(N(plan.istft(sp)), x) < 20 * tol
+    for method, run, okw in (("griffin_lim", si.griffin_lim, dict(max_iter=3, alpha=0.5)), ("admm", si.ADMM, dict(max_iter=2, rho=1.0))):
+        ref = getattr(oracle, method)(init, tol=0, window=w, **okw, **kw)
+        ref64 = getattr(oracle, method)(init.astype(np.complex128), tol=0, window=w64, **okw, **kw)
+        y = N(run(T(init), tol=0, verbose=False, window=torch.from_numpy(w), **okw, **kw))
+        assert y.shape == ref.shape and y.dtype == dtype
+        e, e0 = rel_l2(y, ref64), rel_l2(ref, ref64)
+        assert e < max(3 * e0, 5 * tol), (method, e, e0)
+    # the evaluation of the training loop (methods.py:180-182) on the four-step path: the metric after a short run
+    plan.gla_init(T(init), None, 0.3)
+    done, evals = plan.run(4, 2, 0.0, "sc")
+    tr = []
+    oracle.griffin_lim(init, max_iter=4, alpha=0.3, tol=0, eva_iter=2, window=w, trace=tr, **kw)
+    assert done == 4 and len(evals) == 2 and len(tr) == 2
+    assert abs(10 ** (evals[-1][1] / 20) - 10 ** (tr[-1][1] / 20)) < 1e-4, (evals, tr)
+
+
+def test_transform_too_large_even_for_four_steps_is_refused():
+    """Eight rows of 8192 (float32) / 4096 (float64) points are the largest frame: beyond, SPECINV_EUNSUPPORTED at plan creation, not
+    some slower path; so is RTISI-LA where its frame buffers (two per look-ahead frame, the two-buffer transform) do not fit."""
+    for n_fft, dtype in ((131072, torch.float32), (65536, torch.float64)):
         mag = torch.rand(1, n_fft // 2 + 1, 4, dtype=dtype, device=dev())
-        with pytest.raises(NotImplementedError, match="LDS"):
+        with pytest.raises(NotImplementedError, match="rows"):
             si.griffin_lim(mag, max_iter=1, verbose=False, hop_length=n_fft // 4)
     mag = torch.rand(1, 8193, 6, dtype=torch.float32, device=dev())
     with pytest.raises(NotImplementedError, match="LDS"):
