@@ -479,6 +479,47 @@ def test_large_prime_factors_vs_oracle(n_fft, hop, frames, onesided, dtype):
     assert rel_l2(y, ref64) < max(10 * tol, 20 * rel_l2(ref, ref64)), (rel_l2(y, ref64), rel_l2(ref, ref64))   # no blow-up
 
 
+@pytest.mark.parametrize("n_fft,dtype,onesided", [
+    (2048, np.float64, True), (2048, np.float64, False), (1024, np.float64, True), (2048, np.float32, False),   # k_iter_pair_dr
+    (1024, np.float32, True), (1000, np.float64, True),                                                          # Stockham + LDS twiddles
+    (512, np.float64, False), (4096, np.float32, True),                                                          # Stockham as before
+])
+def test_coverage_iteration_kernels_agree_and_match_the_oracle(monkeypatch, n_fft, dtype, onesided):
+    """Round 5's forms of the coverage path's iteration kernel - the digit-reversed in-place transform with an octant twiddle table
+    in LDS (float64 1024 / 2048, float32 2048), the Stockham kernels with the twiddle table copied to LDS (four-wave workgroups) -
+    against the plain Stockham kernel (SPECINV_GENERIC_DR=0, SPECINV_GENERIC_TWLDS=0: same butterflies, another order / another
+    table: equal to rounding) and against the oracle, Griffin-Lim and ADMM, odd frame counts included (a last pair of one frame)."""
+    rng = np.random.default_rng(n_fft + int(onesided))
+    hop, frames = n_fft // 4, 7
+    F = n_fft // 2 + 1 if onesided else n_fft
+    mag = (rng.random((2, F, frames)) + 0.05).astype(dtype)
+    w = hann(n_fft, dtype)
+    kw = dict(hop_length=hop, onesided=onesided)
+    init = oracle.phase_init(mag, window=w, **kw)
+    tol = 2e-5 if dtype == np.float32 else 1e-10
+    for method, run, okw in (("griffin_lim", si.griffin_lim, dict(max_iter=4, alpha=0.5)), ("admm", si.ADMM, dict(max_iter=3, rho=1.0))):
+        ref = getattr(oracle, method)(init, tol=0, window=w, **okw, **kw)
+        ref64 = getattr(oracle, method)(init.astype(np.complex128), tol=0, window=hann(n_fft, np.float64), **okw, **kw)
+        out = {}
+        for arm, env in (("new", {}), ("plain", {"SPECINV_GENERIC_DR": "0", "SPECINV_GENERIC_TWLDS": "0"})):
+            for k_ in ("SPECINV_GENERIC_DR", "SPECINV_GENERIC_TWLDS"):
+                monkeypatch.delenv(k_, raising=False)
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            from spectrogram_inversion_amd.plan import clear_plan_cache
+            clear_plan_cache()                                   # (the plan picks its kernels when it is created)
+            a = args_helper(T(init), window=torch.from_numpy(w), **kw)
+            plan = get_plan(a, 2, frames, torch.from_numpy(w).dtype, dev())
+            plan.force_generic(True)
+            (plan.gla_init if method == "griffin_lim" else plan.admm_init)(T(init), None, okw.get("alpha", okw.get("rho")))
+            plan.iterate(okw["max_iter"])
+            out[arm] = N(plan.wave())
+        clear_plan_cache()
+        e, e0 = rel_l2(out["new"], ref64), rel_l2(ref, ref64)
+        assert e < max(3 * e0, 5 * tol), (method, e, e0)
+        assert rel_l2(out["new"], out["plain"]) < max(3 * e0, 5 * tol), (method, rel_l2(out["new"], out["plain"]))
+
+
 @pytest.mark.parametrize("n_fft,dtype,tol", [(16384, np.float32, 2e-5), (8192, np.float64, 1e-10)])
 def test_transforms_beyond_two_lds_buffers(n_fft, dtype, tol):
     """The reference derives n_fft from the spectrogram with no bound (torch_specinv/methods.py:65-68).  The generic kernels keep a
