@@ -134,6 +134,17 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
   TwRegs<R> twr;
 #pragma unroll
   for (int k1 = 1; k1 < R; ++k1) twr.w[k1 - 1] = lds_tw1[(k1 - 1) * 64 + lane];
+  // ... and so are the two windows of a symmetric-window run, and the wave's own frame between two inner iterations (round 5: 48
+  // of an inner iteration's ~210 LDS instructions; only where a wave has the whole register file: look_ahead <= 3)
+  constexpr bool kRegs = MAXT == 256;
+  v2f wreg[kRegs ? R : 1], sreg[kRegs ? R : 1], zown[kRegs ? R : 1];
+  if (kRegs) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      wreg[kRegs ? u : 0] = lds_win[64 * u + lane];
+      sreg[kRegs ? u : 0] = lds_wsyn[64 * u + lane];
+    }
+  }
 
   // target of this wave's frame at outer step i (zero outside the spectrogram: methods.py:339); requested a step ahead - the only
   // global load of a step would otherwise sit, exposed, in front of its first inner iteration
@@ -191,8 +202,13 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
     for (int it = 0; it < a.max_iter; ++it) {
       // ---- kept part + own frame + the hop-blocks of the other look-ahead frames q + dl that cover it
       v2f z[R];
+      if (kRegs && it > 0) {
 #pragma unroll
-      for (int u = 0; u < R; ++u) z[u] = zc[u] + own[64 * u + lane];
+        for (int u = 0; u < R; ++u) z[u] = zc[u] + zown[kRegs ? u : 0];
+      } else {
+#pragma unroll
+        for (int u = 0; u < R; ++u) z[u] = zc[u] + own[64 * u + lane];
+      }
 #pragma unroll
       for (int dl = 1 - OV; dl < OV; ++dl) {
         if (dl == 0) continue;
@@ -209,7 +225,10 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
         }
       }
       __syncthreads();                               // every wave has read the ring; slots may be rewritten
-      {
+      if (kRegs && !newest) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) z[u] = z[u] * wreg[kRegs ? u : 0];
+      } else {
         const v2f* win = newest ? lds_win + (it == 0 ? M : 2 * M) : lds_win;
 #pragma unroll
         for (int u = 0; u < R; ++u) z[u] = z[u] * win[64 * u + lane];
@@ -289,8 +308,16 @@ __global__ __launch_bounds__(MAXT, 1) void k_rtisi_fast(RtisiFastArgs a) {
 #pragma unroll
         for (int u = 0; u < R; ++u) out[64u * u + ulane] = z[u] * w[64u * u + ulane];
       }
+      if (kRegs) {
 #pragma unroll
-      for (int u = 0; u < R; ++u) own[64 * u + lane] = z[u] * lds_wsyn[64 * u + lane];   // :398
+        for (int u = 0; u < R; ++u) {
+          zown[kRegs ? u : 0] = z[u] * sreg[kRegs ? u : 0];
+          own[64 * u + lane] = zown[kRegs ? u : 0];   // :398
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < R; ++u) own[64 * u + lane] = z[u] * lds_wsyn[64 * u + lane];   // :398
+      }
       __syncthreads();                               // new frames visible before the next overlap-add
     }
 
