@@ -16,6 +16,7 @@
 #include "kernels_generic.h"
 #include "fast_state.h"
 #include "objective_args.h"
+#include "lbfgs_state.h"
 
 namespace specinv {
 
@@ -1027,37 +1028,6 @@ inline int obj_mel_tiles(int n_mels, int R) {
   return mt <= 3 ? 3 : mt <= 4 ? 4 : mt <= 5 ? 5 : mt <= 8 ? (R == 8 ? 9 : 8) : 0;
 }
 
-// nine figures over the 256 threads of a workgroup, lanes then waves in a fixed order: v[0 .. 6] sums, v[7], v[8] maxima; every
-// thread leaves with the totals
-__device__ inline void block_reduce9(double (&v)[9], double (*red)[9]) {       // red: [waves of the workgroup][9]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) v[i] = wave_sum(v[i]);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    v[7] = fmax(v[7], __shfl_xor(v[7], off, 64));
-    v[8] = fmax(v[8], __shfl_xor(v[8], off, 64));
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) red[wave][i] = v[i];
-  }
-  __syncthreads();
-  // (nine threads add the waves' rows and publish the totals: every thread walking all rows cost 144 LDS reads each - 4 us of a
-  // 1024-thread workgroup)
-  const int nw = (int)(blockDim.x >> 6);
-  if (threadIdx.x < 9) {
-    const int i = threadIdx.x;
-    double t = red[0][i];
-    for (int w = 1; w < nw; ++w) t = i < 7 ? t + red[w][i] : fmax(t, red[w][i]);
-    red[0][i] = t;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 9; ++i) v[i] = red[0][i];
-  __syncthreads();
-}
-
 // What follows k_objective_logmel, in ONE launch of kObjRows blocks (grid-stride over the work):
 //   * chunk seams: grad[n] += the previous tile's tail over the first n_fft - hop samples of tiles 1.. (k_hop_tails_raw),
 //   * fold of the padded margins onto the signal (k_grad_fold_margins with `margins` given),
@@ -1084,18 +1054,24 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
                                                                    double* __restrict__ slot, int T, int nchunks, int n_fft, int hop,
                                                                    int keep, int pad, int pad_mode, int64_t len, int64_t rows,
                                                                    int64_t n_tail, int64_t n_margin, int n_part, double scale,
-                                                                   fast::ObjCtl ctl, fast::ObjStatReq st, int vec_ok, int skew) {
+                                                                   fast::ObjCtl ctl, fast::ObjStatReq st, int vec_ok, int skew,
+                                                                   fast::ObjDecide dec) {
   // (chunks of frames: k_objective_logmel's tiles - even, skew 0 - or k_objective_walk's, which may be skewed in pairs)
   auto hop_chunk_begin_ = [&](int c_, int T_, int n_) { return fast::chunk_begin(c_, T_, n_, skew); };
   float* grad_other = ctl.grad_alt;
   if (ctl.do_eval != nullptr) {                  // device-resident optimiser: gate and gradient ping-pong (lbfgs_dev.h)
-    if (*ctl.do_eval == 0) return;
+    if (*ctl.do_eval == 0) {
+      if (dec.ticket != nullptr && blockIdx.x == 0) lbd_tail_pass(dec);
+      return;
+    }
     if ((*ctl.cur ^ 1) != 0) {
       grad_other = grad;
       grad = ctl.grad_alt;
     }
   }
   __shared__ double red[16];
+  __shared__ LbdState lbd_r;
+  if (dec.ticket != nullptr) lbd_tail_preload(dec, lbd_r);
   if (st.rows == nullptr && blockIdx.x == fast::kObjRows) {
     double sacc = 0;
     for (int i = threadIdx.x; i < n_part; i += blockDim.x) sacc += part[i];
@@ -1320,14 +1296,31 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
   const int lo = (int)((int64_t)n_part * blockIdx.x / fast::kObjRows), hi = (int)((int64_t)n_part * (blockIdx.x + 1) / fast::kObjRows);
   for (int tl = lo + threadIdx.x; tl < hi; tl += blockDim.x) v[6] += part[tl];
   if (!(SPECINV_EPI_ABL & 32)) block_reduce9(v, red9);
+  const bool tail = dec.ticket != nullptr;
+  __shared__ int last;
   if (threadIdx.x == 0) {                       // component-major: readers take one component of every row with one coalesced load
     double* row = st.rows + blockIdx.x;
+    auto w = [&](int c) { return c < 6 ? v[c] : c == 6 ? v[7] : c == 7 ? v[8] : v[6]; };
+    if (!tail) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) row[c * fast::kObjRows] = v[c];
-    row[6 * fast::kObjRows] = v[7];
-    row[7 * fast::kObjRows] = v[8];
-    row[8 * fast::kObjRows] = v[6];
+      for (int c = 0; c < 9; ++c) row[c * fast::kObjRows] = w(c);
+    } else {
+      // ---- the optimiser's decisions ride along, taken by the workgroup that finishes last: the row goes out with device-scope
+      // stores (past this XCD's L2, where the launch's other workgroups' loads find it) and is complete - vmcnt(0) - before the
+      // ticket is drawn.  (A device-scope release fence would write back the whole L2 - the gradient this launch has just
+      // stored - once per workgroup: +11 us on the launch, measured.)
+#pragma unroll
+      for (int c = 0; c < 9; ++c) __hip_atomic_store(row + c * fast::kObjRows, w(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      last = __hip_atomic_fetch_add(dec.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    }
   }
+  if (!tail) return;
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) __hip_atomic_store(dec.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  lbd_tail_decide(dec, scale, red9, lbd_r);
 }
 
 // the second level of the tree: out = {loss, g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev} from the epilogue's rows (one
@@ -1372,11 +1365,33 @@ int tf_finish_loss(P& pl, int64_t n_part, double numel, double* loss_host, doubl
   return SPECINV_OK;
 }
 
+// will the frame walk (kernels_objective_walk.h) serve this plan's objective?  hop = n_fft / {2, 4, 8}, centred, a signal of whole
+// hops, a filterbank with at most two rows per bin (the device-resident optimiser defers its steps into the walk only then)
+template <typename P>
+bool tf_walk_serves(P& pl, int64_t len) {
+  if (pl.force_generic || !pl.cfg.onesided || !pl.fast.xform_ok || (pl.fast.xform_R != 8 && pl.fast.xform_R != 16)) return false;
+  if (pl.tf_kind != SPECINV_TF_LOGMEL || !pl.tf_sp_ok) return false;
+  for (const char* name : {"SPECINV_OBJ_SPARSE", "SPECINV_OBJ_WALK"})
+    if (const char* e = getenv(name)) {
+      if (e[0] == '0') return false;
+    }
+  if (const char* e = getenv("SPECINV_DISABLE_FUSED_OBJECTIVE")) {
+    if (e[0] == '1') return false;
+  }
+  const int N = pl.N(), hop = pl.cfg.hop_length, T = pl.Tn(), pad = pl.pad, R = pl.fast.xform_R;
+  if (hop > N || hop < 2 || pad >= len) return false;
+  const int ov = N % hop == 0 ? N / hop : 0;
+  if (!(pl.tf_walk_ok && (ov == 2 || ov == 4 || ov == 8) && 2 * pad == N && len == (int64_t)(T - 1) * hop && T >= (ov == 8 ? 16 : 8))) return false;
+  const size_t lds = R == 16 ? fast::obj_walk_lds_bytes<16>(pl.tf_walk.total) : fast::obj_walk_lds_bytes<8>(pl.tf_walk.total);
+  return lds <= 160 * 1024 - 512;
+}
+
 // loss and gradient of the log-mel objective in one launch (+ the seam / padding passes of the unfused path).
 // `*used` stays false when the configuration is not covered: the caller then runs the kernel chain.
 template <typename P>
 int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, double* loss, float* grad, bool* used,
-                       double* loss_dev = nullptr, const fast::ObjCtl* ctl = nullptr, const fast::ObjStatReq* st = nullptr) {
+                       double* loss_dev = nullptr, const fast::ObjCtl* ctl = nullptr, const fast::ObjStatReq* st = nullptr,
+                       const fast::ObjDecide* dec = nullptr) {
   *used = false;
   const bool mag = pl.tf_kind == SPECINV_TF_MAG;
   if (pl.force_generic || !pl.cfg.onesided || !pl.fast.xform_ok || (pl.fast.xform_R != 8 && pl.fast.xform_R != 16)) return SPECINV_OK;
@@ -1394,13 +1409,8 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
   // ---- the frame walk (kernels_objective_walk.h): hop = n_fft / 4, centred, a filterbank with at most two rows per bin
   {
     const int ov = hop > 0 && N % hop == 0 ? N / hop : 0;
-    bool walk = !mag && pl.tf_walk_ok && (ov == 2 || ov == 4 || ov == 8) && 2 * pad == N && len == (int64_t)(T - 1) * hop && T >= (ov == 8 ? 16 : 8);
-    if (const char* e = getenv("SPECINV_OBJ_WALK")) {
-      if (e[0] == '0') walk = false;
-    }
-    if (const char* e = getenv("SPECINV_OBJ_SPARSE")) {     // (the matrix-core form was asked for)
-      if (e[0] == '0') walk = false;
-    }
+    const bool walk = tf_walk_serves(pl, len);              // (SPECINV_OBJ_WALK=0 / SPECINV_OBJ_SPARSE=0: the tile kernel)
+    SI_CHECK(walk || !ctl || !ctl->x_sel, SPECINV_ESTATE, "a deferred step without the frame walk");
     if (walk) {
       // chunks: one round of two waves per SIMD where the frames allow it (>= 8 frames per wave), an even count so that the two
       // waves of a SIMD can take a long and a short chunk (the older wave runs faster: kernels_fast_td.h)
@@ -1445,6 +1455,11 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
         a.ctl_eval = ctl->do_eval;
         a.ctl_cur = ctl->cur;
         a.grad_alt = ctl->grad_alt;
+        a.x_alt = ctl->x_alt;
+        a.px_sel = ctl->x_sel;
+        a.px_pending = ctl->x_pending;
+        a.pt_pend = ctl->t_pend;
+        a.pc0_pend = ctl->c0_pend;
       }
       const void* fn = R == 16 ? (ov == 2 ? (const void*)fast::k_objective_walk<16, 2> : ov == 4 ? (const void*)fast::k_objective_walk<16, 4>
                                                                                                  : (const void*)fast::k_objective_walk<16, 8>)
@@ -1468,7 +1483,8 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
         hipLaunchKernelGGL(k_objective_epilogue, dim3((unsigned)blocks), dim3(kObjEpiThreads), 0, pl.stream, grad, (const float*)a.xtail,
                            (const float*)a.margins, (const double*)pl.partials.template as<double>(), slot, T, nch, N, hop, keep,
                            pad, pl.cfg.pad_mode, (int64_t)len, (int64_t)B, n_tail, n_margin, (int)n_waves, 1.0 / numel,
-                           ctl ? *ctl : fast::ObjCtl{}, with_rows ? *st : fast::ObjStatReq{}, vec_ok, skew);
+                           ctl ? *ctl : fast::ObjCtl{}, with_rows ? *st : fast::ObjStatReq{}, vec_ok, skew,
+                           with_rows && dec ? *dec : fast::ObjDecide{});
         SI_HIP(hipGetLastError());
         if (with_rows || loss_dev) return SPECINV_OK;
         SI_HIP(hipMemcpyAsync(loss, pl.sums.p, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
@@ -1587,7 +1603,7 @@ int tf_loss_grad_fused(P& pl, const float* x, int64_t len, const float* target, 
     hipLaunchKernelGGL(k_objective_epilogue, dim3((unsigned)blocks), dim3(kObjEpiThreads), 0, pl.stream, grad, (const float*)a.xtail,
                        (const float*)a.margins, (const double*)pl.partials.template as<double>(), slot, T, nch, N, hop, keep,
                        pad, pl.cfg.pad_mode, (int64_t)len, (int64_t)B, n_tail, n_margin, (int)n_tiles, 1.0 / numel,
-                       ctl ? *ctl : fast::ObjCtl{}, with_rows ? *st : fast::ObjStatReq{}, vec_ok, 0);
+                       ctl ? *ctl : fast::ObjCtl{}, with_rows ? *st : fast::ObjStatReq{}, vec_ok, 0, fast::ObjDecide{});
     SI_HIP(hipGetLastError());
     if (with_rows) return SPECINV_OK;      // (loss and figures are in the rows: the caller finishes them)
   }

@@ -45,6 +45,29 @@ __device__ __forceinline__ void walk_load_block(const float* __restrict__ xrow, 
   else load_block<R, OV>(xrow, nullptr, L, T, 0, 0, T, j, lane, pad_mode, q);
 }
 
+// ... of the iterate with a step pending: x_new = fma(t, (float)(c0 (double)g_prev), x_old) sample by sample (the float operations of
+// k_lbd_direction_lean / k_lbd_lincomb_step), the previous gradient read through the same index map as the samples (padding included);
+// a hop-block the chunk owns - signal blocks [own_lo, own_hi) - goes to the new iterate's buffer on the way
+template <int R, int OV>
+__device__ __forceinline__ void walk_load_step(const float* __restrict__ xrow, const float* __restrict__ gprow, float* __restrict__ xnew,
+                                               float t, double c0, long long L, int T, int j, int own_lo, int own_hi, int lane,
+                                               int pad_mode, v2f (&q)[R / OV]) {
+  using O = Ovl<R, OV>;
+  walk_load_block<R, OV>(xrow, L, T, j, lane, pad_mode, q);
+  v2f gq[R / OV];
+  walk_load_block<R, OV>(gprow, L, T, j, lane, pad_mode, gq);
+#pragma unroll
+  for (int i = 0; i < R / OV; ++i) {
+    q[i].x = fmaf(t, (float)(c0 * (double)gq[i].x), q[i].x);
+    q[i].y = fmaf(t, (float)(c0 * (double)gq[i].y), q[i].y);
+  }
+  if (j >= own_lo && j < own_hi) {
+    v2f* dst = reinterpret_cast<v2f*>(xnew + (long long)(j - O::PB) * O::HOP);
+#pragma unroll
+    for (int i = 0; i < R / OV; ++i) dst[64u * i + (unsigned)lane] = q[i];
+  }
+}
+
 template <int R, int OV>
 __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkArgs a) {
   using G = Geo<R>;
@@ -74,16 +97,41 @@ __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkAr
   if (idle) w = a.n_waves - 1;
   const int b = w / a.nchunks, c = w - b * a.nchunks;
   const int t_begin = chunk_begin(c, a.T, a.nchunks, a.skew), t_end = chunk_begin(c + 1, a.T, a.nchunks, a.skew);
-  const float* xrow = a.x + (long long)b * a.len;
+  // the iterate: plain, or one of the optimiser's two buffers with a step still to be applied (ObjWalkArgs: the deferred step)
+  const float* xbase = a.x;
+  float* xnew = nullptr;
+  bool pend = false;
+  float t_p = 0.0f;
+  double c0_p = 0.0;
+  if (a.px_sel != nullptr) {
+    const int sel = *a.px_sel;
+    pend = *a.px_pending != 0;
+    float* cur_buf = sel ? a.x_alt : const_cast<float*>(a.x);
+    float* oth_buf = sel ? const_cast<float*>(a.x) : a.x_alt;
+    xbase = pend ? oth_buf : cur_buf;              // (a pending step: read the old iterate, write the new one)
+    if (pend) {
+      xnew = cur_buf + (long long)b * a.len;
+      t_p = (float)*a.pt_pend;
+      c0_p = *a.pc0_pend;
+    }
+  }
+  const float* xrow = xbase + (long long)b * a.len;
+  const float* gprow = (grad_base == a.grad ? a.grad_alt : a.grad) + (long long)(pend ? b : 0) * a.len;   // the previous gradient (pending step only)
   float* go = grad_base + (long long)b * a.len;
   float* mgn = a.margins + (long long)b * 2 * (PB * HOP);
   const float* tg = a.target + (long long)b * a.n_mels * a.T;
   // the sample window (the signal is read-only here: no chunk seams to resolve - the loader is told it walks the whole item),
   // requested before the tables are staged: the chunk's first samples fly while the workgroup builds them
   v2f xq[NB][QU], xn[QU];
+  // (signal blocks this chunk owns when it has to write the new iterate: the blocks its frames begin with, the last chunk the rest)
+  const int own_lo = t_begin < PB ? PB : t_begin, own_hi = idle ? 0 : (t_end == a.T ? a.T + PB - 1 : t_end);
+  auto load_x = [&](int j, v2f (&q)[QU]) {
+    if (pend) walk_load_step<R, OV>(xrow, gprow, xnew, t_p, c0_p, a.len, a.T, j, own_lo, own_hi, lane, a.pad_mode, q);
+    else walk_load_block<R, OV>(xrow, a.len, a.T, j, lane, a.pad_mode, q);
+  };
 #pragma unroll
-  for (int q = 0; q < NB; ++q) walk_load_block<R, OV>(xrow, a.len, a.T, t_begin + q, lane, a.pad_mode, xq[q]);
-  walk_load_block<R, OV>(xrow, a.len, a.T, t_begin + NB, lane, a.pad_mode, xn);
+  for (int q = 0; q < NB; ++q) load_x(t_begin + q, xq[q]);
+  load_x(t_begin + NB, xn);
 
   // ---- tables: window, pass-1 twiddles, the filterbank (once per workgroup: the only barrier)
   for (int i = threadIdx.x; i < M; i += blockDim.x) lds_win[i] = v2f{a.window[2 * i], a.window[2 * i + 1]};
@@ -139,7 +187,7 @@ __global__ __launch_bounds__(64 * kWalkWaves, 2) void k_objective_walk(ObjWalkAr
       for (int q = 0; q + 1 < NB; ++q) xq[q][i] = xq[q + 1][i];
       xq[NB - 1][i] = xn[i];
     }
-    if (t + 1 < t_end) walk_load_block<R, OV>(xrow, a.len, a.T, t + OV, lane, a.pad_mode, xn);
+    if (t + 1 < t_end) load_x(t + OV, xn);
     fft_forward_t<R>(z, k, twr, tr);
     v2f un[H], um[H], umid;
     {

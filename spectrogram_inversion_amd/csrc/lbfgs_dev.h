@@ -3,7 +3,14 @@
 // whole and the host synchronises once per step instead of once per inner iteration (kernels_lbfgs.h / lbfgs.py:_step_packed:
 // ~0.05 ms of host turnaround around a 0.15 ms objective).
 //
-// An inner iteration is THREE launches while the memory is empty (round 5; six before):
+// An inner iteration is TWO launches while the memory is empty and the frame walk (kernels_objective_walk.h) serves the objective:
+//   k_objective_walk      loss + gradient; a step x += t d still pending from the iteration before is applied on the way - the walk
+//                         forms x_new = fma(t, (float)(c0 (double)g_prev), x_old) as it loads its samples and writes it to the
+//                         iterate's other buffer (LbdState::x_pending; the step left pending at the end of a step: k_lbd_settle_x)
+//   k_objective_epilogue  seams, margins, statistics, rows - and its workgroup that finishes LAST takes the iteration's decisions
+//                         (lbfgs_state.h: lbd_tail_decide) and writes the other state record.  An iteration that accepts a pair
+//                         suspends the chain instead: the full form takes it from there.
+// Elsewhere (tile kernel, magnitude objective; SPECINV_LBFGS_DEFER=0 / SPECINV_LBFGS_LEAN2=0) THREE launches (six in round 4):
 //   k_objective_logmel    loss + gradient, and the statistics of the new gradient - {g.d, sum|g|, y.s, y.y, g.g, g.g_prev, max|g|,
 //                         max|d|} - taken where each sample becomes final (ObjArgs::st_*), not by a pass of their own
 //   k_objective_epilogue  seams, margins, their share of the statistics, and the first level of the reduction: kObjRows rows
@@ -28,70 +35,6 @@
 
 namespace specinv {
 
-constexpr int kLbdMaxHist = 120;          // history_size the device path takes (Gram matrix in LDS: hist^2 doubles)
-constexpr int kLbdInfo = 2;               // pinned board: [0] the step is live, [1] slots decided, [kLbdInfo ..] what the step leaves (lbfgs_dev_ls.h)
-constexpr int kLbdBoard = 16;             // doubles of the board
-
-struct LbdState {                         // device-resident (two buffers, see above); copied to the host at the end of a step
-  // options
-  double lr, tol_grad, tol_change;
-  int max_iter, max_eval, hist;
-  // torch.optim.LBFGS's state
-  int total_iters, func_evals, m, seq0, cur, pairs_accepted, pairs_rejected, n_prev;
-  double t, h_diag, prev_loss, loss;
-  // control of the step being executed
-  int active, do_lincomb, do_step, do_eval, n_iter, evals, have_prev, k_lin, k_dot;
-  int suspended;                          // a lean chain met a non-empty memory at iteration resume_k: the host continues in the full form
-  int resume_k;
-  // lean iterations that accept no pair form d = (float)(c0 (double)g) and x += t d in registers and do not STORE d: whoever needs it
-  // (the next evaluation's statistics, the pair s = t d of the iteration that does accept) recomputes it from the gradient it was
-  // formed from - gbuf[cur], the previous gradient by then - bit for bit.  Cleared by the lean iteration that accepts a pair.
-  int d_implicit;
-  double c0_d;
-  // the pair accepted by the last decision is FORMED by the direction kernel (y = g - g_prev, s = t_pair d_old, written to the
-  // ring and used from registers): positions of y_new / s_new in the list of the linear combination, -1: no new pair
-  int pair_y, pair_s;
-  double t_pair;
-  double first_loss, gtd;
-  // reductions of the last evaluation: loss; {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev}
-  double b_loss, b_ps[8];
-};
-
-template <typename T>
-struct LbdPtrs {                          // kernel argument: where everything lives
-  LbdState* st;        // the state record this launch reads (and, but for the lean direction kernel, writes)
-  LbdState* st_next;   // lean direction kernel: the record it writes
-  double* sgp;         // [hist]    s_i . g of the previous direction (lbfgs.py: _sg)
-  double* ygp;         // [hist]
-  double* rho;         // [hist]
-  double* sy;          // [hist * hist]  s_i . y_j (i <= j)
-  double* yy;          // [hist * hist]  y_i . y_j
-  double* coef;        // [1 + 2 hist]   coefficients of d over [g] + ys + ss
-  const T** lin_ptr;   // [1 + 2 hist]
-  const T** dot_ptr;   // [2 hist]       ss then ys
-  T** ys_slot;         // [hist + 1]     ring of vector slots (slot of pair number q: q mod (hist + 1))
-  T** ss_slot;         // [hist + 1]
-  T* gbuf[2];          // gradient ping-pong: the evaluation writes gbuf[cur ^ 1], reads gbuf[cur] as the previous gradient
-  T* d;
-  double* board;       // pinned host memory: [0] = active (a peek, not a synchronisation)
-};
-
-// start of a step: the loop is live, the entry evaluation runs
-static __global__ void k_lbd_begin(LbdState* st) {
-  st->active = 1;
-  st->do_eval = 1;
-  st->do_lincomb = 0;
-  st->do_step = 0;
-  st->n_iter = 0;
-  st->evals = 0;
-}
-
-__device__ inline double lbd_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 // Scratch of the decision kernels (one workgroup of 256): the state as it was at entry (one coalesced read instead of a chain of
 // dependent global loads), the finished sums of the evaluation, the vectors of the two triangular recursions.
 struct LbdShared {
@@ -99,37 +42,6 @@ struct LbdShared {
   double dotv[2 * kLbdMaxHist], bps[8], red[16], red9[4][9], loss;
   LbdState R;
 };
-
-__device__ inline void lbd_load_state(LbdState& R, const LbdState* st) {
-  static_assert(sizeof(LbdState) % 8 == 0 && sizeof(LbdState) / 8 <= 256, "LbdState is copied by one pass of doubles");
-  const int tid = threadIdx.x;
-  if (tid < (int)(sizeof(LbdState) / 8)) reinterpret_cast<double*>(&R)[tid] = reinterpret_cast<const double*>(st)[tid];
-  __syncthreads();
-}
-
-// The second level of the evaluation's reduction tree (the first: k_objective_epilogue's rows): every thread of the workgroup
-// leaves with bps = {g.d, sum|g|, max|g|, max|d|, y.s, y.y, g.g, g.g_prev} and the loss, summed in a fixed order.
-__device__ inline void lbd_finish_rows(double (&bps)[8], double& loss, double (*red9)[9], const double* __restrict__ rows, double scale) {
-  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int r = threadIdx.x; r < fast::kObjRows; r += blockDim.x) {
-    const double* q = rows + r;                     // component-major rows (k_objective_epilogue)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) v[c] += q[c * fast::kObjRows];
-    v[6] += q[8 * fast::kObjRows];
-    v[7] = fmax(v[7], q[6 * fast::kObjRows]);
-    v[8] = fmax(v[8], q[7 * fast::kObjRows]);
-  }
-  block_reduce9(v, red9);
-  bps[0] = v[0];
-  bps[1] = v[1];
-  bps[2] = v[7];
-  bps[3] = v[8];
-  bps[4] = v[2];
-  bps[5] = v[3];
-  bps[6] = v[4];
-  bps[7] = v[5];
-  loss = scale * v[6];
-}
 
 // ... and the products of g with the memory, from k_lbd_multi_dot's per-block partial sums: one wave per product
 __device__ inline void lbd_finish_dots(LbdShared& sh, const double* __restrict__ part_dot, int nb, int kd) {
@@ -346,19 +258,6 @@ __device__ inline LbdDirection lbd_iteration(const LbdPtrs<T>& p, LbdShared& sh,
   return LbdDirection{gtd, t, m};
 }
 
-// What follows an evaluation in torch.optim.LBFGS.step - opt_cond at the entry evaluation (k == 1); max_eval, opt_cond, the step
-// and loss tolerances at the end of an iteration - on the finished sums: does the step end here?  `evals`: evaluations of this
-// step including this one.
-__device__ inline bool lbd_step_ends(const LbdState& R, const double (&bps)[8], double loss, int k, int& evals) {
-  const double gmax = bps[2];
-  if (k == 1) {
-    evals = 1;
-    return gmax <= R.tol_grad;
-  }
-  evals = R.evals + 1;
-  return evals >= R.max_eval || gmax <= R.tol_grad || fabs(R.t) * bps[3] <= R.tol_change || fabs(loss - R.prev_loss) < R.tol_change;
-}
-
 // The decisions of iteration k (1-based) of a step with pairs in the memory, preceded by the second level of the evaluation's
 // reductions: 256 threads finish the sums, wave 0 decides; the Gram matrix s_i.y_j is staged in LDS for the two triangular
 // recursions.  Every branch below is uniform over the workgroup, so all four waves reach every barrier.
@@ -425,9 +324,10 @@ __global__ __launch_bounds__(256) void k_lbd_decide(LbdPtrs<T> p, int k, const d
 // d = sum_j coef_j v_j over the device-resident list (float64 accumulation in list order, rounded once), then x += t d:
 // k_lincomb with its arguments read from the state record
 template <typename T>
-__global__ __launch_bounds__(256) void k_lbd_lincomb_step(LbdPtrs<T> p, T* __restrict__ xs, int64_t n) {
+__global__ __launch_bounds__(256) void k_lbd_lincomb_step(LbdPtrs<T> p, int64_t n) {
   const LbdState& S = *p.st;
   if (!S.do_lincomb) return;
+  T* __restrict__ xs = p.xbuf[p.xbuf[1] ? S.x_sel : 0];
   constexpr int W = 16 / sizeof(T);
   typedef T VT __attribute__((ext_vector_type(W)));
   const int k = S.k_lin;
@@ -495,73 +395,11 @@ __global__ __launch_bounds__(256) void k_lbd_lincomb_step(LbdPtrs<T> p, T* __res
   }
 }
 
-// ---- the lean iteration: decisions and direction in one kernel (file header) ------------------------------------------------
-// What one iteration decides while the memory holds no pair when it begins: plain scalars, computed by every thread alike.
-struct LbdLean {
-  int stop, suspend, accept;      // the step ends at this evaluation / a memory to multiply with: not for this kernel / pair accepted
-  int evals, total, m, n_prev, cur, do_step, do_eval, active;
-  double loss, c0, cy, cs, t, gtd, h_diag, rho0, sg0, yg0, ys, yy;
-};
-
-__device__ inline LbdLean lbd_lean_decide(const LbdState& R, const double (&bps)[8], double loss, int k) {
-  LbdLean o{};
-  o.loss = loss;
-  o.stop = lbd_step_ends(R, bps, loss, k, o.evals) ? 1 : 0;
-  if (o.stop) return o;
-  if (R.total_iters >= 1 && R.m > 0) {            // (the iteration after this chain's first accepted pair)
-    o.suspend = 1;
-    return o;
-  }
-  o.cur = R.cur ^ 1;
-  o.total = R.total_iters + 1;
-  o.h_diag = R.h_diag;
-  if (o.total == 1) {                             // (lbfgs.py:_forget) the statistics were taken with d = g
-    o.h_diag = 1.0;
-    o.c0 = -1.0;
-    o.gtd = -bps[0];
-    o.n_prev = -1;
-    o.t = fmin(1.0, 1.0 / bps[1]) * R.lr;
-  } else {
-    const double gd = bps[0], ys = bps[4], yyn = bps[5], gg = bps[6], ggp = bps[7];
-    o.accept = ys > 1e-10 ? 1 : 0;
-    double part = 0.0;
-    if (o.accept) {                               // lbd_iteration with m = 1: the recursion on the one pair
-      o.ys = ys;
-      o.yy = yyn;
-      o.rho0 = 1.0 / ys;
-      o.sg0 = R.t * gd;                           // s_new . g = t_prev (d . g)
-      o.yg0 = gg - ggp;                           // y_new . g = g . g - g_prev . g
-      o.h_diag = ys / yyn;
-      const double al0 = o.rho0 * o.sg0;
-      const double yq0 = o.yg0 - yyn * al0;
-      const double cc0 = al0 - o.rho0 * (o.h_diag * yq0);
-      o.cy = o.h_diag * al0;
-      o.cs = -cc0;
-      part = o.cy * o.yg0 + o.cs * o.sg0;
-      o.m = 1;
-    }
-    o.n_prev = o.m;
-    o.c0 = -o.h_diag;
-    o.gtd = -o.h_diag * gg + part;
-    o.t = R.lr;
-  }
-  if (o.gtd > -R.tol_change) {                    // no descent left: the direction is formed, no step, the loop ends
-    o.do_step = 0;
-    o.do_eval = 0;
-    o.active = 0;
-  } else {
-    o.do_step = 1;
-    o.do_eval = k != R.max_iter ? 1 : 0;
-    o.active = k != R.max_iter ? 1 : 0;
-  }
-  return o;
-}
-
 constexpr int kLbdLeanItems = 2;                  // 16-byte pieces per thread and trip of the lean direction kernel
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_lbd_direction_lean(LbdPtrs<T> p, int k, T* __restrict__ xs, int64_t n,
-                                                            const double* __restrict__ rows, double scale) {
+__global__ __launch_bounds__(256) void k_lbd_direction_lean(LbdPtrs<T> p, int k, int64_t n, const double* __restrict__ rows,
+                                                            double scale, int defer_ok) {
   __shared__ LbdState R;
   __shared__ double red9[4][9];
   const int tid = threadIdx.x;
@@ -580,6 +418,8 @@ __global__ __launch_bounds__(256) void k_lbd_direction_lean(LbdPtrs<T> p, int k,
   const T* __restrict__ g = p.gbuf[R.cur ^ 1];
   const T* __restrict__ gp = p.gbuf[R.cur];
   T* __restrict__ out = p.d;
+  // the iterate this iteration's evaluation was taken at (a pending step has been applied by that evaluation's walk)
+  T* __restrict__ xs = p.xbuf[R.x_sel];
   const int64_t nv = n / W;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   VT ng[kLbdLeanItems], nx[kLbdLeanItems];
@@ -594,7 +434,7 @@ __global__ __launch_bounds__(256) void k_lbd_direction_lean(LbdPtrs<T> p, int k,
     }
   };
   const int64_t base0 = (int64_t)blockIdx.x * blockDim.x + tid;
-  request(base0);
+  if (!defer_ok) request(base0);                  // (with the deferred step most iterations stream nothing: no speculative loads)
   double bps[8], loss;
   lbd_finish_rows(bps, loss, red9, rows, scale);
   const LbdLean o = lbd_lean_decide(R, bps, loss, k);
@@ -606,80 +446,28 @@ __global__ __launch_bounds__(256) void k_lbd_direction_lean(LbdPtrs<T> p, int k,
     __threadfence_block();
     __syncthreads();
   }
-  if (o.suspend) {
-    if (writer) {
-      N.suspended = 1;
-      N.resume_k = k;
-      N.active = 0;
-      N.do_lincomb = 0;
-      N.do_step = 0;
-      N.do_eval = 0;
-      p.board[0] = 0.0;
-    }
-    return;
-  }
-  if (writer) {
-    if (k == 1) N.first_loss = loss;
-    N.loss = loss;
-    N.evals = o.evals;
-    N.func_evals = R.func_evals + 1;
-  }
-  if (o.stop) {                                   // (the gradient just evaluated is dropped: prev_flat_grad stays gbuf[cur])
-    if (writer) {
-      N.active = 0;
-      N.do_lincomb = 0;
-      N.do_step = 0;
-      N.do_eval = 0;
-      p.board[0] = 0.0;
-    }
-    return;
-  }
+  bool go = true;
+  if (writer) go = lbd_lean_commit(N, R, o, bps, loss, k, p.board, defer_ok != 0);
+  if (o.suspend || o.stop) return;
   const int hist = R.hist;
   const int slot = R.seq0 % (hist + 1);           // (the memory is empty: the new pair is number seq0 of the ring)
-  if (writer) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) N.b_ps[c] = bps[c];
-    N.b_loss = loss;
-    N.total_iters = o.total;
-    N.n_iter = k;
-    N.m = o.m;
-    if (o.total == 1) N.seq0 = 0;
-    N.h_diag = o.h_diag;
-    N.prev_loss = loss;
-    N.t = o.t;
-    N.gtd = o.gtd;
-    N.k_lin = 1 + 2 * o.m;
-    N.k_dot = 2 * o.m;
-    N.have_prev = 1;
-    N.n_prev = o.n_prev;
-    N.cur = o.cur;
-    N.pair_y = o.accept ? 1 : -1;
-    N.pair_s = o.accept ? 2 : -1;
-    N.t_pair = R.t;
-    N.do_lincomb = 1;
-    N.do_step = o.do_step;
-    N.do_eval = o.do_eval;
-    N.active = o.active;
-    N.d_implicit = o.accept ? 0 : 1;
-    N.c0_d = o.c0;
-    if (o.total > 1) {
-      N.pairs_accepted = R.pairs_accepted + o.accept;
-      N.pairs_rejected = R.pairs_rejected + (o.accept ? 0 : 1);
-    }
-    if (!o.active) p.board[0] = 0.0;
-    if (o.accept) {                               // what the full form finds when it takes over: Gram entries, products, lists
-      p.rho[0] = o.rho0;
-      p.sgp[0] = o.sg0;
-      p.ygp[0] = o.yg0;
-      p.sy[0] = o.ys;
-      p.yy[0] = o.yy;
-      p.dot_ptr[0] = p.ss_slot[slot];
-      p.dot_ptr[1] = p.ys_slot[slot];
-    }
+  if (writer && o.accept) {                       // what the full form finds when it takes over: Gram entries, products, lists
+    p.rho[0] = o.rho0;
+    p.sgp[0] = o.sg0;
+    p.ygp[0] = o.yg0;
+    p.sy[0] = o.ys;
+    p.yy[0] = o.yy;
+    p.dot_ptr[0] = p.ss_slot[slot];
+    p.dot_ptr[1] = p.ys_slot[slot];
   }
+  (void)go;
+  const bool acc = o.accept != 0, step = o.do_step != 0;
+  // ---- the deferred step: no pair to form and store - d = (float)(c0 g) stays implicit - so the only thing left to stream would be
+  // x += t d, and the next evaluation's walk does that on its way (LbdState::x_pending)
+  if (defer_ok && !acc) return;                   // (lbd_lean_commit has recorded the pending step)
+  if (defer_ok) request(base0);
   // ---- d = c0 g (+ cy y + cs s of the pair just accepted, formed here and stored to its ring slot), x += t d: the float
   // operations of k_lbd_lincomb_step over the list [g, y, s]
-  const bool acc = o.accept != 0, step = o.do_step != 0;
   const T tp = (T)R.t, t = (T)o.t;
   T* ysl = acc ? p.ys_slot[slot] : nullptr;
   T* ssl = acc ? p.ss_slot[slot] : nullptr;
@@ -826,6 +614,26 @@ __global__ __launch_bounds__(256) void k_lbd_materialise_d(LbdPtrs<T> p, int64_t
 }
 static __global__ void k_lbd_clear_implicit(LbdState* st) { st->d_implicit = 0; }
 
+// End of a step: the iterate back in the caller's buffer - a pending step applied (xbuf[0] = fma(t, (float)(c0 g), old), the old
+// iterate being xbuf[x_sel ^ 1], possibly xbuf[0] itself), or a plain copy if the current iterate sits in the optimiser's buffer.
+template <typename T>
+__global__ __launch_bounds__(256) void k_lbd_settle_x(LbdPtrs<T> p, int64_t n) {
+  const LbdState& S = *p.st;
+  const int pending = S.x_pending, sel = S.x_sel;
+  if (!pending && sel == 0) return;
+  const T* __restrict__ src = p.xbuf[pending ? sel ^ 1 : sel];
+  T* __restrict__ dst = p.xbuf[0];
+  const T* __restrict__ g = p.gbuf[S.cur];
+  const T t = (T)S.t_pend;
+  const double c0 = S.c0_pend;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = pending ? fma(t, (T)(c0 * (double)g[i]), src[i]) : src[i];
+}
+static __global__ void k_lbd_settled(LbdState* st) {
+  st->x_pending = 0;
+  st->x_sel = 0;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 template <typename T>
 struct LbfgsDev {
@@ -840,6 +648,9 @@ struct LbfgsDev {
   T* g0 = nullptr;
   T* g1 = nullptr;
   T* d = nullptr;
+  FastBuf ticket;                         // the two-launch lean iteration: workgroups of the epilogue done (fast::ObjDecide)
+  T* x_user = nullptr;                    // the caller's iterate (set per step) and the optimiser's second buffer (deferred step)
+  T* x_alt = nullptr;
   std::vector<T*> pairs_y, pairs_s;       // host mirror of the slot tables (allocated so far)
   double* board_host = nullptr;          // pinned, device-mapped: owned here (a plan outlives many optimisers)
   double* board_dev = nullptr;
@@ -872,6 +683,8 @@ struct LbfgsDev {
     p.ss_slot = ss_slot.as<T*>();
     p.gbuf[0] = g0;
     p.gbuf[1] = g1;
+    p.xbuf[0] = x_user;
+    p.xbuf[1] = x_alt;
     p.d = d;
     p.board = board_dev;
     return p;
@@ -932,8 +745,11 @@ int lbd_create(P& pl, LbfgsDev<float>& L, int64_t n, const specinv_lbfgs_opts& o
   SI_TRY(lbd_take(pl, L, &L.g0));
   SI_TRY(lbd_take(pl, L, &L.g1));
   SI_TRY(lbd_take(pl, L, &L.d));
+  SI_TRY(lbd_take(pl, L, &L.x_alt));
   SI_TRY(L.rows.reserve((size_t)fast::kObjRows * fast::kObjStatRow * sizeof(double)));
   SI_TRY(L.mpart.reserve((size_t)kLbdMaxVec * 1024 * sizeof(double)));
+  SI_TRY(L.ticket.reserve(16));
+  SI_HIP(hipMemsetAsync(L.ticket.p, 0, 16, pl.stream));
   SI_HIP(hipMemsetAsync(L.sy.p, 0, (size_t)hist * hist * sizeof(double), pl.stream));
   SI_HIP(hipMemsetAsync(L.yy.p, 0, (size_t)hist * hist * sizeof(double), pl.stream));
   SI_HIP(hipMemsetAsync(L.ys_slot.p, 0, (size_t)(hist + 1) * sizeof(void*), pl.stream));
@@ -995,13 +811,28 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
   L.board_host[0] = 1.0;
   hipLaunchKernelGGL(k_lbd_begin, dim3(1), dim3(1), 0, pl.stream, L.state(L.par));
   SI_HIP(hipGetLastError());
+  // the deferred step: only where the frame walk serves the objective (it is the kernel that applies the step)
+  bool defer = tf_walk_serves(pl, len) && ((uintptr_t)x & 7) == 0;
+  if (const char* e = getenv("SPECINV_LBFGS_DEFER")) {
+    if (e[0] == '0') defer = false;                 // (tests / A-B runs)
+  }
+  L.x_user = x;
   int n_eval_launched = 0;
-  auto evaluate = [&]() -> int {                    // objective + epilogue on the record that is current NOW
+  // objective + epilogue on the record that is current NOW; k_decide > 0: the epilogue also takes iteration k_decide's decisions
+  // (the two-launch lean iteration) and writes the OTHER record
+  auto evaluate = [&](int k_decide) -> int {
     LbdState* st = L.state(L.par);
     fast::ObjCtl ctl{};
     ctl.do_eval = &st->do_eval;
     ctl.cur = &st->cur;
     ctl.grad_alt = L.g1;
+    if (defer) {
+      ctl.x_alt = L.x_alt;
+      ctl.x_sel = &st->x_sel;
+      ctl.x_pending = &st->x_pending;
+      ctl.t_pend = &st->t_pend;
+      ctl.c0_pend = &st->c0_pend;
+    }
     fast::ObjStatReq sr{};
     sr.d = L.d;
     sr.have = &st->have_prev;
@@ -1012,13 +843,21 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
     bool used = false;
     const bool timed = L.time_objective > 0 && n_eval_launched % L.time_objective == 0 && (size_t)(2 * n_eval_launched + 1) < L.ev.size();
     if (timed) SI_HIP(hipEventRecord(L.ev[2 * n_eval_launched], pl.stream));
-    SI_TRY(tf_loss_grad_fused(pl, x, len, target, nullptr, L.g0, &used, nullptr, &ctl, &sr));
+    fast::ObjDecide dec{};
+    if (k_decide > 0) {
+      dec.ticket = L.ticket.template as<unsigned>();
+      dec.st = st;
+      dec.st_next = L.state(L.par ^ 1);
+      dec.board = L.board_dev;
+      dec.rows = sr.rows;
+      dec.k = k_decide;
+    }
+    SI_TRY(tf_loss_grad_fused(pl, x, len, target, nullptr, L.g0, &used, nullptr, &ctl, &sr, k_decide > 0 ? &dec : nullptr));
     SI_CHECK(used, SPECINV_EUNSUPPORTED, "the one-launch objective does not cover this configuration");
     if (timed) SI_HIP(hipEventRecord(L.ev[2 * n_eval_launched + 1], pl.stream));
     ++n_eval_launched;
     return SPECINV_OK;
   };
-  SI_TRY(evaluate());
   const size_t lds = (size_t)hist * hist * sizeof(double);
   SI_HIP(hipFuncSetAttribute((const void*)k_lbd_decide<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t pieces = n / 4 + 1;
@@ -1033,26 +872,45 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
     hipLaunchKernelGGL(k_lbd_clear_implicit, dim3(1), dim3(1), 0, pl.stream, L.state(L.par));
     SI_HIP(hipGetLastError());
   }
+  // the lean iteration in two launches: with the step deferred into the frame walk nothing is left to stream unless a pair is
+  // accepted, and that iteration hands over to the full form - the decisions ride in the epilogue (lbd_tail_decide)
+  bool lean2 = lean && defer;
+  if (const char* e = getenv("SPECINV_LBFGS_LEAN2")) {
+    if (e[0] == '0') lean2 = false;
+  }
+  if (!lean2) SI_TRY(evaluate(0));                  // (the entry evaluation; lean2: iteration 1's evaluation carries its decision)
   int k = 1, k_first = 1;
   for (;;) {
     for (; k <= L.h.max_iter; ++k) {
       if (k > k_first && L.board_host[0] == 0.0) break;   // a peek at what the device has decided so far (may lag: only saves no-ops)
       LbdPtrs<float> p = L.ptrs();
+      if (lean && lean2) {
+        SI_TRY(evaluate(k));
+        L.par ^= 1;
+        ++L.lean_launches;
+        continue;
+      }
       if (lean) {
-        hipLaunchKernelGGL((k_lbd_direction_lean<float>), dim3(lean_grid), dim3(256), 0, pl.stream, p, k, x, n, rows, scale);
+        hipLaunchKernelGGL((k_lbd_direction_lean<float>), dim3(lean_grid), dim3(256), 0, pl.stream, p, k, n, rows, scale,
+                           defer ? 1 : 0);
         L.par ^= 1;
         ++L.lean_launches;
       } else {
         hipLaunchKernelGGL((k_lbd_multi_dot<float>), dim3(nb), dim3(256), 0, pl.stream, p, n, L.mpart.template as<double>());
         hipLaunchKernelGGL((k_lbd_decide<float>), dim3(1), dim3(256), lds, pl.stream, p, k, rows, scale,
                            (const double*)L.mpart.template as<double>(), nb);
-        hipLaunchKernelGGL((k_lbd_lincomb_step<float>), dim3((unsigned)ceil_div(pieces, 256)), dim3(256), 0, pl.stream, p, x, n);
+        hipLaunchKernelGGL((k_lbd_lincomb_step<float>), dim3((unsigned)ceil_div(pieces, 256)), dim3(256), 0, pl.stream, p, n);
         ++L.full_launches;
       }
       SI_HIP(hipGetLastError());
-      if (k < L.h.max_iter) SI_TRY(evaluate());
+      if (k < L.h.max_iter) SI_TRY(evaluate(0));
     }
     // a step cut short by the peek leaves `active` set on the device only if the device had not stopped: it had (the peek read 0)
+    if (defer) {                                    // the iterate back in the caller's buffer (a suspended chain: its last one)
+      hipLaunchKernelGGL((k_lbd_settle_x<float>), dim3(1024), dim3(256), 0, pl.stream, L.ptrs(), n);
+      hipLaunchKernelGGL(k_lbd_settled, dim3(1), dim3(1), 0, pl.stream, L.state(L.par));
+      SI_HIP(hipGetLastError());
+    }
     SI_HIP(hipMemcpyAsync(&L.h, L.state(L.par), sizeof(LbdState), hipMemcpyDeviceToHost, pl.stream));
     SI_HIP(hipStreamSynchronize(pl.stream));
     if (!L.h.suspended) break;
@@ -1060,6 +918,11 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
     // are as it left them - everything enqueued behind it ran as no-ops): the full form takes over from that decision
     ++L.suspensions;
     lean = false;
+    if (L.h.d_implicit) {                           // (a two-launch chain hands over at the iteration that accepts its first pair:
+      hipLaunchKernelGGL((k_lbd_materialise_d<float>), dim3(1024), dim3(256), 0, pl.stream, L.ptrs(), n);   // s = t d is read from d)
+      L.h.d_implicit = 0;
+      SI_HIP(hipGetLastError());
+    }
     k = k_first = L.h.resume_k;
     L.h.suspended = 0;
     L.h.active = 1;

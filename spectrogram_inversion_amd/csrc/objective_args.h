@@ -63,11 +63,28 @@ struct ObjArgs {
 #endif
 };
 
-// what lbfgs_dev.h hands to the objective: the gate and the gradient ping-pong of the optimiser's state record
+// what lbfgs_dev.h hands to the objective: the gate and the gradient ping-pong of the optimiser's state record; for the frame walk
+// also the iterate's two buffers and the deferred step (ObjWalkArgs)
 struct ObjCtl {
   const int* do_eval;
   const int* cur;
   float* grad_alt;
+  float* x_alt = nullptr;
+  const int* x_sel = nullptr;
+  const int* x_pending = nullptr;
+  const double* t_pend = nullptr;
+  const double* c0_pend = nullptr;
+};
+
+// the two-launch lean iteration of the device-resident optimiser (lbfgs_state.h: lbd_tail_decide): the epilogue's workgroup that
+// finishes last takes iteration k's decisions.  ticket == nullptr: not asked for.
+struct ObjDecide {
+  unsigned* ticket = nullptr;   // workgroups done (reset by the last one)
+  const void* st = nullptr;     // LbdState the evaluation ran under
+  void* st_next = nullptr;      // LbdState the decision writes
+  double* board = nullptr;
+  const double* rows = nullptr;
+  int k = 0;
 };
 
 // the statistics of the evaluated gradient: what the caller hands in, and where the figures go.  d / gp == nullptr: the gradient
@@ -352,6 +369,16 @@ struct ObjWalkArgs {
   const int* ctl_eval;     // device-resident optimiser: as ObjArgs
   const int* ctl_cur;
   float* grad_alt;
+  // ... and its DEFERRED STEP (lbfgs_dev.h): the iterate lives in one of two buffers, x and x_alt; *px_sel names the one this
+  // evaluation is taken at.  *px_pending != 0: that buffer is not written yet - it is the other one advanced by the last
+  // iteration's step, x_new = fma(t, (float)(c0 (double)g_prev), x_old), g_prev the gradient buffer this evaluation does NOT write -
+  // and the walk forms it while it loads its samples and writes every hop-block it owns (the optimiser's direction kernel then
+  // has nothing to stream: 100 MB per iteration less)
+  float* x_alt;
+  const int* px_sel;
+  const int* px_pending;
+  const double* pt_pend;
+  const double* pc0_pend;
 };
 template <int R, int OV>
 __global__ void k_objective_walk(ObjWalkArgs a);

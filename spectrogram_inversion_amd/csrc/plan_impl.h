@@ -1011,7 +1011,7 @@ struct PlanT final : PlanBase {
   // the device-resident optimiser (lbfgs_dev.h): float32 on the one-launch objective
   std::vector<std::unique_ptr<LbfgsDev<float>>> lbfgs_devs;
   std::vector<std::unique_ptr<FastBuf>> lbd_pool;     // parameter-sized vectors of optimisers that are gone, for the next one
-  static constexpr size_t kLbdPoolKeep = 3 + 2 * 11;  // (what an optimiser at main.py:43's history_size = 10 needs)
+  static constexpr size_t kLbdPoolKeep = 4 + 2 * 11;  // (what an optimiser at main.py:43's history_size = 10 needs)
   int lbfgs_dev_create(int64_t n, const specinv_lbfgs_opts* opts, int32_t* handle_out) override {
     SI_CHECK(opts && handle_out, SPECINV_EINVAL, "null pointer");
     if constexpr (std::is_same<T, float>::value) {

@@ -757,6 +757,35 @@ def test_lean_iteration_retraces_the_full_form(monkeypatch, kind, kw, steps):
     np.testing.assert_allclose(lb, la, rtol=1e-9)
 
 
+@pytest.mark.parametrize("kw,steps", [
+    (dict(), 2),                                                 # pairs are accepted: every form hands over to the full one
+    (dict(lr=1e-7, max_iter=8, tolerance_change=0.0, tolerance_grad=0.0), 3),   # every pair rejected (BASELINE C5's regime): lean throughout
+    (dict(lr=1e-7, max_iter=5, tolerance_change=0.0, tolerance_grad=0.0, max_eval=4), 2),
+])
+def test_deferred_step_and_two_launch_iteration_are_bit_identical(monkeypatch, kw, steps):
+    """Where the frame walk serves the objective, a lean iteration that accepts no pair leaves x += t d to the NEXT evaluation's
+    walk (x_new = fma(t, (float)(c0 (double)g), x_old) formed while the samples are loaded, written to the iterate's other
+    buffer), and its decisions are taken by the last workgroup of the evaluation's epilogue - two launches per iteration.  Against
+    the three-launch iteration with the step deferred (SPECINV_LBFGS_LEAN2=0) and with the step streamed by
+    k_lbd_direction_lean (SPECINV_LBFGS_DEFER=0): the same float operations on the same sums - identical iterates, bit for bit,
+    after every step (the step still pending at the end of one is applied by k_lbd_settle_x)."""
+    tr, target, x0 = _device_problem("logmel")
+    runs = []
+    for env in (dict(), dict(SPECINV_LBFGS_LEAN2="0"), dict(SPECINV_LBFGS_DEFER="0")):
+        for name in ("SPECINV_LBFGS_LEAN2", "SPECINV_LBFGS_DEFER"):
+            monkeypatch.delenv(name, raising=False)
+        for name, v in env.items():
+            monkeypatch.setenv(name, v)
+        runs.append(_run_steps(monkeypatch, True, tr, target, x0, steps, **kw))
+    (l0, s0) = runs[0]
+    assert s0[-1][1] > steps                                                # (more than one iteration per step ran)
+    for l1, s1 in runs[1:]:
+        assert l1 == l0
+        for a, b in zip(s0, s1):
+            assert a[1:] == b[1:]
+            assert torch.equal(a[0], b[0])
+
+
 def test_lean_chain_is_suspended_once_and_resumed(monkeypatch):
     """Which form ran: a fresh optimiser starts lean; the iteration after its first accepted pair suspends the chain and the step
     continues in the full form (one extra synchronisation, once per optimisation); with every pair rejected - BASELINE C5's
