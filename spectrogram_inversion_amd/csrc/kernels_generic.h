@@ -608,8 +608,10 @@ __device__ __forceinline__ cplx<T> update_one(cplx<T> r, cplx<T>* __restrict__ S
   return y;
 }
 
-template <typename T, int MODE, bool EVAL, bool IP = false>
-__global__ void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ S0, cplx<T>* __restrict__ S1,
+// MAXT: the largest workgroup the instantiation is launched with (1024: the register allocator keeps to 128 registers per lane -
+// the in-place float64 form then spills 16 ... 24 of them; workgroups of at most 256 threads take the 256-thread instantiation)
+template <typename T, int MODE, bool EVAL, bool IP = false, int MAXT = 1024>
+__global__ __launch_bounds__(MAXT) void k_iter_pair(FrameCfg<T> c, const T* __restrict__ x, cplx<T>* __restrict__ S0, cplx<T>* __restrict__ S1,
                             const T* __restrict__ mag, T coef, T inv1p, T* __restrict__ frames,
                             double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -303,6 +303,8 @@ struct PlanT final : PlanBase {
                            (const void*)k_iter_pair<T, 1, false, false>, (const void*)k_iter_pair<T, 1, true, false>,
                            (const void*)k_iter_pair<T, 0, false, true>, (const void*)k_iter_pair<T, 0, true, true>,
                            (const void*)k_iter_pair<T, 1, false, true>, (const void*)k_iter_pair<T, 1, true, true>,
+                           (const void*)k_iter_pair<T, 0, false, true, 256>, (const void*)k_iter_pair<T, 0, true, true, 256>,
+                           (const void*)k_iter_pair<T, 1, false, true, 256>, (const void*)k_iter_pair<T, 1, true, true, 256>,
                            (const void*)k_iter_pair_dr<T, 0, false>, (const void*)k_iter_pair_dr<T, 0, true>,
                            (const void*)k_iter_pair_dr<T, 1, false>, (const void*)k_iter_pair_dr<T, 1, true>};
       for (const void* fn : fns) SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -690,11 +692,15 @@ struct PlanT final : PlanBase {
           continue;
         }
         const dim3 grid((Tn() + 1) / 2, B()), blk(use_dr ? dr_threads : frame_threads());   // two frames per complex FFT
+        static const bool ip_small = !(getenv("SPECINV_GENERIC_IP256") && getenv("SPECINV_GENERIC_IP256")[0] == '0');
         {
           const void* fn = nullptr;
           const int mode = method == Method::Gla ? 0 : 1;
           if (use_dr) fn = mode == 0 ? (ev ? (const void*)k_iter_pair_dr<T, 0, true> : (const void*)k_iter_pair_dr<T, 0, false>)
                                      : (ev ? (const void*)k_iter_pair_dr<T, 1, true> : (const void*)k_iter_pair_dr<T, 1, false>);
+          else if (use_inplace && blk.x <= 256 && ip_small)
+            fn = mode == 0 ? (ev ? (const void*)k_iter_pair<T, 0, true, true, 256> : (const void*)k_iter_pair<T, 0, false, true, 256>)
+                           : (ev ? (const void*)k_iter_pair<T, 1, true, true, 256> : (const void*)k_iter_pair<T, 1, false, true, 256>);
           else if (use_inplace) fn = mode == 0 ? (ev ? (const void*)k_iter_pair<T, 0, true, true> : (const void*)k_iter_pair<T, 0, false, true>)
                                           : (ev ? (const void*)k_iter_pair<T, 1, true, true> : (const void*)k_iter_pair<T, 1, false, true>);
           else fn = mode == 0 ? (ev ? (const void*)k_iter_pair<T, 0, true, false> : (const void*)k_iter_pair<T, 0, false, false>)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One coverage-path configuration, a few iterations: the process tools/log/r04_final.sh wraps in rocprofv3 for
-profiles/r04_generic_{kernel_stats.csv,pmc.json}.  usage: bench_generic_one.py <n_fft> <hop> <frames> <batch> <f32|f64> [twosided]"""
+profiles/r04_generic_{kernel_stats.csv,pmc.json}.  usage: bench_generic_one.py <n_fft> <hop> <frames> <batch> <f32|f64> [twosided|onesided] [win_length]"""
 import os
 import sys
 
@@ -15,7 +15,11 @@ onesided = not (len(sys.argv) > 6 and sys.argv[6] == "twosided")
 dev = torch.device("cuda", 0)
 F = n_fft // 2 + 1 if onesided else n_fft
 mag = torch.rand((batch, F, frames), dtype=dtype, device=dev)
-plan = Plan(args_helper(mag, hop_length=hop, window=torch.hann_window(n_fft, dtype=dtype), onesided=onesided), batch, frames, dtype, dev)
+wl = int(sys.argv[7]) if len(sys.argv) > 7 else n_fft
+kw = dict(hop_length=hop, window=torch.hann_window(wl, dtype=dtype), onesided=onesided)
+if wl != n_fft:
+    kw["win_length"] = wl
+plan = Plan(args_helper(mag, **kw), batch, frames, dtype, dev)
 plan.force_generic(True)
 plan.gla_init(None, mag, 0.3)
 plan.iterate(12)
