@@ -580,7 +580,7 @@ __device__ __forceinline__ cplx<T> update_core(cplx<T> r, T m, cplx<T> s0, cplx<
   if (MODE == 0) {                                             // methods.py:243-247
     const cplx<T> sv = mk<T>(r.x - s0.x * coef, r.y - s0.y * coef);
     n0 = sv;
-    const T inv = T(1) / (si_hypot(sv.x, sv.y) + eps16<T>::value);
+    const T inv = proj_inv(sv.x, sv.y);
     return mk<T>((sv.x * m) * inv, (sv.y * m) * inv);
   } else {                                                     // methods.py:467-475
     const cplx<T> xo = s0, uo = s1;
@@ -588,7 +588,7 @@ __device__ __forceinline__ cplx<T> update_core(cplx<T> r, T m, cplx<T> s0, cplx<
     const cplx<T> z = mk<T>((coef * y.x + r.x) * inv1p, (coef * y.y + r.y) * inv1p);
     const cplx<T> un = (uo + xo) - z;
     cplx<T> xn = z - un;
-    const T inv = T(1) / (si_hypot(xn.x, xn.y) + eps16<T>::value);
+    const T inv = proj_inv(xn.x, xn.y);
     xn = mk<T>((xn.x * m) * inv, (xn.y * m) * inv);
     n0 = xn;
     n1 = un;
