@@ -74,7 +74,7 @@ DOMINANT = {
     "C2": ("specinv::fast::k_fused4_td<16, false, false>", "valu"),
     "C4": ("specinv::fast::k_fused4<8, 1, false>", "hbm"),
     "C3": ("specinv::fast::k_rtisi_fast<16, 256, 4>", "latency"),
-    "C5": ("specinv::fast::k_objective_walk<16>", "valu"),
+    "C5": ("specinv::fast::k_objective_walk<16, 4>", "valu"),
     "C1": ("specinv::fast::k_semi<8", "latency"),
 }
 PMC_PASSES = (
@@ -116,6 +116,8 @@ def restated_bytes_per_unit(method, hop, n_freq, kernel):
         return 8 * hop + 4 * n_freq
     if method == "ADMM":
         return 8 * hop + 20 * n_freq
+    if method == "L_BFGS" and kernel == "objective+step":      # x_old, g_prev read; x_new, g written; targets
+        return 16 * hop + 4 * N_MELS
     return None
 
 
@@ -504,7 +506,15 @@ class Leg:
             fast = self.plan.fast_path
             return self.plan.path, {"kernel": "k_rtisi_fast" if fast else "k_rtisi"}, \
                 (f"specinv::k_rtisi_fast<{self.n_fft // 128}>" if fast else "specinv::k_rtisi")
-        return "fused", {"kernel": "objective"}, "L-BFGS objective (forward + loss + gradient in one launch)"
+        # (the device-resident optimiser leaves the step x += t d of an iteration that accepts no pair to the next evaluation's
+        # frame walk - DESIGN 3.7 (d): the launch then also reads g_prev and writes the new iterate)
+        opt = (getattr(self, "state", None) or {}).get("opt")
+        dev_opt = bool(getattr(opt, "_dev", False)) and "line_search_fn" not in (getattr(self, "opt_kw", None) or {})
+        obj = getattr(getattr(self, "fg_raw", None), "device_objective", None)
+        walk = bool(obj) and obj[0].objective_kind == "walk"
+        deferred = dev_opt and walk and os.environ.get("SPECINV_LBFGS_DEFER", "1") != "0"
+        return "fused", {"kernel": "objective+step" if deferred else "objective"}, \
+            "L-BFGS objective (forward + loss + gradient in one launch" + (", the optimiser's step applied on the way)" if deferred else ")")
 
     def describe(self):
         o = self.o
@@ -584,8 +594,8 @@ class Leg:
             roof["note"] = ("the kernel carries Y = X + U alone (methods.py:467-468 only read the sum, bit-identical): 8 hop + 20 F "
                             "bytes per frame-iteration instead of SURVEY's 8 hop + 36 F")
         elif self.method == "L_BFGS":
-            roof["note"] = ("two FFTs per frame on the vector units + two mel contractions on the matrix cores (fp32 MFMA), the "
-                            "spectrum never leaves the chip; HBM view in `hbm`")
+            roof["note"] = ("two FFTs per frame and the two mel contractions on the vector units (frame walk; SPECINV_OBJ_SPARSE=0: "
+                            "contractions on the matrix cores), the spectrum never leaves the chip; HBM view in `hbm`")
             roof["evaluations_timed"] = self._frozen[1] if getattr(self, "_frozen", None) else self.counters["evals"]
         return roof
 

@@ -16,9 +16,9 @@ DOMINANT = {
            "specinv::fast::k_phase_init_pairs<16>"],
     "C4": [bench.DOMINANT["C4"][0], "specinv::fast::k_fused4<8, 1, true>"],
     "C3": [bench.DOMINANT["C3"][0]],
-    "C5": [bench.DOMINANT["C5"][0], "specinv::k_objective_epilogue", "specinv::k_lbd_direction_lean<float>"],
+    "C5": [bench.DOMINANT["C5"][0], "specinv::k_objective_epilogue", "specinv::k_lbd_direction_lean<float>", "specinv::k_lbd_settle_x<float>"],
 }
-ALGO = {"C2": 64 * 1024 * 8196, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 4416}
+ALGO = {"C2": 64 * 1024 * 8196, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 8512}   # (C5: 16 hop + 4 mels - the walk applies the step too)
 out = os.path.join(ROOT, "profiles")
 traffic_path = os.path.join(out, "traffic.json")
 try:
