@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python3 tools/sweep.py --tag r05 --out gpurun_out/r05_sweep.json > gpurun_out/r05_sweep.log 2>&1; tail -2 gpurun_out/r05_sweep.log
+[ -n "$WITH_SWEEP" ] && python3 tools/sweep.py --tag r05 --out gpurun_out/r05_sweep.json > gpurun_out/r05_sweep.log 2>&1; tail -2 gpurun_out/r05_sweep.log
 for v in baseline wolfe main memory; do
 python3 bench.py --workload C5 --c5-variant $v --no-extra --no-pmc > gpurun_out/r05_bench_C5_$v.json 2>/dev/null
 done
