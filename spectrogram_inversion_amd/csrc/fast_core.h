@@ -814,6 +814,12 @@ struct FastArgs {
   float inv1p;      // 1/(1+rho)
   float fwd_scale;  // 1 or N^-1/2
   float inv_scale;  // 1/N or N^-1/2
+  // two-sided spectrograms (k_semi2): state and target of the MIRROR bins N - k, in the lower half's layout - record (k, M - k)
+  // holds bins (N - k, M + k), `mid` bin N - M/2; bins 0 and M have no mirror image (their slots are not used)
+  v4f* P2_out;
+  v2f* Pmid2_out;
+  const v4f* m2_pairs;
+  const float* m2_mid;
 };
 
 // |s| where only the metric reads it (sums compared to 1e-5: the hardware square root is good to 1 ulp)
@@ -1232,6 +1238,8 @@ template <int R>
 __global__ void k_fast_inverse_frames(FastXformArgs a);
 template <int R, int MODE, bool EVAL>
 __global__ void k_semi(SemiArgs s);
+template <int R, int MODE, bool EVAL>
+__global__ void k_semi2(SemiArgs s);     // ... of a two-sided spectrogram
 template <int R, int MODE, bool EVAL>
 __global__ void k_hop(HopArgs s);
 template <int R, bool EARLY, bool EVAL>

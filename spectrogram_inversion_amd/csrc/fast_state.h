@@ -59,6 +59,7 @@ struct FastState {
   bool semi = false;
   bool hopk = false;
   bool xform_ok = false;
+  bool two = false;
   bool keep_state = false;
   bool exact = true;
   int n_partials = 0;
@@ -115,6 +116,10 @@ struct FastState<float> {
   int cur = 0;   // index of the buffers holding the current state
   int mode = fast::MODE_GLA;
   FastBuf xb[2], xtail[2], Pb[2], Pmid[2], mpairs, mmid, inv_env, scratch;
+  // a two-sided spectrogram (onesided=False): the frame kernel k_semi2 with the mirror bins' state and target beside the lower
+  // half's (FastArgs::P2_out); no fused / chunked / signal-form kernels, no stand-alone transforms
+  bool two = false;
+  FastBuf Pb2, Pmid2, mpairs2, mmid2;
   // ADMM carries Y = X + U in Pb (FastArgs).  X and U themselves are only written when the caller has asked for them
   // (specinv_plan_keep_state), by the last iteration of every iterate() call.
   bool keep_state = false, xu_valid = false;
@@ -156,11 +161,34 @@ struct FastState<float> {
   int setup(const specinv_stft_cfg& cfg, const std::vector<float>&, int64_t length, int pad) {
     supported = false;
     xform_ok = false;
-    if (cfg.dtype != SPECINV_F32 || !cfg.onesided) return SPECINV_OK;
+    two = false;
+    if (cfg.dtype != SPECINV_F32) return SPECINV_OK;
     if (const char* e = getenv("SPECINV_DISABLE_FAST")) {
       if (e[0] == '1') return SPECINV_OK;
     }
-    if (cfg.n_fft == 512 || cfg.n_fft == 1024 || cfg.n_fft == 2048 || cfg.n_fft == 4096) {
+    const bool size_ok = cfg.n_fft == 512 || cfg.n_fft == 1024 || cfg.n_fft == 2048 || cfg.n_fft == 4096;
+    if (!cfg.onesided) {
+      // two-sided: the frame kernel + gather overlap-add only (round 5; SPECINV_DISABLE_TWOSIDED=1: the coverage kernels)
+      if (const char* e = getenv("SPECINV_DISABLE_TWOSIDED")) {
+        if (e[0] == '1') return SPECINV_OK;
+      }
+      if (!size_ok || pad >= length) return SPECINV_OK;
+      R = cfg.n_fft / 128;
+      two = true;
+      semi = true;
+      hopk = false;
+      OV = 0;
+      chunk = cfg.n_frames;
+      nchunks = 1;
+      const long long nf = (long long)cfg.batch * cfg.n_frames;
+      semi_grid = (int)std::min<long long>((nf + 3) / 4, 256 * 8);
+      n_waves = semi_grid * 4;
+      state_in_place = true;
+      use_template = false;
+      supported = true;
+      return SPECINV_OK;
+    }
+    if (size_ok) {
       xform_ok = true;              // any hop, any pad mode, centred or not
       xform_R = cfg.n_fft / 128;
     }
@@ -382,8 +410,15 @@ struct FastState<float> {
     if (semi && !hopk) SI_TRY(pl.frames_needed());
     SI_TRY(mpairs.reserve((size_t)nf * (G::H / 2) * 64 * sizeof(v4f)));
     SI_TRY(mmid.reserve(nf * sizeof(float)));
+    if (two) {
+      SI_TRY(Pb2.reserve(pbytes));
+      SI_TRY(Pmid2.reserve(nf * sizeof(v2f)));
+      SI_TRY(mpairs2.reserve((size_t)nf * (G::H / 2) * 64 * sizeof(v4f)));
+      SI_TRY(mmid2.reserve(nf * sizeof(float)));
+    }
     SI_TRY(inv_env.reserve(pl.length * sizeof(float)));
     cur = 0;
+    SI_CHECK(!two || spec_user != nullptr, SPECINV_ESTATE, "the two-sided frame kernel takes its starting spectrum in the user layout");
     if (spec_user == nullptr) {
       const int nwg = pl.B() * G::H;
       SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nwg, 3 * 1024) * sizeof(double)));
@@ -404,15 +439,23 @@ struct FastState<float> {
       SI_HIP(hipGetLastError());
       SI_HIP(hipMemcpyAsync(sum_m2_out, pl.sums.template as<double>() + 4, sizeof(double), hipMemcpyDeviceToHost, pl.stream));
     } else {
-      const dim3 grid((pl.Tn() + 31) / 32, (pl.n_freq + 31) / 32, pl.B()), blk(32, 8);
+      const int rows = pl.n_freq;                   // G::M + 1, or N for a two-sided spectrogram
+      const dim3 grid((pl.Tn() + 31) / 32, (G::M + 1 + 31) / 32, pl.B()), blk(32, 8);
       hipLaunchKernelGGL((fast::k_user_spec_to_pairs<RR>), grid, blk, 0, pl.stream, spec_user, Pb[0].template as<v2f>(),
-                         Pmid[0].template as<v2f>(), pl.Tn());
+                         Pmid[0].template as<v2f>(), pl.Tn(), rows, 0);
       SI_HIP(hipGetLastError());
-      const long long nblk = (long long)grid.x * grid.y * grid.z;
+      const long long nblk1 = (long long)grid.x * grid.y * grid.z, nblk = two ? 2 * nblk1 : nblk1;
       SI_TRY(pl.partials.reserve(std::max<size_t>((size_t)nblk, 3 * 1024) * sizeof(double)));
       hipLaunchKernelGGL((fast::k_user_mag_to_pairs<RR>), grid, blk, 0, pl.stream, mag_user, mpairs.template as<float>(),
-                         mmid.template as<float>(), pl.Tn(), pl.partials.template as<double>());
+                         mmid.template as<float>(), pl.Tn(), pl.partials.template as<double>(), rows, 0);
       SI_HIP(hipGetLastError());
+      if (two) {                                    // the mirror rows N - f into the same layout (sum of m^2: their partials behind)
+        hipLaunchKernelGGL((fast::k_user_spec_to_pairs<RR>), grid, blk, 0, pl.stream, spec_user, Pb2.template as<v2f>(),
+                           Pmid2.template as<v2f>(), pl.Tn(), rows, 1);
+        hipLaunchKernelGGL((fast::k_user_mag_to_pairs<RR>), grid, blk, 0, pl.stream, mag_user, mpairs2.template as<float>(),
+                           mmid2.template as<float>(), pl.Tn(), pl.partials.template as<double>() + nblk1, rows, 1);
+        SI_HIP(hipGetLastError());
+      }
       hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, pl.stream, pl.partials.template as<double>(), nblk, 1,
                          pl.sums.template as<double>() + 4);
       SI_HIP(hipGetLastError());
@@ -741,6 +784,12 @@ struct FastState<float> {
     if (MODE == fast::MODE_ADMM) SI_TRY(want_xu(pl, a, last));
     a.m_pairs = mpairs.template as<v4f>();
     a.m_mid = mmid.template as<float>();
+    if (two) {
+      a.P2_out = Pb2.template as<v4f>();
+      a.Pmid2_out = Pmid2.template as<v2f>();
+      a.m2_pairs = mpairs2.template as<v4f>();
+      a.m2_mid = mmid2.template as<float>();
+    }
     a.window = pl.window.template as<float>();
     a.partials = pl.partials.template as<double>();
     a.T = pl.Tn();
@@ -755,7 +804,9 @@ struct FastState<float> {
     s.hop = pl.cfg.hop_length;
     s.pad = pl.pad;
     const size_t lds = G::lds_bytes(4);
-    const void* fn = !exact ? specinv_approx_frame(0, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_semi<RR, MODE, EVAL>;
+    // (two-sided: the reference's operation order only - the approximate copy is not built for k_semi2)
+    const void* fn = two ? (const void*)fast::k_semi2<RR, MODE, EVAL>
+                         : !exact ? specinv_approx_frame(0, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_semi<RR, MODE, EVAL>;
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no approximate-projection frame kernel for this shape");
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&s};
@@ -1001,9 +1052,13 @@ struct FastState<float> {
              "ADMM carries Y = X + U; call specinv_plan_keep_state(plan, 1) before iterating to read X and U (which = 2 reads Y)");
     const FastBuf& src = (!admm || which == 2) ? Pb[ps] : which == 0 ? Xb : Ub;
     const FastBuf& mid = (!admm || which == 2) ? Pmid[ps] : which == 0 ? Xmid : Umid;
+    SI_CHECK(!two || !admm || which == 2, SPECINV_EUNSUPPORTED, "X and U of a two-sided ADMM run are not kept on this path");
     SPECINV_R_SWITCH(R, const long long np = nf * fast::Geo<RR>::H * 64;
                      hipLaunchKernelGGL((fast::k_pairs_to_spec<RR>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0, pl.stream,
-                                        src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf));
+                                        src.template as<v4f>(), mid.template as<v2f>(), scratch.template as<v2f>(), nf, pl.n_freq, 0);
+                     if (two) hipLaunchKernelGGL((fast::k_pairs_to_spec<RR>), dim3((unsigned)ceil_div(np, 256)), dim3(256), 0,
+                                                 pl.stream, Pb2.template as<v4f>(), Pmid2.template as<v2f>(),
+                                                 scratch.template as<v2f>(), nf, pl.n_freq, 1));
     SI_HIP(hipGetLastError());
     return pl.template transpose<cplx<float>>(scratch.template as<cplx<float>>(), out, pl.Tn(), pl.n_freq);
   }

@@ -112,7 +112,12 @@ __global__ __launch_bounds__(256) void k_fast_inverse_frames(FastXformArgs a) {
 // One frame of the frame kernels: state in, (samples -> spectrum -> update) unless MODE_INIT, state out, inverse
 // transform.  On return z holds the synthesis frame before its window (register u <-> samples 128u + 2 lane, +1).
 // PRE: z already holds the frame's samples (unwindowed), fetched by the caller one frame ahead.
-template <int R, int MODE, bool EVAL, bool PRE = false>
+// TWO: a two-sided spectrogram (onesided=False: target and state hold all N bins).  The frame is real, so its spectrum at the
+// mirror bin N - f is the conjugate of bin f; the reference updates both bins on their own - each with its own target and state
+// (methods.py:243-247 / :467-475 on the full spectrum) - and `ifft(.).real` (:142-146) sees the Hermitian part
+// (Y_f + conj Y_{N-f}) / 2 of the result: the update runs a second time on the conjugate with the mirror arrays (FastArgs::P2_out),
+// the two results are averaged, the rest of the frame is the one-sided kernel's.
+template <int R, int MODE, bool EVAL, bool PRE = false, bool TWO = false>
 __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long long b, int t, int hop, int pad,
                                            const LaneConst<R>& k, const v2f* lds_win, const v2f* lds_tw1, v2f* tr,
                                            v2f (&z)[R], double& sd, double& so) {
@@ -126,6 +131,24 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
   const bool keep_xu = MODE == MODE_ADMM && a.U_out != nullptr;   // (uniform: a kernel argument)
   v2f pmid = v2f{0.0f, 0.0f}, umid = v2f{0.0f, 0.0f};
   float mmid = 0.0f;
+  v4f pp2[TWO ? H : 1], mm2[TWO ? (H / 2) : 1];
+  v2f pmid2 = v2f{0.0f, 0.0f};
+  float mmid2 = 0.0f;
+  auto conjv = [](v2f v) { return v2f{v.x, -v.y}; };
+  if (TWO) {
+    const v4f* pin2 = a.P2_out + fi * (H * 64);
+#pragma unroll
+    for (int j = 0; j < H; ++j) pp2[TWO ? j : 0] = ld_stream(&pin2[j * 64u + ulane]);
+    if (MODE != MODE_INIT) {
+      const v4f* min2 = a.m2_pairs + fi * (H / 2 * 64);
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) mm2[TWO ? j : 0] = ld_stream(&min2[j * 64u + ulane]);
+    }
+    if (lane == 0) {
+      pmid2 = a.Pmid2_out[fi];
+      if (MODE != MODE_INIT) mmid2 = a.m2_mid[fi];
+    }
+  }
   {
     v4f* pin = a.P_out + fi * (H * 64);
 #pragma unroll
@@ -178,9 +201,29 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
         st_stream(&a.X_out[fi * (H * 64) + j * 64u + ulane], v4f{sk.x, sk.y, sm.x, sm.y});
         st_stream(&a.U_out[fi * (H * 64) + j * 64u + ulane], v4f{uk.x, uk.y, um.x, um.y});
       }
+      if (TWO) {
+        const int j2 = TWO ? j : 0;
+        v2f pk2 = v2f{pp2[j2].x, pp2[j2].y}, pm2 = v2f{pp2[j2].z, pp2[j2].w};
+        const float mk2 = (j & 1) ? mm2[j2 / 2].z : mm2[j2 / 2].x;
+        const float mq2 = (j & 1) ? mm2[j2 / 2].w : mm2[j2 / 2].y;
+        const bool live2 = !(j == 0 && lane == 0);          // bins 0 and M are their own mirror images
+        v2f u2 = v2f{0.0f, 0.0f}, s2 = v2f{0.0f, 0.0f};
+        const v2f ak2 = update_bin<UMODE, EVAL>(conjv(xk), pk2, u2, s2, mk2, a, live2, sd, so);
+        const v2f am2 = update_bin<UMODE, EVAL>(conjv(xm), pm2, u2, s2, mq2, a, live2, sd, so);
+        st_stream(&a.P2_out[fi * (H * 64) + j * 64u + ulane], v4f{pk2.x, pk2.y, pm2.x, pm2.y});
+        if (live2) {
+          ak = (ak + conjv(ak2)) * 0.5f;
+          am = (am + conjv(am2)) * 0.5f;
+        }
+      }
     } else {
       ak = pk * a.inv_scale;
       am = pm * a.inv_scale;
+      if (TWO && !(j == 0 && lane == 0)) {
+        const int j2 = TWO ? j : 0;
+        ak = (ak + conjv(v2f{pp2[j2].x, pp2[j2].y} * a.inv_scale)) * 0.5f;
+        am = (am + conjv(v2f{pp2[j2].z, pp2[j2].w} * a.inv_scale)) * 0.5f;
+      }
     }
     if (j == 0 && lane == 0) {   // bins 0 and M: irfft ignores their imaginary parts
       ak.y = 0.0f;
@@ -196,7 +239,7 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
     const v2f xmid = z[H] * v2f{a.fwd_scale, -a.fwd_scale};
     const bool live0 = lane == 0;
     v2f smid = v2f{0.0f, 0.0f};
-    const v2f am = update_bin<UMODE, EVAL>(xmid, pmid, umid, smid, mmid, a, live0, sd, so);
+    v2f am = update_bin<UMODE, EVAL>(xmid, pmid, umid, smid, mmid, a, live0, sd, so);
     if (live0) {
       a.Pmid_out[fi] = pmid;
       if (keep_xu) {
@@ -204,9 +247,17 @@ __device__ __forceinline__ void semi_frame(const FastArgs& a, long long fi, long
         a.Umid_out[fi] = umid;
       }
     }
+    if (TWO) {
+      v2f u2 = v2f{0.0f, 0.0f}, s2 = v2f{0.0f, 0.0f};
+      const v2f am2 = update_bin<UMODE, EVAL>(conjv(xmid), pmid2, u2, s2, mmid2, a, live0, sd, so);
+      if (live0) a.Pmid2_out[fi] = pmid2;
+      am = (am + conjv(am2)) * 0.5f;
+    }
     zmid = am * v2f{2.0f, -2.0f};
   } else {
-    zmid = pmid * v2f{2.0f * a.inv_scale, -2.0f * a.inv_scale};
+    v2f pm_ = pmid;
+    if (TWO) pm_ = (pmid + conjv(pmid2)) * 0.5f;
+    zmid = pm_ * v2f{2.0f * a.inv_scale, -2.0f * a.inv_scale};
   }
 #pragma unroll
   for (int m = H; m < R; ++m) {
@@ -237,6 +288,42 @@ __global__ __launch_bounds__(256) void k_semi(SemiArgs s) {
     const int t = (int)(fi - b * a.T);
     v2f z[R];
     semi_frame<R, MODE, EVAL>(a, fi, b, t, s.hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
+    v2f* out = reinterpret_cast<v2f*>(s.frames + fi * (2 * M));
+#pragma unroll
+    for (int u = 0; u < R; ++u) out[64u * u + ulane] = z[u] * lds_win[64 * u + lane];
+  }
+  if (EVAL) {
+    const double d = wave_sum(sd), o = wave_sum(so);
+    if (lane == 0) {
+      const long long w = (long long)blockIdx.x * 4 + wib;
+      a.partials[2 * w] = d;
+      a.partials[2 * w + 1] = o;
+    }
+  }
+}
+
+// k_semi for a two-sided spectrogram (semi_frame<..., TWO>): float32, onesided=False - what two thirds of the reference's own
+// parametrisations ask for (test/test_griffin.py:24-32) - ran on the coverage kernels until round 5.
+template <int R, int MODE, bool EVAL>
+__global__ __launch_bounds__(256) void k_semi2(SemiArgs s) {
+  using G = Geo<R>;
+  constexpr int M = G::M;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v2f* lds_win = reinterpret_cast<v2f*>(smem);
+  v2f* lds_tw1 = lds_win + M;
+  const FastArgs& a = s.f;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  v2f* tr = lds_tw1 + (R - 1) * 64 + wib * G::TR;
+  xform_tables<R>(a.window, lds_win, lds_tw1);
+  const LaneConst<R> k = lane_consts<R>();
+  const int lane = k.lane;
+  const unsigned ulane = (unsigned)lane;
+  double sd = 0.0, so = 0.0;
+  for (long long fi = (long long)blockIdx.x * 4 + wib; fi < s.n_frames_total; fi += (long long)gridDim.x * 4) {
+    const long long b = fi / a.T;
+    const int t = (int)(fi - b * a.T);
+    v2f z[R];
+    semi_frame<R, MODE, EVAL, false, true>(a, fi, b, t, s.hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
     v2f* out = reinterpret_cast<v2f*>(s.frames + fi * (2 * M));
 #pragma unroll
     for (int u = 0; u < R; ++u) out[64u * u + ulane] = z[u] * lds_win[64 * u + lane];

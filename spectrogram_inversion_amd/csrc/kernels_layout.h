@@ -8,16 +8,21 @@ namespace fast {
 // User layout (B, F, T) -> pair layout in one pass (32 x 32 tile transposed through LDS): reads are contiguous in
 // time, writes are 8-byte (spectrum) / 4-byte (magnitude) pieces of the 16-byte pair records, contiguous in k.
 // Bin f goes to pair k = f (first half) for f < M/2, to pair k = M - f (second half) for f > M/2, to `mid` for M/2.
+// Two-sided spectrograms (rows = N = 2 M bins per item): `mirror` = 0 takes the rows 0 .. M as above, 1 the MIRROR rows - bin f's
+// slot receives row N - f (f = 1 .. M - 1; the slots of bins 0 and M, which are their own mirror images, are left zero).
 template <int R>
 __global__ void k_user_spec_to_pairs(const v2f* __restrict__ in, v2f* __restrict__ pairs /* v4f records as 2 x v2f */,
-                                     v2f* __restrict__ mid, int T) {
+                                     v2f* __restrict__ mid, int T, int rows = Geo<R>::M + 1, int mirror = 0) {
   using G = Geo<R>;
   constexpr int F = G::M + 1;
   __shared__ v2f tile[32][33];
   const int b = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
   for (int i = threadIdx.y; i < 32; i += blockDim.y) {
     const int f = f0 + i, t = t0 + threadIdx.x;
-    if (f < F && t < T) tile[i][threadIdx.x] = in[((long long)b * F + f) * T + t];
+    if (f < F && t < T) {
+      const bool none = mirror && (f == 0 || f == G::M);
+      tile[i][threadIdx.x] = none ? v2f{0.0f, 0.0f} : in[((long long)b * rows + (mirror ? rows - f : f)) * T + t];
+    }
   }
   __syncthreads();
   for (int i = threadIdx.y; i < 32; i += blockDim.y) {
@@ -37,7 +42,8 @@ __global__ void k_user_spec_to_pairs(const v2f* __restrict__ in, v2f* __restrict
 // same for the target magnitude; also per-block partial sums of m^2 (for the metrics)
 template <int R>
 __global__ void k_user_mag_to_pairs(const float* __restrict__ in, float* __restrict__ pairs /* v4f records */,
-                                    float* __restrict__ mid, int T, double* __restrict__ partials) {
+                                    float* __restrict__ mid, int T, double* __restrict__ partials, int rows = Geo<R>::M + 1,
+                                    int mirror = 0) {
   using G = Geo<R>;
   constexpr int F = G::M + 1;
   __shared__ float tile[32][33];
@@ -47,7 +53,8 @@ __global__ void k_user_mag_to_pairs(const float* __restrict__ in, float* __restr
   for (int i = threadIdx.y; i < 32; i += blockDim.y) {
     const int f = f0 + i, t = t0 + threadIdx.x;
     if (f < F && t < T) {
-      const float v = in[((long long)b * F + f) * T + t];
+      const bool none = mirror && (f == 0 || f == G::M);
+      const float v = none ? 0.0f : in[((long long)b * rows + (mirror ? rows - f : f)) * T + t];
       tile[i][threadIdx.x] = v;
       s2 += (double)v * (double)v;
     }
@@ -203,19 +210,27 @@ __global__ void k_spec_to_pairs(const v2f* __restrict__ spec, v4f* __restrict__ 
 
 template <int R>
 __global__ void k_pairs_to_spec(const v4f* __restrict__ pairs, const v2f* __restrict__ mid, v2f* __restrict__ spec,
-                                long long n_frames) {
+                                long long n_frames, int rows = Geo<R>::M + 1, int mirror = 0) {
   using G = Geo<R>;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_frames * G::H * 64) return;
   const int lane = i & 63;
   const int j = (i >> 6) % G::H;
   const long long f = i / (64 * G::H);
-  v2f* s = spec + f * (G::M + 1);
+  v2f* s = spec + f * rows;
   const int kk = lane + 64 * j;
   const v4f p = pairs[i];
-  s[kk] = v2f{p.x, p.y};
-  s[G::M - kk] = v2f{p.z, p.w};
-  if (lane == 0 && j == 0) s[G::M / 2] = mid[f];
+  if (!mirror) {
+    s[kk] = v2f{p.x, p.y};
+    s[G::M - kk] = v2f{p.z, p.w};
+    if (lane == 0 && j == 0) s[G::M / 2] = mid[f];
+  } else {                                           // (two-sided: the mirror rows N - kk and M + kk; none for kk = 0)
+    if (kk != 0) {
+      s[rows - kk] = v2f{p.x, p.y};
+      s[G::M + kk] = v2f{p.z, p.w};
+    }
+    if (lane == 0 && j == 0) s[rows - G::M / 2] = mid[f];
+  }
 }
 
 template <int R>

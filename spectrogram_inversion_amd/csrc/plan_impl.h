@@ -333,7 +333,8 @@ struct PlanT final : PlanBase {
     return SPECINV_OK;
   }
 
-  bool fast_path() const override { return fast.supported && !force_generic; }
+  // (a two-sided ADMM run asked to keep X and U takes the coverage kernels: the frame kernel carries Y = X + U alone there)
+  bool fast_path() const override { return fast.supported && !force_generic && !(fast.two && keep_state); }
   int path_kind() const override { return fast_path() ? (fast.semi ? (fast.hopk ? 3 : 2) : 1) : 0; }
   void launch_geometry(int out[4]) const override {
     if (fast_path()) {

@@ -520,6 +520,52 @@ def test_coverage_iteration_kernels_agree_and_match_the_oracle(monkeypatch, n_ff
         assert rel_l2(out["new"], out["plain"]) < max(3 * e0, 5 * tol), (method, rel_l2(out["new"], out["plain"]))
 
 
+@pytest.mark.parametrize("n_fft,hop,frames,kw", [
+    (512, 128, 9, dict()),
+    (512, 100, 12, dict(win_length=300)),                          # the reference's own two-sided shape (test/test_griffin.py:24-32)
+    (1024, 256, 7, dict(pad_mode="constant")),
+    (1024, 300, 6, dict(pad_mode="replicate")),
+    (2048, 512, 6, dict(normalized=True)),
+    (4096, 1024, 5, dict()),
+])
+def test_two_sided_float32_on_the_frame_kernel(monkeypatch, n_fft, hop, frames, kw):
+    """onesided=False in float32 runs on the wave-level frame kernel since round 5 (`k_semi2`: the per-bin update a second time on
+    the conjugate spectrum with the mirror bins' own target and state, the two results averaged to the Hermitian part that
+    ifft(.).real sees - methods.py:142-146, :243-247, :467-475): Griffin-Lim and ADMM from a complex start whose two halves are
+    NOT mirror images (random phases per bin, as phase_init gives), a target whose halves differ - against the coverage kernels
+    (SPECINV_DISABLE_TWOSIDED=1: the same arithmetic per bin, another transform) and the float64 oracle; the evaluation's sums over
+    all N bins and the state read back in the user layout as well."""
+    from spectrogram_inversion_amd.plan import clear_plan_cache
+    rng = np.random.default_rng(n_fft + hop)
+    mag = (rng.random((2, n_fft, frames)) + 0.05).astype(np.float32)
+    wl = kw.get("win_length", n_fft)
+    w = hann(wl, np.float32)
+    okw = dict(hop_length=hop, onesided=False, **kw)
+    init = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(np.complex64)
+    for method, arg, iters in (("griffin_lim", 0.5, 5), ("admm", 1.0, 4)):
+        mk = dict(max_iter=iters, alpha=arg) if method == "griffin_lim" else dict(max_iter=iters, rho=arg)
+        ref64 = getattr(oracle, method)(init.astype(np.complex128), tol=0, window=hann(wl, np.float64), **mk, **okw)
+        ref32 = getattr(oracle, method)(init, tol=0, window=w, **mk, **okw)
+        out, sums, state = {}, {}, {}
+        for arm in ("frame", "coverage"):
+            monkeypatch.setenv("SPECINV_DISABLE_TWOSIDED", "1" if arm == "coverage" else "0")
+            clear_plan_cache()
+            a = args_helper(T(init), window=torch.from_numpy(w), **okw)
+            plan = get_plan(a, 2, frames, torch.float32, dev())
+            assert plan.fast_path == (arm == "frame"), (arm, plan.path)
+            (plan.gla_init if method == "griffin_lim" else plan.admm_init)(T(init), T(mag), arg)
+            sums[arm] = plan.iterate(iters, eval_last=True)
+            out[arm] = N(plan.wave())
+            state[arm] = N(plan.state_spec(0 if method == "griffin_lim" else 2))
+        clear_plan_cache()
+        e, e0 = rel_l2(out["frame"], ref64), rel_l2(ref32, ref64)
+        assert e < max(3 * e0, 1e-4), (method, e, e0)
+        assert rel_l2(out["frame"], out["coverage"]) < max(3 * e0, 1e-4), (method, rel_l2(out["frame"], out["coverage"]))
+        np.testing.assert_allclose(sums["frame"], sums["coverage"], rtol=1e-4)
+        assert state["frame"].shape == (2, n_fft, frames)
+        assert rel_l2(state["frame"], state["coverage"]) < max(10 * e0, 1e-4), rel_l2(state["frame"], state["coverage"])
+
+
 @pytest.mark.parametrize("n_fft,dtype,tol", [(16384, np.float32, 2e-5), (8192, np.float64, 1e-10)])
 def test_transforms_beyond_two_lds_buffers(n_fft, dtype, tol):
     """The reference derives n_fft from the spectrogram with no bound (torch_specinv/methods.py:65-68).  The generic kernels keep a

@@ -53,3 +53,36 @@ for n_fft, wl, hop, frames, batch, dtype, onesided, method in CASES:
           f"{best:8.3f} ms/it {batch * frames / best / 1e3:8.1f} M frames/s {100 * gbs / 8000:5.1f} % of 8 TB/s  wg {plan.launch_geometry['waves_per_workgroup']} waves",
           flush=True)
     del plan
+
+# the same two-sided float32 shapes where they run since round 5: the wave-level frame kernel k_semi2 + k_ola
+print("two-sided float32 on the frame kernel (k_semi2 + k_ola_f4):", flush=True)
+for n_fft, wl, hop, frames, batch, method in [(512, 300, 100, 2048, 64, "gla"), (512, 300, 100, 2048, 64, "admm"),
+                                              (2048, None, 512, 1024, 32, "gla"), (1024, None, 256, 2048, 32, "gla")]:
+    dtype = torch.float32
+    w = torch.hann_window(wl or n_fft, dtype=dtype)
+    mag = torch.rand((batch, n_fft, frames), dtype=dtype, device=dev)
+    kw = dict(hop_length=hop, window=w, onesided=False)
+    if wl:
+        kw["win_length"] = wl
+    res = {}
+    for arm in ("frame", "coverage"):
+        plan = Plan(args_helper(mag, **kw), batch, frames, dtype, dev)
+        plan.force_generic(arm == "coverage")
+        (plan.gla_init if method == "gla" else plan.admm_init)(None, mag, 0.3 if method == "gla" else 0.1)
+        plan.iterate(3)
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            plan.iterate(20)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20)
+        res[arm] = best
+        del plan
+    per_frame = (2 * hop + (5 if method == "gla" else 5) * n_fft + 2 * n_fft) * 4       # (ADMM carries Y alone on the frame kernel)
+    gbs = per_frame * batch * frames / (res["frame"] * 1e-3) / 1e9
+    print(f"{method:4s} n_fft {n_fft:5d} win {wl or n_fft:5d} hop {hop:5d} T {frames:5d} B {batch:3d} frame kernel {res['frame']:7.3f} ms/it "
+          f"({100 * gbs / 8000:5.1f} % of 8 TB/s on (8h+20F+8N)/4 elements)   coverage kernels {res['coverage']:7.3f} ms/it", flush=True)
+
