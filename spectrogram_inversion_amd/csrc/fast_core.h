@@ -1242,6 +1242,8 @@ template <int R, int MODE, bool EVAL>
 __global__ void k_semi2(SemiArgs s);     // ... of a two-sided spectrogram
 template <int R, int MODE, bool EVAL>
 __global__ void k_hop(HopArgs s);
+template <int R, int MODE, bool EVAL>
+__global__ void k_hop2(HopArgs s);       // ... of a two-sided spectrogram
 template <int R, bool EARLY, bool EVAL>
 __global__ void k_hop_td(HopArgs s);
 template <int R>

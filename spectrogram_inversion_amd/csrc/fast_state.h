@@ -167,33 +167,20 @@ struct FastState<float> {
       if (e[0] == '1') return SPECINV_OK;
     }
     const bool size_ok = cfg.n_fft == 512 || cfg.n_fft == 1024 || cfg.n_fft == 2048 || cfg.n_fft == 4096;
+    if (!size_ok) return SPECINV_OK;
     if (!cfg.onesided) {
-      // two-sided: the frame kernel + gather overlap-add only (round 5; SPECINV_DISABLE_TWOSIDED=1: the coverage kernels)
+      // two-sided: the frame kernels only - k_semi2 + gather overlap-add, or k_hop2 over chunks of frames (round 5;
+      // SPECINV_DISABLE_TWOSIDED=1: the coverage kernels); no fused / signal-form kernels, no stand-alone transforms
       if (const char* e = getenv("SPECINV_DISABLE_TWOSIDED")) {
         if (e[0] == '1') return SPECINV_OK;
       }
-      if (!size_ok || pad >= length) return SPECINV_OK;
-      R = cfg.n_fft / 128;
+      if (pad >= length) return SPECINV_OK;
       two = true;
-      semi = true;
-      hopk = false;
-      OV = 0;
-      chunk = cfg.n_frames;
-      nchunks = 1;
-      const long long nf = (long long)cfg.batch * cfg.n_frames;
-      semi_grid = (int)std::min<long long>((nf + 3) / 4, 256 * 8);
-      n_waves = semi_grid * 4;
-      state_in_place = true;
-      use_template = false;
-      supported = true;
-      return SPECINV_OK;
-    }
-    if (size_ok) {
+    } else {
       xform_ok = true;              // any hop, any pad mode, centred or not
       xform_R = cfg.n_fft / 128;
     }
-    if (!xform_ok) return SPECINV_OK;
-    R = xform_R;
+    R = cfg.n_fft / 128;
     semi = false;
     state_in_place = true;     // (same speed as ping-pong buffers, measured; a third less memory)
     if (const char* e = getenv("SPECINV_STATE_INPLACE")) state_in_place = e[0] != '0';
@@ -203,6 +190,7 @@ struct FastState<float> {
     OV = 0;
     for (int o : {2, 4, 8})
       if (cfg.hop_length * o == cfg.n_fft && R % o == 0) OV = o;
+    if (two) OV = 0;
     if (const char* e = getenv("SPECINV_DISABLE_FUSED")) {   // tests: put the shape on the frame kernel
       if (e[0] == '1') OV = 0;
     }
@@ -335,7 +323,8 @@ struct FastState<float> {
     mode = md;
     // (n_fft 4096 runs one wave per SIMD: its vector latency, not the state traffic, is what bounds it there - the signal form
     // measured 0.360 against 0.340 ms per iteration and is not used)
-    td = md == fast::MODE_GLA && (!semi || hopk) && !use_template && !keep_state && RR <= 16;
+    if (two) exact = true;       // (the approximate copy is not built for the two-sided kernels)
+    td = md == fast::MODE_GLA && (!semi || hopk) && !use_template && !keep_state && RR <= 16 && !two;
     // (the reference-chain build leaves the real-FFT split unscaled, which is exact only for a power-of-two fwd_scale / 2)
     if (exact && pl.cfg.normalized && !hopk) td = false;
     // k_hop_td writes two signals and re-reads z_t where k_hop writes one: at large hops its emission loop overtakes the saved state
@@ -840,12 +829,19 @@ struct FastState<float> {
     a.inv1p = 1.0f / (float)(1.0 + (double)pl.coef);
     a.fwd_scale = pl.fc.fwd_scale;
     a.inv_scale = pl.fc.inv_scale;
+    if (two) {
+      a.P2_out = Pb2.template as<v4f>();
+      a.Pmid2_out = Pmid2.template as<v2f>();
+      a.m2_pairs = mpairs2.template as<v4f>();
+      a.m2_mid = mmid2.template as<float>();
+    }
     s.env = inv_env.template as<float>();
     s.xtail = xtail[0].template as<float>();
     s.hop = hop;
     s.pad = pl.pad;
     const size_t lds = G::lds_bytes(wgw) + (size_t)wgw * G::N * sizeof(float);
-    const void* fn = !exact ? specinv_approx_frame(1, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_hop<RR, MODE, EVAL>;
+    const void* fn = two ? (const void*)fast::k_hop2<RR, MODE, EVAL>
+                         : !exact ? specinv_approx_frame(1, RR, MODE, EVAL ? 1 : 0) : (const void*)fast::k_hop<RR, MODE, EVAL>;
     SI_CHECK(fn != nullptr, SPECINV_EUNSUPPORTED, "no approximate-projection chunked frame kernel for this shape");
     SI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* kargs[] = {&s};

@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256) void k_semi2(SemiArgs s) {
 // earlier one leaves the rest of its ring in `xtail`, and k_hop_tails adds the two and divides (a few MB per
 // iteration).  x ping-pongs between two buffers, the spectral state is updated in place.
 
-template <int R, int MODE, bool EVAL>
-__global__ __launch_bounds__(512, (SPECINV_HOP_R8_W2 && R == 8) ? 4 : 1) void k_hop(HopArgs s) {
+template <int R, int MODE, bool EVAL, bool TWO>
+__device__ __forceinline__ void hop_body(const HopArgs& s) {
   using G = Geo<R>;
   constexpr int M = G::M, N = G::N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512, (SPECINV_HOP_R8_W2 && R == 8) ? 4 : 1) void k_
         for (int u = 0; u < R; ++u) z[u] = zn[u];
         if (t + 1 < t1) load_frame_raw<R>(a.x_in + (long long)b * a.L, a.L, (long long)(t + 1) * hop - s.pad, lane, a.pad_mode, zn);
       }
-      semi_frame<R, MODE, EVAL, PRE>(a, fi, b, t, hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
+      semi_frame<R, MODE, EVAL, PRE, TWO>(a, fi, b, t, hop, s.pad, k, lds_win, lds_tw1, tr, z, sd, so);
       if ((slot0 & 1) == 0) {                              // register pairs stay aligned in the ring
         v2f* r2 = reinterpret_cast<v2f*>(ring);
         const int h0 = slot0 >> 1;
@@ -462,6 +462,15 @@ __global__ __launch_bounds__(512, (SPECINV_HOP_R8_W2 && R == 8) ? 4 : 1) void k_
       a.partials[2 * w + 1] = o;
     }
   }
+}
+template <int R, int MODE, bool EVAL>
+__global__ __launch_bounds__(512, (SPECINV_HOP_R8_W2 && R == 8) ? 4 : 1) void k_hop(HopArgs s) {
+  hop_body<R, MODE, EVAL, false>(s);
+}
+// ... of a two-sided spectrogram (semi_frame<..., TWO>: the mirror bins' state and target beside the lower half's)
+template <int R, int MODE, bool EVAL>
+__global__ __launch_bounds__(512, 1) void k_hop2(HopArgs s) {
+  hop_body<R, MODE, EVAL, true>(s);
 }
 
 // ---- k_hop with Griffin-Lim's momentum carried as a signal (kernels_fast_td.h has the derivation) ---------------

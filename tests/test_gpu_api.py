@@ -52,7 +52,7 @@ def test_path_selection_at_the_edges(chunked_kernel):
     w64 = torch.from_numpy(hann(2048, np.float64))
     assert Plan(args_helper(probe.double(), hop_length=512, window=w64), 1, 40, torch.float64, dev).path == "generic"
     two = Plan(args_helper(torch.empty(1, 2048, 1), hop_length=512, window=w, onesided=False), 1, 40, torch.float32, dev)
-    assert two.path == "frame" and two.path_code == 2          # two-sided float32: the frame kernel k_semi2 (round 5)
+    assert two.path == "frame" and two.path_code == 3          # two-sided float32: the frame kernels (round 5; chunked here: the fixture)
     two.keep_state(True)                                       # ... but not when X and U are to be kept: the coverage kernels
     assert two.path == "generic"
     assert Plan(args_helper(torch.empty(1, 2048, 1).double(), hop_length=512, window=w64, onesided=False), 1, 40, torch.float64,

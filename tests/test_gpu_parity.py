@@ -522,7 +522,7 @@ def test_coverage_iteration_kernels_agree_and_match_the_oracle(monkeypatch, n_ff
 
 @pytest.mark.parametrize("n_fft,hop,frames,kw", [
     (512, 128, 9, dict()),
-    (512, 100, 12, dict(win_length=300)),                          # the reference's own two-sided shape (test/test_griffin.py:24-32)
+    (512, 100, 40, dict(win_length=300)),                          # the reference's own two-sided shape (test/test_griffin.py:24-32)
     (1024, 256, 7, dict(pad_mode="constant")),
     (1024, 300, 6, dict(pad_mode="replicate")),
     (2048, 512, 6, dict(normalized=True)),
@@ -547,12 +547,17 @@ def test_two_sided_float32_on_the_frame_kernel(monkeypatch, n_fft, hop, frames, 
         ref64 = getattr(oracle, method)(init.astype(np.complex128), tol=0, window=hann(wl, np.float64), **mk, **okw)
         ref32 = getattr(oracle, method)(init, tol=0, window=w, **mk, **okw)
         out, sums, state = {}, {}, {}
-        for arm in ("frame", "coverage"):
+        for arm in ("frame", "chunked", "coverage"):               # k_semi2 + gather overlap-add / k_hop2 (overlap-add in LDS) / generic
             monkeypatch.setenv("SPECINV_DISABLE_TWOSIDED", "1" if arm == "coverage" else "0")
+            monkeypatch.delenv("SPECINV_SMALL_FRAMES", raising=False)
+            if arm == "chunked":
+                if n_fft > 2048:
+                    continue                                       # (k_hop2 stops at n_fft 2048: ring + scratch in LDS)
+                monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")    # (pins the chunked kernel whatever the number of frames)
             clear_plan_cache()
             a = args_helper(T(init), window=torch.from_numpy(w), **okw)
             plan = get_plan(a, 2, frames, torch.float32, dev())
-            assert plan.fast_path == (arm == "frame"), (arm, plan.path)
+            assert plan.path_code == {"frame": 2, "chunked": 3, "coverage": 0}[arm], (arm, plan.path_code)
             (plan.gla_init if method == "griffin_lim" else plan.admm_init)(T(init), T(mag), arg)
             sums[arm] = plan.iterate(iters, eval_last=True)
             out[arm] = N(plan.wave())
@@ -564,6 +569,11 @@ def test_two_sided_float32_on_the_frame_kernel(monkeypatch, n_fft, hop, frames, 
         np.testing.assert_allclose(sums["frame"], sums["coverage"], rtol=1e-4)
         assert state["frame"].shape == (2, n_fft, frames)
         assert rel_l2(state["frame"], state["coverage"]) < max(10 * e0, 1e-4), rel_l2(state["frame"], state["coverage"])
+        if "chunked" in out:
+            # (the same frame body; the overlap-add divides by the envelope's reciprocal table here, by the envelope there)
+            assert rel_l2(out["chunked"], out["frame"]) < max(3 * e0, 1e-4), (method, rel_l2(out["chunked"], out["frame"]))
+            np.testing.assert_allclose(sums["chunked"], sums["frame"], rtol=1e-4)
+            assert rel_l2(state["chunked"], state["frame"]) < max(10 * e0, 1e-4)
 
 
 @pytest.mark.parametrize("n_fft,dtype,tol", [(16384, np.float32, 2e-5), (8192, np.float64, 1e-10)])
