@@ -560,6 +560,26 @@ static __global__ void k_ola_f4(const float* __restrict__ frames, const float* _
   *reinterpret_cast<f4*>(x + bi * length + n) = acc;
 }
 
+// ... two consecutive samples per thread in float64 (hop / n_fft / pad / length even): 16-byte loads as in k_ola_f4
+static __global__ void k_ola_d2(const double* __restrict__ frames, const double* __restrict__ env, double* __restrict__ x, int n_fft,
+                                int hop, int pad, int n_frames, int64_t length, int64_t total2, int use_env) {
+  using d2 = double __attribute__((ext_vector_type(2)));
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total2) return;
+  const int64_t l2 = length / 2;
+  const int64_t bi = i / l2;
+  const int64_t n = (i - bi * l2) * 2;
+  const int64_t np = n + pad;
+  int64_t t_hi = np / hop;
+  if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+  const int64_t t_lo = np - n_fft + 1 <= 0 ? 0 : (np - n_fft + hop) / hop;
+  const double* fr = frames + bi * n_frames * n_fft;
+  d2 acc = d2{0.0, 0.0};
+  for (int64_t t = t_lo; t <= t_hi; ++t) acc += *reinterpret_cast<const d2*>(fr + t * n_fft + (np - t * hop));
+  if (use_env) acc = acc / *reinterpret_cast<const d2*>(env + n);
+  *reinterpret_cast<d2*>(x + bi * length + n) = acc;
+}
+
 // ---- Griffin-Lim / ADMM iteration, frame part (methods.py:237-248, :458-477) -----------------
 // ---- two frames per complex FFT ---------------------------------------------------------------
 // The frames are real, so frames t and t+1 ride one complex transform: z = a + i b gives

@@ -383,6 +383,14 @@ struct PlanT final : PlanBase {
         return SPECINV_OK;
       }
     }
+    if constexpr (std::is_same<T, double>::value) {
+      if (cfg.hop_length % 2 == 0 && N() % 2 == 0 && pad % 2 == 0 && len % 2 == 0) {
+        hipLaunchKernelGGL(k_ola_d2, dim3((unsigned)ceil_div(total / 2, 256)), dim3(256), 0, stream, fr, env.as<double>(), out,
+                           N(), cfg.hop_length, pad, Tn(), len, total / 2, use_env ? 1 : 0);
+        SI_HIP(hipGetLastError());
+        return SPECINV_OK;
+      }
+    }
     hipLaunchKernelGGL((k_ola<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, fr, env.as<T>(), out,
                        N(), cfg.hop_length, pad, Tn(), len, total, use_env ? 1 : 0);
     SI_HIP(hipGetLastError());
