@@ -6,7 +6,7 @@ hipcc cross-compiles without a GPU; the resulting .so sits next to the sources
 (spectrogram_inversion_amd/libspecinv.so), is git-ignored and travels to the GPU
 box with the repo snapshot.
 
-The library is a dozen translation units (csrc/*.hip): the plan and the light kernels in
+The library is two dozen translation units (csrc/*.hip): the plan and the light kernels in
 specinv.hip, each family of heavy wave-level kernels in its own tu_*.hip (explicit
 instantiations), compiled in parallel and linked once.  Objects and their dependency
 files live in csrc/build/<key>/ (git-ignored); only the units whose sources changed
