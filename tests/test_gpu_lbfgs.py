@@ -549,10 +549,10 @@ def test_one_pinned_board_per_plan():
 
 
 # ---- the device-resident optimiser (csrc/lbfgs_dev.h): decisions in k_lbd_decide, one host synchronisation per step ----------
-def _device_problem(kind, seed=7):
+def _device_problem(kind, seed=7, shape=None):
     rng = np.random.default_rng(seed)
     if kind == "logmel":
-        n_fft, hop, frames, batch = 2048, 512, 24, 2
+        n_fft, hop, frames, batch = shape or (2048, 512, 24, 2)
         tr = LogMelSTFT(torch.from_numpy(si.mel_filterbank(22050, n_fft, 80)).to(dev()), n_fft, hop_length=hop,
                         window=torch.from_numpy(hann(n_fft)))
     else:
@@ -757,19 +757,24 @@ def test_lean_iteration_retraces_the_full_form(monkeypatch, kind, kw, steps):
     np.testing.assert_allclose(lb, la, rtol=1e-9)
 
 
-@pytest.mark.parametrize("kw,steps", [
-    (dict(), 2),                                                 # pairs are accepted: every form hands over to the full one
-    (dict(lr=1e-7, max_iter=8, tolerance_change=0.0, tolerance_grad=0.0), 3),   # every pair rejected (BASELINE C5's regime): lean throughout
-    (dict(lr=1e-7, max_iter=5, tolerance_change=0.0, tolerance_grad=0.0, max_eval=4), 2),
+@pytest.mark.parametrize("kw,steps,shape", [
+    (dict(), 2, None),                                           # pairs are accepted: every form hands over to the full one
+    (dict(lr=1e-7, max_iter=8, tolerance_change=0.0, tolerance_grad=0.0), 3, None),   # every pair rejected (BASELINE C5's regime): lean throughout
+    (dict(lr=1e-7, max_iter=5, tolerance_change=0.0, tolerance_grad=0.0, max_eval=4), 2, None),
+    # the walk's other instantiations (n_fft 1024; hop = n_fft/2, /8), several chunks per item (seams), a batch of one
+    (dict(lr=1e-7, max_iter=6, tolerance_change=0.0, tolerance_grad=0.0), 2, (1024, 256, 40, 3)),
+    (dict(lr=1e-7, max_iter=6, tolerance_change=0.0, tolerance_grad=0.0), 2, (2048, 1024, 33, 1)),
+    (dict(lr=1e-7, max_iter=6, tolerance_change=0.0, tolerance_grad=0.0), 2, (1024, 128, 48, 2)),
+    (dict(), 2, (1024, 512, 17, 2)),
 ])
-def test_deferred_step_and_two_launch_iteration_are_bit_identical(monkeypatch, kw, steps):
+def test_deferred_step_and_two_launch_iteration_are_bit_identical(monkeypatch, kw, steps, shape):
     """Where the frame walk serves the objective, a lean iteration that accepts no pair leaves x += t d to the NEXT evaluation's
     walk (x_new = fma(t, (float)(c0 (double)g), x_old) formed while the samples are loaded, written to the iterate's other
     buffer), and its decisions are taken by the last workgroup of the evaluation's epilogue - two launches per iteration.  Against
     the three-launch iteration with the step deferred (SPECINV_LBFGS_LEAN2=0) and with the step streamed by
     k_lbd_direction_lean (SPECINV_LBFGS_DEFER=0): the same float operations on the same sums - identical iterates, bit for bit,
     after every step (the step still pending at the end of one is applied by k_lbd_settle_x)."""
-    tr, target, x0 = _device_problem("logmel")
+    tr, target, x0 = _device_problem("logmel", shape=shape)
     runs = []
     for env in (dict(), dict(SPECINV_LBFGS_LEAN2="0"), dict(SPECINV_LBFGS_DEFER="0")):
         for name in ("SPECINV_LBFGS_LEAN2", "SPECINV_LBFGS_DEFER"):
