@@ -54,8 +54,8 @@ for n_fft, wl, hop, frames, batch, dtype, onesided, method in CASES:
           flush=True)
     del plan
 
-# the same two-sided float32 shapes where they run since round 5: the wave-level frame kernel k_semi2 + k_ola
-print("two-sided float32 on the frame kernel (k_semi2 + k_ola_f4):", flush=True)
+# the same two-sided float32 shapes where they run since round 5: the wave-level frame kernels k_hop2 / k_semi2 + k_ola
+print("two-sided float32 on the frame kernels (k_hop2 at these frame counts; below 12 k / 32 k frames k_semi2 + k_ola_f4):", flush=True)
 for n_fft, wl, hop, frames, batch, method in [(512, 300, 100, 2048, 64, "gla"), (512, 300, 100, 2048, 64, "admm"),
                                               (2048, None, 512, 1024, 32, "gla"), (1024, None, 256, 2048, 32, "gla")]:
     dtype = torch.float32
