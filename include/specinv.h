@@ -86,9 +86,10 @@ int specinv_plan_set_stream(specinv_plan* plan, void* hip_stream);
 /* n_freq (F), signal length L = (T-1)*hop + n_fft - 2*pad (methods.py:127), and which iteration kernels the plan
  * uses: 1 = fused (one launch per iteration: wave-level FFT, register overlap-add; float32, one-sided, centred,
  * n_fft 512 / 1024 / 2048 / 4096, hop = n_fft/2, /4 or /8, >= n_fft/hop + 2 frames), 2 = the same wave-level frame
- * kernel + gather overlap-add (those n_fft, any hop / centring), 3 = that frame kernel walking chunks of frames with
- * the overlap-add in LDS (n_fft <= 2048, hop <= n_fft, >= 16384 frames in the batch at n_fft 2048, >= 32768 below), 0 = generic LDS Stockham kernels
- * (everything else). */
+ * kernel + gather overlap-add (those n_fft, any hop / centring; two-sided float32 spectrograms as well), 3 = that frame
+ * kernel walking chunks of frames with the overlap-add in LDS (n_fft <= 2048, hop <= n_fft, >= 12288 frames in the batch at
+ * n_fft 2048, >= 32768 below; one- or two-sided), 0 = generic LDS-FFT kernels (everything else: float64, other sizes, a
+ * two-sided run with specinv_plan_keep_state). */
 int specinv_plan_n_freq(const specinv_plan* plan);
 int64_t specinv_plan_length(const specinv_plan* plan);
 int specinv_plan_fast_path(const specinv_plan* plan);
