@@ -119,7 +119,9 @@ int specinv_plan_set_exact(specinv_plan* plan, int on);
  * pre_spec is never formed.
  * 1: ADMM - the last iteration of every specinv_admm_iterate call (and specinv_admm_init) also leaves X and U behind for
  * specinv_get_state_spec; Griffin-Lim - the iteration runs on pre_spec itself (the spectral-state kernel).
- * 0 (default): asking for X / U / pre_spec after an iteration is SPECINV_ESTATE.  Call before specinv_*_init.
+ * 0 (default): asking for X / U / pre_spec after an iteration is SPECINV_ESTATE.  Call before specinv_*_init: where the flag
+ * selects the kernels (a two-sided float32 run keeps X and U on the generic kernels only) it is latched by specinv_gla_init /
+ * specinv_admm_init - a later call takes effect at the next init, the running method keeps its kernels and buffers.
  * (The generic kernels keep X and U anyway; the frame-at-a-time and generic Griffin-Lim kernels keep pre_spec.) */
 int specinv_plan_keep_state(specinv_plan* plan, int on);
 

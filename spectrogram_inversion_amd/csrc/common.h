@@ -86,13 +86,16 @@ __device__ inline double si_hypot(double a, double b) { return hypot(a, b); }
 // 1 / (|s| + 1e-16), the factor of the reference's projection (methods.py:246-247, :472: s m / (|s| + 1e-16) - ATen multiplies by
 // the rounded reciprocal), without the library's hypot and an IEEE division (~45 / ~60 instructions per bin):
 //   float32: the wave-level kernels' chain (fast_core.h: ref_rcp_abs, SPECINV_REFCHAIN 2) - t = |s|^2 + 1e-32 by two fma, y =
-//     v_rsq_f32(t), one Newton step to the correctly rounded t^-1/2; the guard is below float32's resolution above |s| = 3e-9 and
-//     the floor bounds the factor by 1e16 like the guard does (s = 0 -> 0 as in the reference);
+//     v_rsq_f32(t), one Newton step to the correctly rounded t^-1/2; the guard is below float32's resolution above |s| = 3e-9;
+//     below that, and where |s|^2 leaves float32's range, hypot and the division (the float64 overload's rule);
 //   float64: y = v_rsq_f64(t) refined twice, h = t y corrected to the rounded square root, + 1e-16 (visible in float64: 1e-13
 //     relative at |s| = 1e-3), one Newton step from y to 1 / (h + 1e-16) and a second for the last bits; tiny |s| (< 1e-6: the
 //     seed 1 / h is no longer near 1 / (h + 1e-16)), huge or non-finite values take hypot and the division.
 __device__ __forceinline__ float proj_inv(float x, float y) {
   const float t = fmaf(y, y, fmaf(x, x, 1e-32f));
+  // (|s| above 1.8e19 - its square beyond float32 - or not finite, and |s| below 3e-9, where the squared floor and the reference's
+  // additive guard part ways: the reference's own operations)
+  if (!(t > 1e-17f && t < 1e37f)) return 1.0f / (hypotf(x, y) + 1e-16f);
   const float r = __builtin_amdgcn_rsqf(t);
   return fmaf(r * 0.5f, fmaf(-(t * r), r, 1.0f), r);
 }

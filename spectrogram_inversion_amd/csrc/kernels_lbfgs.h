@@ -1049,6 +1049,13 @@ inline int obj_mel_tiles(int n_mels, int R) {
 #define SPECINV_EPI_GROUP 128      // (C5: 512 / 256 / 128 -> 122.7 / 121.2 / 120.8 ms per step)
 #endif
 constexpr int kObjEpiThreads = 1024;   // a streaming pass wants waves in flight: 16 per CU at one block per CU
+// the tail's hand-over of the rows by write-through stores + vmcnt(0) instead of a release (see the tail below): only where the
+// ISA documents it
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+constexpr bool kTailSc1Protocol = false;
+#else
+constexpr bool kTailSc1Protocol = true;
+#endif
 static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(float* __restrict__ grad, const float* __restrict__ xtail,
                                                                    const float* __restrict__ margins, const double* __restrict__ part,
                                                                    double* __restrict__ slot, int T, int nchunks, int n_fft, int hop,
@@ -1305,20 +1312,32 @@ static __global__ __launch_bounds__(kObjEpiThreads) void k_objective_epilogue(fl
 #pragma unroll
       for (int c = 0; c < 9; ++c) row[c * fast::kObjRows] = w(c);
     } else {
-      // ---- the optimiser's decisions ride along, taken by the workgroup that finishes last: the row goes out with device-scope
-      // stores (past this XCD's L2, where the launch's other workgroups' loads find it) and is complete - vmcnt(0) - before the
-      // ticket is drawn.  (A device-scope release fence would write back the whole L2 - the gradient this launch has just
-      // stored - once per workgroup: +11 us on the launch, measured.)
+      // ---- the optimiser's decisions ride along, taken by the workgroup that finishes last.  Two forms of the hand-over:
+      // (a) dec.fence (the default since round 6): the HIP memory model's own - the ticket is an acquire-release
+      // read-modify-write at agent scope drawn by the ONE thread that wrote the row, the last workgroup's row loads follow an
+      // acquire fence.  Measured at C5 against (b): 112.4 / 114.0 / 112.8 against 111.7 / 113.7 / 111.9 ms per step (+0.5 %;
+      // round 5 had measured a release FENCE executed by every thread of every workgroup: +11 us per launch).
+      // (b) SPECINV_LBFGS_TAIL_FENCE=0, gfx942 / gfx950 only - round 5's ISA-level protocol: the row goes out with agent-scope
+      // atomic stores (`sc1`: written THROUGH this XCD's L2), `s_waitcnt vmcnt(0)` retires them (a write-through store is
+      // acknowledged by the memory side: the wait the release sequence `buffer_wbl2 sc1; s_waitcnt vmcnt(0)` itself relies on)
+      // before a RELAXED ticket is drawn; the reader's row loads are agent-scope atomic loads issued after its ticket has
+      // returned.  Not a synchronises-with edge of the language's model; kept for the A/B and pinned against (a) bit for bit at
+      // full size (tests/test_gpu_bench_sizes.py::test_c5_optimiser_step_full_size).
 #pragma unroll
       for (int c = 0; c < 9; ++c) __hip_atomic_store(row + c * fast::kObjRows, w(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_s_waitcnt(0);
-      last = __hip_atomic_fetch_add(dec.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+      if (kTailSc1Protocol && !dec.fence) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        last = __hip_atomic_fetch_add(dec.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+      } else {
+        last = __hip_atomic_fetch_add(dec.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+      }
     }
   }
   if (!tail) return;
   __syncthreads();
   if (!last) return;
+  if (!kTailSc1Protocol || dec.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (threadIdx.x == 0) __hip_atomic_store(dec.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   lbd_tail_decide(dec, scale, red9, lbd_r);
 }

@@ -658,6 +658,8 @@ struct LbfgsDev {
   int time_objective = 0;                 // > 0: HIP events around every time_objective-th evaluation (benchmarks)
   std::vector<hipEvent_t> ev;             // 2 per evaluation of a step
   int lean_launches = 0, full_launches = 0, suspensions = 0;   // diagnostics (tests: which form ran)
+  bool defer_live = false;                // the step being enqueued defers its x += t d (the iterate may sit in x_alt until it is settled)
+  bool broken = false;                    // a step failed half-way: the record on the device no longer matches the caller's x
   LbfgsDev() = default;
   LbfgsDev(const LbfgsDev&) = delete;
   LbfgsDev& operator=(const LbfgsDev&) = delete;
@@ -799,7 +801,32 @@ int lbd_grow(P& pl, LbfgsDev<float>& L, int iterations_ahead) {
 
 // one optimizer.step: everything enqueued, one synchronisation at the end (one more if a lean chain is suspended)
 template <typename P>
+int lbd_step_run(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* target, specinv_lbfgs_info* info);
+
+// ... and what a failure in the middle of it leaves behind: with the step deferred the current iterate may sit in the optimiser's
+// own buffer (LbdState::x_sel / x_pending) - it is brought back to the caller's x, and the optimiser refuses further steps (its
+// record and the enqueued chain no longer describe one consistent iteration).
+template <typename P>
 int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* target, specinv_lbfgs_info* info) {
+  SI_CHECK(!L.broken, SPECINV_ESTATE, "an earlier step of this optimiser failed: create a new one");
+  L.defer_live = false;
+  const int rc = lbd_step_run(pl, L, x, len, target, info);
+  if (rc != SPECINV_OK && L.defer_live) {
+    const std::string why = last_error();            // (the settle's own HIP calls must not replace the message)
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((k_lbd_settle_x<float>), dim3(1024), dim3(256), 0, pl.stream, L.ptrs(), L.n);
+    hipLaunchKernelGGL(k_lbd_settled, dim3(1), dim3(1), 0, pl.stream, L.state(L.par));
+    (void)hipStreamSynchronize(pl.stream);
+    (void)hipGetLastError();
+    last_error() = why;
+  }
+  if (rc != SPECINV_OK) L.broken = true;
+  L.defer_live = false;
+  return rc;
+}
+
+template <typename P>
+int lbd_step_run(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* target, specinv_lbfgs_info* info) {
   SI_CHECK(x && target && info, SPECINV_EINVAL, "null pointer");
   SI_CHECK((int64_t)pl.B() * len == L.n, SPECINV_EINVAL, "signal size does not match the optimiser's parameter vector");
   SI_CHECK(((uintptr_t)x & 15) == 0, SPECINV_EINVAL, "x is not 16-byte aligned");
@@ -817,6 +844,13 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
     if (e[0] == '0') defer = false;                 // (tests / A-B runs)
   }
   L.x_user = x;
+  L.defer_live = defer;
+  // evaluate() launches that EXECUTED, as index ranges [lo, hi): after a suspended lean chain the no-op launches of its tail sit
+  // between the chain's executed evaluations and the resumed ones (only executed launches are summed into objective_ms)
+  std::vector<std::pair<int, int>> exec_ranges;
+  int exec_lo = 0, exec_counted = 0;
+  int tail_fence = 1;                               // the epilogue's rows handed over by release / acquire (0: round 5's write-through protocol)
+  if (const char* e = getenv("SPECINV_LBFGS_TAIL_FENCE")) tail_fence = e[0] != '0';
   int n_eval_launched = 0;
   // objective + epilogue on the record that is current NOW; k_decide > 0: the epilogue also takes iteration k_decide's decisions
   // (the two-launch lean iteration) and writes the OTHER record
@@ -851,6 +885,7 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
       dec.board = L.board_dev;
       dec.rows = sr.rows;
       dec.k = k_decide;
+      dec.fence = tail_fence;
     }
     SI_TRY(tf_loss_grad_fused(pl, x, len, target, nullptr, L.g0, &used, nullptr, &ctl, &sr, k_decide > 0 ? &dec : nullptr));
     SI_CHECK(used, SPECINV_EUNSUPPORTED, "the one-launch objective does not cover this configuration");
@@ -917,6 +952,9 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
     // the lean chain met a memory to multiply with at iteration resume_k (whose evaluation is done: gradient, rows and record
     // are as it left them - everything enqueued behind it ran as no-ops): the full form takes over from that decision
     ++L.suspensions;
+    exec_ranges.emplace_back(exec_lo, std::min(n_eval_launched, exec_lo + (L.h.evals - exec_counted) + 1));   // (+ the suspended iteration's own)
+    exec_counted = L.h.evals + 1;
+    exec_lo = n_eval_launched;
     lean = false;
     if (L.h.d_implicit) {                           // (a two-launch chain hands over at the iteration that accepts its first pair:
       hipLaunchKernelGGL((k_lbd_materialise_d<float>), dim3(1024), dim3(256), 0, pl.stream, L.ptrs(), n);   // s = t d is read from d)
@@ -948,14 +986,17 @@ int lbd_step(P& pl, LbfgsDev<float>& L, float* x, int64_t len, const float* targ
   info->suspensions = L.suspensions;
   info->reserved_ = 0;
   if (L.time_objective) {
-    for (int i = 0; i < std::min(L.h.evals, n_eval_launched); i += L.time_objective) {   // (executed ones; gated launches are no-ops)
-      if ((size_t)(2 * i + 1) >= L.ev.size()) break;
-      float ms = 0.0f;
-      SI_HIP(hipEventElapsedTime(&ms, L.ev[2 * i], L.ev[2 * i + 1]));
-      info->objective_ms += ms;
-      info->objective_timed += 1;
-    }
+    exec_ranges.emplace_back(exec_lo, std::min(n_eval_launched, exec_lo + std::max(0, L.h.evals - exec_counted)));
+    for (const auto& r : exec_ranges)                 // (executed ones; gated launches are no-ops)
+      for (int i = r.first; i < r.second; ++i) {
+        if (i % L.time_objective != 0 || (size_t)(2 * i + 1) >= L.ev.size()) continue;
+        float ms = 0.0f;
+        SI_HIP(hipEventElapsedTime(&ms, L.ev[2 * i], L.ev[2 * i + 1]));
+        info->objective_ms += ms;
+        info->objective_timed += 1;
+      }
   }
+  L.defer_live = false;
   return SPECINV_OK;
 }
 

@@ -40,7 +40,7 @@ __device__ inline void block_reduce9(double (&v)[9], double (*red)[9]) {       /
 }
 
 constexpr int kLbdMaxHist = 120;          // history_size the device path takes (Gram matrix in LDS: hist^2 doubles)
-constexpr int kLbdInfo = 2;               // pinned board: [0] the step is live, [1] slots decided, [kLbdInfo ..] what the step leaves (lbfgs_dev_ls.h)
+constexpr int kLbdInfo = 2;               // pinned board: [0] the step is live, [1] slots decided, [kLbdInfo ..] what the step leaves
 constexpr int kLbdBoard = 16;             // doubles of the board
 
 struct LbdState {                         // device-resident (two buffers, see above); copied to the host at the end of a step
@@ -299,7 +299,8 @@ __device__ inline bool lbd_lean_commit(LbdState& N, const LbdState& R, const Lbd
 }
 
 // The two-launch lean iteration: the decisions of iteration k taken by the LAST workgroup of the evaluation's epilogue to finish
-// (fast::ObjDecide; the rows of all workgroups are in memory by then: release fence + ticket, acquire fence).  All threads of the
+// (fast::ObjDecide; the rows of all workgroups are in memory by then: write-through stores retired before the ticket, or - the
+// portable form - an acquire-release ticket and an acquire fence: k_objective_epilogue's tail has the protocol).  All threads of the
 // workgroup call; blockDim.x >= 256.  red9: [blockDim.x / 64][9].  The record is read by every workgroup when the launch begins
 // (lbd_tail_preload: the last one has it in LDS when it needs it).
 __device__ inline void lbd_tail_decide(const fast::ObjDecide& q, double scale, double (*red9)[9], LbdState& R /* shared */) {

@@ -85,6 +85,7 @@ struct ObjDecide {
   double* board = nullptr;
   const double* rows = nullptr;
   int k = 0;
+  int fence = 0;                // hand the rows over with the memory model's own release / acquire (k_objective_epilogue's tail)
 };
 
 // the statistics of the evaluated gradient: what the caller hands in, and where the figures go.  d / gp == nullptr: the gradient

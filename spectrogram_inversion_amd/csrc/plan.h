@@ -20,6 +20,7 @@ struct PlanBase {
   bool force_generic = false;
   bool exact = true;         // projection / envelope division in the reference's operation order (specinv_plan_set_exact; 0: approximations)
   bool keep_state = false;   // ADMM: the last iteration of every iterate() also writes X and U (specinv_plan_keep_state)
+  bool keep_latched = false; // ... as gla_init / admm_init found it: where the flag selects the kernels (two-sided float32) a run keeps them
   int64_t dev_bytes = 0;   // device memory held by the plan's buffers (account_bytes)
   int objective_kind = -1;   // what the last transform_loss_grad ran (specinv_transform_objective_kind)
 

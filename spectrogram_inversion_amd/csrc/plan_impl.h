@@ -334,7 +334,11 @@ struct PlanT final : PlanBase {
   }
 
   // (a two-sided ADMM run asked to keep X and U takes the coverage kernels: the frame kernel carries Y = X + U alone there)
-  bool fast_path() const override { return fast.supported && !force_generic && !(fast.two && keep_state); }
+  // - decided when the method starts (init_common latches the flag): a toggle in the middle of a run must not send iterate(),
+  // get_wave() and get_state_spec() to buffers the other path never reserved
+  bool fast_path() const override {
+    return fast.supported && !force_generic && !(fast.two && (method != Method::None ? keep_latched : keep_state));
+  }
   int path_kind() const override { return fast_path() ? (fast.semi ? (fast.hopk ? 3 : 2) : 1) : 0; }
   void launch_geometry(int out[4]) const override {
     if (fast_path()) {
@@ -604,6 +608,7 @@ struct PlanT final : PlanBase {
     const int64_t ns = nspec();
     count = (double)ns;
     const C* start_user = static_cast<const C*>(init_spec);
+    keep_latched = keep_state;
     fast.keep_state = keep_state;
     fast.exact = exact;
     if constexpr (std::is_same<T, float>::value) {
@@ -673,7 +678,7 @@ struct PlanT final : PlanBase {
     SI_CHECK(n_iter >= 0, SPECINV_EINVAL, "n_iter < 0");
     if (n_iter == 0) return SPECINV_OK;
     if (fast_path()) {
-      fast.keep_state = keep_state;
+      fast.keep_state = fast.two ? keep_latched : keep_state;
       SI_TRY(fast.iterate(*this, n_iter, eval_last));
     } else {
       SI_TRY(frames_needed());

@@ -195,6 +195,9 @@ int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]) {
 }
 int specinv_plan_keep_state(specinv_plan* plan, int on) {
   PLAN_OR_FAIL(plan);
+  // one-sided plans re-read the flag on every iterate(); a two-sided float32 plan picks its KERNELS by it (the frame kernel carries
+  // Y = X + U alone, keep_state takes the coverage kernels and their buffers, reserved by *_init) and latches it there: like
+  // specinv_plan_set_exact it is read by the next specinv_gla_init / specinv_admm_init, a running method keeps its kernels
   plan->impl->keep_state = on != 0;
   return SPECINV_OK;
 }

@@ -252,3 +252,135 @@ def test_c5_objective_full_size_vs_torch_autograd():
     assert rel_l2(N(v), vr.detach().numpy()) < 1e-5
     assert abs(loss - float(lr)) < 1e-5 * float(lr), (loss, float(lr))
     assert rel_l2(N(grad), gr.numpy()) < 1e-5, rel_l2(N(grad), gr.numpy())
+
+
+# ---- C5: the optimiser's TIMED path at the size it is timed at -------------------------------------------------------------------
+def _c5_inputs(items=None):
+    """bench.py's rank-0 inputs of BASELINE configs[4] (Leg.__init__: Generator(1234), x* = 0.1 randn, x0 = 1e-6 randn)."""
+    n_fft, hop, frames, batch, n_mels = 2048, 512, 1024, 16, 80
+    length = (frames - 1) * hop
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    xs = 0.1 * torch.randn(batch, length, generator=gen)
+    x0 = 1e-6 * torch.randn(batch, length, generator=gen)
+    if items is not None:
+        xs, x0 = xs[items].contiguous(), x0[items].contiguous()
+    fb = torch.from_numpy(si.mel_filterbank(22050, n_fft, n_mels))
+    tr = si.LogMelSTFT(fb.to(DEV), n_fft, hop_length=hop, window=torch.from_numpy(hann(n_fft)))
+    return tr, tr(xs.to(DEV)), x0.to(DEV), xs
+
+
+_C5_FORMS = {                                         # environment of each form of the device-resident optimiser's lean iteration
+    "two_launch": {},                                 # what bench.py times: step deferred into the walk, decisions in the epilogue's tail
+    "two_launch_sc1": {"SPECINV_LBFGS_TAIL_FENCE": "0"},     # ... with round 5's write-through hand-over of the rows instead of release / acquire
+    "three_launch_deferred": {"SPECINV_LBFGS_LEAN2": "0"},
+    "three_launch_streamed": {"SPECINV_LBFGS_DEFER": "0"},
+    "host_driven": {"SPECINV_LBFGS_DEVICE": "0"},     # lbfgs.py:_step_packed, one read-back per inner iteration
+}
+
+
+def _c5_run(monkeypatch, form, tr, target, x0, steps):
+    from spectrogram_inversion_amd.lbfgs import LBFGS
+    for name in ("SPECINV_LBFGS_TAIL_FENCE", "SPECINV_LBFGS_LEAN2", "SPECINV_LBFGS_DEFER", "SPECINV_LBFGS_DEVICE"):
+        monkeypatch.delenv(name, raising=False)
+    for name, v in _C5_FORMS[form].items():
+        monkeypatch.setenv(name, v)
+    x = x0.clone()
+    _, fg = tr.bind(x, target)
+    opt = LBFGS(x, device=DEV)                        # torch.optim.LBFGS defaults: max_iter 20, history 100, lr 1 (methods.py:543)
+    snaps = []
+    for _ in range(steps):
+        first = opt.step(fg)
+        snaps.append((x.clone(), first, opt.total_iters, opt.func_evals, int(opt.pairs_accepted), int(opt.pairs_rejected), opt.history_len))
+    assert bool(opt._dev) == (form != "host_driven")
+    if form == "two_launch" or form == "two_launch_sc1":
+        assert fg.device_objective[0].objective_kind == "walk"
+    return snaps, (opt.dev_iterations if opt._dev else None)
+
+
+def test_c5_optimiser_step_full_size(monkeypatch):
+    """BASELINE configs[4] as bench.py runs it (B 16, 2048 / 512, T 1024, 80 mel bands, rank 0's inputs): `optimizer.step` - 20
+    iterations of torch.optim.LBFGS, every pair rejected by the curvature guard (methods.py:543-556) - on the path the C5 number is
+    timed on: the frame walk at 2048 waves applying the deferred step, the epilogue's 256 workgroups handing their rows to whichever
+    finishes last (an acquire-release ticket since round 6).  Against its three-launch forms and round 5's hand-over (write-through
+    stores retired before a relaxed ticket, kernels_lbfgs.h): iterates bit for bit, same counters; against the host-driven loop: same counters, iterates to the
+    order of the float64 sums.  The two-launch form then twenty more times in this process: the ticket protocol has 256 workgroups
+    over 8 XCDs to go wrong on, and every run must land on the same bits."""
+    tr, target, x0, _ = _c5_inputs()
+    steps = 2
+    runs = {f: _c5_run(monkeypatch, f, tr, target, x0, steps) for f in _C5_FORMS}
+    base, forms_ran = runs["two_launch"]
+    lean, full, susp = forms_ran
+    assert lean >= steps * 19 and full == 0 and susp == 0                   # lean throughout: no pair passes y.s > 1e-10
+    assert base[-1][2] == steps * 20 and base[-1][3] == steps * 20 and base[-1][4] == 0 and base[-1][5] == steps * 20 - 1
+    for form in ("two_launch_sc1", "three_launch_deferred", "three_launch_streamed"):
+        for a, b in zip(base, runs[form][0]):
+            assert a[1:] == b[1:], (form, a[1:], b[1:])
+            assert torch.equal(a[0], b[0]), form
+    for a, b in zip(base, runs["host_driven"][0]):
+        assert a[2:] == b[2:], (a[2:], b[2:])
+        assert abs(a[1] - b[1]) <= 1e-9 * abs(b[1])
+        moved = N(b[0] - x0)
+        assert rel_l2(N(a[0] - x0), moved) < 1e-6, rel_l2(N(a[0] - x0), moved)
+    assert float((base[-1][0] - x0).norm()) > 5 * float(x0.norm())        # (the step is not a no-op: the iterate left its 1e-6 start)
+    for rep in range(20):
+        again, _ = _c5_run(monkeypatch, "two_launch", tr, target, x0, steps)
+        for a, b in zip(base, again):
+            assert a[1:] == b[1:] and torch.equal(a[0], b[0]), rep
+
+
+def test_c5_optimiser_two_items_vs_the_oracle(monkeypatch):
+    """Items 0 and 15 of the same inputs as a two-item problem (the batch is ONE parameter vector: step lengths depend on every
+    item, methods.py:539-543, so the 16-item trajectory cannot be cut into items): oracle/lbfgs.py - the restatement of
+    torch.optim.LBFGS pinned by the g6 / g9 fixtures - against the general host loop, evaluation by evaluation (loss and ||g|| to
+    1e-5), and against the device-resident optimiser's two-launch form on the whole step.  2048 frames: 256 walk chunks, the
+    epilogue's 256 workgroups."""
+    from oracle.lbfgs import LbfgsState, LogMelStft, lbfgs_minimize
+    from spectrogram_inversion_amd.lbfgs import LBFGS
+    items = [0, 15]
+    tr, target, x0, xs = _c5_inputs(items)
+    n_fft, hop, length = 2048, 512, x0.shape[1]
+    a = oracle.args_helper(n_fft // 2 + 1, np.float32, hop_length=hop, window=hann(n_fft))
+    otr = LogMelStft(a, si.mel_filterbank(22050, n_fft, 80))
+    otarget = otr.forward(N(xs))
+    assert rel_l2(N(target), otarget) < 1e-5
+    want = []
+
+    def ofg(v):
+        loss, g = otr.loss_grad(v.reshape(2, length), otarget)
+        want.append((loss, float(np.linalg.norm(g.astype(np.float64))), float(np.abs(g).max())))
+        return loss, g.reshape(-1)
+
+    xo = N(x0).copy().reshape(-1)
+    st = LbfgsState()
+    lbfgs_minimize(ofg, xo, st)
+    assert st.n_iter == 20 and st.func_evals == 20 and len(st.ys_hist) == 0
+    # the general host loop (one fg call per evaluation), recording what the objective returned
+    for name in ("SPECINV_LBFGS_TAIL_FENCE", "SPECINV_LBFGS_LEAN2", "SPECINV_LBFGS_DEFER"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv("SPECINV_LBFGS_DEVICE", "0")
+    x = x0.clone()
+    _, fg = tr.bind(x, target)
+    got = []
+
+    def rec(v):
+        loss, g = fg(v)
+        got.append((loss, float(g.double().norm()), float(g.abs().max())))
+        return loss, g
+
+    opt = LBFGS(x, device=DEV)
+    opt.step(rec)
+    assert (opt.total_iters, opt.func_evals, int(opt.pairs_accepted)) == (20, 20, 0)
+    got, want = np.array(got), np.array(want)
+    assert got.shape == want.shape == (20, 3)
+    np.testing.assert_allclose(got[:, 0], want[:, 0], rtol=1e-5)
+    np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=1e-5)
+    np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=2e-4)
+    moved = xo.reshape(2, length) - N(x0)
+    assert rel_l2(N(x - x0), moved) < 1e-4, rel_l2(N(x - x0), moved)
+    # the device-resident optimiser, as timed
+    monkeypatch.delenv("SPECINV_LBFGS_DEVICE")
+    snaps, forms_ran = _c5_run(monkeypatch, "two_launch", tr, target, x0, 1)
+    assert forms_ran[1] == 0 and forms_ran[2] == 0 and snaps[0][2:] == (20, 20, 0, 19, 0)
+    assert abs(snaps[0][1] - want[0, 0]) <= 1e-5 * want[0, 0]
+    assert rel_l2(N(snaps[0][0] - x0), moved) < 1e-4, rel_l2(N(snaps[0][0] - x0), moved)
+    assert rel_l2(N(snaps[0][0] - x0), N(x - x0)) < 1e-6

@@ -11,7 +11,7 @@ from _util import (G0_CASES, segment_errors, finite_close, g0_kwargs, hann, load
 pytestmark = pytest.mark.gpu
 
 import spectrogram_inversion_amd as si                      # noqa: E402
-from spectrogram_inversion_amd.plan import args_helper, get_plan   # noqa: E402
+from spectrogram_inversion_amd.plan import Plan, args_helper, get_plan   # noqa: E402
 
 
 def dev():
@@ -574,6 +574,41 @@ def test_two_sided_float32_on_the_frame_kernel(monkeypatch, n_fft, hop, frames, 
             assert rel_l2(out["chunked"], out["frame"]) < max(3 * e0, 1e-4), (method, rel_l2(out["chunked"], out["frame"]))
             np.testing.assert_allclose(sums["chunked"], sums["frame"], rtol=1e-4)
             assert rel_l2(state["chunked"], state["frame"]) < max(10 * e0, 1e-4)
+
+
+@pytest.mark.parametrize("method", ["admm", "griffin_lim"])
+def test_keep_state_toggled_in_the_middle_of_a_two_sided_run(method):
+    """On a two-sided float32 plan `keep_state` selects the KERNELS (frame kernel carrying Y alone / coverage kernels with X and U):
+    the choice is latched by *_init, so a toggle between init and iterate - either way - neither switches to buffers the other
+    path never reserved nor changes the iterates; it takes effect at the next init (round-5 advice)."""
+    n_fft, hop, frames = 512, 128, 12
+    rng = np.random.default_rng(77)
+    mag = (rng.random((2, n_fft, frames)) + 0.05).astype(np.float32)
+    init = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(np.complex64)
+    a = args_helper(T(init), hop_length=hop, onesided=False, window=torch.from_numpy(hann(n_fft)))
+    out = {}
+    for first in (False, True):
+        for toggle in (False, True):
+            plan = Plan(a, 2, frames, torch.float32, dev())
+            plan.keep_state(first)
+            (plan.admm_init if method == "admm" else plan.gla_init)(T(init), T(mag), 0.7)
+            code = plan.path_code
+            assert code == (0 if first else 2)
+            if toggle:
+                plan.keep_state(not first)
+            assert plan.path_code == code                          # the running method keeps its kernels
+            plan.iterate(2)
+            plan.iterate(1, eval_last=True)
+            out[first, toggle] = (N(plan.wave()), N(plan.state_spec(2 if method == "admm" else 0)))
+            if first and method == "admm":
+                assert np.isfinite(N(plan.state_spec(0))).all() and np.isfinite(N(plan.state_spec(1))).all()
+            # ... and the next init reads the flag as it stands now
+            (plan.admm_init if method == "admm" else plan.gla_init)(T(init), T(mag), 0.7)
+            assert plan.path_code == (0 if (first != toggle) else 2)
+    for first in (False, True):
+        assert np.array_equal(out[first, True][0], out[first, False][0])
+        assert np.array_equal(out[first, True][1], out[first, False][1])
+    assert rel_l2(out[True, False][0], out[False, False][0]) < 1e-4
 
 
 @pytest.mark.parametrize("n_fft,dtype,tol", [(16384, np.float32, 2e-5), (8192, np.float64, 1e-10)])
