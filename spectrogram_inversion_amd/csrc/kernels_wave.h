@@ -1,0 +1,475 @@
+// The wave-level coverage kernel: one Griffin-Lim / ADMM iteration's frame part (torch_specinv/methods.py:241-248, :464-477) for
+// float32 and float64 at power-of-two n_fft 128 ... 2048 - every stft kwarg the reference's tests sweep (test/test_griffin.py:9-32:
+// both dtypes, n_fft 128 / 256 / 512, win_length, hop, centring, pad mode, `normalized`, sidedness) - on the coverage path's
+// buffers.  Round 6; the generic kernels (kernels_generic.h) keep every other size.
+//
+// What k_iter_pair / k_iter_pair_dr do with a WORKGROUP per frame pair - stage barriers, one wave per SIMD parked between them,
+// 22 - 57 % of their bytes' roofline (profiles/r05_generic.txt) - a lane group of ONE wave does here:
+//   * a real frame of n_fft = 2 M samples is M complex points z[n] = x[2n] + i x[2n+1], held RG = M / LG per lane by a group of LG
+//     lanes (64 / LG frames per wave: 8 frames at n_fft 128 / 256, 4 at 512, one at 1024 / 2048);
+//   * the M-point transform is a Stockham autosort in two or three passes of radix 8 / 16 butterflies in registers; between passes
+//     the points cross the group through a WAVE-PRIVATE piece of LDS (in place: a wave's LDS operations execute in order, all of a
+//     pass's reads are issued before its first write).  No workgroup barrier after the twiddle table is staged: the waves of a CU
+//     drift apart, one streams while another transforms;
+//   * the first pass takes its points straight from the signal (windowed on the way, torch.stft's padding resolved per sample at
+//     the edges only), the last inverse pass writes the windowed synthesis frame straight to the frames buffer;
+//   * between the transforms the group walks the conjugate pairs (k, M - k) of its frame: real-FFT split, the per-bin update of
+//     kernels_generic.h (update_core: the same operations as every other coverage kernel - momentum or ADMM step, projection by
+//     proj_inv), the inverse split; state and target of a chunk of pairs are requested together before the first is used.  A
+//     two-sided spectrogram updates the mirror bins N - k with their own state as k_iter_pair does and takes the Hermitian part.
+// The overlap-add stays k_ola / k_ola_f4 / k_ola_d2 (fixed summation order), so x changes only by the transform's rounding.
+// Bytes per frame and iteration as for the kernels it replaces: 8 hop + 20 F + 8 N elements (ADMM 36 F).
+#pragma once
+#include "wave_api.h"
+
+#ifndef SPECINV_WAVE_ABL            // timing experiments (WRONG RESULTS): 1 no state / target loads, 2 no state stores, 4 no frame
+#define SPECINV_WAVE_ABL 0          // stores, 8 no sample / window loads, 16 no LDS passes
+#endif
+
+namespace specinv {
+namespace wave {
+
+// lanes per frame and the passes' radices, by log2 M (M = n_fft / 2)
+template <int LOGM>
+struct Geo;
+template <>
+struct Geo<6> {      // n_fft 128:  8 x 8
+  static constexpr int LG = 8, NPASS = 2, R0 = 8, R1 = 8, R2 = 1;
+};
+template <>
+struct Geo<7> {      // n_fft 256:  16 x 8
+  static constexpr int LG = 8, NPASS = 2, R0 = 16, R1 = 8, R2 = 1;
+};
+template <>
+struct Geo<8> {      // n_fft 512:  16 x 16
+  static constexpr int LG = 16, NPASS = 2, R0 = 16, R1 = 16, R2 = 1;
+};
+template <>
+struct Geo<9> {      // n_fft 1024: 8 x 8 x 8
+  static constexpr int LG = 64, NPASS = 3, R0 = 8, R1 = 8, R2 = 8;
+};
+template <>
+struct Geo<10> {     // n_fft 2048: 16 x 8 x 8
+  static constexpr int LG = 64, NPASS = 3, R0 = 16, R1 = 8, R2 = 8;
+};
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+// LDS position of point p of a frame: one element of slack after every R0 - the first pass writes point j R0 + i from lane j, a
+// stride of R0 elements that would put every lane of a store on the same banks
+template <int PS>
+__device__ __host__ __forceinline__ constexpr int phys(int p) { return p + (p >> PS); }
+
+template <typename T, bool INV>
+__device__ __forceinline__ void bf16(cplx<T> (&a)[16]) {
+  constexpr double c1d = 0.92387953251128675613, s1d = 0.38268343236508977173, hd = 0.70710678118654752440;
+  const T c1 = (T)c1d, s1 = (T)s1d, h = (T)hd;
+  // n = 4 n1 + n0: radix 4 over n1 (slot n0 + 4 k1), twiddle W16^(n0 k1), radix 4 over n0 (slot 4 k1 + k0 = X[k1 + 4 k0])
+#pragma unroll
+  for (int n0 = 0; n0 < 4; ++n0) bf4<T, INV>(a[n0], a[n0 + 4], a[n0 + 8], a[n0 + 12]);
+  auto tw = [&](cplx<T> v, T c, T s) {      // v * (c - i s), conjugated for the inverse
+    return INV ? mk<T>(v.x * c - v.y * s, v.y * c + v.x * s) : mk<T>(v.x * c + v.y * s, v.y * c - v.x * s);
+  };
+  a[5] = tw(a[5], c1, s1);                   // W16^1
+  a[6] = tw(a[6], h, h);                     // W16^2
+  a[7] = tw(a[7], s1, c1);                   // W16^3
+  a[9] = tw(a[9], h, h);                     // W16^2
+  a[10] = rot_mi<T, INV>(a[10]);             // W16^4 = -i
+  a[11] = tw(a[11], -h, h);                  // W16^6
+  a[13] = tw(a[13], s1, c1);                 // W16^3
+  a[14] = tw(a[14], -h, h);                  // W16^6
+  a[15] = tw(a[15], -c1, -s1);               // W16^9
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) bf4<T, INV>(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+  cplx<T> o[16];
+#pragma unroll
+  for (int k0 = 0; k0 < 4; ++k0)
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) o[k1 + 4 * k0] = a[k0 + 4 * k1];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = o[i];
+}
+template <typename T, int R, bool INV>
+__device__ __forceinline__ void bfly(cplx<T> (&v)[R]) {
+  if constexpr (R == 16) bf16<T, INV>(v);
+  else Butterfly<T, R, INV>::run(v, nullptr, 0);
+}
+
+// Twiddles of a pass with NS > 1 from the pass's OWN table in LDS, tab[(q - 1) NS + k] = W_(NS R)^(k q): lanes with consecutive k read
+// consecutive entries.  (Round 6, first version: one half-circle table W_N^e for every pass, entry (k q) << shift - a stride of
+// q 2^shift elements across the lanes, 16 lanes of a read on the same banks: SQ_LDS_BANK_CONFLICT 53 % of the LDS cycles at float64
+// n_fft 2048.)  Conjugated for the inverse.
+template <typename T, bool INV>
+__device__ __forceinline__ cplx<T> tw_get(const cplx<T>* __restrict__ tab, int idx) {
+  const cplx<T> w = tab[idx];
+  return mk<T>(w.x, INV ? -w.y : w.y);
+}
+// entries of the tables of a geometry: pass 1 (NS = R0) and, with three passes, pass 2 (NS = R0 R1)
+template <int LOGM>
+struct Tabs {
+  using G = Geo<LOGM>;
+  static constexpr int N1 = G::R0 * (G::R1 - 1);
+  static constexpr int N2 = G::NPASS == 3 ? G::R0 * G::R1 * (G::R2 - 1) : 0;
+  static constexpr int NPAIR = ((1 << LOGM) / 2) / G::LG;
+  static constexpr int TOTAL = N1 + N2 + NPAIR;           // + W_N^(i LG), the real-FFT split's step between a lane's pairs
+};
+
+// One Stockham pass on the group's LDS buffer, in place: butterfly j (of M / R) reads points j + q M / R, multiplies by W_m^(k q)
+// (m = NS R, j = blk NS + k), transforms, writes points blk NS R + k + i NS.  A lane owns butterflies gl, gl + LG, ...
+// what orders one lane's LDS write before another lane's read of it: the hardware executes a wave's LDS operations in order; the
+// compiler is told by a wavefront-scope fence (no instruction)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+template <typename T, int R, int LNS, bool INV, int LOGM, int LG, int PS>
+__device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict__ tab, int gl) {
+  constexpr int M = 1 << LOGM, NB = M / R, PER = NB / LG, NS = 1 << LNS;
+  static_assert(PER >= 1, "a lane owns at least one butterfly of every pass");
+  if (SPECINV_WAVE_ABL & 16) return;
+  cplx<T> v[PER][R];
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    const int j = gl + it * LG;
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[it][q] = buf[phys<PS>(j + q * NB)];
+  }
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    const int j = gl + it * LG, k = j & (NS - 1);
+    if (NS > 1) {
+#pragma unroll
+      for (int q = 1; q < R; ++q) v[it][q] = cmul(v[it][q], tw_get<T, INV>(tab, (q - 1) * NS + k));
+    }
+    bfly<T, R, INV>(v[it]);
+  }
+  wave_sync();
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    const int j = gl + it * LG, blk = j >> LNS, k = j & (NS - 1);
+    const int base = ((blk << LNS) * R) + k;
+#pragma unroll
+    for (int i = 0; i < R; ++i) buf[phys<PS>(base + i * NS)] = v[it][i];
+  }
+  wave_sync();
+}
+
+// registers: a float64 frame of 16 points per lane is 64 registers before the first butterfly - those instantiations may take 256
+// (two waves per SIMD, which is also what their 17 KB of LDS per wave allow); everything else is held to 128 (four per SIMD)
+template <typename T, int LOGM>
+constexpr int max_threads() { return (sizeof(T) == 8 && (1 << LOGM) / Geo<LOGM>::LG >= 16) ? 512 : 1024; }
+
+template <typename T, int LOGM, int MODE, bool TWO, bool EVAL>
+__global__ __launch_bounds__((max_threads<T, LOGM>())) void k_wave_iter(WaveIterArgs<T> a) {
+  using G = Geo<LOGM>;
+  using C = cplx<T>;
+  constexpr int M = 1 << LOGM, N = 2 * M, LG = G::LG, FPW = 64 / LG;
+  constexpr int PS = ilog2(G::R0);
+  constexpr int MP = phys<PS>(M) + 1;                    // a frame's points in LDS
+  constexpr int LR0 = ilog2(G::R0), LR1 = ilog2(G::R1);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using TB = Tabs<LOGM>;
+  C* tab1 = reinterpret_cast<C*>(smem);                  // pass tables, then W_N^(i LG)
+  C* tab2 = tab1 + TB::N1;
+  C* tabs = tab2 + TB::N2;
+  // (the wave's index as a scalar: everything derived from it - the group of frames, the bases of their state, target and
+  // synthesis rows - then lives in scalar registers and the loads take the base + 32-bit offset form; from threadIdx.x alone the
+  // compiler would carry a 64-bit address per access in vector registers)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63, g = lane / LG, gl = lane % LG;
+  C* buf = tab1 + TB::TOTAL + (size_t)(wave * FPW + g) * MP;
+  {
+    constexpr int NS1 = G::R0, SH1 = LOGM + 1 - LR0 - LR1;             // W_(NS R)^(k q) = W_N^((k q) N / (NS R))
+    for (int i = threadIdx.x; i < TB::N1; i += blockDim.x) tab1[i] = a.c.tw[((i & (NS1 - 1)) * (i / NS1 + 1)) << SH1];
+    if constexpr (G::NPASS == 3) {
+      constexpr int NS2 = G::R0 * G::R1, SH2 = LOGM + 1 - LR0 - LR1 - ilog2(G::R2);
+      for (int i = threadIdx.x; i < TB::N2; i += blockDim.x) tab2[i] = a.c.tw[((i & (NS2 - 1)) * (i / NS2 + 1)) << SH2];
+    }
+    for (int i = threadIdx.x; i < TB::NPAIR; i += blockDim.x) tabs[i] = a.c.tw[i * LG];
+  }
+  const C wlane = a.c.tw[gl];                            // W_N^gl: pair k = gl + i LG takes W_N^k = wlane W_N^(i LG)
+  __syncthreads();
+  const FrameCfg<T>& c = a.c;
+  const int Tn = c.n_frames, F = c.n_freq;
+  const int64_t total = (int64_t)a.batch * Tn, n_groups = (total + FPW - 1) / FPW;
+  const int64_t w0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave, nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const T hs = T(0.5) * c.fwd_scale;
+  const T coef = a.coef, inv1p = a.inv1p;
+  constexpr bool eval = EVAL, two = TWO;
+  const T* __restrict__ win = c.window;
+  double s_d = 0, s_o = 0;
+  for (int64_t grp = w0; grp < n_groups; grp += nw) {
+    const int64_t f0 = grp * FPW;                   // the wave's first frame (scalar); lane group g owns frame f0 + g
+    const int64_t fi = f0 + g;
+    if (fi >= total) continue;
+    const int64_t bi = total < ((int64_t)1 << 31) ? (int64_t)((unsigned)fi / (unsigned)Tn) : fi / Tn;   // (a 64-bit division is ~200 instructions)
+    const int t = (int)(fi - bi * Tn);
+    C* S0u = a.S0 + f0 * F;
+    C* S1u = MODE == 1 ? a.S1 + f0 * F : nullptr;
+    const T* magu = a.mag + f0 * F;
+    const int so = g * F;                           // this group's row inside the wave's block of state rows
+    // ---- analysis, first pass: butterfly j takes points j + q M / R0 from the signal
+    {
+      constexpr int R = G::R0, NB = M / R, PER = NB / LG;
+      static_assert(PER >= 1, "a lane owns at least one butterfly of the first pass");
+      const int64_t start = (int64_t)t * c.hop - c.pad;
+      const T* xr = a.x + bi * c.length;
+      const T* xp = xr + start;
+      const bool interior = start >= 0 && start + N <= c.length;
+      const bool aligned = ((bi * c.length + start) & 1) == 0;
+      C v[PER][R];
+      if (SPECINV_WAVE_ABL & 8) {
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+#pragma unroll
+          for (int q = 0; q < R; ++q) v[it][q] = mk<T>(T(gl + it + q), T(t));
+      } else if (interior && aligned) {
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+#pragma unroll
+          for (int q = 0; q < R; ++q) v[it][q] = *reinterpret_cast<const C*>(xp + 2 * (gl + it * LG + q * NB));
+      } else if (interior) {
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            const int p = gl + it * LG + q * NB;
+            v[it][q] = mk<T>(xp[2 * p], xp[2 * p + 1]);
+          }
+      } else {
+        // a frame that reaches into the padding (the first and last n_fft / (2 hop) frames of an item): torch.stft's pad modes per
+        // sample - index arithmetic with 64-bit remainders - in a ROLLED loop that parks the lane's points in its LDS buffer (idle
+        // until the first pass writes it); unrolled sixteen-fold in front of every frame it cost 4 000 instructions and the
+        // registers of the common path
+#pragma unroll 1
+        for (int m = 0; m < M / LG; ++m) {
+          const int p = gl + m * LG;
+          buf[phys<PS>(p)] = mk<T>(load_padded(xr, c.length, start + 2 * p, c.pad_mode), load_padded(xr, c.length, start + 2 * p + 1, c.pad_mode));
+        }
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+#pragma unroll
+          for (int q = 0; q < R; ++q) v[it][q] = buf[phys<PS>(gl + it * LG + q * NB)];
+      }
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const C w2 = (SPECINV_WAVE_ABL & 8) ? mk<T>(T(0.5), T(0.25)) : *reinterpret_cast<const C*>(win + 2 * (gl + it * LG + q * NB));
+          v[it][q] = mk<T>(v[it][q].x * w2.x, v[it][q].y * w2.y);
+        }
+        bfly<T, R, false>(v[it]);
+        const int j = gl + it * LG;
+#pragma unroll
+        for (int i = 0; i < R; ++i) buf[phys<PS>(j * R + i)] = v[it][i];
+      }
+      wave_sync();
+    }
+    pass_lds<T, G::R1, LR0, false, LOGM, LG, PS>(buf, tab1, gl);
+    if constexpr (G::NPASS == 3) pass_lds<T, G::R2, LR0 + LR1, false, LOGM, LG, PS>(buf, tab2, gl);
+    // ---- the conjugate pairs (k, M - k): split, update, inverse split
+    auto upd = [&](C r, int f) -> C {               // one bin of this frame
+      C n0, n1;
+      const C zero = mk<T>(T(0), T(0));
+      const C y = update_core<T, MODE>(r, magu[so + f], S0u[so + f], MODE == 1 ? S1u[so + f] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
+      S0u[so + f] = n0;
+      if (MODE == 1) S1u[so + f] = n1;
+      return y;
+    };
+    auto herm = [&](C r, int f) -> C {              // two-sided: bins f and N - f, each with its own state; the Hermitian part
+      const C y1 = upd(r, f), y2 = upd(conj(r), N - f);
+      return mk<T>(T(0.5) * (y1.x + y2.x), T(0.5) * (y1.y - y2.y));
+    };
+    constexpr int NPAIR = (M / 2) / LG;             // k = gl + i LG < M / 2
+    constexpr int CH = sizeof(T) == 8 ? 2 : (NPAIR >= 4 ? 4 : NPAIR);   // pairs whose state is requested together
+#pragma unroll 1
+    for (int i0 = 0; i0 < NPAIR; i0 += CH) {
+      C za[CH], zb[CH], s0a[CH], s0b[CH], s1a[CH], s1b[CH];
+      T ma[CH], mb[CH];
+      // requests first (one-sided: the common case; a two-sided frame takes the per-bin path below)
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int k = gl + (i0 + u) * LG;
+        const int kb = k == 0 ? M : M - k;          // k = 0 pairs the real bins 0 and M
+        if (!two && (SPECINV_WAVE_ABL & 1)) {
+          s0a[u] = s0b[u] = s1a[u] = s1b[u] = mk<T>(T(k), T(1));
+          ma[u] = mb[u] = T(0.5);
+        } else if (!two) {
+          s0a[u] = S0u[so + k];
+          s0b[u] = S0u[so + kb];
+          ma[u] = magu[so + k];
+          mb[u] = magu[so + kb];
+          if (MODE == 1) {
+            s1a[u] = S1u[so + k];
+            s1b[u] = S1u[so + kb];
+          }
+        }
+        za[u] = buf[phys<PS>(k)];
+        zb[u] = buf[phys<PS>(k == 0 ? 0 : M - k)];
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int k = gl + (i0 + u) * LG;
+        const int kb = k == 0 ? M : M - k;
+        C xk, xm;                                   // the frame's bins k and kb
+        const C w = (i0 + u) == 0 ? wlane : cmul(wlane, tabs[i0 + u]);   // W_N^k
+        if (k == 0) {
+          xk = mk<T>((za[u].x + za[u].y) * c.fwd_scale, T(0));
+          xm = mk<T>((za[u].x - za[u].y) * c.fwd_scale, T(0));
+        } else {
+          const C bc = conj(zb[u]);
+          const C e = mk<T>((za[u].x + bc.x) * hs, (za[u].y + bc.y) * hs);
+          const C d = mk<T>((za[u].x - bc.x) * hs, (za[u].y - bc.y) * hs);
+          const C wo = cmul(w, mk<T>(d.y, -d.x));   // W^k (-i d)
+          xk = e + wo;
+          xm = conj(e - wo);
+        }
+        C yk, ym;
+        if (!two) {
+          C n0, n1;
+          const C zero = mk<T>(T(0), T(0));
+          yk = update_core<T, MODE>(xk, ma[u], s0a[u], MODE == 1 ? s1a[u] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
+          if (!(SPECINV_WAVE_ABL & 2)) S0u[so + k] = n0;
+          if (MODE == 1 && !(SPECINV_WAVE_ABL & 2)) S1u[so + k] = n1;
+          ym = update_core<T, MODE>(xm, mb[u], s0b[u], MODE == 1 ? s1b[u] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
+          if (!(SPECINV_WAVE_ABL & 2)) S0u[so + kb] = n0;
+          if (MODE == 1 && !(SPECINV_WAVE_ABL & 2)) S1u[so + kb] = n1;
+        } else if (k == 0) {
+          yk = upd(xk, 0);
+          ym = upd(xm, M);
+        } else {
+          yk = herm(xk, k);
+          ym = herm(xm, kb);
+        }
+        if (k == 0) {                               // irfft / ifft(.).real: the imaginary parts of bins 0 and M do not count
+          buf[phys<PS>(0)] = mk<T>(yk.x + ym.x, yk.x - ym.x);
+        } else {
+          const C p = mk<T>(yk.x + ym.x, yk.y - ym.y);                   // Y_k + conj Y_{M-k}
+          const C q = cmul(mk<T>(yk.x - ym.x, yk.y + ym.y), conj(w));    // (Y_k - conj Y_{M-k}) conj W^k
+          buf[phys<PS>(k)] = mk<T>(p.x - q.y, p.y + q.x);                // p + i q
+          buf[phys<PS>(M - k)] = mk<T>(p.x + q.y, q.x - p.y);            // conj p + i conj q
+        }
+      }
+    }
+    if (gl == 0) {                                  // the one bin that is its own partner: M / 2
+      const C z = buf[phys<PS>(M / 2)];
+      const C xk = mk<T>(z.x * c.fwd_scale, -z.y * c.fwd_scale);
+      const C y = two ? herm(xk, M / 2) : upd(xk, M / 2);
+      buf[phys<PS>(M / 2)] = mk<T>(T(2) * y.x, T(-2) * y.y);
+    }
+    // ---- synthesis: the passes again with conjugated twiddles, the last one straight to the frames buffer
+    wave_sync();
+    pass_lds<T, G::R0, 0, true, LOGM, LG, PS>(buf, tab1, gl);
+    if constexpr (G::NPASS == 3) pass_lds<T, G::R1, LR0, true, LOGM, LG, PS>(buf, tab1, gl);
+    {
+      constexpr int R = G::NPASS == 3 ? G::R2 : G::R1, LNS = LOGM - ilog2(R), NS = 1 << LNS, NB = M / R, PER = NB / LG;
+      static_assert(NB == NS, "the last pass has one block");
+      const C* tabl = G::NPASS == 3 ? tab2 : tab1;
+      C v[PER][R];
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int j = gl + it * LG;
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[it][q] = buf[phys<PS>(j + q * NB)];
+      }
+      T* fru = a.frames + f0 * N;
+      const int fo = g * N;
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int j = gl + it * LG;                 // k = j, blk = 0
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[it][q] = cmul(v[it][q], tw_get<T, true>(tabl, (q - 1) * NS + j));
+        bfly<T, R, true>(v[it]);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const int p = j + i * NS;
+          const C w2 = *reinterpret_cast<const C*>(win + 2 * p);
+          if ((SPECINV_WAVE_ABL & 4) && v[it][i].x != T(1.2345e30)) continue;
+          *reinterpret_cast<C*>(fru + fo + 2 * p) = mk<T>((v[it][i].x * c.inv_scale) * w2.x, (v[it][i].y * c.inv_scale) * w2.y);
+        }
+      }
+      wave_sync();
+    }
+  }
+  if (eval) {
+    const double d = wave_sum(s_d), o = wave_sum(s_o);
+    if (lane == 0) {
+      a.partials[2 * w0] = d;
+      a.partials[2 * w0 + 1] = o;
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+struct Launch {
+  int wgs = 0, waves_per_wg = 0;
+  size_t lds = 0;
+};
+template <typename T, int LOGM>
+const void* kernel_of(int mode) {            // mode: bit 0 ADMM, bit 1 two-sided, bit 2 evaluating
+  switch (mode & 7) {
+    case 0: return (const void*)k_wave_iter<T, LOGM, 0, false, false>;
+    case 1: return (const void*)k_wave_iter<T, LOGM, 1, false, false>;
+    case 2: return (const void*)k_wave_iter<T, LOGM, 0, true, false>;
+    case 3: return (const void*)k_wave_iter<T, LOGM, 1, true, false>;
+    case 4: return (const void*)k_wave_iter<T, LOGM, 0, false, true>;
+    case 5: return (const void*)k_wave_iter<T, LOGM, 1, false, true>;
+    case 6: return (const void*)k_wave_iter<T, LOGM, 0, true, true>;
+    default: return (const void*)k_wave_iter<T, LOGM, 1, true, true>;
+  }
+}
+
+template <typename T, int LOGM>
+Launch shape(int64_t frames_total, int mode) {
+  using G = Geo<LOGM>;
+  constexpr int M = 1 << LOGM, FPW = 64 / G::LG, PS = ilog2(G::R0), MP = phys<PS>(M) + 1;
+  static int n_cu = 0;
+  // workgroups of four or eight waves (each carries its own twiddle table), whichever puts more waves on a CU by the runtime's
+  // own count of resident workgroups (registers and LDS); one launch fills the chip once and every wave walks its share of frames
+  static int wpw_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, per_cu_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto lds_of = [&](int w) { return sizeof(cplx<T>) * ((size_t)Tabs<LOGM>::TOTAL + (size_t)w * FPW * MP); };
+  const void* fn = kernel_of<T, LOGM>(mode);
+  if (wpw_of[mode] == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop{};
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(8));
+    int best = 0;
+    for (int w : {4, 8}) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * w, lds_of(w)) != hipSuccess) nb = 0;
+      if (const char* e = getenv("SPECINV_WAVE_WPW")) {
+        if (atoi(e) != w) continue;
+      }
+      if (nb * w > best) {
+        best = nb * w;
+        wpw_of[mode] = w;
+        per_cu_of[mode] = nb;
+      }
+    }
+    (void)hipGetLastError();
+    if (wpw_of[mode] == 0) {
+      wpw_of[mode] = 4;
+      per_cu_of[mode] = 1;
+    }
+  }
+  const int wpw = wpw_of[mode];
+  const int64_t groups = (frames_total + FPW - 1) / FPW;
+  Launch l;
+  l.waves_per_wg = wpw;
+  l.wgs = (int)std::max<int64_t>(1, std::min<int64_t>((groups + wpw - 1) / wpw, (int64_t)n_cu * per_cu_of[mode]));
+  l.lds = lds_of(wpw);
+  return l;
+}
+
+template <typename T, int LOGM>
+int launch_one(const WaveIterArgs<T>& a, hipStream_t stream) {
+  const int mode = (a.mode & 1) | (a.c.onesided ? 0 : 2) | (a.eval ? 4 : 0);
+  const Launch l = shape<T, LOGM>((int64_t)a.batch * a.c.n_frames, mode);
+  const void* fn = kernel_of<T, LOGM>(mode);
+  WaveIterArgs<T> args = a;
+  void* kargs[] = {&args};
+  SI_HIP(hipLaunchKernel(fn, dim3(l.wgs), dim3(64 * l.waves_per_wg), kargs, l.lds, stream));
+  return SPECINV_OK;
+}
+
+}  // namespace wave
+}  // namespace specinv

@@ -11,6 +11,7 @@
 #include "kernels_adjoint.h"
 #include "fast_state.h"
 #include "kernels_generic.h"
+#include "wave_api.h"
 #include "kernels_lbfgs.h"
 #include "kernels_big.h"
 #include "lbfgs_dev.h"
@@ -117,6 +118,7 @@ struct PlanT final : PlanBase {
   DevBuf tw2, big_y;
   bool tw_lds = false;         // k_iter_pair: the twiddle table copied to LDS (small n_fft)
   bool use_dr = false;         // k_iter_pair_dr: the digit-reversed in-place transform (power-of-two n_fft)
+  bool use_wave = false;       // k_wave_iter (kernels_wave.h): the iteration's frame part on a transform that lives in one wave
   size_t dr_lds = 0;
   int dr_threads = 0;
   double sum_m2 = 0, count = 0;
@@ -290,6 +292,16 @@ struct PlanT final : PlanBase {
       const bool wins = sizeof(T) == 8 ? (n == 1024 || n == 2048) : n == 2048;
       use_dr = dr_lds <= 160 * 1024 - 256 && !(dr_env && dr_env[0] == '0') && (wins || (dr_env && dr_env[0] == '1'));
     }
+    // Power-of-two n_fft 128 ... 2048: the wave-level coverage kernel (kernels_wave.h, round 6) - float64 at every size it covers,
+    // float32 at n_fft 128 / 256 (512 ... 4096 have the packed wave-level kernels of fast_core.h; what falls through those - a
+    // two-sided run that keeps X and U - stays on k_iter_pair).  SPECINV_GENERIC_WAVE=0 never, =1 wherever it covers.
+    {
+      const char* we = getenv("SPECINV_GENERIC_WAVE");
+      // measured (tools/bench_wave.py, round 6): float64 one-sided 2048 / 1024 / 512 / 256: -9 / -31 / -14 / -26 %, float32 128 / 256
+      // -41 / -13 %; a two-sided frame - four bins per conjugate pair, taken one at a time - is 10 % SLOWER than k_iter_pair
+      const bool wins = cfg.onesided && (sizeof(T) == 8 || n <= 256);
+      use_wave = !big && wave_iter_covers(n) && !(we && we[0] == '0') && (wins || (we && we[0] == '1'));
+    }
     if (std::max(lds_bytes, use_dr ? dr_lds : (size_t)0) > 48 * 1024) {
       // (the attribute belongs to the kernel, not to the plan: never lower what another plan has asked for)
       static std::atomic<int> lds_cap{0};
@@ -343,6 +355,10 @@ struct PlanT final : PlanBase {
   void launch_geometry(int out[4]) const override {
     if (fast_path()) {
       fast.geometry(out);
+    } else if (use_wave) {                     // a lane group of one wave per frame, every wave walking its share
+      out[2] = wave_iter_waves<T>(N(), (int64_t)B() * Tn(), &out[0]);   // (workgroups of four or eight waves: kernels_wave.h)
+      out[1] = Tn();
+      out[3] = 8;
     } else {                                   // generic: one workgroup per frame pair
       out[0] = (use_dr ? dr_threads : frame_threads()) / 64;
       out[1] = (Tn() + 1) / 2;
@@ -375,10 +391,10 @@ struct PlanT final : PlanBase {
 
   // `len`: samples per row of `out` (default: the plan's length; another length with the same frame count is allowed
   // for the un-normalised form only, the envelope belongs to the plan's length)
-  int launch_ola(const T* fr, T* out, bool use_env, int64_t len = -1) {
+  int launch_ola(const T* fr, T* out, bool use_env, int64_t len = -1, int items = -1) {   // items: rows of `fr` / `out` (default: the batch)
     if (len < 0) len = length;
     SI_CHECK(!use_env || len == length, SPECINV_EINVAL, "envelope division needs the plan's own signal length");
-    const int64_t total = (int64_t)B() * len;
+    const int64_t total = (int64_t)(items < 0 ? B() : items) * len;
     if constexpr (std::is_same<T, float>::value) {
       if (cfg.hop_length % 4 == 0 && N() % 4 == 0 && pad % 4 == 0 && len % 4 == 0) {
         hipLaunchKernelGGL(k_ola_f4, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, stream, fr, env.as<float>(), out,
@@ -705,6 +721,42 @@ struct PlanT final : PlanBase {
           SI_TRY(launch_ola(frames.as<T>(), x.as<T>(), true));
           continue;
         }
+        if (use_wave) {
+          // The frames take a round trip between this kernel and the overlap-add (16 N of the 8 hop + 20 F + 8 N elements per frame).
+          // Experiment (SPECINV_WAVE_PART_MB > 0; default off): the batch walked in PARTS of a few items whose frames fit the
+          // Infinity Cache - k_wave_iter, then k_ola on the same items, every part through the SAME piece of the frames buffer.
+          // Measured at 32 / 64 / 128 / 256 MB per part: float64 2048 / 512 0.420 / 0.363 / 0.337 / 0.351 against 0.353 ms whole,
+          // float32 256 / 64 0.456 / 0.407 / 0.396 / 0.404 against 0.395: the cache does not hold the frames against the state
+          // streams that pass through it meanwhile.  (An evaluating launch always takes the batch whole.)
+          static const double part_mb = [] {
+            const char* e = getenv("SPECINV_WAVE_PART_MB");
+            return e ? atof(e) : 0.0;
+          }();
+          const double item_mb = (double)Tn() * N() * sizeof(T) / (1024.0 * 1024.0);
+          int ipp = B();
+          if (!ev && part_mb > 0) ipp = (int)std::max(1.0, std::min((double)B(), std::floor(part_mb / item_mb)));
+          if (ev) SI_TRY(partials.reserve((size_t)2 * wave_iter_waves<T>(N(), (int64_t)B() * Tn()) * sizeof(double)));
+          for (int b0 = 0; b0 < B(); b0 += ipp) {
+            const int nb = std::min(ipp, B() - b0);
+            const int64_t so = (int64_t)b0 * Tn() * n_freq;
+            WaveIterArgs<T> wa{};
+            wa.c = fci;
+            wa.x = x.as<T>() + (int64_t)b0 * length;
+            wa.S0 = specA.as<C>() + so;
+            wa.S1 = method == Method::Gla ? (C*)nullptr : specB.as<C>() + so;
+            wa.mag = mag.as<T>() + so;
+            wa.coef = coef;
+            wa.inv1p = inv1p;
+            wa.frames = frames.as<T>();
+            wa.partials = partials.as<double>();
+            wa.batch = nb;
+            wa.mode = method == Method::Gla ? 0 : 1;
+            wa.eval = ev ? 1 : 0;
+            SI_TRY(wave_iter_launch<T>(wa, stream));
+            SI_TRY(launch_ola(frames.as<T>(), x.as<T>() + (int64_t)b0 * length, true, -1, nb));
+          }
+          continue;
+        }
         const dim3 grid((Tn() + 1) / 2, B()), blk(use_dr ? dr_threads : frame_threads());   // two frames per complex FFT
         static const bool ip_small = !(getenv("SPECINV_GENERIC_IP256") && getenv("SPECINV_GENERIC_IP256")[0] == '0');
         {
@@ -737,7 +789,8 @@ struct PlanT final : PlanBase {
     }
     if (eval_last) {
       const int64_t n_part = fast_path() ? (int64_t)fast.n_partials
-                             : big ? (int64_t)B() * Tn() * ceil_div(N() / 2 + 1, 256) : (int64_t)B() * ((Tn() + 1) / 2);
+                             : big ? (int64_t)B() * Tn() * ceil_div(N() / 2 + 1, 256)
+                             : use_wave ? (int64_t)wave_iter_waves<T>(N(), (int64_t)B() * Tn()) : (int64_t)B() * ((Tn() + 1) / 2);
       if (deferred_slot >= 0) {
         // deferred evaluation (run_loop with tol == 0 and no callback): keep the sums on the device
         SI_TRY(eval_log.reserve((size_t)(deferred_slot + 1) * 2 * sizeof(double)));

@@ -1,0 +1,31 @@
+// Host interface of the wave-level coverage kernel (kernels_wave.h, compiled in tu_wave.hip): one Griffin-Lim / ADMM iteration's
+// frame part - torch_specinv/methods.py:241-248, :464-477 - for float32 AND float64 at power-of-two n_fft 128 ... 2048, any hop,
+// centring, pad mode, sidedness and `normalized`, on the coverage path's buffers (x, the (B, T, F) state and target, the frames
+// that k_ola overlap-adds): what k_iter_pair / k_iter_pair_dr compute, on a transform that lives in a wave instead of a workgroup.
+#pragma once
+#include "kernels_generic.h"
+
+namespace specinv {
+
+template <typename T>
+struct WaveIterArgs {
+  FrameCfg<T> c;            // n_fft, n_freq, n_frames, hop, pad, pad_mode, onesided, length, scales, tw (n_fft entries), window
+  const T* x;               // (B, length)
+  cplx<T>* S0;              // (B, T, F): pre_spec (Griffin-Lim) / X (ADMM)
+  cplx<T>* S1;              //            U (ADMM)
+  const T* mag;             // (B, T, F)
+  T coef, inv1p;
+  T* frames;                // (B, T, n_fft) out: windowed synthesis frames
+  double* partials;         // [waves][2] evaluation sums (eval != 0)
+  int batch, mode, eval;    // mode 0 Griffin-Lim, 1 ADMM
+};
+
+// n_fft the kernel covers (a power of two, 128 ... 2048)
+bool wave_iter_covers(int n_fft);
+// workgroups x waves the launch will use for `frames_total` frames: the number of partial-sum pairs an evaluating launch leaves
+template <typename T>
+int wave_iter_waves(int n_fft, int64_t frames_total, int* waves_per_workgroup = nullptr);
+template <typename T>
+int wave_iter_launch(const WaveIterArgs<T>& a, hipStream_t stream);
+
+}  // namespace specinv

@@ -176,7 +176,7 @@ class Plan:
         """Diagnostics: how the iteration kernel is launched (`specinv_plan_launch_geometry`)."""
         out = (C.c_int32 * 4)()
         _lib.check(self.lib.specinv_plan_launch_geometry(self._h, out))
-        kernel = ("k_iter_pair", "k_fused4", "k_fused", "k_semi", "k_hop", "k_fused4_td", "k_fused_td", "k_hop_td")[out[3]]
+        kernel = ("k_iter_pair", "k_fused4", "k_fused", "k_semi", "k_hop", "k_fused4_td", "k_fused_td", "k_hop_td", "k_wave_iter")[out[3]]
         return {"waves_per_workgroup": out[0], "chunks": out[1], "waves": out[2], "kernel": kernel}
 
     def force_generic(self, on=True):

@@ -202,14 +202,15 @@ def test_exact_projection_switch_of_the_drop_in_functions(monkeypatch):
     assert rel_l2(exact_admm, ref) < 1e-5 and rel_l2(approx_admm, ref) < 1e-5
 
 
-@pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "frame_lds_prespec", "generic", "float64"])
+@pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "frame_lds_prespec", "generic", "float64", "float64_workgroup"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
     """g14 (consistent magnitudes of a real signal, true phase perturbed by 0.5 rad): 100 iterations held to the STRICT
     gate min(1e-4, 6 x the reference's float32-vs-float64 noise) - no segment statistics - on every kernel path: the
     frame kernel (default for a problem this small), the fused chunk-walking kernel with the momentum carried as a signal
     (`k_fused_td<4, 4>`) and on pre_spec itself (`k_fused<4, 4>`), the chunked frame kernel with the overlap-add in LDS, the
-    generic kernels, and float64.  (g2's random magnitudes are inconsistent: there a near-zero
+    generic kernels, and float64 (the wave-level coverage kernel `k_wave_iter` since round 6, and the workgroup-level kernel it
+    replaced).  (g2's random magnitudes are inconsistent: there a near-zero
     bin can decorrelate a neighbourhood between ANY two float32 runs, see test_gla_waveforms.)"""
     from spectrogram_inversion_amd.plan import Plan, clear_plan_cache
     g = load_golden("g14_wellcond")
@@ -222,19 +223,21 @@ def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
         monkeypatch.setenv("SPECINV_SMALL_FRAMES", "0")
     if path in ("frame_lds", "frame_lds_prespec"):
         monkeypatch.setenv("SPECINV_DISABLE_FUSED", "1")
-    if path == "float64":
+    if path.startswith("float64"):
         init, w = init.to(torch.complex128), w.double()
+    if path == "float64_workgroup":
+        monkeypatch.setenv("SPECINV_GENERIC_WAVE", "0")
     p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], w.dtype, dev())
     if path == "generic":
         p.force_generic(True)
     want = {"default": "k_semi", "fused": "k_fused_td", "fused_prespec": "k_fused", "frame_lds": "k_hop_td", "frame_lds_prespec": "k_hop",
-            "generic": "k_iter_pair", "float64": "k_iter_pair"}[path]
+            "generic": "k_iter_pair", "float64": "k_wave_iter", "float64_workgroup": "k_iter_pair"}[path]
     p.keep_state(path.endswith("_prespec"))
     p.gla_init(init, None, alpha)
     assert p.launch_geometry["kernel"] == want, p.launch_geometry
     done, _ = p.run(100, 10, 0.0, "sc")
     y = N(p.wave())
-    if path == "float64":
+    if path.startswith("float64"):
         assert rel_l2(y, ref64) < 1e-9, rel_l2(y, ref64)
     else:
         assert rel_l2(y, ref) < gate, (path, rel_l2(y, ref), rel_l2(y, ref64), noise)
@@ -483,6 +486,7 @@ def test_large_prime_factors_vs_oracle(n_fft, hop, frames, onesided, dtype):
     (2048, np.float64, True), (2048, np.float64, False), (1024, np.float64, True), (2048, np.float32, False),   # k_iter_pair_dr
     (1024, np.float32, True), (1000, np.float64, True),                                                          # Stockham + LDS twiddles
     (512, np.float64, False), (4096, np.float32, True),                                                          # Stockham as before
+    (512, np.float64, True), (256, np.float64, True), (256, np.float32, True), (128, np.float32, True),          # k_wave_iter (round 6)
 ])
 def test_coverage_iteration_kernels_agree_and_match_the_oracle(monkeypatch, n_fft, dtype, onesided):
     """Round 5's forms of the coverage path's iteration kernel - the digit-reversed in-place transform with an octant twiddle table
@@ -501,8 +505,11 @@ def test_coverage_iteration_kernels_agree_and_match_the_oracle(monkeypatch, n_ff
         ref = getattr(oracle, method)(init, tol=0, window=w, **okw, **kw)
         ref64 = getattr(oracle, method)(init.astype(np.complex128), tol=0, window=hann(n_fft, np.float64), **okw, **kw)
         out = {}
-        for arm, env in (("new", {}), ("plain", {"SPECINV_GENERIC_DR": "0", "SPECINV_GENERIC_TWLDS": "0"})):
-            for k_ in ("SPECINV_GENERIC_DR", "SPECINV_GENERIC_TWLDS"):
+        # (round 6: one-sided float64 at n_fft 128 ... 2048 and float32 at 128 / 256 run the wave-level kernel by default - arm "new";
+        # "workgroup" is what ran there before)
+        for arm, env in (("new", {}), ("workgroup", {"SPECINV_GENERIC_WAVE": "0"}),
+                         ("plain", {"SPECINV_GENERIC_DR": "0", "SPECINV_GENERIC_TWLDS": "0", "SPECINV_GENERIC_WAVE": "0"})):
+            for k_ in ("SPECINV_GENERIC_DR", "SPECINV_GENERIC_TWLDS", "SPECINV_GENERIC_WAVE"):
                 monkeypatch.delenv(k_, raising=False)
             for k_, v_ in env.items():
                 monkeypatch.setenv(k_, v_)
@@ -518,6 +525,7 @@ def test_coverage_iteration_kernels_agree_and_match_the_oracle(monkeypatch, n_ff
         e, e0 = rel_l2(out["new"], ref64), rel_l2(ref, ref64)
         assert e < max(3 * e0, 5 * tol), (method, e, e0)
         assert rel_l2(out["new"], out["plain"]) < max(3 * e0, 5 * tol), (method, rel_l2(out["new"], out["plain"]))
+        assert rel_l2(out["workgroup"], out["plain"]) < max(3 * e0, 5 * tol), (method, rel_l2(out["workgroup"], out["plain"]))
 
 
 @pytest.mark.parametrize("n_fft,hop,frames,kw", [

@@ -1,0 +1,143 @@
+"""The wave-level coverage kernel `k_wave_iter` (csrc/kernels_wave.h, round 6): float64 at power-of-two n_fft 128 ... 2048 and float32
+at 128 / 256 - both dtypes and two of the three frame sizes of the reference's own sweep (test/test_griffin.py:9-32,
+test/consts.py:1-3) - through the C ABI against the oracle, and against the workgroup-level kernels it replaced on the same
+buffers.  Needs an MI355X: `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _util import hann, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+import spectrogram_inversion_amd as si                                    # noqa: E402
+from spectrogram_inversion_amd.plan import Plan, args_helper               # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _plan(init, frames, dtype, wave, monkeypatch, **kw):
+    monkeypatch.setenv("SPECINV_GENERIC_WAVE", "1" if wave else "0")
+    tkw = dict(kw)
+    tkw["window"] = torch.from_numpy(kw["window"])
+    p = Plan(args_helper(T(init), **tkw), init.shape[0], frames, torch.float32 if dtype == np.float32 else torch.float64, DEV)
+    p.force_generic(True)
+    return p
+
+
+SWEEP = [  # n_fft, hop, frames, batch, extra stft kwargs
+    (128, 32, 23, 5, {}),                                           # five items of 23 frames: groups of eight frames straddle items
+    (128, 100, 9, 3, dict(win_length=100)),                         # the reference's win_length < n_fft, a hop that divides nothing
+    (256, 64, 19, 3, dict(pad_mode="constant")),
+    (256, 64, 12, 2, dict(center=False)),                           # the envelope vanishes at the edges: the reference's NaN pattern
+    (256, 77, 11, 2, dict(pad_mode="circular", normalized=True)),
+    (512, 128, 10, 3, dict(pad_mode="replicate")),
+    (512, 300, 7, 2, dict(win_length=300, normalized=True)),
+    (1024, 256, 9, 2, {}),
+    (2048, 512, 7, 2, dict(pad_mode="reflect")),
+    (2048, 333, 6, 1, dict(center=False)),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n_fft,hop,frames,batch,extra", SWEEP)
+def test_wave_kernel_kwarg_sweep_vs_oracle(monkeypatch, dtype, n_fft, hop, frames, batch, extra):
+    """Griffin-Lim (4 iterations, alpha 0.5) and ADMM (3 iterations, rho 1.0) from a complex start on `k_wave_iter`, every stft
+    kwarg of the reference's sweep: waveform against the oracle in the plan's dtype and in float64, the evaluation's sums and the
+    stored state against the workgroup-level kernel (`k_iter_pair`: the same update_core per bin on another transform)."""
+    rng = np.random.default_rng(n_fft + hop + frames)
+    wl = extra.get("win_length", n_fft)
+    w = hann(wl, dtype)
+    kw = dict(hop_length=hop, **extra)
+    mag = (rng.random((batch, n_fft // 2 + 1, frames)) + 0.05).astype(dtype)
+    cd = np.complex64 if dtype == np.float32 else np.complex128
+    init = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(cd)
+    tol = 2e-5 if dtype == np.float32 else 1e-10
+    for method, arg, iters in (("griffin_lim", 0.5, 4), ("admm", 1.0, 3)):
+        okw = dict(max_iter=iters, alpha=arg) if method == "griffin_lim" else dict(max_iter=iters, rho=arg)
+        with np.errstate(all="ignore"):
+            ref = getattr(oracle, method)(init, tol=0, window=w, **okw, **kw)
+            ref64 = getattr(oracle, method)(init.astype(np.complex128), tol=0, window=hann(wl, np.float64), **okw, **kw)
+        out = {}
+        for arm in ("wave", "workgroup"):
+            p = _plan(init, frames, dtype, arm == "wave", monkeypatch, window=w, **kw)
+            (p.gla_init if method == "griffin_lim" else p.admm_init)(T(init), None, arg)
+            assert p.launch_geometry["kernel"] == ("k_wave_iter" if arm == "wave" else "k_iter_pair"), p.launch_geometry
+            p.iterate(iters - 1)
+            sums = p.iterate(1, eval_last=True)
+            out[arm] = (N(p.wave()), N(p.state_spec(0)), np.array(sums[:2]),
+                        N(p.state_spec(1)) if method == "admm" else None)
+        y, fin = out["wave"][0], np.isfinite(ref64)
+        assert np.array_equal(np.isfinite(y), fin)                              # the reference's 0 / 0 where the envelope vanishes
+        e, e0 = rel_l2(y[fin], ref64[fin]), rel_l2(ref[fin], ref64[fin])
+        assert e < max(3 * e0, 5 * tol), (method, e, e0)
+        yw = out["workgroup"][0]
+        assert np.array_equal(np.isfinite(yw), fin) and rel_l2(y[fin], yw[fin]) < max(3 * e0, 5 * tol)
+        for a, b in ((out["wave"][1], out["workgroup"][1]), (out["wave"][3], out["workgroup"][3])):
+            if a is None:
+                continue
+            f2 = np.isfinite(b)
+            assert np.array_equal(np.isfinite(a), f2) and rel_l2(a[f2], b[f2]) < max(10 * e0, 5 * tol)
+        if np.isfinite(out["workgroup"][2]).all():
+            np.testing.assert_allclose(out["wave"][2], out["workgroup"][2], rtol=1e-5 if dtype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("dtype,n_fft,hop,frames,batch", [(np.float32, 128, 32, 600, 70), (np.float32, 256, 64, 300, 160),
+                                                          (np.float64, 1024, 256, 200, 24), (np.float64, 2048, 512, 150, 20)])
+def test_wave_kernel_walks_more_frames_than_the_chip_holds(monkeypatch, dtype, n_fft, hop, frames, batch):
+    """More groups of frames than resident waves: every wave of the launch walks several (the grid is sized to the chip, not to the
+    problem).  Ten iterations from the magnitudes (phase_init), the whole batch against the workgroup-level kernel - waveforms and
+    the evaluation every fifth iteration - and three items against the oracle."""
+    rng = np.random.default_rng(n_fft)
+    mag = (rng.random((batch, n_fft // 2 + 1, frames)) + 0.05).astype(dtype)
+    w = hann(n_fft, dtype)
+    out = {}
+    for arm in ("wave", "workgroup"):
+        p = _plan(mag, frames, dtype, arm == "wave", monkeypatch, window=w, hop_length=hop)
+        if arm == "wave":
+            geo = p.launch_geometry
+            assert geo["kernel"] == "k_wave_iter" and geo["waves"] * (1 if n_fft >= 1024 else (4 if n_fft == 512 else 8)) < batch * frames, geo
+        c0 = p.phase_init(T(mag))
+        p.gla_init(c0, None, 0.3)
+        done, evals = p.run(10, 5, 0.0, "sc")
+        out[arm] = (N(p.wave()), np.array([[m, l] for _, m, l in evals]), N(c0))
+    tol = 5e-5 if dtype == np.float32 else 1e-10
+    assert rel_l2(out["wave"][0], out["workgroup"][0]) < tol
+    np.testing.assert_allclose(out["wave"][1], out["workgroup"][1], rtol=1e-4 if dtype == np.float32 else 1e-10)
+    items = [0, batch // 2, batch - 1]
+    ref = oracle.griffin_lim(out["wave"][2][items], max_iter=10, alpha=0.3, tol=0, hop_length=hop, window=w)
+    for k, b in enumerate(items):
+        assert rel_l2(out["wave"][0][b], ref[k]) < (1e-4 if dtype == np.float32 else 1e-9), (b, rel_l2(out["wave"][0][b], ref[k]))
+
+
+def test_wave_kernel_is_what_float64_and_small_frames_run(monkeypatch):
+    """The drop-in functions on the reference's own test sizes (test/consts.py:1-3: n_fft 128 / 256 / 512, both dtypes) land on the
+    wave-level coverage kernel where the plan says it wins - one-sided float64 at 128 ... 2048, one-sided float32 at 128 / 256 - and
+    on the kernels that served them before everywhere else (two-sided spectrograms, float32 512: the packed frame kernels)."""
+    monkeypatch.delenv("SPECINV_GENERIC_WAVE", raising=False)
+    for dtype, n_fft, onesided, want in ((torch.float64, 128, True, "k_wave_iter"), (torch.float64, 512, True, "k_wave_iter"),
+                                         (torch.float64, 2048, True, "k_wave_iter"), (torch.float32, 128, True, "k_wave_iter"),
+                                         (torch.float32, 256, True, "k_wave_iter"), (torch.float32, 512, True, "k_semi"),
+                                         (torch.float64, 512, False, "k_iter_pair"), (torch.float64, 4096, True, "k_iter_pair"),
+                                         (torch.float64, 1000, True, "k_iter_pair")):
+        F = n_fft // 2 + 1 if onesided else n_fft
+        mag = torch.rand((2, F, 12), dtype=dtype, device=DEV) + 0.05
+        p = Plan(args_helper(mag, hop_length=n_fft // 4, onesided=onesided, window=torch.hann_window(n_fft, dtype=dtype)), 2, 12, dtype, DEV)
+        p.gla_init(None, mag, 0.5)
+        assert p.launch_geometry["kernel"] == want, (dtype, n_fft, onesided, p.launch_geometry)
+    # ... and end to end through the drop-in function, float64 at the reference's largest test size
+    rng = np.random.default_rng(1)
+    mag = (rng.random((2, 257, 20)) + 0.05)
+    y = N(si.griffin_lim(T(mag), max_iter=8, alpha=0.5, tol=0, verbose=False, hop_length=128, window=torch.from_numpy(hann(512, np.float64))))
+    ref = oracle.griffin_lim(oracle.phase_init(mag, hop_length=128, window=hann(512, np.float64)), max_iter=8, alpha=0.5, tol=0,
+                             hop_length=128, window=hann(512, np.float64))
+    assert rel_l2(y, ref) < 1e-9
