@@ -22,8 +22,9 @@
 #pragma once
 #include "wave_api.h"
 
-#ifndef SPECINV_WAVE_ABL            // timing experiments (WRONG RESULTS): 1 no state / target loads, 2 no state stores, 4 no frame
-#define SPECINV_WAVE_ABL 0          // stores, 8 no sample / window loads, 16 no LDS passes
+
+#ifndef SPECINV_WAVE_OLA_ALL        // experiments: 1 the register overlap-add for float64 frames of 16 points per lane as well
+#define SPECINV_WAVE_OLA_ALL 0
 #endif
 
 namespace specinv {
@@ -31,26 +32,39 @@ namespace wave {
 
 // lanes per frame and the passes' radices, by log2 M (M = n_fft / 2)
 template <int LOGM>
-struct Geo;
+struct GeoF;
 template <>
-struct Geo<6> {      // n_fft 128:  8 x 8
+struct GeoF<6> {     // n_fft 128:  8 x 8
   static constexpr int LG = 8, NPASS = 2, R0 = 8, R1 = 8, R2 = 1;
 };
 template <>
-struct Geo<7> {      // n_fft 256:  16 x 8
+struct GeoF<7> {     // n_fft 256:  16 x 8
   static constexpr int LG = 8, NPASS = 2, R0 = 16, R1 = 8, R2 = 1;
 };
 template <>
-struct Geo<8> {      // n_fft 512:  16 x 16
+struct GeoF<8> {     // n_fft 512:  16 x 16
   static constexpr int LG = 16, NPASS = 2, R0 = 16, R1 = 16, R2 = 1;
 };
 template <>
-struct Geo<9> {      // n_fft 1024: 8 x 8 x 8
+struct GeoF<9> {     // n_fft 1024: 8 x 8 x 8
   static constexpr int LG = 64, NPASS = 3, R0 = 8, R1 = 8, R2 = 8;
 };
 template <>
-struct Geo<10> {     // n_fft 2048: 16 x 8 x 8
+struct GeoF<10> {    // n_fft 2048: 16 x 8 x 8
   static constexpr int LG = 64, NPASS = 3, R0 = 16, R1 = 8, R2 = 8;
+};
+template <typename T, int LOGM>
+struct Geo : GeoF<LOGM> {};
+// float64 at n_fft 256 / 512: EIGHT points per lane (32 registers) on twice the lanes, three passes - the partial sums of the
+// register overlap-add then fit beside the frame (with sixteen points per lane they were spilled: slower than frames + k_ola), and
+// a wave's piece of LDS halves
+template <>
+struct Geo<double, 7> {   // 8 x 4 x 4
+  static constexpr int LG = 16, NPASS = 3, R0 = 8, R1 = 4, R2 = 4;
+};
+template <>
+struct Geo<double, 8> {   // 8 x 8 x 4
+  static constexpr int LG = 32, NPASS = 3, R0 = 8, R1 = 8, R2 = 4;
 };
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
@@ -104,9 +118,9 @@ __device__ __forceinline__ cplx<T> tw_get(const cplx<T>* __restrict__ tab, int i
   return mk<T>(w.x, INV ? -w.y : w.y);
 }
 // entries of the tables of a geometry: pass 1 (NS = R0) and, with three passes, pass 2 (NS = R0 R1)
-template <int LOGM>
+template <typename T, int LOGM>
 struct Tabs {
-  using G = Geo<LOGM>;
+  using G = Geo<T, LOGM>;
   static constexpr int N1 = G::R0 * (G::R1 - 1);
   static constexpr int N2 = G::NPASS == 3 ? G::R0 * G::R1 * (G::R2 - 1) : 0;
   static constexpr int NPAIR = ((1 << LOGM) / 2) / G::LG;
@@ -123,7 +137,6 @@ template <typename T, int R, int LNS, bool INV, int LOGM, int LG, int PS>
 __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict__ tab, int gl) {
   constexpr int M = 1 << LOGM, NB = M / R, PER = NB / LG, NS = 1 << LNS;
   static_assert(PER >= 1, "a lane owns at least one butterfly of every pass");
-  if (SPECINV_WAVE_ABL & 16) return;
   cplx<T> v[PER][R];
 #pragma unroll
   for (int it = 0; it < PER; ++it) {
@@ -154,18 +167,25 @@ __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict
 // registers: a float64 frame of 16 points per lane is 64 registers before the first butterfly - those instantiations may take 256
 // (two waves per SIMD, which is also what their 17 KB of LDS per wave allow); everything else is held to 128 (four per SIMD)
 template <typename T, int LOGM>
-constexpr int max_threads() { return (sizeof(T) == 8 && (1 << LOGM) / Geo<LOGM>::LG >= 16) ? 512 : 1024; }
+constexpr int max_threads() { return (sizeof(T) == 8 && (1 << LOGM) / Geo<T, LOGM>::LG >= 16) ? 512 : 1024; }
+// ... and with the overlap-add in registers (partial sums, the frame's outputs, envelope and signal addresses on top): three waves
+// per SIMD, 168 registers (at 128 those instantiations spilled 33 - 187 registers and ran slower than frames + k_ola)
+template <typename T, int LOGM, int OV>
+constexpr int waves_per_simd() {
+  return max_threads<T, LOGM>() == 512 ? 2 : (OV > 0 ? (((1 << LOGM) / Geo<T, LOGM>::LG >= 16 || sizeof(T) == 8) ? 2 : 3) : 4);
+}
 
-template <typename T, int LOGM, int MODE, bool TWO, bool EVAL>
-__global__ __launch_bounds__((max_threads<T, LOGM>())) void k_wave_iter(WaveIterArgs<T> a) {
-  using G = Geo<LOGM>;
+template <typename T, int LOGM, int MODE, bool TWO, bool EVAL, int OV>
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu((waves_per_simd<T, LOGM, OV>()))))
+void k_wave_iter(WaveIterArgs<T> a) {
+  using G = Geo<T, LOGM>;
   using C = cplx<T>;
   constexpr int M = 1 << LOGM, N = 2 * M, LG = G::LG, FPW = 64 / LG;
   constexpr int PS = ilog2(G::R0);
   constexpr int MP = phys<PS>(M) + 1;                    // a frame's points in LDS
   constexpr int LR0 = ilog2(G::R0), LR1 = ilog2(G::R1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using TB = Tabs<LOGM>;
+  using TB = Tabs<T, LOGM>;
   C* tab1 = reinterpret_cast<C*>(smem);                  // pass tables, then W_N^(i LG)
   C* tab2 = tab1 + TB::N1;
   C* tabs = tab2 + TB::N2;
@@ -195,32 +215,62 @@ __global__ __launch_bounds__((max_threads<T, LOGM>())) void k_wave_iter(WaveIter
   constexpr bool eval = EVAL, two = TWO;
   const T* __restrict__ win = c.window;
   double s_d = 0, s_o = 0;
-  for (int64_t grp = w0; grp < n_groups; grp += nw) {
-    const int64_t f0 = grp * FPW;                   // the wave's first frame (scalar); lane group g owns frame f0 + g
-    const int64_t fi = f0 + g;
-    if (fi >= total) continue;
-    const int64_t bi = total < ((int64_t)1 << 31) ? (int64_t)((unsigned)fi / (unsigned)Tn) : fi / Tn;   // (a 64-bit division is ~200 instructions)
-    const int t = (int)(fi - bi * Tn);
-    C* S0u = a.S0 + f0 * F;
-    C* S1u = MODE == 1 ? a.S1 + f0 * F : nullptr;
-    const T* magu = a.mag + f0 * F;
-    const int so = g * F;                           // this group's row inside the wave's block of state rows
+  // Work units.  OV == 0: a frame, its windowed synthesis frame written to the frames buffer for k_ola.  OV in {2, 4, 8} (hop =
+  // n_fft / OV): a CHUNK of consecutive frames [cb(c), cb(c + 1)) of one item, walked in order by one lane group with the
+  // overlap-add in registers - OV - 1 hop-blocks of partial sums carried from frame to frame, one finished block divided by the
+  // envelope and stored to the OTHER signal buffer per frame, added in ascending frame order like k_ola.  The first OV - 1 blocks
+  // of a chunk lack the previous chunk's frames and its last OV - 1 partial sums lack the next one's: both go to side buffers and
+  // k_wave_seams finishes those blocks.
+  static_assert(OV == 0 || OV == 2 || OV == 4 || OV == 8, "hop = n_fft / 2, / 4 or / 8");
+  constexpr int RL = G::NPASS == 3 ? G::R2 : G::R1, PERL = (M / RL) / LG;       // the last pass: radix, butterflies per lane
+  constexpr int RPB = OV > 0 ? RL / (OV > 0 ? OV : 1) : 1, NBLK = PERL * RPB, NACC = OV > 0 ? OV - 1 : 1;   // complex values per lane and hop-block
+  static_assert(OV == 0 || RL % OV == 0, "a hop-block is whole outputs of the last pass");
+  const int nch = OV > 0 ? a.nch : 1;
+  const int64_t units = OV > 0 ? (int64_t)a.batch * nch : total;
+  const int trips = OV > 0 ? (Tn + nch - 1) / nch : 1;
+  auto cb = [&](int cc) { return (int)(((int64_t)cc * Tn) / nch); };
+  for (int64_t ur = w0; ur * FPW < units; ur += nw) {
+    const int64_t u = ur * FPW + g;                 // this lane group's unit
+    int fstart = 0, len = 0, ub = 0, ta = 0;
+    if (u < units) {
+      if (OV > 0) {
+        ub = (int)(u / nch);
+        const int cc = (int)(u - (int64_t)ub * nch);
+        ta = cb(cc);
+        len = cb(cc + 1) - ta;
+        fstart = ub * Tn + ta;
+      } else {
+        fstart = (int)u;
+        len = 1;
+      }
+    }
+    C acc[NACC][NBLK];
+#pragma unroll
+    for (int b = 0; b < NACC; ++b)
+#pragma unroll
+      for (int e = 0; e < NBLK; ++e) acc[b][e] = mk<T>(T(0), T(0));
+   for (int s = 0; s < trips; ++s) {
+    if (s >= len) continue;
+    const int fi = fstart + s;                      // (host: fewer than 2^31 frames)
+    const int bi = OV > 0 ? ub : (int)((unsigned)fi / (unsigned)Tn);
+    const int t = OV > 0 ? ta + s : fi - bi * Tn;
+    // state, target and synthesis rows: a scalar base (the wave's first active group) + this group's 32-bit offset
+    const int fi0 = __builtin_amdgcn_readfirstlane(fi);
+    C* S0u = a.S0 + (int64_t)fi0 * F;
+    C* S1u = MODE == 1 ? a.S1 + (int64_t)fi0 * F : nullptr;
+    const T* magu = a.mag + (int64_t)fi0 * F;
+    const int so = (fi - fi0) * F;
     // ---- analysis, first pass: butterfly j takes points j + q M / R0 from the signal
     {
       constexpr int R = G::R0, NB = M / R, PER = NB / LG;
       static_assert(PER >= 1, "a lane owns at least one butterfly of the first pass");
       const int64_t start = (int64_t)t * c.hop - c.pad;
-      const T* xr = a.x + bi * c.length;
+      const T* xr = a.x + (int64_t)bi * c.length;
       const T* xp = xr + start;
       const bool interior = start >= 0 && start + N <= c.length;
-      const bool aligned = ((bi * c.length + start) & 1) == 0;
+      const bool aligned = (((int64_t)bi * c.length + start) & 1) == 0;
       C v[PER][R];
-      if (SPECINV_WAVE_ABL & 8) {
-#pragma unroll
-        for (int it = 0; it < PER; ++it)
-#pragma unroll
-          for (int q = 0; q < R; ++q) v[it][q] = mk<T>(T(gl + it + q), T(t));
-      } else if (interior && aligned) {
+      if (interior && aligned) {
 #pragma unroll
         for (int it = 0; it < PER; ++it)
 #pragma unroll
@@ -252,7 +302,7 @@ __global__ __launch_bounds__((max_threads<T, LOGM>())) void k_wave_iter(WaveIter
       for (int it = 0; it < PER; ++it) {
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-          const C w2 = (SPECINV_WAVE_ABL & 8) ? mk<T>(T(0.5), T(0.25)) : *reinterpret_cast<const C*>(win + 2 * (gl + it * LG + q * NB));
+          const C w2 = *reinterpret_cast<const C*>(win + 2 * (gl + it * LG + q * NB));
           v[it][q] = mk<T>(v[it][q].x * w2.x, v[it][q].y * w2.y);
         }
         bfly<T, R, false>(v[it]);
@@ -288,10 +338,7 @@ __global__ __launch_bounds__((max_threads<T, LOGM>())) void k_wave_iter(WaveIter
       for (int u = 0; u < CH; ++u) {
         const int k = gl + (i0 + u) * LG;
         const int kb = k == 0 ? M : M - k;          // k = 0 pairs the real bins 0 and M
-        if (!two && (SPECINV_WAVE_ABL & 1)) {
-          s0a[u] = s0b[u] = s1a[u] = s1b[u] = mk<T>(T(k), T(1));
-          ma[u] = mb[u] = T(0.5);
-        } else if (!two) {
+        if (!two) {
           s0a[u] = S0u[so + k];
           s0b[u] = S0u[so + kb];
           ma[u] = magu[so + k];
@@ -326,11 +373,11 @@ __global__ __launch_bounds__((max_threads<T, LOGM>())) void k_wave_iter(WaveIter
           C n0, n1;
           const C zero = mk<T>(T(0), T(0));
           yk = update_core<T, MODE>(xk, ma[u], s0a[u], MODE == 1 ? s1a[u] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
-          if (!(SPECINV_WAVE_ABL & 2)) S0u[so + k] = n0;
-          if (MODE == 1 && !(SPECINV_WAVE_ABL & 2)) S1u[so + k] = n1;
+          S0u[so + k] = n0;
+          if (MODE == 1) S1u[so + k] = n1;
           ym = update_core<T, MODE>(xm, mb[u], s0b[u], MODE == 1 ? s1b[u] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
-          if (!(SPECINV_WAVE_ABL & 2)) S0u[so + kb] = n0;
-          if (MODE == 1 && !(SPECINV_WAVE_ABL & 2)) S1u[so + kb] = n1;
+          S0u[so + kb] = n0;
+          if (MODE == 1) S1u[so + kb] = n1;
         } else if (k == 0) {
           yk = upd(xk, 0);
           ym = upd(xm, M);
@@ -369,24 +416,81 @@ __global__ __launch_bounds__((max_threads<T, LOGM>())) void k_wave_iter(WaveIter
 #pragma unroll
         for (int q = 0; q < R; ++q) v[it][q] = buf[phys<PS>(j + q * NB)];
       }
-      T* fru = a.frames + f0 * N;
-      const int fo = g * N;
 #pragma unroll
       for (int it = 0; it < PER; ++it) {
         const int j = gl + it * LG;                 // k = j, blk = 0
 #pragma unroll
         for (int q = 1; q < R; ++q) v[it][q] = cmul(v[it][q], tw_get<T, true>(tabl, (q - 1) * NS + j));
         bfly<T, R, true>(v[it]);
+      }
+      {
+      // (no contraction in this block: the frame's windowed samples are ROUNDED products - what the frames buffer would hold - before
+      // they are added, or the register overlap-add would differ from k_ola by a fused multiply-add's rounding in a quarter of the
+      // samples)
+#pragma clang fp contract(off)
+      C y[PER][R];                                  // the windowed synthesis frame: samples 2 p, 2 p + 1 at p = j + i NS
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          const int p = j + i * NS;
-          const C w2 = *reinterpret_cast<const C*>(win + 2 * p);
-          if ((SPECINV_WAVE_ABL & 4) && v[it][i].x != T(1.2345e30)) continue;
-          *reinterpret_cast<C*>(fru + fo + 2 * p) = mk<T>((v[it][i].x * c.inv_scale) * w2.x, (v[it][i].y * c.inv_scale) * w2.y);
+          const C w2 = *reinterpret_cast<const C*>(win + 2 * (gl + it * LG + i * NS));
+          y[it][i] = mk<T>((v[it][i].x * c.inv_scale) * w2.x, (v[it][i].y * c.inv_scale) * w2.y);
         }
+      }
+      if constexpr (OV == 0) {
+        T* fru = a.frames + (int64_t)fi0 * N;
+        const int fo = (fi - fi0) * N;
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+#pragma unroll
+          for (int i = 0; i < R; ++i) *reinterpret_cast<C*>(fru + fo + 2 * (gl + it * LG + i * NS)) = y[it][i];
+      } else {
+        // hop-block b of the frame is outputs i in [b RPB, (b + 1) RPB): slot e = it RPB + i mod RPB sits at complex offset
+        // gl + it LG + (i mod RPB) NS of the block.  Block 0 closes the oldest partial sum (padded position t hop): stored - or,
+        // for the first OV - 1 frames of the chunk, parked for k_wave_seams - then the sums move up by one block.
+        const bool complete = s >= OV - 1;
+        const int64_t seam = ((int64_t)u * (OV - 1)) * c.hop;
+        T* xo = a.x_out + (int64_t)bi * c.length;
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+#pragma unroll
+          for (int ii = 0; ii < RPB; ++ii) {
+            const int e = it * RPB + ii, o = gl + it * LG + ii * NS;
+            const C val = acc[0][e] + y[it][ii];
+            if (complete) {
+              const int64_t n = (int64_t)t * c.hop + 2 * o - c.pad;
+              if (n >= 0 && n < c.length) {
+                const C ev = *reinterpret_cast<const C*>(a.env + n);
+                *reinterpret_cast<C*>(xo + n) = mk<T>(val.x / ev.x, val.y / ev.y);
+              }
+            } else {
+              *reinterpret_cast<C*>(a.seamR + seam + (int64_t)s * c.hop + 2 * o) = val;
+            }
+          }
+#pragma unroll
+        for (int b = 0; b + 1 < OV - 1; ++b)
+#pragma unroll
+          for (int it = 0; it < PER; ++it)
+#pragma unroll
+            for (int ii = 0; ii < RPB; ++ii) acc[b][it * RPB + ii] = acc[b + 1][it * RPB + ii] + y[it][(b + 1) * RPB + ii];
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+#pragma unroll
+          for (int ii = 0; ii < RPB; ++ii) acc[OV - 2][it * RPB + ii] = y[it][(OV - 1) * RPB + ii];
+        if (s == len - 1) {                         // what the chunk leaves for the blocks after its last frame
+#pragma unroll
+          for (int b = 0; b < OV - 1; ++b)
+#pragma unroll
+            for (int it = 0; it < PER; ++it)
+#pragma unroll
+              for (int ii = 0; ii < RPB; ++ii)
+                *reinterpret_cast<C*>(a.seamL + seam + (int64_t)b * c.hop + 2 * (gl + it * LG + ii * NS)) = acc[b][it * RPB + ii];
+        }
+      }
       }
       wave_sync();
     }
+   }
   }
   if (eval) {
     const double d = wave_sum(s_d), o = wave_sum(s_o);
@@ -397,36 +501,83 @@ __global__ __launch_bounds__((max_threads<T, LOGM>())) void k_wave_iter(WaveIter
   }
 }
 
-// ---- host side ---------------------------------------------------------------------------------------------------------------
-struct Launch {
-  int wgs = 0, waves_per_wg = 0;
-  size_t lds = 0;
-};
-template <typename T, int LOGM>
-const void* kernel_of(int mode) {            // mode: bit 0 ADMM, bit 1 two-sided, bit 2 evaluating
-  switch (mode & 7) {
-    case 0: return (const void*)k_wave_iter<T, LOGM, 0, false, false>;
-    case 1: return (const void*)k_wave_iter<T, LOGM, 1, false, false>;
-    case 2: return (const void*)k_wave_iter<T, LOGM, 0, true, false>;
-    case 3: return (const void*)k_wave_iter<T, LOGM, 1, true, false>;
-    case 4: return (const void*)k_wave_iter<T, LOGM, 0, false, true>;
-    case 5: return (const void*)k_wave_iter<T, LOGM, 1, false, true>;
-    case 6: return (const void*)k_wave_iter<T, LOGM, 0, true, true>;
-    default: return (const void*)k_wave_iter<T, LOGM, 1, true, true>;
+// The hop-blocks at chunk boundaries of the register overlap-add: boundary c of item b (c = 0 ... nch; frame position cb(c), T for
+// the last) has OV - 1 blocks whose sums are split between the chunk before it (seamL: what its last frames left) and the chunk
+// after it (seamR: what its first frames had so far); x = (left + right) / envelope.
+template <typename T>
+__global__ void k_wave_seams(const T* __restrict__ seamL, const T* __restrict__ seamR, const T* __restrict__ env, T* __restrict__ x_out,
+                             int Tn, int nch, int ov, int hop, int pad, int64_t length, int batch) {
+  const int64_t per = (int64_t)(ov - 1) * hop, total = (int64_t)batch * (nch + 1) * per;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cu = idx / per;
+    const int rem = (int)(idx - cu * per), s = rem / hop, r = rem - s * hop;
+    const int b = (int)(cu / (nch + 1)), cc = (int)(cu - (int64_t)b * (nch + 1));
+    const int pos = (cc < nch ? (int)(((int64_t)cc * Tn) / nch) : Tn) + s;
+    const int64_t n = (int64_t)pos * hop + r - pad;
+    if (n < 0 || n >= length) continue;
+    const T right = cc < nch ? seamR[((int64_t)(b * (int64_t)nch + cc) * (ov - 1) + s) * hop + r] : T(0);
+    const T left = cc > 0 ? seamL[((int64_t)(b * (int64_t)nch + cc - 1) * (ov - 1) + s) * hop + r] : T(0);
+    x_out[(int64_t)b * length + n] = (left + right) / env[n];
   }
 }
 
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+struct Launch {
+  int wgs = 0, waves_per_wg = 0, capacity = 0;      // capacity: lane groups (frames in flight) the chip holds at once
+  size_t lds = 0;
+};
+// can the partial sums of the register overlap-add stay in registers?  (a float64 frame of 16 points per lane already fills them:
+// its OV - 1 blocks would be spilled - the traffic of the frames buffer in another place)
+// - and a hop-block must be whole outputs of the last pass (its radix a multiple of OV)
+template <typename T, int LOGM, int OV>
+constexpr bool ola_fits() {
+  using G = Geo<T, LOGM>;
+  return OV == 0 || ((SPECINV_WAVE_OLA_ALL || !(sizeof(T) == 8 && (1 << LOGM) / G::LG >= 16)) && (G::NPASS == 3 ? G::R2 : G::R1) % OV == 0);
+}
+
+template <typename T, int LOGM, int OV>
+const void* kernel_ov(int mode) {            // mode: bit 0 ADMM, bit 2 evaluating (one-sided)
+  if constexpr (!ola_fits<T, LOGM, OV>()) return nullptr;
+  else {
+    switch (mode & 5) {
+      case 0: return (const void*)k_wave_iter<T, LOGM, 0, false, false, OV>;
+      case 1: return (const void*)k_wave_iter<T, LOGM, 1, false, false, OV>;
+      case 4: return (const void*)k_wave_iter<T, LOGM, 0, false, true, OV>;
+      default: return (const void*)k_wave_iter<T, LOGM, 1, false, true, OV>;
+    }
+  }
+}
 template <typename T, int LOGM>
-Launch shape(int64_t frames_total, int mode) {
-  using G = Geo<LOGM>;
+const void* kernel_of(int mode, int ov) {    // mode: bit 0 ADMM, bit 1 two-sided, bit 2 evaluating
+  if (mode & 2) {
+    switch (mode & 5) {
+      case 0: return (const void*)k_wave_iter<T, LOGM, 0, true, false, 0>;
+      case 1: return (const void*)k_wave_iter<T, LOGM, 1, true, false, 0>;
+      case 4: return (const void*)k_wave_iter<T, LOGM, 0, true, true, 0>;
+      default: return (const void*)k_wave_iter<T, LOGM, 1, true, true, 0>;
+    }
+  }
+  switch (ov) {
+    case 2: return kernel_ov<T, LOGM, 2>(mode);
+    case 4: return kernel_ov<T, LOGM, 4>(mode);
+    case 8: return kernel_ov<T, LOGM, 8>(mode);
+    default: return kernel_ov<T, LOGM, 0>(mode);
+  }
+}
+
+// `work`: frames (ov == 0) or chunks (ov > 0) the launch has to cover
+template <typename T, int LOGM>
+Launch shape(int64_t work, int mode, int ov) {
+  using G = Geo<T, LOGM>;
   constexpr int M = 1 << LOGM, FPW = 64 / G::LG, PS = ilog2(G::R0), MP = phys<PS>(M) + 1;
   static int n_cu = 0;
   // workgroups of four or eight waves (each carries its own twiddle table), whichever puts more waves on a CU by the runtime's
   // own count of resident workgroups (registers and LDS); one launch fills the chip once and every wave walks its share of frames
-  static int wpw_of[8] = {0, 0, 0, 0, 0, 0, 0, 0}, per_cu_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto lds_of = [&](int w) { return sizeof(cplx<T>) * ((size_t)Tabs<LOGM>::TOTAL + (size_t)w * FPW * MP); };
-  const void* fn = kernel_of<T, LOGM>(mode);
-  if (wpw_of[mode] == 0) {
+  static int wpw_of[32] = {}, per_cu_of[32] = {};
+  const int key = (mode & 7) | (ov == 2 ? 8 : ov == 4 ? 16 : ov == 8 ? 24 : 0);
+  auto lds_of = [&](int w) { return sizeof(cplx<T>) * ((size_t)Tabs<T, LOGM>::TOTAL + (size_t)w * FPW * MP); };
+  const void* fn = kernel_of<T, LOGM>(mode, ov);
+  if (wpw_of[key] == 0) {
     int dev = 0;
     hipDeviceProp_t prop{};
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
@@ -441,33 +592,61 @@ Launch shape(int64_t frames_total, int mode) {
       }
       if (nb * w > best) {
         best = nb * w;
-        wpw_of[mode] = w;
-        per_cu_of[mode] = nb;
+        wpw_of[key] = w;
+        per_cu_of[key] = nb;
       }
     }
     (void)hipGetLastError();
-    if (wpw_of[mode] == 0) {
-      wpw_of[mode] = 4;
-      per_cu_of[mode] = 1;
+    if (wpw_of[key] == 0) {
+      wpw_of[key] = 4;
+      per_cu_of[key] = 1;
     }
   }
-  const int wpw = wpw_of[mode];
-  const int64_t groups = (frames_total + FPW - 1) / FPW;
+  const int wpw = wpw_of[key];
+  const int64_t groups = (work + FPW - 1) / FPW;
   Launch l;
   l.waves_per_wg = wpw;
-  l.wgs = (int)std::max<int64_t>(1, std::min<int64_t>((groups + wpw - 1) / wpw, (int64_t)n_cu * per_cu_of[mode]));
+  l.wgs = (int)std::max<int64_t>(1, std::min<int64_t>((groups + wpw - 1) / wpw, (int64_t)n_cu * per_cu_of[key]));
+  l.capacity = n_cu * per_cu_of[key] * wpw * FPW;
   l.lds = lds_of(wpw);
   return l;
 }
 
+// chunks per item of the register overlap-add: enough units to fill the chip once, chunks of at least max(2 OV, 8) frames
 template <typename T, int LOGM>
-int launch_one(const WaveIterArgs<T>& a, hipStream_t stream) {
+int ola_chunks(int ov, int n_frames, int batch) {
+  const bool fits = ov == 2 ? ola_fits<T, LOGM, 2>() : ov == 4 ? ola_fits<T, LOGM, 4>() : ov == 8 ? ola_fits<T, LOGM, 8>() : false;
+  if (!fits || n_frames < 2 * ov) return 0;
+  if (const char* e = getenv("SPECINV_WAVE_OLA")) {
+    if (e[0] == '0') return 0;
+  }
+  const Launch l = shape<T, LOGM>(1, 0, ov);
+  const int min_len = std::max(2 * ov, 8);
+  int nch = (int)std::max<int64_t>(1, (int64_t)l.capacity / std::max(1, batch));
+  if (const char* e = getenv("SPECINV_WAVE_CHUNK")) nch = std::max(1, n_frames / std::max(1, atoi(e)));
+  return std::max(1, std::min(nch, n_frames / min_len));
+}
+
+template <typename T, int LOGM>
+int launch_one(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_out) {
   const int mode = (a.mode & 1) | (a.c.onesided ? 0 : 2) | (a.eval ? 4 : 0);
-  const Launch l = shape<T, LOGM>((int64_t)a.batch * a.c.n_frames, mode);
-  const void* fn = kernel_of<T, LOGM>(mode);
+  const int ov = a.nch > 0 ? a.ov : 0;
+  const void* fn = kernel_of<T, LOGM>(mode, ov);
+  SI_CHECK(fn != nullptr && (ov == 0 || (a.x_out && a.env && a.seamL && a.seamR && a.x_out != a.x)), SPECINV_EINVAL,
+           "k_wave_iter: bad overlap-add arguments");
+  SI_CHECK((int64_t)a.batch * a.c.n_frames < ((int64_t)1 << 31) && (int64_t)8 * a.c.n_frames * a.c.n_fft < ((int64_t)1 << 31), SPECINV_EUNSUPPORTED,
+           "k_wave_iter: too many frames for 32-bit frame offsets");
+  const Launch l = shape<T, LOGM>(ov > 0 ? (int64_t)a.batch * a.nch : (int64_t)a.batch * a.c.n_frames, mode, ov);
+  if (waves_out) *waves_out = l.wgs * l.waves_per_wg;
   WaveIterArgs<T> args = a;
   void* kargs[] = {&args};
   SI_HIP(hipLaunchKernel(fn, dim3(l.wgs), dim3(64 * l.waves_per_wg), kargs, l.lds, stream));
+  if (ov > 0) {
+    const int64_t total = (int64_t)a.batch * (a.nch + 1) * (ov - 1) * a.c.hop;
+    hipLaunchKernelGGL((k_wave_seams<T>), dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, stream,
+                       (const T*)a.seamL, (const T*)a.seamR, a.env, a.x_out, a.c.n_frames, a.nch, ov, a.c.hop, a.c.pad, a.c.length, a.batch);
+    SI_HIP(hipGetLastError());
+  }
   return SPECINV_OK;
 }
 

@@ -119,6 +119,8 @@ struct PlanT final : PlanBase {
   bool tw_lds = false;         // k_iter_pair: the twiddle table copied to LDS (small n_fft)
   bool use_dr = false;         // k_iter_pair_dr: the digit-reversed in-place transform (power-of-two n_fft)
   bool use_wave = false;       // k_wave_iter (kernels_wave.h): the iteration's frame part on a transform that lives in one wave
+  int wave_last_waves = 0;     // ... waves of its last launch (an evaluating launch leaves that many pairs of partial sums)
+  DevBuf x_alt, seam_l, seam_r;   // ... with the overlap-add in registers: the other signal buffer, the chunk boundaries' partial sums
   size_t dr_lds = 0;
   int dr_threads = 0;
   double sum_m2 = 0, count = 0;
@@ -297,9 +299,12 @@ struct PlanT final : PlanBase {
     // two-sided run that keeps X and U - stays on k_iter_pair).  SPECINV_GENERIC_WAVE=0 never, =1 wherever it covers.
     {
       const char* we = getenv("SPECINV_GENERIC_WAVE");
-      // measured (tools/bench_wave.py, round 6): float64 one-sided 2048 / 1024 / 512 / 256: -9 / -31 / -14 / -26 %, float32 128 / 256
-      // -41 / -13 %; a two-sided frame - four bins per conjugate pair, taken one at a time - is 10 % SLOWER than k_iter_pair
-      const bool wins = cfg.onesided && (sizeof(T) == 8 || n <= 256);
+      // measured (tools/bench_wave.py, round 6, ms per iteration against k_iter_pair / k_iter_pair_dr): float64 one-sided 2048 / 512
+      // 0.386 -> 0.326, 1024 / 256 0.429 -> 0.215, 512 / 128 0.370 -> 0.240, 256 / 64 0.857 -> 0.405; float32 128 / 32 0.284 -> 0.143,
+      // 256 / 64 0.455 -> 0.295 (hop = n_fft / 2, / 4, / 8: overlap-add in registers; other hops -8 ... -25 % on frames + k_ola).
+      // A two-sided frame - four bins per conjugate pair, taken one at a time - only wins where a float64 frame is 8 points per
+      // lane (n_fft <= 512: 0.966 -> 0.895 at 512 / 300 / 100); elsewhere it is 10 - 15 % slower and stays on k_iter_pair.
+      const bool wins = cfg.onesided ? (sizeof(T) == 8 || n <= 256) : (sizeof(T) == 8 && n <= 512);
       use_wave = !big && wave_iter_covers(n) && !(we && we[0] == '0') && (wins || (we && we[0] == '1'));
     }
     if (std::max(lds_bytes, use_dr ? dr_lds : (size_t)0) > 48 * 1024) {
@@ -356,9 +361,8 @@ struct PlanT final : PlanBase {
     if (fast_path()) {
       fast.geometry(out);
     } else if (use_wave) {                     // a lane group of one wave per frame, every wave walking its share
-      out[2] = wave_iter_waves<T>(N(), (int64_t)B() * Tn(), &out[0]);   // (workgroups of four or eight waves: kernels_wave.h)
-      out[1] = Tn();
-      out[3] = 8;
+      wave_iter_geometry<T>(N(), cfg.hop_length, Tn(), B(), cfg.onesided != 0, out);   // (out[1]: chunks per item where the overlap-add
+      out[3] = 8;                                                                        //  runs in registers, else the frame count)
     } else {                                   // generic: one workgroup per frame pair
       out[0] = (use_dr ? dr_threads : frame_threads()) / 64;
       out[1] = (Tn() + 1) / 2;
@@ -697,7 +701,7 @@ struct PlanT final : PlanBase {
       fast.keep_state = fast.two ? keep_latched : keep_state;
       SI_TRY(fast.iterate(*this, n_iter, eval_last));
     } else {
-      SI_TRY(frames_needed());
+      if (!(use_wave && wave_iter_ola_chunks<T>(N(), cfg.hop_length, Tn(), B(), cfg.onesided != 0) > 0)) SI_TRY(frames_needed());
       const T inv1p = T(1) / (T)(1.0 + (double)coef);
       const FrameCfg<T> fci = frame_cfg(length);
       for (int i = 0; i < n_iter; ++i) {
@@ -722,38 +726,44 @@ struct PlanT final : PlanBase {
           continue;
         }
         if (use_wave) {
-          // The frames take a round trip between this kernel and the overlap-add (16 N of the 8 hop + 20 F + 8 N elements per frame).
-          // Experiment (SPECINV_WAVE_PART_MB > 0; default off): the batch walked in PARTS of a few items whose frames fit the
-          // Infinity Cache - k_wave_iter, then k_ola on the same items, every part through the SAME piece of the frames buffer.
-          // Measured at 32 / 64 / 128 / 256 MB per part: float64 2048 / 512 0.420 / 0.363 / 0.337 / 0.351 against 0.353 ms whole,
-          // float32 256 / 64 0.456 / 0.407 / 0.396 / 0.404 against 0.395: the cache does not hold the frames against the state
-          // streams that pass through it meanwhile.  (An evaluating launch always takes the batch whole.)
-          static const double part_mb = [] {
-            const char* e = getenv("SPECINV_WAVE_PART_MB");
-            return e ? atof(e) : 0.0;
-          }();
-          const double item_mb = (double)Tn() * N() * sizeof(T) / (1024.0 * 1024.0);
-          int ipp = B();
-          if (!ev && part_mb > 0) ipp = (int)std::max(1.0, std::min((double)B(), std::floor(part_mb / item_mb)));
-          if (ev) SI_TRY(partials.reserve((size_t)2 * wave_iter_waves<T>(N(), (int64_t)B() * Tn()) * sizeof(double)));
-          for (int b0 = 0; b0 < B(); b0 += ipp) {
-            const int nb = std::min(ipp, B() - b0);
-            const int64_t so = (int64_t)b0 * Tn() * n_freq;
-            WaveIterArgs<T> wa{};
-            wa.c = fci;
-            wa.x = x.as<T>() + (int64_t)b0 * length;
-            wa.S0 = specA.as<C>() + so;
-            wa.S1 = method == Method::Gla ? (C*)nullptr : specB.as<C>() + so;
-            wa.mag = mag.as<T>() + so;
-            wa.coef = coef;
-            wa.inv1p = inv1p;
+          WaveIterArgs<T> wa{};
+          wa.c = fci;
+          wa.x = x.as<T>();
+          wa.S0 = specA.as<C>();
+          wa.S1 = method == Method::Gla ? (C*)nullptr : specB.as<C>();
+          wa.mag = mag.as<T>();
+          wa.coef = coef;
+          wa.inv1p = inv1p;
+          wa.batch = B();
+          wa.mode = method == Method::Gla ? 0 : 1;
+          wa.eval = ev ? 1 : 0;
+          // hop = n_fft / 2, / 4, / 8: the overlap-add in the kernel's registers - no frames buffer, the new signal written to the
+          // plan's other signal buffer (the frames of an iteration read the old one), the chunk boundaries finished by k_wave_seams
+          const int nch = wave_iter_ola_chunks<T>(N(), cfg.hop_length, Tn(), B(), cfg.onesided != 0);
+          if (nch > 0) {
+            const int ov = N() / cfg.hop_length;
+            const size_t seam_bytes = (size_t)B() * nch * (ov - 1) * cfg.hop_length * sizeof(T);
+            SI_TRY(x_alt.reserve((size_t)B() * length * sizeof(T)));
+            SI_TRY(seam_l.reserve(seam_bytes));
+            SI_TRY(seam_r.reserve(seam_bytes));
+            wa.x_out = x_alt.as<T>();
+            wa.env = env.as<T>();
+            wa.seamL = seam_l.as<T>();
+            wa.seamR = seam_r.as<T>();
+            wa.nch = nch;
+            wa.ov = ov;
+          } else {
             wa.frames = frames.as<T>();
-            wa.partials = partials.as<double>();
-            wa.batch = nb;
-            wa.mode = method == Method::Gla ? 0 : 1;
-            wa.eval = ev ? 1 : 0;
-            SI_TRY(wave_iter_launch<T>(wa, stream));
-            SI_TRY(launch_ola(frames.as<T>(), x.as<T>() + (int64_t)b0 * length, true, -1, nb));
+          }
+          // (an evaluating launch leaves a pair of partial sums per wave: room for the fullest launch)
+          if (ev) SI_TRY(partials.reserve((size_t)2 * std::max(wave_iter_waves<T>(N(), (int64_t)B() * Tn()), 16 * 1024) * sizeof(double)));
+          wa.partials = partials.as<double>();
+          SI_TRY(wave_iter_launch<T>(wa, stream, &wave_last_waves));
+          if (nch > 0) {
+            std::swap(x.p, x_alt.p);
+            std::swap(x.bytes, x_alt.bytes);
+          } else {
+            SI_TRY(launch_ola(frames.as<T>(), x.as<T>(), true));
           }
           continue;
         }
@@ -790,7 +800,7 @@ struct PlanT final : PlanBase {
     if (eval_last) {
       const int64_t n_part = fast_path() ? (int64_t)fast.n_partials
                              : big ? (int64_t)B() * Tn() * ceil_div(N() / 2 + 1, 256)
-                             : use_wave ? (int64_t)wave_iter_waves<T>(N(), (int64_t)B() * Tn()) : (int64_t)B() * ((Tn() + 1) / 2);
+                             : use_wave ? (int64_t)wave_last_waves : (int64_t)B() * ((Tn() + 1) / 2);
       if (deferred_slot >= 0) {
         // deferred evaluation (run_loop with tol == 0 and no callback): keep the sums on the device
         SI_TRY(eval_log.reserve((size_t)(deferred_slot + 1) * 2 * sizeof(double)));

@@ -17,7 +17,7 @@ int wave_iter_waves(int n_fft, int64_t frames_total, int* waves_per_workgroup) {
     constexpr int LOGM = decltype(tag)::value;
     wave::Launch best{};
     for (int mode = 4; mode < 8; ++mode) {       // (the evaluating instantiations: theirs are the partial sums)
-      const wave::Launch a = wave::shape<T, LOGM>(frames_total, mode);
+      const wave::Launch a = wave::shape<T, LOGM>(frames_total, mode, 0);
       if (a.wgs * a.waves_per_wg > best.wgs * best.waves_per_wg) best = a;
     }
     return best;
@@ -35,22 +35,60 @@ int wave_iter_waves(int n_fft, int64_t frames_total, int* waves_per_workgroup) {
 }
 
 template <typename T>
-int wave_iter_launch(const WaveIterArgs<T>& a, hipStream_t stream) {
+int wave_iter_launch(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_out) {
   switch (a.c.n_fft) {
-    case 128: return wave::launch_one<T, 6>(a, stream);
-    case 256: return wave::launch_one<T, 7>(a, stream);
-    case 512: return wave::launch_one<T, 8>(a, stream);
-    case 1024: return wave::launch_one<T, 9>(a, stream);
-    case 2048: return wave::launch_one<T, 10>(a, stream);
+    case 128: return wave::launch_one<T, 6>(a, stream, waves_out);
+    case 256: return wave::launch_one<T, 7>(a, stream, waves_out);
+    case 512: return wave::launch_one<T, 8>(a, stream, waves_out);
+    case 1024: return wave::launch_one<T, 9>(a, stream, waves_out);
+    case 2048: return wave::launch_one<T, 10>(a, stream, waves_out);
     default: break;
   }
   SI_CHECK(false, SPECINV_EUNSUPPORTED, "k_wave_iter does not cover n_fft=%d", a.c.n_fft);
   return SPECINV_OK;
 }
 
+template <typename T>
+int wave_iter_ola_chunks(int n_fft, int hop, int n_frames, int batch, bool onesided) {
+  if (!onesided || hop <= 0 || n_fft % hop != 0) return 0;
+  const int ov = n_fft / hop;
+  if (ov != 2 && ov != 4 && ov != 8) return 0;
+  switch (n_fft) {
+    case 128: return wave::ola_chunks<T, 6>(ov, n_frames, batch);
+    case 256: return wave::ola_chunks<T, 7>(ov, n_frames, batch);
+    case 512: return wave::ola_chunks<T, 8>(ov, n_frames, batch);
+    case 1024: return wave::ola_chunks<T, 9>(ov, n_frames, batch);
+    case 2048: return wave::ola_chunks<T, 10>(ov, n_frames, batch);
+    default: return 0;
+  }
+}
+
+template <typename T>
+void wave_iter_geometry(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[3]) {
+  const int nch = wave_iter_ola_chunks<T>(n_fft, hop, n_frames, batch, onesided);
+  const int ov = nch > 0 ? n_fft / hop : 0, mode = onesided ? 0 : 2;
+  const int64_t work = nch > 0 ? (int64_t)batch * nch : (int64_t)batch * n_frames;
+  wave::Launch l{};
+  switch (n_fft) {
+    case 128: l = wave::shape<T, 6>(work, mode, ov); break;
+    case 256: l = wave::shape<T, 7>(work, mode, ov); break;
+    case 512: l = wave::shape<T, 8>(work, mode, ov); break;
+    case 1024: l = wave::shape<T, 9>(work, mode, ov); break;
+    case 2048: l = wave::shape<T, 10>(work, mode, ov); break;
+    default: break;
+  }
+  out[0] = l.waves_per_wg;
+  out[1] = nch > 0 ? nch : n_frames;
+  out[2] = l.wgs * l.waves_per_wg;
+}
+
+template void wave_iter_geometry<float>(int, int, int, int, bool, int*);
+template void wave_iter_geometry<double>(int, int, int, int, bool, int*);
+template int wave_iter_ola_chunks<float>(int, int, int, int, bool);
+template int wave_iter_ola_chunks<double>(int, int, int, int, bool);
 template int wave_iter_waves<float>(int, int64_t, int*);
 template int wave_iter_waves<double>(int, int64_t, int*);
-template int wave_iter_launch<float>(const WaveIterArgs<float>&, hipStream_t);
-template int wave_iter_launch<double>(const WaveIterArgs<double>&, hipStream_t);
+template int wave_iter_launch<float>(const WaveIterArgs<float>&, hipStream_t, int*);
+template int wave_iter_launch<double>(const WaveIterArgs<double>&, hipStream_t, int*);
 
 }  // namespace specinv

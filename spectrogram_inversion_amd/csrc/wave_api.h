@@ -18,6 +18,13 @@ struct WaveIterArgs {
   T* frames;                // (B, T, n_fft) out: windowed synthesis frames
   double* partials;         // [waves][2] evaluation sums (eval != 0)
   int batch, mode, eval;    // mode 0 Griffin-Lim, 1 ADMM
+  // overlap-add in registers (hop = n_fft / 2, / 4 or / 8; wave_iter_ola_chunks() > 0): no frames buffer - the new signal goes to
+  // x_out (another buffer than x: other waves still read x), the blocks at chunk boundaries through seamL / seamR and k_wave_seams
+  T* x_out = nullptr;
+  const T* env = nullptr;   // (length) window-square envelope
+  T* seamL = nullptr;       // [batch * nch][ov - 1][hop] each
+  T* seamR = nullptr;
+  int nch = 0, ov = 0;      // chunks of frames per item; n_fft / hop (0: frames buffer + k_ola)
 };
 
 // n_fft the kernel covers (a power of two, 128 ... 2048)
@@ -25,7 +32,17 @@ bool wave_iter_covers(int n_fft);
 // workgroups x waves the launch will use for `frames_total` frames: the number of partial-sum pairs an evaluating launch leaves
 template <typename T>
 int wave_iter_waves(int n_fft, int64_t frames_total, int* waves_per_workgroup = nullptr);
+// `waves_out`: waves the launch used (an evaluating launch leaves that many pairs of partial sums)
 template <typename T>
-int wave_iter_launch(const WaveIterArgs<T>& a, hipStream_t stream);
+int wave_iter_launch(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_out = nullptr);
+// Chunks of frames per item for the register overlap-add, 0 where it does not apply (hop is not n_fft / 2, / 4, / 8; a two-sided
+// spectrogram; a float64 frame of 16 points per lane, whose partial sums would not fit the registers; fewer than 2 OV frames).
+// wave_iter_launch with nch > 0 also runs k_wave_seams.
+template <typename T>
+int wave_iter_ola_chunks(int n_fft, int hop, int n_frames, int batch, bool onesided);
+// diagnostics (specinv_plan_launch_geometry): out = {waves per workgroup, chunks of frames per item (register overlap-add) or the
+// frame count, waves of a plain launch}
+template <typename T>
+void wave_iter_geometry(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[3]);
 
 }  // namespace specinv

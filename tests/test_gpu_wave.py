@@ -122,12 +122,14 @@ def test_wave_kernel_walks_more_frames_than_the_chip_holds(monkeypatch, dtype, n
 def test_wave_kernel_is_what_float64_and_small_frames_run(monkeypatch):
     """The drop-in functions on the reference's own test sizes (test/consts.py:1-3: n_fft 128 / 256 / 512, both dtypes) land on the
     wave-level coverage kernel where the plan says it wins - one-sided float64 at 128 ... 2048, one-sided float32 at 128 / 256 - and
-    on the kernels that served them before everywhere else (two-sided spectrograms, float32 512: the packed frame kernels)."""
+    two-sided float64 up to 512 - and on the kernels that served them before everywhere else (other two-sided spectrograms,
+    float32 512: the packed frame kernels)."""
     monkeypatch.delenv("SPECINV_GENERIC_WAVE", raising=False)
     for dtype, n_fft, onesided, want in ((torch.float64, 128, True, "k_wave_iter"), (torch.float64, 512, True, "k_wave_iter"),
                                          (torch.float64, 2048, True, "k_wave_iter"), (torch.float32, 128, True, "k_wave_iter"),
                                          (torch.float32, 256, True, "k_wave_iter"), (torch.float32, 512, True, "k_semi"),
-                                         (torch.float64, 512, False, "k_iter_pair"), (torch.float64, 4096, True, "k_iter_pair"),
+                                         (torch.float64, 512, False, "k_wave_iter"), (torch.float64, 1024, False, "k_iter_pair"),
+                                         (torch.float32, 256, False, "k_iter_pair"), (torch.float64, 4096, True, "k_iter_pair"),
                                          (torch.float64, 1000, True, "k_iter_pair")):
         F = n_fft // 2 + 1 if onesided else n_fft
         mag = torch.rand((2, F, 12), dtype=dtype, device=DEV) + 0.05
@@ -141,3 +143,60 @@ def test_wave_kernel_is_what_float64_and_small_frames_run(monkeypatch):
     ref = oracle.griffin_lim(oracle.phase_init(mag, hop_length=128, window=hann(512, np.float64)), max_iter=8, alpha=0.5, tol=0,
                              hop_length=128, window=hann(512, np.float64))
     assert rel_l2(y, ref) < 1e-9
+
+
+@pytest.mark.parametrize("dtype,n_fft,ov,frames,batch,extra", [
+    (np.float32, 128, 4, 301, 7, {}), (np.float32, 256, 4, 150, 5, dict(pad_mode="constant")), (np.float32, 256, 2, 77, 3, {}),
+    (np.float32, 128, 8, 200, 3, dict(center=False)), (np.float64, 256, 4, 90, 4, {}), (np.float64, 512, 4, 64, 3, dict(normalized=True)),
+    (np.float64, 1024, 4, 70, 2, {}), (np.float64, 1024, 8, 100, 2, dict(pad_mode="circular")), (np.float64, 512, 2, 40, 2, dict(center=False)),
+])
+def test_register_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, ov, frames, batch, extra):
+    """hop = n_fft / 2, / 4, / 8: `k_wave_iter` walks chunks of consecutive frames with the overlap-add in registers (partial sums
+    carried from frame to frame, a finished hop-block divided by the envelope and stored per frame; methods.py:127-132) instead of
+    writing frames for `k_ola`.  The sums are taken in ascending frame order like k_ola's, on rounded windowed samples like the
+    frames buffer's: after one iteration the samples outside the chunk boundaries are bit-identical to the frames + k_ola form but
+    for the few where the two instantiations' transforms contract a multiply-add differently (3 % measured, one ulp), and the
+    boundary blocks (k_wave_seams: left partial + right partial, another association) agree to rounding; after five iterations
+    of Griffin-Lim and ADMM both agree with the oracle.
+    SPECINV_WAVE_CHUNK pins short chunks so that every shape has several boundaries per item."""
+    hop = n_fft // ov
+    rng = np.random.default_rng(n_fft + ov)
+    w = hann(n_fft, dtype)
+    mag = (rng.random((batch, n_fft // 2 + 1, frames)) + 0.05).astype(dtype)
+    cd = np.complex64 if dtype == np.float32 else np.complex128
+    init = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(cd)
+    kw = dict(hop_length=hop, **extra)
+    monkeypatch.setenv("SPECINV_WAVE_CHUNK", str(max(2 * ov, 9)))
+    for method, arg in (("griffin_lim", 0.5), ("admm", 1.0)):
+        res = {}
+        for arm in ("registers", "frames"):
+            monkeypatch.setenv("SPECINV_WAVE_OLA", "1" if arm == "registers" else "0")
+            p = _plan(init, frames, dtype, True, monkeypatch, window=w, **kw)
+            (p.gla_init if method == "griffin_lim" else p.admm_init)(T(init), None, arg)
+            geo = p.launch_geometry
+            assert geo["kernel"] == "k_wave_iter" and (geo["chunks"] < frames) == (arm == "registers"), (arm, geo)
+            p.iterate(1)
+            y1 = N(p.wave())
+            p.iterate(3)
+            sums = p.iterate(1, eval_last=True)
+            res[arm] = (y1, N(p.wave()), np.array(sums[:2]), geo["chunks"])
+        a, b = res["registers"], res["frames"]
+        fin = np.isfinite(b[0])
+        assert np.array_equal(np.isfinite(a[0]), fin)
+        same = (a[0] == b[0]) | ~fin
+        nch = a[3]
+        assert nch >= 3
+        seam_share = (nch + 1) * (ov - 1) * hop / a[0].shape[1]
+        assert 1.0 - same.mean() <= 0.5 * seam_share + 0.1, (1.0 - same.mean(), seam_share)   # mostly at the chunk boundaries
+        eps = np.finfo(dtype).eps
+        assert np.abs(a[0][fin] - b[0][fin]).max() <= 8 * eps * np.abs(b[0][fin]).max()
+        with np.errstate(all="ignore"):
+            ref64 = getattr(oracle, method)(init.astype(np.complex128), tol=0, window=hann(n_fft, np.float64), max_iter=5,
+                                            **({"alpha": arg} if method == "griffin_lim" else {"rho": arg}), **kw)
+            ref = getattr(oracle, method)(init, tol=0, window=w, max_iter=5, **({"alpha": arg} if method == "griffin_lim" else {"rho": arg}), **kw)
+        f5 = np.isfinite(ref64)
+        e0 = rel_l2(ref[f5], ref64[f5])
+        tol = 2e-5 if dtype == np.float32 else 1e-10
+        assert np.array_equal(np.isfinite(a[1]), f5) and rel_l2(a[1][f5], ref64[f5]) < max(3 * e0, 5 * tol)
+        if np.isfinite(b[2]).all():
+            np.testing.assert_allclose(a[2], b[2], rtol=1e-5 if dtype == np.float32 else 1e-12)

@@ -17,7 +17,8 @@ dev = torch.device("cuda", 0)
 
 
 def make(n_fft, wl, hop, frames, batch, dtype, onesided, method, arm, mag, init=None, **extra):
-    os.environ["SPECINV_GENERIC_WAVE"] = "1" if arm == "wave" else "0"
+    os.environ["SPECINV_GENERIC_WAVE"] = "0" if arm == "ref" else "1"
+    os.environ["SPECINV_WAVE_OLA"] = "0" if arm == "wave_frames" else "1"     # (overlap-add in registers where it applies / frames + k_ola)
     w = torch.hann_window(wl or n_fft, dtype=dtype)
     kw = dict(hop_length=hop, window=w, onesided=onesided, **extra)
     if wl:
@@ -45,7 +46,9 @@ def check():
         for n_fft in (128, 256, 512, 1024, 2048):
             for onesided, hop, frames, batch, extra in ((True, n_fft // 4, 21, 3, {}), (False, n_fft // 4 + 3, 10, 2, {}),
                                                         (True, n_fft // 2, 9, 1, dict(center=False)),
-                                                        (True, n_fft // 8, 13, 2, dict(normalized=True, pad_mode="constant"))):
+                                                        (True, n_fft // 8, 13, 2, dict(normalized=True, pad_mode="constant")),
+                                                        (True, n_fft // 8, 45, 3, dict(pad_mode="replicate")), (True, n_fft // 2, 37, 2, {}),
+                                                        (True, n_fft // 4, 64, 5, dict(center=False))):
                 for method in ("gla", "admm"):
                     F = n_fft // 2 + 1 if onesided else n_fft
                     mag = torch.rand((batch, F, frames), dtype=dtype, device=dev) + 0.05
@@ -91,7 +94,7 @@ def bench(cases=CASES):
         F = n_fft // 2 + 1 if onesided else n_fft
         mag = torch.rand((batch, F, frames), dtype=dtype, device=dev)
         res = {}
-        for arm in ("ref", "wave"):
+        for arm in ("ref", "wave_frames", "wave"):
             plan = make(n_fft, wl, hop, frames, batch, dtype, onesided, method, arm, mag)
             geo = plan.launch_geometry
             plan.iterate(3)
@@ -111,7 +114,8 @@ def bench(cases=CASES):
         frac = {k: per_frame * batch * frames / (v[0] * 1e-3) / 8e12 for k, v in res.items()}
         g = res["wave"][1]
         print(f"{method:4s} n_fft {n_fft:5d} win {wl or n_fft:5d} hop {hop:5d} T {frames:5d} B {batch:3d} {str(dtype)[6:]:8s} onesided={onesided!s:5s} "
-              f"k_iter_pair {res['ref'][0]:7.3f} ms/it ({100 * frac['ref']:4.1f} %)   k_wave_iter {res['wave'][0]:7.3f} ms/it ({100 * frac['wave']:4.1f} % of 8 TB/s; "
+              f"k_iter_pair {res['ref'][0]:7.3f} ms/it ({100 * frac['ref']:4.1f} %)   k_wave_iter + k_ola {res['wave_frames'][0]:7.3f} ({100 * frac['wave_frames']:4.1f} %)   "
+              f"k_wave_iter {res['wave'][0]:7.3f} ms/it ({100 * frac['wave']:4.1f} % of 8 TB/s; "
               f"{g['waves']} waves, {g['waves_per_workgroup']} per workgroup)", flush=True)
 
 
