@@ -170,13 +170,15 @@ template <typename T, int LOGM>
 constexpr int max_threads() { return (sizeof(T) == 8 && (1 << LOGM) / Geo<T, LOGM>::LG >= 16) ? 512 : 1024; }
 // ... and with the overlap-add in registers (partial sums, the frame's outputs, envelope and signal addresses on top): three waves
 // per SIMD, 168 registers (at 128 those instantiations spilled 33 - 187 registers and ran slower than frames + k_ola)
-template <typename T, int LOGM, int OV>
+// - and a two-sided frame's four bins per conjugate pair: two (float64) or three waves
+template <typename T, int LOGM, int OV, bool TWO>
 constexpr int waves_per_simd() {
+  if (TWO) return sizeof(T) == 8 ? 2 : 3;
   return max_threads<T, LOGM>() == 512 ? 2 : (OV > 0 ? (((1 << LOGM) / Geo<T, LOGM>::LG >= 16 || sizeof(T) == 8) ? 2 : 3) : 4);
 }
 
 template <typename T, int LOGM, int MODE, bool TWO, bool EVAL, int OV>
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu((waves_per_simd<T, LOGM, OV>()))))
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per_eu((waves_per_simd<T, LOGM, OV, TWO>()))))
 void k_wave_iter(WaveIterArgs<T> a) {
   using G = Geo<T, LOGM>;
   using C = cplx<T>;
@@ -333,19 +335,32 @@ void k_wave_iter(WaveIterArgs<T> a) {
     for (int i0 = 0; i0 < NPAIR; i0 += CH) {
       C za[CH], zb[CH], s0a[CH], s0b[CH], s1a[CH], s1b[CH];
       T ma[CH], mb[CH];
-      // requests first (one-sided: the common case; a two-sided frame takes the per-bin path below)
+      // a two-sided spectrogram (methods.py:142-146): the mirror bins N - k and N - (M - k) = M + k carry their own state and target
+      constexpr int CT = TWO ? CH : 1;
+      C s0c[CT], s0d[CT], s1c[CT], s1d[CT];
+      T mc[CT], md[CT];
+      // requests first
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int k = gl + (i0 + u) * LG;
         const int kb = k == 0 ? M : M - k;          // k = 0 pairs the real bins 0 and M
-        if (!two) {
-          s0a[u] = S0u[so + k];
-          s0b[u] = S0u[so + kb];
-          ma[u] = magu[so + k];
-          mb[u] = magu[so + kb];
+        s0a[u] = S0u[so + k];
+        s0b[u] = S0u[so + kb];
+        ma[u] = magu[so + k];
+        mb[u] = magu[so + kb];
+        if (MODE == 1) {
+          s1a[u] = S1u[so + k];
+          s1b[u] = S1u[so + kb];
+        }
+        if constexpr (TWO) {
+          const int kc = k == 0 ? 0 : N - k, kd = k == 0 ? M : M + k;   // (bins 0 and M are their own mirror images: loaded, not used)
+          s0c[u] = S0u[so + kc];
+          s0d[u] = S0u[so + kd];
+          mc[u] = magu[so + kc];
+          md[u] = magu[so + kd];
           if (MODE == 1) {
-            s1a[u] = S1u[so + k];
-            s1b[u] = S1u[so + kb];
+            s1c[u] = S1u[so + kc];
+            s1d[u] = S1u[so + kd];
           }
         }
         za[u] = buf[phys<PS>(k)];
@@ -369,7 +384,7 @@ void k_wave_iter(WaveIterArgs<T> a) {
           xm = conj(e - wo);
         }
         C yk, ym;
-        if (!two) {
+        {
           C n0, n1;
           const C zero = mk<T>(T(0), T(0));
           yk = update_core<T, MODE>(xk, ma[u], s0a[u], MODE == 1 ? s1a[u] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
@@ -378,12 +393,18 @@ void k_wave_iter(WaveIterArgs<T> a) {
           ym = update_core<T, MODE>(xm, mb[u], s0b[u], MODE == 1 ? s1b[u] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
           S0u[so + kb] = n0;
           if (MODE == 1) S1u[so + kb] = n1;
-        } else if (k == 0) {
-          yk = upd(xk, 0);
-          ym = upd(xm, M);
-        } else {
-          yk = herm(xk, k);
-          ym = herm(xm, kb);
+          if constexpr (TWO) {
+            if (k != 0) {                           // the mirror bins see the conjugate spectrum; what ifft(.).real keeps is the Hermitian part
+              const C y2 = update_core<T, MODE>(conj(xk), mc[u], s0c[u], MODE == 1 ? s1c[u] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
+              S0u[so + N - k] = n0;
+              if (MODE == 1) S1u[so + N - k] = n1;
+              yk = mk<T>(T(0.5) * (yk.x + y2.x), T(0.5) * (yk.y - y2.y));
+              const C y3 = update_core<T, MODE>(conj(xm), md[u], s0d[u], MODE == 1 ? s1d[u] : zero, coef, inv1p, eval, s_d, s_o, n0, n1);
+              S0u[so + M + k] = n0;
+              if (MODE == 1) S1u[so + M + k] = n1;
+              ym = mk<T>(T(0.5) * (ym.x + y3.x), T(0.5) * (ym.y - y3.y));
+            }
+          }
         }
         if (k == 0) {                               // irfft / ifft(.).real: the imaginary parts of bins 0 and M do not count
           buf[phys<PS>(0)] = mk<T>(yk.x + ym.x, yk.x - ym.x);

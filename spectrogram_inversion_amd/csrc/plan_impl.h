@@ -302,9 +302,9 @@ struct PlanT final : PlanBase {
       // measured (tools/bench_wave.py, round 6, ms per iteration against k_iter_pair / k_iter_pair_dr): float64 one-sided 2048 / 512
       // 0.386 -> 0.326, 1024 / 256 0.429 -> 0.215, 512 / 128 0.370 -> 0.240, 256 / 64 0.857 -> 0.405; float32 128 / 32 0.284 -> 0.143,
       // 256 / 64 0.455 -> 0.295 (hop = n_fft / 2, / 4, / 8: overlap-add in registers; other hops -8 ... -25 % on frames + k_ola).
-      // A two-sided frame - four bins per conjugate pair, taken one at a time - only wins where a float64 frame is 8 points per
-      // lane (n_fft <= 512: 0.966 -> 0.895 at 512 / 300 / 100); elsewhere it is 10 - 15 % slower and stays on k_iter_pair.
-      const bool wins = cfg.onesided ? (sizeof(T) == 8 || n <= 256) : (sizeof(T) == 8 && n <= 512);
+      // A two-sided frame updates four bins per conjugate pair (their state requested together): 512 / 300 / 100 two-sided float64
+      // 0.971 -> 0.767, float32 0.536 -> 0.466 (float32 at n_fft >= 512 normally runs k_semi2 / k_hop2, faster still).
+      const bool wins = sizeof(T) == 8 || n <= 256;
       use_wave = !big && wave_iter_covers(n) && !(we && we[0] == '0') && (wins || (we && we[0] == '1'));
     }
     if (std::max(lds_bytes, use_dr ? dr_lds : (size_t)0) > 48 * 1024) {

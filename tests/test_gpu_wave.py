@@ -45,6 +45,10 @@ SWEEP = [  # n_fft, hop, frames, batch, extra stft kwargs
     (1024, 256, 9, 2, {}),
     (2048, 512, 7, 2, dict(pad_mode="reflect")),
     (2048, 333, 6, 1, dict(center=False)),
+    (128, 32, 17, 3, dict(onesided=False)),
+    (512, 100, 11, 2, dict(onesided=False, win_length=300)),        # the reference's own two-sided parametrisation
+    (1024, 256, 9, 2, dict(onesided=False, normalized=True)),
+    (2048, 512, 6, 2, dict(onesided=False, pad_mode="constant")),
 ]
 
 
@@ -58,7 +62,7 @@ def test_wave_kernel_kwarg_sweep_vs_oracle(monkeypatch, dtype, n_fft, hop, frame
     wl = extra.get("win_length", n_fft)
     w = hann(wl, dtype)
     kw = dict(hop_length=hop, **extra)
-    mag = (rng.random((batch, n_fft // 2 + 1, frames)) + 0.05).astype(dtype)
+    mag = (rng.random((batch, n_fft // 2 + 1 if extra.get("onesided", True) else n_fft, frames)) + 0.05).astype(dtype)
     cd = np.complex64 if dtype == np.float32 else np.complex128
     init = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(cd)
     tol = 2e-5 if dtype == np.float32 else 1e-10
@@ -121,15 +125,14 @@ def test_wave_kernel_walks_more_frames_than_the_chip_holds(monkeypatch, dtype, n
 
 def test_wave_kernel_is_what_float64_and_small_frames_run(monkeypatch):
     """The drop-in functions on the reference's own test sizes (test/consts.py:1-3: n_fft 128 / 256 / 512, both dtypes) land on the
-    wave-level coverage kernel where the plan says it wins - one-sided float64 at 128 ... 2048, one-sided float32 at 128 / 256 - and
-    two-sided float64 up to 512 - and on the kernels that served them before everywhere else (other two-sided spectrograms,
-    float32 512: the packed frame kernels)."""
+    wave-level coverage kernel where the plan says it wins - float64 at 128 ... 2048, float32 at 128 / 256, one- and two-sided - and
+    on the kernels that served them before everywhere else (float32 512: the packed frame kernels; other sizes)."""
     monkeypatch.delenv("SPECINV_GENERIC_WAVE", raising=False)
     for dtype, n_fft, onesided, want in ((torch.float64, 128, True, "k_wave_iter"), (torch.float64, 512, True, "k_wave_iter"),
                                          (torch.float64, 2048, True, "k_wave_iter"), (torch.float32, 128, True, "k_wave_iter"),
                                          (torch.float32, 256, True, "k_wave_iter"), (torch.float32, 512, True, "k_semi"),
-                                         (torch.float64, 512, False, "k_wave_iter"), (torch.float64, 1024, False, "k_iter_pair"),
-                                         (torch.float32, 256, False, "k_iter_pair"), (torch.float64, 4096, True, "k_iter_pair"),
+                                         (torch.float64, 512, False, "k_wave_iter"), (torch.float64, 1024, False, "k_wave_iter"),
+                                         (torch.float32, 256, False, "k_wave_iter"), (torch.float64, 4096, True, "k_iter_pair"),
                                          (torch.float64, 1000, True, "k_iter_pair")):
         F = n_fft // 2 + 1 if onesided else n_fft
         mag = torch.rand((2, F, 12), dtype=dtype, device=DEV) + 0.05
