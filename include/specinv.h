@@ -78,6 +78,10 @@ typedef int (*specinv_eval_cb)(const specinv_eval* ev, void* user);
 
 const char* specinv_last_error(void);
 int specinv_abi_version(void);
+/* 1 if the library carries the approximate-projection copies of the float32 wave-level kernels (built with SPECINV_BUILD_APPROX=1;
+ * not in a default build since round 6: five translation units, ~2 CPU-minutes, for a 3 % opt-in), else 0 - specinv_plan_set_exact(plan, 0)
+ * is then accepted and the plan keeps the reference's operation order. */
+int specinv_has_approx(void);
 
 /* ---- plan ---------------------------------------------------------------------------- */
 int specinv_plan_create(const specinv_stft_cfg* cfg, specinv_plan** out);
@@ -111,7 +115,8 @@ int specinv_plan_force_generic(specinv_plan* plan, int on);
  * correctly rounded division by the envelope: 73 % of the projected bins bit-identical to the reference's chain, every one within
  * its rounding noise; + 3 % on the headline step.  on = 0: S * (m * v_rsq_f32(|S|^2 + 1e-32)) and a multiplication by 1 / envelope
  * (52 % bit-identical, the same distance from the exact value).  The generic kernels and float64 use IEEE operations in the
- * reference's order throughout.  Takes effect at the next specinv_gla_init / specinv_admm_init. */
+ * reference's order throughout.  Takes effect at the next specinv_gla_init / specinv_admm_init.  on = 0 needs a library built with
+ * SPECINV_BUILD_APPROX=1 (specinv_has_approx()); a default build keeps on = 1 whatever is asked. */
 int specinv_plan_set_exact(specinv_plan* plan, int on);
 /* The float32 fast paths do not carry the reference's spectral state as such.
  * ADMM keeps only Y = X + U between iterations: methods.py:467-468 read the two as U + X, i.e. the Y that :475 has just

@@ -18,4 +18,4 @@ from .metrics import sc, snr, ser                                       # noqa: 
 from .transforms import MagSTFT, LogMelSTFT                             # noqa: E402,F401
 from .streaming import RTISIStream                                      # noqa: E402,F401
 from .mel import mel_filterbank                                         # noqa: E402,F401
-from .plan import set_exact_projection                                  # noqa: E402,F401
+from .plan import set_exact_projection, has_approx                      # noqa: E402,F401

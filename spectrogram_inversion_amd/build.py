@@ -6,6 +6,8 @@ hipcc cross-compiles without a GPU; the resulting .so sits next to the sources
 (spectrogram_inversion_amd/libspecinv.so), is git-ignored and travels to the GPU
 box with the repo snapshot.
 
+    SPECINV_BUILD_APPROX=1 python -m spectrogram_inversion_amd.build      (+ the approximate-projection kernels, see with_approx)
+
 The library is two dozen translation units (csrc/*.hip): the plan and the light kernels in
 specinv.hip, each family of heavy wave-level kernels in its own tu_*.hip (explicit
 instantiations), compiled in parallel and linked once.  Objects and their dependency
@@ -40,8 +42,17 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
 
 
+def with_approx() -> bool:
+    """SPECINV_BUILD_APPROX=1: also build the approximate-projection copies of the float32 wave-level kernels (tu_approx_*.hip - five
+    units that compile every kernel header a second time, ~2 CPU-minutes - selected per plan by specinv_plan_set_exact(plan, 0): 3 %
+    on the headline step, used by no BASELINE configuration).  Default: not built; tu_noapprox.hip stands in with empty kernel tables."""
+    return os.environ.get("SPECINV_BUILD_APPROX", "0") == "1"
+
+
 def sources():
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    names = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    names = [f for f in names if (f != "tu_noapprox.hip" if with_approx() else not f.startswith("tu_approx_"))]
+    srcs = [os.path.join(CSRC, f) for f in names]
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "specinv.h"))
     return srcs, hdrs
@@ -59,12 +70,22 @@ def sources_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def _units_stamp() -> str:
+    return os.path.join(CSRC, "build", "default", "units.txt")
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     srcs, hdrs = sources()
-    return any(os.path.getmtime(p) > t for p in srcs + hdrs)
+    if any(os.path.getmtime(p) > t for p in srcs + hdrs):
+        return True
+    try:                                            # (the set of units linked last time: SPECINV_BUILD_APPROX toggled since?)
+        with open(_units_stamp()) as fh:
+            return fh.read().split() != [os.path.basename(p) for p in srcs]
+    except OSError:
+        return False
 
 
 def _deps(depfile: str):
@@ -164,6 +185,9 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(f"{target}.{os.getpid()}.tmp", target)
+    if key == "default":
+        with open(_units_stamp(), "w") as fh:
+            fh.write("\n".join(os.path.basename(u[0]) for u in units))
     if key != "default":
         # a tuning variant's objects are not kept (12 MB each): the whole tree, csrc/build included, travels to the GPU box
         import shutil

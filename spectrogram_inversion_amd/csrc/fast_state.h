@@ -11,6 +11,7 @@ __attribute__((visibility("hidden"))) const void* specinv_approx_fused_b(int R, 
 __attribute__((visibility("hidden"))) const void* specinv_approx_fused_c(int R, int OV, int mode, int eval, int tuned4);
 __attribute__((visibility("hidden"))) const void* specinv_approx_td(int R, int OV, int early, int eval, int tuned4);
 __attribute__((visibility("hidden"))) const void* specinv_approx_frame(int family, int R, int a, int b);
+__attribute__((visibility("hidden"))) int specinv_approx_units_built(void);   // 0: the library was built without them (tu_noapprox.hip)
 }
 
 namespace specinv {
@@ -323,7 +324,7 @@ struct FastState<float> {
     mode = md;
     // (n_fft 4096 runs one wave per SIMD: its vector latency, not the state traffic, is what bounds it there - the signal form
     // measured 0.360 against 0.340 ms per iteration and is not used)
-    if (two) exact = true;       // (the approximate copy is not built for the two-sided kernels)
+    if (two || !specinv_approx_units_built()) exact = true;   // (no approximate copy: of the two-sided kernels; in a default build)
     td = md == fast::MODE_GLA && (!semi || hopk) && !use_template && !keep_state && RR <= 16 && !two;
     // (the reference-chain build leaves the real-FFT split unscaled, which is exact only for a power-of-two fwd_scale / 2)
     if (exact && pl.cfg.normalized && !hopk) td = false;

@@ -210,7 +210,7 @@ void k_wave_iter(WaveIterArgs<T> a) {
   __syncthreads();
   const FrameCfg<T>& c = a.c;
   const int Tn = c.n_frames, F = c.n_freq;
-  const int64_t total = (int64_t)a.batch * Tn, n_groups = (total + FPW - 1) / FPW;
+  const int64_t total = (int64_t)a.batch * Tn;
   const int64_t w0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave, nw = (int64_t)gridDim.x * (blockDim.x >> 6);
   const T hs = T(0.5) * c.fwd_scale;
   const T coef = a.coef, inv1p = a.inv1p;

@@ -146,6 +146,7 @@ extern "C" {
 
 const char* specinv_last_error(void) { return last_error().c_str(); }
 int specinv_abi_version(void) { return SPECINV_ABI_VERSION; }
+int specinv_has_approx(void) { return specinv_approx_units_built(); }
 
 int specinv_plan_create(const specinv_stft_cfg* cfg, specinv_plan** out) {
   SI_CHECK(cfg && out, SPECINV_EINVAL, "null argument");

@@ -60,6 +60,8 @@ template __global__ void k_hop_td<16, true, true>(HopArgs);
 }  // namespace fast_approx
 }  // namespace specinv
 
+extern "C" __attribute__((visibility("hidden"))) int specinv_approx_units_built(void) { return 1; }   // (tu_noapprox.hip: 0)
+
 extern "C" __attribute__((visibility("hidden"))) const void* specinv_approx_frame(int family /* 0 k_semi, 1 k_hop, 2 k_hop_td */, int R, int a /* mode, or early */, int b /* eval */) {
   using namespace specinv::fast_approx;
   if (family == 0 && R == 4 && a == 0 && b == 0) return (const void*)k_semi<4, MODE_GLA, false>;

@@ -1,12 +1,11 @@
-// The wave-level coverage kernel (kernels_wave.h): float32 / float64 x n_fft 128 ... 2048 x {Griffin-Lim, ADMM}, and its host entry
-// points (wave_api.h).
+// Template definitions of the wave-level coverage kernel's host entry points (wave_api.h); tu_wave_f32.hip / tu_wave_f64.hip
+// instantiate them - and with them the kernels of kernels_wave.h - for one element type each (two units: they build side by side).
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include "kernels_wave.h"
 
 namespace specinv {
-
-bool wave_iter_covers(int n_fft) { return n_fft == 128 || n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048; }
 
 template <typename T>
 int wave_iter_waves(int n_fft, int64_t frames_total, int* waves_per_workgroup) {
@@ -82,13 +81,6 @@ void wave_iter_geometry(int n_fft, int hop, int n_frames, int batch, bool onesid
   out[2] = l.wgs * l.waves_per_wg;
 }
 
-template void wave_iter_geometry<float>(int, int, int, int, bool, int*);
-template void wave_iter_geometry<double>(int, int, int, int, bool, int*);
-template int wave_iter_ola_chunks<float>(int, int, int, int, bool);
-template int wave_iter_ola_chunks<double>(int, int, int, int, bool);
-template int wave_iter_waves<float>(int, int64_t, int*);
-template int wave_iter_waves<double>(int, int64_t, int*);
-template int wave_iter_launch<float>(const WaveIterArgs<float>&, hipStream_t, int*);
-template int wave_iter_launch<double>(const WaveIterArgs<double>&, hipStream_t, int*);
+
 
 }  // namespace specinv

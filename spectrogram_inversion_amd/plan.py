@@ -643,6 +643,13 @@ def set_exact_projection(on: bool | None):
     _EXACT[0] = on
 
 
+def has_approx() -> bool:
+    """Does the loaded library carry the approximate-projection kernels (built with SPECINV_BUILD_APPROX=1)?  Without them
+    `set_exact(False)` / `set_exact_projection(False)` / SPECINV_EXACT=0 are accepted and every plan keeps the reference's operation
+    order."""
+    return bool(_lib.load().specinv_has_approx())
+
+
 def exact_projection() -> bool:
     if _EXACT[0] is not None:
         return bool(_EXACT[0])

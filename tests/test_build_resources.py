@@ -68,9 +68,10 @@ def test_headline_kernels_keep_their_register_budgets(kernels):
     # C3: k_rtisi_fast<16, 256, 4> - one wave per SIMD, the whole 512-entry file, no spills
     v, sp, a = _find(kernels, "12k_rtisi_fastILi16ELi256ELi4E")
     assert v > 256 and sp == 0, (v, sp, a)
-    # the approximate-projection copy of the headline kernel keeps the two-waves budget as well
-    v, sp, _ = _find(kernels, "11k_fused4_tdILi16ELb0ELb0E", approx=True)
-    assert v <= 256 and sp == 0, (v, sp)
+    # the approximate-projection copy of the headline kernel (SPECINV_BUILD_APPROX=1 builds only) keeps the two-waves budget as well
+    if any("11fast_approx" in k for k in kernels):
+        v, sp, _ = _find(kernels, "11k_fused4_tdILi16ELb0ELb0E", approx=True)
+        assert v <= 256 and sp == 0, (v, sp)
     # C5: k_objective_logmel<16, 9, false, true> (the mel filterbank as bands) and <16, 5> (the same on the matrix cores) - two
     # waves per SIMD (<= 256 registers), no spills
     for name in ("18k_objective_logmelILi16ELi9ELb0ELb1E", "18k_objective_logmelILi16ELi5ELb0ELb0E"):

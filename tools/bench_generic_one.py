@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One coverage-path configuration, a few iterations: the process tools/log/r04_final.sh wraps in rocprofv3 for
+"""One coverage-path configuration, a few iterations: the process tools/prof_generic.sh wraps in rocprofv3 for
 profiles/r04_generic_{kernel_stats.csv,pmc.json}.  usage: bench_generic_one.py <n_fft> <hop> <frames> <batch> <f32|f64> [twosided|onesided] [win_length]"""
 import os
 import sys
