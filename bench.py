@@ -63,7 +63,11 @@ WORKLOADS = {
     "C3": ("RTISI_LA", 32, 2048, 512, 1024, 25, 0.99),
     "C4": ("ADMM", 32, 1024, 256, 2048, 200, 0.1),
     "C5": ("L_BFGS", 16, 2048, 512, 1024, 20, None),
+    # the coverage path (every dtype / size the reference's own tests sweep, test/test_griffin.py:9-32) - extra legs only
+    "F64": ("griffin_lim", 16, 2048, 512, 1024, 100, 0.3),      # float64 at the headline frame size
+    "S32": ("griffin_lim", 64, 256, 64, 4096, 100, 0.3),        # float32 at n_fft 256 (test/consts.py:1-3)
 }
+LEG_DTYPE = {"F64": torch.float64}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 N_MELS, SR, LOOK_AHEAD = 80, 22050, 3
@@ -76,6 +80,8 @@ DOMINANT = {
     "C3": ("specinv::fast::k_rtisi_fast<16, 256, 4>", "latency"),
     "C5": ("specinv::fast::k_objective_walk<16, 4>", "valu"),
     "C1": ("specinv::fast::k_semi<8", "latency"),
+    "F64": ("specinv::wave::k_wave_iter<double, 10", "hbm"),
+    "S32": ("specinv::wave::k_wave_iter<float, 7", "hbm"),
 }
 PMC_PASSES = (
     ("fetch", ["FETCH_SIZE"]),
@@ -319,7 +325,8 @@ class Leg:
             self.batch = o.batch
         self.n_freq = self.n_fft // 2 + 1
         rng = np.random.default_rng(1234 + rank)
-        self.window = torch.from_numpy(hann(self.n_fft))
+        self.dtype = LEG_DTYPE.get(workload, torch.float32)
+        self.window = torch.from_numpy(hann(self.n_fft)).to(self.dtype)
         self.events, self.pending, self.state = [], [], {}
         self.folded = {"ms": 0.0, "n": 0}
         self.counters = {"evals": 0}
@@ -328,9 +335,9 @@ class Leg:
         m = self.method
         if m != "L_BFGS":
             mag_np = rng.random((self.batch, self.n_freq, self.frames), dtype=np.float32)
-            self.mag = torch.from_numpy(mag_np).to(dev)
+            self.mag = torch.from_numpy(mag_np).to(dev).to(self.dtype)
             self.plan = get_plan(args_helper(self.mag, hop_length=self.hop, window=self.window), self.batch, self.frames,
-                                 torch.float32, dev)
+                                 self.dtype, dev)
             if o.generic:
                 self.plan.force_generic(True)
             self.length = self.plan.length
@@ -500,7 +507,8 @@ class Leg:
                                    f"and the evaluation kernel k_eval_td averaged in launch_ms)",
                     "k_fused": f"specinv::fast::k_fused<{r}, {self.n_fft // self.hop}>", "k_semi": "k_semi+k_ola_f4",
                     "k_fused_td": f"specinv::fast::k_fused_td<{r}, {self.n_fft // self.hop}>", "k_hop": "k_hop",
-                    "k_hop_td": "k_hop_td", "k_iter_pair": "k_iter_pair+k_ola"}[g["kernel"]]
+                    "k_hop_td": "k_hop_td", "k_iter_pair": "k_iter_pair+k_ola",
+                    "k_wave_iter": "specinv::wave::k_wave_iter" + ("" if g["chunks"] < self.frames else "+k_ola")}[g["kernel"]]
             return self.plan.path, g, name
         if m == "RTISI_LA":
             fast = self.plan.fast_path
@@ -538,11 +546,14 @@ class Leg:
         launch_ms, n_launch = self.launch_ms()
         secs = launch_ms * 1e-3
         kname = (geo or {}).get("kernel")
-        default_shape = self.batch == WORKLOADS[self.workload][1] and not self.o.generic and path != "generic"
+        default_shape = self.batch == WORKLOADS[self.workload][1] and not self.o.generic and (path != "generic" or self.workload in ("F64", "S32"))
         bound = DOMINANT[self.workload][1] if default_shape else ("valu" if path == "generic" else "hbm")
         units = self.batch * self.frames
-        ref_unit = algorithmic_bytes_per_unit(self.method, self.hop, self.n_freq, self.coef)
+        es = 2 if self.dtype == torch.float64 else 1              # (SURVEY 8d prices float32 elements)
+        ref_unit = es * algorithmic_bytes_per_unit(self.method, self.hop, self.n_freq, self.coef)
         must_unit = restated_bytes_per_unit(self.method, self.hop, self.n_freq, kname) or ref_unit
+        if kname == "k_wave_iter" and geo["chunks"] >= self.frames:   # frames buffer + k_ola: the frames' round trip on top
+            must_unit += es * 8 * self.n_fft
         pmc = pmc or {}
         traffic = pmc.get("hbm_bytes_per_launch")
         vfrac = pmc.get("valu_issue_frac")
@@ -678,6 +689,36 @@ def check(leg, x):
                 "loss": loss, "mse": mse, "directional_fd": fd, "directional_g": gd, "ok": bool(ok)}
     mag = leg.mag
     from spectrogram_inversion_amd.plan import Plan, args_helper
+    if leg.workload in LEG_DTYPE or leg.workload == "S32":
+        # coverage legs: item 0 again on the workgroup-level kernels k_wave_iter replaced (the same update per bin on another
+        # transform), from the same starting spectrum, in the leg's own dtype
+        a = args_helper(mag[:1], hop_length=hop, window=window)
+        p0 = Plan(a, 1, mag.shape[2], leg.dtype, dev)
+        c0 = p0.phase_init(mag[:1])
+        saved = os.environ.get("SPECINV_GENERIC_WAVE")
+        os.environ["SPECINV_GENERIC_WAVE"] = "0"
+        try:
+            pr = Plan(a, 1, mag.shape[2], leg.dtype, dev)
+            pr.force_generic(True)
+        finally:
+            if saved is None:
+                os.environ.pop("SPECINV_GENERIC_WAVE", None)
+            else:
+                os.environ["SPECINV_GENERIC_WAVE"] = saved
+        pr.gla_init(c0, None, coef)
+        pr.iterate(iters)
+        xr = pr.wave()[0].double()
+        m64 = mag[0].double()[None]
+        pe = Plan(args_helper(m64, hop_length=hop, window=window.double()), 1, mag.shape[2], torch.float64, dev)
+
+        def sc(v):
+            s_ = pe.stft(v[None])
+            return (torch.linalg.norm(s_.abs() - m64) / torch.linalg.norm(m64)).item()
+        sc_a, sc_b = sc(x[0].double()), sc(xr)
+        tol = 1e-5
+        return {"what": "self-check (tripwire): SC_lin of item 0 (float64 evaluation) vs the same iterations on the workgroup-level "
+                        "coverage kernels (k_iter_pair)", "sc_lin": sc_a, "sc_lin_ref": sc_b, "abs_diff": abs(sc_a - sc_b), "tol": tol,
+                "ok": bool(abs(sc_a - sc_b) <= tol)}
     sc32, p64 = sc_lin_f64(x[0], mag[0], hop, window, dev)
     if method == "RTISI_LA":
         a = args_helper(mag[:1], hop_length=hop, window=window)
@@ -864,6 +905,8 @@ EXTRA_LEGS = (          # (key, workload, steps, warmup, option overrides, envir
     ("C5_wolfe", "C5", 2, 1, {"outer": 50, "c5_variant": "wolfe"}, {}),
     ("C5_memory", "C5", 1, 1, {"outer": 8, "c5_variant": "memory"}, {}),                             # the memory fills: the recursion carries weight
     ("C1", "C1", 50, 5, {}, {}),
+    ("F64", "F64", 3, 1, {}, {}),                                                                    # coverage path, float64 (k_wave_iter + k_ola)
+    ("S32", "S32", 3, 1, {}, {}),                                                                    # coverage path, n_fft 256 (k_wave_iter, register overlap-add)
 )
 
 
