@@ -35,23 +35,23 @@ template <int LOGM>
 struct GeoF;
 template <>
 struct GeoF<6> {     // n_fft 128:  8 x 8
-  static constexpr int LG = 8, NPASS = 2, R0 = 8, R1 = 8, R2 = 1;
+  static constexpr int LG = 8, NPASS = 2, R0 = 8, R1 = 8, R2 = 1, R3 = 1;
 };
 template <>
 struct GeoF<7> {     // n_fft 256:  16 x 8
-  static constexpr int LG = 8, NPASS = 2, R0 = 16, R1 = 8, R2 = 1;
+  static constexpr int LG = 8, NPASS = 2, R0 = 16, R1 = 8, R2 = 1, R3 = 1;
 };
 template <>
 struct GeoF<8> {     // n_fft 512:  16 x 16
-  static constexpr int LG = 16, NPASS = 2, R0 = 16, R1 = 16, R2 = 1;
+  static constexpr int LG = 16, NPASS = 2, R0 = 16, R1 = 16, R2 = 1, R3 = 1;
 };
 template <>
 struct GeoF<9> {     // n_fft 1024: 8 x 8 x 8
-  static constexpr int LG = 64, NPASS = 3, R0 = 8, R1 = 8, R2 = 8;
+  static constexpr int LG = 64, NPASS = 3, R0 = 8, R1 = 8, R2 = 8, R3 = 1;
 };
 template <>
 struct GeoF<10> {    // n_fft 2048: 16 x 8 x 8
-  static constexpr int LG = 64, NPASS = 3, R0 = 16, R1 = 8, R2 = 8;
+  static constexpr int LG = 64, NPASS = 3, R0 = 16, R1 = 8, R2 = 8, R3 = 1;
 };
 template <typename T, int LOGM>
 struct Geo : GeoF<LOGM> {};
@@ -60,11 +60,18 @@ struct Geo : GeoF<LOGM> {};
 // a wave's piece of LDS halves
 template <>
 struct Geo<double, 7> {   // 8 x 4 x 4
-  static constexpr int LG = 16, NPASS = 3, R0 = 8, R1 = 4, R2 = 4;
+  static constexpr int LG = 16, NPASS = 3, R0 = 8, R1 = 4, R2 = 4, R3 = 1;
+};
+// float64 at n_fft 2048: the frame on the 128 lanes of a TWO-WAVE workgroup (a "team": LG = 128), eight points per lane, four passes.
+// On one wave it is 16 points per lane - 64 registers before the first butterfly - and the register overlap-add's partial sums had
+// to be spilled (measured: slower than frames + k_ola).  What was a wave-private exchange becomes a workgroup barrier of two waves.
+template <>
+struct Geo<double, 10> {  // 8 x 8 x 4 x 4
+  static constexpr int LG = 128, NPASS = 4, R0 = 8, R1 = 8, R2 = 4, R3 = 4;
 };
 template <>
 struct Geo<double, 8> {   // 8 x 8 x 4
-  static constexpr int LG = 32, NPASS = 3, R0 = 8, R1 = 8, R2 = 4;
+  static constexpr int LG = 32, NPASS = 3, R0 = 8, R1 = 8, R2 = 4, R3 = 1;
 };
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
@@ -122,16 +129,23 @@ template <typename T, int LOGM>
 struct Tabs {
   using G = Geo<T, LOGM>;
   static constexpr int N1 = G::R0 * (G::R1 - 1);
-  static constexpr int N2 = G::NPASS == 3 ? G::R0 * G::R1 * (G::R2 - 1) : 0;
+  static constexpr int N2 = G::NPASS >= 3 ? G::R0 * G::R1 * (G::R2 - 1) : 0;
+  static constexpr int N3 = G::NPASS == 4 ? G::R0 * G::R1 * G::R2 * (G::R3 - 1) : 0;
   static constexpr int NPAIR = ((1 << LOGM) / 2) / G::LG;
-  static constexpr int TOTAL = N1 + N2 + NPAIR;           // + W_N^(i LG), the real-FFT split's step between a lane's pairs
+  static constexpr int TOTAL = N1 + N2 + N3 + NPAIR;           // + W_N^(i LG), the real-FFT split's step between a lane's pairs
 };
 
 // One Stockham pass on the group's LDS buffer, in place: butterfly j (of M / R) reads points j + q M / R, multiplies by W_m^(k q)
 // (m = NS R, j = blk NS + k), transforms, writes points blk NS R + k + i NS.  A lane owns butterflies gl, gl + LG, ...
 // what orders one lane's LDS write before another lane's read of it: the hardware executes a wave's LDS operations in order; the
 // compiler is told by a wavefront-scope fence (no instruction)
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+// A frame on a two-wave team (LG = 128) synchronises with the workgroup's barrier instead - the workgroup IS the team, so every
+// thread reaches every barrier (the unit loop's bounds are the same for both waves).
+template <int LG>
+__device__ __forceinline__ void wave_sync() {
+  if constexpr (LG > 64) __syncthreads();
+  else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 
 template <typename T, int R, int LNS, bool INV, int LOGM, int LG, int PS>
 __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict__ tab, int gl) {
@@ -153,7 +167,7 @@ __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict
     }
     bfly<T, R, INV>(v[it]);
   }
-  wave_sync();
+  wave_sync<LG>();
 #pragma unroll
   for (int it = 0; it < PER; ++it) {
     const int j = gl + it * LG, blk = j >> LNS, k = j & (NS - 1);
@@ -161,7 +175,7 @@ __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict
 #pragma unroll
     for (int i = 0; i < R; ++i) buf[phys<PS>(base + i * NS)] = v[it][i];
   }
-  wave_sync();
+  wave_sync<LG>();
 }
 
 // registers: a float64 frame of 16 points per lane is 64 registers before the first butterfly - those instantiations may take 256
@@ -174,6 +188,7 @@ constexpr int max_threads() { return (sizeof(T) == 8 && (1 << LOGM) / Geo<T, LOG
 template <typename T, int LOGM, int OV, bool TWO>
 constexpr int waves_per_simd() {
   if (TWO) return sizeof(T) == 8 ? 2 : 3;
+  if (Geo<T, LOGM>::LG > 64) return 2;            // (a team's workgroups: four to a CU by their LDS)
   return max_threads<T, LOGM>() == 512 ? 2 : (OV > 0 ? (((1 << LOGM) / Geo<T, LOGM>::LG >= 16 || sizeof(T) == 8) ? 2 : 3) : 4);
 }
 
@@ -182,7 +197,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per
 void k_wave_iter(WaveIterArgs<T> a) {
   using G = Geo<T, LOGM>;
   using C = cplx<T>;
-  constexpr int M = 1 << LOGM, N = 2 * M, LG = G::LG, FPW = 64 / LG;
+  constexpr int M = 1 << LOGM, N = 2 * M, LG = G::LG;
+  constexpr int TEAM = LG > 64 ? LG / 64 : 1;            // waves per frame (a team is a whole workgroup)
+  constexpr int FPW = LG > 64 ? 1 : 64 / LG;             // frames per wave (per workgroup for a team)
   constexpr int PS = ilog2(G::R0);
   constexpr int MP = phys<PS>(M) + 1;                    // a frame's points in LDS
   constexpr int LR0 = ilog2(G::R0), LR1 = ilog2(G::R1);
@@ -190,19 +207,25 @@ void k_wave_iter(WaveIterArgs<T> a) {
   using TB = Tabs<T, LOGM>;
   C* tab1 = reinterpret_cast<C*>(smem);                  // pass tables, then W_N^(i LG)
   C* tab2 = tab1 + TB::N1;
-  C* tabs = tab2 + TB::N2;
+  C* tab3 = tab2 + TB::N2;
+  C* tabs = tab3 + TB::N3;
   // (the wave's index as a scalar: everything derived from it - the group of frames, the bases of their state, target and
   // synthesis rows - then lives in scalar registers and the loads take the base + 32-bit offset form; from threadIdx.x alone the
   // compiler would carry a 64-bit address per access in vector registers)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63, g = lane / LG, gl = lane % LG;
-  C* buf = tab1 + TB::TOTAL + (size_t)(wave * FPW + g) * MP;
+  const int lane = threadIdx.x & 63;
+  const int g = TEAM > 1 ? 0 : lane / LG, gl = TEAM > 1 ? (int)threadIdx.x : lane % LG;
+  C* buf = tab1 + TB::TOTAL + (size_t)(TEAM > 1 ? 0 : wave * FPW + g) * MP;
   {
     constexpr int NS1 = G::R0, SH1 = LOGM + 1 - LR0 - LR1;             // W_(NS R)^(k q) = W_N^((k q) N / (NS R))
     for (int i = threadIdx.x; i < TB::N1; i += blockDim.x) tab1[i] = a.c.tw[((i & (NS1 - 1)) * (i / NS1 + 1)) << SH1];
-    if constexpr (G::NPASS == 3) {
+    if constexpr (G::NPASS >= 3) {
       constexpr int NS2 = G::R0 * G::R1, SH2 = LOGM + 1 - LR0 - LR1 - ilog2(G::R2);
       for (int i = threadIdx.x; i < TB::N2; i += blockDim.x) tab2[i] = a.c.tw[((i & (NS2 - 1)) * (i / NS2 + 1)) << SH2];
+    }
+    if constexpr (G::NPASS == 4) {
+      constexpr int NS3 = G::R0 * G::R1 * G::R2, SH3 = LOGM + 1 - LR0 - LR1 - ilog2(G::R2) - ilog2(G::R3);
+      for (int i = threadIdx.x; i < TB::N3; i += blockDim.x) tab3[i] = a.c.tw[((i & (NS3 - 1)) * (i / NS3 + 1)) << SH3];
     }
     for (int i = threadIdx.x; i < TB::NPAIR; i += blockDim.x) tabs[i] = a.c.tw[i * LG];
   }
@@ -211,7 +234,9 @@ void k_wave_iter(WaveIterArgs<T> a) {
   const FrameCfg<T>& c = a.c;
   const int Tn = c.n_frames, F = c.n_freq;
   const int64_t total = (int64_t)a.batch * Tn;
-  const int64_t w0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave, nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  // (the stride of the unit loop: waves of the launch, or teams)
+  const int64_t w0 = TEAM > 1 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  const int64_t nw = TEAM > 1 ? (int64_t)gridDim.x : (int64_t)gridDim.x * (blockDim.x >> 6);
   const T hs = T(0.5) * c.fwd_scale;
   const T coef = a.coef, inv1p = a.inv1p;
   constexpr bool eval = EVAL, two = TWO;
@@ -224,7 +249,7 @@ void k_wave_iter(WaveIterArgs<T> a) {
   // of a chunk lack the previous chunk's frames and its last OV - 1 partial sums lack the next one's: both go to side buffers and
   // k_wave_seams finishes those blocks.
   static_assert(OV == 0 || OV == 2 || OV == 4 || OV == 8, "hop = n_fft / 2, / 4 or / 8");
-  constexpr int RL = G::NPASS == 3 ? G::R2 : G::R1, PERL = (M / RL) / LG;       // the last pass: radix, butterflies per lane
+  constexpr int RL = G::NPASS == 4 ? G::R3 : G::NPASS == 3 ? G::R2 : G::R1, PERL = (M / RL) / LG;       // the last pass: radix, butterflies per lane
   constexpr int RPB = OV > 0 ? RL / (OV > 0 ? OV : 1) : 1, NBLK = PERL * RPB, NACC = OV > 0 ? OV - 1 : 1;   // complex values per lane and hop-block
   static_assert(OV == 0 || RL % OV == 0, "a hop-block is whole outputs of the last pass");
   const int nch = OV > 0 ? a.nch : 1;
@@ -299,6 +324,9 @@ void k_wave_iter(WaveIterArgs<T> a) {
         for (int it = 0; it < PER; ++it)
 #pragma unroll
           for (int q = 0; q < R; ++q) v[it][q] = buf[phys<PS>(gl + it * LG + q * NB)];
+        // (a team: the other wave may still be reading its parked points when this one starts writing the pass's outputs over
+        // them - `interior` is the frame's, the same for every thread of the team)
+        wave_sync<LG>();
       }
 #pragma unroll
       for (int it = 0; it < PER; ++it) {
@@ -312,10 +340,11 @@ void k_wave_iter(WaveIterArgs<T> a) {
 #pragma unroll
         for (int i = 0; i < R; ++i) buf[phys<PS>(j * R + i)] = v[it][i];
       }
-      wave_sync();
+      wave_sync<LG>();
     }
     pass_lds<T, G::R1, LR0, false, LOGM, LG, PS>(buf, tab1, gl);
-    if constexpr (G::NPASS == 3) pass_lds<T, G::R2, LR0 + LR1, false, LOGM, LG, PS>(buf, tab2, gl);
+    if constexpr (G::NPASS >= 3) pass_lds<T, G::R2, LR0 + LR1, false, LOGM, LG, PS>(buf, tab2, gl);
+    if constexpr (G::NPASS == 4) pass_lds<T, G::R3, LR0 + LR1 + ilog2(G::R2), false, LOGM, LG, PS>(buf, tab3, gl);
     // ---- the conjugate pairs (k, M - k): split, update, inverse split
     auto upd = [&](C r, int f) -> C {               // one bin of this frame
       C n0, n1;
@@ -423,13 +452,14 @@ void k_wave_iter(WaveIterArgs<T> a) {
       buf[phys<PS>(M / 2)] = mk<T>(T(2) * y.x, T(-2) * y.y);
     }
     // ---- synthesis: the passes again with conjugated twiddles, the last one straight to the frames buffer
-    wave_sync();
+    wave_sync<LG>();
     pass_lds<T, G::R0, 0, true, LOGM, LG, PS>(buf, tab1, gl);
-    if constexpr (G::NPASS == 3) pass_lds<T, G::R1, LR0, true, LOGM, LG, PS>(buf, tab1, gl);
+    if constexpr (G::NPASS >= 3) pass_lds<T, G::R1, LR0, true, LOGM, LG, PS>(buf, tab1, gl);
+    if constexpr (G::NPASS == 4) pass_lds<T, G::R2, LR0 + LR1, true, LOGM, LG, PS>(buf, tab2, gl);
     {
-      constexpr int R = G::NPASS == 3 ? G::R2 : G::R1, LNS = LOGM - ilog2(R), NS = 1 << LNS, NB = M / R, PER = NB / LG;
+      constexpr int R = RL, LNS = LOGM - ilog2(R), NS = 1 << LNS, NB = M / R, PER = NB / LG;
       static_assert(NB == NS, "the last pass has one block");
-      const C* tabl = G::NPASS == 3 ? tab2 : tab1;
+      const C* tabl = G::NPASS == 4 ? tab3 : G::NPASS == 3 ? tab2 : tab1;
       C v[PER][R];
 #pragma unroll
       for (int it = 0; it < PER; ++it) {
@@ -509,15 +539,16 @@ void k_wave_iter(WaveIterArgs<T> a) {
         }
       }
       }
-      wave_sync();
+      wave_sync<LG>();
     }
    }
   }
   if (eval) {
     const double d = wave_sum(s_d), o = wave_sum(s_o);
     if (lane == 0) {
-      a.partials[2 * w0] = d;
-      a.partials[2 * w0 + 1] = o;
+      const int64_t wi = TEAM > 1 ? w0 * TEAM + wave : w0;     // a pair of sums per WAVE of the launch
+      a.partials[2 * wi] = d;
+      a.partials[2 * wi + 1] = o;
     }
   }
 }
@@ -553,7 +584,7 @@ struct Launch {
 template <typename T, int LOGM, int OV>
 constexpr bool ola_fits() {
   using G = Geo<T, LOGM>;
-  return OV == 0 || ((SPECINV_WAVE_OLA_ALL || !(sizeof(T) == 8 && (1 << LOGM) / G::LG >= 16)) && (G::NPASS == 3 ? G::R2 : G::R1) % OV == 0);
+  return OV == 0 || ((SPECINV_WAVE_OLA_ALL || !(sizeof(T) == 8 && (1 << LOGM) / G::LG >= 16)) && (G::NPASS == 4 ? G::R3 : G::NPASS == 3 ? G::R2 : G::R1) % OV == 0);
 }
 
 template <typename T, int LOGM, int OV>
@@ -590,13 +621,14 @@ const void* kernel_of(int mode, int ov) {    // mode: bit 0 ADMM, bit 1 two-side
 template <typename T, int LOGM>
 Launch shape(int64_t work, int mode, int ov) {
   using G = Geo<T, LOGM>;
-  constexpr int M = 1 << LOGM, FPW = 64 / G::LG, PS = ilog2(G::R0), MP = phys<PS>(M) + 1;
+  constexpr int M = 1 << LOGM, TEAM = G::LG > 64 ? G::LG / 64 : 1, FPW = G::LG > 64 ? 1 : 64 / G::LG, PS = ilog2(G::R0), MP = phys<PS>(M) + 1;
   static int n_cu = 0;
   // workgroups of four or eight waves (each carries its own twiddle table), whichever puts more waves on a CU by the runtime's
   // own count of resident workgroups (registers and LDS); one launch fills the chip once and every wave walks its share of frames
   static int wpw_of[32] = {}, per_cu_of[32] = {};
   const int key = (mode & 7) | (ov == 2 ? 8 : ov == 4 ? 16 : ov == 8 ? 24 : 0);
-  auto lds_of = [&](int w) { return sizeof(cplx<T>) * ((size_t)Tabs<T, LOGM>::TOTAL + (size_t)w * FPW * MP); };
+  // (a team - a frame on the lanes of TEAM waves - is a workgroup of its own: `w` counts its one frame)
+  auto lds_of = [&](int w) { return sizeof(cplx<T>) * ((size_t)Tabs<T, LOGM>::TOTAL + (size_t)(TEAM > 1 ? 1 : w) * FPW * MP); };
   const void* fn = kernel_of<T, LOGM>(mode, ov);
   if (wpw_of[key] == 0) {
     int dev = 0;
@@ -607,9 +639,10 @@ Launch shape(int64_t work, int mode, int ov) {
     int best = 0;
     for (int w : {4, 8}) {
       int nb = 0;
+      if (TEAM > 1) w = TEAM;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * w, lds_of(w)) != hipSuccess) nb = 0;
       if (const char* e = getenv("SPECINV_WAVE_WPW")) {
-        if (atoi(e) != w) continue;
+        if (TEAM == 1 && atoi(e) != w) continue;
       }
       if (nb * w > best) {
         best = nb * w;
@@ -627,8 +660,9 @@ Launch shape(int64_t work, int mode, int ov) {
   const int64_t groups = (work + FPW - 1) / FPW;
   Launch l;
   l.waves_per_wg = wpw;
-  l.wgs = (int)std::max<int64_t>(1, std::min<int64_t>((groups + wpw - 1) / wpw, (int64_t)n_cu * per_cu_of[key]));
-  l.capacity = n_cu * per_cu_of[key] * wpw * FPW;
+  const int64_t wg_work = TEAM > 1 ? groups : (groups + wpw - 1) / wpw;      // workgroups the work fills: a team takes a frame
+  l.wgs = (int)std::max<int64_t>(1, std::min<int64_t>(wg_work, (int64_t)n_cu * per_cu_of[key]));
+  l.capacity = TEAM > 1 ? n_cu * per_cu_of[key] : n_cu * per_cu_of[key] * wpw * FPW;
   l.lds = lds_of(wpw);
   return l;
 }

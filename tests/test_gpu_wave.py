@@ -203,3 +203,36 @@ def test_register_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, 
         assert np.array_equal(np.isfinite(a[1]), f5) and rel_l2(a[1][f5], ref64[f5]) < max(3 * e0, 5 * tol)
         if np.isfinite(b[2]).all():
             np.testing.assert_allclose(a[2], b[2], rtol=1e-5 if dtype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("batch,frames", [(24, 400), (64, 1024)])
+def test_float64_2048_on_a_two_wave_team_at_full_occupancy(monkeypatch, batch, frames):
+    """float64 at n_fft 2048 runs a frame on the 128 lanes of a two-wave workgroup (eight points per lane: room for the register
+    overlap-add's partial sums).  What is a wave-private exchange elsewhere is a workgroup barrier there - and a missing one (the
+    edge frames' parked samples overwritten by the other wave's first-pass outputs) only showed with every workgroup slot of the
+    chip taken: BASELINE C2's shape in float64 (B 64, T 1024) and a ragged one, five iterations, both forms of the overlap-add
+    against the workgroup-level kernel - 1e-12 on every item, item edges included - and the evaluation's sums."""
+    rng = np.random.default_rng(batch)
+    mag = (rng.random((batch, 1025, frames)) + 0.05)
+    init = mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))
+    w = hann(2048, np.float64)
+    res = {}
+    for arm in ("workgroup", "frames", "registers"):
+        monkeypatch.setenv("SPECINV_WAVE_OLA", "0" if arm == "frames" else "1")
+        p = _plan(init, frames, np.float64, arm != "workgroup", monkeypatch, window=w, hop_length=512)
+        p.gla_init(T(init), None, 0.3)
+        geo = p.launch_geometry
+        if arm != "workgroup":
+            assert geo["kernel"] == "k_wave_iter" and geo["waves_per_workgroup"] == 2 and (geo["chunks"] < frames) == (arm == "registers"), geo
+        p.iterate(4)
+        sums = p.iterate(1, eval_last=True)
+        res[arm] = (N(p.wave()), np.array(sums[:2]))
+    ref = res["workgroup"]
+    for arm in ("frames", "registers"):
+        y = res[arm][0]
+        per_item = np.linalg.norm(y - ref[0], axis=1) / np.linalg.norm(ref[0], axis=1)
+        assert per_item.max() < 1e-12, (arm, int(per_item.argmax()), per_item.max())
+        edge = 16 * 512
+        assert np.abs(y[:, :edge] - ref[0][:, :edge]).max() < 1e-12 * np.abs(ref[0]).max()
+        assert np.abs(y[:, -edge:] - ref[0][:, -edge:]).max() < 1e-12 * np.abs(ref[0]).max()
+        np.testing.assert_allclose(res[arm][1], ref[1], rtol=1e-12)
