@@ -33,13 +33,16 @@ namespace wave {
 // lanes per frame and the passes' radices, by log2 M (M = n_fft / 2)
 template <int LOGM>
 struct GeoF;
+// (n_fft 128 / 256: sixteen lanes per frame, FOUR frames per wave - first cut as eight lanes x 8 / 16 points: the wider groups load
+// 128-byte pieces instead of 64-byte ones and the shallower registers leave three waves per SIMD their room; 128 / 32 0.137 -> 0.120 ms,
+// 256 / 64 0.302 -> 0.242)
 template <>
-struct GeoF<6> {     // n_fft 128:  8 x 8
-  static constexpr int LG = 8, NPASS = 2, R0 = 8, R1 = 8, R2 = 1, R3 = 1;
+struct GeoF<6> {     // n_fft 128:  4 x 4 x 4
+  static constexpr int LG = 16, NPASS = 3, R0 = 4, R1 = 4, R2 = 4, R3 = 1;
 };
 template <>
-struct GeoF<7> {     // n_fft 256:  16 x 8
-  static constexpr int LG = 8, NPASS = 2, R0 = 16, R1 = 8, R2 = 1, R3 = 1;
+struct GeoF<7> {     // n_fft 256:  8 x 4 x 4
+  static constexpr int LG = 16, NPASS = 3, R0 = 8, R1 = 4, R2 = 4, R3 = 1;
 };
 template <>
 struct GeoF<8> {     // n_fft 512:  16 x 16
@@ -55,13 +58,9 @@ struct GeoF<10> {    // n_fft 2048: 16 x 8 x 8
 };
 template <typename T, int LOGM>
 struct Geo : GeoF<LOGM> {};
-// float64 at n_fft 256 / 512: EIGHT points per lane (32 registers) on twice the lanes, three passes - the partial sums of the
-// register overlap-add then fit beside the frame (with sixteen points per lane they were spilled: slower than frames + k_ola), and
-// a wave's piece of LDS halves
-template <>
-struct Geo<double, 7> {   // 8 x 4 x 4
-  static constexpr int LG = 16, NPASS = 3, R0 = 8, R1 = 4, R2 = 4, R3 = 1;
-};
+// float64 at n_fft 512: EIGHT points per lane (32 registers) on twice the lanes, three passes - the partial sums of the register
+// overlap-add then fit beside the frame (with sixteen points per lane they were spilled: slower than frames + k_ola), and a wave's
+// piece of LDS halves
 // float64 at n_fft 2048: the frame on the 128 lanes of a TWO-WAVE workgroup (a "team": LG = 128), eight points per lane, four passes.
 // On one wave it is 16 points per lane - 64 registers before the first butterfly - and the register overlap-add's partial sums had
 // to be spilled (measured: slower than frames + k_ola).  What was a wave-private exchange becomes a workgroup barrier of two waves.
