@@ -58,9 +58,9 @@ struct GeoF<10> {    // n_fft 2048: 16 x 8 x 8
 };
 template <typename T, int LOGM>
 struct Geo : GeoF<LOGM> {};
-// float64 at n_fft 512: EIGHT points per lane (32 registers) on twice the lanes, three passes - the partial sums of the register
-// overlap-add then fit beside the frame (with sixteen points per lane they were spilled: slower than frames + k_ola), and a wave's
-// piece of LDS halves
+// float64 at n_fft 512: FOUR points per lane on a whole wave, four radix-4 passes (sixteen points per lane on sixteen lanes: the
+// partial sums of the register overlap-add were spilled, slower than frames + k_ola; eight on thirty-two: 0.253 ms at 512 / 128;
+// four on sixty-four: 0.206 - wider groups load longer pieces and leave the registers to the loads in flight)
 // float64 at n_fft 2048: the frame on the 128 lanes of a TWO-WAVE workgroup (a "team": LG = 128), eight points per lane, four passes.
 // On one wave it is 16 points per lane - 64 registers before the first butterfly - and the register overlap-add's partial sums had
 // to be spilled (measured: slower than frames + k_ola).  What was a wave-private exchange becomes a workgroup barrier of two waves.
@@ -69,8 +69,8 @@ struct Geo<double, 10> {  // 8 x 8 x 4 x 4
   static constexpr int LG = 128, NPASS = 4, R0 = 8, R1 = 8, R2 = 4, R3 = 4;
 };
 template <>
-struct Geo<double, 8> {   // 8 x 8 x 4
-  static constexpr int LG = 32, NPASS = 3, R0 = 8, R1 = 8, R2 = 4, R3 = 1;
+struct Geo<double, 8> {   // 4 x 4 x 4 x 4
+  static constexpr int LG = 64, NPASS = 4, R0 = 4, R1 = 4, R2 = 4, R3 = 4;
 };
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
