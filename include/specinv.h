@@ -160,6 +160,11 @@ int specinv_gla_run(specinv_plan* plan, int max_iter, int eva_iter, double tol, 
 /* ---- ADMM (methods.py:415-506) --------------------------------------------------------- */
 int specinv_admm_init(specinv_plan* plan, const void* init_spec, const void* mag, double rho);
 int specinv_admm_iterate(specinv_plan* plan, int n_iter, int eval_last, double sums_host[4]);
+/* n_iter iterations of the running method (Griffin-Lim or ADMM), the last one evaluating (methods.py:180-182) - its four sums
+ * {sum (|S| - m)^2, sum |S|^2, sum m^2, count} left in DEVICE memory (4 doubles) instead of on the host: nothing waits.  For callers
+ * that reduce the sums over several plans / ranks before they look at them (`_training_loop`'s whole-batch metric across GPUs,
+ * methods.py:181-190: one all-reduce on the device, one read). */
+int specinv_iterate_eval_dev(specinv_plan* plan, int n_iter, void* sums_dev);
 int specinv_admm_run(specinv_plan* plan, int max_iter, int eva_iter, double tol, int metric,
                      specinv_eval* evals_out, int* n_evals_out, int* iters_done_out,
                      specinv_eval_cb cb, void* user);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "specinv_last_error": (C.c_char_p, []),
     "specinv_abi_version": (C.c_int, []),
     "specinv_has_approx": (C.c_int, []),
+    "specinv_iterate_eval_dev": (C.c_int, [_P, C.c_int, _P]),
     "specinv_plan_create": (C.c_int, [C.POINTER(StftCfg), C.POINTER(_P)]),
     "specinv_plan_destroy": (C.c_int, [_P]),
     "specinv_plan_set_stream": (C.c_int, [_P, _P]),

@@ -899,6 +899,11 @@ static __global__ void k_finish_partials(const double* __restrict__ partials, in
   }
 }
 
+static __global__ void k_store2(double* __restrict__ out, double a, double b) {
+  out[0] = a;
+  out[1] = b;
+}
+
 // per-block partial sums of (a-b)^2, a^2, b^2 (b may be null: only a^2 is meaningful)
 template <typename T>
 __global__ void k_metric_partials(const T* __restrict__ a, const T* __restrict__ b, int64_t n,

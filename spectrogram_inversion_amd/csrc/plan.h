@@ -42,6 +42,9 @@ struct PlanBase {
   // evaluations whose result cannot influence the run (tol == 0, no callback) stay on the device and are
   // read back once at the end: deferred_slot >= 0 makes iterate() park its sums in that slot
   int deferred_slot = -1;
+  // ... or to device memory the caller names (specinv_iterate_eval_dev: 4 doubles, nothing waits): the multi-GPU loop all-reduces
+  // them where they are and reads the result once
+  double* eval_dev_out = nullptr;
   virtual int begin_deferred(int n_slots) = 0;
   virtual int read_deferred(int n_slots, double* out) = 0;
   virtual int get_wave(void* x_out) = 0;

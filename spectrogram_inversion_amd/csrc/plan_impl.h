@@ -801,6 +801,12 @@ struct PlanT final : PlanBase {
       const int64_t n_part = fast_path() ? (int64_t)fast.n_partials
                              : big ? (int64_t)B() * Tn() * ceil_div(N() / 2 + 1, 256)
                              : use_wave ? (int64_t)wave_last_waves : (int64_t)B() * ((Tn() + 1) / 2);
+      if (eval_dev_out != nullptr) {
+        hipLaunchKernelGGL(k_finish_partials, dim3(1), dim3(256), 0, stream, partials.as<double>(), n_part, 2, eval_dev_out);
+        hipLaunchKernelGGL(k_store2, dim3(1), dim3(1), 0, stream, eval_dev_out + 2, sum_m2, count);
+        SI_HIP(hipGetLastError());
+        return SPECINV_OK;
+      }
       if (deferred_slot >= 0) {
         // deferred evaluation (run_loop with tol == 0 and no callback): keep the sums on the device
         SI_TRY(eval_log.reserve((size_t)(deferred_slot + 1) * 2 * sizeof(double)));

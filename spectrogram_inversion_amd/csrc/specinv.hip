@@ -273,6 +273,16 @@ int specinv_admm_run(specinv_plan* plan, int max_iter, int eva_iter, double tol,
   return plan->impl->run_loop(max_iter, eva_iter, tol, metric, evals_out, n_evals_out, iters_done_out, cb, user);
 }
 
+int specinv_iterate_eval_dev(specinv_plan* plan, int n_iter, void* sums_dev) {
+  ENTER(plan);
+  SI_CHECK(plan->impl->method != Method::None, SPECINV_ESTATE, "specinv_gla_init / specinv_admm_init has not been called");
+  SI_CHECK(sums_dev != nullptr && n_iter >= 1, SPECINV_EINVAL, "bad arguments");
+  plan->impl->eval_dev_out = static_cast<double*>(sums_dev);
+  const int rc = plan->impl->iterate(n_iter, true, nullptr);
+  plan->impl->eval_dev_out = nullptr;
+  return rc;
+}
+
 int specinv_get_wave(specinv_plan* plan, void* x_out) {
   ENTER(plan);
   return plan->impl->get_wave(x_out);

@@ -99,6 +99,9 @@ def gather_waveforms(x_local: torch.Tensor, dst: int = 0, group=None, sizes=None
     return None
 
 
+LAST_LOOP = {"device_sums": None}          # diagnostics of the last run_loop_global (tests: which path the evaluations took)
+
+
 def run_loop_global(plan, max_iter, eva_iter=10, tol=0.0, metric="sc", callback=None, group=None):
     """`_training_loop` (methods.py:153-190) with whole-batch semantics across ranks: every
     evaluation all-reduces (sum) the rank-local sums before the metric / stop rule."""
@@ -115,12 +118,22 @@ def run_loop_global(plan, max_iter, eva_iter=10, tol=0.0, metric="sc", callback=
             plan.iterate(max_iter - done)
             done = max_iter
             break
-        s = plan.iterate(until, eval_last=True)          # this rank's four sums (host floats)
-        if dist.is_initialized():
-            where = torch.device("cpu") if _host_staged(group, plan.device) else plan.device
-            s = torch.tensor(s, dtype=torch.float64, device=where)
+        if dist.is_initialized() and hasattr(plan, "iterate_dev") and not _host_staged(group, plan.device):
+            # the rank's four sums stay on the device, are all-reduced there (RCCL, the plan's stream order) and read ONCE per
+            # evaluation (round 5: a read of the local sums, then a second one of the reduced sums)
+            s = torch.empty(4, dtype=torch.float64, device=plan.device)
+            plan.iterate_dev(until, s)
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
             s = s.tolist()
+            LAST_LOOP["device_sums"] = True
+        else:
+            s = plan.iterate(until, eval_last=True)      # this rank's four sums (host floats)
+            LAST_LOOP["device_sums"] = False
+            if dist.is_initialized():
+                where = torch.device("cpu") if _host_staged(group, plan.device) else plan.device
+                s = torch.tensor(s, dtype=torch.float64, device=where)
+                dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+                s = s.tolist()
         done += until
         m, loss = _from_sums(name, s), s[0] / s[3]
         evals.append((done - 1, m, loss))

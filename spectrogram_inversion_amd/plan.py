@@ -261,6 +261,13 @@ class Plan:
         _lib.check(fn(self._h, int(n_iter), int(eval_last), sums))
         return list(sums) if eval_last else None
 
+    def iterate_dev(self, n_iter: int, out: torch.Tensor):
+        """`iterate(n_iter, eval_last=True)` with the evaluation's four sums left in `out` (4 float64 on the plan's device): no
+        host synchronisation - `distributed.run_loop_global` all-reduces them where they are."""
+        assert out.dtype == torch.float64 and out.numel() >= 4 and out.is_contiguous() and out.device == self.device
+        self._sync_stream()
+        _lib.check(self.lib.specinv_iterate_eval_dev(self._h, int(n_iter), C.c_void_p(out.data_ptr())))
+
     def run(self, max_iter, eva_iter=10, tol=0.0, metric="sc", callback=None):
         """The reference's `_training_loop` (methods.py:153-190) executed by the library.
         Returns (iterations_done, [(iteration, metric, loss), ...])."""

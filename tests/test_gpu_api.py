@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from _util import hann, rel_l2
+from _util import hann, rel_l2, segment_errors
 
 pytestmark = pytest.mark.gpu
 
@@ -167,6 +167,21 @@ def test_small_problems_take_the_frame_kernel():
     ref = oracle.griffin_lim(mag, max_iter=5, alpha=0.0, tol=0, hop_length=256, window=hann(1024))
     y = N(si.griffin_lim(torch.from_numpy(mag).to(DEV), max_iter=5, alpha=0.0, tol=0, verbose=False, hop_length=256, window=w))
     assert rel_l2(y, ref) < 1e-4
+    # ... and BASELINE configs[0] exactly: 50 iterations at alpha 0 from the magnitudes.  Random magnitudes are inconsistent (isolated
+    # near-zero bins part any two float32 runs after a few dozen iterations), so the 50-iteration result is held the way the C2
+    # headline is: spectral convergence within 1e-5 of the float64 oracle's, and the bulk of the hop segments within 1e-4 of it
+    # (the float64 yardstick starts from the float32 phase_init - what the device starts from, to an ulp: SURVEY 8c)
+    init32 = oracle.phase_init(mag, hop_length=256, window=hann(1024))
+    ref64 = oracle.griffin_lim(init32.astype(np.complex128), max_iter=50, alpha=0.0, tol=0, hop_length=256, window=hann(1024, np.float64))
+    y50 = N(si.griffin_lim(torch.from_numpy(mag).to(DEV), max_iter=50, alpha=0.0, tol=0, verbose=False, hop_length=256, window=w))
+    a64 = oracle.args_helper(513, np.float64, hop_length=256, window=hann(1024, np.float64))
+
+    def sc(v):
+        s_ = np.abs(oracle.stft(v.astype(np.float64), a64))
+        return float(np.linalg.norm(s_ - mag) / np.linalg.norm(mag))
+    assert abs(sc(y50) - sc(ref64)) < 1e-5, (sc(y50), sc(ref64))
+    seg = segment_errors(y50[0], ref64[0], 256)
+    assert np.median(seg) < 1e-4, np.median(seg)
 
 
 def test_c_abi_argument_errors():

@@ -56,6 +56,8 @@ def test_rccl_loop_gather_and_sharded_entry_points(nccl_group):
     assert 5 < done_ref < 400
     plan.gla_init(None, mag, 0.99)
     done, evals = run_loop_global(plan, 400, eva_iter=5, tol=1e-3, metric="sc")
+    from spectrogram_inversion_amd import distributed as D
+    assert D.LAST_LOOP["device_sums"] is True          # the sums were reduced on the device: one read per evaluation
     assert done == done_ref and len(evals) == len(evals_ref)
     np.testing.assert_allclose(np.array(evals), np.array(evals_ref), rtol=1e-12)
     x = plan.wave()
