@@ -669,6 +669,7 @@ Launch shape(int64_t work, int mode, int ov) {
 // chunks per item of the register overlap-add: enough units to fill the chip once, chunks of at least max(2 OV, 8) frames
 template <typename T, int LOGM>
 int ola_chunks(int ov, int n_frames, int batch) {
+  if (!wave_iter_fits(2 << LOGM, n_frames, batch, true)) return 0;
   const bool fits = ov == 2 ? ola_fits<T, LOGM, 2>() : ov == 4 ? ola_fits<T, LOGM, 4>() : ov == 8 ? ola_fits<T, LOGM, 8>() : false;
   if (!fits || n_frames < 2 * ov) return 0;
   if (const char* e = getenv("SPECINV_WAVE_OLA")) {
@@ -688,8 +689,9 @@ int launch_one(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_out) {
   const void* fn = kernel_of<T, LOGM>(mode, ov);
   SI_CHECK(fn != nullptr && (ov == 0 || (a.x_out && a.env && a.seamL && a.seamR && a.x_out != a.x)), SPECINV_EINVAL,
            "k_wave_iter: bad overlap-add arguments");
-  SI_CHECK((int64_t)a.batch * a.c.n_frames < ((int64_t)1 << 31) && (int64_t)8 * a.c.n_frames * a.c.n_fft < ((int64_t)1 << 31), SPECINV_EUNSUPPORTED,
-           "k_wave_iter: too many frames for 32-bit frame offsets");
+  // (frames are indexed with 32 bits; the lane groups of a wave address their rows relative to the first group's, with the register
+  // overlap-add up to a chunk apart - the plan keeps such shapes on the frames form / the workgroup kernels: wave_iter_fits)
+  SI_CHECK(wave_iter_fits(a.c.n_fft, a.c.n_frames, a.batch, ov > 0), SPECINV_EUNSUPPORTED, "k_wave_iter: too many frames for 32-bit frame offsets");
   const Launch l = shape<T, LOGM>(ov > 0 ? (int64_t)a.batch * a.nch : (int64_t)a.batch * a.c.n_frames, mode, ov);
   if (waves_out) *waves_out = l.wgs * l.waves_per_wg;
   WaveIterArgs<T> args = a;

@@ -305,7 +305,8 @@ struct PlanT final : PlanBase {
       // A two-sided frame updates four bins per conjugate pair (their state requested together): 512 / 300 / 100 two-sided float64
       // 0.971 -> 0.767, float32 0.536 -> 0.466 (float32 at n_fft >= 512 normally runs k_semi2 / k_hop2, faster still).
       const bool wins = sizeof(T) == 8 || n <= 256;
-      use_wave = !big && wave_iter_covers(n) && !(we && we[0] == '0') && (wins || (we && we[0] == '1'));
+      use_wave = !big && wave_iter_covers(n) && wave_iter_fits(n, cfg.n_frames, cfg.batch, false) && !(we && we[0] == '0') &&
+                 (wins || (we && we[0] == '1'));
     }
     if (std::max(lds_bytes, use_dr ? dr_lds : (size_t)0) > 48 * 1024) {
       // (the attribute belongs to the kernel, not to the plan: never lower what another plan has asked for)

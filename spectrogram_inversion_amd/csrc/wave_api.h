@@ -29,6 +29,12 @@ struct WaveIterArgs {
 
 // n_fft the kernel covers (a power of two, 128 ... 2048)
 bool wave_iter_covers(int n_fft);
+// ... and the frame counts its 32-bit frame indices and row offsets take (`chunks`: with the register overlap-add, whose lane groups
+// walk chunks up to n_frames apart); beyond them the plan uses the frames form / the workgroup-level kernels
+inline bool wave_iter_fits(int n_fft, int n_frames, int batch, bool chunks) {
+  const int64_t total = (int64_t)batch * n_frames, lim = (int64_t)1 << 31;
+  return total * 1 < lim && (int64_t)8 * (n_fft + 2) < lim && (!chunks || (int64_t)8 * n_frames * (n_fft + 2) < lim);
+}
 // workgroups x waves the launch will use for `frames_total` frames: the number of partial-sum pairs an evaluating launch leaves
 template <typename T>
 int wave_iter_waves(int n_fft, int64_t frames_total, int* waves_per_workgroup = nullptr);

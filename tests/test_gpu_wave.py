@@ -236,3 +236,24 @@ def test_float64_2048_on_a_two_wave_team_at_full_occupancy(monkeypatch, batch, f
         assert np.abs(y[:, :edge] - ref[0][:, :edge]).max() < 1e-12 * np.abs(ref[0]).max()
         assert np.abs(y[:, -edge:] - ref[0][:, -edge:]).max() < 1e-12 * np.abs(ref[0]).max()
         np.testing.assert_allclose(res[arm][1], ref[1], rtol=1e-12)
+
+
+def test_long_signals_keep_the_frames_form(monkeypatch):
+    """`k_wave_iter` indexes frames with 32 bits and addresses a wave's lane groups relative to the first; with the register
+    overlap-add the groups walk chunks up to a whole item apart, so a signal of 8 n_frames (n_fft + 2) >= 2^31 elements keeps the
+    frames + k_ola form (float64 n_fft 2048, 140 000 frames) - against the workgroup-level kernels on the same input."""
+    rng = np.random.default_rng(8)
+    frames, n_fft, hop = 140_000, 2048, 512
+    mag = (rng.random((1, n_fft // 2 + 1, frames)) + 0.05)
+    w = hann(n_fft, np.float64)
+    res = {}
+    for arm in ("wave", "workgroup"):
+        p = _plan(mag, frames, np.float64, arm == "wave", monkeypatch, window=w, hop_length=hop)
+        c0 = p.phase_init(T(mag))
+        p.gla_init(c0, None, 0.3)
+        if arm == "wave":
+            geo = p.launch_geometry
+            assert geo["kernel"] == "k_wave_iter" and geo["chunks"] == frames, geo       # no chunks: the frames form
+        p.iterate(3)
+        res[arm] = N(p.wave())
+    assert rel_l2(res["wave"], res["workgroup"]) < 1e-12

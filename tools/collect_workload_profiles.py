@@ -6,7 +6,7 @@ FETCH_SIZE counts a 16-B/lane streaming read at half its bytes, MI355X_MICROARCH
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 sys.path.insert(0, ROOT)
 import bench                                           # noqa: E402  (the dominant-kernel table is bench.py's)
 
@@ -17,8 +17,11 @@ DOMINANT = {
     "C4": [bench.DOMINANT["C4"][0], "specinv::fast::k_fused4<8, 1, true>"],
     "C3": [bench.DOMINANT["C3"][0]],
     "C5": [bench.DOMINANT["C5"][0], "specinv::k_objective_epilogue", "specinv::k_lbd_direction_lean<float>", "specinv::k_lbd_settle_x<float>"],
+    "F64": [bench.DOMINANT["F64"][0], "specinv::wave::k_wave_seams<double>"],
+    "S32": [bench.DOMINANT["S32"][0], "specinv::wave::k_wave_seams<float>"],
 }
-ALGO = {"C2": 64 * 1024 * 8196, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 8512}   # (C5: 16 hop + 4 mels - the walk applies the step too)
+ALGO = {"C2": 64 * 1024 * 8196, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 8512,
+        "F64": 16 * 1024 * 2 * (8 * 512 + 20 * 1025), "S32": 64 * 4096 * (8 * 64 + 20 * 129)}   # (C5: 16 hop + 4 mels - the walk applies the step too)
 out = os.path.join(ROOT, "profiles")
 traffic_path = os.path.join(out, "traffic.json")
 try:

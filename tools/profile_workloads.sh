@@ -1,8 +1,8 @@
 # rocprofv3 runs of every bench workload (on the GPU box via gpurun); outputs land in gpurun_out/${TAG}_<W>_*.
 # Per workload: 1) kernel trace + stats; 2) PMC passes (separate runs, kernel dispatch only - never combined with trace domains).
-TAG=${1:-r05}
+TAG=${1:-r06}
 shift
-WL=${@:-C2 C4 C3 C5}
+WL=${@:-C2 C4 C3 C5 F64 S32}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
