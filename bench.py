@@ -1018,6 +1018,10 @@ def build_parser():
     ap.add_argument("--no-h2d", action="store_true", help="skip the H2D-inclusive legs")
     ap.add_argument("--no-overlap-gather", action="store_true",
                     help="N > 1: wait for each step's RCCL gather before the next step starts (default: it overlaps the next step)")
+    ap.add_argument("--gather-kernel-budget", type=int, default=None, metavar="K",
+                    help="N > 1: plan the iteration launches for 256 - K compute units (SPECINV_CU_BUDGET) so that the RCCL kernels of "
+                         "a gather that overlaps the next step find free CUs instead of pushing iteration workgroups into a second "
+                         "round; default 16 over RCCL (NCCL_MAX_NCHANNELS is capped to 8 with it), 0 at N = 1 and in the gloo rehearsal")
     ap.add_argument("--even-chunks", action="store_true",
                     help="even chunks of frames per wave instead of the skewed ones (DESIGN 3.2 (7)): to try when RCCL's kernels share "
                          "the chip with an exactly-full iteration launch")
@@ -1037,6 +1041,16 @@ def main():
         os.environ["SPECINV_K4_SKEW"] = "0,0"
     if args.pmc_child:
         return pmc_child(args.pmc_child.split(","))
+    # N > 1 over RCCL: leave compute units to the gather's kernels (see --gather-kernel-budget); decided before anything is planned
+    # and before the communicator exists (NCCL_MAX_NCHANNELS is read at its creation)
+    n_ranks = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    budget = args.gather_kernel_budget
+    if budget is None:
+        budget = 16 if (n_ranks > 1 and os.environ.get("SPECINV_BENCH_BACKEND", "nccl") == "nccl") else 0
+    budget = max(0, min(128, budget)) if n_ranks > 1 else 0
+    if budget:
+        os.environ["SPECINV_CU_BUDGET"] = str(budget)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(max(1, budget // 2)))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
 
@@ -1096,6 +1110,7 @@ def main():
                 "ranks_seen": int(sum(float(t[2]) for t in every)), "backend": backend,
                 "gather": "overlapped with the next step (RCCL stream)" if not args.no_overlap_gather else "blocking after each step",
                 "gather_alone_ms_rank0": gather_ms,
+                "gather_kernel_budget_cus": budget, "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                 "gather_bytes_per_rank": None if method == "L_BFGS" else batch * leg.length * 4}
     if rank == 0:
         want = (batch * world if method != "L_BFGS" else batch, leg.length)

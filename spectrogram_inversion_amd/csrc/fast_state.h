@@ -267,6 +267,14 @@ struct FastState<float> {
     long long slots = 1024LL * (R >= 32 ? 1 : R <= 4 ? 3 : 2);
     if (SPECINV_R8_W3 && R == 8) slots = 3072;
     if (const char* e = getenv("SPECINV_FUSED_SLOTS")) slots = atoll(e);      // (experiments: wave slots of the chip)
+    // SPECINV_CU_BUDGET=k: plan the launch for a chip of 256 - k compute units - the chunk count is chosen so that one round of
+    // workgroups leaves k CUs free.  For multi-GPU runs whose RCCL gather overlaps the next step's launches: an iteration
+    // workgroup takes a whole CU's registers, so RCCL's workgroups can only run beside a launch that does not fill the chip
+    // (bench.py --gather-kernel-budget; C2: 30 chunks of 34 frames on 240 CUs instead of 32 x 32 on 256: +6 % per launch).
+    if (const char* e = getenv("SPECINV_CU_BUDGET")) {
+      const int k = atoi(e);
+      if (k > 0 && k < 256) slots = slots * (256 - k) / 256;
+    }
     int best_nch = 1;
     double best_cost = 1e300;
     for (int nch = 1; nch <= std::max(1, cfg.n_frames / floor_ch); ++nch) {

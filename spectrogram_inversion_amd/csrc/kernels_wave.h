@@ -20,6 +20,8 @@
 // The overlap-add stays k_ola / k_ola_f4 / k_ola_d2 (fixed summation order), so x changes only by the transform's rounding.
 // Bytes per frame and iteration as for the kernels it replaces: 8 hop + 20 F + 8 N elements (ADMM 36 F).
 #pragma once
+#include <mutex>
+
 #include "wave_api.h"
 
 
@@ -629,6 +631,8 @@ Launch shape(int64_t work, int mode, int ov) {
   // (a team - a frame on the lanes of TEAM waves - is a workgroup of its own: `w` counts its one frame)
   auto lds_of = [&](int w) { return sizeof(cplx<T>) * ((size_t)Tabs<T, LOGM>::TOTAL + (size_t)(TEAM > 1 ? 1 : w) * FPW * MP); };
   const void* fn = kernel_of<T, LOGM>(mode, ov);
+  static std::mutex mu;                                  // (plans of several host threads may ask at once)
+  std::lock_guard<std::mutex> lock(mu);
   if (wpw_of[key] == 0) {
     int dev = 0;
     hipDeviceProp_t prop{};

@@ -384,3 +384,32 @@ def test_c5_optimiser_two_items_vs_the_oracle(monkeypatch):
     assert abs(snaps[0][1] - want[0, 0]) <= 1e-5 * want[0, 0]
     assert rel_l2(N(snaps[0][0] - x0), moved) < 1e-4, rel_l2(N(snaps[0][0] - x0), moved)
     assert rel_l2(N(snaps[0][0] - x0), N(x - x0)) < 1e-6
+
+
+def test_c2_with_compute_units_left_to_the_gather(monkeypatch):
+    """N > 1: `bench.py` plans the C2 launches for 256 - 16 compute units (SPECINV_CU_BUDGET, --gather-kernel-budget) so that RCCL's
+    kernels find free CUs while a gather overlaps the next step: 30 chunks per item on 240 workgroups instead of 32 on 256.  Same
+    iterates up to where the chunk seams fall: ten iterations against the oracle on three items and against the full-chip plan."""
+    n_fft, hop, frames, batch, alpha = 2048, 512, 1024, 64, 0.3
+    mag_np = bench_mag(batch, n_fft // 2 + 1, frames)
+    mag = torch.from_numpy(mag_np).to(DEV)
+    w = hann(n_fft)
+    items = [0, 40, 63]
+    res = {}
+    for budget in (0, 16):
+        monkeypatch.setenv("SPECINV_CU_BUDGET", str(budget))
+        p = make_plan(n_fft, hop, frames, batch)
+        c0 = p.phase_init(mag)
+        p.gla_init(c0, None, alpha)
+        geo = p.launch_geometry
+        want = {"waves_per_workgroup": 8, "chunks": 32 if budget == 0 else 30, "waves": 2048 if budget == 0 else 1920, "kernel": "k_fused4_td"}
+        assert geo == want, geo
+        p.iterate(9)
+        sums = p.iterate(1, eval_last=True)
+        res[budget] = (N(p.wave()), np.array(sums[:2]), N(c0[items]))
+        del p
+    ref = oracle.griffin_lim(res[16][2], max_iter=10, alpha=alpha, tol=0, hop_length=hop, window=w)
+    for k, it in enumerate(items):
+        assert rel_l2(res[16][0][it], ref[k]) < 1e-4, (it, rel_l2(res[16][0][it], ref[k]))
+    assert rel_l2(res[16][0], res[0][0]) < 2e-5
+    np.testing.assert_allclose(res[16][1], res[0][1], rtol=1e-5)
