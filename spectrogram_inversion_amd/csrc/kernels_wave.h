@@ -186,11 +186,23 @@ constexpr int max_threads() { return (sizeof(T) == 8 && (1 << LOGM) / Geo<T, LOG
 // ... and with the overlap-add in registers (partial sums, the frame's outputs, envelope and signal addresses on top): three waves
 // per SIMD, 168 registers (at 128 those instantiations spilled 33 - 187 registers and ran slower than frames + k_ola)
 // - and a two-sided frame's four bins per conjugate pair: two (float64) or three waves
+// ... and with the ring (measured at 4 / 3 / 2 waves per SIMD, tools/log/EXPERIMENTS.md r06-u: float64 512 / 300 / 100 0.499 / 0.397 /
+// 0.398 ms, 1024 / 800 / 200 0.513 / 0.351 / 0.247, 256 / 200 / 50 0.754 / 0.529 / 0.471 - at 128 registers those spill 31 ... 280;
+// float32 1024 / 800 / 200 0.295 / 0.260 / 0.286, 256 / 200 / 50 0.304 / 0.272 / 0.301)
+#ifndef SPECINV_WAVE_RING_WPS64
+#define SPECINV_WAVE_RING_WPS64 2
+#endif
+#ifndef SPECINV_WAVE_RING_WPS32
+#define SPECINV_WAVE_RING_WPS32 3
+#endif
 template <typename T, int LOGM, int OV, bool TWO>
 constexpr int waves_per_simd() {
-  if (TWO) return sizeof(T) == 8 ? 2 : 3;
   if (Geo<T, LOGM>::LG > 64) return 2;            // (a team's workgroups: four to a CU by their LDS)
-  return max_threads<T, LOGM>() == 512 ? 2 : (OV > 0 ? (((1 << LOGM) / Geo<T, LOGM>::LG >= 16 || sizeof(T) == 8) ? 2 : 3) : 4);
+  // (the ring: a wave's frame buffers and rings are 16 KB of LDS where a lane carries 16 points - two waves per SIMD fit anyway)
+  if (OV == 1 && sizeof(T) == 4 && (1 << LOGM) / Geo<T, LOGM>::LG >= 16) return 2;
+  if (TWO) return sizeof(T) == 8 ? 2 : 3;
+  if (OV == 1) return sizeof(T) == 8 ? SPECINV_WAVE_RING_WPS64 : SPECINV_WAVE_RING_WPS32;
+  return max_threads<T, LOGM>() == 512 ? 2 : (OV > 1 ? (((1 << LOGM) / Geo<T, LOGM>::LG >= 16 || sizeof(T) == 8) ? 2 : 3) : 4);
 }
 
 template <typename T, int LOGM, int MODE, bool TWO, bool EVAL, int OV>
@@ -249,10 +261,19 @@ void k_wave_iter(WaveIterArgs<T> a) {
   // envelope and stored to the OTHER signal buffer per frame, added in ascending frame order like k_ola.  The first OV - 1 blocks
   // of a chunk lack the previous chunk's frames and its last OV - 1 partial sums lack the next one's: both go to side buffers and
   // k_wave_seams finishes those blocks.
-  static_assert(OV == 0 || OV == 2 || OV == 4 || OV == 8, "hop = n_fft / 2, / 4 or / 8");
+  // OV == 1 (any other hop < n_fft, two-sided spectrograms): the same chunk walk with the overlap-add in an LDS RING of n_fft samples
+  // per lane group - a frame's samples are added at (t hop + s) mod n_fft, the first hop of them are complete, leave for the signal
+  // (or, at the chunk's start, for k_wave_seams) and are zeroed; consecutive frames of a group follow each other in program order
+  // (a team: behind the frame's closing barrier), so every ring entry is summed in ascending frame order like k_ola's sums.
+  static_assert(OV == 0 || OV == 1 || OV == 2 || OV == 4 || OV == 8, "hop = n_fft / 2, / 4 or / 8, or the ring");
   constexpr int RL = G::NPASS == 4 ? G::R3 : G::NPASS == 3 ? G::R2 : G::R1, PERL = (M / RL) / LG;       // the last pass: radix, butterflies per lane
-  constexpr int RPB = OV > 0 ? RL / (OV > 0 ? OV : 1) : 1, NBLK = PERL * RPB, NACC = OV > 0 ? OV - 1 : 1;   // complex values per lane and hop-block
-  static_assert(OV == 0 || RL % OV == 0, "a hop-block is whole outputs of the last pass");
+  constexpr int RPB = OV > 1 ? RL / (OV > 1 ? OV : 1) : 1, NBLK = OV > 1 ? PERL * RPB : 1, NACC = OV > 1 ? OV - 1 : 1;   // complex values per lane and hop-block
+  static_assert(OV <= 1 || RL % OV == 0, "a hop-block is whole outputs of the last pass");
+  T* ring = nullptr;                                     // OV == 1: n_fft samples per lane group, behind the frame buffers
+  if constexpr (OV == 1) {
+    const int nbuf = TEAM > 1 ? 1 : (int)(blockDim.x >> 6) * FPW;
+    ring = reinterpret_cast<T*>(tab1 + TB::TOTAL + (size_t)nbuf * MP) + (size_t)(TEAM > 1 ? 0 : wave * FPW + g) * N;
+  }
   const int nch = OV > 0 ? a.nch : 1;
   const int64_t units = OV > 0 ? (int64_t)a.batch * nch : total;
   const int trips = OV > 0 ? (Tn + nch - 1) / nch : 1;
@@ -277,6 +298,11 @@ void k_wave_iter(WaveIterArgs<T> a) {
     for (int b = 0; b < NACC; ++b)
 #pragma unroll
       for (int e = 0; e < NBLK; ++e) acc[b][e] = mk<T>(T(0), T(0));
+    if constexpr (OV == 1) {                        // an empty ring (every lane its own sample slots)
+#pragma unroll
+      for (int m = 0; m < M / LG; ++m) *reinterpret_cast<C*>(ring + 2 * (gl + m * LG)) = mk<T>(T(0), T(0));
+      wave_sync<LG>();
+    }
    for (int s = 0; s < trips; ++s) {
     if (s >= len) continue;
     const int fi = fstart + s;                      // (host: fewer than 2^31 frames)
@@ -496,6 +522,40 @@ void k_wave_iter(WaveIterArgs<T> a) {
         for (int it = 0; it < PER; ++it)
 #pragma unroll
           for (int i = 0; i < R; ++i) *reinterpret_cast<C*>(fru + fo + 2 * (gl + it * LG + i * NS)) = y[it][i];
+      } else if constexpr (OV == 1) {
+        const int hop = c.hop, keep = N - hop;
+        const int64_t a0 = (int64_t)t * hop;        // padded position of the frame's first sample (the chunk's: ta hop)
+        const int rb = (int)(a0 & (N - 1));
+        const int64_t n0 = a0 - c.pad;              // ... its place in the signal; samples [lo, hi) of the frame are inside
+        const int lo = (int)(n0 < 0 ? (-n0 < N ? -n0 : N) : 0), hi = (int)(c.length - n0 < N ? (c.length - n0 > 0 ? c.length - n0 : 0) : N);
+        const int head = keep - s * hop;            // the previous chunk's last frames reach samples [0, head): k_wave_seams' part
+        T* xf = a.x_out + ((int64_t)bi * c.length + n0);
+        const T* ef = a.env + n0;
+        T* sR = a.seamR + ((int64_t)u * keep + (int64_t)s * hop);
+        T* sL = a.seamL + ((int64_t)u * keep - hop);
+        const bool last = s == len - 1, even = !(hop & 1);   // (an even hop: sample pairs stay together in the ring)
+        auto emit = [&](int sidx, T v) -> T {       // the new ring entry
+          if (sidx < hop) {                         // complete as far as this chunk's frames go
+            if (sidx < head) sR[sidx] = v;
+            else if (sidx >= lo && sidx < hi) xf[sidx] = v / ef[sidx];
+            return T(0);
+          }
+          if (last) sL[sidx] = v;                   // what the chunk leaves for the samples after its last frame's first hop
+          return v;
+        };
+#pragma unroll
+        for (int it = 0; it < PER; ++it)
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            const int s0 = 2 * (gl + it * LG + i * NS), i0 = (rb + s0) & (N - 1), i1 = (rb + s0 + 1) & (N - 1);
+            if (even) {
+              const C r = *reinterpret_cast<const C*>(ring + i0);
+              *reinterpret_cast<C*>(ring + i0) = mk<T>(emit(s0, r.x + y[it][i].x), emit(s0 + 1, r.y + y[it][i].y));
+            } else {
+              ring[i0] = emit(s0, ring[i0] + y[it][i].x);
+              ring[i1] = emit(s0 + 1, ring[i1] + y[it][i].y);
+            }
+          }
       } else {
         // hop-block b of the frame is outputs i in [b RPB, (b + 1) RPB): slot e = it RPB + i mod RPB sits at complex offset
         // gl + it LG + (i mod RPB) NS of the block.  Block 0 closes the oldest partial sum (padded position t hop): stored - or,
@@ -557,19 +617,20 @@ void k_wave_iter(WaveIterArgs<T> a) {
 // The hop-blocks at chunk boundaries of the register overlap-add: boundary c of item b (c = 0 ... nch; frame position cb(c), T for
 // the last) has OV - 1 blocks whose sums are split between the chunk before it (seamL: what its last frames left) and the chunk
 // after it (seamR: what its first frames had so far); x = (left + right) / envelope.
+// (`keep` samples per boundary: (OV - 1) hop of the register form, n_fft - hop of the ring)
 template <typename T>
 __global__ void k_wave_seams(const T* __restrict__ seamL, const T* __restrict__ seamR, const T* __restrict__ env, T* __restrict__ x_out,
-                             int Tn, int nch, int ov, int hop, int pad, int64_t length, int batch) {
-  const int64_t per = (int64_t)(ov - 1) * hop, total = (int64_t)batch * (nch + 1) * per;
+                             int Tn, int nch, int keep, int hop, int pad, int64_t length, int batch) {
+  const int64_t per = keep, total = (int64_t)batch * (nch + 1) * per;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t cu = idx / per;
-    const int rem = (int)(idx - cu * per), s = rem / hop, r = rem - s * hop;
+    const int r = (int)(idx - cu * per);
     const int b = (int)(cu / (nch + 1)), cc = (int)(cu - (int64_t)b * (nch + 1));
-    const int pos = (cc < nch ? (int)(((int64_t)cc * Tn) / nch) : Tn) + s;
+    const int pos = cc < nch ? (int)(((int64_t)cc * Tn) / nch) : Tn;
     const int64_t n = (int64_t)pos * hop + r - pad;
     if (n < 0 || n >= length) continue;
-    const T right = cc < nch ? seamR[((int64_t)(b * (int64_t)nch + cc) * (ov - 1) + s) * hop + r] : T(0);
-    const T left = cc > 0 ? seamL[((int64_t)(b * (int64_t)nch + cc - 1) * (ov - 1) + s) * hop + r] : T(0);
+    const T right = cc < nch ? seamR[(int64_t)(b * (int64_t)nch + cc) * keep + r] : T(0);
+    const T left = cc > 0 ? seamL[(int64_t)(b * (int64_t)nch + cc - 1) * keep + r] : T(0);
     x_out[(int64_t)b * length + n] = (left + right) / env[n];
   }
 }
@@ -585,7 +646,7 @@ struct Launch {
 template <typename T, int LOGM, int OV>
 constexpr bool ola_fits() {
   using G = Geo<T, LOGM>;
-  return OV == 0 || ((SPECINV_WAVE_OLA_ALL || !(sizeof(T) == 8 && (1 << LOGM) / G::LG >= 16)) && (G::NPASS == 4 ? G::R3 : G::NPASS == 3 ? G::R2 : G::R1) % OV == 0);
+  return OV <= 1 || ((SPECINV_WAVE_OLA_ALL || !(sizeof(T) == 8 && (1 << LOGM) / G::LG >= 16)) && (G::NPASS == 4 ? G::R3 : G::NPASS == 3 ? G::R2 : G::R1) % OV == 0);
 }
 
 template <typename T, int LOGM, int OV>
@@ -600,17 +661,20 @@ const void* kernel_ov(int mode) {            // mode: bit 0 ADMM, bit 2 evaluati
     }
   }
 }
+template <typename T, int LOGM, int OV>
+const void* kernel_two(int mode) {           // two-sided: frames form (OV 0) or the ring (OV 1)
+  switch (mode & 5) {
+    case 0: return (const void*)k_wave_iter<T, LOGM, 0, true, false, OV>;
+    case 1: return (const void*)k_wave_iter<T, LOGM, 1, true, false, OV>;
+    case 4: return (const void*)k_wave_iter<T, LOGM, 0, true, true, OV>;
+    default: return (const void*)k_wave_iter<T, LOGM, 1, true, true, OV>;
+  }
+}
 template <typename T, int LOGM>
 const void* kernel_of(int mode, int ov) {    // mode: bit 0 ADMM, bit 1 two-sided, bit 2 evaluating
-  if (mode & 2) {
-    switch (mode & 5) {
-      case 0: return (const void*)k_wave_iter<T, LOGM, 0, true, false, 0>;
-      case 1: return (const void*)k_wave_iter<T, LOGM, 1, true, false, 0>;
-      case 4: return (const void*)k_wave_iter<T, LOGM, 0, true, true, 0>;
-      default: return (const void*)k_wave_iter<T, LOGM, 1, true, true, 0>;
-    }
-  }
+  if (mode & 2) return ov == 1 ? kernel_two<T, LOGM, 1>(mode) : kernel_two<T, LOGM, 0>(mode);
   switch (ov) {
+    case 1: return kernel_ov<T, LOGM, 1>(mode);
     case 2: return kernel_ov<T, LOGM, 2>(mode);
     case 4: return kernel_ov<T, LOGM, 4>(mode);
     case 8: return kernel_ov<T, LOGM, 8>(mode);
@@ -626,10 +690,14 @@ Launch shape(int64_t work, int mode, int ov) {
   static int n_cu = 0;
   // workgroups of four or eight waves (each carries its own twiddle table), whichever puts more waves on a CU by the runtime's
   // own count of resident workgroups (registers and LDS); one launch fills the chip once and every wave walks its share of frames
-  static int wpw_of[32] = {}, per_cu_of[32] = {};
-  const int key = (mode & 7) | (ov == 2 ? 8 : ov == 4 ? 16 : ov == 8 ? 24 : 0);
-  // (a team - a frame on the lanes of TEAM waves - is a workgroup of its own: `w` counts its one frame)
-  auto lds_of = [&](int w) { return sizeof(cplx<T>) * ((size_t)Tabs<T, LOGM>::TOTAL + (size_t)(TEAM > 1 ? 1 : w) * FPW * MP); };
+  static int wpw_of[64] = {}, per_cu_of[64] = {};
+  const int key = (mode & 7) | (ov == 2 ? 8 : ov == 4 ? 16 : ov == 8 ? 24 : 0) | (ov == 1 ? 32 : 0);
+  // (a team - a frame on the lanes of TEAM waves - is a workgroup of its own: `w` counts its one frame;
+  // + the ring of n_fft samples per lane group where the overlap-add runs in LDS)
+  auto lds_of = [&](int w) {
+    const size_t groups_wg = (size_t)(TEAM > 1 ? 1 : w) * FPW;
+    return sizeof(cplx<T>) * ((size_t)Tabs<T, LOGM>::TOTAL + groups_wg * MP) + (ov == 1 ? groups_wg * 2 * M * sizeof(T) : 0);
+  };
   const void* fn = kernel_of<T, LOGM>(mode, ov);
   static std::mutex mu;                                  // (plans of several host threads may ask at once)
   std::lock_guard<std::mutex> lock(mu);
@@ -671,16 +739,21 @@ Launch shape(int64_t work, int mode, int ov) {
 }
 
 // chunks per item of the register overlap-add: enough units to fill the chip once, chunks of at least max(2 OV, 8) frames
+// does the register overlap-add apply to hop = n_fft / ov here?
 template <typename T, int LOGM>
-int ola_chunks(int ov, int n_frames, int batch) {
+bool ola_registers(int ov) {
+  return ov == 2 ? ola_fits<T, LOGM, 2>() : ov == 4 ? ola_fits<T, LOGM, 4>() : ov == 8 ? ola_fits<T, LOGM, 8>() : false;
+}
+// `ov`: 2 / 4 / 8 registers, 1 the ring (frames_over = ceil(n_fft / hop) frames cover a sample)
+template <typename T, int LOGM>
+int ola_chunks(int ov, int frames_over, int n_frames, int batch, int mode) {
   if (!wave_iter_fits(2 << LOGM, n_frames, batch, true)) return 0;
-  const bool fits = ov == 2 ? ola_fits<T, LOGM, 2>() : ov == 4 ? ola_fits<T, LOGM, 4>() : ov == 8 ? ola_fits<T, LOGM, 8>() : false;
-  if (!fits || n_frames < 2 * ov) return 0;
+  const int min_len = std::max(2 * frames_over, 8);
+  if (n_frames < min_len) return 0;
   if (const char* e = getenv("SPECINV_WAVE_OLA")) {
     if (e[0] == '0') return 0;
   }
-  const Launch l = shape<T, LOGM>(1, 0, ov);
-  const int min_len = std::max(2 * ov, 8);
+  const Launch l = shape<T, LOGM>(1, mode, ov);
   int nch = (int)std::max<int64_t>(1, (int64_t)l.capacity / std::max(1, batch));
   if (const char* e = getenv("SPECINV_WAVE_CHUNK")) nch = std::max(1, n_frames / std::max(1, atoi(e)));
   return std::max(1, std::min(nch, n_frames / min_len));
@@ -691,8 +764,8 @@ int launch_one(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_out) {
   const int mode = (a.mode & 1) | (a.c.onesided ? 0 : 2) | (a.eval ? 4 : 0);
   const int ov = a.nch > 0 ? a.ov : 0;
   const void* fn = kernel_of<T, LOGM>(mode, ov);
-  SI_CHECK(fn != nullptr && (ov == 0 || (a.x_out && a.env && a.seamL && a.seamR && a.x_out != a.x)), SPECINV_EINVAL,
-           "k_wave_iter: bad overlap-add arguments");
+  SI_CHECK(fn != nullptr && (ov == 0 || (a.x_out && a.env && a.seamL && a.seamR && a.x_out != a.x)) && (ov != 1 || a.c.hop < a.c.n_fft),
+           SPECINV_EINVAL, "k_wave_iter: bad overlap-add arguments");
   // (frames are indexed with 32 bits; the lane groups of a wave address their rows relative to the first group's, with the register
   // overlap-add up to a chunk apart - the plan keeps such shapes on the frames form / the workgroup kernels: wave_iter_fits)
   SI_CHECK(wave_iter_fits(a.c.n_fft, a.c.n_frames, a.batch, ov > 0), SPECINV_EUNSUPPORTED, "k_wave_iter: too many frames for 32-bit frame offsets");
@@ -702,9 +775,10 @@ int launch_one(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_out) {
   void* kargs[] = {&args};
   SI_HIP(hipLaunchKernel(fn, dim3(l.wgs), dim3(64 * l.waves_per_wg), kargs, l.lds, stream));
   if (ov > 0) {
-    const int64_t total = (int64_t)a.batch * (a.nch + 1) * (ov - 1) * a.c.hop;
+    const int keep = ov == 1 ? a.c.n_fft - a.c.hop : (ov - 1) * a.c.hop;
+    const int64_t total = (int64_t)a.batch * (a.nch + 1) * keep;
     hipLaunchKernelGGL((k_wave_seams<T>), dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, stream,
-                       (const T*)a.seamL, (const T*)a.seamR, a.env, a.x_out, a.c.n_frames, a.nch, ov, a.c.hop, a.c.pad, a.c.length, a.batch);
+                       (const T*)a.seamL, (const T*)a.seamR, a.env, a.x_out, a.c.n_frames, a.nch, keep, a.c.hop, a.c.pad, a.c.length, a.batch);
     SI_HIP(hipGetLastError());
   }
   return SPECINV_OK;

@@ -304,7 +304,11 @@ struct PlanT final : PlanBase {
       // 256 / 64 0.455 -> 0.295 (hop = n_fft / 2, / 4, / 8: overlap-add in registers; other hops -8 ... -25 % on frames + k_ola).
       // A two-sided frame updates four bins per conjugate pair (their state requested together): 512 / 300 / 100 two-sided float64
       // 0.971 -> 0.767, float32 0.536 -> 0.466 (float32 at n_fft >= 512 normally runs k_semi2 / k_hop2, faster still).
-      const bool wins = sizeof(T) == 8 || n <= 256;
+      // With the overlap-add inside the kernel (registers or the LDS ring: every hop < n_fft, two-sided too) it is ahead of
+      // k_iter_pair at float32 512 ... 2048 as well - two-sided 512 / 300 / 100 0.560 -> 0.414, 2048 / 512 0.521 -> 0.417, one-sided
+      // 1024 / 800 / 200 0.448 -> 0.260, ADMM 2048 / 1200 / 300 0.470 -> 0.400; its frames + k_ola form is not (ADMM 2048: 0.518).
+      const bool wins = sizeof(T) == 8 || n <= 256 ||
+                        (wave_iter_covers(n) && wave_iter_ola_chunks<T>(n, cfg.hop_length, cfg.n_frames, cfg.batch, cfg.onesided != 0) > 0);
       use_wave = !big && wave_iter_covers(n) && wave_iter_fits(n, cfg.n_frames, cfg.batch, false) && !(we && we[0] == '0') &&
                  (wins || (we && we[0] == '1'));
     }
@@ -740,10 +744,11 @@ struct PlanT final : PlanBase {
           wa.eval = ev ? 1 : 0;
           // hop = n_fft / 2, / 4, / 8: the overlap-add in the kernel's registers - no frames buffer, the new signal written to the
           // plan's other signal buffer (the frames of an iteration read the old one), the chunk boundaries finished by k_wave_seams
-          const int nch = wave_iter_ola_chunks<T>(N(), cfg.hop_length, Tn(), B(), cfg.onesided != 0);
+          int ov = 0;
+          const int nch = wave_iter_ola_chunks<T>(N(), cfg.hop_length, Tn(), B(), cfg.onesided != 0, &ov);
           if (nch > 0) {
-            const int ov = N() / cfg.hop_length;
-            const size_t seam_bytes = (size_t)B() * nch * (ov - 1) * cfg.hop_length * sizeof(T);
+            const size_t keep = ov == 1 ? (size_t)(N() - cfg.hop_length) : (size_t)(ov - 1) * cfg.hop_length;
+            const size_t seam_bytes = (size_t)B() * nch * keep * sizeof(T);
             SI_TRY(x_alt.reserve((size_t)B() * length * sizeof(T)));
             SI_TRY(seam_l.reserve(seam_bytes));
             SI_TRY(seam_r.reserve(seam_bytes));

@@ -8,7 +8,7 @@ bool wave_iter_covers(int n_fft) { return n_fft == 128 || n_fft == 256 || n_fft 
 
 template int wave_iter_waves<float>(int, int64_t, int*);
 template int wave_iter_launch<float>(const WaveIterArgs<float>&, hipStream_t, int*);
-template int wave_iter_ola_chunks<float>(int, int, int, int, bool);
+template int wave_iter_ola_chunks<float>(int, int, int, int, bool, int*);
 template void wave_iter_geometry<float>(int, int, int, int, bool, int*);
 
 }  // namespace specinv

@@ -6,7 +6,7 @@ namespace specinv {
 
 template int wave_iter_waves<double>(int, int64_t, int*);
 template int wave_iter_launch<double>(const WaveIterArgs<double>&, hipStream_t, int*);
-template int wave_iter_ola_chunks<double>(int, int, int, int, bool);
+template int wave_iter_ola_chunks<double>(int, int, int, int, bool, int*);
 template void wave_iter_geometry<double>(int, int, int, int, bool, int*);
 
 }  // namespace specinv

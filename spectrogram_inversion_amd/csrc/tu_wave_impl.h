@@ -48,24 +48,39 @@ int wave_iter_launch(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_ou
 }
 
 template <typename T>
-int wave_iter_ola_chunks(int n_fft, int hop, int n_frames, int batch, bool onesided) {
-  if (!onesided || hop <= 0 || n_fft % hop != 0) return 0;
-  const int ov = n_fft / hop;
-  if (ov != 2 && ov != 4 && ov != 8) return 0;
+int wave_iter_ola_chunks(int n_fft, int hop, int n_frames, int batch, bool onesided, int* ov_out) {
+  if (ov_out) *ov_out = 0;
+  if (hop <= 0 || hop >= n_fft) return 0;
+  // registers where hop = n_fft / 2, / 4, / 8 of a one-sided spectrogram and the partial sums fit; the LDS ring for every other hop
+  // below n_fft and for two-sided spectrograms (SPECINV_WAVE_RING=0: frames + k_ola there)
+  auto pick = [&](auto tag) -> int {
+    constexpr int LOGM = decltype(tag)::value;
+    const int ovd = n_fft % hop == 0 ? n_fft / hop : 0;
+    int ov = onesided && wave::ola_registers<T, LOGM>(ovd) ? ovd : 1;
+    if (ov == 1) {
+      if (const char* e = getenv("SPECINV_WAVE_RING")) {
+        if (e[0] == '0') return 0;
+      }
+    }
+    const int nch = wave::ola_chunks<T, LOGM>(ov, (n_fft + hop - 1) / hop, n_frames, batch, onesided ? 0 : 2);
+    if (nch > 0 && ov_out) *ov_out = ov;
+    return nch;
+  };
   switch (n_fft) {
-    case 128: return wave::ola_chunks<T, 6>(ov, n_frames, batch);
-    case 256: return wave::ola_chunks<T, 7>(ov, n_frames, batch);
-    case 512: return wave::ola_chunks<T, 8>(ov, n_frames, batch);
-    case 1024: return wave::ola_chunks<T, 9>(ov, n_frames, batch);
-    case 2048: return wave::ola_chunks<T, 10>(ov, n_frames, batch);
+    case 128: return pick(std::integral_constant<int, 6>{});
+    case 256: return pick(std::integral_constant<int, 7>{});
+    case 512: return pick(std::integral_constant<int, 8>{});
+    case 1024: return pick(std::integral_constant<int, 9>{});
+    case 2048: return pick(std::integral_constant<int, 10>{});
     default: return 0;
   }
 }
 
 template <typename T>
 void wave_iter_geometry(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[3]) {
-  const int nch = wave_iter_ola_chunks<T>(n_fft, hop, n_frames, batch, onesided);
-  const int ov = nch > 0 ? n_fft / hop : 0, mode = onesided ? 0 : 2;
+  int ov = 0;
+  const int nch = wave_iter_ola_chunks<T>(n_fft, hop, n_frames, batch, onesided, &ov);
+  const int mode = onesided ? 0 : 2;
   const int64_t work = nch > 0 ? (int64_t)batch * nch : (int64_t)batch * n_frames;
   wave::Launch l{};
   switch (n_fft) {

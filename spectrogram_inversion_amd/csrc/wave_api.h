@@ -22,9 +22,9 @@ struct WaveIterArgs {
   // x_out (another buffer than x: other waves still read x), the blocks at chunk boundaries through seamL / seamR and k_wave_seams
   T* x_out = nullptr;
   const T* env = nullptr;   // (length) window-square envelope
-  T* seamL = nullptr;       // [batch * nch][ov - 1][hop] each
+  T* seamL = nullptr;       // [batch * nch][keep] each, keep = (ov - 1) hop (registers) or n_fft - hop (ring)
   T* seamR = nullptr;
-  int nch = 0, ov = 0;      // chunks of frames per item; n_fft / hop (0: frames buffer + k_ola)
+  int nch = 0, ov = 0;      // chunks of frames per item; wave_iter_ola_chunks' ov_out (0: frames buffer + k_ola)
 };
 
 // n_fft the kernel covers (a power of two, 128 ... 2048)
@@ -44,8 +44,9 @@ int wave_iter_launch(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_ou
 // Chunks of frames per item for the register overlap-add, 0 where it does not apply (hop is not n_fft / 2, / 4, / 8; a two-sided
 // spectrogram; a float64 frame of 16 points per lane, whose partial sums would not fit the registers; fewer than 2 OV frames).
 // wave_iter_launch with nch > 0 also runs k_wave_seams.
+// `ov_out`: how - 2 / 4 / 8 = n_fft / hop, the partial sums in registers; 1: in an LDS ring (any other hop < n_fft, two-sided)
 template <typename T>
-int wave_iter_ola_chunks(int n_fft, int hop, int n_frames, int batch, bool onesided);
+int wave_iter_ola_chunks(int n_fft, int hop, int n_frames, int batch, bool onesided, int* ov_out = nullptr);
 // diagnostics (specinv_plan_launch_geometry): out = {waves per workgroup, chunks of frames per item (register overlap-add) or the
 // frame count, waves of a plain launch}
 template <typename T>

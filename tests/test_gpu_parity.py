@@ -213,15 +213,16 @@ def test_exact_projection_switch_of_the_drop_in_functions(monkeypatch):
     assert rel_l2(exact_admm, ref) < 1e-5 and rel_l2(approx_admm, ref) < 1e-5
 
 
-@pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "frame_lds_prespec", "generic", "float64", "float64_workgroup"])
+@pytest.mark.parametrize("path", ["default", "fused", "fused_prespec", "frame_lds", "frame_lds_prespec", "generic", "generic_workgroup", "float64",
+                                  "float64_workgroup"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
     """g14 (consistent magnitudes of a real signal, true phase perturbed by 0.5 rad): 100 iterations held to the STRICT
     gate min(1e-4, 6 x the reference's float32-vs-float64 noise) - no segment statistics - on every kernel path: the
     frame kernel (default for a problem this small), the fused chunk-walking kernel with the momentum carried as a signal
     (`k_fused_td<4, 4>`) and on pre_spec itself (`k_fused<4, 4>`), the chunked frame kernel with the overlap-add in LDS, the
-    generic kernels, and float64 (the wave-level coverage kernel `k_wave_iter` since round 6, and the workgroup-level kernel it
-    replaced).  (g2's random magnitudes are inconsistent: there a near-zero
+    generic kernels (the wave-level coverage kernel `k_wave_iter` with the overlap-add in its registers since round 6, and the
+    workgroup-level kernel it replaced), and the same two in float64.  (g2's random magnitudes are inconsistent: there a near-zero
     bin can decorrelate a neighbourhood between ANY two float32 runs, see test_gla_waveforms.)"""
     from spectrogram_inversion_amd.plan import Plan, clear_plan_cache
     g = load_golden("g14_wellcond")
@@ -236,13 +237,13 @@ def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
         monkeypatch.setenv("SPECINV_DISABLE_FUSED", "1")
     if path.startswith("float64"):
         init, w = init.to(torch.complex128), w.double()
-    if path == "float64_workgroup":
+    if path.endswith("_workgroup"):
         monkeypatch.setenv("SPECINV_GENERIC_WAVE", "0")
     p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], w.dtype, dev())
-    if path == "generic":
+    if path.startswith("generic"):
         p.force_generic(True)
     want = {"default": "k_semi", "fused": "k_fused_td", "fused_prespec": "k_fused", "frame_lds": "k_hop_td", "frame_lds_prespec": "k_hop",
-            "generic": "k_iter_pair", "float64": "k_wave_iter", "float64_workgroup": "k_iter_pair"}[path]
+            "generic": "k_wave_iter", "generic_workgroup": "k_iter_pair", "float64": "k_wave_iter", "float64_workgroup": "k_iter_pair"}[path]
     p.keep_state(path.endswith("_prespec"))
     p.gla_init(init, None, alpha)
     assert p.launch_geometry["kernel"] == want, p.launch_geometry
@@ -254,7 +255,7 @@ def test_gla_wellconditioned_100_iterations(alpha, path, monkeypatch):
         assert rel_l2(y, ref) < gate, (path, rel_l2(y, ref), rel_l2(y, ref64), noise)
 
 
-@pytest.mark.parametrize("kernel", ["k_fused4_td", "k_fused4", "k_fused", "k_hop_td", "k_hop", "k_iter_pair"])
+@pytest.mark.parametrize("kernel", ["k_fused4_td", "k_fused4", "k_fused", "k_hop_td", "k_hop", "k_iter_pair", "k_wave_iter"])
 @pytest.mark.parametrize("alpha", [0.0, 0.3, 0.99])
 def test_gla_wellconditioned_hop_quarter_100_iterations(alpha, kernel, monkeypatch):
     """g15 (g14's construction at n_fft 1024 / hop 256, the shape class of the headline): 100 iterations of the reference in
@@ -274,8 +275,10 @@ def test_gla_wellconditioned_hop_quarter_100_iterations(alpha, kernel, monkeypat
         monkeypatch.setenv("SPECINV_FUSED_TEMPLATE", "1")
     if kernel in ("k_hop", "k_hop_td"):
         monkeypatch.setenv("SPECINV_DISABLE_FUSED", "1")
-    p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], w.dtype, dev())
     if kernel == "k_iter_pair":
+        monkeypatch.setenv("SPECINV_GENERIC_WAVE", "0")      # (the wave-level kernel serves forced-generic plans since round 6)
+    p = Plan(args_helper(init, hop_length=hop, window=w), init.shape[0], init.shape[2], w.dtype, dev())
+    if kernel in ("k_iter_pair", "k_wave_iter"):
         p.force_generic(True)
     p.keep_state(kernel not in ("k_fused4_td", "k_hop_td"))
     p.gla_init(init, None, alpha)

@@ -205,6 +205,68 @@ def test_register_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, 
             np.testing.assert_allclose(a[2], b[2], rtol=1e-5 if dtype == np.float32 else 1e-12)
 
 
+@pytest.mark.parametrize("dtype,n_fft,hop,frames,batch,extra", [
+    (np.float32, 128, 50, 90, 5, dict(win_length=100)), (np.float32, 256, 77, 120, 3, dict(pad_mode="circular", normalized=True)),
+    (np.float64, 512, 100, 130, 3, dict(onesided=False, win_length=300)), (np.float32, 512, 300, 60, 4, dict(win_length=400)),
+    (np.float64, 2048, 333, 70, 2, dict(center=False)), (np.float32, 1024, 256, 80, 3, dict(onesided=False)),
+    (np.float64, 256, 255, 50, 2, {}), (np.float32, 128, 5, 700, 2, dict(pad_mode="constant")),
+    (np.float32, 2048, 512, 48, 3, dict(onesided=False, pad_mode="replicate")), (np.float64, 1024, 200, 75, 2, dict(win_length=800)),
+    (np.float64, 128, 32, 100, 3, dict(onesided=False)),
+])
+def test_ring_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, hop, frames, batch, extra):
+    """Every other hop below n_fft (odd ones, hops above n_fft / 2, one sample short of n_fft) and two-sided spectrograms: the same
+    chunk walk with the overlap-add in an LDS ring of n_fft samples per lane group (kernels_wave.h, OV == 1) - a frame's samples
+    added at (t hop + s) mod n_fft, its first hop samples complete, divided by the envelope and stored (methods.py:127-132); the
+    n_fft - hop samples either side of a chunk boundary go through k_wave_seams.  Against the frames + k_ola form of the same
+    kernel after one iteration (same order of summation: equal but at the boundaries and where a multiply-add contracts
+    differently), and against the oracle after five iterations of Griffin-Lim and ADMM.
+    SPECINV_WAVE_CHUNK pins short chunks so that every shape has several boundaries per item."""
+    onesided = extra.get("onesided", True)
+    rng = np.random.default_rng(n_fft + hop)
+    wl = extra.get("win_length", n_fft)
+    w = hann(wl, dtype)
+    F = n_fft // 2 + 1 if onesided else n_fft
+    mag = (rng.random((batch, F, frames)) + 0.05).astype(dtype)
+    cd = np.complex64 if dtype == np.float32 else np.complex128
+    init = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(cd)
+    kw = dict(hop_length=hop, **extra)
+    over = -(-n_fft // hop)
+    monkeypatch.setenv("SPECINV_WAVE_CHUNK", str(max(2 * over, 9)))
+    for method, arg in (("griffin_lim", 0.5), ("admm", 1.0)):
+        res = {}
+        for arm in ("ring", "frames"):
+            monkeypatch.setenv("SPECINV_WAVE_OLA", "1" if arm == "ring" else "0")
+            p = _plan(init, frames, dtype, True, monkeypatch, window=w, **kw)
+            (p.gla_init if method == "griffin_lim" else p.admm_init)(T(init), None, arg)
+            geo = p.launch_geometry
+            assert geo["kernel"] == "k_wave_iter" and (geo["chunks"] < frames) == (arm == "ring"), (arm, geo)
+            p.iterate(1)
+            y1 = N(p.wave())
+            p.iterate(3)
+            sums = p.iterate(1, eval_last=True)
+            res[arm] = (y1, N(p.wave()), np.array(sums[:2]), geo["chunks"])
+        a, b = res["ring"], res["frames"]
+        fin = np.isfinite(b[0])
+        assert np.array_equal(np.isfinite(a[0]), fin)
+        same = (a[0] == b[0]) | ~fin
+        nch = a[3]
+        assert nch >= 3
+        seam_share = (nch + 1) * (n_fft - hop) / a[0].shape[1]
+        assert 1.0 - same.mean() <= 0.5 * seam_share + 0.1, (1.0 - same.mean(), seam_share)   # mostly at the chunk boundaries
+        eps = np.finfo(dtype).eps
+        assert np.abs(a[0][fin] - b[0][fin]).max() <= 8 * eps * np.abs(b[0][fin]).max()
+        with np.errstate(all="ignore"):
+            ref64 = getattr(oracle, method)(init.astype(np.complex128), tol=0, window=hann(wl, np.float64), max_iter=5,
+                                            **({"alpha": arg} if method == "griffin_lim" else {"rho": arg}), **kw)
+            ref = getattr(oracle, method)(init, tol=0, window=w, max_iter=5, **({"alpha": arg} if method == "griffin_lim" else {"rho": arg}), **kw)
+        f5 = np.isfinite(ref64)
+        e0 = rel_l2(ref[f5], ref64[f5])
+        tol = 2e-5 if dtype == np.float32 else 1e-10
+        assert np.array_equal(np.isfinite(a[1]), f5) and rel_l2(a[1][f5], ref64[f5]) < max(3 * e0, 5 * tol)
+        if np.isfinite(b[2]).all():
+            np.testing.assert_allclose(a[2], b[2], rtol=1e-5 if dtype == np.float32 else 1e-12)
+
+
 @pytest.mark.parametrize("batch,frames", [(24, 400), (64, 1024)])
 def test_float64_2048_on_a_two_wave_team_at_full_occupancy(monkeypatch, batch, frames):
     """float64 at n_fft 2048 runs a frame on the 128 lanes of a two-wave workgroup (eight points per lane: room for the register

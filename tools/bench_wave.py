@@ -86,6 +86,13 @@ CASES = [  # n_fft, win_length, hop, frames, batch, dtype, onesided, method
     (512, 300, 100, 2048, 64, torch.float32, False, "gla"),
     (1024, None, 256, 2048, 32, torch.float32, True, "gla"),
     (2048, None, 512, 1024, 32, torch.float32, False, "gla"),
+    (512, 300, 100, 2048, 64, torch.float32, True, "gla"),      # 12 ...: hops that do not divide n_fft (the LDS ring)
+    (512, 300, 100, 2048, 64, torch.float64, True, "gla"),
+    (1024, 800, 200, 2048, 32, torch.float32, True, "gla"),
+    (2048, 1200, 300, 1024, 32, torch.float32, True, "admm"),
+    (256, 200, 50, 4096, 64, torch.float32, True, "gla"),
+    (1024, 800, 200, 2048, 16, torch.float64, True, "gla"),
+    (256, 200, 50, 4096, 64, torch.float64, True, "gla"),
 ]
 
 
