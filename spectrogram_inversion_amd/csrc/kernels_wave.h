@@ -58,8 +58,28 @@ template <>
 struct GeoF<10> {    // n_fft 2048: 16 x 8 x 8
   static constexpr int LG = 64, NPASS = 3, R0 = 16, R1 = 8, R2 = 8, R3 = 1;
 };
+// The sizes people use that are not 128 2^k - n_fft 400 / 800 / 1000 (25 / 50 / 62.5 ms at 16 kHz; torchaudio's default is 400) - by
+// M itself: passes of radix 10 butterflies (2 x 5 in registers) and a short last one; ten points per lane at 400 / 1000 (three
+// frames / one frame per wave on 60 / 50 of its lanes), twenty at 800 (three frames per wave).  (First cuts: radix 8 / 5 / 5 passes
+// on 16 / 32 lanes without an overlap-add in the kernel - not ahead of the workgroup kernels, tools/log/EXPERIMENTS.md r06-q; two
+// passes of radix 10 / 20 with twenty points per lane everywhere - 95 ... 540 registers spilled at 256.)
+template <>
+struct GeoF<200> {   // n_fft 400:  10 x 10 x 2
+  static constexpr int LG = 20, NPASS = 3, R0 = 10, R1 = 10, R2 = 2, R3 = 1;
+};
+template <>
+struct GeoF<400> {   // n_fft 800:  10 x 10 x 2 x 2
+  static constexpr int LG = 40, NPASS = 4, R0 = 10, R1 = 10, R2 = 2, R3 = 2;
+};
+template <>
+struct GeoF<500> {   // n_fft 1000: 10 x 10 x 5
+  static constexpr int LG = 50, NPASS = 3, R0 = 10, R1 = 10, R2 = 5, R3 = 1;
+};
 template <typename T, int LOGM>
 struct Geo : GeoF<LOGM> {};
+// `LOGM` names a size: log2 M for the powers of two, M itself (>= 100) for the others
+template <int LOGM>
+constexpr int m_of() { return LOGM >= 100 ? LOGM : 1 << LOGM; }
 // float64 at n_fft 512: FOUR points per lane on a whole wave, four radix-4 passes (sixteen points per lane on sixteen lanes: the
 // partial sums of the register overlap-add were spilled, slower than frames + k_ola; eight on thirty-two: 0.253 ms at 512 / 128;
 // four on sixty-four: 0.206 - wider groups load longer pieces and leave the registers to the loads in flight)
@@ -78,8 +98,8 @@ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
 // LDS position of point p of a frame: one element of slack after every R0 - the first pass writes point j R0 + i from lane j, a
 // stride of R0 elements that would put every lane of a store on the same banks
-template <int PS>
-__device__ __host__ __forceinline__ constexpr int phys(int p) { return p + (p >> PS); }
+template <int R0>
+__device__ __host__ __forceinline__ constexpr int phys(int p) { return p + p / R0; }
 
 template <typename T, bool INV>
 __device__ __forceinline__ void bf16(cplx<T> (&a)[16]) {
@@ -110,9 +130,70 @@ __device__ __forceinline__ void bf16(cplx<T> (&a)[16]) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) a[i] = o[i];
 }
+template <typename T, bool INV>
+__device__ __forceinline__ void bf5(cplx<T>& v0, cplx<T>& v1, cplx<T>& v2, cplx<T>& v3, cplx<T>& v4) {
+  const T c1 = T(0.30901699437494742410), c2 = T(-0.80901699437494742410), s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);
+  const cplx<T> t1 = v1 + v4, t2 = v2 + v3, t3 = v1 - v4, t4 = v2 - v3;
+  const cplx<T> m1 = mk<T>(v0.x + c1 * t1.x + c2 * t2.x, v0.y + c1 * t1.y + c2 * t2.y);
+  const cplx<T> m2 = mk<T>(v0.x + c2 * t1.x + c1 * t2.x, v0.y + c2 * t1.y + c1 * t2.y);
+  const cplx<T> r1 = rot_mi<T, INV>(mk<T>(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));   // -i (s1 t3 + s2 t4), +i for the inverse
+  const cplx<T> r2 = rot_mi<T, INV>(mk<T>(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+  v0 = v0 + t1 + t2;
+  v1 = m1 + r1;
+  v4 = m1 - r1;
+  v2 = m2 + r2;
+  v3 = m2 - r2;
+}
+// W_20^e = kW20C[e] - i kW20S[e]
+__device__ constexpr double kW20C[20] = {1.0, 0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917, 0.30901699437494742410, 0.0,
+                                         -0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410, -0.95105651629515357212, -1.0,
+                                         -0.95105651629515357212, -0.80901699437494742410, -0.58778525229247312917, -0.30901699437494742410, 0.0,
+                                         0.30901699437494742410, 0.58778525229247312917, 0.80901699437494742410, 0.95105651629515357212};
+__device__ constexpr double kW20S[20] = {0.0, 0.30901699437494742410, 0.58778525229247312917, 0.80901699437494742410, 0.95105651629515357212, 1.0,
+                                         0.95105651629515357212, 0.80901699437494742410, 0.58778525229247312917, 0.30901699437494742410, 0.0,
+                                         -0.30901699437494742410, -0.58778525229247312917, -0.80901699437494742410, -0.95105651629515357212, -1.0,
+                                         -0.95105651629515357212, -0.80901699437494742410, -0.58778525229247312917, -0.30901699437494742410};
+// R = RA RB points in registers: n = RB n1 + n2; DFT_RA over n1 for every n2 (slot RB k1 + n2), twiddle W_R^(n2 k1), DFT_RB over n2
+// for every k1, output X[k1 + RA k2]
+template <typename T, int RA, int RB, bool INV>
+__device__ __forceinline__ void bf_comp(cplx<T> (&a)[RA * RB]) {
+  constexpr int R = RA * RB;
+  static_assert(20 % R == 0 && (RA == 2 || RA == 4) && RB == 5, "2 x 5 and 4 x 5");
+#pragma unroll
+  for (int n2 = 0; n2 < RB; ++n2) {
+    if constexpr (RA == 2) {
+      const cplx<T> u = a[n2], w = a[RB + n2];
+      a[n2] = u + w;
+      a[RB + n2] = u - w;
+    } else {
+      bf4<T, INV>(a[n2], a[RB + n2], a[2 * RB + n2], a[3 * RB + n2]);
+    }
+  }
+#pragma unroll
+  for (int k1 = 1; k1 < RA; ++k1)
+#pragma unroll
+    for (int n2 = 1; n2 < RB; ++n2) {
+      const int e = (n2 * k1 * (20 / R)) % 20;
+      const T c = (T)kW20C[e], sn = (T)kW20S[e];
+      const cplx<T> v = a[RB * k1 + n2];
+      a[RB * k1 + n2] = INV ? mk<T>(v.x * c - v.y * sn, v.y * c + v.x * sn) : mk<T>(v.x * c + v.y * sn, v.y * c - v.x * sn);
+    }
+#pragma unroll
+  for (int k1 = 0; k1 < RA; ++k1) bf5<T, INV>(a[RB * k1], a[RB * k1 + 1], a[RB * k1 + 2], a[RB * k1 + 3], a[RB * k1 + 4]);
+  cplx<T> o[R];
+#pragma unroll
+  for (int k1 = 0; k1 < RA; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) o[k1 + RA * k2] = a[RB * k1 + k2];
+#pragma unroll
+  for (int i = 0; i < R; ++i) a[i] = o[i];
+}
 template <typename T, int R, bool INV>
 __device__ __forceinline__ void bfly(cplx<T> (&v)[R]) {
   if constexpr (R == 16) bf16<T, INV>(v);
+  else if constexpr (R == 5) bf5<T, INV>(v[0], v[1], v[2], v[3], v[4]);
+  else if constexpr (R == 10) bf_comp<T, 2, 5, INV>(v);
+  else if constexpr (R == 20) bf_comp<T, 4, 5, INV>(v);
   else Butterfly<T, R, INV>::run(v, nullptr, 0);
 }
 
@@ -132,7 +213,7 @@ struct Tabs {
   static constexpr int N1 = G::R0 * (G::R1 - 1);
   static constexpr int N2 = G::NPASS >= 3 ? G::R0 * G::R1 * (G::R2 - 1) : 0;
   static constexpr int N3 = G::NPASS == 4 ? G::R0 * G::R1 * G::R2 * (G::R3 - 1) : 0;
-  static constexpr int NPAIR = ((1 << LOGM) / 2) / G::LG;
+  static constexpr int NPAIR = (m_of<LOGM>() / 2) / G::LG;
   static constexpr int TOTAL = N1 + N2 + N3 + NPAIR;           // + W_N^(i LG), the real-FFT split's step between a lane's pairs
 };
 
@@ -148,10 +229,10 @@ __device__ __forceinline__ void wave_sync() {
   else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-template <typename T, int R, int LNS, bool INV, int LOGM, int LG, int PS>
+template <typename T, int R, int NS, bool INV, int LOGM, int LG, int PS>
 __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict__ tab, int gl) {
-  constexpr int M = 1 << LOGM, NB = M / R, PER = NB / LG, NS = 1 << LNS;
-  static_assert(PER >= 1, "a lane owns at least one butterfly of every pass");
+  constexpr int M = m_of<LOGM>(), NB = M / R, PER = NB / LG;
+  static_assert(PER >= 1 && NB % LG == 0, "a lane owns whole butterflies of every pass");
   cplx<T> v[PER][R];
 #pragma unroll
   for (int it = 0; it < PER; ++it) {
@@ -161,7 +242,7 @@ __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict
   }
 #pragma unroll
   for (int it = 0; it < PER; ++it) {
-    const int j = gl + it * LG, k = j & (NS - 1);
+    const int j = gl + it * LG, k = j % NS;
     if (NS > 1) {
 #pragma unroll
       for (int q = 1; q < R; ++q) v[it][q] = cmul(v[it][q], tw_get<T, INV>(tab, (q - 1) * NS + k));
@@ -171,8 +252,8 @@ __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict
   wave_sync<LG>();
 #pragma unroll
   for (int it = 0; it < PER; ++it) {
-    const int j = gl + it * LG, blk = j >> LNS, k = j & (NS - 1);
-    const int base = ((blk << LNS) * R) + k;
+    const int j = gl + it * LG, blk = j / NS, k = j % NS;
+    const int base = blk * NS * R + k;
 #pragma unroll
     for (int i = 0; i < R; ++i) buf[phys<PS>(base + i * NS)] = v[it][i];
   }
@@ -182,7 +263,7 @@ __device__ __forceinline__ void pass_lds(cplx<T>* buf, const cplx<T>* __restrict
 // registers: a float64 frame of 16 points per lane is 64 registers before the first butterfly - those instantiations may take 256
 // (two waves per SIMD, which is also what their 17 KB of LDS per wave allow); everything else is held to 128 (four per SIMD)
 template <typename T, int LOGM>
-constexpr int max_threads() { return (sizeof(T) == 8 && (1 << LOGM) / Geo<T, LOGM>::LG >= 16) ? 512 : 1024; }
+constexpr int max_threads() { return (sizeof(T) == 8 && m_of<LOGM>() / Geo<T, LOGM>::LG >= 16) ? 512 : 1024; }
 // ... and with the overlap-add in registers (partial sums, the frame's outputs, envelope and signal addresses on top): three waves
 // per SIMD, 168 registers (at 128 those instantiations spilled 33 - 187 registers and ran slower than frames + k_ola)
 // - and a two-sided frame's four bins per conjugate pair: two (float64) or three waves
@@ -195,14 +276,19 @@ constexpr int max_threads() { return (sizeof(T) == 8 && (1 << LOGM) / Geo<T, LOG
 #ifndef SPECINV_WAVE_RING_WPS32
 #define SPECINV_WAVE_RING_WPS32 3
 #endif
+// ... at n_fft 400 / 800 / 1000 (ten points per lane; 3 / 2 waves per SIMD: 1000 / 250 0.111 / 0.084 ms, ADMM 400 / 100 0.430 / 0.313,
+// 400 / 160 0.277 / 0.272, 800 / 200 0.329 / 0.336)
+#ifndef SPECINV_WAVE_RING_WPS32S
+#define SPECINV_WAVE_RING_WPS32S 2
+#endif
 template <typename T, int LOGM, int OV, bool TWO>
 constexpr int waves_per_simd() {
   if (Geo<T, LOGM>::LG > 64) return 2;            // (a team's workgroups: four to a CU by their LDS)
   // (the ring: a wave's frame buffers and rings are 16 KB of LDS where a lane carries 16 points - two waves per SIMD fit anyway)
-  if (OV == 1 && sizeof(T) == 4 && (1 << LOGM) / Geo<T, LOGM>::LG >= 16) return 2;
-  if (TWO) return sizeof(T) == 8 ? 2 : 3;
-  if (OV == 1) return sizeof(T) == 8 ? SPECINV_WAVE_RING_WPS64 : SPECINV_WAVE_RING_WPS32;
-  return max_threads<T, LOGM>() == 512 ? 2 : (OV > 1 ? (((1 << LOGM) / Geo<T, LOGM>::LG >= 16 || sizeof(T) == 8) ? 2 : 3) : 4);
+  if (OV == 1 && sizeof(T) == 4 && m_of<LOGM>() / Geo<T, LOGM>::LG >= 16) return 2;
+  if (TWO) return sizeof(T) == 8 || LOGM >= 100 ? 2 : 3;
+  if (OV == 1) return sizeof(T) == 8 ? SPECINV_WAVE_RING_WPS64 : (LOGM >= 100 ? SPECINV_WAVE_RING_WPS32S : SPECINV_WAVE_RING_WPS32);
+  return max_threads<T, LOGM>() == 512 ? 2 : (OV > 1 ? ((m_of<LOGM>() / Geo<T, LOGM>::LG >= 16 || sizeof(T) == 8) ? 2 : 3) : 4);
 }
 
 template <typename T, int LOGM, int MODE, bool TWO, bool EVAL, int OV>
@@ -210,12 +296,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 512), amdgpu_waves_per
 void k_wave_iter(WaveIterArgs<T> a) {
   using G = Geo<T, LOGM>;
   using C = cplx<T>;
-  constexpr int M = 1 << LOGM, N = 2 * M, LG = G::LG;
+  constexpr int M = m_of<LOGM>(), N = 2 * M, LG = G::LG;
   constexpr int TEAM = LG > 64 ? LG / 64 : 1;            // waves per frame (a team is a whole workgroup)
-  constexpr int FPW = LG > 64 ? 1 : 64 / LG;             // frames per wave (per workgroup for a team)
-  constexpr int PS = ilog2(G::R0);
+  constexpr int FPW = LG > 64 ? 1 : 64 / LG;             // frames per wave (per workgroup for a team); lanes >= FPW LG idle
+  constexpr int PS = G::R0;
   constexpr int MP = phys<PS>(M) + 1;                    // a frame's points in LDS
-  constexpr int LR0 = ilog2(G::R0), LR1 = ilog2(G::R1);
+  constexpr bool POW2 = (N & (N - 1)) == 0;
+  constexpr int NS1 = G::R0, NS2 = G::R0 * G::R1, NS3 = G::R0 * G::R1 * G::R2;   // block lengths before passes 1, 2, 3
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using TB = Tabs<T, LOGM>;
   C* tab1 = reinterpret_cast<C*>(smem);                  // pass tables, then W_N^(i LG)
@@ -227,18 +314,19 @@ void k_wave_iter(WaveIterArgs<T> a) {
   // compiler would carry a 64-bit address per access in vector registers)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const int g = TEAM > 1 ? 0 : lane / LG, gl = TEAM > 1 ? (int)threadIdx.x : lane % LG;
+  const bool lane_on = TEAM > 1 || lane < FPW * LG;
+  const int g = TEAM > 1 ? 0 : (lane_on ? lane / LG : 0), gl = TEAM > 1 ? (int)threadIdx.x : lane % LG;
   C* buf = tab1 + TB::TOTAL + (size_t)(TEAM > 1 ? 0 : wave * FPW + g) * MP;
   {
-    constexpr int NS1 = G::R0, SH1 = LOGM + 1 - LR0 - LR1;             // W_(NS R)^(k q) = W_N^((k q) N / (NS R))
-    for (int i = threadIdx.x; i < TB::N1; i += blockDim.x) tab1[i] = a.c.tw[((i & (NS1 - 1)) * (i / NS1 + 1)) << SH1];
+    constexpr int ST1 = N / (NS1 * G::R1);                             // W_(NS R)^(k q) = W_N^((k q) N / (NS R))
+    for (int i = threadIdx.x; i < TB::N1; i += blockDim.x) tab1[i] = a.c.tw[((i % NS1) * (i / NS1 + 1)) * ST1];
     if constexpr (G::NPASS >= 3) {
-      constexpr int NS2 = G::R0 * G::R1, SH2 = LOGM + 1 - LR0 - LR1 - ilog2(G::R2);
-      for (int i = threadIdx.x; i < TB::N2; i += blockDim.x) tab2[i] = a.c.tw[((i & (NS2 - 1)) * (i / NS2 + 1)) << SH2];
+      constexpr int ST2 = N / (NS2 * G::R2);
+      for (int i = threadIdx.x; i < TB::N2; i += blockDim.x) tab2[i] = a.c.tw[((i % NS2) * (i / NS2 + 1)) * ST2];
     }
     if constexpr (G::NPASS == 4) {
-      constexpr int NS3 = G::R0 * G::R1 * G::R2, SH3 = LOGM + 1 - LR0 - LR1 - ilog2(G::R2) - ilog2(G::R3);
-      for (int i = threadIdx.x; i < TB::N3; i += blockDim.x) tab3[i] = a.c.tw[((i & (NS3 - 1)) * (i / NS3 + 1)) << SH3];
+      constexpr int ST3 = N / (NS3 * G::R3);
+      for (int i = threadIdx.x; i < TB::N3; i += blockDim.x) tab3[i] = a.c.tw[((i % NS3) * (i / NS3 + 1)) * ST3];
     }
     for (int i = threadIdx.x; i < TB::NPAIR; i += blockDim.x) tabs[i] = a.c.tw[i * LG];
   }
@@ -281,7 +369,7 @@ void k_wave_iter(WaveIterArgs<T> a) {
   for (int64_t ur = w0; ur * FPW < units; ur += nw) {
     const int64_t u = ur * FPW + g;                 // this lane group's unit
     int fstart = 0, len = 0, ub = 0, ta = 0;
-    if (u < units) {
+    if (u < units && lane_on) {
       if (OV > 0) {
         ub = (int)(u / nch);
         const int cc = (int)(u - (int64_t)ub * nch);
@@ -369,9 +457,9 @@ void k_wave_iter(WaveIterArgs<T> a) {
       }
       wave_sync<LG>();
     }
-    pass_lds<T, G::R1, LR0, false, LOGM, LG, PS>(buf, tab1, gl);
-    if constexpr (G::NPASS >= 3) pass_lds<T, G::R2, LR0 + LR1, false, LOGM, LG, PS>(buf, tab2, gl);
-    if constexpr (G::NPASS == 4) pass_lds<T, G::R3, LR0 + LR1 + ilog2(G::R2), false, LOGM, LG, PS>(buf, tab3, gl);
+    pass_lds<T, G::R1, NS1, false, LOGM, LG, PS>(buf, tab1, gl);
+    if constexpr (G::NPASS >= 3) pass_lds<T, G::R2, NS2, false, LOGM, LG, PS>(buf, tab2, gl);
+    if constexpr (G::NPASS == 4) pass_lds<T, G::R3, NS3, false, LOGM, LG, PS>(buf, tab3, gl);
     // ---- the conjugate pairs (k, M - k): split, update, inverse split
     auto upd = [&](C r, int f) -> C {               // one bin of this frame
       C n0, n1;
@@ -386,7 +474,8 @@ void k_wave_iter(WaveIterArgs<T> a) {
       return mk<T>(T(0.5) * (y1.x + y2.x), T(0.5) * (y1.y - y2.y));
     };
     constexpr int NPAIR = (M / 2) / LG;             // k = gl + i LG < M / 2
-    constexpr int CH = sizeof(T) == 8 ? 2 : (NPAIR >= 4 ? 4 : NPAIR);   // pairs whose state is requested together
+    constexpr int CH = sizeof(T) == 8 ? (NPAIR % 2 == 0 ? 2 : 1) : (NPAIR % 4 == 0 ? 4 : NPAIR % 5 == 0 ? 5 : NPAIR % 2 == 0 ? 2 : 1);   // pairs whose state is requested together
+    static_assert(NPAIR % CH == 0 && (M / 2) % LG == 0, "whole chunks of pairs");
 #pragma unroll 1
     for (int i0 = 0; i0 < NPAIR; i0 += CH) {
       C za[CH], zb[CH], s0a[CH], s0b[CH], s1a[CH], s1b[CH];
@@ -480,11 +569,11 @@ void k_wave_iter(WaveIterArgs<T> a) {
     }
     // ---- synthesis: the passes again with conjugated twiddles, the last one straight to the frames buffer
     wave_sync<LG>();
-    pass_lds<T, G::R0, 0, true, LOGM, LG, PS>(buf, tab1, gl);
-    if constexpr (G::NPASS >= 3) pass_lds<T, G::R1, LR0, true, LOGM, LG, PS>(buf, tab1, gl);
-    if constexpr (G::NPASS == 4) pass_lds<T, G::R2, LR0 + LR1, true, LOGM, LG, PS>(buf, tab2, gl);
+    pass_lds<T, G::R0, 1, true, LOGM, LG, PS>(buf, tab1, gl);
+    if constexpr (G::NPASS >= 3) pass_lds<T, G::R1, NS1, true, LOGM, LG, PS>(buf, tab1, gl);
+    if constexpr (G::NPASS == 4) pass_lds<T, G::R2, NS2, true, LOGM, LG, PS>(buf, tab2, gl);
     {
-      constexpr int R = RL, LNS = LOGM - ilog2(R), NS = 1 << LNS, NB = M / R, PER = NB / LG;
+      constexpr int R = RL, NS = M / R, NB = M / R, PER = NB / LG;
       static_assert(NB == NS, "the last pass has one block");
       const C* tabl = G::NPASS == 4 ? tab3 : G::NPASS == 3 ? tab2 : tab1;
       C v[PER][R];
@@ -525,7 +614,7 @@ void k_wave_iter(WaveIterArgs<T> a) {
       } else if constexpr (OV == 1) {
         const int hop = c.hop, keep = N - hop;
         const int64_t a0 = (int64_t)t * hop;        // padded position of the frame's first sample (the chunk's: ta hop)
-        const int rb = (int)(a0 & (N - 1));
+        const int rb = POW2 ? (int)(a0 & (N - 1)) : (int)(a0 % N);
         const int64_t n0 = a0 - c.pad;              // ... its place in the signal; samples [lo, hi) of the frame are inside
         const int lo = (int)(n0 < 0 ? (-n0 < N ? -n0 : N) : 0), hi = (int)(c.length - n0 < N ? (c.length - n0 > 0 ? c.length - n0 : 0) : N);
         const int head = keep - s * hop;            // the previous chunk's last frames reach samples [0, head): k_wave_seams' part
@@ -547,7 +636,15 @@ void k_wave_iter(WaveIterArgs<T> a) {
         for (int it = 0; it < PER; ++it)
 #pragma unroll
           for (int i = 0; i < R; ++i) {
-            const int s0 = 2 * (gl + it * LG + i * NS), i0 = (rb + s0) & (N - 1), i1 = (rb + s0 + 1) & (N - 1);
+            const int s0 = 2 * (gl + it * LG + i * NS);
+            int i0 = rb + s0, i1 = rb + s0 + 1;
+            if constexpr (POW2) {
+              i0 &= N - 1;
+              i1 &= N - 1;
+            } else {
+              i0 -= i0 >= N ? N : 0;
+              i1 -= i1 >= N ? N : 0;
+            }
             if (even) {
               const C r = *reinterpret_cast<const C*>(ring + i0);
               *reinterpret_cast<C*>(ring + i0) = mk<T>(emit(s0, r.x + y[it][i].x), emit(s0 + 1, r.y + y[it][i].y));
@@ -646,7 +743,9 @@ struct Launch {
 template <typename T, int LOGM, int OV>
 constexpr bool ola_fits() {
   using G = Geo<T, LOGM>;
-  return OV <= 1 || ((SPECINV_WAVE_OLA_ALL || !(sizeof(T) == 8 && (1 << LOGM) / G::LG >= 16)) && (G::NPASS == 4 ? G::R3 : G::NPASS == 3 ? G::R2 : G::R1) % OV == 0);
+  // (the sizes that are not powers of two: the ring only)
+  return OV <= 1 || (LOGM < 100 && (SPECINV_WAVE_OLA_ALL || !(sizeof(T) == 8 && m_of<LOGM>() / G::LG >= 16)) &&
+                     (G::NPASS == 4 ? G::R3 : G::NPASS == 3 ? G::R2 : G::R1) % OV == 0);
 }
 
 template <typename T, int LOGM, int OV>
@@ -686,7 +785,7 @@ const void* kernel_of(int mode, int ov) {    // mode: bit 0 ADMM, bit 1 two-side
 template <typename T, int LOGM>
 Launch shape(int64_t work, int mode, int ov) {
   using G = Geo<T, LOGM>;
-  constexpr int M = 1 << LOGM, TEAM = G::LG > 64 ? G::LG / 64 : 1, FPW = G::LG > 64 ? 1 : 64 / G::LG, PS = ilog2(G::R0), MP = phys<PS>(M) + 1;
+  constexpr int M = m_of<LOGM>(), TEAM = G::LG > 64 ? G::LG / 64 : 1, FPW = G::LG > 64 ? 1 : 64 / G::LG, PS = G::R0, MP = phys<PS>(M) + 1;
   static int n_cu = 0;
   // workgroups of four or eight waves (each carries its own twiddle table), whichever puts more waves on a CU by the runtime's
   // own count of resident workgroups (registers and LDS); one launch fills the chip once and every wave walks its share of frames
@@ -706,10 +805,13 @@ Launch shape(int64_t work, int mode, int ov) {
     hipDeviceProp_t prop{};
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
     if (n_cu <= 0) n_cu = 256;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(8));
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(lds_of(8), 160 * 1024));
     int best = 0;
-    for (int w : {4, 8}) {
+    // (n_fft 400 / 800 / 1000: a wave's three float64 frames and rings are 20 KB - any size from two waves up, so that the LDS is
+    // not left half empty by the granularity of four)
+    for (int w : {4, 8, 7, 6, 5, 3, 2}) {
       int nb = 0;
+      if (LOGM < 100 && w != 4 && w != 8) continue;
       if (TEAM > 1) w = TEAM;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * w, lds_of(w)) != hipSuccess) nb = 0;
       if (const char* e = getenv("SPECINV_WAVE_WPW")) {
@@ -747,7 +849,7 @@ bool ola_registers(int ov) {
 // `ov`: 2 / 4 / 8 registers, 1 the ring (frames_over = ceil(n_fft / hop) frames cover a sample)
 template <typename T, int LOGM>
 int ola_chunks(int ov, int frames_over, int n_frames, int batch, int mode) {
-  if (!wave_iter_fits(2 << LOGM, n_frames, batch, true)) return 0;
+  if (!wave_iter_fits(2 * m_of<LOGM>(), n_frames, batch, true)) return 0;
   const int min_len = std::max(2 * frames_over, 8);
   if (n_frames < min_len) return 0;
   if (const char* e = getenv("SPECINV_WAVE_OLA")) {

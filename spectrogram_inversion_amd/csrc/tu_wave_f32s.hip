@@ -1,0 +1,8 @@
+// The wave-level coverage kernel (kernels_wave.h) for float at n_fft 400 / 800 / 1000 (radix 5 / 10 / 20 passes; frames buffer or LDS ring).
+#include "tu_wave_impl.h"
+
+namespace specinv {
+
+SPECINV_WAVE_FAMILY(float, 1)
+
+}  // namespace specinv

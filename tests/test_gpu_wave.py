@@ -49,6 +49,12 @@ SWEEP = [  # n_fft, hop, frames, batch, extra stft kwargs
     (512, 100, 11, 2, dict(onesided=False, win_length=300)),        # the reference's own two-sided parametrisation
     (1024, 256, 9, 2, dict(onesided=False, normalized=True)),
     (2048, 512, 6, 2, dict(onesided=False, pad_mode="constant")),
+    (400, 160, 13, 3, {}),                                          # the sizes that are not powers of two: radix 10 / 5 / 2 passes
+    (400, 100, 9, 2, dict(onesided=False, pad_mode="replicate")),
+    (800, 200, 8, 2, dict(win_length=600, normalized=True)),
+    (800, 300, 7, 2, dict(center=False)),
+    (1000, 250, 7, 2, dict(pad_mode="circular")),
+    (1000, 333, 6, 1, dict(onesided=False, win_length=800)),
 ]
 
 
@@ -133,7 +139,8 @@ def test_wave_kernel_is_what_float64_and_small_frames_run(monkeypatch):
                                          (torch.float32, 256, True, "k_wave_iter"), (torch.float32, 512, True, "k_semi"),
                                          (torch.float64, 512, False, "k_wave_iter"), (torch.float64, 1024, False, "k_wave_iter"),
                                          (torch.float32, 256, False, "k_wave_iter"), (torch.float64, 4096, True, "k_iter_pair"),
-                                         (torch.float64, 1000, True, "k_iter_pair")):
+                                         (torch.float64, 1000, True, "k_wave_iter"), (torch.float32, 400, True, "k_wave_iter"),
+                                         (torch.float32, 800, False, "k_wave_iter"), (torch.float64, 1200, True, "k_iter_pair")):
         F = n_fft // 2 + 1 if onesided else n_fft
         mag = torch.rand((2, F, 12), dtype=dtype, device=DEV) + 0.05
         p = Plan(args_helper(mag, hop_length=n_fft // 4, onesided=onesided, window=torch.hann_window(n_fft, dtype=dtype)), 2, 12, dtype, DEV)
@@ -212,6 +219,9 @@ def test_register_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, 
     (np.float64, 256, 255, 50, 2, {}), (np.float32, 128, 5, 700, 2, dict(pad_mode="constant")),
     (np.float32, 2048, 512, 48, 3, dict(onesided=False, pad_mode="replicate")), (np.float64, 1024, 200, 75, 2, dict(win_length=800)),
     (np.float64, 128, 32, 100, 3, dict(onesided=False)),
+    (np.float32, 400, 160, 100, 5, {}), (np.float64, 400, 100, 70, 3, dict(pad_mode="constant")), (np.float32, 800, 200, 60, 3, dict(onesided=False)),
+    (np.float64, 800, 333, 50, 2, dict(win_length=700)), (np.float32, 1000, 250, 64, 3, dict(normalized=True)),
+    (np.float64, 1000, 999, 30, 2, dict(onesided=False)), (np.float32, 1000, 77, 140, 2, dict(center=False)),
 ])
 def test_ring_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, hop, frames, batch, extra):
     """Every other hop below n_fft (odd ones, hops above n_fft / 2, one sample short of n_fft) and two-sided spectrograms: the same

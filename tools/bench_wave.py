@@ -43,7 +43,7 @@ def check():
     bad = 0
     torch.manual_seed(3)
     for dtype in (torch.float32, torch.float64):
-        for n_fft in (128, 256, 512, 1024, 2048):
+        for n_fft in (128, 256, 512, 1024, 2048, 400, 800, 1000):
             for onesided, hop, frames, batch, extra in ((True, n_fft // 4, 21, 3, {}), (False, n_fft // 4 + 3, 10, 2, {}),
                                                         (True, n_fft // 2, 9, 1, dict(center=False)),
                                                         (True, n_fft // 8, 13, 2, dict(normalized=True, pad_mode="constant")),
@@ -93,6 +93,17 @@ CASES = [  # n_fft, win_length, hop, frames, batch, dtype, onesided, method
     (256, 200, 50, 4096, 64, torch.float32, True, "gla"),
     (1024, 800, 200, 2048, 16, torch.float64, True, "gla"),
     (256, 200, 50, 4096, 64, torch.float64, True, "gla"),
+    (400, None, 160, 2048, 64, torch.float32, True, "gla"),     # 19 ...: n_fft 400 / 800 / 1000 (profiles/r06_generic.txt's shapes first)
+    (1000, None, 250, 1024, 16, torch.float32, True, "gla"),
+    (1000, None, 250, 1024, 16, torch.float64, True, "gla"),
+    (400, None, 100, 2048, 64, torch.float32, True, "admm"),
+    (800, None, 200, 2048, 32, torch.float32, True, "gla"),
+    (400, None, 160, 2048, 64, torch.float64, True, "gla"),
+    (800, None, 200, 2048, 32, torch.float64, True, "gla"),
+    (1000, None, 250, 2048, 32, torch.float32, False, "gla"),
+    (400, None, 160, 2048, 64, torch.float32, False, "gla"),
+    (400, None, 160, 2048, 32, torch.float64, False, "gla"),
+    (1000, 800, 200, 1024, 32, torch.float64, True, "admm"),
 ]
 
 
