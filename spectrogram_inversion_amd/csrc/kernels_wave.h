@@ -632,27 +632,30 @@ void k_wave_iter(WaveIterArgs<T> a) {
           if (last) sL[sidx] = v;                   // what the chunk leaves for the samples after its last frame's first hop
           return v;
         };
+        auto put = [&](int p, C yv) {               // samples 2 p, 2 p + 1 of the frame into the ring
+          const int s0 = 2 * p;
+          int i0 = rb + s0, i1 = rb + s0 + 1;
+          if constexpr (POW2) {
+            i0 &= N - 1;
+            i1 &= N - 1;
+          } else {
+            i0 -= i0 >= N ? N : 0;
+            i1 -= i1 >= N ? N : 0;
+          }
+          if (even) {
+            const C r = *reinterpret_cast<const C*>(ring + i0);
+            *reinterpret_cast<C*>(ring + i0) = mk<T>(emit(s0, r.x + yv.x), emit(s0 + 1, r.y + yv.y));
+          } else {
+            ring[i0] = emit(s0, ring[i0] + yv.x);
+            ring[i1] = emit(s0 + 1, ring[i1] + yv.y);
+          }
+        };
+        // (taking the frame to the ring through its LDS buffer in a rolled loop - fewer live registers - was no faster at 2, 3 or 4
+        // waves per SIMD: tools/log/EXPERIMENTS.md r06-w)
 #pragma unroll
         for (int it = 0; it < PER; ++it)
 #pragma unroll
-          for (int i = 0; i < R; ++i) {
-            const int s0 = 2 * (gl + it * LG + i * NS);
-            int i0 = rb + s0, i1 = rb + s0 + 1;
-            if constexpr (POW2) {
-              i0 &= N - 1;
-              i1 &= N - 1;
-            } else {
-              i0 -= i0 >= N ? N : 0;
-              i1 -= i1 >= N ? N : 0;
-            }
-            if (even) {
-              const C r = *reinterpret_cast<const C*>(ring + i0);
-              *reinterpret_cast<C*>(ring + i0) = mk<T>(emit(s0, r.x + y[it][i].x), emit(s0 + 1, r.y + y[it][i].y));
-            } else {
-              ring[i0] = emit(s0, ring[i0] + y[it][i].x);
-              ring[i1] = emit(s0 + 1, ring[i1] + y[it][i].y);
-            }
-          }
+          for (int i = 0; i < R; ++i) put(gl + it * LG + i * NS, y[it][i]);
       } else {
         // hop-block b of the frame is outputs i in [b RPB, (b + 1) RPB): slot e = it RPB + i mod RPB sits at complex offset
         // gl + it LG + (i mod RPB) NS of the block.  Block 0 closes the oldest partial sum (padded position t hop): stored - or,
