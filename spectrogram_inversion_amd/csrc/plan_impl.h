@@ -367,7 +367,7 @@ struct PlanT final : PlanBase {
       fast.geometry(out);
     } else if (use_wave) {                     // a lane group of one wave per frame, every wave walking its share
       wave_iter_geometry<T>(N(), cfg.hop_length, Tn(), B(), cfg.onesided != 0, out);   // (out[1]: chunks per item where the overlap-add
-      out[3] = 8;                                                                        //  runs in registers, else the frame count)
+                                                                                         //  runs in the kernel, else the frame count)
     } else {                                   // generic: one workgroup per frame pair
       out[0] = (use_dr ? dr_threads : frame_threads()) / 64;
       out[1] = (Tn() + 1) / 2;

@@ -80,7 +80,7 @@ int wave_iter_ola_chunks_f(int n_fft, int hop, int n_frames, int batch, bool one
 }
 
 template <typename T, int FAM>
-void wave_iter_geometry_f(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[3]) {
+void wave_iter_geometry_f(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[4]) {
   int ov = 0;
   const int nch = wave_iter_ola_chunks_f<T, FAM>(n_fft, hop, n_frames, batch, onesided, &ov);
   const int mode = onesided ? 0 : 2;
@@ -89,6 +89,7 @@ void wave_iter_geometry_f(int n_fft, int hop, int n_frames, int batch, bool ones
   out[0] = l.waves_per_wg;
   out[1] = nch > 0 ? nch : n_frames;
   out[2] = l.wgs * l.waves_per_wg;
+  out[3] = ov == 1 ? 9 : 8;                   // (specinv_plan_launch_geometry's kernel codes)
 }
 
 // what a unit instantiates for its element type and family ...
@@ -117,7 +118,7 @@ void wave_iter_geometry_f(int n_fft, int hop, int n_frames, int batch, bool ones
                                    : wave_iter_ola_chunks_f<T, 0>(n_fft, hop, n_frames, batch, onesided, ov_out);                           \
   }                                                                                                       \
   template <>                                                                                             \
-  void wave_iter_geometry<T>(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[3]) {    \
+  void wave_iter_geometry<T>(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[4]) {    \
     if (wave_smooth_size(n_fft)) wave_iter_geometry_f<T, 1>(n_fft, hop, n_frames, batch, onesided, out);  \
     else wave_iter_geometry_f<T, 0>(n_fft, hop, n_frames, batch, onesided, out);                          \
   }

@@ -47,9 +47,9 @@ int wave_iter_launch(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_ou
 // `ov_out`: how - 2 / 4 / 8 = n_fft / hop, the partial sums in registers; 1: in an LDS ring (any other hop < n_fft, two-sided)
 template <typename T>
 int wave_iter_ola_chunks(int n_fft, int hop, int n_frames, int batch, bool onesided, int* ov_out = nullptr);
-// diagnostics (specinv_plan_launch_geometry): out = {waves per workgroup, chunks of frames per item (register overlap-add) or the
-// frame count, waves of a plain launch}
+// diagnostics (specinv_plan_launch_geometry): out = {waves per workgroup, chunks of frames per item (overlap-add in the kernel) or
+// the frame count, waves of a plain launch, kernel code: 9 with the LDS ring, else 8}
 template <typename T>
-void wave_iter_geometry(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[3]);
+void wave_iter_geometry(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[4]);
 
 }  // namespace specinv

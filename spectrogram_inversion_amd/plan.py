@@ -176,8 +176,11 @@ class Plan:
         """Diagnostics: how the iteration kernel is launched (`specinv_plan_launch_geometry`)."""
         out = (C.c_int32 * 4)()
         _lib.check(self.lib.specinv_plan_launch_geometry(self._h, out))
-        kernel = ("k_iter_pair", "k_fused4", "k_fused", "k_semi", "k_hop", "k_fused4_td", "k_fused_td", "k_hop_td", "k_wave_iter")[out[3]]
-        return {"waves_per_workgroup": out[0], "chunks": out[1], "waves": out[2], "kernel": kernel}
+        kernel = ("k_iter_pair", "k_fused4", "k_fused", "k_semi", "k_hop", "k_fused4_td", "k_fused_td", "k_hop_td", "k_wave_iter", "k_wave_iter")[out[3]]
+        geo = {"waves_per_workgroup": out[0], "chunks": out[1], "waves": out[2], "kernel": kernel}
+        if kernel == "k_wave_iter":      # where its overlap-add runs: the frames buffer + k_ola, the kernel's registers or its LDS ring
+            geo["overlap_add"] = "ring" if out[3] == 9 else ("registers" if out[1] < self.n_frames else "frames")
+        return geo
 
     def force_generic(self, on=True):
         _lib.check(self.lib.specinv_plan_force_generic(self._h, int(on)))

@@ -184,7 +184,7 @@ def test_register_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, 
             p = _plan(init, frames, dtype, True, monkeypatch, window=w, **kw)
             (p.gla_init if method == "griffin_lim" else p.admm_init)(T(init), None, arg)
             geo = p.launch_geometry
-            assert geo["kernel"] == "k_wave_iter" and (geo["chunks"] < frames) == (arm == "registers"), (arm, geo)
+            assert geo["kernel"] == "k_wave_iter" and geo["overlap_add"] == arm and (geo["chunks"] < frames) == (arm == "registers"), (arm, geo)
             p.iterate(1)
             y1 = N(p.wave())
             p.iterate(3)
@@ -249,7 +249,7 @@ def test_ring_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, hop,
             p = _plan(init, frames, dtype, True, monkeypatch, window=w, **kw)
             (p.gla_init if method == "griffin_lim" else p.admm_init)(T(init), None, arg)
             geo = p.launch_geometry
-            assert geo["kernel"] == "k_wave_iter" and (geo["chunks"] < frames) == (arm == "ring"), (arm, geo)
+            assert geo["kernel"] == "k_wave_iter" and geo["overlap_add"] == arm and (geo["chunks"] < frames) == (arm == "ring"), (arm, geo)
             p.iterate(1)
             y1 = N(p.wave())
             p.iterate(3)

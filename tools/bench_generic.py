@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""ms per iteration of the coverage path (`force_generic`: kernels_wave.h where it applies since round 6 - float64 at n_fft 128 ... 2048,
-float32 at 128 / 256 - kernels_generic.h elsewhere: odd sizes, n_fft >= 4096): float32 / float64, one- and two-sided, Griffin-Lim
+"""ms per iteration of the coverage path (`force_generic`: kernels_wave.h where it applies since round 6 - n_fft 128 ... 2048 and 400 / 800 / 1000 -
+kernels_generic.h elsewhere: other odd sizes, n_fft >= 4096): float32 / float64, one- and two-sided, Griffin-Lim
 and ADMM, with the HBM fraction of 8 hop + 20 F + 8 N elements per frame and iteration (ADMM: 36 F) - the bytes of the frames + k_ola
 form, so that rounds compare; the register overlap-add moves 8 N fewer - and the kernel that ran.  A/B through the environment:
 SPECINV_GENERIC_WAVE=0 keeps the workgroup-level kernels, SPECINV_WAVE_OLA=0 the frames buffer, SPECINV_GENERIC_DR=0 the Stockham
@@ -33,6 +33,12 @@ CASES = [  # n_fft, win_length, hop, frames, batch, dtype, onesided, method
     (1000, None, 250, 1024, 16, torch.float64, True, "gla"),         # the sizes that are not 128 * 2^k
     (1000, None, 250, 1024, 16, torch.float32, True, "gla"),
     (400, None, 160, 2048, 64, torch.float32, True, "gla"),
+    (400, None, 160, 2048, 64, torch.float64, True, "gla"),
+    (800, None, 200, 2048, 32, torch.float32, True, "gla"),
+    (400, None, 100, 2048, 64, torch.float32, True, "admm"),
+    (512, 300, 100, 2048, 64, torch.float64, True, "gla"),           # hops that divide nothing: the LDS ring
+    (1024, 800, 200, 2048, 32, torch.float64, True, "gla"),
+    (256, 200, 50, 4096, 64, torch.float32, True, "gla"),
 ]
 for n_fft, wl, hop, frames, batch, dtype, onesided, method in CASES:
     F = n_fft // 2 + 1 if onesided else n_fft
@@ -59,7 +65,7 @@ for n_fft, wl, hop, frames, batch, dtype, onesided, method in CASES:
     gbs = per_frame * batch * frames / (best * 1e-3) / 1e9
     print(f"{method:4s} n_fft {n_fft:5d} win {wl or n_fft:5d} hop {hop:5d} T {frames:5d} B {batch:3d} {str(dtype)[6:]:8s} onesided={onesided!s:5s} "
           f"{best:8.3f} ms/it {batch * frames / best / 1e3:8.1f} M frames/s {100 * gbs / 8000:5.1f} % of 8 TB/s  {plan.launch_geometry['kernel']}"
-          f"{' (overlap-add in registers)' if plan.launch_geometry['kernel'] == 'k_wave_iter' and plan.launch_geometry['chunks'] < frames else ''}",
+          f"{' (overlap-add: ' + plan.launch_geometry['overlap_add'] + ')' if plan.launch_geometry['kernel'] == 'k_wave_iter' else ''}",
           flush=True)
     del plan
 
