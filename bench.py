@@ -66,8 +66,10 @@ WORKLOADS = {
     # the coverage path (every dtype / size the reference's own tests sweep, test/test_griffin.py:9-32) - extra legs only
     "F64": ("griffin_lim", 16, 2048, 512, 1024, 100, 0.3),      # float64 at the headline frame size
     "S32": ("griffin_lim", 64, 256, 64, 4096, 100, 0.3),        # float32 at n_fft 256 (test/consts.py:1-3)
+    "W400": ("griffin_lim", 64, 400, 160, 2048, 100, 0.3),      # float32 at 25 ms / 10 ms of 16 kHz speech: a size that is not a power of two
 }
 LEG_DTYPE = {"F64": torch.float64}
+COVERAGE_LEGS = ("F64", "S32", "W400")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 N_MELS, SR, LOOK_AHEAD = 80, 22050, 3
@@ -82,6 +84,7 @@ DOMINANT = {
     "C1": ("specinv::fast::k_semi<8", "latency"),
     "F64": ("specinv::wave::k_wave_iter<double, 10", "hbm"),
     "S32": ("specinv::wave::k_wave_iter<float, 7", "hbm"),
+    "W400": ("specinv::wave::k_wave_iter<float, 200", "hbm"),
 }
 PMC_PASSES = (
     ("fetch", ["FETCH_SIZE"]),
@@ -546,7 +549,7 @@ class Leg:
         launch_ms, n_launch = self.launch_ms()
         secs = launch_ms * 1e-3
         kname = (geo or {}).get("kernel")
-        default_shape = self.batch == WORKLOADS[self.workload][1] and not self.o.generic and (path != "generic" or self.workload in ("F64", "S32"))
+        default_shape = self.batch == WORKLOADS[self.workload][1] and not self.o.generic and (path != "generic" or self.workload in COVERAGE_LEGS)
         bound = DOMINANT[self.workload][1] if default_shape else ("valu" if path == "generic" else "hbm")
         units = self.batch * self.frames
         es = 2 if self.dtype == torch.float64 else 1              # (SURVEY 8d prices float32 elements)
@@ -689,7 +692,7 @@ def check(leg, x):
                 "loss": loss, "mse": mse, "directional_fd": fd, "directional_g": gd, "ok": bool(ok)}
     mag = leg.mag
     from spectrogram_inversion_amd.plan import Plan, args_helper
-    if leg.workload in LEG_DTYPE or leg.workload == "S32":
+    if leg.workload in COVERAGE_LEGS:
         # coverage legs: item 0 again on the workgroup-level kernels k_wave_iter replaced (the same update per bin on another
         # transform), from the same starting spectrum, in the leg's own dtype
         a = args_helper(mag[:1], hop_length=hop, window=window)
@@ -907,6 +910,7 @@ EXTRA_LEGS = (          # (key, workload, steps, warmup, option overrides, envir
     ("C1", "C1", 50, 5, {}, {}),
     ("F64", "F64", 3, 1, {}, {}),                                                                    # coverage path, float64 (k_wave_iter + k_ola)
     ("S32", "S32", 3, 1, {}, {}),                                                                    # coverage path, n_fft 256 (k_wave_iter, register overlap-add)
+    ("W400", "W400", 3, 1, {}, {}),                                                                  # coverage path, n_fft 400 / hop 160 (k_wave_iter, LDS ring)
 )
 
 

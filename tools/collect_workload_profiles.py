@@ -19,9 +19,11 @@ DOMINANT = {
     "C5": [bench.DOMINANT["C5"][0], "specinv::k_objective_epilogue", "specinv::k_lbd_direction_lean<float>", "specinv::k_lbd_settle_x<float>"],
     "F64": [bench.DOMINANT["F64"][0], "specinv::wave::k_wave_seams<double>"],
     "S32": [bench.DOMINANT["S32"][0], "specinv::wave::k_wave_seams<float>"],
+    "W400": [bench.DOMINANT["W400"][0], "specinv::wave::k_wave_seams<float>"],
 }
 ALGO = {"C2": 64 * 1024 * 8196, "C4": 32 * 2048 * 12308, "C3": None, "C5": 16 * 1024 * 8512,
-        "F64": 16 * 1024 * 2 * (8 * 512 + 20 * 1025), "S32": 64 * 4096 * (8 * 64 + 20 * 129)}   # (C5: 16 hop + 4 mels - the walk applies the step too)
+        "F64": 16 * 1024 * 2 * (8 * 512 + 20 * 1025), "S32": 64 * 4096 * (8 * 64 + 20 * 129),
+        "W400": 64 * 2048 * (8 * 160 + 20 * 201)}   # (C5: 16 hop + 4 mels - the walk applies the step too)
 out = os.path.join(ROOT, "profiles")
 traffic_path = os.path.join(out, "traffic.json")
 try:

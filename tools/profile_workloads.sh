@@ -2,7 +2,7 @@
 # Per workload: 1) kernel trace + stats; 2) PMC passes (separate runs, kernel dispatch only - never combined with trace domains).
 TAG=${1:-r06}
 shift
-WL=${@:-C2 C4 C3 C5 F64 S32}
+WL=${@:-C2 C4 C3 C5 F64 S32 W400}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
