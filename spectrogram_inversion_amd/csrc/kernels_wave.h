@@ -90,6 +90,16 @@ template <>
 struct Geo<double, 10> {  // 8 x 8 x 4 x 4
   static constexpr int LG = 128, NPASS = 4, R0 = 8, R1 = 8, R2 = 4, R3 = 4;
 };
+// n_fft 4096 (float32 normally runs the packed frame kernels; this is its coverage form): teams of two waves x 16 points / four
+// waves x 8 points
+template <>
+struct GeoF<11> {         // 16 x 16 x 8
+  static constexpr int LG = 128, NPASS = 3, R0 = 16, R1 = 16, R2 = 8, R3 = 1;
+};
+template <>
+struct Geo<double, 11> {  // 8 x 8 x 8 x 4
+  static constexpr int LG = 256, NPASS = 4, R0 = 8, R1 = 8, R2 = 8, R3 = 4;
+};
 template <>
 struct Geo<double, 8> {   // 4 x 4 x 4 x 4
   static constexpr int LG = 64, NPASS = 4, R0 = 4, R1 = 4, R2 = 4, R3 = 4;

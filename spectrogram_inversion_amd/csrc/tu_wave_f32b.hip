@@ -1,0 +1,8 @@
+// The wave-level coverage kernel (kernels_wave.h) for float at n_fft 4096: a frame on a team of two waves.
+#include "tu_wave_impl.h"
+
+namespace specinv {
+
+SPECINV_WAVE_FAMILY(float, 2)
+
+}  // namespace specinv

@@ -1,0 +1,8 @@
+// The wave-level coverage kernel (kernels_wave.h) for double at n_fft 4096: a frame on a team of four waves.
+#include "tu_wave_impl.h"
+
+namespace specinv {
+
+SPECINV_WAVE_FAMILY(double, 2)
+
+}  // namespace specinv

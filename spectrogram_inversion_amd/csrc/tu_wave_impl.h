@@ -1,6 +1,7 @@
 // Template definitions of the wave-level coverage kernel's host entry points (wave_api.h).  The kernels of kernels_wave.h are
-// instantiated in four units that build side by side: tu_wave_f32.hip / tu_wave_f64.hip (FAM 0: n_fft 128 ... 2048, and the public
-// entry points) and tu_wave_f32s.hip / tu_wave_f64s.hip (FAM 1: n_fft 400 / 800 / 1000).
+// instantiated in six units that build side by side: tu_wave_f32.hip / tu_wave_f64.hip (FAM 0: n_fft 128 ... 2048, and the public
+// entry points), tu_wave_f32s.hip / tu_wave_f64s.hip (FAM 1: n_fft 400 / 800 / 1000) and tu_wave_f32b.hip / tu_wave_f64b.hip (FAM 2:
+// n_fft 4096, a frame on a team of two / four waves).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -11,6 +12,7 @@
 namespace specinv {
 
 inline bool wave_smooth_size(int n_fft) { return n_fft == 400 || n_fft == 800 || n_fft == 1000; }
+inline int wave_family(int n_fft) { return wave_smooth_size(n_fft) ? 1 : n_fft == 4096 ? 2 : 0; }
 
 // f(size tag) for the family's size n_fft, `dflt` for any other
 template <int FAM, typename F, typename R>
@@ -24,13 +26,15 @@ R wave_by_size(int n_fft, F&& f, R dflt) {
       case 2048: return f(std::integral_constant<int, 10>{});
       default: return dflt;
     }
-  } else {
+  } else if constexpr (FAM == 1) {
     switch (n_fft) {
       case 400: return f(std::integral_constant<int, 200>{});
       case 800: return f(std::integral_constant<int, 400>{});
       case 1000: return f(std::integral_constant<int, 500>{});
       default: return dflt;
     }
+  } else {
+    return n_fft == 4096 ? f(std::integral_constant<int, 11>{}) : dflt;
   }
 }
 
@@ -69,6 +73,9 @@ int wave_iter_ola_chunks_f(int n_fft, int hop, int n_frames, int batch, bool one
     const int ovd = n_fft % hop == 0 ? n_fft / hop : 0;
     int ov = onesided && wave::ola_registers<T, LOGM>(ovd) ? ovd : 1;
     if (ov == 1) {
+      // (float64 at n_fft 4096: frame buffer + ring are 69 KB per team, two teams per CU - measured behind frames + k_ola, 0.463
+      // against 0.394 ms at 4096 / 3000 / 1000, 0.466 against 0.414 two-sided)
+      if (sizeof(T) == 8 && LOGM == 11) return 0;
       if (const char* e = getenv("SPECINV_WAVE_RING")) {
         if (e[0] == '0') return 0;
       }
@@ -98,29 +105,32 @@ void wave_iter_geometry_f(int n_fft, int hop, int n_frames, int batch, bool ones
   template int wave_iter_launch_f<T, FAM>(const WaveIterArgs<T>&, hipStream_t, int*);                     \
   template int wave_iter_ola_chunks_f<T, FAM>(int, int, int, int, bool, int*);                            \
   template void wave_iter_geometry_f<T, FAM>(int, int, int, int, bool, int*);
-// ... and the public entry points of an element type (in its FAM 0 unit; the other family is another unit's)
+// ... and the public entry points of an element type (in its FAM 0 unit; the other families are other units')
+#define SPECINV_WAVE_EXTERN(T, FAM)                                                                       \
+  extern template int wave_iter_waves_f<T, FAM>(int, int64_t, int*);                                      \
+  extern template int wave_iter_launch_f<T, FAM>(const WaveIterArgs<T>&, hipStream_t, int*);              \
+  extern template int wave_iter_ola_chunks_f<T, FAM>(int, int, int, int, bool, int*);                     \
+  extern template void wave_iter_geometry_f<T, FAM>(int, int, int, int, bool, int*);
+#define SPECINV_WAVE_DISPATCH(T, n_fft, fn, ...)                                                          \
+  (wave_family(n_fft) == 1 ? fn<T, 1>(__VA_ARGS__) : wave_family(n_fft) == 2 ? fn<T, 2>(__VA_ARGS__) : fn<T, 0>(__VA_ARGS__))
 #define SPECINV_WAVE_PUBLIC(T)                                                                            \
-  extern template int wave_iter_waves_f<T, 1>(int, int64_t, int*);                                        \
-  extern template int wave_iter_launch_f<T, 1>(const WaveIterArgs<T>&, hipStream_t, int*);                \
-  extern template int wave_iter_ola_chunks_f<T, 1>(int, int, int, int, bool, int*);                       \
-  extern template void wave_iter_geometry_f<T, 1>(int, int, int, int, bool, int*);                        \
+  SPECINV_WAVE_EXTERN(T, 1)                                                                               \
+  SPECINV_WAVE_EXTERN(T, 2)                                                                               \
   template <>                                                                                             \
   int wave_iter_waves<T>(int n_fft, int64_t frames_total, int* wpw) {                                     \
-    return wave_smooth_size(n_fft) ? wave_iter_waves_f<T, 1>(n_fft, frames_total, wpw) : wave_iter_waves_f<T, 0>(n_fft, frames_total, wpw); \
+    return SPECINV_WAVE_DISPATCH(T, n_fft, wave_iter_waves_f, n_fft, frames_total, wpw);                  \
   }                                                                                                       \
   template <>                                                                                             \
   int wave_iter_launch<T>(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_out) {                 \
-    return wave_smooth_size(a.c.n_fft) ? wave_iter_launch_f<T, 1>(a, stream, waves_out) : wave_iter_launch_f<T, 0>(a, stream, waves_out); \
+    return SPECINV_WAVE_DISPATCH(T, a.c.n_fft, wave_iter_launch_f, a, stream, waves_out);                 \
   }                                                                                                       \
   template <>                                                                                             \
   int wave_iter_ola_chunks<T>(int n_fft, int hop, int n_frames, int batch, bool onesided, int* ov_out) {  \
-    return wave_smooth_size(n_fft) ? wave_iter_ola_chunks_f<T, 1>(n_fft, hop, n_frames, batch, onesided, ov_out)                            \
-                                   : wave_iter_ola_chunks_f<T, 0>(n_fft, hop, n_frames, batch, onesided, ov_out);                           \
+    return SPECINV_WAVE_DISPATCH(T, n_fft, wave_iter_ola_chunks_f, n_fft, hop, n_frames, batch, onesided, ov_out); \
   }                                                                                                       \
   template <>                                                                                             \
   void wave_iter_geometry<T>(int n_fft, int hop, int n_frames, int batch, bool onesided, int out[4]) {    \
-    if (wave_smooth_size(n_fft)) wave_iter_geometry_f<T, 1>(n_fft, hop, n_frames, batch, onesided, out);  \
-    else wave_iter_geometry_f<T, 0>(n_fft, hop, n_frames, batch, onesided, out);                          \
+    SPECINV_WAVE_DISPATCH(T, n_fft, wave_iter_geometry_f, n_fft, hop, n_frames, batch, onesided, out);    \
   }
 
 }  // namespace specinv

@@ -43,7 +43,7 @@ def check():
     bad = 0
     torch.manual_seed(3)
     for dtype in (torch.float32, torch.float64):
-        for n_fft in (128, 256, 512, 1024, 2048, 400, 800, 1000):
+        for n_fft in (128, 256, 512, 1024, 2048, 400, 800, 1000, 4096):
             for onesided, hop, frames, batch, extra in ((True, n_fft // 4, 21, 3, {}), (False, n_fft // 4 + 3, 10, 2, {}),
                                                         (True, n_fft // 2, 9, 1, dict(center=False)),
                                                         (True, n_fft // 8, 13, 2, dict(normalized=True, pad_mode="constant")),
@@ -104,6 +104,10 @@ CASES = [  # n_fft, win_length, hop, frames, batch, dtype, onesided, method
     (400, None, 160, 2048, 64, torch.float32, False, "gla"),
     (400, None, 160, 2048, 32, torch.float64, False, "gla"),
     (1000, 800, 200, 1024, 32, torch.float64, True, "admm"),
+    (4096, None, 1024, 512, 16, torch.float64, True, "gla"),     # 30 ...: n_fft 4096 on teams of four / two waves
+    (4096, None, 1024, 512, 32, torch.float32, True, "gla"),
+    (4096, 3000, 1000, 512, 16, torch.float64, True, "admm"),
+    (4096, None, 1024, 512, 16, torch.float64, False, "gla"),
 ]
 
 
