@@ -100,6 +100,15 @@ template <>
 struct Geo<double, 11> {  // 8 x 8 x 8 x 4
   static constexpr int LG = 256, NPASS = 4, R0 = 8, R1 = 8, R2 = 8, R3 = 4;
 };
+// n_fft 8192: teams of four waves x 16 points (float32) / eight waves x 8 points (float64)
+template <>
+struct GeoF<12> {         // 16 x 16 x 16
+  static constexpr int LG = 256, NPASS = 3, R0 = 16, R1 = 16, R2 = 16, R3 = 1;
+};
+template <>
+struct Geo<double, 12> {  // 8 x 8 x 8 x 8
+  static constexpr int LG = 512, NPASS = 4, R0 = 8, R1 = 8, R2 = 8, R3 = 8;
+};
 template <>
 struct Geo<double, 8> {   // 4 x 4 x 4 x 4
   static constexpr int LG = 64, NPASS = 4, R0 = 4, R1 = 4, R2 = 4, R3 = 4;

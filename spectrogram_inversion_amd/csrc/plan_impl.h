@@ -307,7 +307,9 @@ struct PlanT final : PlanBase {
       // With the overlap-add inside the kernel (registers or the LDS ring: every hop < n_fft, two-sided too) it is ahead of
       // k_iter_pair at float32 512 ... 2048 as well - two-sided 512 / 300 / 100 0.560 -> 0.414, 2048 / 512 0.521 -> 0.417, one-sided
       // 1024 / 800 / 200 0.448 -> 0.260, ADMM 2048 / 1200 / 300 0.470 -> 0.400; its frames + k_ola form is not (ADMM 2048: 0.518).
-      const bool wins = sizeof(T) == 8 || n <= 256 ||
+      // n_fft 4096 / 8192 (teams of two to eight waves per frame): ahead in every form - float32 8192 / 2048 0.305 -> 0.161,
+      // frames + k_ola 0.200; 4096 / 1024 0.546 -> 0.257.
+      const bool wins = sizeof(T) == 8 || n <= 256 || n >= 4096 ||
                         (wave_iter_covers(n) && wave_iter_ola_chunks<T>(n, cfg.hop_length, cfg.n_frames, cfg.batch, cfg.onesided != 0) > 0);
       use_wave = !big && wave_iter_covers(n) && wave_iter_fits(n, cfg.n_frames, cfg.batch, false) && !(we && we[0] == '0') &&
                  (wins || (we && we[0] == '1'));

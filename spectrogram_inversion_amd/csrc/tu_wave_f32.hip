@@ -5,7 +5,7 @@
 namespace specinv {
 
 bool wave_iter_covers(int n_fft) {
-  return n_fft == 128 || n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048 || n_fft == 4096 || wave_smooth_size(n_fft);
+  return n_fft == 128 || n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048 || n_fft == 4096 || n_fft == 8192 || wave_smooth_size(n_fft);
 }
 
 SPECINV_WAVE_FAMILY(float, 0)

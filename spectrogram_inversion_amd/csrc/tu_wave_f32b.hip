@@ -1,4 +1,4 @@
-// The wave-level coverage kernel (kernels_wave.h) for float at n_fft 4096: a frame on a team of two waves.
+// The wave-level coverage kernel (kernels_wave.h) for float at n_fft 4096 / 8192: a frame on a team of two / four waves.
 #include "tu_wave_impl.h"
 
 namespace specinv {

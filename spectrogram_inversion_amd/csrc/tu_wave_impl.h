@@ -1,7 +1,7 @@
 // Template definitions of the wave-level coverage kernel's host entry points (wave_api.h).  The kernels of kernels_wave.h are
 // instantiated in six units that build side by side: tu_wave_f32.hip / tu_wave_f64.hip (FAM 0: n_fft 128 ... 2048, and the public
 // entry points), tu_wave_f32s.hip / tu_wave_f64s.hip (FAM 1: n_fft 400 / 800 / 1000) and tu_wave_f32b.hip / tu_wave_f64b.hip (FAM 2:
-// n_fft 4096, a frame on a team of two / four waves).
+// n_fft 4096 / 8192, a frame on a team of two to eight waves).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,7 +12,7 @@
 namespace specinv {
 
 inline bool wave_smooth_size(int n_fft) { return n_fft == 400 || n_fft == 800 || n_fft == 1000; }
-inline int wave_family(int n_fft) { return wave_smooth_size(n_fft) ? 1 : n_fft == 4096 ? 2 : 0; }
+inline int wave_family(int n_fft) { return wave_smooth_size(n_fft) ? 1 : n_fft >= 4096 ? 2 : 0; }
 
 // f(size tag) for the family's size n_fft, `dflt` for any other
 template <int FAM, typename F, typename R>
@@ -34,7 +34,7 @@ R wave_by_size(int n_fft, F&& f, R dflt) {
       default: return dflt;
     }
   } else {
-    return n_fft == 4096 ? f(std::integral_constant<int, 11>{}) : dflt;
+    return n_fft == 4096 ? f(std::integral_constant<int, 11>{}) : n_fft == 8192 ? f(std::integral_constant<int, 12>{}) : dflt;
   }
 }
 
@@ -73,9 +73,10 @@ int wave_iter_ola_chunks_f(int n_fft, int hop, int n_frames, int batch, bool one
     const int ovd = n_fft % hop == 0 ? n_fft / hop : 0;
     int ov = onesided && wave::ola_registers<T, LOGM>(ovd) ? ovd : 1;
     if (ov == 1) {
-      // (float64 at n_fft 4096: frame buffer + ring are 69 KB per team, two teams per CU - measured behind frames + k_ola, 0.463
-      // against 0.394 ms at 4096 / 3000 / 1000, 0.466 against 0.414 two-sided)
-      if (sizeof(T) == 8 && LOGM == 11) return 0;
+      // (float64 at n_fft 4096, both dtypes at 8192: frame buffer + ring are 69 - 135 KB per team, half the teams per CU - measured
+      // behind frames + k_ola: float64 4096 / 3000 / 1000 0.463 against 0.394 ms, two-sided 0.466 against 0.414; float32 8192 / 6000 /
+      // 1500 ADMM 0.310 against 0.247, two-sided 0.325 against 0.260)
+      if (LOGM == 12 || (sizeof(T) == 8 && LOGM == 11)) return 0;
       if (const char* e = getenv("SPECINV_WAVE_RING")) {
         if (e[0] == '0') return 0;
       }

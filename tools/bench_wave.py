@@ -43,7 +43,7 @@ def check():
     bad = 0
     torch.manual_seed(3)
     for dtype in (torch.float32, torch.float64):
-        for n_fft in (128, 256, 512, 1024, 2048, 400, 800, 1000, 4096):
+        for n_fft in (128, 256, 512, 1024, 2048, 400, 800, 1000, 4096, 8192):
             for onesided, hop, frames, batch, extra in ((True, n_fft // 4, 21, 3, {}), (False, n_fft // 4 + 3, 10, 2, {}),
                                                         (True, n_fft // 2, 9, 1, dict(center=False)),
                                                         (True, n_fft // 8, 13, 2, dict(normalized=True, pad_mode="constant")),
@@ -108,6 +108,12 @@ CASES = [  # n_fft, win_length, hop, frames, batch, dtype, onesided, method
     (4096, None, 1024, 512, 32, torch.float32, True, "gla"),
     (4096, 3000, 1000, 512, 16, torch.float64, True, "admm"),
     (4096, None, 1024, 512, 16, torch.float64, False, "gla"),
+    (8192, None, 2048, 256, 16, torch.float32, True, "gla"),     # 34 ...: n_fft 8192 (profiles/r06_generic.txt's shapes)
+    (8192, None, 2048, 128, 16, torch.float64, True, "gla"),
+    (8192, 6000, 1500, 256, 16, torch.float32, True, "admm"),
+    (4096, 3000, 1000, 512, 32, torch.float32, True, "gla"),
+    (4096, None, 1024, 512, 32, torch.float32, False, "gla"),
+    (8192, None, 2048, 256, 16, torch.float32, False, "gla"),
 ]
 
 
