@@ -165,7 +165,7 @@ def test_wave_kernel_is_what_float64_and_small_frames_run(monkeypatch):
     (np.float32, 128, 2, 200, 3, dict(center=False)), (np.float64, 256, 4, 90, 4, {}), (np.float64, 512, 4, 64, 3, dict(normalized=True)),
     (np.float64, 1024, 4, 70, 2, {}), (np.float64, 1024, 8, 100, 2, dict(pad_mode="circular")), (np.float64, 512, 2, 40, 2, dict(center=False)),
     (np.float64, 4096, 4, 40, 2, {}), (np.float32, 4096, 8, 60, 1, dict(pad_mode="replicate")),
-    (np.float64, 8192, 4, 24, 1, {}), (np.float32, 8192, 2, 20, 2, dict(center=False)),
+    (np.float64, 8192, 4, 30, 1, {}), (np.float32, 8192, 2, 29, 2, dict(center=False)),
 ])
 def test_register_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, ov, frames, batch, extra):
     """hop = n_fft / 2, / 4, / 8: `k_wave_iter` walks chunks of consecutive frames with the overlap-add in registers (partial sums
