@@ -104,7 +104,7 @@ int64_t specinv_plan_device_bytes(const specinv_plan* plan);
  * cover): out = { waves per workgroup, chunks of frames per item, waves per launch, kernel }, kernel: 0 generic
  * k_iter_pair, 1 k_fused4 (hop = n_fft/4 at n_fft 1024 / 2048), 2 k_fused<R, OV>, 3 k_semi, 4 k_hop, 5 k_fused4_td and
  * 6 k_fused_td<R, OV>, 7 k_hop_td (Griffin-Lim with the momentum carried as a signal; known once specinv_gla_init has run),
- * 8 k_wave_iter (the generic path's wave-level kernel: n_fft 128 ... 8192 and 400 / 800 / 1000; frames buffer + k_ola where out[1] is
+ * 8 k_wave_iter (the generic path's wave-level kernel: n_fft 128 ... 8192 (float32: 16384) and 400 / 800 / 1000; frames buffer + k_ola where out[1] is
  * the frame count, else the overlap-add in its registers), 9 k_wave_iter with the overlap-add in an LDS ring. */
 int specinv_plan_launch_geometry(const specinv_plan* plan, int32_t out[4]);
 /* 0: allow the fast path when the configuration supports it (default); 1: force the generic kernels. */

@@ -109,6 +109,12 @@ template <>
 struct Geo<double, 12> {  // 8 x 8 x 8 x 8
   static constexpr int LG = 512, NPASS = 4, R0 = 8, R1 = 8, R2 = 8, R3 = 8;
 };
+// n_fft 16384, float32 only (float64 frames of that size take kernels_big.h's rows): eight waves x 16 points; the radix-2 pass second,
+// where its table is 16 entries (last: 64 KB of twiddles)
+template <>
+struct Geo<float, 13> {   // 16 x 2 x 16 x 16
+  static constexpr int LG = 512, NPASS = 4, R0 = 16, R1 = 2, R2 = 16, R3 = 16;
+};
 template <>
 struct Geo<double, 8> {   // 4 x 4 x 4 x 4
   static constexpr int LG = 64, NPASS = 4, R0 = 4, R1 = 4, R2 = 4, R3 = 4;
@@ -766,6 +772,8 @@ template <typename T, int LOGM, int OV>
 constexpr bool ola_fits() {
   using G = Geo<T, LOGM>;
   // (the sizes that are not powers of two: the ring only)
+  // (... and float32 n_fft 16384 at hop = n_fft / 8: seven blocks of sums beside sixteen points - 0.394 ms against 0.270 on frames + k_ola)
+  if (LOGM == 13 && OV == 8) return false;
   return OV <= 1 || (LOGM < 100 && (SPECINV_WAVE_OLA_ALL || !(sizeof(T) == 8 && m_of<LOGM>() / G::LG >= 16)) &&
                      (G::NPASS == 4 ? G::R3 : G::NPASS == 3 ? G::R2 : G::R1) % OV == 0);
 }

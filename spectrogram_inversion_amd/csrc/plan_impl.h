@@ -310,8 +310,8 @@ struct PlanT final : PlanBase {
       // n_fft 4096 / 8192 (teams of two to eight waves per frame): ahead in every form - float32 8192 / 2048 0.305 -> 0.161,
       // frames + k_ola 0.200; 4096 / 1024 0.546 -> 0.257.
       const bool wins = sizeof(T) == 8 || n <= 256 || n >= 4096 ||
-                        (wave_iter_covers(n) && wave_iter_ola_chunks<T>(n, cfg.hop_length, cfg.n_frames, cfg.batch, cfg.onesided != 0) > 0);
-      use_wave = !big && wave_iter_covers(n) && wave_iter_fits(n, cfg.n_frames, cfg.batch, false) && !(we && we[0] == '0') &&
+                        (wave_iter_covers(n, (int)sizeof(T)) && wave_iter_ola_chunks<T>(n, cfg.hop_length, cfg.n_frames, cfg.batch, cfg.onesided != 0) > 0);
+      use_wave = !big && wave_iter_covers(n, (int)sizeof(T)) && wave_iter_fits(n, cfg.n_frames, cfg.batch, false) && !(we && we[0] == '0') &&
                  (wins || (we && we[0] == '1'));
     }
     if (std::max(lds_bytes, use_dr ? dr_lds : (size_t)0) > 48 * 1024) {

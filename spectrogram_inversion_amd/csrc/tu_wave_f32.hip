@@ -4,7 +4,8 @@
 
 namespace specinv {
 
-bool wave_iter_covers(int n_fft) {
+bool wave_iter_covers(int n_fft, int elem_size) {
+  if (n_fft == 16384) return elem_size == 4;
   return n_fft == 128 || n_fft == 256 || n_fft == 512 || n_fft == 1024 || n_fft == 2048 || n_fft == 4096 || n_fft == 8192 || wave_smooth_size(n_fft);
 }
 

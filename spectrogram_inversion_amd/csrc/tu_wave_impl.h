@@ -15,7 +15,7 @@ inline bool wave_smooth_size(int n_fft) { return n_fft == 400 || n_fft == 800 ||
 inline int wave_family(int n_fft) { return wave_smooth_size(n_fft) ? 1 : n_fft >= 4096 ? 2 : 0; }
 
 // f(size tag) for the family's size n_fft, `dflt` for any other
-template <int FAM, typename F, typename R>
+template <int FAM, typename T, typename F, typename R>
 R wave_by_size(int n_fft, F&& f, R dflt) {
   if constexpr (FAM == 0) {
     switch (n_fft) {
@@ -34,6 +34,9 @@ R wave_by_size(int n_fft, F&& f, R dflt) {
       default: return dflt;
     }
   } else {
+    if constexpr (sizeof(T) == 4) {
+      if (n_fft == 16384) return f(std::integral_constant<int, 13>{});
+    }
     return n_fft == 4096 ? f(std::integral_constant<int, 11>{}) : n_fft == 8192 ? f(std::integral_constant<int, 12>{}) : dflt;
   }
 }
@@ -42,7 +45,7 @@ template <typename T, int FAM>
 int wave_iter_waves_f(int n_fft, int64_t frames_total, int* waves_per_workgroup) {
   // (the two modes of a size share their launch shape unless their register counts part them: the evaluation's partial sums are
   // sized for the larger)
-  const wave::Launch l = wave_by_size<FAM>(n_fft, [&](auto tag) {
+  const wave::Launch l = wave_by_size<FAM, T>(n_fft, [&](auto tag) {
     constexpr int LOGM = decltype(tag)::value;
     wave::Launch best{};
     for (int mode = 4; mode < 8; ++mode) {       // (the evaluating instantiations: theirs are the partial sums)
@@ -57,7 +60,7 @@ int wave_iter_waves_f(int n_fft, int64_t frames_total, int* waves_per_workgroup)
 
 template <typename T, int FAM>
 int wave_iter_launch_f(const WaveIterArgs<T>& a, hipStream_t stream, int* waves_out) {
-  const int rc = wave_by_size<FAM>(a.c.n_fft, [&](auto tag) { return wave::launch_one<T, decltype(tag)::value>(a, stream, waves_out); }, -1);
+  const int rc = wave_by_size<FAM, T>(a.c.n_fft, [&](auto tag) { return wave::launch_one<T, decltype(tag)::value>(a, stream, waves_out); }, -1);
   SI_CHECK(rc != -1, SPECINV_EUNSUPPORTED, "k_wave_iter does not cover n_fft=%d", a.c.n_fft);
   return rc;
 }
@@ -68,7 +71,7 @@ int wave_iter_ola_chunks_f(int n_fft, int hop, int n_frames, int batch, bool one
   if (hop <= 0 || hop >= n_fft) return 0;
   // registers where hop = n_fft / 2, / 4, / 8 of a one-sided spectrogram and the partial sums fit; the LDS ring for every other hop
   // below n_fft and for two-sided spectrograms (SPECINV_WAVE_RING=0: frames + k_ola there)
-  return wave_by_size<FAM>(n_fft, [&](auto tag) -> int {
+  return wave_by_size<FAM, T>(n_fft, [&](auto tag) -> int {
     constexpr int LOGM = decltype(tag)::value;
     const int ovd = n_fft % hop == 0 ? n_fft / hop : 0;
     int ov = onesided && wave::ola_registers<T, LOGM>(ovd) ? ovd : 1;
@@ -76,7 +79,7 @@ int wave_iter_ola_chunks_f(int n_fft, int hop, int n_frames, int batch, bool one
       // (float64 at n_fft 4096, both dtypes at 8192: frame buffer + ring are 69 - 135 KB per team, half the teams per CU - measured
       // behind frames + k_ola: float64 4096 / 3000 / 1000 0.463 against 0.394 ms, two-sided 0.466 against 0.414; float32 8192 / 6000 /
       // 1500 ADMM 0.310 against 0.247, two-sided 0.325 against 0.260)
-      if (LOGM == 12 || (sizeof(T) == 8 && LOGM == 11)) return 0;
+      if (LOGM == 12 || LOGM == 13 || (sizeof(T) == 8 && LOGM == 11)) return 0;
       if (const char* e = getenv("SPECINV_WAVE_RING")) {
         if (e[0] == '0') return 0;
       }
@@ -93,7 +96,7 @@ void wave_iter_geometry_f(int n_fft, int hop, int n_frames, int batch, bool ones
   const int nch = wave_iter_ola_chunks_f<T, FAM>(n_fft, hop, n_frames, batch, onesided, &ov);
   const int mode = onesided ? 0 : 2;
   const int64_t work = nch > 0 ? (int64_t)batch * nch : (int64_t)batch * n_frames;
-  const wave::Launch l = wave_by_size<FAM>(n_fft, [&](auto tag) { return wave::shape<T, decltype(tag)::value>(work, mode, ov); }, wave::Launch{});
+  const wave::Launch l = wave_by_size<FAM, T>(n_fft, [&](auto tag) { return wave::shape<T, decltype(tag)::value>(work, mode, ov); }, wave::Launch{});
   out[0] = l.waves_per_wg;
   out[1] = nch > 0 ? nch : n_frames;
   out[2] = l.wgs * l.waves_per_wg;

@@ -28,7 +28,7 @@ struct WaveIterArgs {
 };
 
 // n_fft the kernel covers (a power of two, 128 ... 2048)
-bool wave_iter_covers(int n_fft);
+bool wave_iter_covers(int n_fft, int elem_size);
 // ... and the frame counts its 32-bit frame indices and row offsets take (`chunks`: with the register overlap-add, whose lane groups
 // walk chunks up to n_frames apart); beyond them the plan uses the frames form / the workgroup-level kernels
 inline bool wave_iter_fits(int n_fft, int n_frames, int batch, bool chunks) {

@@ -633,11 +633,17 @@ def test_keep_state_toggled_in_the_middle_of_a_two_sided_run(method):
     assert rel_l2(out[True, False][0], out[False, False][0]) < 1e-4
 
 
+@pytest.mark.parametrize("kernels", ["workgroup", "default"])
 @pytest.mark.parametrize("n_fft,dtype,tol", [(16384, np.float32, 2e-5), (8192, np.float64, 1e-10)])
-def test_transforms_beyond_two_lds_buffers(n_fft, dtype, tol):
+def test_transforms_beyond_two_lds_buffers(monkeypatch, n_fft, dtype, tol, kernels):
     """The reference derives n_fft from the spectrogram with no bound (torch_specinv/methods.py:65-68).  The generic kernels keep a
     frame pair's transform in LDS: with the in-place form (one buffer of n_fft complex points, kernels_generic.h) 16384 points in
-    float32 and 8192 in float64 - refused until round 3 - run: Griffin-Lim and ADMM against the oracle."""
+    float32 and 8192 in float64 - refused until round 3 - run: Griffin-Lim and ADMM against the oracle.  (Since round 6 these two
+    sizes run on teams of eight waves of `k_wave_iter` by default: both.)"""
+    from spectrogram_inversion_amd.plan import clear_plan_cache
+    if kernels == "workgroup":
+        monkeypatch.setenv("SPECINV_GENERIC_WAVE", "0")
+    clear_plan_cache()
     rng = np.random.default_rng(n_fft)
     hop, frames = n_fft // 4, 6
     mag = (rng.random((2, n_fft // 2 + 1, frames)) + 0.05).astype(dtype)

@@ -59,6 +59,7 @@ SWEEP = [  # n_fft, hop, frames, batch, extra stft kwargs
     (4096, 1000, 8, 1, dict(win_length=3000, onesided=False)),
     (8192, 2048, 9, 1, dict(pad_mode="constant")),                  # ... of four / eight waves
     (8192, 3000, 7, 1, dict(onesided=False, normalized=True)),
+    (16384, 4096, 9, 1, {}),                                        # float32 only (see the test): eight waves
 ]
 
 
@@ -68,6 +69,8 @@ def test_wave_kernel_kwarg_sweep_vs_oracle(monkeypatch, dtype, n_fft, hop, frame
     """Griffin-Lim (4 iterations, alpha 0.5) and ADMM (3 iterations, rho 1.0) from a complex start on `k_wave_iter`, every stft
     kwarg of the reference's sweep: waveform against the oracle in the plan's dtype and in float64, the evaluation's sums and the
     stored state against the workgroup-level kernel (`k_iter_pair`: the same update_core per bin on another transform)."""
+    if n_fft == 16384 and dtype == np.float64:
+        pytest.skip("float64 frames of 16384 samples are kernels_big.h's (rows through device memory)")
     rng = np.random.default_rng(n_fft + hop + frames)
     wl = extra.get("win_length", n_fft)
     w = hann(wl, dtype)
@@ -143,7 +146,7 @@ def test_wave_kernel_is_what_float64_and_small_frames_run(monkeypatch):
                                          (torch.float32, 256, True, "k_wave_iter"), (torch.float32, 512, True, "k_semi"),
                                          (torch.float64, 512, False, "k_wave_iter"), (torch.float64, 1024, False, "k_wave_iter"),
                                          (torch.float32, 256, False, "k_wave_iter"), (torch.float64, 4096, True, "k_wave_iter"), (torch.float64, 8192, True, "k_wave_iter"), (torch.float32, 8192, True, "k_wave_iter"),
-                                         (torch.float32, 16384, True, "k_iter_pair"),
+                                         (torch.float32, 16384, True, "k_wave_iter"), (torch.float64, 16384, True, "k_iter_pair"),
                                          (torch.float64, 1000, True, "k_wave_iter"), (torch.float32, 400, True, "k_wave_iter"),
                                          (torch.float32, 800, False, "k_wave_iter"), (torch.float64, 1200, True, "k_iter_pair")):
         F = n_fft // 2 + 1 if onesided else n_fft
@@ -165,7 +168,7 @@ def test_wave_kernel_is_what_float64_and_small_frames_run(monkeypatch):
     (np.float32, 128, 2, 200, 3, dict(center=False)), (np.float64, 256, 4, 90, 4, {}), (np.float64, 512, 4, 64, 3, dict(normalized=True)),
     (np.float64, 1024, 4, 70, 2, {}), (np.float64, 1024, 8, 100, 2, dict(pad_mode="circular")), (np.float64, 512, 2, 40, 2, dict(center=False)),
     (np.float64, 4096, 4, 40, 2, {}), (np.float32, 4096, 8, 60, 1, dict(pad_mode="replicate")),
-    (np.float64, 8192, 4, 30, 1, {}), (np.float32, 8192, 2, 29, 2, dict(center=False)),
+    (np.float64, 8192, 4, 30, 1, {}), (np.float32, 8192, 2, 29, 2, dict(center=False)), (np.float32, 16384, 4, 28, 1, {}),
 ])
 def test_register_overlap_add_equals_frames_plus_ola(monkeypatch, dtype, n_fft, ov, frames, batch, extra):
     """hop = n_fft / 2, / 4, / 8: `k_wave_iter` walks chunks of consecutive frames with the overlap-add in registers (partial sums

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""ms per iteration of the coverage path (`force_generic`: kernels_wave.h where it applies since round 6 - n_fft 128 ... 8192 and 400 / 800 / 1000 -
-kernels_generic.h elsewhere: other odd sizes, n_fft 16384): float32 / float64, one- and two-sided, Griffin-Lim
+"""ms per iteration of the coverage path (`force_generic`: kernels_wave.h where it applies since round 6 - n_fft 128 ... 16384 and 400 / 800 / 1000 -
+kernels_generic.h elsewhere: other odd sizes): float32 / float64, one- and two-sided, Griffin-Lim
 and ADMM, with the HBM fraction of 8 hop + 20 F + 8 N elements per frame and iteration (ADMM: 36 F) - the bytes of the frames + k_ola
 form, so that rounds compare; the register overlap-add moves 8 N fewer - and the kernel that ran.  A/B through the environment:
 SPECINV_GENERIC_WAVE=0 keeps the workgroup-level kernels, SPECINV_WAVE_OLA=0 the frames buffer, SPECINV_GENERIC_DR=0 the Stockham
