@@ -321,6 +321,45 @@ def test_float64_2048_on_a_two_wave_team_at_full_occupancy(monkeypatch, batch, f
         np.testing.assert_allclose(res[arm][1], ref[1], rtol=1e-12)
 
 
+@pytest.mark.parametrize("dtype,n_fft,hop,frames,batch,extra", [
+    (np.float64, 2048, 500, 700, 20, {}),                            # the ring on a two-wave team
+    (np.float32, 4096, 1000, 400, 24, dict(onesided=False)),         # ... on a two-wave float32 team, two-sided
+    (np.float32, 400, 160, 2048, 64, {}),                            # bench.py's W400 leg: three frames per wave
+    (np.float64, 512, 100, 1024, 24, dict(onesided=False, win_length=300)),
+    (np.float32, 1000, 250, 1024, 24, {}),
+])
+def test_ring_at_full_occupancy(monkeypatch, dtype, n_fft, hop, frames, batch, extra):
+    """The ring overlap-add with every wave slot of the chip taken (the team's missing barrier of this round only showed there):
+    five iterations against the workgroup-level kernels on the same input, item by item and at the item edges."""
+    rng = np.random.default_rng(n_fft + hop)
+    onesided = extra.get("onesided", True)
+    wl = extra.get("win_length", n_fft)
+    w = hann(wl, dtype)
+    F = n_fft // 2 + 1 if onesided else n_fft
+    mag = (rng.random((batch, F, frames)) + 0.05).astype(dtype)
+    cd = np.complex64 if dtype == np.float32 else np.complex128
+    init = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(cd)
+    res = {}
+    for arm in ("workgroup", "ring"):
+        p = _plan(init, frames, dtype, arm == "ring", monkeypatch, window=w, hop_length=hop, **extra)
+        p.gla_init(T(init), None, 0.3)
+        geo = p.launch_geometry
+        if arm == "ring":
+            assert geo["kernel"] == "k_wave_iter" and geo["overlap_add"] == "ring" and geo["waves"] >= 1000, geo   # every slot its kernel has
+        p.iterate(4)
+        sums = p.iterate(1, eval_last=True)
+        res[arm] = (N(p.wave()), np.array(sums[:2]))
+        del p
+    y, ref = res["ring"][0], res["workgroup"][0]
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    per_item = np.linalg.norm(y - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert per_item.max() < tol, (int(per_item.argmax()), per_item.max())
+    edge = 4 * n_fft
+    assert np.abs(y[:, :edge] - ref[:, :edge]).max() < 10 * tol * np.abs(ref).max()
+    assert np.abs(y[:, -edge:] - ref[:, -edge:]).max() < 10 * tol * np.abs(ref).max()
+    np.testing.assert_allclose(res["ring"][1], res["workgroup"][1], rtol=1e-5 if dtype == np.float32 else 1e-12)
+
+
 def test_long_signals_keep_the_frames_form(monkeypatch):
     """`k_wave_iter` indexes frames with 32 bits and addresses a wave's lane groups relative to the first; with the register
     overlap-add the groups walk chunks up to a whole item apart, so a signal of 8 n_frames (n_fft + 2) >= 2^31 elements keeps the
