@@ -321,6 +321,45 @@ def test_float64_2048_on_a_two_wave_team_at_full_occupancy(monkeypatch, batch, f
         np.testing.assert_allclose(res[arm][1], ref[1], rtol=1e-12)
 
 
+@pytest.mark.parametrize("dtype,n_fft,frames,batch,waves_per_wg", [
+    (np.float64, 4096, 512, 16, 4), (np.float32, 4096, 512, 32, 2), (np.float64, 8192, 128, 16, 8), (np.float32, 8192, 256, 16, 4),
+    (np.float32, 16384, 128, 16, 8),
+])
+def test_large_frames_on_teams_at_full_occupancy(monkeypatch, dtype, n_fft, frames, batch, waves_per_wg):
+    """n_fft 4096 / 8192 / 16384: a frame on the lanes of a two- to eight-wave workgroup (profiles/r06_generic.txt's shapes: every
+    team slot of the chip taken), hop = n_fft / 4, five iterations with the overlap-add in registers and on frames + k_ola against
+    the workgroup-level kernels."""
+    rng = np.random.default_rng(n_fft)
+    mag = (rng.random((batch, n_fft // 2 + 1, frames)) + 0.05).astype(dtype)
+    cd = np.complex64 if dtype == np.float32 else np.complex128
+    init = (mag * np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))).astype(cd)
+    w = hann(n_fft, dtype)
+    res = {}
+    for arm in ("workgroup", "frames", "registers"):
+        monkeypatch.setenv("SPECINV_WAVE_OLA", "0" if arm == "frames" else "1")
+        p = _plan(init, frames, dtype, arm != "workgroup", monkeypatch, window=w, hop_length=n_fft // 4)
+        p.gla_init(T(init), None, 0.3)
+        geo = p.launch_geometry
+        if arm != "workgroup":
+            assert geo["kernel"] == "k_wave_iter" and geo["waves_per_workgroup"] == waves_per_wg and geo["overlap_add"] == arm, geo
+        p.iterate(4)
+        sums = p.iterate(1, eval_last=True)
+        res[arm] = (N(p.wave()), np.array(sums[:2]))
+        del p
+    ref = res["workgroup"]
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    for arm in ("frames", "registers"):
+        y = res[arm][0]
+        per_item = np.linalg.norm(y - ref[0], axis=1) / np.linalg.norm(ref[0], axis=1)
+        # (float32 on random magnitudes: a bin that passes close to zero amplifies rounding in its item - 2e-5 on one of 32 items of the
+        # 4096 case, 1 - 3e-6 on the others; the float64 cases of the same code hold 1e-12 everywhere)
+        assert np.median(per_item) < tol / 2 and per_item.max() < (5 * tol if dtype == np.float32 else tol), (arm, int(per_item.argmax()), per_item.max())
+        edge = 4 * n_fft
+        assert np.abs(y[:, :edge] - ref[0][:, :edge]).max() < 10 * tol * np.abs(ref[0]).max()
+        assert np.abs(y[:, -edge:] - ref[0][:, -edge:]).max() < 10 * tol * np.abs(ref[0]).max()
+        np.testing.assert_allclose(res[arm][1], ref[1], rtol=1e-5 if dtype == np.float32 else 1e-12)
+
+
 @pytest.mark.parametrize("dtype,n_fft,hop,frames,batch,extra", [
     (np.float64, 2048, 500, 700, 20, {}),                            # the ring on a two-wave team
     (np.float32, 4096, 1000, 400, 24, dict(onesided=False)),         # ... on a two-wave float32 team, two-sided
