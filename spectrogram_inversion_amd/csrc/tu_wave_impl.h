@@ -1,7 +1,7 @@
 // Template definitions of the wave-level coverage kernel's host entry points (wave_api.h).  The kernels of kernels_wave.h are
-// instantiated in six units that build side by side: tu_wave_f32.hip / tu_wave_f64.hip (FAM 0: n_fft 128 ... 2048, and the public
+// instantiated in seven units that build side by side: tu_wave_f32.hip / tu_wave_f64.hip (FAM 0: n_fft 128 ... 2048, and the public
 // entry points), tu_wave_f32s.hip / tu_wave_f64s.hip (FAM 1: n_fft 400 / 800 / 1000) and tu_wave_f32b.hip / tu_wave_f64b.hip (FAM 2:
-// n_fft 4096 / 8192, a frame on a team of two to eight waves).
+// n_fft 4096 / 8192, a frame on a team of two to eight waves; tu_wave_f32c.hip, FAM 3: float32 n_fft 16384).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,7 +12,7 @@
 namespace specinv {
 
 inline bool wave_smooth_size(int n_fft) { return n_fft == 400 || n_fft == 800 || n_fft == 1000; }
-inline int wave_family(int n_fft) { return wave_smooth_size(n_fft) ? 1 : n_fft >= 4096 ? 2 : 0; }
+inline int wave_family(int n_fft) { return wave_smooth_size(n_fft) ? 1 : n_fft == 16384 ? 3 : n_fft >= 4096 ? 2 : 0; }
 
 // f(size tag) for the family's size n_fft, `dflt` for any other
 template <int FAM, typename T, typename F, typename R>
@@ -33,11 +33,13 @@ R wave_by_size(int n_fft, F&& f, R dflt) {
       case 1000: return f(std::integral_constant<int, 500>{});
       default: return dflt;
     }
+  } else if constexpr (FAM == 2) {
+    return n_fft == 4096 ? f(std::integral_constant<int, 11>{}) : n_fft == 8192 ? f(std::integral_constant<int, 12>{}) : dflt;
   } else {
     if constexpr (sizeof(T) == 4) {
       if (n_fft == 16384) return f(std::integral_constant<int, 13>{});
     }
-    return n_fft == 4096 ? f(std::integral_constant<int, 11>{}) : n_fft == 8192 ? f(std::integral_constant<int, 12>{}) : dflt;
+    return dflt;
   }
 }
 
@@ -116,10 +118,12 @@ void wave_iter_geometry_f(int n_fft, int hop, int n_frames, int batch, bool ones
   extern template int wave_iter_ola_chunks_f<T, FAM>(int, int, int, int, bool, int*);                     \
   extern template void wave_iter_geometry_f<T, FAM>(int, int, int, int, bool, int*);
 #define SPECINV_WAVE_DISPATCH(T, n_fft, fn, ...)                                                          \
-  (wave_family(n_fft) == 1 ? fn<T, 1>(__VA_ARGS__) : wave_family(n_fft) == 2 ? fn<T, 2>(__VA_ARGS__) : fn<T, 0>(__VA_ARGS__))
+  (wave_family(n_fft) == 1 ? fn<T, 1>(__VA_ARGS__) : wave_family(n_fft) == 2 ? fn<T, 2>(__VA_ARGS__) :    \
+   wave_family(n_fft) == 3 ? fn<T, 3>(__VA_ARGS__) : fn<T, 0>(__VA_ARGS__))
 #define SPECINV_WAVE_PUBLIC(T)                                                                            \
   SPECINV_WAVE_EXTERN(T, 1)                                                                               \
   SPECINV_WAVE_EXTERN(T, 2)                                                                               \
+  SPECINV_WAVE_EXTERN(T, 3)                                                                               \
   template <>                                                                                             \
   int wave_iter_waves<T>(int n_fft, int64_t frames_total, int* wpw) {                                     \
     return SPECINV_WAVE_DISPATCH(T, n_fft, wave_iter_waves_f, n_fft, frames_total, wpw);                  \
